@@ -1,0 +1,139 @@
+"""ctypes binding of libdae_hip.so (C ABI declared in include/dae_hip.h).
+
+The library is the product's only compute path: there is NO CPU fallback.  ``load()`` raises if the
+shared object is missing (run ``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C dae_rnn_news_recommendation_amd/csrc``), and every wrapper raises ``RuntimeError`` with the
+library's message when an entry point returns non-zero.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdae_hip.so")
+
+# enums (mirror include/dae_hip.h)
+BF16, F32 = 0, 1
+ACT = {"none": 0, "sigmoid": 1, "tanh": 2}
+LOSS = {"cross_entropy": 0, "mean_squared": 1, "cosine_proximity": 2}
+OPT = {"gradient_descent": 0, "ada_grad": 1, "momentum": 2, "adam": 3}
+TRIPLET = {"none": 0, "batch_all": 1, "batch_hard": 2, "explicit": 3}
+CORR_NONE, CORR_KEEPBITS, CORR_PHILOX_MASK = 0, 1, 2
+STATS_STRIDE = 8
+STAT_COST, STAT_AE, STAT_TRIPLET, STAT_FRACTION, STAT_NUM, STAT_NVALID = range(6)
+PAD = 128
+
+i32, i64, u32, u64, f32, vp = C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float, C.c_void_p
+
+
+class dae_config(C.Structure):
+    _fields_ = [("n_features", i32), ("n_components", i32), ("max_batch", i32),
+                ("dtype", i32), ("enc_act", i32), ("dec_act", i32), ("loss_func", i32), ("opt", i32),
+                ("triplet", i32), ("pos_triplets_only", i32),
+                ("encode_splits", i32), ("dh_splits", i32), ("gram_splits", i32),
+                ("learning_rate", f32), ("momentum", f32), ("alpha", f32)]
+
+
+class dae_buffers(C.Structure):
+    _fields_ = [("indptr", vp), ("indices", vp), ("values", vp), ("dense", vp), ("ld_dense", i64),
+                ("n_rows", i64), ("nnz", i64),
+                ("W", vp), ("bh", vp), ("bv", vp), ("grad", vp), ("opt_s1", vp), ("opt_s2", vp),
+                ("W_lo", vp), ("Wt_lo", vp), ("workspace", vp), ("workspace_bytes", u64)]
+
+
+class dae_step(C.Structure):
+    _fields_ = [("row_idx", vp), ("labels", vp), ("B", i32),
+                ("corr_mode", i32), ("keep_bits", vp), ("seed", u64), ("rng_stream", u32),
+                ("corr_frac", f32), ("scale", f32),
+                ("c_indptr", vp), ("c_indices", vp), ("c_values", vp),
+                ("stats", vp), ("phase", i32), ("adam_t", i32), ("grad_scale", f32)]
+
+
+# name -> (restype, argtypes); every exported symbol of include/dae_hip.h is listed here and
+# tests/test_abi.py checks the list against the header and the built library.
+SIGNATURES = {
+    "dae_abi_version": (i32, []),
+    "dae_last_error": (C.c_char_p, []),
+    "dae_pad": (i64, [i64]),
+    "dae_set_glds": (None, [i32]),
+    "dae_gather_csr": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp, i64, vp, i64, vp, i32, vp, u64, u32, f32, f32, vp]),
+    "dae_gather_dense": (i32, [vp, i64, vp, i32, i32, i32, vp, vp, i64, vp, i64, vp, vp, i32, vp, u64, u32, f32, f32, vp]),
+    "dae_gemm_nt": (i32, [i32, i32, i32, vp, i64, vp, i64, i32, vp, i64, vp, i64, i32, vp, i64, i32, i64, vp]),
+    "dae_encode_finish": (i32, [vp, i32, i64, i64, vp, i32, i32, i32, i32, vp, vp, i64, vp, i64, vp]),
+    "dae_decode_loss": (i32, [i32, i32, i32, i32, vp, i64, vp, i64, vp, vp, i64, vp, i32, i32, i32, vp, vp, vp, vp,
+                              vp, i64, vp, i64, vp, i64, vp]),
+    "dae_cos_reduce": (i32, [vp, i32, i32, i32, vp, vp, vp]),
+    "dae_gram": (i32, [vp, i64, i32, i32, vp, i32, vp]),
+    "dae_label_stats": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
+    "dae_triplet_batch_all": (i32, [vp, i32, i64, i64, vp, i32, i32, i32, vp, vp, vp, vp, vp]),
+    "dae_triplet_batch_hard": (i32, [vp, i32, i64, i64, vp, i32, i32, vp, vp, vp, vp, vp]),
+    "dae_triplet_finalize": (i32, [i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "dae_sym_scale": (i32, [vp, i32, i32, vp, i32, vp, vp]),
+    "dae_dh_finish": (i32, [vp, i32, i64, i64, vp, vp, i64, vp, i32, i32, i32, i32, vp, i64, vp, vp, vp]),
+    "dae_bias_grads": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp]),
+    "dae_opt_step": (i32, [i32, f32, f32, f32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, i32, vp]),
+    "dae_step_stats": (i32, [vp, i32, vp, i32, i32, i32, f32, vp, vp, vp, vp]),
+    "dae_explicit_triplet": (i32, [vp, i64, i32, i32, f32, vp, vp, vp, vp]),
+    "dae_plan_create": (i32, [C.POINTER(dae_config), C.POINTER(vp)]),
+    "dae_plan_destroy": (None, [vp]),
+    "dae_plan_workspace_bytes": (u64, [vp]),
+    "dae_plan_bind": (i32, [vp, C.POINTER(dae_buffers)]),
+    "dae_plan_sync_shadows": (i32, [vp, vp]),
+    "dae_train_step": (i32, [vp, C.POINTER(dae_step), vp]),
+    "dae_plan_apply": (i32, [vp, i32, f32, vp]),
+    "dae_encode_rows": (i32, [vp, vp, i32, f32, vp, vp, vp, vp, i64, vp, i64, vp]),
+    "dae_plan_buffer": (vp, [vp, C.c_char_p]),
+    "dae_plan_info": (i32, [vp, vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libdae_hip.so (once).  Raises OSError/RuntimeError loudly if it is missing or stale."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built "
+            "(run `make -C dae_rnn_news_recommendation_amd/csrc -j` or __graft_entry__.build()). "
+            "There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError here == stale library
+        fn.restype = res
+        fn.argtypes = args
+    if lib.dae_abi_version() != 1:
+        raise RuntimeError("libdae_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def pad(n: int) -> int:
+    return (int(n) + PAD - 1) // PAD * PAD
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().dae_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"libdae_hip {what} failed (rc={rc}): {msg}")
+
+
+def ptr(t):
+    """Device (or host) pointer of a torch tensor / None as a void*."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def call(name, *args):
+    """Call an int-returning entry point and raise on error."""
+    fn = getattr(load(), name)
+    check(fn(*args), name)
+
+
+def current_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

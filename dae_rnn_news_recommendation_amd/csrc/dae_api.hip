@@ -1,0 +1,340 @@
+// dae_api.hip -- extern "C" surface of libdae_hip.so (declared in include/dae_hip.h) and the whole-step
+// driver that enqueues one DAE training step (DenoisingAutoencoder._run_train_step's per-batch body,
+// autoencoder.py:223-245) as a fixed sequence of HIP kernels on one stream, with no host sync.
+#include <stdarg.h>
+
+#include <new>
+
+#include "dae_kernels.h"
+
+namespace dae {
+
+static thread_local char g_err[1024] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+}  // namespace dae
+
+using namespace dae;
+
+extern "C" int dae_abi_version(void) { return DAE_ABI_VERSION; }
+extern "C" const char* dae_last_error(void) { return g_err; }
+extern "C" int64_t dae_pad(int64_t n) { return pad128(n); }
+extern "C" void dae_set_glds(int32_t on) { set_use_glds(on != 0); }
+
+extern "C" int dae_gemm_nt(int32_t dtype, int32_t M, int32_t N, const void* A0, int64_t lda0, const void* Bt0, int64_t ldb0,
+                           int32_t K0, const void* A1, int64_t lda1, const void* Bt1, int64_t ldb1, int32_t K1, float* C,
+                           int64_t ldc, int32_t splits, int64_t slab_stride, void* stream) {
+    return launch_gemm_f32out(dtype, M, N, A0, lda0, Bt0, ldb0, K0, A1, lda1, Bt1, ldb1, K1, C, ldc, splits, slab_stride,
+                              (hipStream_t)stream);
+}
+
+extern "C" int dae_gram(const float* h_f32, int64_t ldh, int32_t Bp, int32_t Hp, float* D_slabs, int32_t splits, void* stream) {
+    return launch_gemm_f32out(DAE_F32, Bp, Bp, h_f32, ldh, h_f32, ldh, Hp, nullptr, 0, nullptr, 0, 0, D_slabs, Bp, splits,
+                              (int64_t)Bp * Bp, (hipStream_t)stream);
+}
+
+extern "C" int dae_decode_loss(int32_t dtype, int32_t B, int32_t F, int32_t H, const void* h_lo, int64_t ldh, const void* W_lo,
+                               int64_t ldw, const float* bv, const void* x, int64_t ldx, const float* cw, int32_t dec_act,
+                               int32_t loss_func, int32_t cos_pass, const float* cos_stats, float* cos_part,
+                               float* rowloss_part, float* dbv_part, void* delta2, int64_t ldd, void* delta2_t, int64_t lddt,
+                               float* y_out, int64_t ldy, void* stream) {
+    DAE_CHECK_ARG(h_lo && W_lo && bv && x && cw, "decode_loss: null input");
+    DAE_CHECK_ARG(B > 0 && F > 0 && H > 0, "decode_loss: bad shape");
+    DAE_CHECK_ARG(loss_func >= DAE_LOSS_CROSS_ENTROPY && loss_func <= DAE_LOSS_COSINE, "decode_loss: unknown loss %d", loss_func);
+    if (loss_func == DAE_LOSS_COSINE) {
+        DAE_CHECK_ARG(cos_pass == 1 || cos_pass == 2, "decode_loss: cosine needs cos_pass 1 or 2");
+        DAE_CHECK_ARG(cos_stats && (cos_pass != 1 || cos_part), "decode_loss: cosine statistics buffers required");
+    } else {
+        DAE_CHECK_ARG(cos_pass == 0 && rowloss_part, "decode_loss: rowloss_part required");
+    }
+    DecodeEpi e;
+    e.bv = bv; e.x = x; e.ldx = ldx; e.cw = cw; e.cos_stats = cos_stats; e.rowloss_part = rowloss_part; e.dbv_part = dbv_part;
+    e.cos_part = cos_part; e.delta2 = delta2; e.ldd = ldd; e.delta2_t = delta2_t; e.lddt = lddt; e.y_out = y_out; e.ldy = ldy;
+    e.B = B; e.F = F; e.Bp = (int)pad128(B); e.Fp = (int)pad128(F); e.dec_act = dec_act; e.loss_func = loss_func;
+    e.cos_pass = cos_pass;
+    return launch_decode_loss(dtype, e.Bp, e.Fp, (int)pad128(H), h_lo, ldh, W_lo, ldw, e, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// plan: sizes, workspace carving, step driver
+// ------------------------------------------------------------------------------------------------
+struct dae_plan {
+    dae_config cfg;
+    dae_buffers b;
+    bool bound;
+    int F, H, Fp, Hp, Bmax, Bpm;     // Bpm = padded max batch (leading dimension of every [.. x batch] image)
+    int es;
+    int s_enc, s_dh, s_gram;
+    uint64_t ws_bytes;
+    // carved pointers
+    char *x, *xc, *xct, *h_lo, *h_t, *Gs, *delta2, *delta2_t, *delta1_t;
+    float *slabs, *h_f32, *D_slabs, *G, *rowloss_part, *dbv_part, *colsum_part, *cos_part, *cos_stats, *cw, *loss_part,
+        *dw_f32, *tri_scalars, *dh_extra, *rowsq_scratch;
+    uint32_t *cnt_part, *role_cnt;
+    int32_t *dw_i32, *n_same;
+    int64_t *nvalid, *dw_i64;
+    uint64_t* acc;
+};
+
+static int auto_splits(int tiles, int ktiles) {
+    int s = 384 / (tiles > 0 ? tiles : 1);
+    if (s >= 8) s = (s / 8) * 8;
+    if (s > 16) s = 16;
+    int cap = ktiles / 4;
+    if (s > cap) s = cap;
+    if (s < 1) s = 1;
+    return s;
+}
+
+static uint64_t carve(dae_plan* p, char* base) {
+    uint64_t off = 0;
+    auto take = [&](uint64_t bytes) -> char* {
+        char* r = base ? base + off : nullptr;
+        off += (bytes + 255) / 256 * 256;
+        return r;
+    };
+    const uint64_t Bp = p->Bpm, Fp = p->Fp, Hp = p->Hp, es = p->es;
+    p->x = take(Bp * Fp * es);
+    p->xc = take(Bp * Fp * es);
+    p->xct = take(Fp * Bp * es);
+    p->delta2 = take(Bp * Fp * es);
+    p->delta2_t = take(Fp * Bp * es);
+    const int smax = p->s_enc > p->s_dh ? p->s_enc : p->s_dh;
+    p->slabs = (float*)take((uint64_t)smax * Bp * Hp * 4);
+    p->h_f32 = (float*)take(Bp * Hp * 4);
+    p->h_lo = take(Bp * Hp * es);
+    p->h_t = take(Hp * Bp * es);
+    p->delta1_t = take(Hp * Bp * es);
+    p->dh_extra = (float*)take(Bp * Hp * 4);
+    p->D_slabs = (float*)take((uint64_t)p->s_gram * Bp * Bp * 4);
+    p->G = (float*)take(Bp * Bp * 4);
+    p->Gs = take(Bp * Bp * es);
+    p->role_cnt = (uint32_t*)take(p->cfg.pos_triplets_only ? Bp * Bp * 4 : 256);
+    p->rowloss_part = (float*)take((2 * Fp / 128) * Bp * 4);
+    p->dbv_part = (float*)take((2 * Bp / 128) * Fp * 4);
+    p->colsum_part = (float*)take(2 * (Bp / 64) * Hp * 4);
+    p->cos_part = (float*)take(2 * (2 * Fp / 128) * Bp * 4);
+    p->cos_stats = (float*)take(3 * Bp * 4);
+    p->rowsq_scratch = (float*)take((Fp / 64) * Bp * 4);
+    p->cw = (float*)take(Bp * 4);
+    p->loss_part = (float*)take(Bp * 4);
+    p->dw_f32 = (float*)take(Bp * 4);
+    p->cnt_part = (uint32_t*)take(Bp * 4);
+    p->dw_i32 = (int32_t*)take(Bp * 4);
+    p->n_same = (int32_t*)take(Bp * 4);
+    p->dw_i64 = (int64_t*)take(Bp * 8);
+    p->nvalid = (int64_t*)take(256);
+    p->acc = (uint64_t*)take(256);
+    p->tri_scalars = (float*)take(256);
+    return off;
+}
+
+extern "C" int dae_plan_create(const dae_config* cfg, dae_plan** out) {
+    DAE_CHECK_ARG(cfg && out, "plan_create: null argument");
+    DAE_CHECK_ARG(cfg->n_features > 0 && cfg->n_components > 0 && cfg->max_batch > 0, "plan_create: bad sizes");
+    DAE_CHECK_ARG(cfg->dtype == DAE_BF16 || cfg->dtype == DAE_F32, "plan_create: bad dtype");
+    DAE_CHECK_ARG(cfg->enc_act >= 0 && cfg->enc_act <= 2 && cfg->dec_act >= 0 && cfg->dec_act <= 2, "plan_create: bad activation");
+    DAE_CHECK_ARG(cfg->loss_func >= 0 && cfg->loss_func <= 2, "plan_create: bad loss_func");
+    DAE_CHECK_ARG(cfg->opt >= 0 && cfg->opt <= 3, "plan_create: bad optimizer");
+    DAE_CHECK_ARG(cfg->triplet >= 0 && cfg->triplet <= 3, "plan_create: bad triplet strategy");
+    dae_plan* p = new (std::nothrow) dae_plan();
+    DAE_CHECK_ARG(p, "plan_create: out of memory");
+    memset(p, 0, sizeof(*p));
+    p->cfg = *cfg;
+    p->F = cfg->n_features; p->H = cfg->n_components; p->Bmax = cfg->max_batch;
+    p->Fp = (int)pad128(p->F); p->Hp = (int)pad128(p->H); p->Bpm = (int)pad128(p->Bmax);
+    p->es = cfg->dtype == DAE_BF16 ? 2 : 4;
+    const int tiles_bh = (p->Bpm / 128) * (p->Hp / 128);
+    const int kt_f = p->Fp * p->es / 128;
+    p->s_enc = cfg->encode_splits > 0 ? cfg->encode_splits : auto_splits(tiles_bh, kt_f);
+    p->s_dh = cfg->dh_splits > 0 ? cfg->dh_splits : auto_splits(tiles_bh, kt_f);
+    const int tiles_bb = (p->Bpm / 128) * (p->Bpm / 128);
+    p->s_gram = cfg->gram_splits > 0 ? cfg->gram_splits : auto_splits(tiles_bb, p->Hp * 4 / 128);
+    if (p->s_enc > kt_f) p->s_enc = kt_f;
+    if (p->s_dh > kt_f) p->s_dh = kt_f;
+    if (p->s_gram > p->Hp * 4 / 128) p->s_gram = p->Hp * 4 / 128;
+    p->ws_bytes = carve(p, nullptr);
+    *out = p;
+    return 0;
+}
+
+extern "C" void dae_plan_destroy(dae_plan* p) { delete p; }
+extern "C" uint64_t dae_plan_workspace_bytes(const dae_plan* p) { return p ? p->ws_bytes : 0; }
+
+extern "C" int dae_plan_bind(dae_plan* p, const dae_buffers* bufs) {
+    DAE_CHECK_ARG(p && bufs, "plan_bind: null argument");
+    DAE_CHECK_ARG(bufs->W && bufs->bh && bufs->bv && bufs->grad && bufs->W_lo && bufs->Wt_lo, "plan_bind: null parameter buffer");
+    DAE_CHECK_ARG(bufs->workspace && bufs->workspace_bytes >= p->ws_bytes, "plan_bind: workspace too small (%llu < %llu)",
+                  (unsigned long long)bufs->workspace_bytes, (unsigned long long)p->ws_bytes);
+    DAE_CHECK_ARG(((uintptr_t)bufs->workspace % 256) == 0, "plan_bind: workspace must be 256-byte aligned");
+    DAE_CHECK_ARG((bufs->indptr != nullptr) != (bufs->dense != nullptr) || (!bufs->indptr && !bufs->dense),
+                  "plan_bind: give either a CSR or a dense train set");
+    DAE_CHECK_ARG(p->cfg.opt == DAE_OPT_SGD || bufs->opt_s1, "plan_bind: optimizer slot buffer required");
+    DAE_CHECK_ARG(p->cfg.opt != DAE_OPT_ADAM || bufs->opt_s2, "plan_bind: second optimizer slot buffer required");
+    p->b = *bufs;
+    carve(p, (char*)bufs->workspace);
+    p->bound = true;
+    return 0;
+}
+
+extern "C" int dae_plan_sync_shadows(dae_plan* p, void* stream) {
+    DAE_CHECK_ARG(p && p->bound, "plan_sync_shadows: plan not bound");
+    return dae_opt_step(p->cfg.opt, 0.f, 0.f, 1.f, p->b.W, p->b.bh, p->b.bv, p->b.grad, p->b.opt_s1, p->b.opt_s2, p->Fp, p->Hp,
+                        p->cfg.dtype, p->b.W_lo, p->b.Wt_lo, /*apply=*/0, stream);
+}
+
+extern "C" void* dae_plan_buffer(dae_plan* p, const char* name) {
+    if (!p || !p->bound || !name) return nullptr;
+#define DAE_BUF(n) if (!strcmp(name, #n)) return (void*)p->n;
+    DAE_BUF(x) DAE_BUF(xc) DAE_BUF(xct) DAE_BUF(h_lo) DAE_BUF(h_t) DAE_BUF(Gs) DAE_BUF(delta2) DAE_BUF(delta2_t) DAE_BUF(delta1_t)
+    DAE_BUF(slabs) DAE_BUF(h_f32) DAE_BUF(D_slabs) DAE_BUF(G) DAE_BUF(rowloss_part) DAE_BUF(dbv_part) DAE_BUF(colsum_part)
+    DAE_BUF(cos_part) DAE_BUF(cos_stats) DAE_BUF(cw) DAE_BUF(loss_part) DAE_BUF(dw_f32) DAE_BUF(tri_scalars) DAE_BUF(dh_extra)
+    DAE_BUF(cnt_part) DAE_BUF(role_cnt) DAE_BUF(dw_i32) DAE_BUF(n_same) DAE_BUF(nvalid) DAE_BUF(dw_i64)
+#undef DAE_BUF
+    return nullptr;
+}
+
+extern "C" int dae_plan_info(const dae_plan* p, int32_t* out8) {
+    DAE_CHECK_ARG(p && out8, "plan_info: null");
+    out8[0] = p->Fp; out8[1] = p->Hp; out8[2] = p->Bpm; out8[3] = p->s_enc; out8[4] = p->s_dh; out8[5] = p->s_gram;
+    out8[6] = p->es; out8[7] = 0;
+    return 0;
+}
+
+static int gather_batch(dae_plan* p, const int64_t* indptr, const int32_t* indices, const float* values, const float* dense,
+                        int64_t ld_dense, const int32_t* row_idx, int B, void* x, void* xc, void* xct, float* rowsq,
+                        int corr_mode, const uint32_t* keep_bits, uint64_t seed, uint32_t rng_stream, float corr_frac,
+                        float scale, void* stream) {
+    if (indptr)
+        return dae_gather_csr(indptr, indices, values, row_idx, B, p->F, p->cfg.dtype, x, xc, p->Fp, xct, p->Bpm, rowsq, corr_mode,
+                              keep_bits, seed, rng_stream, corr_frac, scale, stream);
+    DAE_CHECK_ARG(dense, "step: no train set bound");
+    return dae_gather_dense(dense, ld_dense, row_idx, B, p->F, p->cfg.dtype, x, xc, p->Fp, xct, p->Bpm, rowsq, p->rowsq_scratch,
+                            corr_mode, keep_bits, seed, rng_stream, corr_frac, scale, stream);
+}
+
+#define RC(expr) do { if (int rc__ = (expr)) return rc__; } while (0)
+
+extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
+    DAE_CHECK_ARG(p && p->bound && s, "train_step: plan not bound / null step");
+    DAE_CHECK_ARG(s->row_idx && s->B > 0 && s->B <= p->Bmax, "train_step: batch %d outside (0, %d]", s ? s->B : -1, p->Bmax);
+    const dae_config& c = p->cfg;
+    const bool explicit3 = (c.triplet == 3);
+    DAE_CHECK_ARG(c.triplet == DAE_TRIPLET_NONE || explicit3 || s->labels, "train_step: labels required for triplet mining");
+    DAE_CHECK_ARG(!explicit3 || s->B % 3 == 0, "train_step: explicit-triplet batch must stack org/pos/neg (B %% 3 == 0)");
+    DAE_CHECK_ARG(s->stats, "train_step: stats pointer required");
+    hipStream_t st = (hipStream_t)stream;
+    const int B = s->B, Bp = (int)pad128(B), F = p->F, H = p->H, Fp = p->Fp, Hp = p->Hp, ldB = p->Bpm, dt = c.dtype;
+    const bool is_cos = c.loss_func == DAE_LOSS_COSINE;
+    const bool backward = s->phase != 2;
+
+    // 1-2. corrupt + gather  (K0/K1 front half)
+    if (backward) DAE_CHECK_HIP(hipMemsetAsync(p->xct, 0, (size_t)Fp * ldB * p->es, st));
+    float* rowsq = is_cos ? p->cos_stats : nullptr;
+    if (s->c_indptr) {   // an explicitly corrupted copy of the train set (salt&pepper, host-side noise)
+        RC(gather_batch(p, p->b.indptr, p->b.indices, p->b.values, p->b.dense, p->b.ld_dense, s->row_idx, B, p->x, nullptr, nullptr,
+                        rowsq, DAE_CORR_NONE, nullptr, 0, 0, 0.f, 1.f, stream));
+        RC(gather_batch(p, s->c_indptr, s->c_indices, s->c_values, nullptr, 0, s->row_idx, B, nullptr, p->xc,
+                        backward ? p->xct : nullptr, nullptr, DAE_CORR_NONE, nullptr, 0, 0, 0.f, s->scale, stream));
+    } else {
+        RC(gather_batch(p, p->b.indptr, p->b.indices, p->b.values, p->b.dense, p->b.ld_dense, s->row_idx, B, p->x, p->xc,
+                        backward ? p->xct : nullptr, rowsq, s->corr_mode, s->keep_bits, s->seed, s->rng_stream, s->corr_frac,
+                        s->scale, stream));
+    }
+    // 3-4. encode (K1/K2)
+    const int64_t slab = (int64_t)Bp * Hp;
+    RC(launch_gemm_f32out(dt, Bp, Hp, p->xc, Fp, p->b.Wt_lo, Fp, Fp, nullptr, 0, nullptr, 0, 0, p->slabs, Hp, p->s_enc, slab, st));
+    RC(dae_encode_finish(p->slabs, p->s_enc, slab, Hp, p->b.bh, B, H, c.enc_act, dt, p->h_f32, p->h_lo, Hp, p->h_t, ldB, stream));
+    // 5-6. miners (K5-K7)
+    const int Bt = explicit3 ? B / 3 : B;
+    if (explicit3) {
+        RC(dae_label_stats(nullptr, Bt, Bp, DAE_TRIPLET_NONE, nullptr, nullptr, nullptr, nullptr, p->cw, stream));
+        // every one of the 3*Bt stacked rows carries weight 1/(Bt + 1e-16): three unweighted row means (:303-305)
+        DAE_CHECK_HIP(hipMemcpyAsync(p->cw + Bt, p->cw, (size_t)Bt * 4, hipMemcpyDeviceToDevice, st));
+        DAE_CHECK_HIP(hipMemcpyAsync(p->cw + 2 * Bt, p->cw, (size_t)Bt * 4, hipMemcpyDeviceToDevice, st));
+        RC(dae_explicit_triplet(p->h_f32, Hp, Bt, H, c.alpha, p->dh_extra, p->loss_part, p->tri_scalars, stream));
+    } else {
+        RC(dae_label_stats(s->labels, B, Bp, c.triplet, p->n_same, p->acc, p->nvalid, p->dw_i64, p->cw, stream));
+    }
+    if (c.triplet == DAE_TRIPLET_BATCH_ALL || c.triplet == DAE_TRIPLET_BATCH_HARD) {
+        const int64_t dslab = (int64_t)Bp * Bp;
+        RC(launch_gemm_f32out(DAE_F32, Bp, Bp, p->h_f32, Hp, p->h_f32, Hp, Hp, nullptr, 0, nullptr, 0, 0, p->D_slabs, Bp, p->s_gram,
+                              dslab, st));
+        if (c.triplet == DAE_TRIPLET_BATCH_ALL)
+            RC(dae_triplet_batch_all(p->D_slabs, p->s_gram, dslab, Bp, s->labels, B, Bp, c.pos_triplets_only, p->loss_part,
+                                     p->cnt_part, p->G, p->role_cnt, stream));
+        else
+            RC(dae_triplet_batch_hard(p->D_slabs, p->s_gram, dslab, Bp, s->labels, B, Bp, p->loss_part, p->cnt_part, p->dw_i32, p->G,
+                                      stream));
+        RC(dae_triplet_finalize(c.triplet, c.pos_triplets_only, B, Bp, c.alpha, p->loss_part, p->cnt_part, p->nvalid, p->dw_i32,
+                                p->role_cnt, p->dw_f32, p->cw, p->tri_scalars, stream));
+        if (backward) RC(dae_sym_scale(p->G, B, Bp, p->tri_scalars, dt, p->Gs, stream));
+    }
+    // 7. decode + reconstruction loss + d cost/d z2   (K3/K4)
+    const int ncw = 2 * Fp / 128;
+    DecodeEpi e;
+    e.bv = p->b.bv; e.x = p->x; e.ldx = Fp; e.cw = p->cw; e.cos_stats = is_cos ? p->cos_stats : nullptr;
+    e.rowloss_part = p->rowloss_part; e.dbv_part = backward ? p->dbv_part : nullptr; e.cos_part = p->cos_part;
+    e.delta2 = backward ? p->delta2 : nullptr; e.ldd = Fp; e.delta2_t = backward ? p->delta2_t : nullptr; e.lddt = ldB;
+    e.y_out = nullptr; e.ldy = 0; e.B = B; e.F = F; e.Bp = Bp; e.Fp = Fp; e.dec_act = c.dec_act; e.loss_func = c.loss_func;
+    if (is_cos) {
+        e.cos_pass = 1;
+        RC(launch_decode_loss(dt, Bp, Fp, Hp, p->h_lo, Hp, p->b.W_lo, Hp, e, st));
+        RC(dae_cos_reduce(p->cos_part, ncw, B, Bp, p->cos_stats, p->rowloss_part, stream));
+        if (backward) { e.cos_pass = 2; RC(launch_decode_loss(dt, Bp, Fp, Hp, p->h_lo, Hp, p->b.W_lo, Hp, e, st)); }
+    } else {
+        e.cos_pass = 0;
+        RC(launch_decode_loss(dt, Bp, Fp, Hp, p->h_lo, Hp, p->b.W_lo, Hp, e, st));
+    }
+    // 8. statistics of this step (autoencoder.py:233 fetch list)
+    RC(dae_step_stats(p->rowloss_part, is_cos ? 1 : ncw, p->cw, B, Bp, c.triplet == 3 ? DAE_TRIPLET_BATCH_HARD : c.triplet, c.alpha,
+                      p->tri_scalars, c.triplet == DAE_TRIPLET_BATCH_ALL ? p->nvalid : nullptr, s->stats, stream));
+    if (!backward) return 0;
+    // 9-10. dL/dh = delta2 W + alpha (G+G^T) h ; delta1                     (K8)
+    const bool mined = (c.triplet == DAE_TRIPLET_BATCH_ALL || c.triplet == DAE_TRIPLET_BATCH_HARD);
+    RC(launch_gemm_f32out(dt, Bp, Hp, p->delta2, Fp, p->b.Wt_lo, Fp, Fp, mined ? p->Gs : nullptr, Bp, mined ? p->h_t : nullptr, ldB,
+                          mined ? Bp : 0, p->slabs, Hp, p->s_dh, slab, st));
+    RC(dae_dh_finish(p->slabs, p->s_dh, slab, Hp, explicit3 ? p->dh_extra : nullptr, p->h_f32, Hp, p->b.bh, B, H, c.enc_act, dt,
+                     p->delta1_t, ldB, p->colsum_part, nullptr, stream));
+    // 11. dW = x~^T delta1 + delta2^T h                                      (K8, tied weights)
+    RC(launch_gemm_f32out(dt, Fp, Hp, p->xct, ldB, p->delta1_t, ldB, Bp, p->delta2_t, ldB, p->h_t, ldB, Bp, p->b.grad, Hp, 1, 0, st));
+    // 12. bias gradients
+    float* g_bh = p->b.grad + (int64_t)Fp * Hp;
+    RC(dae_bias_grads(p->dbv_part, 2 * Bp / 128, p->colsum_part, Bp / 64, p->b.bh, H, Hp, F, Fp, c.enc_act, g_bh, g_bh + Hp, stream));
+    if (s->phase == 1) return 0;
+    // 13. optimizer (K9)
+    return dae_plan_apply(p, s->adam_t, s->grad_scale, stream);
+}
+
+extern "C" int dae_plan_apply(dae_plan* p, int32_t adam_t, float grad_scale, void* stream) {
+    DAE_CHECK_ARG(p && p->bound, "plan_apply: plan not bound");
+    float lr = p->cfg.learning_rate;
+    if (p->cfg.opt == DAE_OPT_ADAM) {
+        const double t = adam_t < 1 ? 1 : adam_t;
+        lr = (float)((double)lr * sqrt(1.0 - pow(0.999, t)) / (1.0 - pow(0.9, t)));
+    }
+    return dae_opt_step(p->cfg.opt, lr, p->cfg.momentum, grad_scale, p->b.W, p->b.bh, p->b.bv, p->b.grad, p->b.opt_s1, p->b.opt_s2,
+                        p->Fp, p->Hp, p->cfg.dtype, p->b.W_lo, p->b.Wt_lo, /*apply=*/1, stream);
+}
+
+extern "C" int dae_encode_rows(dae_plan* p, const int32_t* row_idx, int32_t B, float scale, const int64_t* indptr,
+                               const int32_t* indices, const float* values, const float* dense, int64_t ld_dense, float* out,
+                               int64_t ld_out, void* stream) {
+    DAE_CHECK_ARG(p && p->bound && row_idx && out, "encode_rows: bad arguments");
+    DAE_CHECK_ARG(B > 0 && B <= p->Bmax, "encode_rows: batch %d outside (0, %d]", B, p->Bmax);
+    DAE_CHECK_ARG((indptr != nullptr) != (dense != nullptr), "encode_rows: give either a CSR or a dense matrix");
+    hipStream_t st = (hipStream_t)stream;
+    const int Bp = (int)pad128(B), Fp = p->Fp, Hp = p->Hp, dt = p->cfg.dtype;
+    RC(gather_batch(p, indptr, indices, values, dense, ld_dense, row_idx, B, nullptr, p->xc, nullptr, nullptr, DAE_CORR_NONE, nullptr, 0,
+                    0, 0.f, scale, stream));
+    const int64_t slab = (int64_t)Bp * Hp;
+    RC(launch_gemm_f32out(dt, Bp, Hp, p->xc, Fp, p->b.Wt_lo, Fp, Fp, nullptr, 0, nullptr, 0, 0, p->slabs, Hp, p->s_enc, slab, st));
+    RC(dae_encode_finish(p->slabs, p->s_enc, slab, Hp, p->b.bh, B, p->H, p->cfg.enc_act, dt, p->h_f32, nullptr, Hp, nullptr, 0, stream));
+    DAE_CHECK_HIP(hipMemcpy2DAsync(out, (size_t)ld_out * 4, p->h_f32, (size_t)Hp * 4, (size_t)p->H * 4, B, hipMemcpyDeviceToDevice, st));
+    return 0;
+}

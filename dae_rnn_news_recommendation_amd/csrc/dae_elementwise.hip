@@ -1,0 +1,529 @@
+// dae_elementwise.hip -- the small HBM-bound kernels between the MFMA GEMMs of the DAE step:
+// split-K reductions fused with the non-linear epilogues, label statistics, bias gradients,
+// optimizer update (with low-precision shadow refresh) and the per-step statistics.
+// All of them are stream-ordered, deterministic (fixed reduction order; only integer atomics).
+#include "dae_common.h"
+
+namespace dae {
+
+// ------------------------------------------------------------------------------------------------
+// K2 encode epilogue: h = act(sum_s slab_s + bh) - act(bh)          (autoencoder.py:389)
+// 64x64 tiles; h^T goes through an LDS transpose so both images are written coalesced.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void encode_finish_kernel(const float* __restrict__ slabs, int splits, int64_t slab_stride,
+                                                            int64_t ld_slab, const float* __restrict__ bh, int B, int H,
+                                                            int enc_act, float* __restrict__ h_f32, T* __restrict__ h_lo,
+                                                            int64_t ldh, T* __restrict__ h_t, int64_t ldht) {
+    __shared__ float tile[64][65];
+    const int j0 = blockIdx.x * 64, i0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int j = j0 + tx;
+    const float b = bh[j];
+    const float ab = act_apply(enc_act, b);
+#pragma unroll 4
+    for (int r = ty; r < 64; r += 4) {
+        const int i = i0 + r;
+        float z = 0.f;
+        for (int s = 0; s < splits; ++s) z += slabs[(int64_t)s * slab_stride + (int64_t)i * ld_slab + j];
+        float h = (i < B && j < H) ? act_apply(enc_act, z + b) - ab : 0.f;
+        if (h_f32) h_f32[(int64_t)i * ldh + j] = h;
+        if (h_lo) h_lo[(int64_t)i * ldh + j] = Elem<T>::from(h);
+        tile[r][tx] = h;
+    }
+    __syncthreads();
+    if (h_t) {
+#pragma unroll 4
+        for (int r = ty; r < 64; r += 4) h_t[(int64_t)(j0 + r) * ldht + i0 + tx] = Elem<T>::from(tile[tx][r]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K8 (middle): dh = sum_s slab_s (+ dh_extra); delta1 = dh * act'(z1); delta1^T; column partial sums
+// for db_h = sum_i delta1 - act'(bh) * sum_i dh    (the -act(bh) term of autoencoder.py:389)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void dh_finish_kernel(const float* __restrict__ slabs, int splits, int64_t slab_stride,
+                                                        int64_t ld_slab, const float* __restrict__ dh_extra,
+                                                        const float* __restrict__ h_f32, int64_t ldh,
+                                                        const float* __restrict__ bh, int B, int H, int enc_act,
+                                                        T* __restrict__ delta1_t, int64_t ldt, float* __restrict__ colsum_part,
+                                                        int Hp, float* __restrict__ delta1_f32) {
+    __shared__ float tile[64][65];
+    __shared__ float cs[2][4][64];
+    const int j0 = blockIdx.x * 64, i0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int j = j0 + tx;
+    const float ab = act_apply(enc_act, bh[j]);
+    float s_d1 = 0.f, s_dh = 0.f;
+#pragma unroll 4
+    for (int r = ty; r < 64; r += 4) {
+        const int i = i0 + r;
+        float dh = 0.f;
+        for (int s = 0; s < splits; ++s) dh += slabs[(int64_t)s * slab_stride + (int64_t)i * ld_slab + j];
+        if (dh_extra) dh += dh_extra[(int64_t)i * ldh + j];
+        const bool ok = (i < B && j < H);
+        dh = ok ? dh : 0.f;
+        const float a1 = h_f32[(int64_t)i * ldh + j] + ab;          // act(z1)
+        const float d1 = ok ? dh * act_grad(enc_act, a1) : 0.f;
+        s_d1 += d1; s_dh += dh;
+        tile[r][tx] = d1;
+        if (delta1_f32) delta1_f32[(int64_t)i * ldh + j] = d1;
+    }
+    cs[0][ty][tx] = s_d1; cs[1][ty][tx] = s_dh;
+    __syncthreads();
+    if (delta1_t) {
+#pragma unroll 4
+        for (int r = ty; r < 64; r += 4) delta1_t[(int64_t)(j0 + r) * ldt + i0 + tx] = Elem<T>::from(tile[tx][r]);
+    }
+    if (threadIdx.x < 128) {
+        const int which = threadIdx.x >> 6, c = threadIdx.x & 63;
+        const float v = cs[which][0][c] + cs[which][1][c] + cs[which][2][c] + cs[which][3][c];
+        // layout [2][n_row_blocks][Hp]
+        colsum_part[((int64_t)which * gridDim.y + blockIdx.y) * Hp + j0 + c] = v;
+    }
+}
+
+// Gs = scale * (G + G^T) restricted to [0,B)^2, zero elsewhere      (autodiff of D = h h^T)
+template <typename T>
+__global__ __launch_bounds__(256) void sym_scale_kernel(const float* __restrict__ G, int B, int Bp,
+                                                        const float* __restrict__ tri_scalars, T* __restrict__ Gs) {
+    __shared__ float tile[64][65];
+    const int j0 = blockIdx.x * 64, i0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const float sc = tri_scalars[0];
+#pragma unroll 4
+    for (int r = ty; r < 64; r += 4) {   // tile of G^T: element (j0+r, i0+tx)
+        const int a = j0 + r, b = i0 + tx;
+        tile[r][tx] = (a < B && b < B) ? G[(int64_t)a * Bp + b] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int r = ty; r < 64; r += 4) {
+        const int i = i0 + r, j = j0 + tx;
+        float v = 0.f;
+        if (i < B && j < B) v = sc * (G[(int64_t)i * Bp + j] + tile[tx][r]);
+        Gs[(int64_t)i * Bp + j] = Elem<T>::from(v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// label statistics (triplet_loss_utils.py:47-76,110-111,129) -- integer exact
+// acc: int64[2] = {S = sum_i (n_i - 1), N_valid}, zeroed by the caller before kernel 1
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void label_count_kernel(const int32_t* __restrict__ labels, int B, int32_t* __restrict__ n_same,
+                                                          unsigned long long* __restrict__ acc) {
+    __shared__ int32_t lab[1024];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int32_t li = (i < B) ? labels[i] : 0;
+    int cnt = 0;
+    for (int base = 0; base < B; base += 1024) {
+        const int n = min(1024, B - base);
+        for (int k = threadIdx.x; k < n; k += blockDim.x) lab[k] = labels[base + k];
+        __syncthreads();
+        for (int k = 0; k < n; ++k) cnt += (lab[k] == li);
+        __syncthreads();
+    }
+    if (i < B) {
+        n_same[i] = cnt;
+        atomicAdd(&acc[0], (unsigned long long)(cnt - 1));
+        atomicAdd(&acc[1], (unsigned long long)(cnt - 1) * (unsigned long long)(B - cnt));
+    }
+}
+
+__global__ void label_weight_kernel(const int32_t* __restrict__ n_same, int B, int Bp, int triplet,
+                                    const unsigned long long* __restrict__ acc, int64_t* __restrict__ nvalid_out,
+                                    int64_t* __restrict__ dw_out, float* __restrict__ cw) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Bp) return;
+    if (triplet == DAE_TRIPLET_NONE) {                    // weighted_loss default weight = ones (:266)
+        cw[i] = (i < B) ? 1.0f / ((float)B + 1e-16f) : 0.f;
+        return;
+    }
+    const long long S = (long long)acc[0], NV = (long long)acc[1];
+    if (i == 0 && nvalid_out) nvalid_out[0] = NV;
+    if (i < B) {
+        const long long n = n_same[i];
+        const long long dw = 2 * (n - 1) * (B - n) + (S - n * (n - 1));
+        if (dw_out) dw_out[i] = dw;
+        // sum_i dw_i = 3 * N_valid exactly (each valid triplet has three roles)
+        if (triplet == DAE_TRIPLET_BATCH_ALL) cw[i] = (float)dw / ((float)(3 * NV) + 1e-16f);
+    } else if (triplet == DAE_TRIPLET_BATCH_ALL) {
+        cw[i] = 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// miner partials -> normalisers / statistics (single 1024-thread block)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double block_sum_d(double v, double* sm) {
+    const int t = threadIdx.x;
+    sm[t] = v;
+    __syncthreads();
+    for (int o = blockDim.x >> 1; o > 0; o >>= 1) {
+        if (t < o) sm[t] += sm[t + o];
+        __syncthreads();
+    }
+    double r = sm[0];
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(1024) void triplet_finalize_kernel(int triplet, int pos_only, int B, int Bp, float alpha,
+                                                                const float* __restrict__ loss_part,
+                                                                const uint32_t* __restrict__ cnt_part,
+                                                                const int64_t* __restrict__ nvalid,
+                                                                const int32_t* __restrict__ dw_i32,
+                                                                const uint32_t* __restrict__ role_cnt,
+                                                                float* __restrict__ dw_f32_out, float* __restrict__ cw,
+                                                                float* __restrict__ tri_scalars) {
+    __shared__ double sm[1024];
+    const int t = threadIdx.x;
+    double ls = 0.0, cs = 0.0;
+    for (int i = t; i < B; i += blockDim.x) { ls += (double)loss_part[i]; cs += (double)cnt_part[i]; }
+    const double loss_sum = block_sum_d(ls, sm);
+    const double cnt_sum = block_sum_d(cs, sm);
+    double N, frac, num = cnt_sum;
+    if (triplet == DAE_TRIPLET_BATCH_ALL) {
+        const double nv = (double)nvalid[0];
+        N = pos_only ? cnt_sum : nv;
+        frac = (double)((float)cnt_sum / ((float)nv + 1e-16f));
+    } else {
+        N = cnt_sum;
+        frac = (double)((float)cnt_sum / (float)B);
+    }
+    const float Nf = (float)N;
+    if (t == 0) {
+        tri_scalars[0] = alpha / (Nf + 1e-16f);
+        tri_scalars[1] = (float)loss_sum / (Nf + 1e-16f);
+        tri_scalars[2] = (float)frac;
+        tri_scalars[3] = (float)num;
+    }
+    const bool need_dw = (triplet == DAE_TRIPLET_BATCH_HARD) || pos_only;
+    if (!need_dw) return;
+    // data_weight from the miner's integer counts, then cw = dw / (sum dw + 1e-16)
+    double ws = 0.0;
+    for (int j = t; j < B; j += blockDim.x) {
+        long long w;
+        if (triplet == DAE_TRIPLET_BATCH_HARD) {
+            w = dw_i32[j];
+        } else {
+            w = cnt_part[j];                                   // anchor role
+            for (int a = 0; a < B; ++a) w += role_cnt[(int64_t)a * Bp + j];   // positive + negative roles
+        }
+        dw_f32_out[j] = (float)w;
+        ws += (double)w;
+    }
+    const double wsum = block_sum_d(ws, sm);
+    const float wsf = (float)wsum + 1e-16f;
+    for (int j = t; j < Bp; j += blockDim.x) cw[j] = (j < B) ? dw_f32_out[j] / wsf : 0.f;
+}
+
+// cosine_proximity: reduce the first pass' partials into per-row statistics and the row loss
+__global__ void cos_reduce_kernel(const float* __restrict__ cos_part, int n_col_waves, int B, int Bp,
+                                  float* __restrict__ cos_stats, float* __restrict__ rowloss) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Bp) return;
+    float yy = 0.f, xy = 0.f;
+    for (int p = 0; p < n_col_waves; ++p) {
+        yy += cos_part[(int64_t)p * Bp + i];
+        xy += cos_part[(int64_t)(n_col_waves + p) * Bp + i];
+    }
+    cos_stats[Bp + i] = yy;
+    cos_stats[2 * Bp + i] = xy;
+    rowloss[i] = (i < B) ? -xy * rsqrtf(fmaxf(yy, 1e-12f)) : 0.f;    // -sum xhat*yhat (:273)
+}
+
+// bias gradients into the flat gradient buffer
+__global__ void bias_grads_kernel(const float* __restrict__ dbv_part, int n_row_waves, const float* __restrict__ colsum_part,
+                                  int n_row_blocks, const float* __restrict__ bh, int H, int Hp, int F, int Fp, int enc_act,
+                                  float* __restrict__ dbh, float* __restrict__ dbv) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < Fp) {
+        float s = 0.f;
+        if (k < F) for (int p = 0; p < n_row_waves; ++p) s += dbv_part[(int64_t)p * Fp + k];
+        dbv[k] = s;
+    } else if (k < Fp + Hp) {
+        const int j = k - Fp;
+        float s1 = 0.f, s2 = 0.f;
+        if (j < H) {
+            for (int p = 0; p < n_row_blocks; ++p) {
+                s1 += colsum_part[(int64_t)p * Hp + j];
+                s2 += colsum_part[((int64_t)n_row_blocks + p) * Hp + j];
+            }
+            const float ab = act_apply(enc_act, bh[j]);
+            s1 -= act_grad(enc_act, ab) * s2;
+        }
+        dbh[j] = s1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K9 optimizer (autoencoder.py:444-477, tf.train.* semantics)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float opt_update(int opt, float lr, float mom, float p, float g, float* s1, float* s2, int64_t k) {
+    switch (opt) {
+        case DAE_OPT_SGD: return p - lr * g;
+        case DAE_OPT_ADAGRAD: { float a = s1[k] + g * g; s1[k] = a; return p - lr * g * rsqrtf(a); }
+        case DAE_OPT_MOMENTUM: { float a = mom * s1[k] + g; s1[k] = a; return p - lr * a; }
+        default: {   // Adam; lr already holds lr_t = lr*sqrt(1-b2^t)/(1-b1^t)
+            float m = 0.9f * s1[k] + 0.1f * g;
+            float v = 0.999f * s2[k] + 0.001f * g * g;
+            s1[k] = m; s2[k] = v;
+            return p - lr * m / (sqrtf(v) + 1e-8f);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void opt_w_kernel(int opt, float lr, float mom, float gscale, float* __restrict__ W,
+                                                    const float* __restrict__ grad, float* __restrict__ s1,
+                                                    float* __restrict__ s2, int Fp, int Hp, T* __restrict__ W_lo,
+                                                    T* __restrict__ Wt_lo, int apply) {
+    __shared__ float tile[64][65];
+    const int j0 = blockIdx.x * 64, f0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll 4
+    for (int r = ty; r < 64; r += 4) {
+        const int64_t k = (int64_t)(f0 + r) * Hp + j0 + tx;
+        float p = W[k];
+        if (apply) {
+            p = opt_update(opt, lr, mom, p, grad[k] * gscale, s1, s2, k);
+            W[k] = p;
+        }
+        if (W_lo) W_lo[k] = Elem<T>::from(p);
+        tile[r][tx] = p;
+    }
+    __syncthreads();
+    if (Wt_lo) {
+#pragma unroll 4
+        for (int r = ty; r < 64; r += 4) Wt_lo[(int64_t)(j0 + r) * Fp + f0 + tx] = Elem<T>::from(tile[tx][r]);
+    }
+}
+
+__global__ void opt_bias_kernel(int opt, float lr, float mom, float gscale, float* __restrict__ bh, float* __restrict__ bv,
+                                const float* __restrict__ grad_b, float* __restrict__ s1b, float* __restrict__ s2b, int Hp,
+                                int Fp) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= Hp + Fp) return;
+    float* p = (k < Hp) ? &bh[k] : &bv[k - Hp];
+    *p = opt_update(opt, lr, mom, *p, grad_b[k] * gscale, s1b, s2b, k);
+}
+
+// per-step statistics (autoencoder.py:233 fetch list)
+__global__ __launch_bounds__(1024) void step_stats_kernel(const float* __restrict__ rowloss_part, int n_col_waves,
+                                                          const float* __restrict__ cw, int B, int Bp, int triplet, float alpha,
+                                                          const float* __restrict__ tri_scalars,
+                                                          const int64_t* __restrict__ nvalid, float* __restrict__ stats) {
+    __shared__ double sm[1024];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < B; i += blockDim.x) {
+        float r = 0.f;
+        for (int p = 0; p < n_col_waves; ++p) r += rowloss_part[(int64_t)p * Bp + i];
+        s += (double)(r * cw[i]);
+    }
+    const double ae = block_sum_d(s, sm);
+    if (threadIdx.x == 0) {
+        const float aef = (float)ae;
+        float tl = 0.f, fr = 0.f, nm = 0.f, nv = 0.f;
+        if (triplet != DAE_TRIPLET_NONE) {
+            tl = tri_scalars[1]; fr = tri_scalars[2]; nm = tri_scalars[3];
+            nv = (triplet == DAE_TRIPLET_BATCH_ALL && nvalid) ? (float)nvalid[0] : nm;
+        }
+        stats[DAE_STAT_COST] = (triplet != DAE_TRIPLET_NONE) ? aef + alpha * tl : aef;
+        stats[DAE_STAT_AE] = aef;
+        stats[DAE_STAT_TRIPLET] = tl;
+        stats[DAE_STAT_FRACTION] = fr;
+        stats[DAE_STAT_NUM] = nm;
+        stats[DAE_STAT_NVALID] = nv;
+        stats[6] = 0.f; stats[7] = 0.f;
+    }
+}
+
+// explicit (anchor,pos,neg) triplet term (autoencoder_triplet.py:308-311); one wave per triplet row
+__global__ __launch_bounds__(256) void explicit_triplet_kernel(const float* __restrict__ h3, int64_t ldh, int B, int H,
+                                                               float alpha, float* __restrict__ dh3,
+                                                               float* __restrict__ loss_part) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= B) return;
+    const float* ho = h3 + (int64_t)i * ldh;
+    const float* hp = h3 + (int64_t)(B + i) * ldh;
+    const float* hn = h3 + (int64_t)(2 * B + i) * ldh;
+    float t = 0.f;
+    for (int j = lane; j < H; j += 64) t += ho[j] * hn[j] - ho[j] * hp[j];
+    t = wave_sum(t);
+    const float g = alpha * sigmoidf_(t) / (float)B;            // d/dt of alpha * mean softplus(t)
+    if (lane == 0) loss_part[i] = softplus_tf(t);
+    for (int j = lane; j < H; j += 64) {
+        const float o = ho[j], p = hp[j], n = hn[j];
+        dh3[(int64_t)i * ldh + j] = g * (n - p);
+        dh3[(int64_t)(B + i) * ldh + j] = -g * o;
+        dh3[(int64_t)(2 * B + i) * ldh + j] = g * o;
+    }
+}
+
+__global__ __launch_bounds__(1024) void explicit_triplet_finalize_kernel(const float* __restrict__ loss_part, int B,
+                                                                         float* __restrict__ tri_scalars) {
+    __shared__ double sm[1024];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < B; i += blockDim.x) s += (double)loss_part[i];
+    const double tot = block_sum_d(s, sm);
+    if (threadIdx.x == 0) {
+        tri_scalars[0] = 0.f;
+        tri_scalars[1] = (float)(tot / (double)B);
+        tri_scalars[2] = 0.f; tri_scalars[3] = 0.f;
+    }
+}
+
+}  // namespace dae
+
+using namespace dae;
+
+#define ST(s) ((hipStream_t)(s))
+
+extern "C" int dae_encode_finish(const float* slabs, int32_t splits, int64_t slab_stride, int64_t ld_slab, const float* bh,
+                                 int32_t B, int32_t H, int32_t enc_act, int32_t dtype, float* h_f32, void* h_lo, int64_t ldh,
+                                 void* h_t, int64_t ldht, void* stream) {
+    DAE_CHECK_ARG(slabs && bh && splits >= 1, "encode_finish: null input");
+    DAE_CHECK_ARG(B > 0 && H > 0 && ldh >= dae_pad(H) && (!h_t || ldht >= dae_pad(B)), "encode_finish: bad shape");
+    const int Bp = (int)dae_pad(B), Hp = (int)dae_pad(H);
+    dim3 grid(Hp / 64, Bp / 64), block(256);
+    if (dtype == DAE_BF16)
+        hipLaunchKernelGGL((encode_finish_kernel<bf16_t>), grid, block, 0, ST(stream), slabs, splits, slab_stride, ld_slab, bh, B,
+                           H, enc_act, h_f32, (bf16_t*)h_lo, ldh, (bf16_t*)h_t, ldht);
+    else
+        hipLaunchKernelGGL((encode_finish_kernel<float>), grid, block, 0, ST(stream), slabs, splits, slab_stride, ld_slab, bh, B,
+                           H, enc_act, h_f32, (float*)h_lo, ldh, (float*)h_t, ldht);
+    DAE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dae_dh_finish(const float* slabs, int32_t splits, int64_t slab_stride, int64_t ld_slab, const float* dh_extra,
+                             const float* h_f32, int64_t ldh, const float* bh, int32_t B, int32_t H, int32_t enc_act,
+                             int32_t dtype, void* delta1_t, int64_t ldt, float* colsum_part, float* delta1_f32, void* stream) {
+    DAE_CHECK_ARG(slabs && h_f32 && bh && colsum_part, "dh_finish: null input");
+    DAE_CHECK_ARG(B > 0 && H > 0 && ldh >= dae_pad(H), "dh_finish: bad shape");
+    const int Bp = (int)dae_pad(B), Hp = (int)dae_pad(H);
+    dim3 grid(Hp / 64, Bp / 64), block(256);
+    if (dtype == DAE_BF16)
+        hipLaunchKernelGGL((dh_finish_kernel<bf16_t>), grid, block, 0, ST(stream), slabs, splits, slab_stride, ld_slab, dh_extra,
+                           h_f32, ldh, bh, B, H, enc_act, (bf16_t*)delta1_t, ldt, colsum_part, Hp, delta1_f32);
+    else
+        hipLaunchKernelGGL((dh_finish_kernel<float>), grid, block, 0, ST(stream), slabs, splits, slab_stride, ld_slab, dh_extra,
+                           h_f32, ldh, bh, B, H, enc_act, (float*)delta1_t, ldt, colsum_part, Hp, delta1_f32);
+    DAE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dae_sym_scale(const float* G, int32_t B, int32_t Bp, const float* tri_scalars, int32_t dtype, void* Gs,
+                             void* stream) {
+    DAE_CHECK_ARG(G && tri_scalars && Gs && Bp % DAE_PAD == 0 && B <= Bp, "sym_scale: bad args");
+    dim3 grid(Bp / 64, Bp / 64), block(256);
+    if (dtype == DAE_BF16)
+        hipLaunchKernelGGL((sym_scale_kernel<bf16_t>), grid, block, 0, ST(stream), G, B, Bp, tri_scalars, (bf16_t*)Gs);
+    else
+        hipLaunchKernelGGL((sym_scale_kernel<float>), grid, block, 0, ST(stream), G, B, Bp, tri_scalars, (float*)Gs);
+    DAE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dae_label_stats(const int32_t* labels, int32_t B, int32_t Bp, int32_t triplet, int32_t* n_same_scratch,
+                               uint64_t* acc_scratch, int64_t* nvalid_out, int64_t* dw_out, float* cw, void* stream) {
+    DAE_CHECK_ARG(cw && B > 0 && Bp >= B, "label_stats: bad args");
+    if (triplet != DAE_TRIPLET_NONE) {
+        DAE_CHECK_ARG(labels && n_same_scratch && acc_scratch, "label_stats: labels/scratch required");
+        DAE_CHECK_HIP(hipMemsetAsync(acc_scratch, 0, 2 * sizeof(uint64_t), ST(stream)));
+        hipLaunchKernelGGL(label_count_kernel, dim3((B + 255) / 256), dim3(256), 0, ST(stream), labels, B, n_same_scratch,
+                           (unsigned long long*)acc_scratch);
+        DAE_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(label_weight_kernel, dim3((Bp + 255) / 256), dim3(256), 0, ST(stream), n_same_scratch, B, Bp, triplet,
+                       (const unsigned long long*)acc_scratch, nvalid_out, dw_out, cw);
+    DAE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dae_triplet_finalize(int32_t triplet, int32_t pos_only, int32_t B, int32_t Bp, float alpha,
+                                    const float* loss_part, const uint32_t* cnt_part, const int64_t* nvalid,
+                                    const int32_t* dw_i32, const uint32_t* role_cnt, float* dw_f32_out, float* cw,
+                                    float* tri_scalars, void* stream) {
+    DAE_CHECK_ARG(loss_part && cnt_part && tri_scalars, "triplet_finalize: null input");
+    DAE_CHECK_ARG(triplet == DAE_TRIPLET_BATCH_ALL || triplet == DAE_TRIPLET_BATCH_HARD, "triplet_finalize: bad strategy");
+    DAE_CHECK_ARG(triplet != DAE_TRIPLET_BATCH_ALL || nvalid, "triplet_finalize: nvalid required");
+    if (triplet == DAE_TRIPLET_BATCH_HARD) DAE_CHECK_ARG(dw_i32 && dw_f32_out && cw, "triplet_finalize: dw buffers required");
+    if (triplet == DAE_TRIPLET_BATCH_ALL && pos_only) DAE_CHECK_ARG(role_cnt && dw_f32_out && cw, "triplet_finalize: role_cnt required");
+    hipLaunchKernelGGL(triplet_finalize_kernel, dim3(1), dim3(1024), 0, ST(stream), triplet, pos_only, B, Bp, alpha, loss_part,
+                       cnt_part, nvalid, dw_i32, role_cnt, dw_f32_out, cw, tri_scalars);
+    DAE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dae_cos_reduce(const float* cos_part, int32_t n_col_waves, int32_t B, int32_t Bp, float* cos_stats,
+                              float* rowloss, void* stream) {
+    DAE_CHECK_ARG(cos_part && cos_stats && rowloss, "cos_reduce: null input");
+    hipLaunchKernelGGL(cos_reduce_kernel, dim3((Bp + 255) / 256), dim3(256), 0, ST(stream), cos_part, n_col_waves, B, Bp,
+                       cos_stats, rowloss);
+    DAE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dae_bias_grads(const float* dbv_part, int32_t n_row_waves, const float* colsum_part, int32_t n_row_blocks,
+                              const float* bh, int32_t H, int32_t Hp, int32_t F, int32_t Fp, int32_t enc_act, float* dbh,
+                              float* dbv, void* stream) {
+    DAE_CHECK_ARG(dbv_part && colsum_part && bh && dbh && dbv, "bias_grads: null input");
+    const int n = Fp + Hp;
+    hipLaunchKernelGGL(bias_grads_kernel, dim3((n + 255) / 256), dim3(256), 0, ST(stream), dbv_part, n_row_waves, colsum_part,
+                       n_row_blocks, bh, H, Hp, F, Fp, enc_act, dbh, dbv);
+    DAE_CHECK_LAUNCH();
+    return 0;
+}
+
+// flat layout of grad / s1 / s2: [W (Fp*Hp) | bh (Hp) | bv (Fp)]
+extern "C" int dae_opt_step(int32_t opt, float lr, float momentum, float grad_scale, float* W, float* bh, float* bv,
+                            const float* grad, float* s1, float* s2, int32_t Fp, int32_t Hp, int32_t dtype, void* W_lo,
+                            void* Wt_lo, int32_t apply, void* stream) {
+    DAE_CHECK_ARG(W && Fp % DAE_PAD == 0 && Hp % DAE_PAD == 0, "opt_step: bad args");
+    DAE_CHECK_ARG(opt >= DAE_OPT_SGD && opt <= DAE_OPT_ADAM, "opt_step: unknown optimizer %d", opt);
+    if (apply) {
+        DAE_CHECK_ARG(grad && bh && bv, "opt_step: null grad/bias");
+        DAE_CHECK_ARG(opt == DAE_OPT_SGD || s1, "opt_step: optimizer slot s1 required");
+        DAE_CHECK_ARG(opt != DAE_OPT_ADAM || s2, "opt_step: optimizer slot s2 required");
+    }
+    dim3 grid(Hp / 64, Fp / 64), block(256);
+    if (dtype == DAE_BF16)
+        hipLaunchKernelGGL((opt_w_kernel<bf16_t>), grid, block, 0, ST(stream), opt, lr, momentum, grad_scale, W, grad, s1, s2, Fp, Hp,
+                           (bf16_t*)W_lo, (bf16_t*)Wt_lo, apply);
+    else
+        hipLaunchKernelGGL((opt_w_kernel<float>), grid, block, 0, ST(stream), opt, lr, momentum, grad_scale, W, grad, s1, s2, Fp, Hp,
+                           (float*)W_lo, (float*)Wt_lo, apply);
+    DAE_CHECK_LAUNCH();
+    if (apply) {
+        const int64_t off = (int64_t)Fp * Hp;
+        hipLaunchKernelGGL(opt_bias_kernel, dim3((Hp + Fp + 255) / 256), dim3(256), 0, ST(stream), opt, lr, momentum, grad_scale, bh,
+                           bv, grad + off, s1 ? s1 + off : nullptr, s2 ? s2 + off : nullptr, Hp, Fp);
+        DAE_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+extern "C" int dae_step_stats(const float* rowloss_part, int32_t n_col_waves, const float* cw, int32_t B, int32_t Bp,
+                              int32_t triplet, float alpha, const float* tri_scalars, const int64_t* nvalid, float* stats,
+                              void* stream) {
+    DAE_CHECK_ARG(rowloss_part && cw && stats, "step_stats: null input");
+    DAE_CHECK_ARG(triplet == DAE_TRIPLET_NONE || tri_scalars, "step_stats: tri_scalars required");
+    hipLaunchKernelGGL(step_stats_kernel, dim3(1), dim3(1024), 0, ST(stream), rowloss_part, n_col_waves, cw, B, Bp, triplet, alpha,
+                       tri_scalars, nvalid, stats);
+    DAE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dae_explicit_triplet(const float* h3, int64_t ldh, int32_t B, int32_t H, float alpha, float* dh3,
+                                    float* loss_part, float* tri_scalars, void* stream) {
+    DAE_CHECK_ARG(h3 && dh3 && loss_part && tri_scalars && B > 0, "explicit_triplet: bad args");
+    hipLaunchKernelGGL(explicit_triplet_kernel, dim3((B + 3) / 4), dim3(256), 0, ST(stream), h3, ldh, B, H, alpha, dh3, loss_part);
+    DAE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(explicit_triplet_finalize_kernel, dim3(1), dim3(1024), 0, ST(stream), loss_part, B, tri_scalars);
+    DAE_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,32 @@
+// dae_kernels.h -- internal (non-ABI) declarations shared by the translation units of libdae_hip.so.
+#pragma once
+#include "dae_common.h"
+
+namespace dae {
+
+// epilogue descriptor of the fused decode + loss kernel (dae_gemm.hip)
+struct DecodeEpi {
+    const float* bv;          // [Fp]
+    const void* x;            // [Bp x ldx] clean input, element type T
+    int64_t ldx;
+    const float* cw;          // [Bp] w_i / (sum w + 1e-16), zero for i >= B
+    const float* cos_stats;   // cosine: [3 x Bp] = {sum x^2 | sum y^2 | sum xhat.y}; NULL otherwise
+    float* rowloss_part;      // [2*tiles_n x Bp]
+    float* dbv_part;          // [2*tiles_m x Fp]
+    float* cos_part;          // cosine first pass: [2 x 2*tiles_n x Bp] partial {sum y^2, sum xhat*y}
+    void* delta2; int64_t ldd;
+    void* delta2_t; int64_t lddt;
+    float* y_out; int64_t ldy;
+    int B, F, Bp, Fp;
+    int dec_act, loss_func;
+    int cos_pass;             // 0: not cosine, 1: statistics pass, 2: final pass
+};
+
+int launch_gemm_f32out(int dtype, int M, int N, const void* A0, int64_t lda0, const void* Bt0, int64_t ldb0, int K0,
+                       const void* A1, int64_t lda1, const void* Bt1, int64_t ldb1, int K1, float* C, int64_t ldc, int splits,
+                       int64_t slab_stride, hipStream_t st);
+int launch_decode_loss(int dtype, int Bp, int Fp, int Hp, const void* h_lo, int64_t ldh, const void* W_lo, int64_t ldw,
+                       const DecodeEpi& e, hipStream_t st);
+void set_use_glds(bool v);
+
+}  // namespace dae

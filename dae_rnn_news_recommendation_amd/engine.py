@@ -1,0 +1,197 @@
+"""Device-side engine: owns the HBM-resident train set, the padded parameters / optimizer slots and the
+workspace, and drives libdae_hip's whole-step entry point (`dae_train_step`).
+
+HBM layout: the train set stays resident as CSR (int64 indptr, int32 sorted column
+ids, fp32 values or none for binary) or as a dense fp32 matrix; parameters are fp32 masters padded to
+multiples of 128 (W [Fp x Hp], bh [Hp], bv [Fp]) with bf16 (or fp32) shadows W_lo and W^T_lo that the
+optimizer kernel refreshes; the gradient is one flat fp32 buffer [dW | dbh | dbv] so data parallelism is
+a single all-reduce.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+class Engine:
+    def __init__(self, n_features, n_components, max_batch, *, dtype="bf16", enc_act="sigmoid", dec_act="sigmoid",
+                 loss_func="cross_entropy", opt="gradient_descent", learning_rate=0.1, momentum=0.5, alpha=1.0,
+                 triplet="none", pos_triplets_only=False, device=None, encode_splits=0, dh_splits=0, gram_splits=0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("dae_rnn_news_recommendation_amd.Engine needs a ROCm GPU (MI355X): no CPU fallback exists")
+        self.lib = L.load()
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.F, self.H, self.Bmax = int(n_features), int(n_components), int(max_batch)
+        self.dtype = {"bf16": L.BF16, "bfloat16": L.BF16, "fp32": L.F32, "f32": L.F32, "float32": L.F32}.get(dtype, dtype)
+        assert self.dtype in (L.BF16, L.F32), dtype
+        self.td = torch.bfloat16 if self.dtype == L.BF16 else torch.float32
+        self.opt = opt
+        self.cfg = L.dae_config(self.F, self.H, self.Bmax, self.dtype, L.ACT[enc_act], L.ACT[dec_act], L.LOSS[loss_func],
+                                L.OPT[opt], L.TRIPLET[triplet], int(pos_triplets_only), encode_splits, dh_splits,
+                                gram_splits, float(learning_rate), float(momentum), float(alpha))
+        plan = C.c_void_p()
+        L.check(self.lib.dae_plan_create(C.byref(self.cfg), C.byref(plan)), "dae_plan_create")
+        self.plan = plan
+        self.Fp, self.Hp, self.Bpm = L.pad(self.F), L.pad(self.H), L.pad(self.Bmax)
+        dev = self.device
+        n_flat = self.Fp * self.Hp + self.Hp + self.Fp
+        self.W = torch.zeros((self.Fp, self.Hp), dtype=torch.float32, device=dev)
+        self.bh = torch.zeros(self.Hp, dtype=torch.float32, device=dev)
+        self.bv = torch.zeros(self.Fp, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(n_flat, dtype=torch.float32, device=dev)
+        self.s1 = self.s2 = None
+        if opt == "ada_grad":
+            self.s1 = torch.full((n_flat,), 0.1, dtype=torch.float32, device=dev)   # TF initial_accumulator_value
+        elif opt == "momentum":
+            self.s1 = torch.zeros(n_flat, dtype=torch.float32, device=dev)
+        elif opt == "adam":
+            self.s1 = torch.zeros(n_flat, dtype=torch.float32, device=dev)
+            self.s2 = torch.zeros(n_flat, dtype=torch.float32, device=dev)
+        self.W_lo = torch.zeros((self.Fp, self.Hp), dtype=self.td, device=dev)
+        self.Wt_lo = torch.zeros((self.Hp, self.Fp), dtype=self.td, device=dev)
+        ws_bytes = int(self.lib.dae_plan_workspace_bytes(self.plan))
+        self.workspace = torch.zeros(ws_bytes, dtype=torch.uint8, device=dev)
+        self.csr = None
+        self.dense = None
+        self.adam_t = 0
+        self._bound = False
+
+    # ------------------------------------------------------------------ data
+    def upload_csr(self, m):
+        """Make a scipy CSR matrix resident in HBM (canonical form: sorted, no duplicates)."""
+        from scipy import sparse
+        m = sparse.csr_matrix(m)
+        if not m.has_canonical_format:
+            m = m.copy(); m.sum_duplicates(); m.sort_indices()
+        assert m.shape[1] == self.F, (m.shape, self.F)
+        dev = self.device
+        binary = bool(m.nnz == 0 or np.all(m.data == 1))
+        self.csr = dict(
+            indptr=torch.from_numpy(m.indptr.astype(np.int64)).to(dev),
+            indices=torch.from_numpy(m.indices.astype(np.int32)).to(dev),
+            values=None if binary else torch.from_numpy(m.data.astype(np.float32)).to(dev),
+            n_rows=m.shape[0], nnz=int(m.nnz))
+        self.dense = None
+        self._bind()
+        return self.csr
+
+    def upload_dense(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        assert a.shape[1] == self.F
+        self.dense = torch.from_numpy(a).to(self.device)
+        self.csr = None
+        self._bind()
+
+    @staticmethod
+    def to_device_csr(m, device):
+        from scipy import sparse
+        m = sparse.csr_matrix(m)
+        if not m.has_canonical_format:
+            m = m.copy(); m.sum_duplicates(); m.sort_indices()
+        return dict(indptr=torch.from_numpy(m.indptr.astype(np.int64)).to(device),
+                    indices=torch.from_numpy(m.indices.astype(np.int32)).to(device),
+                    values=torch.from_numpy(m.data.astype(np.float32)).to(device), n_rows=m.shape[0], nnz=int(m.nnz))
+
+    def _bind(self):
+        b = L.dae_buffers()
+        if self.csr is not None:
+            b.indptr = self.csr["indptr"].data_ptr(); b.indices = self.csr["indices"].data_ptr()
+            b.values = None if self.csr["values"] is None else self.csr["values"].data_ptr()
+            b.n_rows = self.csr["n_rows"]; b.nnz = self.csr["nnz"]
+        if self.dense is not None:
+            b.dense = self.dense.data_ptr(); b.ld_dense = self.dense.stride(0); b.n_rows = self.dense.shape[0]
+        b.W = self.W.data_ptr(); b.bh = self.bh.data_ptr(); b.bv = self.bv.data_ptr(); b.grad = self.grad.data_ptr()
+        b.opt_s1 = None if self.s1 is None else self.s1.data_ptr()
+        b.opt_s2 = None if self.s2 is None else self.s2.data_ptr()
+        b.W_lo = self.W_lo.data_ptr(); b.Wt_lo = self.Wt_lo.data_ptr()
+        b.workspace = self.workspace.data_ptr(); b.workspace_bytes = self.workspace.numel()
+        L.check(self.lib.dae_plan_bind(self.plan, C.byref(b)), "dae_plan_bind")
+        self._bound = True
+
+    # ------------------------------------------------------------------ params
+    def set_params(self, W, bh=None, bv=None):
+        """Inject (unpadded) parameters; padding stays exactly zero."""
+        if not self._bound:
+            self._bind()
+        self.W.zero_(); self.bh.zero_(); self.bv.zero_()
+        self.W[:self.F, :self.H] = torch.as_tensor(np.asarray(W, np.float32)).to(self.device)
+        if bh is not None:
+            self.bh[:self.H] = torch.as_tensor(np.asarray(bh, np.float32)).to(self.device)
+        if bv is not None:
+            self.bv[:self.F] = torch.as_tensor(np.asarray(bv, np.float32)).to(self.device)
+        L.check(self.lib.dae_plan_sync_shadows(self.plan, L.current_stream()), "dae_plan_sync_shadows")
+
+    def get_params(self):
+        return (self.W[:self.F, :self.H].cpu().numpy(), self.bh[:self.H].cpu().numpy(), self.bv[:self.F].cpu().numpy())
+
+    def grads(self):
+        """(dW, dbh, dbv) views of the flat gradient buffer, unpadded copies on the host."""
+        n = self.Fp * self.Hp
+        dW = self.grad[:n].view(self.Fp, self.Hp)[:self.F, :self.H].cpu().numpy()
+        dbh = self.grad[n:n + self.Hp][:self.H].cpu().numpy()
+        dbv = self.grad[n + self.Hp:][:self.F].cpu().numpy()
+        return dW, dbh, dbv
+
+    def optimizer_state(self):
+        return {"s1": self.s1, "s2": self.s2, "adam_t": self.adam_t}
+
+    # ------------------------------------------------------------------ steps
+    def train_step(self, row_idx, labels, stats, *, corr_mode=L.CORR_NONE, keep_bits=None, seed=0, rng_stream=0,
+                   corr_frac=0.0, scale=1.0, corrupted_csr=None, phase=0, grad_scale=1.0):
+        """Enqueue one mini-batch step.  row_idx / labels: device int32 tensors; stats: device float32[8]."""
+        s = L.dae_step()
+        s.row_idx = row_idx.data_ptr(); s.labels = None if labels is None else labels.data_ptr()
+        s.B = int(row_idx.numel())
+        s.corr_mode = corr_mode; s.keep_bits = None if keep_bits is None else keep_bits.data_ptr()
+        s.seed = int(seed); s.rng_stream = int(rng_stream); s.corr_frac = float(corr_frac); s.scale = float(scale)
+        if corrupted_csr is not None:
+            s.c_indptr = corrupted_csr["indptr"].data_ptr(); s.c_indices = corrupted_csr["indices"].data_ptr()
+            s.c_values = None if corrupted_csr["values"] is None else corrupted_csr["values"].data_ptr()
+        s.stats = stats.data_ptr(); s.phase = int(phase)
+        if phase == 0 and self.opt == "adam":
+            self.adam_t += 1
+        s.adam_t = self.adam_t; s.grad_scale = float(grad_scale)
+        L.check(self.lib.dae_train_step(self.plan, C.byref(s), L.current_stream()), "dae_train_step")
+
+    def apply(self, grad_scale=1.0):
+        """Optimizer step on the (all-reduced) flat gradient -- the second half of a DP step."""
+        if self.opt == "adam":
+            self.adam_t += 1
+        L.check(self.lib.dae_plan_apply(self.plan, self.adam_t, float(grad_scale), L.current_stream()), "dae_plan_apply")
+
+    def encode_rows(self, row_idx, out, *, scale=1.0, csr=None, dense=None):
+        """out[B x H] (device fp32) = encode(scale * rows) -- transform() (autoencoder.py:479-505)."""
+        csr = self.csr if (csr is None and dense is None) else csr
+        dense = self.dense if (csr is None and dense is None) else dense
+        L.check(self.lib.dae_encode_rows(
+            self.plan, L.ptr(row_idx), int(row_idx.numel()), float(scale),
+            None if csr is None else L.ptr(csr["indptr"]), None if csr is None else L.ptr(csr["indices"]),
+            None if csr is None else L.ptr(csr["values"]),
+            None if dense is None else L.ptr(dense), 0 if dense is None else dense.stride(0),
+            L.ptr(out), out.stride(0), L.current_stream()), "dae_encode_rows")
+
+    def buffer(self, name, shape, dtype):
+        """Debug/test view of a workspace buffer as a torch tensor (no copy)."""
+        p = self.lib.dae_plan_buffer(self.plan, name.encode())
+        if not p:
+            raise KeyError(name)
+        off = p - self.workspace.data_ptr()
+        n = int(np.prod(shape)) * torch.tensor([], dtype=dtype).element_size()
+        return self.workspace[off:off + n].view(dtype).view(*shape)
+
+    def info(self):
+        out = (C.c_int32 * 8)()
+        L.check(self.lib.dae_plan_info(self.plan, out), "dae_plan_info")
+        return dict(Fp=out[0], Hp=out[1], Bpm=out[2], encode_splits=out[3], dh_splits=out[4], gram_splits=out[5], es=out[6])
+
+    def __del__(self):
+        try:
+            if getattr(self, "plan", None):
+                self.lib.dae_plan_destroy(self.plan)
+                self.plan = None
+        except Exception:
+            pass

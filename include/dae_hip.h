@@ -1,0 +1,274 @@
+/*
+ * dae_hip.h -- C ABI of libdae_hip.so: the MI355X (gfx950) implementation of the DAE
+ * article-embedding training hot path of louislung/DAE_RNN_News_Recommendation.
+ *
+ * The reference has NO native/FFI boundary (100 % Python on TensorFlow 1.12): the hot path is
+ * whatever `tf_session.run([train_step, ...])` executes per mini-batch.  This header therefore
+ * defines the boundary a maintainer would bind with ctypes from the reference's own Python
+ * (see INTEGRATION.md).  Each entry point cites the reference code it replaces; paths are
+ * relative to the reference repo root.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in `_host`;
+ *   - every function returns 0 on success, non-zero on error (message via dae_last_error());
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is
+ *     stream-ordered, nothing synchronises the host;
+ *   - dense activations use one element type per call: DAE_BF16 (MFMA bf16, fp32 accumulate)
+ *     or DAE_F32 (exact-fp32 MFMA, the parity mode); parameters / gradients / statistics are fp32;
+ *   - "padded" sizes: every dense row/column extent is rounded up to a multiple of DAE_PAD (128)
+ *     and the padding is kept EXACTLY ZERO by every kernel (see DESIGN.md "HBM layout").
+ */
+#ifndef DAE_HIP_H
+#define DAE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DAE_PAD 128
+#define DAE_ABI_VERSION 1
+
+enum { DAE_BF16 = 0, DAE_F32 = 1 };
+enum { DAE_ACT_NONE = 0, DAE_ACT_SIGMOID = 1, DAE_ACT_TANH = 2 };
+enum { DAE_LOSS_CROSS_ENTROPY = 0, DAE_LOSS_MEAN_SQUARED = 1, DAE_LOSS_COSINE = 2 };
+enum { DAE_OPT_SGD = 0, DAE_OPT_ADAGRAD = 1, DAE_OPT_MOMENTUM = 2, DAE_OPT_ADAM = 3 };
+enum { DAE_TRIPLET_NONE = 0, DAE_TRIPLET_BATCH_ALL = 1, DAE_TRIPLET_BATCH_HARD = 2,
+       DAE_TRIPLET_EXPLICIT = 3 /* DenoisingAutoencoderTriplet: rows stacked [org; pos; neg] */ };
+enum { DAE_CORR_NONE = 0, DAE_CORR_KEEPBITS = 1, DAE_CORR_PHILOX_MASK = 2 };
+
+/* slots of the per-step statistics record (float[DAE_STATS_STRIDE]) -- the values the reference
+ * fetches at autoencoder.py:233 and averages per epoch at :283-294 */
+enum { DAE_STAT_COST = 0, DAE_STAT_AE = 1, DAE_STAT_TRIPLET = 2, DAE_STAT_FRACTION = 3,
+       DAE_STAT_NUM = 4, DAE_STAT_NVALID = 5, DAE_STATS_STRIDE = 8 };
+
+int         dae_abi_version(void);
+const char* dae_last_error(void);
+/* padded extent: ceil(n / DAE_PAD) * DAE_PAD */
+int64_t     dae_pad(int64_t n);
+
+/* ---------------------------------------------------------------------------------------------
+ * K0+K1 (front half): corrupt + CSR-row -> dense tile gather, staged through LDS.
+ * Replaces utils.masking_noise (utils.py:94-115), the per-batch CSR fancy-index
+ * (utils.py:59-60), get_sparse_ind_val_shape (utils.py:162-180) and tf.sparse.to_dense
+ * (triplet_loss_utils.py:264).
+ *   rows  i = 0..B-1 take CSR row row_idx[i];  columns are the CSR's (sorted) column ids.
+ *   x      [Bp x ldx]  clean rows (target of the reconstruction loss)          (may be NULL)
+ *   xc     [Bp x ldx]  corrupted rows  x~ = scale * keep(e) * value(e)         (may be NULL)
+ *   xct    [Fp x ldt]  transpose of xc (A operand of the dW GEMM)              (may be NULL;
+ *                      must be zero-filled by the caller, only kept entries are written)
+ *   rowsq  [Bp] fp32   sum of squares of each clean row (cosine_proximity)     (may be NULL)
+ *   corr_mode: DAE_CORR_NONE      -> keep everything
+ *              DAE_CORR_KEEPBITS  -> keep entry e iff bit e of keep_bits (reference-exact stream
+ *                                    np.random.rand(nnz) >= v, generated on the host)
+ *              DAE_CORR_PHILOX_MASK -> keep iff philox_uniform(e; seed, stream) >= corr_frac
+ *   values == NULL means a binary matrix (all stored values 1.0; main_autoencoder.py:235).
+ * ------------------------------------------------------------------------------------------- */
+int dae_gather_csr(const int64_t* indptr, const int32_t* indices, const float* values,
+                   const int32_t* row_idx, int32_t B, int32_t F, int32_t dtype,
+                   void* x, void* xc, int64_t ldx, void* xct, int64_t ldt, float* rowsq,
+                   int32_t corr_mode, const uint32_t* keep_bits, uint64_t seed, uint32_t rng_stream,
+                   float corr_frac, float scale, void* stream);
+
+/* Dense-ndarray input (autoencoder.py:143 sparse_input=False; utils.py:107-109 dense masking):
+ * gathers fp32 rows data[row_idx[i], :] into x / xc / xct with optional Philox masking. */
+int dae_gather_dense(const float* data, int64_t ld_data, const int32_t* row_idx, int32_t B, int32_t F,
+                     int32_t dtype, void* x, void* xc, int64_t ldx, void* xct, int64_t ldt, float* rowsq,
+                     float* rowsq_scratch /* [(Fp/64) x Bp], needed iff rowsq */,
+                     int32_t corr_mode, const uint32_t* keep_bits /* bit index = row*F + f */,
+                     uint64_t seed, uint32_t rng_stream, float corr_frac, float scale, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Generic NT GEMM on MFMA tiles:  C[M x N] (+)= sum_seg A_seg[M x K_seg] * Bt_seg[N x K_seg]^T
+ * fp32 accumulate, fp32 output; up to two K segments (tied-weight gradient, triplet term).
+ * M, N multiples of 128, K_seg multiples of 64 (bf16) / 32 (fp32); lda/ldb/ldc in ELEMENTS.
+ * splits > 1 writes `splits` partial slabs C + s*slab_stride (consumer sums them).
+ * This is tf.matmul / tf.sparse.matmul of the reference graph (autoencoder.py:389,411;
+ * triplet_loss_utils.py:93,219) and of its autodiff (autoencoder.py:452-472).
+ * ------------------------------------------------------------------------------------------- */
+int dae_gemm_nt(int32_t dtype, int32_t M, int32_t N,
+                const void* A0, int64_t lda0, const void* Bt0, int64_t ldb0, int32_t K0,
+                const void* A1, int64_t lda1, const void* Bt1, int64_t ldb1, int32_t K1,
+                float* C, int64_t ldc, int32_t splits, int64_t slab_stride, void* stream);
+
+/* K2: encode epilogue  h = act(sum_s slab_s + bh) - act(bh)   (autoencoder.py:389)
+ * writes h fp32 [Bp x ldh], h in `dtype` [Bp x ldh] and h^T in `dtype` [Hp x ldht]; rows >= B
+ * and columns >= H are written as zero.  Any output pointer may be NULL. */
+int dae_encode_finish(const float* slabs, int32_t splits, int64_t slab_stride, int64_t ld_slab,
+                      const float* bh, int32_t B, int32_t H, int32_t enc_act, int32_t dtype,
+                      float* h_f32, void* h_lo, int64_t ldh, void* h_t, int64_t ldht, void* stream);
+
+/* K3+K4 (+ seeds of K8): decode GEMM fused with bias, activation, per-row reconstruction loss
+ * and d cost / d z2   (autoencoder.py:411; triplet_loss_utils.py:262-277 weighted_loss).
+ *   y = act(h W^T + bv);  rowloss_i = sum_f loss(x_if, y_if);
+ *   delta2_if = cw_i * dloss/dy * act'(z2)      with cw_i = w_i / (sum w + 1e-16)
+ * outputs: rowloss_part [n_col_waves x Bp] partial row sums (n_col_waves = 2*Fp/128),
+ *          dbv_part [n_row_waves x Fp] partial column sums of delta2 (n_row_waves = 2*Bp/128),
+ *          delta2 [Bp x ldd] and delta2^T [Fp x lddt] in `dtype` (any of these may be NULL),
+ *          y_out fp32 [Bp x ldy] (NULL unless the caller wants the reconstruction).
+ * cosine_proximity needs whole-row statistics and runs as two passes over the same GEMM:
+ *   cos_pass 1: cos_stats[0..Bp) = sum x^2 (from the gather) is read, cos_part
+ *               [2 x n_col_waves x Bp] receives partial {sum y^2, sum xhat.y};
+ *   dae_cos_reduce folds them into cos_stats[Bp..3Bp) and the row loss;
+ *   cos_pass 2: produces delta2 / delta2^T / dbv_part.   Other losses: cos_pass = 0. */
+int dae_decode_loss(int32_t dtype, int32_t B, int32_t F, int32_t H,
+                    const void* h_lo, int64_t ldh, const void* W_lo, int64_t ldw,
+                    const float* bv, const void* x, int64_t ldx, const float* cw,
+                    int32_t dec_act, int32_t loss_func, int32_t cos_pass, const float* cos_stats,
+                    float* cos_part, float* rowloss_part, float* dbv_part,
+                    void* delta2, int64_t ldd, void* delta2_t, int64_t lddt,
+                    float* y_out, int64_t ldy, void* stream);
+int dae_cos_reduce(const float* cos_part, int32_t n_col_waves, int32_t B, int32_t Bp,
+                   float* cos_stats, float* rowloss, void* stream);
+
+/* K5: Gram matrix D = h h^T in exact fp32 MFMA (triplet_loss_utils.py:93,219).
+ * D_slabs: `splits` slabs of [Bp x Bp] (consumers sum them). */
+int dae_gram(const float* h_f32, int64_t ldh, int32_t Bp, int32_t Hp, float* D_slabs, int32_t splits,
+             void* stream);
+
+/* Label statistics (triplet_loss_utils.py:47-76,110-111,129): integer-exact N_valid and batch_all
+ * data_weight from label multiplicities, and cw_i = w_i/(sum w + 1e-16) (zero beyond B).
+ *   labels int32[B]; n_same_scratch int32[B]; acc_scratch uint64[2]; nvalid_out int64[1];
+ *   dw_out int64[B] (may be NULL); cw float[Bp].
+ * DAE_TRIPLET_NONE writes cw_i = 1/(B + 1e-16) (weighted_loss's default weight ones, :266) and
+ * needs no labels/scratch; DAE_TRIPLET_BATCH_HARD only fills nvalid/dw (cw comes from the miner). */
+int dae_label_stats(const int32_t* labels, int32_t B, int32_t Bp, int32_t triplet,
+                    int32_t* n_same_scratch, uint64_t* acc_scratch,
+                    int64_t* nvalid_out, int64_t* dw_out, float* cw, void* stream);
+
+/* K6: batch_all online miner, one fused sweep per anchor (triplet_loss_utils.py:79-131).
+ *   loss_part[a] = sum_{p,n valid} softplus(D[a,n]-D[a,p])   (only positive triplets if pos_only)
+ *   npos_part[a] = #{valid (p,n): D[a,n]-D[a,p] > 1e-16}
+ *   G[a,:]       = d(sum softplus)/dD[a,:]   (un-normalised, [Bp x Bp], row stride Bp)
+ *   role_cnt[a,:] (pos_only): per-column positive-triplet counts (NULL otherwise)
+ * D is given as `d_splits` slabs (stride slab_stride) that are summed on load. */
+int dae_triplet_batch_all(const float* D_slabs, int32_t d_splits, int64_t slab_stride, int64_t ldd,
+                          const int32_t* labels, int32_t B, int32_t Bp, int32_t pos_only,
+                          float* loss_part, uint32_t* npos_part, float* G, uint32_t* role_cnt,
+                          void* stream);
+
+/* K7: batch_hard online miner (triplet_loss_utils.py:202-259) incl. its quirks.
+ *   dist_a = max(hn_a - hp_a, 0); cnt_a = dist_a > 0;
+ *   loss_part[a] = softplus(dist_a)*cnt_a;  cnt_part[a] = cnt_a;
+ *   dw[j] += cnt_a*([D[a,j]==hp_a] + [D[a,j]==hn_a] + [j==a])     (int32 atomics; zeroed here)
+ *   G[a,:] = d(sum_a softplus(dist_a) cnt_a)/dD[a,:]  (un-normalised; ties split equally) */
+int dae_triplet_batch_hard(const float* D_slabs, int32_t d_splits, int64_t slab_stride, int64_t ldd,
+                           const int32_t* labels, int32_t B, int32_t Bp,
+                           float* loss_part, uint32_t* cnt_part, int32_t* dw, float* G, void* stream);
+
+/* Reduce miner partials into the normalisers / statistics:
+ *   tri_scalars[0] = alpha / (N + 1e-16)  (N = N_valid | N_pos | sum cnt) -> scale of (G+G^T)
+ *   tri_scalars[1] = triplet loss, [2] = fraction, [3] = num
+ * For batch_hard (and pos_only) also converts the integer data_weight into dw_f32_out and cw. */
+int dae_triplet_finalize(int32_t triplet, int32_t pos_only, int32_t B, int32_t Bp, float alpha,
+                         const float* loss_part, const uint32_t* cnt_part, const int64_t* nvalid,
+                         const int32_t* dw_i32, const uint32_t* role_cnt, float* dw_f32_out,
+                         float* cw, float* tri_scalars, void* stream);
+
+/* Gs = tri_scalars[0] * (G + G^T) on [0,B)^2 (zero elsewhere) in `dtype` [Bp x Bp] -- the A operand
+ * of the triplet term of dL/dh = delta2 W + alpha (G + G^T) h (autodiff of triplet_loss_utils.py:93). */
+int dae_sym_scale(const float* G, int32_t B, int32_t Bp, const float* tri_scalars, int32_t dtype,
+                  void* Gs, void* stream);
+
+/* K8 (middle): dh = sum_s slab_s (+ dh_extra);  delta1 = dh * act'(z1);  delta1^T in `dtype`
+ * [Hp x ldt]; partial column sums for db_h = sum_i delta1 - act'(bh) * sum_i dh (the -act(bh) term
+ * of autoencoder.py:389).  colsum_part: [2 x (Bp/64) x Hp].  delta1_f32 optional [Bp x ldh]. */
+int dae_dh_finish(const float* slabs, int32_t splits, int64_t slab_stride, int64_t ld_slab,
+                  const float* dh_extra, const float* h_f32, int64_t ldh, const float* bh,
+                  int32_t B, int32_t H, int32_t enc_act, int32_t dtype, void* delta1_t, int64_t ldt,
+                  float* colsum_part, float* delta1_f32, void* stream);
+
+/* Reduce the bias-gradient partials into the flat gradient buffer [dW | dbh | dbv]. */
+int dae_bias_grads(const float* dbv_part, int32_t n_row_waves, const float* colsum_part, int32_t n_row_blocks,
+                   const float* bh, int32_t H, int32_t Hp, int32_t F, int32_t Fp, int32_t enc_act,
+                   float* dbh, float* dbv, void* stream);
+
+/* K9: optimizer step on the padded flat parameter vector [W (Fp*Hp) | bh (Hp) | bv (Fp)] (grad, s1,
+ * s2 share that layout), refreshing the low-precision shadows W_lo [Fp x Hp] and W^T_lo [Hp x Fp]
+ * (autoencoder.py:444-477; tf.train.* semantics: Adagrad accumulator starts at 0.1, Momentum without
+ * Nesterov, Adam with lr = lr_t precomputed by the caller).  grad_scale multiplies the gradient first
+ * (1/world_size for data parallel).  apply = 0 only refreshes the shadows. */
+int dae_opt_step(int32_t opt, float lr, float momentum, float grad_scale,
+                 float* W, float* bh, float* bv, const float* grad, float* s1, float* s2,
+                 int32_t Fp, int32_t Hp, int32_t dtype, void* W_lo, void* Wt_lo, int32_t apply, void* stream);
+
+/* Final per-step statistics (autoencoder.py:233 fetch list):
+ * ae = sum_i cw_i * rowloss_i; cost = ae + alpha * triplet.  stats: float[DAE_STATS_STRIDE]. */
+int dae_step_stats(const float* rowloss_part, int32_t n_col_waves, const float* cw, int32_t B, int32_t Bp,
+                   int32_t triplet, float alpha, const float* tri_scalars, const int64_t* nvalid,
+                   float* stats, void* stream);
+
+/* Explicit (anchor,pos,neg) triplet term of DenoisingAutoencoderTriplet
+ * (autoencoder_triplet.py:308-311): t_i = h_i.hneg_i - h_i.hpos_i; loss = mean softplus(t).
+ * h3 = [org; pos; neg] stacked compactly (3*B rows, stride ldh); writes alpha * dloss/dh3 into dh3
+ * (same layout), loss_part[B] and tri_scalars[1] = loss. */
+int dae_explicit_triplet(const float* h3, int64_t ldh, int32_t B, int32_t H, float alpha,
+                         float* dh3, float* loss_part, float* tri_scalars, void* stream);
+
+/* A/B switch for the GEMM staging path: 1 = global_load_lds (default), 0 = register staging. */
+void dae_set_glds(int32_t on);
+
+/* ---------------------------------------------------------------------------------------------
+ * Whole-step driver: what DenoisingAutoencoder._run_train_step (autoencoder.py:206-246) does per
+ * mini-batch, as one host call that enqueues every kernel above on `stream`.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct dae_plan dae_plan;
+
+typedef struct {
+    int32_t n_features, n_components, max_batch;
+    int32_t dtype, enc_act, dec_act, loss_func, opt, triplet;
+    int32_t pos_triplets_only;
+    int32_t encode_splits, dh_splits, gram_splits;   /* 0 = pick automatically */
+    float   learning_rate, momentum, alpha;
+} dae_config;
+
+typedef struct {
+    /* train set, CSR (sorted column ids) or dense fp32; exactly one of indptr / dense non-NULL */
+    const int64_t* indptr; const int32_t* indices; const float* values;
+    const float* dense; int64_t ld_dense;
+    int64_t n_rows, nnz;
+    /* parameters, padded: W [Fp x Hp], bh [Hp], bv [Fp]; flat gradient [Fp*Hp + Hp + Fp];
+     * optimizer slots (same length as the gradient; may be NULL for SGD) */
+    float* W; float* bh; float* bv; float* grad; float* opt_s1; float* opt_s2;
+    /* low-precision shadows W_lo [Fp x Hp], Wt_lo [Hp x Fp] in cfg.dtype */
+    void* W_lo; void* Wt_lo;
+    void* workspace; uint64_t workspace_bytes;
+} dae_buffers;
+
+typedef struct {
+    const int32_t* row_idx;      /* device int32[B]: rows of the train set in this batch */
+    const int32_t* labels;       /* device int32[B] (NULL for triplet none) */
+    int32_t B;
+    int32_t corr_mode; const uint32_t* keep_bits; uint64_t seed; uint32_t rng_stream;
+    float corr_frac, scale;
+    /* optional second CSR holding an already-corrupted copy of the train set (salt&pepper etc.) */
+    const int64_t* c_indptr; const int32_t* c_indices; const float* c_values;
+    float* stats;                /* device float[DAE_STATS_STRIDE] for this step */
+    int32_t phase;               /* 0 = forward+backward+update, 1 = forward+backward only (DP:
+                                    caller all-reduces `grad` then calls dae_plan_apply), 2 = forward only */
+    int32_t adam_t; float grad_scale;
+} dae_step;
+
+int      dae_plan_create(const dae_config* cfg, dae_plan** out);
+void     dae_plan_destroy(dae_plan* p);
+uint64_t dae_plan_workspace_bytes(const dae_plan* p);
+int      dae_plan_bind(dae_plan* p, const dae_buffers* bufs);
+/* refresh W_lo / Wt_lo from W (after set_params / checkpoint restore) */
+int      dae_plan_sync_shadows(dae_plan* p, void* stream);
+int      dae_train_step(dae_plan* p, const dae_step* step, void* stream);
+int      dae_plan_apply(dae_plan* p, int32_t adam_t, float grad_scale, void* stream);
+/* transform(): out[B x H] fp32 (ld_out) = encode of rows row_idx (autoencoder.py:479-505) */
+int      dae_encode_rows(dae_plan* p, const int32_t* row_idx, int32_t B, float scale,
+                         const int64_t* indptr, const int32_t* indices, const float* values,
+                         const float* dense, int64_t ld_dense, float* out, int64_t ld_out, void* stream);
+/* pointers into the workspace for tests / debugging (NULL if name unknown) */
+void*    dae_plan_buffer(dae_plan* p, const char* name);
+/* out8 = {Fp, Hp, Bp_max, encode_splits, dh_splits, gram_splits, element_size, 0} */
+int      dae_plan_info(const dae_plan* p, int32_t* out8);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DAE_HIP_H */

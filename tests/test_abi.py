@@ -1,0 +1,95 @@
+"""CPU checks of the drop-in boundary: libdae_hip.so loads without a GPU, exports every symbol that
+include/dae_hip.h declares, and the ctypes table in _lib.py covers exactly that set."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "dae_hip.h")
+
+
+def _declared():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return set(re.findall(r"\b(dae_[a-z0-9_]+)\s*\(", src))
+
+
+def test_library_exports_every_declared_symbol():
+    from dae_rnn_news_recommendation_amd import _lib
+    lib = _lib.load()
+    names = _declared()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in dae_hip.h but not exported by libdae_hip.so"
+    assert names == set(_lib.SIGNATURES), names ^ set(_lib.SIGNATURES)
+    assert lib.dae_abi_version() == 1
+    assert lib.dae_pad(800) == 896 and lib.dae_pad(10000) == 10112 and lib.dae_pad(128) == 128
+
+
+def test_ctypes_arity_matches_header():
+    from dae_rnn_news_recommendation_amd import _lib
+    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    for name, (_, args) in _lib.SIGNATURES.items():
+        m = re.search(r"\b" + name + r"\s*\(([^;]*?)\)\s*;", src, flags=re.S)
+        assert m, name
+        params = m.group(1).strip()
+        n = 0 if params in ("", "void") else params.count(",") + 1
+        assert n == len(args), (name, n, len(args))
+
+
+def test_struct_sizes_match_c():
+    """sizeof() of the three ABI structs as the C compiler lays them out == ctypes' layout."""
+    from dae_rnn_news_recommendation_amd import _lib
+    prog = r'''
+#include <stdio.h>
+#include "dae_hip.h"
+int main(void){ printf("%zu %zu %zu\n", sizeof(dae_config), sizeof(dae_buffers), sizeof(dae_step)); return 0; }
+'''
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "s.c"); exe = os.path.join(d, "s")
+        open(c, "w").write(prog)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
+        sizes = [int(v) for v in subprocess.check_output([exe]).split()]
+    assert sizes == [ctypes.sizeof(_lib.dae_config), ctypes.sizeof(_lib.dae_buffers), ctypes.sizeof(_lib.dae_step)]
+
+
+def test_argument_errors_are_reported_without_a_gpu():
+    from dae_rnn_news_recommendation_amd import _lib
+    lib = _lib.load()
+    cfg = _lib.dae_config(); cfg.n_features = 0
+    plan = ctypes.c_void_p()
+    assert lib.dae_plan_create(ctypes.byref(cfg), ctypes.byref(plan)) != 0
+    assert b"plan_create" in lib.dae_last_error()
+    cfg = _lib.dae_config(10000, 500, 800, 0, 1, 1, 0, 0, 1, 0, 0, 0, 0, 0.1, 0.5, 1.0)
+    assert lib.dae_plan_create(ctypes.byref(cfg), ctypes.byref(plan)) == 0
+    assert lib.dae_plan_workspace_bytes(plan) > 100 << 20
+    info = (ctypes.c_int32 * 8)()
+    assert lib.dae_plan_info(plan, info) == 0 and list(info)[:3] == [10112, 512, 896]
+    lib.dae_plan_destroy(plan)
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under the product package (or the CLI) may import it."""
+    bad = []
+    for base, _, files in os.walk(os.path.join(ROOT, "dae_rnn_news_recommendation_amd")):
+        for f in files:
+            if f.endswith(".py") and re.search(r"^\s*(from|import)\s+oracle\b", open(os.path.join(base, f)).read(), flags=re.M):
+                bad.append(f)
+    for f in ("main_autoencoder.py", "main_autoencoder_triplet.py"):
+        pth = os.path.join(ROOT, f)
+        if os.path.exists(pth) and re.search(r"^\s*(from|import)\s+oracle\b", open(pth).read(), flags=re.M):
+            bad.append(f)
+    assert not bad, bad
+
+
+def test_engine_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from dae_rnn_news_recommendation_amd.engine import Engine
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        Engine(100, 10, 16)

@@ -1,0 +1,227 @@
+"""GPU parity tests of the whole training step (dae_train_step through the C ABI) vs the CPU oracle:
+statistics, gradients and updated parameters on identical seeded inputs, injected W0 and the
+reference's own (host-generated) masking decisions."""
+import numpy as np
+import pytest
+import torch
+from scipy import sparse
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(rng, N, F, binary, density=0.05):
+    m = sparse.random(N, F, density=density, random_state=np.random.RandomState(int(rng.integers(1 << 30))),
+                      format="csr", dtype=np.float32)
+    m.data = np.ones_like(m.data) if binary else (m.data * 0.9 + 0.1).astype(np.float32)
+    m.sort_indices()
+    return m
+
+
+def _keep_bits(keep):
+    bits = np.packbits(keep, bitorder="little")
+    bits = np.concatenate([bits, np.zeros((-len(bits)) % 4, np.uint8)]).view(np.int32)
+    return torch.from_numpy(bits.copy()).cuda()
+
+
+def _run_case(dtype, strategy, loss_func, acts, opt, *, N=400, F=700, H=90, B=150, steps=2, seed=0, dense=False,
+              alpha=0.7, tol=None):
+    from dae_rnn_news_recommendation_amd import _lib as L
+    from dae_rnn_news_recommendation_amd.engine import Engine
+    rng = np.random.default_rng(seed)
+    binary = loss_func == "cross_entropy"
+    m = _mk(rng, N, F, binary)
+    lab = rng.integers(0, 4, N)
+    W0 = rng.uniform(-0.3, 0.3, (F, H)).astype(np.float32)
+    bh0 = (rng.standard_normal(H) * 0.1).astype(np.float32); bv0 = (rng.standard_normal(F) * 0.1).astype(np.float32)
+    if dtype == "bf16":
+        W0 = torch.as_tensor(W0).to(torch.bfloat16).float().numpy()     # start from bf16-representable weights
+    eng = Engine(F, H, B, dtype=dtype, enc_act=acts[0], dec_act=acts[1], loss_func=loss_func, opt=opt,
+                 learning_rate=0.05, momentum=0.5, alpha=alpha, triplet=strategy)
+    if dense:
+        eng.upload_dense(m.toarray())
+    else:
+        eng.upload_csr(m)
+    eng.set_params(W0, bh0, bv0)
+    W, bh, bv = W0.astype(np.float64), bh0.astype(np.float64), bv0.astype(np.float64)
+    st = O.OptState(opt, [W.shape, bh.shape, bv.shape], np.float64)
+    stats = torch.zeros((steps, 8), dtype=torch.float32, device="cuda")
+    out = []
+    for s in range(steps):
+        idx = rng.permutation(N)[:B]
+        if dense:
+            keep_d = rng.random((N, F)) >= 0.3
+            xc_all = m.toarray() * keep_d
+            bits = _keep_bits(keep_d.ravel())
+        else:
+            keep = rng.random(m.nnz) >= 0.3
+            mc = m.copy(); mc.data = mc.data * keep
+            xc_all = mc
+            bits = _keep_bits(keep)
+        labels = torch.from_numpy(lab[idx].astype(np.int32)).cuda() if strategy != "none" else None
+        eng.train_step(torch.from_numpy(idx.astype(np.int32)).cuda(), labels, stats[s], corr_mode=L.CORR_KEEPBITS,
+                       keep_bits=bits, phase=0)
+        torch.cuda.synchronize()
+        xb = m[idx].toarray(); xcb = xc_all[idx] if dense else xc_all[idx].toarray()
+        r = O.forward_backward(W, bh, bv, xb, xcb, lab[idx], enc_act=acts[0], dec_act=acts[1], loss_func=loss_func,
+                               triplet_strategy=strategy, alpha=alpha, dt=np.float64)
+        dWg, dbhg, dbvg = eng.grads()
+        out.append((r, stats[s].cpu().numpy(), dWg, dbhg, dbvg))
+        O.opt_apply(st, [W, bh, bv], [r["dW"], r["dbh"], r["dbv"]], 0.05, 0.5, np.float64)
+    Wg, bhg, bvg = eng.get_params()
+    return out, (W, bh, bv), (Wg, bhg, bvg)
+
+
+def _rel(a, b):
+    return float(np.max(np.abs(np.asarray(a, np.float64) - b)) / (np.max(np.abs(b)) + 1e-30))
+
+
+@pytest.mark.parametrize("strategy", ["none", "batch_all", "batch_hard"])
+@pytest.mark.parametrize("loss_func,acts", [("cross_entropy", ("sigmoid", "sigmoid")), ("mean_squared", ("tanh", "none")),
+                                            ("cosine_proximity", ("sigmoid", "sigmoid"))])
+def test_step_fp32_matches_oracle(strategy, loss_func, acts):
+    out, ref, got = _run_case("fp32", strategy, loss_func, acts, "gradient_descent")
+    for r, st, dW, dbh, dbv in out:
+        assert abs(st[0] - r["cost"]) <= 2e-5 * abs(r["cost"]), (st, r["cost"])
+        assert abs(st[1] - r["ae_loss"]) <= 2e-5 * abs(r["ae_loss"])
+        if strategy != "none":
+            assert abs(st[2] - r["triplet_loss"]) <= 2e-5 * abs(r["triplet_loss"]) + 1e-9
+            assert abs(st[4] - r["num"]) <= 3          # fp32 vs fp64 Gram: a near-tie may flip (exactness on the
+            assert abs(st[3] - r["fraction"]) <= 1e-4  # SAME D is asserted in test_hip_kernels.py)
+        assert _rel(dW, r["dW"]) < 5e-5, _rel(dW, r["dW"])
+        assert _rel(dbh, r["dbh"]) < 5e-5 and _rel(dbv, r["dbv"]) < 5e-5
+    for a, b in zip(got, ref):
+        assert _rel(a, b) < 1e-5
+
+
+@pytest.mark.parametrize("strategy", ["none", "batch_all", "batch_hard"])
+def test_step_bf16_matches_oracle(strategy):
+    """bf16 MFMA operands, fp32 accumulate: loss within the 1e-4 relative gate, gradients ~1e-2."""
+    out, ref, got = _run_case("bf16", strategy, "cross_entropy", ("sigmoid", "sigmoid"), "gradient_descent", steps=1)
+    r, st, dW, dbh, dbv = out[0]
+    assert abs(st[1] - r["ae_loss"]) <= 1e-4 * abs(r["ae_loss"]), (st[1], r["ae_loss"])
+    if strategy == "batch_all":
+        assert abs(st[2] - r["triplet_loss"]) <= 1e-4 * abs(r["triplet_loss"])
+        assert abs(st[4] - r["num"]) <= 2e-3 * r["num"]                 # near-tie flips from bf16 rounding of h
+    assert abs(st[0] - r["cost"]) <= 2e-4 * abs(r["cost"])
+    assert _rel(dW, r["dW"]) < 2e-2 and _rel(dbh, r["dbh"]) < 2e-2 and _rel(dbv, r["dbv"]) < 2e-2
+
+
+@pytest.mark.parametrize("opt", ["ada_grad", "momentum", "adam"])
+def test_step_optimizers(opt):
+    out, ref, got = _run_case("fp32", "batch_all", "cross_entropy", ("sigmoid", "sigmoid"), opt, steps=3)
+    for a, b in zip(got, ref):
+        assert _rel(a, b) < 5e-5, (opt, _rel(a, b))
+
+
+def test_step_dense_input_matches_oracle():
+    out, ref, got = _run_case("fp32", "batch_all", "mean_squared", ("sigmoid", "sigmoid"), "gradient_descent", dense=True,
+                              N=200, F=300, H=60, B=100)
+    for r, st, dW, dbh, dbv in out:
+        assert abs(st[0] - r["cost"]) <= 2e-5 * abs(r["cost"])
+        assert _rel(dW, r["dW"]) < 5e-5
+    for a, b in zip(got, ref):
+        assert _rel(a, b) < 1e-5
+
+
+def test_step_short_last_batch_and_pad_invariants():
+    """A short batch after a full one: stale rows of the workspace must not leak (padding stays zero)."""
+    from dae_rnn_news_recommendation_amd import _lib as L
+    from dae_rnn_news_recommendation_amd.engine import Engine
+    rng = np.random.default_rng(3)
+    N, F, H, B = 300, 260, 70, 200
+    m = _mk(rng, N, F, True); lab = rng.integers(0, 3, N)
+    W0 = rng.uniform(-0.3, 0.3, (F, H)).astype(np.float32)
+    eng = Engine(F, H, B, dtype="fp32", triplet="batch_all", learning_rate=0.05)
+    eng.upload_csr(m); eng.set_params(W0)
+    stats = torch.zeros((2, 8), device="cuda")
+    W = W0.astype(np.float64); bh = np.zeros(H); bv = np.zeros(F)
+    st = O.OptState("gradient_descent", [W.shape, bh.shape, bv.shape], np.float64)
+    for s, nb in enumerate([200, 37]):
+        idx = rng.permutation(N)[:nb]
+        eng.train_step(torch.from_numpy(idx.astype(np.int32)).cuda(), torch.from_numpy(lab[idx].astype(np.int32)).cuda(),
+                       stats[s])
+        r = O.forward_backward(W, bh, bv, m[idx].toarray(), m[idx].toarray(), lab[idx], triplet_strategy="batch_all",
+                               dt=np.float64)
+        assert abs(stats[s, 0].item() - r["cost"]) <= 2e-5 * abs(r["cost"])
+        dW, dbh, dbv = eng.grads()
+        assert _rel(dW, r["dW"]) < 5e-5
+        O.opt_apply(st, [W, bh, bv], [r["dW"], r["dbh"], r["dbv"]], 0.05, 0.5, np.float64)
+    assert (eng.W[F:].abs().sum() == 0) and (eng.W[:, H:].abs().sum() == 0)          # padding exactly zero
+    assert (eng.Wt_lo[H:].abs().sum() == 0) and (eng.Wt_lo[:, F:].abs().sum() == 0)
+
+
+def test_explicit_triplet_step_matches_oracle():
+    from dae_rnn_news_recommendation_amd import _lib as L
+    from dae_rnn_news_recommendation_amd.engine import Engine
+    rng = np.random.default_rng(4)
+    N, F, H, Bt = 120, 300, 60, 50
+    ms = [_mk(rng, N, F, False) for _ in range(3)]
+    stacked = sparse.vstack(ms).tocsr()
+    W0 = rng.uniform(-0.3, 0.3, (F, H)).astype(np.float32)
+    eng = Engine(F, H, 3 * Bt, dtype="fp32", loss_func="cosine_proximity", triplet="explicit", alpha=2.0, learning_rate=0.05)
+    eng.upload_csr(stacked); eng.set_params(W0)
+    idx = rng.permutation(N)[:Bt]
+    rows = np.concatenate([idx, N + idx, 2 * N + idx]).astype(np.int32)
+    stats = torch.zeros(8, device="cuda")
+    eng.train_step(torch.from_numpy(rows).cuda(), None, stats, phase=1)
+    xs = [mm[idx].toarray() for mm in ms]
+    r = O.explicit_triplet_forward_backward(W0, np.zeros(H), np.zeros(F), xs, xs, loss_func="cosine_proximity", alpha=2.0,
+                                            dt=np.float64)
+    st = stats.cpu().numpy()
+    assert abs(st[0] - r["cost"]) <= 2e-5 * abs(r["cost"]), (st, r["cost"], r["ae_loss"], r["triplet_loss"])
+    assert abs(st[2] - r["triplet_loss"]) <= 2e-5 * abs(r["triplet_loss"])
+    dW, dbh, dbv = eng.grads()
+    assert _rel(dW, r["dW"]) < 5e-5 and _rel(dbh, r["dbh"]) < 5e-5 and _rel(dbv, r["dbv"]) < 5e-5
+
+
+def test_encode_rows_matches_oracle():
+    from dae_rnn_news_recommendation_amd.engine import Engine
+    rng = np.random.default_rng(5)
+    N, F, H = 333, 500, 77
+    m = _mk(rng, N, F, False)
+    W0 = rng.uniform(-0.3, 0.3, (F, H)).astype(np.float32); bh0 = (rng.standard_normal(H) * 0.1).astype(np.float32)
+    eng = Engine(F, H, 128, dtype="fp32")
+    eng.upload_csr(m); eng.set_params(W0, bh0)
+    out = torch.zeros((N, H), device="cuda")
+    for i0 in range(0, N, 128):
+        idx = torch.arange(i0, min(N, i0 + 128), dtype=torch.int32, device="cuda")
+        eng.encode_rows(idx, out[i0:i0 + idx.numel()], scale=0.7)
+    want, _ = O.encode(m.toarray() * 0.7, W0, bh0, "sigmoid", np.float64)
+    assert _rel(out.cpu().numpy(), want) < 1e-5
+
+
+@pytest.mark.parametrize("dtype,strategy", [("fp32", "batch_all"), ("bf16", "batch_all"), ("bf16", "batch_hard")])
+def test_full_size_step_config2(dtype, strategy):
+    """BASELINE config 2 shapes (B=800, F=10000, H=500) for one step against the fp32 oracle."""
+    from dae_rnn_news_recommendation_amd import _lib as L
+    from dae_rnn_news_recommendation_amd.engine import Engine
+    from dae_rnn_news_recommendation_amd.synthetic import synthetic_csr, synthetic_labels, xavier_uniform
+    N, F, H, B = 1600, 10000, 500, 800
+    m = synthetic_csr(N, F, nnz_per_row=200, seed=7)
+    lab = synthetic_labels(N, seed=7)
+    W0 = xavier_uniform(F, H, seed=42)
+    rng = np.random.default_rng(0)
+    keep = rng.random(m.nnz) >= 0.3
+    mc = m.copy(); mc.data = mc.data * keep
+    idx = rng.permutation(N)[:B]
+    eng = Engine(F, H, B, dtype=dtype, triplet=strategy, learning_rate=0.1, alpha=1.0)
+    eng.upload_csr(m); eng.set_params(W0)
+    stats = torch.zeros(8, device="cuda")
+    eng.train_step(torch.from_numpy(idx.astype(np.int32)).cuda(), torch.from_numpy(lab[idx].astype(np.int32)).cuda(), stats,
+                   corr_mode=L.CORR_KEEPBITS, keep_bits=_keep_bits(keep), phase=1)
+    st = stats.cpu().numpy()
+    r = O.forward_backward(W0, np.zeros(H, np.float32), np.zeros(F, np.float32), m[idx].toarray(), mc[idx].toarray(),
+                           lab[idx], triplet_strategy=strategy, alpha=1.0, dt=np.float32)
+    tol = 2e-5 if dtype == "fp32" else 1e-4
+    assert abs(st[1] - r["ae_loss"]) <= tol * abs(r["ae_loss"]), (st, r["ae_loss"])
+    assert abs(st[2] - r["triplet_loss"]) <= tol * abs(r["triplet_loss"]) + 1e-9, (st, r["triplet_loss"])
+    assert abs(st[0] - r["cost"]) <= tol * abs(r["cost"])
+    nv, dwc = O.batch_all_closed_form(lab[idx])
+    if strategy == "batch_all":
+        assert st[5] == np.float32(nv)                                   # N_valid: exact integer
+        assert abs(st[4] - r["num"]) <= (1e-5 if dtype == "fp32" else 2e-3) * r["num"] + 64
+    dW, dbh, dbv = eng.grads()
+    gt = 1e-4 if dtype == "fp32" else 3e-2
+    assert _rel(dW, r["dW"]) < gt and _rel(dbh, r["dbh"]) < gt and _rel(dbv, r["dbv"]) < gt
