@@ -74,6 +74,7 @@ SIGNATURES = {
     "dae_bias_grads": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp]),
     "dae_opt_step": (i32, [i32, f32, f32, f32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, i32, vp]),
     "dae_step_stats": (i32, [vp, i32, vp, i32, i32, i32, f32, vp, vp, vp, vp]),
+    "dae_weighted_loss_rows": (i32, [vp, i64, vp, i64, i32, i32, i32, vp, vp]),
     "dae_explicit_triplet": (i32, [vp, i64, i32, i32, f32, vp, vp, vp, vp]),
     "dae_plan_create": (i32, [C.POINTER(dae_config), C.POINTER(vp)]),
     "dae_plan_destroy": (None, [vp]),
@@ -85,6 +86,10 @@ SIGNATURES = {
     "dae_encode_rows": (i32, [vp, vp, i32, f32, vp, vp, vp, vp, i64, vp, i64, vp]),
     "dae_plan_buffer": (vp, [vp, C.c_char_p]),
     "dae_plan_info": (i32, [vp, vp]),
+    "dae_plan_profile": (i32, [vp, i32]),
+    "dae_plan_profile_read": (i32, [vp, i32, vp, vp]),
+    "dae_plan_profile_slots": (i32, []),
+    "dae_plan_profile_name": (C.c_char_p, [i32]),
 }
 
 _lib = None

@@ -1,0 +1,401 @@
+"""``DenoisingAutoencoder`` -- drop-in for the reference estimator (``autoencoder/autoencoder.py:14``)
+with the training step running as gfx950 HIP kernels (libdae_hip) instead of a TF1 graph.
+
+Kept from the reference: constructor keywords and defaults (:20-23), ``fit`` / ``transform`` /
+``load_model`` / ``get_model_parameters`` signatures, the ``results/<algo>/<main_dir>/{models,data,logs,
+data/tsv,data/plot}/`` layout and the attributes the CLI reads, ``parameter.txt``, the per-epoch stdout
+line (:283-294), the per-epoch order of host RNG draws (corrupt the whole set, then shuffle; :218-220)
+and variable names of the checkpoint (``enc-w``, ``hidden-bias``, ``visible-bias``; :365-367).
+
+New (keyword-only, all optional):
+  precision   'bf16' (MFMA bf16 operands, fp32 accumulate/master weights) or 'fp32' (exact-fp32 MFMA)
+  rng         'numpy'  -- reference-exact legacy-RandomState stream: keep decisions are drawn on the host
+                          and shipped as one bit per stored entry per epoch;
+              'philox' -- counter-based masking generated on the device (statistically equivalent,
+                          no host RNG in the epoch loop)
+  init_weights  (W0[, bh0, bv0]) injected instead of the Xavier draw (tf.random_uniform is not reproducible)
+  data_parallel  True -> shard every mini-batch over torch.distributed ranks (RCCL all-reduce of the flat
+                 gradient), see dae_rnn_news_recommendation_amd/dp.py
+"""
+from __future__ import annotations
+
+import os
+import time
+
+import numpy as np
+from scipy import sparse
+
+from . import utils
+from .. import _lib as L
+
+__all__ = ["DenoisingAutoencoder"]
+
+
+class DenoisingAutoencoder(object):
+    """Denoising autoencoder with tied weights, h = f(W x~ + b) - f(b), optional online triplet mining.
+    The interface is sklearn-like (reference autoencoder.py:14-18)."""
+
+    _STRATEGIES = ['batch_all', 'batch_hard', 'none']
+
+    def __init__(self, algo_name='dae', model_name='dae', compress_factor=10, main_dir='dae/', enc_act_func='tanh',
+                 dec_act_func='none', loss_func='mean_squared', num_epochs=10, batch_size=10,
+                 xavier_init=1, opt='gradient_descent', learning_rate=0.01, momentum=0.5, corr_type='none',
+                 corr_frac=0., verbose=True, verbose_step=5, seed=-1, alpha=1, triplet_strategy='batch_all',
+                 *, precision='bf16', rng='numpy', init_weights=None, device=None, data_parallel=False,
+                 results_root='results/'):
+        self.algo_name = algo_name
+        self.model_name = model_name
+        self.compress_factor = compress_factor
+        self.main_dir = main_dir
+        self.enc_act_func = enc_act_func
+        self.dec_act_func = dec_act_func
+        self.loss_func = loss_func
+        self.num_epochs = num_epochs
+        self.batch_size = batch_size
+        self.xavier_init = xavier_init
+        self.opt = opt
+        self.learning_rate = learning_rate
+        self.momentum = momentum
+        self.corr_type = corr_type
+        self.corr_frac = corr_frac
+        self.verbose = verbose
+        self.verbose_step = verbose_step
+        self.seed = seed
+        self.alpha = alpha
+        self.triplet_strategy = triplet_strategy
+        self.precision = precision
+        self.rng = rng
+        self.init_weights = init_weights
+        self.device = device
+        self.data_parallel = data_parallel
+        self.results_root = results_root
+
+        assert type(self.verbose_step) == int                      # reference :68
+        assert self.verbose >= 0
+        assert self.triplet_strategy in self._STRATEGIES           # reference :70
+        assert self.precision in ('bf16', 'fp32')
+        assert self.rng in ('numpy', 'philox')
+
+        if self.seed >= 0:
+            np.random.seed(self.seed)                              # reference :72-73 (the TF seed has no analogue)
+
+        self.models_dir, self.data_dir, self.tf_summary_dir, self.tsv_dir, self.plot_dir = self._create_data_directories()
+        self.model_path = self.models_dir + self.model_name
+        self.parameter_file = self.tf_summary_dir + 'parameter.txt'
+
+        self.sparse_input = None
+        self.n_components = None
+        self.engine = None
+        self.history = []            # per verbose epoch: dict of the means the reference prints
+        self.train_time = 0.0
+        self.samples_per_sec = None
+
+    # ------------------------------------------------------------------ bookkeeping (reference :101-124, :544-564)
+    def _create_data_directories(self):
+        algo = self.algo_name if self.algo_name[-1] == '/' else self.algo_name + '/'
+        main = self.main_dir if self.main_dir[-1] == '/' else self.main_dir + '/'
+        self.main_dir = algo + main
+        root = self.results_root + self.main_dir
+        dirs = [root + 'models/', root + 'data/', root + 'logs/', root + 'data/tsv/', root + 'data/plot/']
+        for d in dirs:
+            os.makedirs(d, exist_ok=True)
+        return tuple(dirs)
+
+    _PARAM_KEYS = ['algo_name', 'model_name', 'compress_factor', 'main_dir', 'enc_act_func', 'dec_act_func', 'loss_func',
+                   'num_epochs', 'batch_size', 'xavier_init', 'opt', 'learning_rate', 'momentum', 'corr_type',
+                   'corr_frac', 'verbose', 'verbose_step', 'seed', 'alpha', 'triplet_strategy']
+
+    def _write_parameter_to_file(self, restore):
+        with open(self.parameter_file, 'a+' if restore else 'w') as fh:
+            print('---------------------------------------', file=fh)
+            for k in self._PARAM_KEYS:
+                print('{}={}'.format(k, getattr(self, k)), file=fh)
+            print('precision={}'.format(self.precision), file=fh)
+            print('rng={}'.format(self.rng), file=fh)
+
+    # ------------------------------------------------------------------ model construction
+    def _strategy_key(self):
+        return self.triplet_strategy
+
+    def _resolve_batch(self, n_rows):
+        bs = self.batch_size
+        if bs < 1.:
+            bs = max(round(n_rows * bs), 1)                         # reference utils.py:47
+        return int(bs)
+
+    def _build_engine(self, n_features, max_batch):
+        from ..engine import Engine                                # raises loudly without a GPU / the library
+        if self.opt not in L.OPT:
+            raise ValueError("unknown optimizer %r (reference :444-475 silently builds no train step)" % (self.opt,))
+        act = lambda a: a if a in ('sigmoid', 'tanh') else 'none'
+        self.engine = Engine(n_features, self.n_components, max_batch,
+                             dtype=self.precision, enc_act=act(self.enc_act_func), dec_act=act(self.dec_act_func),
+                             loss_func=self.loss_func, opt=self.opt, learning_rate=self.learning_rate,
+                             momentum=self.momentum, alpha=float(self.alpha), triplet=self._strategy_key(),
+                             device=self.device)
+        return self.engine
+
+    def _initial_parameters(self, n_features):
+        if self.init_weights is not None:
+            iw = self.init_weights
+            W0 = iw[0] if isinstance(iw, (tuple, list)) else iw
+            bh0 = iw[1] if isinstance(iw, (tuple, list)) and len(iw) > 1 else None
+            bv0 = iw[2] if isinstance(iw, (tuple, list)) and len(iw) > 2 else None
+            assert np.shape(W0) == (n_features, self.n_components), (np.shape(W0), (n_features, self.n_components))
+            return W0, bh0, bv0
+        return utils.xavier_init(n_features, self.n_components, self.xavier_init), None, None   # reference :365-367
+
+    # ------------------------------------------------------------------ fit
+    def fit(self, train_set, validation_set=None, train_set_label=None, validation_set_label=None,
+            restore_previous_model=False):
+        """Fit the model to the data (reference :126-156).  ``train_set``: ndarray (dense path) or scipy
+        sparse matrix; labels are required iff ``triplet_strategy != 'none'``."""
+        if self.triplet_strategy != 'none':
+            assert train_set_label is not None
+        if train_set_label is not None:
+            assert train_set.shape[0] == len(train_set_label)
+        if validation_set is not None and validation_set_label is not None:
+            assert validation_set.shape[0] == len(validation_set_label)
+
+        n_features = train_set.shape[1]
+        self.sparse_input = not isinstance(train_set, np.ndarray)
+        self.n_components = int(np.floor(n_features / self.compress_factor))
+        batch = self._resolve_batch(train_set.shape[0])
+
+        world, rank = self._dist()
+        local_batch = -(-batch // world)
+        eng = self._build_engine(n_features, local_batch)
+        if self.sparse_input:
+            eng.upload_csr(train_set)
+        else:
+            eng.upload_dense(train_set)
+        W0, bh0, bv0 = self._initial_parameters(n_features)
+        if world > 1:
+            from .. import dp
+            W0 = dp.broadcast_array(np.asarray(W0, np.float32))
+        eng.set_params(W0, bh0, bv0)
+        if restore_previous_model:
+            self._restore(self.model_path)
+        self._write_parameter_to_file(restore_previous_model)
+
+        self._train_model(train_set, validation_set, train_set_label, validation_set_label)
+        self._save(self.model_path)
+        return None
+
+    def _dist(self):
+        if not self.data_parallel:
+            return 1, 0
+        from .. import dp
+        return dp.world_size(), dp.rank()
+
+    def _train_model(self, train_set, validation_set, train_set_label, validation_set_label):
+        """Epoch loop (reference :175-204)."""
+        import torch
+        eng = self.engine
+        N = train_set.shape[0]
+        batch = self._resolve_batch(N)
+        world, rank = self._dist()
+        label_ids = None
+        if train_set_label is not None:
+            from .triplet_loss_utils import _labels_to_ids
+            label_ids = _labels_to_ids(train_set_label)
+        n_batches = -(-N // batch)
+        self._stats = torch.zeros((max(self.num_epochs, 1), n_batches, L.STATS_STRIDE), dtype=torch.float32,
+                                  device=eng.device)
+        self._epoch_seconds = []
+        t_fit = time.time()
+        i = -1
+        for i in range(self.num_epochs):
+            t0 = time.time()
+            self._run_train_step(train_set, label_ids, i, batch, world, rank)
+            if (i + 1) % self.verbose_step == 0:
+                torch.cuda.synchronize()
+                self.train_time = time.time() - t0
+                self._run_validation_error_and_summaries(i + 1, validation_set, validation_set_label)
+            self._epoch_seconds.append(time.time() - t0)
+        else:
+            if self.num_epochs != 0 and (i + 1) % self.verbose_step != 0:
+                torch.cuda.synchronize()
+                self.train_time = self._epoch_seconds[-1]
+                self._run_validation_error_and_summaries(i + 1, validation_set, validation_set_label)
+        torch.cuda.synchronize()
+        wall = time.time() - t_fit
+        if self.num_epochs > 0 and wall > 0:
+            self.samples_per_sec = N * self.num_epochs / wall
+
+    def _corruption_plan(self, train_set, epoch):
+        """Per-epoch corruption, BEFORE the shuffle, like the reference (:218-220).  Returns the keyword
+        arguments of Engine.train_step that realise ``self.corr_type`` for this epoch."""
+        import torch
+        eng = self.engine
+        if self.corr_type == 'masking':
+            if self.rng == 'philox':
+                seed = self.seed if self.seed >= 0 else 0x5EED
+                return dict(corr_mode=L.CORR_PHILOX_MASK, seed=seed, rng_stream=epoch, corr_frac=float(self.corr_frac))
+            if self.sparse_input:
+                keep = utils.masking_keep(eng.csr["nnz"], self.corr_frac)            # np.random.rand(nnz) >= v
+            else:
+                keep = np.random.choice(a=[0, 1], size=train_set.shape, p=[self.corr_frac, 1 - self.corr_frac]).ravel() != 0
+            bits = torch.from_numpy(utils.pack_keep_bits(keep).view(np.int32)).to(eng.device, non_blocking=True)
+            self._keep_bits = bits                                                       # keep alive while steps run
+            return dict(corr_mode=L.CORR_KEEPBITS, keep_bits=bits)
+        if self.corr_type == 'decay':
+            return dict(scale=1.0 - float(self.corr_frac))
+        if self.corr_type == 'salt_and_pepper':
+            v = int(np.round(self.corr_frac * train_set.shape[1]))                       # reference :187
+            xc = utils.salt_and_pepper_noise(train_set, v)
+            from ..engine import Engine
+            self._corrupted = Engine.to_device_csr(sparse.csr_matrix(xc), eng.device)
+            return dict(corrupted_csr=self._corrupted)
+        if self.corr_type == 'none':
+            return dict()
+        raise ValueError("unknown corr_type %r (reference :268 returns None and fails later)" % (self.corr_type,))
+
+    def _run_train_step(self, train_set, label_ids, epoch, batch, world, rank):
+        """One epoch: corrupt, shuffle, then one fused device step per mini-batch (reference :206-246)."""
+        import torch
+        eng = self.engine
+        N = train_set.shape[0]
+        plan = self._corruption_plan(train_set, epoch)
+        order = utils.epoch_permutation(N)                              # np.random.shuffle, after the corruption draws
+        order_dev = torch.from_numpy(order.astype(np.int32)).to(eng.device, non_blocking=True)
+        labels_dev = None
+        if label_ids is not None:
+            labels_dev = torch.from_numpy(label_ids[order]).to(eng.device, non_blocking=True)
+        stats = self._stats[epoch]
+        for b, start in enumerate(range(0, N, batch)):
+            stop = min(N, start + batch)
+            if world > 1:                                               # contiguous shard of every global batch
+                from .. import dp
+                lo, hi = dp.shard_bounds(start, stop, world, rank)
+            else:
+                lo, hi = start, stop
+            rows = order_dev[lo:hi]
+            labs = None if labels_dev is None else labels_dev[lo:hi]
+            if world > 1:
+                if hi > lo:
+                    eng.train_step(rows, labs, stats[b], phase=1, **plan)
+                else:
+                    eng.grad.zero_()                                    # ragged tail: this rank has no rows
+                dp.allreduce_sum_(eng.grad)
+                eng.apply(grad_scale=1.0 / world)
+            else:
+                eng.train_step(rows, labs, stats[b], phase=0, **plan)
+
+    # ------------------------------------------------------------------ reporting (reference :272-320)
+    def epoch_stats(self, epoch):
+        """Means over the epoch's batches of (cost, ae, triplet, fraction, num) -- what :283-294 prints."""
+        s = self._stats[epoch - 1].cpu().numpy()
+        return dict(cost=float(s[:, L.STAT_COST].mean()), ae=float(s[:, L.STAT_AE].mean()),
+                    triplet=float(s[:, L.STAT_TRIPLET].mean()), fraction=float(s[:, L.STAT_FRACTION].mean()),
+                    num=float(s[:, L.STAT_NUM].mean()), per_batch=s)
+
+    def _run_validation_error_and_summaries(self, epoch, validation_set, validation_set_label):
+        st = self.epoch_stats(epoch)
+        rec = dict(epoch=epoch, seconds=self.train_time, **{k: st[k] for k in ('cost', 'ae', 'triplet', 'fraction', 'num')})
+        if self.verbose == 1:
+            print('At step %d (%.2f seconds): ' % (epoch, self.train_time), end='')
+            print('[Train Stat (average over past steps)] - ', end='')
+            if self.triplet_strategy != 'none':
+                print('Triplet: ', end='')
+                print('Fraction=%.4f\t' % st['fraction'], end='')
+                print('Number=%.2f\t' % st['num'], end='')
+            print('Cost: ', end='')
+            print('Overall=%.4f\t' % st['cost'], end='')
+            if self.triplet_strategy != 'none':
+                print('Autoencoder=%.4f\t' % st['ae'], end='')
+                print('Triplet=%.4f\t' % st['triplet'], end='')
+        if validation_set is None:
+            if self.verbose == 1:
+                print()
+            self.history.append(rec)
+            return
+        v = self._validation_forward(validation_set, validation_set_label)
+        rec.update(val_cost=v[L.STAT_COST], val_ae=v[L.STAT_AE], val_triplet=v[L.STAT_TRIPLET])
+        if self.verbose:
+            print("[Validation Stat (at this step)] - Cost: ")
+            print('Overall=%.4f' % v[L.STAT_COST], end='')
+            if self.triplet_strategy != 'none':
+                print('Autoencoder=%.4f\t' % v[L.STAT_AE], end='')
+                print('Triplet=%.4f\t' % v[L.STAT_TRIPLET], end='')
+            print()
+        self.history.append(rec)
+
+    def _validation_forward(self, validation_set, validation_set_label):
+        """Forward pass of the whole validation set as ONE batch, uncorrupted (reference :300-312)."""
+        import torch
+        from ..engine import Engine
+        from .triplet_loss_utils import _labels_to_ids
+        nv, F = validation_set.shape
+        if getattr(self, '_val_engine', None) is None or self._val_engine.Bmax < nv:
+            act = lambda a: a if a in ('sigmoid', 'tanh') else 'none'
+            self._val_engine = Engine(F, self.n_components, nv, dtype=self.precision, enc_act=act(self.enc_act_func),
+                                      dec_act=act(self.dec_act_func), loss_func=self.loss_func, opt='gradient_descent',
+                                      alpha=float(self.alpha), triplet=self._strategy_key(), device=self.device)
+            if isinstance(validation_set, np.ndarray):
+                self._val_engine.upload_dense(validation_set)
+            else:
+                self._val_engine.upload_csr(validation_set)
+        ve = self._val_engine
+        ve.set_params(*self.engine.get_params())
+        labels = None
+        if self.triplet_strategy != 'none':
+            labels = torch.from_numpy(_labels_to_ids(validation_set_label)).to(ve.device)
+        stats = torch.zeros(L.STATS_STRIDE, dtype=torch.float32, device=ve.device)
+        ve.train_step(torch.arange(nv, dtype=torch.int32, device=ve.device), labels, stats, phase=2)
+        return stats.cpu().numpy()
+
+    # ------------------------------------------------------------------ inference / persistence
+    def transform(self, data, name='train', save=False):
+        """Encode ``data`` with the trained model: act(x W + bh) - act(bh)  (reference :479-505).
+        Serves from the in-memory weights (the reference re-opens a session and restores the checkpoint)."""
+        import torch
+        from ..engine import Engine
+        assert self.engine is not None, "fit() or load_model() first"
+        eng = self.engine
+        n = data.shape[0]
+        dev = eng.device
+        out = torch.empty((n, eng.H), dtype=torch.float32, device=dev)
+        if isinstance(data, np.ndarray):
+            src = dict(dense=torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)).to(dev))
+        else:
+            src = dict(csr=Engine.to_device_csr(data, dev))
+        step = eng.Bmax
+        for i0 in range(0, n, step):
+            idx = torch.arange(i0, min(n, i0 + step), dtype=torch.int32, device=dev)
+            eng.encode_rows(idx, out[i0:i0 + idx.numel()], **src)
+        encoded = out.cpu().numpy()
+        if save:
+            np.save(self.data_dir + name, encoded)
+            np.save(self.data_dir + 'weights', eng.get_params()[0])
+        return encoded
+
+    def _save(self, path):
+        W, bh, bv = self.engine.get_params()
+        state = {'enc-w': W, 'hidden-bias': bh, 'visible-bias': bv, 'adam_t': np.int64(self.engine.adam_t)}
+        for k in ('s1', 's2'):
+            t = getattr(self.engine, k)
+            if t is not None:
+                state['opt-' + k] = t.cpu().numpy()
+        np.savez(path + '.npz', **state)
+
+    def _restore(self, path):
+        import torch
+        z = np.load(path if path.endswith('.npz') else path + '.npz')
+        self.engine.set_params(z['enc-w'], z['hidden-bias'], z['visible-bias'])
+        for k in ('s1', 's2'):
+            t = getattr(self.engine, k)
+            if t is not None and ('opt-' + k) in z and z['opt-' + k].shape == tuple(t.shape):
+                t.copy_(torch.from_numpy(z['opt-' + k]))
+        self.engine.adam_t = int(z['adam_t']) if 'adam_t' in z else 0
+
+    def load_model(self, shape, model_path):
+        """Restore a trained model: shape = (n_features, n_components)  (reference :507-527)."""
+        self.n_components = int(shape[1])
+        self._build_engine(int(shape[0]), self._resolve_batch(1024) if self.batch_size >= 1 else 1024)
+        self._restore(model_path)
+
+    def get_model_parameters(self):
+        """{'enc_w', 'enc_b', 'dec_b'} as NumPy arrays (reference :529-542)."""
+        W, bh, bv = self.engine.get_params()
+        return {'enc_w': W, 'enc_b': bh, 'dec_b': bv}

@@ -63,7 +63,18 @@ extern "C" int dae_decode_loss(int32_t dtype, int32_t B, int32_t F, int32_t H, c
 // ------------------------------------------------------------------------------------------------
 // plan: sizes, workspace carving, step driver
 // ------------------------------------------------------------------------------------------------
+// per-kernel HIP-event timing slots of the step driver (bench.py's roofline leg)
+enum { PS_MEMSET = 0, PS_GATHER, PS_ENC_GEMM, PS_ENC_FIN, PS_LABEL, PS_GRAM, PS_MINER, PS_TRI_FIN, PS_SYM, PS_DECODE,
+       PS_COS_REDUCE, PS_STATS, PS_DH_GEMM, PS_DH_FIN, PS_DW_GEMM, PS_BIAS, PS_OPT, PS_COUNT };
+static const char* const kProfNames[PS_COUNT] = {"memset_xct", "gather", "encode_gemm", "encode_finish", "label_stats", "gram",
+                                                 "miner", "triplet_finalize", "sym_scale", "decode_loss", "cos_reduce",
+                                                 "step_stats", "dh_gemm", "dh_finish", "dw_gemm", "bias_grads", "opt_step"};
+
 struct dae_plan {
+    bool prof;
+    hipEvent_t ev0, ev1;
+    double prof_ms[PS_COUNT];
+    int prof_n[PS_COUNT];
     dae_config cfg;
     dae_buffers b;
     bool bound;
@@ -163,7 +174,32 @@ extern "C" int dae_plan_create(const dae_config* cfg, dae_plan** out) {
     return 0;
 }
 
-extern "C" void dae_plan_destroy(dae_plan* p) { delete p; }
+extern "C" void dae_plan_destroy(dae_plan* p) {
+    if (!p) return;
+    if (p->ev0) (void)hipEventDestroy(p->ev0);
+    if (p->ev1) (void)hipEventDestroy(p->ev1);
+    delete p;
+}
+
+extern "C" int dae_plan_profile(dae_plan* p, int32_t enable) {
+    DAE_CHECK_ARG(p, "plan_profile: null plan");
+    if (enable && !p->ev0) {
+        DAE_CHECK_HIP(hipEventCreate(&p->ev0));
+        DAE_CHECK_HIP(hipEventCreate(&p->ev1));
+    }
+    if (enable) { memset(p->prof_ms, 0, sizeof(p->prof_ms)); memset(p->prof_n, 0, sizeof(p->prof_n)); }
+    p->prof = enable != 0;
+    return 0;
+}
+
+extern "C" int dae_plan_profile_read(const dae_plan* p, int32_t max_slots, double* ms_total, int32_t* counts) {
+    DAE_CHECK_ARG(p && ms_total && counts, "plan_profile_read: null argument");
+    for (int i = 0; i < PS_COUNT && i < max_slots; ++i) { ms_total[i] = p->prof_ms[i]; counts[i] = p->prof_n[i]; }
+    return PS_COUNT <= max_slots ? 0 : 1;
+}
+
+extern "C" int32_t dae_plan_profile_slots(void) { return PS_COUNT; }
+extern "C" const char* dae_plan_profile_name(int32_t slot) { return (slot >= 0 && slot < PS_COUNT) ? kProfNames[slot] : ""; }
 extern "C" uint64_t dae_plan_workspace_bytes(const dae_plan* p) { return p ? p->ws_bytes : 0; }
 
 extern "C" int dae_plan_bind(dae_plan* p, const dae_buffers* bufs) {
@@ -219,6 +255,24 @@ static int gather_batch(dae_plan* p, const int64_t* indptr, const int32_t* indic
 }
 
 #define RC(expr) do { if (int rc__ = (expr)) return rc__; } while (0)
+// PROF(slot, call): in profile mode bracket the call with HIP events ON THE STEP'S STREAM and accumulate the
+// elapsed GPU time of that slot (costs a host sync per call, so it is never on when throughput is measured).
+#define PROF(slot, expr)                                                            \
+    do {                                                                            \
+        if (p->prof) DAE_CHECK_HIP(hipEventRecord(p->ev0, st));                     \
+        RC(expr);                                                                   \
+        if (p->prof) {                                                              \
+            DAE_CHECK_HIP(hipEventRecord(p->ev1, st));                              \
+            DAE_CHECK_HIP(hipEventSynchronize(p->ev1));                             \
+            float ms__ = 0.f;                                                       \
+            DAE_CHECK_HIP(hipEventElapsedTime(&ms__, p->ev0, p->ev1));              \
+            p->prof_ms[slot] += ms__; p->prof_n[slot] += 1;                         \
+        }                                                                           \
+    } while (0)
+static int memset_async(void* ptr, size_t bytes, hipStream_t st) {
+    DAE_CHECK_HIP(hipMemsetAsync(ptr, 0, bytes, st));
+    return 0;
+}
 
 extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     DAE_CHECK_ARG(p && p->bound && s, "train_step: plan not bound / null step");
@@ -234,46 +288,46 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     const bool backward = s->phase != 2;
 
     // 1-2. corrupt + gather  (K0/K1 front half)
-    if (backward) DAE_CHECK_HIP(hipMemsetAsync(p->xct, 0, (size_t)Fp * ldB * p->es, st));
+    if (backward) PROF(PS_MEMSET, memset_async(p->xct, (size_t)Fp * ldB * p->es, st));
     float* rowsq = is_cos ? p->cos_stats : nullptr;
     if (s->c_indptr) {   // an explicitly corrupted copy of the train set (salt&pepper, host-side noise)
-        RC(gather_batch(p, p->b.indptr, p->b.indices, p->b.values, p->b.dense, p->b.ld_dense, s->row_idx, B, p->x, nullptr, nullptr,
+        PROF(PS_GATHER, gather_batch(p, p->b.indptr, p->b.indices, p->b.values, p->b.dense, p->b.ld_dense, s->row_idx, B, p->x, nullptr, nullptr,
                         rowsq, DAE_CORR_NONE, nullptr, 0, 0, 0.f, 1.f, stream));
-        RC(gather_batch(p, s->c_indptr, s->c_indices, s->c_values, nullptr, 0, s->row_idx, B, nullptr, p->xc,
+        PROF(PS_GATHER, gather_batch(p, s->c_indptr, s->c_indices, s->c_values, nullptr, 0, s->row_idx, B, nullptr, p->xc,
                         backward ? p->xct : nullptr, nullptr, DAE_CORR_NONE, nullptr, 0, 0, 0.f, s->scale, stream));
     } else {
-        RC(gather_batch(p, p->b.indptr, p->b.indices, p->b.values, p->b.dense, p->b.ld_dense, s->row_idx, B, p->x, p->xc,
+        PROF(PS_GATHER, gather_batch(p, p->b.indptr, p->b.indices, p->b.values, p->b.dense, p->b.ld_dense, s->row_idx, B, p->x, p->xc,
                         backward ? p->xct : nullptr, rowsq, s->corr_mode, s->keep_bits, s->seed, s->rng_stream, s->corr_frac,
                         s->scale, stream));
     }
     // 3-4. encode (K1/K2)
     const int64_t slab = (int64_t)Bp * Hp;
-    RC(launch_gemm_f32out(dt, Bp, Hp, p->xc, Fp, p->b.Wt_lo, Fp, Fp, nullptr, 0, nullptr, 0, 0, p->slabs, Hp, p->s_enc, slab, st));
-    RC(dae_encode_finish(p->slabs, p->s_enc, slab, Hp, p->b.bh, B, H, c.enc_act, dt, p->h_f32, p->h_lo, Hp, p->h_t, ldB, stream));
+    PROF(PS_ENC_GEMM, launch_gemm_f32out(dt, Bp, Hp, p->xc, Fp, p->b.Wt_lo, Fp, Fp, nullptr, 0, nullptr, 0, 0, p->slabs, Hp, p->s_enc, slab, st));
+    PROF(PS_ENC_FIN, dae_encode_finish(p->slabs, p->s_enc, slab, Hp, p->b.bh, B, H, c.enc_act, dt, p->h_f32, p->h_lo, Hp, p->h_t, ldB, stream));
     // 5-6. miners (K5-K7)
     const int Bt = explicit3 ? B / 3 : B;
     if (explicit3) {
-        RC(dae_label_stats(nullptr, Bt, Bp, DAE_TRIPLET_NONE, nullptr, nullptr, nullptr, nullptr, p->cw, stream));
+        PROF(PS_LABEL, dae_label_stats(nullptr, Bt, Bp, DAE_TRIPLET_NONE, nullptr, nullptr, nullptr, nullptr, p->cw, stream));
         // every one of the 3*Bt stacked rows carries weight 1/(Bt + 1e-16): three unweighted row means (:303-305)
         DAE_CHECK_HIP(hipMemcpyAsync(p->cw + Bt, p->cw, (size_t)Bt * 4, hipMemcpyDeviceToDevice, st));
         DAE_CHECK_HIP(hipMemcpyAsync(p->cw + 2 * Bt, p->cw, (size_t)Bt * 4, hipMemcpyDeviceToDevice, st));
-        RC(dae_explicit_triplet(p->h_f32, Hp, Bt, H, c.alpha, p->dh_extra, p->loss_part, p->tri_scalars, stream));
+        PROF(PS_MINER, dae_explicit_triplet(p->h_f32, Hp, Bt, H, c.alpha, p->dh_extra, p->loss_part, p->tri_scalars, stream));
     } else {
-        RC(dae_label_stats(s->labels, B, Bp, c.triplet, p->n_same, p->acc, p->nvalid, p->dw_i64, p->cw, stream));
+        PROF(PS_LABEL, dae_label_stats(s->labels, B, Bp, c.triplet, p->n_same, p->acc, p->nvalid, p->dw_i64, p->cw, stream));
     }
     if (c.triplet == DAE_TRIPLET_BATCH_ALL || c.triplet == DAE_TRIPLET_BATCH_HARD) {
         const int64_t dslab = (int64_t)Bp * Bp;
-        RC(launch_gemm_f32out(DAE_F32, Bp, Bp, p->h_f32, Hp, p->h_f32, Hp, Hp, nullptr, 0, nullptr, 0, 0, p->D_slabs, Bp, p->s_gram,
+        PROF(PS_GRAM, launch_gemm_f32out(DAE_F32, Bp, Bp, p->h_f32, Hp, p->h_f32, Hp, Hp, nullptr, 0, nullptr, 0, 0, p->D_slabs, Bp, p->s_gram,
                               dslab, st));
         if (c.triplet == DAE_TRIPLET_BATCH_ALL)
-            RC(dae_triplet_batch_all(p->D_slabs, p->s_gram, dslab, Bp, s->labels, B, Bp, c.pos_triplets_only, p->loss_part,
+            PROF(PS_MINER, dae_triplet_batch_all(p->D_slabs, p->s_gram, dslab, Bp, s->labels, B, Bp, c.pos_triplets_only, p->loss_part,
                                      p->cnt_part, p->G, p->role_cnt, stream));
         else
-            RC(dae_triplet_batch_hard(p->D_slabs, p->s_gram, dslab, Bp, s->labels, B, Bp, p->loss_part, p->cnt_part, p->dw_i32, p->G,
+            PROF(PS_MINER, dae_triplet_batch_hard(p->D_slabs, p->s_gram, dslab, Bp, s->labels, B, Bp, p->loss_part, p->cnt_part, p->dw_i32, p->G,
                                       stream));
-        RC(dae_triplet_finalize(c.triplet, c.pos_triplets_only, B, Bp, c.alpha, p->loss_part, p->cnt_part, p->nvalid, p->dw_i32,
+        PROF(PS_TRI_FIN, dae_triplet_finalize(c.triplet, c.pos_triplets_only, B, Bp, c.alpha, p->loss_part, p->cnt_part, p->nvalid, p->dw_i32,
                                 p->role_cnt, p->dw_f32, p->cw, p->tri_scalars, stream));
-        if (backward) RC(dae_sym_scale(p->G, B, Bp, p->tri_scalars, dt, p->Gs, stream));
+        if (backward) PROF(PS_SYM, dae_sym_scale(p->G, B, Bp, p->tri_scalars, dt, p->Gs, stream));
     }
     // 7. decode + reconstruction loss + d cost/d z2   (K3/K4)
     const int ncw = 2 * Fp / 128;
@@ -284,31 +338,32 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     e.y_out = nullptr; e.ldy = 0; e.B = B; e.F = F; e.Bp = Bp; e.Fp = Fp; e.dec_act = c.dec_act; e.loss_func = c.loss_func;
     if (is_cos) {
         e.cos_pass = 1;
-        RC(launch_decode_loss(dt, Bp, Fp, Hp, p->h_lo, Hp, p->b.W_lo, Hp, e, st));
-        RC(dae_cos_reduce(p->cos_part, ncw, B, Bp, p->cos_stats, p->rowloss_part, stream));
-        if (backward) { e.cos_pass = 2; RC(launch_decode_loss(dt, Bp, Fp, Hp, p->h_lo, Hp, p->b.W_lo, Hp, e, st)); }
+        PROF(PS_DECODE, launch_decode_loss(dt, Bp, Fp, Hp, p->h_lo, Hp, p->b.W_lo, Hp, e, st));
+        PROF(PS_COS_REDUCE, dae_cos_reduce(p->cos_part, ncw, B, Bp, p->cos_stats, p->rowloss_part, stream));
+        if (backward) { e.cos_pass = 2; PROF(PS_DECODE, launch_decode_loss(dt, Bp, Fp, Hp, p->h_lo, Hp, p->b.W_lo, Hp, e, st)); }
     } else {
         e.cos_pass = 0;
-        RC(launch_decode_loss(dt, Bp, Fp, Hp, p->h_lo, Hp, p->b.W_lo, Hp, e, st));
+        PROF(PS_DECODE, launch_decode_loss(dt, Bp, Fp, Hp, p->h_lo, Hp, p->b.W_lo, Hp, e, st));
     }
     // 8. statistics of this step (autoencoder.py:233 fetch list)
-    RC(dae_step_stats(p->rowloss_part, is_cos ? 1 : ncw, p->cw, B, Bp, c.triplet == 3 ? DAE_TRIPLET_BATCH_HARD : c.triplet, c.alpha,
+    PROF(PS_STATS, dae_step_stats(p->rowloss_part, is_cos ? 1 : ncw, p->cw, B, Bp, c.triplet == 3 ? DAE_TRIPLET_BATCH_HARD : c.triplet, c.alpha,
                       p->tri_scalars, c.triplet == DAE_TRIPLET_BATCH_ALL ? p->nvalid : nullptr, s->stats, stream));
     if (!backward) return 0;
     // 9-10. dL/dh = delta2 W + alpha (G+G^T) h ; delta1                     (K8)
     const bool mined = (c.triplet == DAE_TRIPLET_BATCH_ALL || c.triplet == DAE_TRIPLET_BATCH_HARD);
-    RC(launch_gemm_f32out(dt, Bp, Hp, p->delta2, Fp, p->b.Wt_lo, Fp, Fp, mined ? p->Gs : nullptr, Bp, mined ? p->h_t : nullptr, ldB,
+    PROF(PS_DH_GEMM, launch_gemm_f32out(dt, Bp, Hp, p->delta2, Fp, p->b.Wt_lo, Fp, Fp, mined ? p->Gs : nullptr, Bp, mined ? p->h_t : nullptr, ldB,
                           mined ? Bp : 0, p->slabs, Hp, p->s_dh, slab, st));
-    RC(dae_dh_finish(p->slabs, p->s_dh, slab, Hp, explicit3 ? p->dh_extra : nullptr, p->h_f32, Hp, p->b.bh, B, H, c.enc_act, dt,
+    PROF(PS_DH_FIN, dae_dh_finish(p->slabs, p->s_dh, slab, Hp, explicit3 ? p->dh_extra : nullptr, p->h_f32, Hp, p->b.bh, B, H, c.enc_act, dt,
                      p->delta1_t, ldB, p->colsum_part, nullptr, stream));
     // 11. dW = x~^T delta1 + delta2^T h                                      (K8, tied weights)
-    RC(launch_gemm_f32out(dt, Fp, Hp, p->xct, ldB, p->delta1_t, ldB, Bp, p->delta2_t, ldB, p->h_t, ldB, Bp, p->b.grad, Hp, 1, 0, st));
+    PROF(PS_DW_GEMM, launch_gemm_f32out(dt, Fp, Hp, p->xct, ldB, p->delta1_t, ldB, Bp, p->delta2_t, ldB, p->h_t, ldB, Bp, p->b.grad, Hp, 1, 0, st));
     // 12. bias gradients
     float* g_bh = p->b.grad + (int64_t)Fp * Hp;
-    RC(dae_bias_grads(p->dbv_part, 2 * Bp / 128, p->colsum_part, Bp / 64, p->b.bh, H, Hp, F, Fp, c.enc_act, g_bh, g_bh + Hp, stream));
+    PROF(PS_BIAS, dae_bias_grads(p->dbv_part, 2 * Bp / 128, p->colsum_part, Bp / 64, p->b.bh, H, Hp, F, Fp, c.enc_act, g_bh, g_bh + Hp, stream));
     if (s->phase == 1) return 0;
     // 13. optimizer (K9)
-    return dae_plan_apply(p, s->adam_t, s->grad_scale, stream);
+    PROF(PS_OPT, dae_plan_apply(p, s->adam_t, s->grad_scale, stream));
+    return 0;
 }
 
 extern "C" int dae_plan_apply(dae_plan* p, int32_t adam_t, float grad_scale, void* stream) {

@@ -527,3 +527,49 @@ extern "C" int dae_explicit_triplet(const float* h3, int64_t ldh, int32_t B, int
     DAE_CHECK_LAUNCH();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// stand-alone weighted_loss(input, decode) for the function-level API (triplet_loss_utils.py:262-277):
+// one workgroup per row, fp32 x / y, row loss into rowloss[B]; the weighted mean is taken by step_stats.
+// ------------------------------------------------------------------------------------------------
+namespace dae {
+__global__ __launch_bounds__(256) void weighted_loss_rows_kernel(const float* __restrict__ x, int64_t ldx,
+                                                                 const float* __restrict__ y, int64_t ldy, int F,
+                                                                 int loss_func, float* __restrict__ rowloss) {
+    __shared__ float red[3][4];
+    const int i = blockIdx.x, tid = threadIdx.x;
+    const float* xr = x + (int64_t)i * ldx;
+    const float* yr = y + (int64_t)i * ldy;
+    float a = 0.f, b = 0.f, c = 0.f;
+    for (int f = tid; f < F; f += 256) {
+        const float xv = xr[f], yv = yr[f];
+        if (loss_func == DAE_LOSS_CROSS_ENTROPY) {
+            a += -(xv * logf(yv + 1e-16f) + (1.0f - xv) * logf((1.0f - yv) + 1e-16f));
+        } else if (loss_func == DAE_LOSS_MEAN_SQUARED) {
+            const float d = xv - yv;
+            a += d * d;
+        } else {
+            a += xv * yv; b += xv * xv; c += yv * yv;
+        }
+    }
+    a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
+    if ((tid & 63) == 0) { red[0][tid >> 6] = a; red[1][tid >> 6] = b; red[2][tid >> 6] = c; }
+    __syncthreads();
+    if (tid == 0) {
+        a = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        b = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        c = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+        if (loss_func == DAE_LOSS_COSINE) a = -a * rsqrtf(fmaxf(b, 1e-12f)) * rsqrtf(fmaxf(c, 1e-12f));
+        rowloss[i] = a;
+    }
+}
+}  // namespace dae
+
+extern "C" int dae_weighted_loss_rows(const float* x, int64_t ldx, const float* y, int64_t ldy, int32_t B, int32_t F,
+                                      int32_t loss_func, float* rowloss, void* stream) {
+    DAE_CHECK_ARG(x && y && rowloss && B > 0 && F > 0, "weighted_loss_rows: bad args");
+    DAE_CHECK_ARG(loss_func >= DAE_LOSS_CROSS_ENTROPY && loss_func <= DAE_LOSS_COSINE, "weighted_loss_rows: unknown loss");
+    hipLaunchKernelGGL(dae::weighted_loss_rows_kernel, dim3(B), dim3(256), 0, ST(stream), x, ldx, y, ldy, F, loss_func, rowloss);
+    DAE_CHECK_LAUNCH();
+    return 0;
+}

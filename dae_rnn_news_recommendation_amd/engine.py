@@ -183,6 +183,16 @@ class Engine:
         n = int(np.prod(shape)) * torch.tensor([], dtype=dtype).element_size()
         return self.workspace[off:off + n].view(dtype).view(*shape)
 
+    def profile(self, enable):
+        L.check(self.lib.dae_plan_profile(self.plan, int(bool(enable))), "dae_plan_profile")
+
+    def profile_read(self):
+        """{kernel slot name: (total ms, launches)} accumulated since profile(True)."""
+        n = int(self.lib.dae_plan_profile_slots())
+        ms = (C.c_double * n)(); cnt = (C.c_int32 * n)()
+        L.check(self.lib.dae_plan_profile_read(self.plan, n, ms, cnt), "dae_plan_profile_read")
+        return {self.lib.dae_plan_profile_name(i).decode(): (float(ms[i]), int(cnt[i])) for i in range(n)}
+
     def info(self):
         out = (C.c_int32 * 8)()
         L.check(self.lib.dae_plan_info(self.plan, out), "dae_plan_info")

@@ -207,6 +207,12 @@ int dae_step_stats(const float* rowloss_part, int32_t n_col_waves, const float* 
 int dae_explicit_triplet(const float* h3, int64_t ldh, int32_t B, int32_t H, float alpha,
                          float* dh3, float* loss_part, float* tri_scalars, void* stream);
 
+/* Stand-alone per-row reconstruction loss of a given decode (triplet_loss_utils.py:268-273) for the
+ * function-level weighted_loss() API: x, y fp32 [B x F]; rowloss[B].  The weighted mean
+ * sum(row*w)/(sum w + 1e-16) (:275) is then taken by dae_step_stats with n_col_waves = 1. */
+int dae_weighted_loss_rows(const float* x, int64_t ldx, const float* y, int64_t ldy, int32_t B, int32_t F,
+                           int32_t loss_func, float* rowloss, void* stream);
+
 /* A/B switch for the GEMM staging path: 1 = global_load_lds (default), 0 = register staging. */
 void dae_set_glds(int32_t on);
 
@@ -265,6 +271,13 @@ int      dae_encode_rows(dae_plan* p, const int32_t* row_idx, int32_t B, float s
                          const float* dense, int64_t ld_dense, float* out, int64_t ld_out, void* stream);
 /* pointers into the workspace for tests / debugging (NULL if name unknown) */
 void*    dae_plan_buffer(dae_plan* p, const char* name);
+/* Per-kernel timing of dae_train_step with HIP events recorded on the step's own stream (bench.py's
+ * roofline leg).  While enabled every launch is bracketed by two events and the host waits for it, so
+ * throughput numbers must be taken with profiling off.  Slot names via dae_plan_profile_name(). */
+int         dae_plan_profile(dae_plan* p, int32_t enable);
+int         dae_plan_profile_read(const dae_plan* p, int32_t max_slots, double* ms_total, int32_t* counts);
+int32_t     dae_plan_profile_slots(void);
+const char* dae_plan_profile_name(int32_t slot);
 /* out8 = {Fp, Hp, Bp_max, encode_splits, dh_splits, gram_splits, element_size, 0} */
 int      dae_plan_info(const dae_plan* p, int32_t* out8);
 

