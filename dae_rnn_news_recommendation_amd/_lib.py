@@ -61,8 +61,8 @@ SIGNATURES = {
     "dae_gather_dense": (i32, [vp, i64, vp, i32, i32, i32, vp, vp, i64, vp, i64, vp, vp, i32, vp, u64, u32, f32, f32, vp]),
     "dae_gemm_nt": (i32, [i32, i32, i32, vp, i64, vp, i64, i32, vp, i64, vp, i64, i32, vp, i64, i32, i64, vp]),
     "dae_encode_finish": (i32, [vp, i32, i64, i64, vp, i32, i32, i32, i32, vp, vp, i64, vp, i64, vp]),
-    "dae_decode_loss": (i32, [i32, i32, i32, i32, vp, i64, vp, i64, vp, vp, i64, vp, i32, i32, i32, vp, vp, vp, vp,
-                              vp, i64, vp, i64, vp, i64, vp]),
+    "dae_decode_loss": (i32, [i32, i32, i32, i32, vp, i64, vp, i64, vp, vp, i64, vp, i32, i32, i32, vp, vp, vp, vp, vp,
+                              vp, i64, vp, i64, vp]),
     "dae_cos_reduce": (i32, [vp, i32, i32, i32, vp, vp, vp]),
     "dae_gram": (i32, [vp, i64, i32, i32, vp, i32, vp]),
     "dae_label_stats": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
@@ -73,7 +73,7 @@ SIGNATURES = {
     "dae_dh_finish": (i32, [vp, i32, i64, i64, vp, vp, i64, vp, i32, i32, i32, i32, vp, i64, vp, vp, vp]),
     "dae_bias_grads": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp]),
     "dae_opt_step": (i32, [i32, f32, f32, f32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, i32, vp]),
-    "dae_step_stats": (i32, [vp, i32, vp, i32, i32, i32, f32, vp, vp, vp, vp]),
+    "dae_step_stats": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, f32, vp, vp, vp, vp]),
     "dae_weighted_loss_rows": (i32, [vp, i64, vp, i64, i32, i32, i32, vp, vp]),
     "dae_explicit_triplet": (i32, [vp, i64, i32, i32, f32, vp, vp, vp, vp]),
     "dae_plan_create": (i32, [C.POINTER(dae_config), C.POINTER(vp)]),

@@ -24,7 +24,7 @@ using namespace dae;
 extern "C" int dae_abi_version(void) { return DAE_ABI_VERSION; }
 extern "C" const char* dae_last_error(void) { return g_err; }
 extern "C" int64_t dae_pad(int64_t n) { return pad128(n); }
-extern "C" void dae_set_glds(int32_t on) { set_use_glds(on != 0); }
+extern "C" void dae_set_glds(int32_t nst) { set_use_glds(nst); }
 
 extern "C" int dae_gemm_nt(int32_t dtype, int32_t M, int32_t N, const void* A0, int64_t lda0, const void* Bt0, int64_t ldb0,
                            int32_t K0, const void* A1, int64_t lda1, const void* Bt1, int64_t ldb1, int32_t K1, float* C,
@@ -41,8 +41,8 @@ extern "C" int dae_gram(const float* h_f32, int64_t ldh, int32_t Bp, int32_t Hp,
 extern "C" int dae_decode_loss(int32_t dtype, int32_t B, int32_t F, int32_t H, const void* h_lo, int64_t ldh, const void* W_lo,
                                int64_t ldw, const float* bv, const void* x, int64_t ldx, const float* cw, int32_t dec_act,
                                int32_t loss_func, int32_t cos_pass, const float* cos_stats, float* cos_part,
-                               float* rowloss_part, float* dbv_part, void* delta2, int64_t ldd, void* delta2_t, int64_t lddt,
-                               float* y_out, int64_t ldy, void* stream) {
+                               float* rowloss_part, float* tile_part, float* dbv_part, void* delta2, int64_t ldd,
+                               void* delta2_t, int64_t lddt, void* stream) {
     DAE_CHECK_ARG(h_lo && W_lo && bv && x && cw, "decode_loss: null input");
     DAE_CHECK_ARG(B > 0 && F > 0 && H > 0, "decode_loss: bad shape");
     DAE_CHECK_ARG(loss_func >= DAE_LOSS_CROSS_ENTROPY && loss_func <= DAE_LOSS_COSINE, "decode_loss: unknown loss %d", loss_func);
@@ -50,11 +50,12 @@ extern "C" int dae_decode_loss(int32_t dtype, int32_t B, int32_t F, int32_t H, c
         DAE_CHECK_ARG(cos_pass == 1 || cos_pass == 2, "decode_loss: cosine needs cos_pass 1 or 2");
         DAE_CHECK_ARG(cos_stats && (cos_pass != 1 || cos_part), "decode_loss: cosine statistics buffers required");
     } else {
-        DAE_CHECK_ARG(cos_pass == 0 && rowloss_part, "decode_loss: rowloss_part required");
+        DAE_CHECK_ARG(cos_pass == 0 && (rowloss_part || tile_part), "decode_loss: rowloss_part or tile_part required");
     }
     DecodeEpi e;
-    e.bv = bv; e.x = x; e.ldx = ldx; e.cw = cw; e.cos_stats = cos_stats; e.rowloss_part = rowloss_part; e.dbv_part = dbv_part;
-    e.cos_part = cos_part; e.delta2 = delta2; e.ldd = ldd; e.delta2_t = delta2_t; e.lddt = lddt; e.y_out = y_out; e.ldy = ldy;
+    memset(&e, 0, sizeof(e));
+    e.bv = bv; e.x = x; e.ldx = ldx; e.cw = cw; e.cos_stats = cos_stats; e.rowloss_part = rowloss_part; e.tile_part = tile_part; e.dbv_part = dbv_part;
+    e.cos_part = cos_part; e.delta2 = delta2; e.ldd = ldd; e.delta2_t = delta2_t; e.lddt = lddt;
     e.B = B; e.F = F; e.Bp = (int)pad128(B); e.Fp = (int)pad128(F); e.dec_act = dec_act; e.loss_func = loss_func;
     e.cos_pass = cos_pass;
     return launch_decode_loss(dtype, e.Bp, e.Fp, (int)pad128(H), h_lo, ldh, W_lo, ldw, e, (hipStream_t)stream);
@@ -85,7 +86,7 @@ struct dae_plan {
     // carved pointers
     char *x, *xc, *xct, *h_lo, *h_t, *Gs, *delta2, *delta2_t, *delta1_t;
     float *slabs, *h_f32, *D_slabs, *G, *rowloss_part, *dbv_part, *colsum_part, *cos_part, *cos_stats, *cw, *loss_part,
-        *dw_f32, *tri_scalars, *dh_extra, *rowsq_scratch;
+        *dw_f32, *tri_scalars, *dh_extra, *rowsq_scratch, *tile_part;
     uint32_t *cnt_part, *role_cnt;
     int32_t *dw_i32, *n_same;
     int64_t *nvalid, *dw_i64;
@@ -128,10 +129,11 @@ static uint64_t carve(dae_plan* p, char* base) {
     p->role_cnt = (uint32_t*)take(p->cfg.pos_triplets_only ? Bp * Bp * 4 : 256);
     p->rowloss_part = (float*)take((2 * Fp / 128) * Bp * 4);
     p->dbv_part = (float*)take((2 * Bp / 128) * Fp * 4);
-    p->colsum_part = (float*)take(2 * (Bp / 64) * Hp * 4);
+    p->colsum_part = (float*)take(2 * (Bp / 32) * Hp * 4);
     p->cos_part = (float*)take(2 * (2 * Fp / 128) * Bp * 4);
     p->cos_stats = (float*)take(3 * Bp * 4);
     p->rowsq_scratch = (float*)take((Fp / 64) * Bp * 4);
+    p->tile_part = (float*)take((Bp / 128) * (Fp / 128) * 4);
     p->cw = (float*)take(Bp * 4);
     p->loss_part = (float*)take(Bp * 4);
     p->dw_f32 = (float*)take(Bp * 4);
@@ -230,7 +232,7 @@ extern "C" void* dae_plan_buffer(dae_plan* p, const char* name) {
     DAE_BUF(x) DAE_BUF(xc) DAE_BUF(xct) DAE_BUF(h_lo) DAE_BUF(h_t) DAE_BUF(Gs) DAE_BUF(delta2) DAE_BUF(delta2_t) DAE_BUF(delta1_t)
     DAE_BUF(slabs) DAE_BUF(h_f32) DAE_BUF(D_slabs) DAE_BUF(G) DAE_BUF(rowloss_part) DAE_BUF(dbv_part) DAE_BUF(colsum_part)
     DAE_BUF(cos_part) DAE_BUF(cos_stats) DAE_BUF(cw) DAE_BUF(loss_part) DAE_BUF(dw_f32) DAE_BUF(tri_scalars) DAE_BUF(dh_extra)
-    DAE_BUF(cnt_part) DAE_BUF(role_cnt) DAE_BUF(dw_i32) DAE_BUF(n_same) DAE_BUF(nvalid) DAE_BUF(dw_i64)
+    DAE_BUF(tile_part) DAE_BUF(cnt_part) DAE_BUF(role_cnt) DAE_BUF(dw_i32) DAE_BUF(n_same) DAE_BUF(nvalid) DAE_BUF(dw_i64)
 #undef DAE_BUF
     return nullptr;
 }
@@ -332,10 +334,12 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     // 7. decode + reconstruction loss + d cost/d z2   (K3/K4)
     const int ncw = 2 * Fp / 128;
     DecodeEpi e;
+    memset(&e, 0, sizeof(e));
     e.bv = p->b.bv; e.x = p->x; e.ldx = Fp; e.cw = p->cw; e.cos_stats = is_cos ? p->cos_stats : nullptr;
-    e.rowloss_part = p->rowloss_part; e.dbv_part = backward ? p->dbv_part : nullptr; e.cos_part = p->cos_part;
+    e.rowloss_part = is_cos ? p->rowloss_part : nullptr; e.tile_part = is_cos ? nullptr : p->tile_part;
+    e.dbv_part = backward ? p->dbv_part : nullptr; e.cos_part = p->cos_part;
     e.delta2 = backward ? p->delta2 : nullptr; e.ldd = Fp; e.delta2_t = backward ? p->delta2_t : nullptr; e.lddt = ldB;
-    e.y_out = nullptr; e.ldy = 0; e.B = B; e.F = F; e.Bp = Bp; e.Fp = Fp; e.dec_act = c.dec_act; e.loss_func = c.loss_func;
+    e.B = B; e.F = F; e.Bp = Bp; e.Fp = Fp; e.dec_act = c.dec_act; e.loss_func = c.loss_func;
     if (is_cos) {
         e.cos_pass = 1;
         PROF(PS_DECODE, launch_decode_loss(dt, Bp, Fp, Hp, p->h_lo, Hp, p->b.W_lo, Hp, e, st));
@@ -346,7 +350,8 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
         PROF(PS_DECODE, launch_decode_loss(dt, Bp, Fp, Hp, p->h_lo, Hp, p->b.W_lo, Hp, e, st));
     }
     // 8. statistics of this step (autoencoder.py:233 fetch list)
-    PROF(PS_STATS, dae_step_stats(p->rowloss_part, is_cos ? 1 : ncw, p->cw, B, Bp, c.triplet == 3 ? DAE_TRIPLET_BATCH_HARD : c.triplet, c.alpha,
+    PROF(PS_STATS, dae_step_stats(is_cos ? p->rowloss_part : nullptr, 1, is_cos ? nullptr : p->tile_part, (Bp / 128) * (Fp / 128), p->cw, B, Bp,
+                      c.triplet == 3 ? DAE_TRIPLET_BATCH_HARD : c.triplet, c.alpha,
                       p->tri_scalars, c.triplet == DAE_TRIPLET_BATCH_ALL ? p->nvalid : nullptr, s->stats, stream));
     if (!backward) return 0;
     // 9-10. dL/dh = delta2 W + alpha (G+G^T) h ; delta1                     (K8)
@@ -359,7 +364,7 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     PROF(PS_DW_GEMM, launch_gemm_f32out(dt, Fp, Hp, p->xct, ldB, p->delta1_t, ldB, Bp, p->delta2_t, ldB, p->h_t, ldB, Bp, p->b.grad, Hp, 1, 0, st));
     // 12. bias gradients
     float* g_bh = p->b.grad + (int64_t)Fp * Hp;
-    PROF(PS_BIAS, dae_bias_grads(p->dbv_part, 2 * Bp / 128, p->colsum_part, Bp / 64, p->b.bh, H, Hp, F, Fp, c.enc_act, g_bh, g_bh + Hp, stream));
+    PROF(PS_BIAS, dae_bias_grads(p->dbv_part, 2 * Bp / 128, p->colsum_part, Bp / 32, p->b.bh, H, Hp, F, Fp, c.enc_act, g_bh, g_bh + Hp, stream));
     if (s->phase == 1) return 0;
     // 13. optimizer (K9)
     PROF(PS_OPT, dae_plan_apply(p, s->adam_t, s->grad_scale, stream));

@@ -42,6 +42,13 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
     return (bf16_t)(u >> 16);
 }
 __device__ __forceinline__ float bf2f(bf16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+// hardware RNE convert (v_cvt_pk_bf16_f32 on gfx950); identical to f2bf for finite inputs
+__device__ __forceinline__ bf16_t f2bf_hw(float f) { return __builtin_bit_cast(bf16_t, static_cast<__bf16>(f)); }
+__device__ __forceinline__ uint32_t f2bf_pack_hw(float lo, float hi) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    bf16x2_t v = {static_cast<__bf16>(lo), static_cast<__bf16>(hi)};
+    return __builtin_bit_cast(uint32_t, v);
+}
 
 template <typename T> struct Elem;
 template <> struct Elem<float> {
@@ -79,6 +86,33 @@ __device__ __forceinline__ float softplus_tf(float x) {
     float e = __expf(x);
     if (x < thr) return e;
     return log1pf(e);
+}
+
+// ---- DPP cross-lane sums (no LDS traffic): gfx9 data-parallel primitives on the VALU operand path ----
+// dpp_ctrl: quad_perm = 8-bit lane permutation; 0x140 row_mirror; 0x141 row_half_mirror;
+//           0x142 row_bcast15 (lane 15 of each 16-lane row -> next row); 0x143 row_bcast31 (lane 31 -> rows 2,3)
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ __forceinline__ float dpp_mov(float old, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL,
+                                                                 ROW_MASK, 0xF, BOUND));
+}
+// sum over each 16-lane row; every lane of the row receives it
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_mov<0xB1, 0xF, true>(0.f, v);     // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E, 0xF, true>(0.f, v);     // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141, 0xF, true>(0.f, v);    // row_half_mirror: the other quad of each 8
+    v += dpp_mov<0x140, 0xF, true>(0.f, v);    // row_mirror: the other 8 of each 16
+    return v;
+}
+// sum over each 32-lane half wave; valid in lanes 16..31 and 48..63
+__device__ __forceinline__ float half32_sum_hi(float v) {
+    v = row16_sum(v);
+    return v + dpp_mov<0x142, 0xA, false>(0.f, v);   // rows 1 and 3 += lane 15 of rows 0 and 2
+}
+// sum over all 64 lanes; valid in lanes 48..63
+__device__ __forceinline__ float wave64_sum_hi(float v) {
+    v = half32_sum_hi(v);
+    return v + dpp_mov<0x143, 0xC, false>(0.f, v);   // rows 2,3 += lane 31
 }
 
 // ---- wave reductions over 64 lanes (wavefront shuffles) ----

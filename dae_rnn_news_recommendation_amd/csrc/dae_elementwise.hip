@@ -15,26 +15,36 @@ __global__ __launch_bounds__(256) void encode_finish_kernel(const float* __restr
                                                             int64_t ld_slab, const float* __restrict__ bh, int B, int H,
                                                             int enc_act, float* __restrict__ h_f32, T* __restrict__ h_lo,
                                                             int64_t ldh, T* __restrict__ h_t, int64_t ldht) {
-    __shared__ float tile[64][65];
-    const int j0 = blockIdx.x * 64, i0 = blockIdx.y * 64;
+    __shared__ float tile[32][65];
+    const int j0 = blockIdx.x * 64, i0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int j = j0 + tx;
     const float b = bh[j];
     const float ab = act_apply(enc_act, b);
-#pragma unroll 4
-    for (int r = ty; r < 64; r += 4) {
-        const int i = i0 + r;
-        float z = 0.f;
-        for (int s = 0; s < splits; ++s) z += slabs[(int64_t)s * slab_stride + (int64_t)i * ld_slab + j];
-        float h = (i < B && j < H) ? act_apply(enc_act, z + b) - ab : 0.f;
+    float z[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) z[k] = 0.f;
+    for (int s = 0; s < splits; ++s) {                  // 8 independent loads in flight per slab
+        const float* sl = slabs + (int64_t)s * slab_stride + (int64_t)i0 * ld_slab + j;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) z[k] += sl[(int64_t)(ty + 4 * k) * ld_slab];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int r = ty + 4 * k, i = i0 + r;
+        const float h = (i < B && j < H) ? act_apply(enc_act, z[k] + b) - ab : 0.f;
         if (h_f32) h_f32[(int64_t)i * ldh + j] = h;
         if (h_lo) h_lo[(int64_t)i * ldh + j] = Elem<T>::from(h);
         tile[r][tx] = h;
     }
     __syncthreads();
-    if (h_t) {
-#pragma unroll 4
-        for (int r = ty; r < 64; r += 4) h_t[(int64_t)(j0 + r) * ldht + i0 + tx] = Elem<T>::from(tile[tx][r]);
+    if (h_t) {                                          // 64 feature rows x 32 batch columns
+        const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int r = r0 + 8 * k;
+            h_t[(int64_t)(j0 + r) * ldht + i0 + c] = Elem<T>::from(tile[c][r]);
+        }
     }
 }
 
@@ -49,18 +59,25 @@ __global__ __launch_bounds__(256) void dh_finish_kernel(const float* __restrict_
                                                         const float* __restrict__ bh, int B, int H, int enc_act,
                                                         T* __restrict__ delta1_t, int64_t ldt, float* __restrict__ colsum_part,
                                                         int Hp, float* __restrict__ delta1_f32) {
-    __shared__ float tile[64][65];
+    __shared__ float tile[32][65];
     __shared__ float cs[2][4][64];
-    const int j0 = blockIdx.x * 64, i0 = blockIdx.y * 64;
+    const int j0 = blockIdx.x * 64, i0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int j = j0 + tx;
     const float ab = act_apply(enc_act, bh[j]);
+    float dhv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dhv[k] = 0.f;
+    for (int s = 0; s < splits; ++s) {
+        const float* sl = slabs + (int64_t)s * slab_stride + (int64_t)i0 * ld_slab + j;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dhv[k] += sl[(int64_t)(ty + 4 * k) * ld_slab];
+    }
     float s_d1 = 0.f, s_dh = 0.f;
-#pragma unroll 4
-    for (int r = ty; r < 64; r += 4) {
-        const int i = i0 + r;
-        float dh = 0.f;
-        for (int s = 0; s < splits; ++s) dh += slabs[(int64_t)s * slab_stride + (int64_t)i * ld_slab + j];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int r = ty + 4 * k, i = i0 + r;
+        float dh = dhv[k];
         if (dh_extra) dh += dh_extra[(int64_t)i * ldh + j];
         const bool ok = (i < B && j < H);
         dh = ok ? dh : 0.f;
@@ -73,13 +90,17 @@ __global__ __launch_bounds__(256) void dh_finish_kernel(const float* __restrict_
     cs[0][ty][tx] = s_d1; cs[1][ty][tx] = s_dh;
     __syncthreads();
     if (delta1_t) {
-#pragma unroll 4
-        for (int r = ty; r < 64; r += 4) delta1_t[(int64_t)(j0 + r) * ldt + i0 + tx] = Elem<T>::from(tile[tx][r]);
+        const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int r = r0 + 8 * k;
+            delta1_t[(int64_t)(j0 + r) * ldt + i0 + c] = Elem<T>::from(tile[c][r]);
+        }
     }
     if (threadIdx.x < 128) {
         const int which = threadIdx.x >> 6, c = threadIdx.x & 63;
         const float v = cs[which][0][c] + cs[which][1][c] + cs[which][2][c] + cs[which][3][c];
-        // layout [2][n_row_blocks][Hp]
+        // layout [2][n_row_blocks][Hp], n_row_blocks = Bp / 32
         colsum_part[((int64_t)which * gridDim.y + blockIdx.y) * Hp + j0 + c] = v;
     }
 }
@@ -312,15 +333,20 @@ __global__ void opt_bias_kernel(int opt, float lr, float mom, float gscale, floa
 
 // per-step statistics (autoencoder.py:233 fetch list)
 __global__ __launch_bounds__(1024) void step_stats_kernel(const float* __restrict__ rowloss_part, int n_col_waves,
+                                                          const float* __restrict__ tile_part, int n_tiles,
                                                           const float* __restrict__ cw, int B, int Bp, int triplet, float alpha,
                                                           const float* __restrict__ tri_scalars,
                                                           const int64_t* __restrict__ nvalid, float* __restrict__ stats) {
     __shared__ double sm[1024];
     double s = 0.0;
-    for (int i = threadIdx.x; i < B; i += blockDim.x) {
-        float r = 0.f;
-        for (int p = 0; p < n_col_waves; ++p) r += rowloss_part[(int64_t)p * Bp + i];
-        s += (double)(r * cw[i]);
+    if (tile_part) {                                    // per-tile weighted sums from the fused decode epilogue
+        for (int i = threadIdx.x; i < n_tiles; i += blockDim.x) s += (double)tile_part[i];
+    } else {
+        for (int i = threadIdx.x; i < B; i += blockDim.x) {
+            float r = 0.f;
+            for (int p = 0; p < n_col_waves; ++p) r += rowloss_part[(int64_t)p * Bp + i];
+            s += (double)(r * cw[i]);
+        }
     }
     const double ae = block_sum_d(s, sm);
     if (threadIdx.x == 0) {
@@ -388,7 +414,7 @@ extern "C" int dae_encode_finish(const float* slabs, int32_t splits, int64_t sla
     DAE_CHECK_ARG(slabs && bh && splits >= 1, "encode_finish: null input");
     DAE_CHECK_ARG(B > 0 && H > 0 && ldh >= dae_pad(H) && (!h_t || ldht >= dae_pad(B)), "encode_finish: bad shape");
     const int Bp = (int)dae_pad(B), Hp = (int)dae_pad(H);
-    dim3 grid(Hp / 64, Bp / 64), block(256);
+    dim3 grid(Hp / 64, Bp / 32), block(256);
     if (dtype == DAE_BF16)
         hipLaunchKernelGGL((encode_finish_kernel<bf16_t>), grid, block, 0, ST(stream), slabs, splits, slab_stride, ld_slab, bh, B,
                            H, enc_act, h_f32, (bf16_t*)h_lo, ldh, (bf16_t*)h_t, ldht);
@@ -405,7 +431,7 @@ extern "C" int dae_dh_finish(const float* slabs, int32_t splits, int64_t slab_st
     DAE_CHECK_ARG(slabs && h_f32 && bh && colsum_part, "dh_finish: null input");
     DAE_CHECK_ARG(B > 0 && H > 0 && ldh >= dae_pad(H), "dh_finish: bad shape");
     const int Bp = (int)dae_pad(B), Hp = (int)dae_pad(H);
-    dim3 grid(Hp / 64, Bp / 64), block(256);
+    dim3 grid(Hp / 64, Bp / 32), block(256);
     if (dtype == DAE_BF16)
         hipLaunchKernelGGL((dh_finish_kernel<bf16_t>), grid, block, 0, ST(stream), slabs, splits, slab_stride, ld_slab, dh_extra,
                            h_f32, ldh, bh, B, H, enc_act, (bf16_t*)delta1_t, ldt, colsum_part, Hp, delta1_f32);
@@ -507,12 +533,12 @@ extern "C" int dae_opt_step(int32_t opt, float lr, float momentum, float grad_sc
     return 0;
 }
 
-extern "C" int dae_step_stats(const float* rowloss_part, int32_t n_col_waves, const float* cw, int32_t B, int32_t Bp,
-                              int32_t triplet, float alpha, const float* tri_scalars, const int64_t* nvalid, float* stats,
-                              void* stream) {
-    DAE_CHECK_ARG(rowloss_part && cw && stats, "step_stats: null input");
+extern "C" int dae_step_stats(const float* rowloss_part, int32_t n_col_waves, const float* tile_part, int32_t n_tiles,
+                              const float* cw, int32_t B, int32_t Bp, int32_t triplet, float alpha, const float* tri_scalars,
+                              const int64_t* nvalid, float* stats, void* stream) {
+    DAE_CHECK_ARG(((rowloss_part && cw) || tile_part) && stats, "step_stats: null input");
     DAE_CHECK_ARG(triplet == DAE_TRIPLET_NONE || tri_scalars, "step_stats: tri_scalars required");
-    hipLaunchKernelGGL(step_stats_kernel, dim3(1), dim3(1024), 0, ST(stream), rowloss_part, n_col_waves, cw, B, Bp, triplet, alpha,
+    hipLaunchKernelGGL(step_stats_kernel, dim3(1), dim3(1024), 0, ST(stream), rowloss_part, n_col_waves, tile_part, n_tiles, cw, B, Bp, triplet, alpha,
                        tri_scalars, nvalid, stats);
     DAE_CHECK_LAUNCH();
     return 0;

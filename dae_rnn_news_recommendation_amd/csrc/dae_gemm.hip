@@ -25,6 +25,8 @@
 // ds_write_b128) with the loads issued before the MFMA block and the LDS write after it.
 #include "dae_kernels.h"
 
+#include <stdlib.h>
+
 #include <type_traits>
 
 namespace dae {
@@ -34,7 +36,9 @@ constexpr int BKB = 128;                 // K-tile width in bytes
 constexpr int GEMM_THREADS = 256;
 constexpr int TILE_BYTES = BM * BKB;     // 16 KiB per operand per stage
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;
-constexpr int GEMM_LDS_BYTES = 2 * STAGE_BYTES;
+// NST = number of LDS stages of the global_load_lds ring (0 = legacy register staging, 2 buffers)
+constexpr int lds_bytes_for(int nst) { return (nst < 2 ? 2 : nst) * STAGE_BYTES; }
+constexpr int wg_per_cu_for(int nst) { return nst <= 2 ? 2 : 1; }
 
 struct GemmSeg {
     const char* A;
@@ -142,7 +146,12 @@ __device__ __forceinline__ void compute_stage(const char* stage, int wm, int wn,
     }
 }
 
-template <typename T, bool GLDS>
+// K loop.  NST >= 2: ring of NST LDS stages filled by global_load_lds with COUNTED vmcnt waits -- tile i+NST-1 is
+// requested right after the barrier of iteration i (its buffer was last read in iteration i-1), and the wait in
+// front of the barrier only retires tile i, leaving up to NST-2 younger tiles (8 LDS-DMA ops per wave each) in
+// flight across the barrier.  One raw s_barrier per K tile; __syncthreads() would drain the DMA queue (its
+// fence waits vmcnt(0) while LDS-DMA writes are pending).
+template <typename T, int NST>
 __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, int tm, int tn, int kt0, int kt1, char* lds,
                                               f32x16 (&acc)[2][2]) {
     const int tid = threadIdx.x;
@@ -156,19 +165,25 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, int tm, int t
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    if (kt0 >= kt1) return;
+    const int nk = kt1 - kt0;
+    if (nk <= 0) return;
 
-    if constexpr (GLDS) {
-        stage_glds(p, kt0, row0_m, row0_n, wave, lane, lds);
-        __builtin_amdgcn_s_waitcnt(0);      // vmcnt(0) expcnt(0) lgkmcnt(0)
-        __syncthreads();
-        for (int kt = kt0; kt < kt1; ++kt) {
-            char* cur = lds + ((kt - kt0) & 1) * STAGE_BYTES;
-            char* nxt = lds + (((kt - kt0) & 1) ^ 1) * STAGE_BYTES;
-            if (kt + 1 < kt1) stage_glds(p, kt + 1, row0_m, row0_n, wave, lane, nxt);
-            compute_stage<T>(cur, wm, wn, lane, acc);
-            __builtin_amdgcn_s_waitcnt(0);
-            __syncthreads();
+    if constexpr (NST >= 2) {
+#pragma unroll
+        for (int s = 0; s < NST - 1; ++s)
+            if (s < nk) stage_glds(p, kt0 + s, row0_m, row0_n, wave, lane, lds + s * STAGE_BYTES);
+        int cur = 0, nxt = NST - 1;                       // ring positions of tile i and of tile i+NST-1
+        for (int i = 0; i < nk; ++i) {
+            const int ahead = min(NST - 2, nk - 1 - i);   // younger tiles that may stay in flight
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (i + NST - 1 < nk) stage_glds(p, kt0 + i + NST - 1, row0_m, row0_n, wave, lane, lds + nxt * STAGE_BYTES);
+            compute_stage<T>(lds + cur * STAGE_BYTES, wm, wn, lane, acc);
+            cur = (cur + 1 == NST) ? 0 : cur + 1;
+            nxt = (nxt + 1 == NST) ? 0 : nxt + 1;
         }
     } else {
         StageRegs regs;
@@ -200,14 +215,14 @@ __device__ __forceinline__ void block_to_tile(const GemmParams& p, int& tm, int&
 // ------------------------------------------------------------------------------------------------
 // plain fp32-output kernel (split-K slabs or final C)
 // ------------------------------------------------------------------------------------------------
-template <typename T, bool GLDS>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32out(GemmParams p, float* __restrict__ C, int64_t ldc,
-                                                                  int64_t slab_stride) {
+template <typename T, int NST>
+__global__ __launch_bounds__(GEMM_THREADS, wg_per_cu_for(NST)) void gemm_nt_f32out(GemmParams p, float* __restrict__ C, int64_t ldc,
+                                                                                   int64_t slab_stride) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     int tm, tn, split, kt0, kt1;
     block_to_tile(p, tm, tn, split, kt0, kt1);
     f32x16 acc[2][2];
-    gemm_mainloop<T, GLDS>(p, tm, tn, kt0, kt1, lds, acc);
+    gemm_mainloop<T, NST>(p, tm, tn, kt0, kt1, lds, acc);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1, g = lane >> 5, c = lane & 31;
     float* Cs = C + (int64_t)split * slab_stride;
@@ -226,7 +241,21 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_f32out(GemmParams p, 
 // ------------------------------------------------------------------------------------------------
 // decode kernel: GEMM + bias + activation + reconstruction loss + d cost/d z2 (+ bias-gradient partials)
 // autoencoder.py:411, triplet_loss_utils.py:262-277
+//
+// Epilogue data flow (bf16, "STAGED"): the clean-input tile x[128x128] is prefetched into registers with
+// coalesced 16-byte loads BEFORE the K loop (its HBM latency hides under the MFMAs), parked in LDS after the
+// loop and read per accumulator element from there; delta2 is written back into the same LDS cell, delta2^T
+// into a second LDS tile, and both leave the CU as coalesced 16-byte row segments.  Row sums (loss) and
+// column sums (db_v) are accumulated with LDS float atomics whose addresses are private to one wave, so the
+// addition order -- and the result -- is deterministic.  fp32 (parity mode) keeps direct global accesses.
+// LOSS / ACT are compile-time so the hot specialisation (cross_entropy + sigmoid) carries no dead code.
 // ------------------------------------------------------------------------------------------------
+constexpr int EPI_PITCH = 272;                       // bytes per staged row: 128 bf16 + 16 B pad (bank shift of 4 rows)
+constexpr int EPI_TILE_BYTES = 128 * EPI_PITCH;      // 34816
+constexpr int EPI_AUX_OFF = 2 * EPI_TILE_BYTES;      // 69632 (>= the 64 KiB of the K-loop stages)
+constexpr int EPI_AUX_FLOATS = 13 * 128;
+constexpr int DECODE_EPI_BYTES = EPI_AUX_OFF + EPI_AUX_FLOATS * 4;   // 76288 (epilogue footprint; the K loop may need more)
+
 template <typename T> __device__ __forceinline__ void store4(T* p, float a, float b, float c, float d);
 template <> __device__ __forceinline__ void store4<float>(float* p, float a, float b, float c, float d) {
     f32x4 v = {a, b, c, d};
@@ -239,112 +268,190 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float a, f
     *reinterpret_cast<uint2*>(p) = v;
 }
 
-__device__ __forceinline__ float half_sum32(float v) {   // sum over the 32 lanes sharing lane>>5
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
+
+template <int ACT> __device__ __forceinline__ float act_fwd(float z) {
+    if constexpr (ACT == DAE_ACT_SIGMOID) {
+        const float en = __builtin_amdgcn_exp2f(-fabsf(z) * kLog2e);      // exp(-|z|) in (0,1]
+        const float r = __builtin_amdgcn_rcpf(1.0f + en);
+        return z >= 0.f ? r : en * r;
+    } else if constexpr (ACT == DAE_ACT_TANH) {
+        const float e2 = __builtin_amdgcn_exp2f(-2.0f * fabsf(z) * kLog2e);   // exp(-2|z|)
+        const float t = (1.0f - e2) * __builtin_amdgcn_rcpf(1.0f + e2);
+        return z >= 0.f ? t : -t;
+    } else {
+        return z;
+    }
+}
+template <int ACT> __device__ __forceinline__ float act_bwd(float a) {
+    if constexpr (ACT == DAE_ACT_SIGMOID) return a * (1.0f - a);
+    else if constexpr (ACT == DAE_ACT_TANH) return 1.0f - a * a;
+    else return 1.0f;
 }
 
-template <typename T, bool GLDS>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_decode_loss(GemmParams p, DecodeEpi e) {
+constexpr int DECODE_NST = 2;
+template <typename T, int LOSS, int ACT>
+__global__ __launch_bounds__(GEMM_THREADS, wg_per_cu_for(DECODE_NST)) void gemm_decode_loss(GemmParams p, DecodeEpi e) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr bool STAGED = (sizeof(T) == 2);
+    constexpr bool IS_COS = (LOSS == DAE_LOSS_COSINE);
     int tm, tn, split, kt0, kt1;
     block_to_tile(p, tm, tn, split, kt0, kt1);
-    f32x16 acc[2][2];
-    gemm_mainloop<T, GLDS>(p, tm, tn, kt0, kt1, lds, acc);
-
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, g = lane >> 5, c = lane & 31;
     const T* X = reinterpret_cast<const T*>(e.x);
     T* D2 = reinterpret_cast<T*>(e.delta2);
     T* D2T = reinterpret_cast<T*>(e.delta2_t);
-    const int colbase = tn * BN + wn * 64 + c;
-    const int rowbase = tm * BM + wm * 64 + 4 * g;
-    const float eps = 1e-16f;
-    const bool is_cos = e.loss_func == DAE_LOSS_COSINE;
+    const bool pass1 = IS_COS && e.cos_pass == 1;
 
-    float bvv[2];
-    bool colok[2];
+    // ---- prefetch the clean-input tile (registers now, LDS after the K loop) ----
+    i32x4 xr[8];
+    if constexpr (STAGED) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int ch = tid + GEMM_THREADS * i;
+            const int row = ch >> 4, c16 = ch & 15;
+            xr[i] = *reinterpret_cast<const i32x4*>(X + (int64_t)(tm * BM + row) * e.ldx + tn * BN + c16 * 8);
+        }
+    }
+
+    f32x16 acc[2][2];
+    gemm_mainloop<T, DECODE_NST>(p, tm, tn, kt0, kt1, lds, acc);
+    __syncthreads();                                   // every wave is done with the K-loop stages
+
+    char* R0 = lds;                                    // x tile, overwritten in place by delta2   [128][EPI_PITCH]
+    char* R1 = lds + EPI_TILE_BYTES;                   // delta2^T tile                             [128][EPI_PITCH]
+    float* aux = reinterpret_cast<float*>(lds + EPI_AUX_OFF);
+    float* cw_l = aux;                                 // [128] row weights
+    float* bv_l = aux + 128;                           // [128] visible bias
+    float* rowsum_l = aux + 256;                       // [2 (wn)][128]
+    float* colsum_l = aux + 512;                       // [2 (wm)][128]
+    float* inx_l = aux + 768;                          // [128] 1/|x|            (cosine)
+    float* cyy_l = aux + 896;                          // [128] sum y^2          (cosine pass 2)
+    float* cxy_l = aux + 1024;                         // [128] sum xhat.y       (cosine pass 2)
+    float* pyy_l = aux + 1152;                         // [2][128] partial sum y^2   (cosine pass 1)
+    float* pxy_l = aux + 1408;                         // [2][128] partial sum xhat.y
+
+    if constexpr (STAGED) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int ch = tid + GEMM_THREADS * i;
+            const int row = ch >> 4, c16 = ch & 15;
+            *reinterpret_cast<i32x4*>(R0 + row * EPI_PITCH + c16 * 16) = xr[i];
+        }
+    }
+    if (tid < 128) {
+        const int row = tm * BM + tid, col = tn * BN + tid;
+        cw_l[tid] = e.cw[row];                         // zero beyond B by construction
+        bv_l[tid] = col < e.F ? e.bv[col] : 0.f;
+        if constexpr (IS_COS) {
+            inx_l[tid] = rsqrtf(fmaxf(e.cos_stats[row], 1e-12f));
+            cyy_l[tid] = e.cos_pass == 2 ? e.cos_stats[e.Bp + row] : 0.f;
+            cxy_l[tid] = e.cos_pass == 2 ? e.cos_stats[2 * e.Bp + row] : 0.f;
+        }
+    }
+    __syncthreads();
+
+    const int lcol0 = wn * 64 + c;                     // local column of nt = 0
+    const int lrow0 = wm * 64 + 4 * g;                 // local row of (mt = 0, r = 0)
+    const float eps = 1e-16f;
+    float colsum[2] = {0.f, 0.f};
+    float cm[2], bvv[2];                               // column mask as a multiplier: padded features contribute nothing
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
-        int col = colbase + nt * 32;
-        colok[nt] = col < e.F;
-        bvv[nt] = colok[nt] ? e.bv[col] : 0.f;
+        cm[nt] = (tn * BN + lcol0 + nt * 32) < e.F ? 1.f : 0.f;
+        bvv[nt] = bv_l[lcol0 + nt * 32];
     }
-    float colsum[2] = {0.f, 0.f};
+    // per-lane base addresses; everything else is a compile-time offset
+    char* r0_lane = R0 + lrow0 * EPI_PITCH + lcol0 * 2;
+    char* r1_lane = R1 + lcol0 * EPI_PITCH + lrow0 * 2;
+    const T* x_lane = X + (int64_t)(tm * BM + lrow0) * e.ldx + tn * BN + lcol0;
+    T* d2_lane = D2 ? D2 + (int64_t)(tm * BM + lrow0) * e.ldd + tn * BN + lcol0 : nullptr;
+    T* d2t_lane = D2T ? D2T + (int64_t)(tn * BN + lcol0) * e.lddt + tm * BM + lrow0 : nullptr;
 
     // static (compile-time) accumulator indexing: a runtime-indexed f32x16 would be demoted to scratch
     auto epi_block = [&](auto MT, auto R4) {
         constexpr int mt = decltype(MT)::value, r4 = decltype(R4)::value;
-            float d2v[2][4];
+        constexpr int rloc = mt * 32 + 8 * r4;         // local row offset of q = 0 relative to lrow0
+        float d2v[2][4];
+        float xin[4][2];
+        if constexpr (!STAGED) {                       // fp32: batch the 8 global loads of this block
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int r = r4 * 4 + q;
-                const int row = rowbase + mt * 32 + 8 * r4 + q;
-                const bool rowok = row < e.B;
-                const float cwi = e.cw[row];                  // zero beyond B by construction
-                float rl = 0.f, s_yy = 0.f, s_xy = 0.f;
-                // cosine_proximity (tf.nn.l2_normalize on both operands, triplet_loss_utils.py:273):
-                // cos_stats = [sum x^2 | sum y^2 | sum xhat.y] per row; pass 1 produces the last two.
-                float inx = 0.f, cs_yy = 0.f, cs_xy = 0.f;
-                if (is_cos) {
-                    inx = rsqrtf(fmaxf(e.cos_stats[row], 1e-12f));
-                    if (e.cos_pass == 2) { cs_yy = e.cos_stats[e.Bp + row]; cs_xy = e.cos_stats[2 * e.Bp + row]; }
-                }
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    const int col = colbase + nt * 32;
-                    const bool ok = rowok && colok[nt];
-                    float z = acc[mt][nt][r] + bvv[nt];
-                    float y = act_apply(e.dec_act, z);
-                    float x = ok ? Elem<T>::to(X[(int64_t)row * e.ldx + col]) : 0.f;
-                    float l = 0.f, dy = 0.f;
-                    if (e.loss_func == DAE_LOSS_CROSS_ENTROPY) {
-                        float a = y + eps, b = (1.0f - y) + eps;      // reference op order: (1.-y)+1e-16
-                        l = -(x * __logf(a) + (1.0f - x) * __logf(b));
-                        dy = -(x / a - (1.0f - x) / b);               // TF differentiates the two logs separately
-                    } else if (e.loss_func == DAE_LOSS_MEAN_SQUARED) {
-                        float d = x - y;
-                        l = d * d;
-                        dy = -2.0f * d;
+                for (int nt = 0; nt < 2; ++nt) xin[q][nt] = Elem<T>::to(x_lane[(int64_t)(rloc + q) * e.ldx + nt * 32]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            constexpr int rbase = r4 * 4;
+            const int r = rbase + q;
+            const int lrow = lrow0 + rloc + q;
+            const float cwi = cw_l[lrow];
+            float rl = 0.f, s_yy = 0.f, s_xy = 0.f;
+            float inx = 0.f, cs_yy = 0.f, cs_xy = 0.f;
+            if constexpr (IS_COS) { inx = inx_l[lrow]; cs_yy = cyy_l[lrow]; cs_xy = cxy_l[lrow]; }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const float z = acc[mt][nt][r] + bvv[nt];
+                const float y = act_fwd<ACT>(z);
+                float x;
+                if constexpr (STAGED) x = bf2f(*reinterpret_cast<const bf16_t*>(r0_lane + (rloc + q) * EPI_PITCH + nt * 64));
+                else x = xin[q][nt];
+                float l = 0.f, dy = 0.f;
+                if constexpr (LOSS == DAE_LOSS_CROSS_ENTROPY) {
+                    const float a = y + eps, b = (1.0f - y) + eps;          // reference op order: (1.-y)+1e-16
+                    const float la = __builtin_amdgcn_logf(a), lb = __builtin_amdgcn_logf(b);   // log2; a, b >= 1e-16 (normal)
+                    l = -kLn2 * (x * la + (1.0f - x) * lb);
+                    dy = (1.0f - x) * __builtin_amdgcn_rcpf(b) - x * __builtin_amdgcn_rcpf(a);  // the two logs are differentiated separately
+                } else if constexpr (LOSS == DAE_LOSS_MEAN_SQUARED) {
+                    const float d = x - y;
+                    l = d * d;
+                    dy = -2.0f * d;
+                } else {
+                    const float xh = x * inx;
+                    if (pass1) {
+                        s_yy += cm[nt] * y * y;
+                        s_xy += cm[nt] * xh * y;
                     } else {
-                        float xh = x * inx;
-                        if (e.cos_pass == 1) {
-                            s_yy += ok ? y * y : 0.f;
-                            s_xy += ok ? xh * y : 0.f;
-                        } else {
-                            float big = cs_yy >= 1e-12f ? 1.f : 0.f;  // tf.maximum routes grad to sum y^2 iff >= eps
-                            float s = rsqrtf(fmaxf(cs_yy, 1e-12f));
-                            dy = -(xh * s - big * cs_xy * s * s * s * y);
-                        }
+                        const float big = cs_yy >= 1e-12f ? 1.f : 0.f;      // tf.maximum routes grad to sum y^2 iff >= eps
+                        const float s = rsqrtf(fmaxf(cs_yy, 1e-12f));
+                        dy = -(xh * s - big * cs_xy * s * s * s * y);
                     }
-                    float d2 = (ok && e.cos_pass != 1) ? cwi * dy * act_grad(e.dec_act, y) : 0.f;
-                    rl += ok ? l : 0.f;
-                    d2v[nt][q] = d2;
-                    colsum[nt] += d2;
-                    if (e.y_out && ok) e.y_out[(int64_t)row * e.ldy + col] = y;
-                    if (D2 && e.cos_pass != 1) D2[(int64_t)row * e.ldd + col] = Elem<T>::from(d2);
                 }
-                if (e.cos_pass == 1) {
-                    s_yy = half_sum32(s_yy); s_xy = half_sum32(s_xy);
-                    if (c == 0) {
-                        int pw = tn * 2 + wn;
-                        e.cos_part[(int64_t)pw * e.Bp + row] = s_yy;
-                        e.cos_part[(int64_t)(2 * p.tiles_n + pw) * e.Bp + row] = s_xy;
-                    }
-                } else if (!is_cos) {
-                    rl = half_sum32(rl);
-                    if (c == 0) e.rowloss_part[(int64_t)(tn * 2 + wn) * e.Bp + row] = rl;
+                const float d2 = pass1 ? 0.f : (cwi * cm[nt]) * dy * act_bwd<ACT>(y);   // cw is 0 on padded rows
+                rl += cm[nt] * l;
+                d2v[nt][q] = d2;
+                colsum[nt] += d2;
+                if constexpr (STAGED) {
+                    *reinterpret_cast<bf16_t*>(r0_lane + (rloc + q) * EPI_PITCH + nt * 64) = f2bf_hw(d2);
+                } else {
+                    if (d2_lane && !pass1) d2_lane[(int64_t)(rloc + q) * e.ldd + nt * 32] = Elem<T>::from(d2);
                 }
             }
-            if (D2T && e.cos_pass != 1) {
-                const int row0 = rowbase + mt * 32 + 8 * r4;
+            // wavefront (DPP) sum over the 32 lanes that share this row; lanes 16..31 / 48..63 hold it
+            if constexpr (IS_COS) {
+                if (pass1) {
+                    s_yy = half32_sum_hi(s_yy); s_xy = half32_sum_hi(s_xy);
+                    if (c == 31) { pyy_l[wn * 128 + lrow] = s_yy; pxy_l[wn * 128 + lrow] = s_xy; }
+                }
+            } else {
+                rl = half32_sum_hi(rl);
+                if (c == 31) rowsum_l[wn * 128 + lrow] = rl;
+            }
+        }
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    const int col = colbase + nt * 32;
-                    store4<T>(D2T + (int64_t)col * e.lddt + row0, d2v[nt][0], d2v[nt][1], d2v[nt][2], d2v[nt][3]);
-                }
+        for (int nt = 0; nt < 2; ++nt) {
+            if constexpr (STAGED) {
+                uint2 v;
+                v.x = f2bf_pack_hw(d2v[nt][0], d2v[nt][1]);
+                v.y = f2bf_pack_hw(d2v[nt][2], d2v[nt][3]);
+                *reinterpret_cast<uint2*>(r1_lane + nt * 32 * EPI_PITCH + rloc * 2) = v;
+            } else {
+                if (d2t_lane && !pass1)
+                    store4<T>(d2t_lane + (int64_t)nt * 32 * e.lddt + rloc, d2v[nt][0], d2v[nt][1], d2v[nt][2], d2v[nt][3]);
             }
+        }
     };
 #define DAE_EPI_ROWS(MTV)                                                                       \
     epi_block(std::integral_constant<int, MTV>{}, std::integral_constant<int, 0>{});            \
@@ -354,19 +461,59 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_decode_loss(GemmParams p
     DAE_EPI_ROWS(0)
     DAE_EPI_ROWS(1)
 #undef DAE_EPI_ROWS
-    if (e.dbv_part && e.cos_pass != 1) {
+    if (!pass1) {                                       // column sums: rows of g = 0 and g = 1, then one lane per column
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-            float v = colsum[nt] + __shfl_xor(colsum[nt], 32, 64);
-            if (g == 0) e.dbv_part[(int64_t)(tm * 2 + wm) * e.Fp + colbase + nt * 32] = v;
+            const float v = colsum[nt] + __shfl_xor(colsum[nt], 32, 64);
+            if (g == 0) colsum_l[wm * 128 + lcol0 + nt * 32] = v;
         }
+    }
+    __syncthreads();
+
+    // ---- leave the CU: coalesced tiles and per-wave partial sums ----
+    if constexpr (STAGED) {
+        if (!pass1) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int ch = tid + GEMM_THREADS * i;
+                const int row = ch >> 4, c16 = ch & 15;
+                if (D2)
+                    *reinterpret_cast<i32x4*>(D2 + (int64_t)(tm * BM + row) * e.ldd + tn * BN + c16 * 8) =
+                        *reinterpret_cast<const i32x4*>(R0 + row * EPI_PITCH + c16 * 16);
+                if (D2T)
+                    *reinterpret_cast<i32x4*>(D2T + (int64_t)(tn * BN + row) * e.lddt + tm * BM + c16 * 8) =
+                        *reinterpret_cast<const i32x4*>(R1 + row * EPI_PITCH + c16 * 16);
+            }
+        }
+    }
+    {
+        const int w = tid >> 7, k = tid & 127;          // 256 threads = 2 partial rows x 128
+        const bool rowok = (tm * BM + k) < e.B;
+        if constexpr (IS_COS) {
+            if (pass1) {
+                e.cos_part[(int64_t)(tn * 2 + w) * e.Bp + tm * BM + k] = rowok ? pyy_l[w * 128 + k] : 0.f;
+                e.cos_part[(int64_t)(2 * p.tiles_n + tn * 2 + w) * e.Bp + tm * BM + k] = rowok ? pxy_l[w * 128 + k] : 0.f;
+            }
+        } else {
+            if (e.rowloss_part) e.rowloss_part[(int64_t)(tn * 2 + w) * e.Bp + tm * BM + k] = rowok ? rowsum_l[w * 128 + k] : 0.f;
+        }
+        if (e.dbv_part && !pass1) e.dbv_part[(int64_t)(tm * 2 + w) * e.Fp + tn * BN + k] = colsum_l[w * 128 + k];
+    }
+    if constexpr (!IS_COS) {
+        if (e.tile_part && tid < 128) {                 // this tile's share of sum_i cw_i * rowloss_i (2 waves, fixed order)
+            float v = cw_l[tid] * (rowsum_l[tid] + rowsum_l[128 + tid]);
+            v = wave64_sum_hi(v);
+            if (lane == 63) pyy_l[wave] = v;            // pyy_l is unused outside cosine
+        }
+        __syncthreads();
+        if (e.tile_part && tid == 0) e.tile_part[tm * p.tiles_n + tn] = pyy_l[0] + pyy_l[1];
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------------
-static bool g_use_glds = true;
+static int g_nst = 2;   // staging variant of the plain GEMM: 0 register-staged, 2/3/4 global_load_lds ring depth
 
 static int fill_params(GemmParams& p, int dtype, int M, int N, const void* A0, int64_t lda0, const void* Bt0,
                        int64_t ldb0, int K0, const void* A1, int64_t lda1, const void* Bt1, int64_t ldb1, int K1,
@@ -390,21 +537,40 @@ static int fill_params(GemmParams& p, int dtype, int M, int N, const void* A0, i
     return 0;
 }
 
-template <typename K> static int set_lds(K kernel) {
-    DAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      GEMM_LDS_BYTES));
-    return 0;
+constexpr int DECODE_LDS_BYTES = lds_bytes_for(DECODE_NST) > DECODE_EPI_BYTES ? lds_bytes_for(DECODE_NST) : DECODE_EPI_BYTES;
+
+typedef void (*f32out_fn)(GemmParams, float*, int64_t, int64_t);
+template <typename T> static f32out_fn f32out_kernel(int nst) {
+    switch (nst) {
+        case 0: return gemm_nt_f32out<T, 0>;
+        case 3: return gemm_nt_f32out<T, 3>;
+        case 4: return gemm_nt_f32out<T, 4>;
+        default: return gemm_nt_f32out<T, 2>;
+    }
+}
+typedef void (*decode_fn)(GemmParams, DecodeEpi);
+template <typename T> static decode_fn decode_kernel(int loss, int act) {
+#define DAE_DK(LV, AV) if (loss == LV && act == AV) return gemm_decode_loss<T, LV, AV>;
+    DAE_DK(0, 0) DAE_DK(0, 1) DAE_DK(0, 2) DAE_DK(1, 0) DAE_DK(1, 1) DAE_DK(1, 2) DAE_DK(2, 0) DAE_DK(2, 1) DAE_DK(2, 2)
+#undef DAE_DK
+    return nullptr;
 }
 static int gemm_init() {
     static int rc = [] {
-        if (int r = set_lds(gemm_nt_f32out<bf16_t, true>)) return r;
-        if (int r = set_lds(gemm_nt_f32out<bf16_t, false>)) return r;
-        if (int r = set_lds(gemm_nt_f32out<float, true>)) return r;
-        if (int r = set_lds(gemm_nt_f32out<float, false>)) return r;
-        if (int r = set_lds(gemm_decode_loss<bf16_t, true>)) return r;
-        if (int r = set_lds(gemm_decode_loss<bf16_t, false>)) return r;
-        if (int r = set_lds(gemm_decode_loss<float, true>)) return r;
-        if (int r = set_lds(gemm_decode_loss<float, false>)) return r;
+        const int nsts[4] = {0, 2, 3, 4};
+        for (int n : nsts) {
+            DAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(f32out_kernel<bf16_t>(n)),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes_for(n)));
+            DAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(f32out_kernel<float>(n)),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes_for(n)));
+        }
+        for (int l = 0; l < 3; ++l)
+            for (int a = 0; a < 3; ++a) {
+                DAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decode_kernel<bf16_t>(l, a)),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, DECODE_LDS_BYTES));
+                DAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decode_kernel<float>(l, a)),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, DECODE_LDS_BYTES));
+            }
         return 0;
     }();
     return rc;
@@ -418,13 +584,9 @@ int launch_gemm_f32out(int dtype, int M, int N, const void* A0, int64_t lda0, co
     DAE_CHECK_ARG(C != nullptr, "gemm: C is null");
     if (int rc = gemm_init()) return rc;
     dim3 grid(p.tiles_m * p.tiles_n * p.splits), block(GEMM_THREADS);
-#define DAE_LAUNCH_F32OUT(T, G)                                                              \
-    do {                                                                                     \
-        hipLaunchKernelGGL((gemm_nt_f32out<T, G>), grid, block, GEMM_LDS_BYTES, st, p, C, ldc, slab_stride); \
-    } while (0)
-    if (dtype == DAE_BF16) { if (g_use_glds) DAE_LAUNCH_F32OUT(bf16_t, true); else DAE_LAUNCH_F32OUT(bf16_t, false); }
-    else                   { if (g_use_glds) DAE_LAUNCH_F32OUT(float, true);  else DAE_LAUNCH_F32OUT(float, false); }
-#undef DAE_LAUNCH_F32OUT
+    const int nst = g_nst;
+    f32out_fn k = dtype == DAE_BF16 ? f32out_kernel<bf16_t>(nst) : f32out_kernel<float>(nst);
+    hipLaunchKernelGGL(k, grid, block, lds_bytes_for(nst == 0 || nst == 3 || nst == 4 ? nst : 2), st, p, C, ldc, slab_stride);
     DAE_CHECK_LAUNCH();
     return 0;
 }
@@ -434,18 +596,16 @@ int launch_decode_loss(int dtype, int Bp, int Fp, int Hp, const void* h_lo, int6
     GemmParams p;
     if (int rc = fill_params(p, dtype, Bp, Fp, h_lo, ldh, W_lo, ldw, Hp, nullptr, 0, nullptr, 0, 0, 1)) return rc;
     if (int rc = gemm_init()) return rc;
+    DAE_CHECK_ARG(e.dec_act >= 0 && e.dec_act <= 2 && e.loss_func >= 0 && e.loss_func <= 2, "decode_loss: bad act/loss");
+    DAE_CHECK_ARG(e.ldx % 8 == 0 && (!e.delta2 || e.ldd % 8 == 0) && (!e.delta2_t || e.lddt % 8 == 0),
+                  "decode_loss: leading dimensions must be multiples of 8 elements");
+    decode_fn k = dtype == DAE_BF16 ? decode_kernel<bf16_t>(e.loss_func, e.dec_act) : decode_kernel<float>(e.loss_func, e.dec_act);
     dim3 grid(p.tiles_m * p.tiles_n), block(GEMM_THREADS);
-#define DAE_LAUNCH_DEC(T, G)                                                                 \
-    do {                                                                                     \
-        hipLaunchKernelGGL((gemm_decode_loss<T, G>), grid, block, GEMM_LDS_BYTES, st, p, e); \
-    } while (0)
-    if (dtype == DAE_BF16) { if (g_use_glds) DAE_LAUNCH_DEC(bf16_t, true); else DAE_LAUNCH_DEC(bf16_t, false); }
-    else                   { if (g_use_glds) DAE_LAUNCH_DEC(float, true);  else DAE_LAUNCH_DEC(float, false); }
-#undef DAE_LAUNCH_DEC
+    hipLaunchKernelGGL(k, grid, block, DECODE_LDS_BYTES, st, p, e);
     DAE_CHECK_LAUNCH();
     return 0;
 }
 
-void set_use_glds(bool v) { g_use_glds = v; }
+void set_use_glds(int nst) { g_nst = nst; }
 
 }  // namespace dae

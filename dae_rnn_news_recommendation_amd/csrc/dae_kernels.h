@@ -11,12 +11,12 @@ struct DecodeEpi {
     int64_t ldx;
     const float* cw;          // [Bp] w_i / (sum w + 1e-16), zero for i >= B
     const float* cos_stats;   // cosine: [3 x Bp] = {sum x^2 | sum y^2 | sum xhat.y}; NULL otherwise
-    float* rowloss_part;      // [2*tiles_n x Bp]
+    float* rowloss_part;      // [2*tiles_n x Bp] per-row partial sums (may be NULL)
+    float* tile_part;         // [tiles_m*tiles_n] sum_rows cw_i * rowloss_i of each tile (may be NULL)
     float* dbv_part;          // [2*tiles_m x Fp]
     float* cos_part;          // cosine first pass: [2 x 2*tiles_n x Bp] partial {sum y^2, sum xhat*y}
     void* delta2; int64_t ldd;
     void* delta2_t; int64_t lddt;
-    float* y_out; int64_t ldy;
     int B, F, Bp, Fp;
     int dec_act, loss_func;
     int cos_pass;             // 0: not cosine, 1: statistics pass, 2: final pass
@@ -27,6 +27,6 @@ int launch_gemm_f32out(int dtype, int M, int N, const void* A0, int64_t lda0, co
                        int64_t slab_stride, hipStream_t st);
 int launch_decode_loss(int dtype, int Bp, int Fp, int Hp, const void* h_lo, int64_t ldh, const void* W_lo, int64_t ldw,
                        const DecodeEpi& e, hipStream_t st);
-void set_use_glds(bool v);
+void set_use_glds(int nst);
 
 }  // namespace dae

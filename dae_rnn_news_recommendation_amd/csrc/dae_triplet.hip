@@ -62,6 +62,67 @@ __device__ __forceinline__ float sigmoid_only(float t) {
     return t >= 0.f ? r : en * r;
 }
 
+// Sweep of the |P| x |N| rectangle of one anchor.  Work split: WAVE w owns the positives p = w, w+4, w+8, ...
+// and walks ALL negatives in chunks of 64*Q (lane l keeps negatives k0 + q*64 + l, q < Q, in registers), so a
+// positive's gradient is complete inside one wave and the per-positive overhead is amortised over Q pairs per
+// lane.  Each (p, n) pair is evaluated once: softplus for the loss, sigmoid for both gradient roles.
+//   positive role: sum over the wave's lanes with a wavefront DPP reduction (VALU operand path, no LDS round
+//                  trip), accumulated by lane 63 into gpos[p] -- a single owner, fixed order, deterministic;
+//   negative role: per-wave partial sums in registers, parked in gneg_w[wave][k] and added up over the 4 waves
+//                  in wave order at the end.
+// Lanes without a negative carry v = -inf: v - u = -inf gives softplus = 0, sigmoid = 0, "positive" = false,
+// so the hot loop needs no masks.
+constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
+
+template <bool POS_ONLY, int Q>
+__device__ __forceinline__ void sweep_pairs(const float* __restrict__ pu, const float* __restrict__ nv, int nP, int nN,
+                                            int k0, int wave, int lane, float* __restrict__ gpos,
+                                            unsigned* __restrict__ cpos, float* __restrict__ gneg_w,
+                                            unsigned* __restrict__ cneg_w, float& loss, unsigned& cnt) {
+    float v[Q], gs[Q];
+    unsigned rc[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int k = k0 + q * 64 + lane;
+        v[q] = (k < nN) ? nv[k] : -INFINITY;
+        gs[q] = 0.f; rc[q] = 0u;
+    }
+#pragma unroll 2
+    for (int p = wave; p < nP; p += 4) {
+        const float u = pu[p];
+        float sgp = 0.f;
+        unsigned cp = 0u;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const float t = v[q] - u;                                   // triplet_distance[a,p,n]  (:106)
+            const float en = __builtin_amdgcn_exp2f(-fabsf(t) * kLog2e);    // exp(-|t|) in [0,1]
+            const float w = 1.0f + en;
+            const float r = __builtin_amdgcn_rcpf(w);
+            const float l = en < 1e-4f ? en * (1.0f - 0.5f * en) : kLn2 * __builtin_amdgcn_logf(w);   // log1p(en)
+            const float sp = fmaxf(t, 0.f) + l;                         // softplus(t) = -log_sigmoid(-t)  (:126)
+            const float sg = t >= 0.f ? r : en * r;                     // sigmoid(t) = SoftplusGrad
+            const bool pos = t > 1e-16f;                                // (:114)
+            loss += POS_ONLY ? (pos ? sp : 0.f) : sp;
+            const float sgu = POS_ONLY ? (pos ? sg : 0.f) : sg;
+            gs[q] += sgu;
+            sgp += sgu;
+            cnt += pos ? 1u : 0u;
+            if (POS_ONLY) { rc[q] += pos ? 1u : 0u; cp += pos ? 1u : 0u; }
+        }
+        sgp = wave64_sum_hi(sgp);
+        if (POS_ONLY) cp = wave_sum_u32(cp);
+        if (lane == 63) {
+            gpos[p] += sgp;
+            if (POS_ONLY) cpos[p] += cp;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int k = k0 + q * 64 + lane;
+        if (k < nN) { gneg_w[k] = gs[q]; if (POS_ONLY) cneg_w[k] = rc[q]; }
+    }
+}
+
 template <bool POS_ONLY>
 __global__ __launch_bounds__(TRIP_THREADS) void batch_all_kernel(const float* __restrict__ D_slabs, int d_splits,
                                                                  int64_t slab_stride, int64_t ldd,
@@ -69,26 +130,33 @@ __global__ __launch_bounds__(TRIP_THREADS) void batch_all_kernel(const float* __
                                                                  float* __restrict__ loss_part, uint32_t* __restrict__ npos_part,
                                                                  float* __restrict__ G, uint32_t* __restrict__ role_cnt) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* pu = reinterpret_cast<float*>(smem);              // positives' D[a,p]      [Bp]
-    float* nv = pu + Bp;                                      // negatives' D[a,n]      [Bp]
-    int* pidx = reinterpret_cast<int*>(nv + Bp);              // [Bp]
-    int* nidx = pidx + Bp;                                    // [Bp]
-    int* scan = nidx + Bp;                                    // [2][TRIP_THREADS + 1]
-    float* red = reinterpret_cast<float*>(scan + 2 * (TRIP_THREADS + 1));   // [8]
-    unsigned* redu = reinterpret_cast<unsigned*>(red + 4);
+    // positives are compacted from the front of val[]/idx[], negatives from the back (nP + nN <= B)
+    float* val = reinterpret_cast<float*>(smem);             // [Bp]
+    int* idx = reinterpret_cast<int*>(val + Bp);              // [Bp]
+    float* gpos = reinterpret_cast<float*>(idx + Bp);         // [Bp]    positive-role gradient sums (one owner wave each)
+    float* gneg = gpos + Bp;                                  // [4][Bp] per-wave negative-role partial sums
+    int* scan = reinterpret_cast<int*>(gneg + 4 * Bp);        // [2][TRIP_THREADS + 1]
+    float* red = reinterpret_cast<float*>(scan + 2 * (TRIP_THREADS + 1));   // [4]
+    unsigned* redu = reinterpret_cast<unsigned*>(red + 4);    // [4]
+    unsigned* cpos = POS_ONLY ? redu + 4 : nullptr;           // [Bp]    (pos_only role counts)
+    unsigned* cneg = POS_ONLY ? cpos + Bp : nullptr;          // [4][Bp]
 
     const int a = blockIdx.x;
     const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
     const int32_t la = labels[a];
     float* Grow = G + (int64_t)a * Bp;
     uint32_t* Rrow = POS_ONLY ? role_cnt + (int64_t)a * Bp : nullptr;
 
-    // zero the gradient row (covers j == a, j >= B)
-    for (int j = tid; j < Bp; j += TRIP_THREADS) { Grow[j] = 0.f; if (POS_ONLY) Rrow[j] = 0u; }
+    // zero the gradient row (covers j == a and j >= B) and the positive-role accumulators
+    for (int j = tid; j < Bp; j += TRIP_THREADS) {
+        Grow[j] = 0.f; gpos[j] = 0.f;
+        if (POS_ONLY) { Rrow[j] = 0u; cpos[j] = 0u; }
+    }
 
     // ---- deterministic compaction: thread t owns the contiguous index range [t*C, (t+1)*C) ----
     const int C = (B + TRIP_THREADS - 1) / TRIP_THREADS;
-    const int jb = tid * C, je = min(B, jb + C);
+    const int jb = min(B, tid * C), je = min(B, jb + C);
     int cp = 0, cn = 0;
     for (int j = jb; j < je; ++j) {
         const int32_t lj = labels[j];
@@ -99,87 +167,55 @@ __global__ __launch_bounds__(TRIP_THREADS) void batch_all_kernel(const float* __
     if (tid == 0) { scan[0] = 0; scan[TRIP_THREADS + 1] = 0; }
     __syncthreads();
     if (tid < 2) {   // tiny serial scans (2 x 256 adds)
-        int* s = scan + tid * (TRIP_THREADS + 1);
-        for (int k = 1; k <= TRIP_THREADS; ++k) s[k] += s[k - 1];
+        int* sc = scan + tid * (TRIP_THREADS + 1);
+        for (int k = 1; k <= TRIP_THREADS; ++k) sc[k] += sc[k - 1];
     }
     __syncthreads();
     const int nP = scan[TRIP_THREADS], nN = scan[TRIP_THREADS + 1 + TRIP_THREADS];
+    float* pu = val;                      // positives: val[0 .. nP)
+    float* nv = val + (Bp - nN);          // negatives: val[Bp-nN .. Bp)
+    int* pidx = idx;
+    int* nidx = idx + (Bp - nN);
     {
         int op = scan[tid], on = scan[TRIP_THREADS + 1 + tid];
         for (int j = jb; j < je; ++j) {
             const int32_t lj = labels[j];
             float d = 0.f;
-            for (int s = 0; s < d_splits; ++s) d += D_slabs[(int64_t)s * slab_stride + (int64_t)a * ldd + j];
+            for (int sl = 0; sl < d_splits; ++sl) d += D_slabs[(int64_t)sl * slab_stride + (int64_t)a * ldd + j];
             if (lj == la) { if (j != a) { pu[op] = d; pidx[op] = j; ++op; } }
             else { nv[on] = d; nidx[on] = j; ++on; }
         }
     }
     __syncthreads();
 
-    // ---- role 1: each thread owns up to 4 negatives per sweep, loops over all positives ----
     float loss = 0.f;
     unsigned cnt = 0u;
-    for (int k0 = 0; k0 < nN; k0 += 4 * TRIP_THREADS) {
-        float v[4], gs[4];
-        unsigned rc[4];
-        bool act[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int k = k0 + q * TRIP_THREADS + tid;
-            act[q] = k < nN;
-            v[q] = act[q] ? nv[k] : 0.f;
-            gs[q] = 0.f; rc[q] = 0u;
+    float* gneg_w = gneg + wave * Bp;
+    unsigned* cneg_w = POS_ONLY ? cneg + wave * Bp : nullptr;
+    for (int k0 = 0; k0 < nN;) {
+        const int q = min(8, (nN - k0 + 63) / 64);          // negatives per lane in this chunk
+#define DAE_SWEEP(QV) sweep_pairs<POS_ONLY, QV>(pu, nv, nP, nN, k0, wave, lane, gpos, cpos, gneg_w, cneg_w, loss, cnt)
+        switch (q) {
+            case 8: DAE_SWEEP(8); break;
+            case 7: DAE_SWEEP(7); break;
+            case 6: DAE_SWEEP(6); break;
+            case 5: DAE_SWEEP(5); break;
+            case 4: DAE_SWEEP(4); break;
+            case 3: DAE_SWEEP(3); break;
+            case 2: DAE_SWEEP(2); break;
+            default: DAE_SWEEP(1); break;
         }
-        for (int p = 0; p < nP; ++p) {
-            const float u = pu[p];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float t = v[q] - u;                    // triplet_distance[a,p,n] (:106)
-                float sp, sg;
-                softplus_sigmoid(t, sp, sg);
-                const bool pos = t > 1e-16f;                 // (:114)
-                const bool use = act[q] && (POS_ONLY ? pos : true);
-                loss += use ? sp : 0.f;
-                gs[q] += use ? sg : 0.f;
-                cnt += (act[q] && pos) ? 1u : 0u;
-                if (POS_ONLY) rc[q] += (act[q] && pos) ? 1u : 0u;
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int k = k0 + q * TRIP_THREADS + tid;
-            if (act[q]) { Grow[nidx[k]] = gs[q]; if (POS_ONLY) Rrow[nidx[k]] = rc[q]; }
-        }
+#undef DAE_SWEEP
+        k0 += q * 64;
     }
-    // ---- role 2: each thread owns up to 4 positives, loops over all negatives (sigmoid only) ----
-    for (int k0 = 0; k0 < nP; k0 += 4 * TRIP_THREADS) {
-        float u[4], gs[4];
-        unsigned rc[4];
-        bool act[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int k = k0 + q * TRIP_THREADS + tid;
-            act[q] = k < nP;
-            u[q] = act[q] ? pu[k] : 0.f;
-            gs[q] = 0.f; rc[q] = 0u;
-        }
-        for (int n = 0; n < nN; ++n) {
-            const float vv = nv[n];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float t = vv - u[q];
-                const float sg = sigmoid_only(t);
-                const bool pos = t > 1e-16f;
-                const bool use = act[q] && (POS_ONLY ? pos : true);
-                gs[q] += use ? sg : 0.f;
-                if (POS_ONLY) rc[q] += (act[q] && pos) ? 1u : 0u;
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int k = k0 + q * TRIP_THREADS + tid;
-            if (act[q]) { Grow[pidx[k]] = -gs[q]; if (POS_ONLY) Rrow[pidx[k]] = rc[q]; }
-        }
+    __syncthreads();
+    for (int k = tid; k < nP; k += TRIP_THREADS) {
+        Grow[pidx[k]] = -gpos[k];
+        if (POS_ONLY) Rrow[pidx[k]] = cpos[k];
+    }
+    for (int k = tid; k < nN; k += TRIP_THREADS) {
+        Grow[nidx[k]] = (gneg[k] + gneg[Bp + k]) + (gneg[2 * Bp + k] + gneg[3 * Bp + k]);
+        if (POS_ONLY) Rrow[nidx[k]] = cneg[k] + cneg[Bp + k] + cneg[2 * Bp + k] + cneg[3 * Bp + k];
     }
     const float ltot = block_sum_f(loss, red);
     const unsigned ctot = block_sum_u(cnt, redu);
@@ -275,13 +311,15 @@ extern "C" int dae_triplet_batch_all(const float* D_slabs, int32_t d_splits, int
     DAE_CHECK_ARG(D_slabs && labels && loss_part && npos_part && G, "batch_all: null input");
     DAE_CHECK_ARG(B > 0 && B <= Bp && Bp <= TRIP_MAX_B, "batch_all: batch %d (padded %d) exceeds the supported %d", B, Bp, TRIP_MAX_B);
     DAE_CHECK_ARG(!pos_only || role_cnt, "batch_all: role_cnt required with pos_triplets_only");
-    const size_t lds = (size_t)Bp * 16 + 2 * (TRIP_THREADS + 1) * sizeof(int) + 8 * sizeof(float);
+    // val + idx + 4 per-wave gradient rows (+ 4 count rows when pos_only) + scans + reductions
+    const size_t lds = (size_t)Bp * (pos_only ? 48 : 28) + 2 * (TRIP_THREADS + 1) * sizeof(int) + 8 * sizeof(float);
+    DAE_CHECK_ARG(lds <= 160 * 1024, "batch_all: batch %d needs %zu B of LDS (> 160 KiB)", B, lds);
     static bool attr_done = false;
     if (!attr_done) {
         DAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(batch_all_kernel<false>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, TRIP_MAX_B * 16 + 4096));
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         DAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(batch_all_kernel<true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, TRIP_MAX_B * 16 + 4096));
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
     hipStream_t st = (hipStream_t)stream;

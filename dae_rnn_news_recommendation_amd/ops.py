@@ -78,21 +78,20 @@ def encode_finish(slabs, bh, B, H, enc_act, dtype):
     return h32, hlo, ht
 
 
-def decode_loss(h_lo, W_lo, bv, x, cw, B, F, H, dec_act, loss_func, dtype, *, cos_pass=0, cos_stats=None,
-                want_y=False):
+def decode_loss(h_lo, W_lo, bv, x, cw, B, F, H, dec_act, loss_func, dtype, *, cos_pass=0, cos_stats=None):
     Bp, Fp, Hp = L.pad(B), L.pad(F), L.pad(H)
     dev = h_lo.device
     ncw, nrw = 2 * Fp // 128, 2 * Bp // 128
     rowloss_part = torch.zeros((ncw, Bp), dtype=torch.float32, device=dev)
     dbv_part = torch.zeros((nrw, Fp), dtype=torch.float32, device=dev)
     cos_part = torch.zeros((2, ncw, Bp), dtype=torch.float32, device=dev) if loss_func == 2 else None
+    tile_part = torch.zeros((Bp // 128) * (Fp // 128), dtype=torch.float32, device=dev)
     d2 = torch.zeros((Bp, Fp), dtype=tdtype(dtype), device=dev)
     d2t = torch.zeros((Fp, Bp), dtype=tdtype(dtype), device=dev)
-    y = torch.zeros((Bp, Fp), dtype=torch.float32, device=dev) if want_y else None
     L.call("dae_decode_loss", dtype, B, F, H, L.ptr(h_lo), Hp, L.ptr(W_lo), Hp, L.ptr(bv), L.ptr(x), Fp, L.ptr(cw),
-           dec_act, loss_func, cos_pass, L.ptr(cos_stats), L.ptr(cos_part), L.ptr(rowloss_part), L.ptr(dbv_part),
-           L.ptr(d2), Fp, L.ptr(d2t), Bp, L.ptr(y), Fp, L.current_stream())
-    return dict(rowloss_part=rowloss_part, dbv_part=dbv_part, cos_part=cos_part, delta2=d2, delta2_t=d2t, y=y)
+           dec_act, loss_func, cos_pass, L.ptr(cos_stats), L.ptr(cos_part), L.ptr(rowloss_part), L.ptr(tile_part), L.ptr(dbv_part),
+           L.ptr(d2), Fp, L.ptr(d2t), Bp, L.current_stream())
+    return dict(rowloss_part=rowloss_part, tile_part=tile_part, dbv_part=dbv_part, cos_part=cos_part, delta2=d2, delta2_t=d2t)
 
 
 def cos_reduce(cos_part, B, cos_stats):
@@ -167,7 +166,7 @@ def dh_finish(slabs, h_f32, bh, B, H, enc_act, dtype, dh_extra=None):
     S, Bp, Hp = slabs.shape
     dev = slabs.device
     d1t = torch.empty((Hp, Bp), dtype=tdtype(dtype), device=dev)
-    colsum = torch.zeros((2, Bp // 64, Hp), dtype=torch.float32, device=dev)
+    colsum = torch.zeros((2, Bp // 32, Hp), dtype=torch.float32, device=dev)
     d1 = torch.empty((Bp, Hp), dtype=torch.float32, device=dev)
     L.call("dae_dh_finish", L.ptr(slabs), S, Bp * Hp, Hp, L.ptr(dh_extra), L.ptr(h_f32), Hp, L.ptr(bh), B, H, enc_act,
            dtype, L.ptr(d1t), Bp, L.ptr(colsum), L.ptr(d1), L.current_stream())
@@ -191,11 +190,11 @@ def opt_step(opt, lr, momentum, grad_scale, W, bh, bv, grad, s1, s2, dtype, W_lo
            L.ptr(s2), Fp, Hp, dtype, L.ptr(W_lo), L.ptr(Wt_lo), int(apply), L.current_stream())
 
 
-def step_stats(rowloss_part, cw, B, triplet, alpha, tri_scalars, nvalid):
+def step_stats(rowloss_part, cw, B, triplet, alpha, tri_scalars, nvalid, tile_part=None):
     ncw, Bp = rowloss_part.shape
     stats = torch.zeros(L.STATS_STRIDE, dtype=torch.float32, device=rowloss_part.device)
-    L.call("dae_step_stats", L.ptr(rowloss_part), ncw, L.ptr(cw), B, Bp, triplet, alpha, L.ptr(tri_scalars),
-           L.ptr(nvalid), L.ptr(stats), L.current_stream())
+    L.call("dae_step_stats", L.ptr(rowloss_part), ncw, L.ptr(tile_part), 0 if tile_part is None else tile_part.numel(),
+           L.ptr(cw), B, Bp, triplet, alpha, L.ptr(tri_scalars), L.ptr(nvalid), L.ptr(stats), L.current_stream())
     return stats
 
 

@@ -104,10 +104,10 @@ int dae_encode_finish(const float* slabs, int32_t splits, int64_t slab_stride, i
  * and d cost / d z2   (autoencoder.py:411; triplet_loss_utils.py:262-277 weighted_loss).
  *   y = act(h W^T + bv);  rowloss_i = sum_f loss(x_if, y_if);
  *   delta2_if = cw_i * dloss/dy * act'(z2)      with cw_i = w_i / (sum w + 1e-16)
- * outputs: rowloss_part [n_col_waves x Bp] partial row sums (n_col_waves = 2*Fp/128),
+ * outputs: rowloss_part [n_col_waves x Bp] partial row sums (n_col_waves = 2*Fp/128; may be NULL),
+ *          tile_part [(Bp/128)*(Fp/128)] each tile's share of sum_i cw_i * rowloss_i (may be NULL),
  *          dbv_part [n_row_waves x Fp] partial column sums of delta2 (n_row_waves = 2*Bp/128),
- *          delta2 [Bp x ldd] and delta2^T [Fp x lddt] in `dtype` (any of these may be NULL),
- *          y_out fp32 [Bp x ldy] (NULL unless the caller wants the reconstruction).
+ *          delta2 [Bp x ldd] and delta2^T [Fp x lddt] in `dtype` (any of these may be NULL).
  * cosine_proximity needs whole-row statistics and runs as two passes over the same GEMM:
  *   cos_pass 1: cos_stats[0..Bp) = sum x^2 (from the gather) is read, cos_part
  *               [2 x n_col_waves x Bp] receives partial {sum y^2, sum xhat.y};
@@ -117,9 +117,8 @@ int dae_decode_loss(int32_t dtype, int32_t B, int32_t F, int32_t H,
                     const void* h_lo, int64_t ldh, const void* W_lo, int64_t ldw,
                     const float* bv, const void* x, int64_t ldx, const float* cw,
                     int32_t dec_act, int32_t loss_func, int32_t cos_pass, const float* cos_stats,
-                    float* cos_part, float* rowloss_part, float* dbv_part,
-                    void* delta2, int64_t ldd, void* delta2_t, int64_t lddt,
-                    float* y_out, int64_t ldy, void* stream);
+                    float* cos_part, float* rowloss_part, float* tile_part, float* dbv_part,
+                    void* delta2, int64_t ldd, void* delta2_t, int64_t lddt, void* stream);
 int dae_cos_reduce(const float* cos_part, int32_t n_col_waves, int32_t B, int32_t Bp,
                    float* cos_stats, float* rowloss, void* stream);
 
@@ -174,7 +173,7 @@ int dae_sym_scale(const float* G, int32_t B, int32_t Bp, const float* tri_scalar
 
 /* K8 (middle): dh = sum_s slab_s (+ dh_extra);  delta1 = dh * act'(z1);  delta1^T in `dtype`
  * [Hp x ldt]; partial column sums for db_h = sum_i delta1 - act'(bh) * sum_i dh (the -act(bh) term
- * of autoencoder.py:389).  colsum_part: [2 x (Bp/64) x Hp].  delta1_f32 optional [Bp x ldh]. */
+ * of autoencoder.py:389).  colsum_part: [2 x (Bp/32) x Hp].  delta1_f32 optional [Bp x ldh]. */
 int dae_dh_finish(const float* slabs, int32_t splits, int64_t slab_stride, int64_t ld_slab,
                   const float* dh_extra, const float* h_f32, int64_t ldh, const float* bh,
                   int32_t B, int32_t H, int32_t enc_act, int32_t dtype, void* delta1_t, int64_t ldt,
@@ -195,10 +194,11 @@ int dae_opt_step(int32_t opt, float lr, float momentum, float grad_scale,
                  int32_t Fp, int32_t Hp, int32_t dtype, void* W_lo, void* Wt_lo, int32_t apply, void* stream);
 
 /* Final per-step statistics (autoencoder.py:233 fetch list):
- * ae = sum_i cw_i * rowloss_i; cost = ae + alpha * triplet.  stats: float[DAE_STATS_STRIDE]. */
-int dae_step_stats(const float* rowloss_part, int32_t n_col_waves, const float* cw, int32_t B, int32_t Bp,
-                   int32_t triplet, float alpha, const float* tri_scalars, const int64_t* nvalid,
-                   float* stats, void* stream);
+ * ae = sum_i cw_i * rowloss_i (from rowloss_part + cw, or from the decode kernel's tile_part if given);
+ * cost = ae + alpha * triplet.  stats: float[DAE_STATS_STRIDE]. */
+int dae_step_stats(const float* rowloss_part, int32_t n_col_waves, const float* tile_part, int32_t n_tiles,
+                   const float* cw, int32_t B, int32_t Bp, int32_t triplet, float alpha,
+                   const float* tri_scalars, const int64_t* nvalid, float* stats, void* stream);
 
 /* Explicit (anchor,pos,neg) triplet term of DenoisingAutoencoderTriplet
  * (autoencoder_triplet.py:308-311): t_i = h_i.hneg_i - h_i.hpos_i; loss = mean softplus(t).
@@ -213,8 +213,9 @@ int dae_explicit_triplet(const float* h3, int64_t ldh, int32_t B, int32_t H, flo
 int dae_weighted_loss_rows(const float* x, int64_t ldx, const float* y, int64_t ldy, int32_t B, int32_t F,
                            int32_t loss_func, float* rowloss, void* stream);
 
-/* A/B switch for the GEMM staging path: 1 = global_load_lds (default), 0 = register staging. */
-void dae_set_glds(int32_t on);
+/* A/B switch for the plain GEMM's staging: 0 = register staging (2 LDS buffers), 2/3/4 = depth of the
+ * global_load_lds ring with counted vmcnt waits (default 2). */
+void dae_set_glds(int32_t nst);
 
 /* ---------------------------------------------------------------------------------------------
  * Whole-step driver: what DenoisingAutoencoder._run_train_step (autoencoder.py:206-246) does per

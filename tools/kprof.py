@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Per-kernel HIP-event timings of the training step (dae_plan_profile) for quick A/B experiments.
+usage: python tools/kprof.py [--strategy batch_all] [--precision bf16] [--steps 20]"""
+import argparse, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from dae_rnn_news_recommendation_amd import _lib as L
+from dae_rnn_news_recommendation_amd.engine import Engine
+from dae_rnn_news_recommendation_amd.synthetic import synthetic_csr, synthetic_labels, xavier_uniform
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--strategy", default="batch_all"); ap.add_argument("--precision", default="bf16")
+ap.add_argument("--steps", type=int, default=20); ap.add_argument("--rows", type=int, default=1600)
+ap.add_argument("--features", type=int, default=10000); ap.add_argument("--hidden", type=int, default=500)
+ap.add_argument("--batch", type=int, default=800); ap.add_argument("--loss", default="cross_entropy")
+ap.add_argument("--enc-splits", type=int, default=0); ap.add_argument("--tag", default="")
+ap.add_argument("--nst", type=int, default=-1)
+a = ap.parse_args()
+if a.nst >= 0:
+    L.load().dae_set_glds(a.nst)
+m = synthetic_csr(a.rows, a.features, seed=1); lab = synthetic_labels(a.rows, seed=1).astype(np.int32)
+eng = Engine(a.features, a.hidden, a.batch, dtype=a.precision, triplet=a.strategy, loss_func=a.loss, learning_rate=0.1,
+             encode_splits=a.enc_splits, dh_splits=a.enc_splits)
+eng.upload_csr(m); eng.set_params(xavier_uniform(a.features, a.hidden))
+idx = torch.arange(a.batch, dtype=torch.int32, device="cuda"); labs = torch.from_numpy(lab[:a.batch]).cuda()
+stats = torch.zeros(8, device="cuda")
+kw = dict(corr_mode=L.CORR_PHILOX_MASK, seed=1, rng_stream=0, corr_frac=0.3)
+for _ in range(5):
+    eng.train_step(idx, labs if a.strategy != "none" else None, stats, **kw)
+torch.cuda.synchronize()
+eng.profile(True)
+for _ in range(a.steps):
+    eng.train_step(idx, labs if a.strategy != "none" else None, stats, **kw)
+prof = eng.profile_read(); eng.profile(False)
+tot = sum(ms for ms, n in prof.values())
+print(f"== nst={a.nst} {a.tag} {a.strategy} {a.precision} decode_debug={os.environ.get('DAE_DECODE_DEBUG','0')} total {1e3*tot/a.steps:.1f} us/step  info={eng.info()}")
+for k, (ms, n) in prof.items():
+    if n: print(f"   {k:18s} {1e3*ms/n:9.1f} us  x{n/a.steps:.0f}")
