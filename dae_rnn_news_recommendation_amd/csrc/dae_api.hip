@@ -304,7 +304,8 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     }
     // 3-4. encode (K1/K2)
     const int64_t slab = (int64_t)Bp * Hp;
-    PROF(PS_ENC_GEMM, launch_gemm_f32out(dt, Bp, Hp, p->xc, Fp, p->b.Wt_lo, Fp, Fp, nullptr, 0, nullptr, 0, 0, p->slabs, Hp, p->s_enc, slab, st));
+    PROF(PS_ENC_GEMM, launch_gemm_f32out(dt, Bp, Hp, p->xc, Fp, p->b.Wt_lo, Fp, Fp, nullptr, 0, nullptr, 0, 0, p->slabs, Hp, p->s_enc, slab, st,
+                                         GEMM_ROLE_ENCODE));
     PROF(PS_ENC_FIN, dae_encode_finish(p->slabs, p->s_enc, slab, Hp, p->b.bh, B, H, c.enc_act, dt, p->h_f32, p->h_lo, Hp, p->h_t, ldB, stream));
     // 5-6. miners (K5-K7)
     const int Bt = explicit3 ? B / 3 : B;
@@ -320,7 +321,7 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     if (c.triplet == DAE_TRIPLET_BATCH_ALL || c.triplet == DAE_TRIPLET_BATCH_HARD) {
         const int64_t dslab = (int64_t)Bp * Bp;
         PROF(PS_GRAM, launch_gemm_f32out(DAE_F32, Bp, Bp, p->h_f32, Hp, p->h_f32, Hp, Hp, nullptr, 0, nullptr, 0, 0, p->D_slabs, Bp, p->s_gram,
-                              dslab, st));
+                              dslab, st, GEMM_ROLE_GRAM));
         if (c.triplet == DAE_TRIPLET_BATCH_ALL)
             PROF(PS_MINER, dae_triplet_batch_all(p->D_slabs, p->s_gram, dslab, Bp, s->labels, B, Bp, c.pos_triplets_only, p->loss_part,
                                      p->cnt_part, p->G, p->role_cnt, stream));
@@ -357,11 +358,11 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     // 9-10. dL/dh = delta2 W + alpha (G+G^T) h ; delta1                     (K8)
     const bool mined = (c.triplet == DAE_TRIPLET_BATCH_ALL || c.triplet == DAE_TRIPLET_BATCH_HARD);
     PROF(PS_DH_GEMM, launch_gemm_f32out(dt, Bp, Hp, p->delta2, Fp, p->b.Wt_lo, Fp, Fp, mined ? p->Gs : nullptr, Bp, mined ? p->h_t : nullptr, ldB,
-                          mined ? Bp : 0, p->slabs, Hp, p->s_dh, slab, st));
+                          mined ? Bp : 0, p->slabs, Hp, p->s_dh, slab, st, GEMM_ROLE_DH));
     PROF(PS_DH_FIN, dae_dh_finish(p->slabs, p->s_dh, slab, Hp, explicit3 ? p->dh_extra : nullptr, p->h_f32, Hp, p->b.bh, B, H, c.enc_act, dt,
                      p->delta1_t, ldB, p->colsum_part, nullptr, stream));
     // 11. dW = x~^T delta1 + delta2^T h                                      (K8, tied weights)
-    PROF(PS_DW_GEMM, launch_gemm_f32out(dt, Fp, Hp, p->xct, ldB, p->delta1_t, ldB, Bp, p->delta2_t, ldB, p->h_t, ldB, Bp, p->b.grad, Hp, 1, 0, st));
+    PROF(PS_DW_GEMM, launch_gemm_f32out(dt, Fp, Hp, p->xct, ldB, p->delta1_t, ldB, Bp, p->delta2_t, ldB, p->h_t, ldB, Bp, p->b.grad, Hp, 1, 0, st, GEMM_ROLE_DW));
     // 12. bias gradients
     float* g_bh = p->b.grad + (int64_t)Fp * Hp;
     PROF(PS_BIAS, dae_bias_grads(p->dbv_part, 2 * Bp / 128, p->colsum_part, Bp / 32, p->b.bh, H, Hp, F, Fp, c.enc_act, g_bh, g_bh + Hp, stream));
@@ -393,7 +394,8 @@ extern "C" int dae_encode_rows(dae_plan* p, const int32_t* row_idx, int32_t B, f
     RC(gather_batch(p, indptr, indices, values, dense, ld_dense, row_idx, B, nullptr, p->xc, nullptr, nullptr, DAE_CORR_NONE, nullptr, 0,
                     0, 0.f, scale, stream));
     const int64_t slab = (int64_t)Bp * Hp;
-    RC(launch_gemm_f32out(dt, Bp, Hp, p->xc, Fp, p->b.Wt_lo, Fp, Fp, nullptr, 0, nullptr, 0, 0, p->slabs, Hp, p->s_enc, slab, st));
+    RC(launch_gemm_f32out(dt, Bp, Hp, p->xc, Fp, p->b.Wt_lo, Fp, Fp, nullptr, 0, nullptr, 0, 0, p->slabs, Hp, p->s_enc, slab, st,
+                          GEMM_ROLE_ENCODE));
     RC(dae_encode_finish(p->slabs, p->s_enc, slab, Hp, p->b.bh, B, p->H, p->cfg.enc_act, dt, p->h_f32, nullptr, Hp, nullptr, 0, stream));
     DAE_CHECK_HIP(hipMemcpy2DAsync(out, (size_t)ld_out * 4, p->h_f32, (size_t)Hp * 4, (size_t)p->H * 4, B, hipMemcpyDeviceToDevice, st));
     return 0;

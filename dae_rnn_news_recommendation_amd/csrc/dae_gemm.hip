@@ -215,7 +215,10 @@ __device__ __forceinline__ void block_to_tile(const GemmParams& p, int& tm, int&
 // ------------------------------------------------------------------------------------------------
 // plain fp32-output kernel (split-K slabs or final C)
 // ------------------------------------------------------------------------------------------------
-template <typename T, int NST>
+// ROLE only names the instantiation (encode / dh / dW / gram / generic) so that per-kernel profiles
+// (rocprofv3 --kernel-trace) can tell the step's GEMMs apart; the code is identical.
+enum { ROLE_GENERIC = 0, ROLE_ENCODE = 1, ROLE_DH = 2, ROLE_DW = 3, ROLE_GRAM = 4 };
+template <typename T, int NST, int ROLE>
 __global__ __launch_bounds__(GEMM_THREADS, wg_per_cu_for(NST)) void gemm_nt_f32out(GemmParams p, float* __restrict__ C, int64_t ldc,
                                                                                    int64_t slab_stride) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -540,12 +543,22 @@ static int fill_params(GemmParams& p, int dtype, int M, int N, const void* A0, i
 constexpr int DECODE_LDS_BYTES = lds_bytes_for(DECODE_NST) > DECODE_EPI_BYTES ? lds_bytes_for(DECODE_NST) : DECODE_EPI_BYTES;
 
 typedef void (*f32out_fn)(GemmParams, float*, int64_t, int64_t);
-template <typename T> static f32out_fn f32out_kernel(int nst) {
+constexpr int DEFAULT_NST = 2;
+template <typename T> static f32out_fn f32out_kernel(int nst, int role) {
+    if (nst == DEFAULT_NST) {
+        switch (role) {
+            case ROLE_ENCODE: return gemm_nt_f32out<T, DEFAULT_NST, ROLE_ENCODE>;
+            case ROLE_DH: return gemm_nt_f32out<T, DEFAULT_NST, ROLE_DH>;
+            case ROLE_DW: return gemm_nt_f32out<T, DEFAULT_NST, ROLE_DW>;
+            case ROLE_GRAM: return gemm_nt_f32out<T, DEFAULT_NST, ROLE_GRAM>;
+            default: break;
+        }
+    }
     switch (nst) {
-        case 0: return gemm_nt_f32out<T, 0>;
-        case 3: return gemm_nt_f32out<T, 3>;
-        case 4: return gemm_nt_f32out<T, 4>;
-        default: return gemm_nt_f32out<T, 2>;
+        case 0: return gemm_nt_f32out<T, 0, ROLE_GENERIC>;
+        case 3: return gemm_nt_f32out<T, 3, ROLE_GENERIC>;
+        case 4: return gemm_nt_f32out<T, 4, ROLE_GENERIC>;
+        default: return gemm_nt_f32out<T, 2, ROLE_GENERIC>;
     }
 }
 typedef void (*decode_fn)(GemmParams, DecodeEpi);
@@ -558,12 +571,13 @@ template <typename T> static decode_fn decode_kernel(int loss, int act) {
 static int gemm_init() {
     static int rc = [] {
         const int nsts[4] = {0, 2, 3, 4};
-        for (int n : nsts) {
-            DAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(f32out_kernel<bf16_t>(n)),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes_for(n)));
-            DAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(f32out_kernel<float>(n)),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes_for(n)));
-        }
+        for (int n : nsts)
+            for (int role = 0; role <= ROLE_GRAM; ++role) {
+                DAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(f32out_kernel<bf16_t>(n, role)),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes_for(n)));
+                DAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(f32out_kernel<float>(n, role)),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes_for(n)));
+            }
         for (int l = 0; l < 3; ++l)
             for (int a = 0; a < 3; ++a) {
                 DAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decode_kernel<bf16_t>(l, a)),
@@ -578,14 +592,14 @@ static int gemm_init() {
 
 int launch_gemm_f32out(int dtype, int M, int N, const void* A0, int64_t lda0, const void* Bt0, int64_t ldb0, int K0,
                        const void* A1, int64_t lda1, const void* Bt1, int64_t ldb1, int K1, float* C, int64_t ldc,
-                       int splits, int64_t slab_stride, hipStream_t st) {
+                       int splits, int64_t slab_stride, hipStream_t st, int role) {
     GemmParams p;
     if (int rc = fill_params(p, dtype, M, N, A0, lda0, Bt0, ldb0, K0, A1, lda1, Bt1, ldb1, K1, splits)) return rc;
     DAE_CHECK_ARG(C != nullptr, "gemm: C is null");
     if (int rc = gemm_init()) return rc;
     dim3 grid(p.tiles_m * p.tiles_n * p.splits), block(GEMM_THREADS);
     const int nst = g_nst;
-    f32out_fn k = dtype == DAE_BF16 ? f32out_kernel<bf16_t>(nst) : f32out_kernel<float>(nst);
+    f32out_fn k = dtype == DAE_BF16 ? f32out_kernel<bf16_t>(nst, role) : f32out_kernel<float>(nst, role);
     hipLaunchKernelGGL(k, grid, block, lds_bytes_for(nst == 0 || nst == 3 || nst == 4 ? nst : 2), st, p, C, ldc, slab_stride);
     DAE_CHECK_LAUNCH();
     return 0;
