@@ -1,0 +1,96 @@
+"""``DenoisingAutoencoderTriplet`` -- the paper-style DAE with EXPLICIT (anchor, positive, negative) inputs
+(reference ``autoencoder/autoencoder_triplet.py:14-315``) on the MI355X kernels.
+
+Three row blocks (org, pos, neg) go through the same tied weights; autoencoder loss = sum of the three
+unweighted row means (:303-305); triplet loss = mean softplus(h.h_neg - h.h_pos) (:308-311); cost = AE + alpha *
+triplet (:314).  On the device the three blocks are stacked into one [3B x F] batch: every GEMM of the step runs
+once with M = 3B, the explicit-triplet kernel adds d loss/d h per block (``dae_explicit_triplet``).
+
+The shipped reference class cannot train (it reads ``self.train_summary`` that is never set, :146, and
+``gen_batches_triplet`` forgets the int() cast, utils.py:86-90 -- SURVEY appendix B); this class implements the
+behaviour its code describes.
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+from scipy import sparse
+
+from . import utils
+from .autoencoder import DenoisingAutoencoder
+from .. import _lib as L
+
+__all__ = ["DenoisingAutoencoderTriplet"]
+
+
+class DenoisingAutoencoderTriplet(DenoisingAutoencoder):
+    def __init__(self, algo_name='dae_triplet', model_name='dae_triplet', compress_factor=10, main_dir='dae_triplet/',
+                 enc_act_func='tanh', dec_act_func='none', loss_func='mean_squared', num_epochs=10, batch_size=10,
+                 xavier_init=1, opt='gradient_descent', learning_rate=0.01, momentum=0.5, corr_type='none',
+                 corr_frac=0., verbose=True, verbose_step=5, seed=-1, alpha=1, **kw):
+        super().__init__(algo_name=algo_name, model_name=model_name, compress_factor=compress_factor, main_dir=main_dir,
+                         enc_act_func=enc_act_func, dec_act_func=dec_act_func, loss_func=loss_func, num_epochs=num_epochs,
+                         batch_size=batch_size, xavier_init=xavier_init, opt=opt, learning_rate=learning_rate,
+                         momentum=momentum, corr_type=corr_type, corr_frac=corr_frac, verbose=verbose,
+                         verbose_step=verbose_step, seed=seed, alpha=alpha, triplet_strategy='none', **kw)
+
+    def _strategy_key(self):
+        return "explicit"
+
+    @staticmethod
+    def _stack(d):
+        blocks = [d[k] for k in ('org', 'pos', 'neg')]
+        if isinstance(blocks[0], np.ndarray):
+            return np.concatenate(blocks, axis=0)
+        return sparse.vstack([sparse.csr_matrix(b) for b in blocks]).tocsr()
+
+    def fit(self, train_set, validation_set=None, restore_previous_model=False):
+        """``train_set``: dict {'org','pos','neg'} of same-shape matrices (reference :40-56)."""
+        assert isinstance(train_set, dict) and all(k in train_set for k in ('org', 'pos', 'neg'))
+        shape = train_set['org'].shape
+        assert train_set['pos'].shape == shape and train_set['neg'].shape == shape
+        N, n_features = shape
+        self.sparse_input = not isinstance(train_set['org'], np.ndarray)
+        self.n_components = int(np.floor(n_features / self.compress_factor))
+        batch = self._resolve_batch(N)
+        stacked = self._stack(train_set)                    # rows [0,N) org, [N,2N) pos, [2N,3N) neg
+        eng = self._build_engine(n_features, 3 * batch)
+        eng.upload_csr(stacked) if self.sparse_input else eng.upload_dense(stacked)
+        eng.set_params(*self._initial_parameters(n_features))
+        if restore_previous_model:
+            self._restore(self.model_path)
+        self._write_parameter_to_file(restore_previous_model)
+        self._train_triplet(stacked, N, batch, validation_set)
+        self._save(self.model_path)
+
+    def _train_triplet(self, stacked, N, batch, validation_set):
+        import torch
+        eng = self.engine
+        n_batches = -(-N // batch)
+        self._stats = torch.zeros((max(self.num_epochs, 1), n_batches, L.STATS_STRIDE), dtype=torch.float32, device=eng.device)
+        t_fit = time.time()
+        for i in range(self.num_epochs):
+            t0 = time.time()
+            plan = self._corruption_plan(stacked, i)        # one corruption draw over the stacked set
+            order = utils.epoch_permutation(N)               # ONE shuffle shared by the three blocks (utils.py:87-91)
+            for b, start in enumerate(range(0, N, batch)):
+                idx = order[start:start + batch]
+                rows = np.concatenate([idx, N + idx, 2 * N + idx]).astype(np.int32)
+                eng.train_step(torch.from_numpy(rows).to(eng.device), None, self._stats[i, b], phase=0, **plan)
+            if (i + 1) % self.verbose_step == 0 or i + 1 == self.num_epochs:
+                torch.cuda.synchronize()
+                self.train_time = time.time() - t0
+                self._run_validation_error_and_summaries(i + 1, None, None)
+        torch.cuda.synchronize()
+        wall = time.time() - t_fit
+        if self.num_epochs > 0 and wall > 0:
+            self.samples_per_sec = 3 * N * self.num_epochs / wall
+
+    def _run_validation_error_and_summaries(self, epoch, validation_set, validation_set_label):
+        st = self.epoch_stats(epoch)
+        self.history.append(dict(epoch=epoch, seconds=self.train_time, cost=st['cost'], ae=st['ae'], triplet=st['triplet']))
+        if self.verbose == 1:
+            print('At step %d (%.2f seconds): ' % (epoch, self.train_time), end='')
+            print('[Train Stat (average over past steps)] - Cost: ', end='')
+            print('Overall=%.4f\tAutoencoder=%.4f\tTriplet=%.4f\t' % (st['cost'], st['ae'], st['triplet']))

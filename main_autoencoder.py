@@ -1,0 +1,150 @@
+#!/usr/bin/env python3
+"""Command-line trainer with the flag surface of the reference's ``main_autoencoder.py`` (:27-74) on the
+MI355X-native estimator.
+
+Kept: flag names, defaults, choices and the validation asserts (:94-109), ``main_dir`` defaulting to
+``model_name`` (:111), the fit -> transform(decay-compensated) sequence (:277-290), parameter.txt, the saved
+artefact names under results/<algo>/<main_dir>/data/.  Not kept (out of the hot path): the parquet /
+jieba / CountVectorizer preprocessing and the matplotlib ROC plots -- the UCI dataset blob is absent from the
+reference checkout (.MISSING_LARGE_BLOBS:2), so data comes from ``--data <matrix.npz> [--labels <labels.npy>]``
+(scipy CSR / dense .npy) or from the seeded synthetic generator (default).
+
+examples:
+  python main_autoencoder.py --model_name demo --num_epochs 5 --verbose --verbose_step 1
+  python main_autoencoder.py --model_name uci --data X.npz --labels y.npy --triplet_strategy batch_hard
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+from scipy import sparse
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def str2bool(v):
+    return str(v).lower() in ("1", "true", "t", "yes", "y")
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    b = dict(type=str2bool, nargs="?", const=True)
+    # Global configuration (reference :27-35)
+    p.add_argument("--verbose", default=False, **b)
+    p.add_argument("--verbose_step", type=int, default=5)
+    p.add_argument("--encode_full", default=False, **b)
+    p.add_argument("--validation", default=False, **b)
+    p.add_argument("--input_format", default="binary", choices=["binary", "tfidf"])
+    p.add_argument("--label", default="category_publish_name", choices=["category_publish_name", "story"])
+    p.add_argument("--save_tsv", default=False, **b)
+    p.add_argument("--train_row", type=int, default=8000)
+    p.add_argument("--validate_row", type=int, default=2000)
+    # Count-vectorizer parameters (:47-50); only max_features matters for synthetic data
+    p.add_argument("--restore_previous_data", default=False, **b)
+    p.add_argument("--min_df", type=float, default=0)
+    p.add_argument("--max_df", type=float, default=0.99)
+    p.add_argument("--max_features", type=int, default=10000)
+    # Autoencoder parameters (:56-74)
+    p.add_argument("--model_name", default="")
+    p.add_argument("--restore_previous_model", default=False, **b)
+    p.add_argument("--seed", type=int, default=-1)
+    p.add_argument("--compress_factor", type=int, default=20)
+    p.add_argument("--corr_type", default="masking", choices=["masking", "salt_and_pepper", "decay", "none"])
+    p.add_argument("--corr_frac", type=float, default=0.3)
+    p.add_argument("--xavier_init", type=int, default=1)
+    p.add_argument("--enc_act_func", default="sigmoid", choices=["sigmoid", "tanh"])
+    p.add_argument("--dec_act_func", default="sigmoid", choices=["sigmoid", "tanh", "none"])
+    p.add_argument("--main_dir", default="")
+    p.add_argument("--loss_func", default="cross_entropy", choices=["mean_squared", "cross_entropy", "cosine_proximity"])
+    p.add_argument("--opt", default="gradient_descent", choices=["gradient_descent", "ada_grad", "momentum"])
+    p.add_argument("--learning_rate", type=float, default=0.1)
+    p.add_argument("--momentum", type=float, default=0.5)
+    p.add_argument("--num_epochs", type=int, default=50)
+    p.add_argument("--batch_size", type=float, default=0.1)
+    p.add_argument("--alpha", type=float, default=1)
+    p.add_argument("--triplet_strategy", default="batch_all", choices=["batch_all", "batch_hard", "none"])
+    # MI355X-side additions
+    p.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--rng", default="numpy", choices=["numpy", "philox"])
+    p.add_argument("--data", default="", help="scipy-sparse .npz or dense .npy feature matrix (rows = articles)")
+    p.add_argument("--labels", default="", help=".npy label vector aligned with --data")
+    p.add_argument("--data_parallel", default=False, **b)
+    return p
+
+
+def validate(a):
+    """The reference's asserts (:94-109)."""
+    assert 0. <= a.min_df <= 1.
+    assert 0. <= a.max_df <= 1.
+    assert a.max_features >= 1
+    assert 0. <= a.corr_frac <= 1.
+    assert a.verbose_step > 0
+    if a.input_format == 'tfidf':
+        assert a.loss_func in ['mean_squared', 'cosine_proximity']
+    if a.main_dir == '':
+        a.main_dir = a.model_name
+    assert a.model_name != '', "--model_name is required"
+    return a
+
+
+def load_data(a):
+    from dae_rnn_news_recommendation_amd.synthetic import synthetic_csr, synthetic_labels
+    n = a.train_row + (a.validate_row if a.validation else 0)
+    if a.data:
+        X = sparse.load_npz(a.data).tocsr() if a.data.endswith(".npz") else np.load(a.data)
+        y = np.load(a.labels, allow_pickle=True) if a.labels else None
+        X = X[:n]; y = None if y is None else y[:n]
+    else:
+        seed = a.seed if a.seed >= 0 else 1234
+        X = synthetic_csr(n, a.max_features, nnz_per_row=200, seed=seed, tfidf=(a.input_format == "tfidf"))
+        y = synthetic_labels(n, kind="category" if a.label == "category_publish_name" else "story", seed=seed)
+    if a.input_format == "binary" and sparse.issparse(X):
+        X.data[:] = 1                                                   # reference :235-236
+    return X, y
+
+
+def main(argv=None):
+    a = validate(build_parser().parse_args(argv))
+    print(__file__ + ': Start')
+    from dae_rnn_news_recommendation_amd import dp
+    from dae_rnn_news_recommendation_amd.autoencoder import DenoisingAutoencoder, utils
+    if a.data_parallel:
+        dp.init_from_env()
+    model = DenoisingAutoencoder(
+        model_name=a.model_name, main_dir=a.main_dir, compress_factor=a.compress_factor, enc_act_func=a.enc_act_func,
+        dec_act_func=a.dec_act_func, loss_func=a.loss_func, num_epochs=a.num_epochs, batch_size=a.batch_size,
+        xavier_init=a.xavier_init, opt=a.opt, learning_rate=a.learning_rate, momentum=a.momentum, corr_type=a.corr_type,
+        corr_frac=a.corr_frac, verbose=a.verbose, verbose_step=a.verbose_step, seed=a.seed, alpha=a.alpha,
+        triplet_strategy=a.triplet_strategy, precision=a.precision, rng=a.rng, data_parallel=a.data_parallel)
+    X, y = load_data(a)
+    trX, vlX = X[:a.train_row], (X[a.train_row:a.train_row + a.validate_row] if a.validation else None)
+    trY = None if y is None else y[:a.train_row]
+    vlY = None if (y is None or not a.validation) else y[a.train_row:a.train_row + a.validate_row]
+    if sparse.issparse(trX):
+        sparse.save_npz(model.data_dir + 'article_binary_count_vectorized_train.npz', sparse.csr_matrix(trX))
+    if trY is not None:
+        np.save(model.data_dir + 'article_label_train.npy', np.asarray(trY))
+    need_labels = a.triplet_strategy != 'none'
+    model.fit(trX, vlX, trY if need_labels else None, vlY if need_labels else None,
+              restore_previous_model=a.restore_previous_model)
+    with open(model.parameter_file, 'a+') as fh:                        # reference :279-285
+        print('train_row={}'.format(a.train_row), file=fh)
+        print('validate_row={}'.format(a.validate_row), file=fh)
+        print('input_format={}'.format(a.input_format), file=fh)
+        print('label={}'.format(a.label), file=fh)
+    # encode with the decay compensation the reference applies at inference (:289-290)
+    emb = model.transform(utils.decay_noise(trX, a.corr_frac), name='article_encoded_train', save=True)
+    if vlX is not None:
+        model.transform(utils.decay_noise(vlX, a.corr_frac), name='article_encoded_validate', save=True)
+    if model.samples_per_sec:
+        print('training throughput: %.0f samples/s over %d epochs; embeddings %s -> %s' %
+              (model.samples_per_sec, a.num_epochs, emb.shape, model.data_dir))
+    print(__file__ + ': End')
+    return model
+
+
+if __name__ == '__main__':
+    main()

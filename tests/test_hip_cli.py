@@ -1,0 +1,65 @@
+"""GPU smoke/parity of the remaining drop-in surface: the CLI (flag-compatible main_autoencoder.py) and the
+explicit-triplet estimator."""
+import os
+
+import numpy as np
+import pytest
+from scipy import sparse
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def test_cli_end_to_end(tmp_path, monkeypatch, capsys):
+    import main_autoencoder as cli
+    monkeypatch.chdir(tmp_path)
+    model = cli.main(["--model_name", "demo", "--num_epochs", "3", "--train_row", "600", "--validate_row", "200",
+                      "--validation", "--max_features", "1000", "--verbose", "--verbose_step", "1", "--seed", "3",
+                      "--triplet_strategy", "batch_hard", "--opt", "ada_grad"])
+    out = capsys.readouterr().out
+    assert out.count("At step") == 3 and "Triplet: Fraction=" in out and "[Validation Stat" in out
+    d = model.data_dir
+    assert os.path.exists(d + "article_encoded_train.npy") and os.path.exists(d + "article_encoded_validate.npy")
+    emb = np.load(d + "article_encoded_train.npy")
+    assert emb.shape == (600, 50) and np.isfinite(emb).all()
+    assert os.path.exists(model.model_path + ".npz") and "triplet_strategy=batch_hard" in open(model.parameter_file).read()
+    costs = [h["cost"] for h in model.history]
+    assert costs[-1] < costs[0]                               # it trains
+
+
+def test_explicit_triplet_estimator_matches_oracle(tmp_path):
+    from dae_rnn_news_recommendation_amd.autoencoder.autoencoder_triplet import DenoisingAutoencoderTriplet
+    rng = np.random.default_rng(0)
+    N, F = 120, 400
+    H = F // 10
+
+    def mk(seed):
+        m = sparse.random(N, F, density=0.05, random_state=np.random.RandomState(seed), format="csr", dtype=np.float32)
+        m.data = (m.data * 0.9 + 0.1).astype(np.float32); m.sort_indices()
+        return m
+    data = {"org": mk(1), "pos": mk(2), "neg": mk(3)}
+    W0 = rng.uniform(-0.2, 0.2, (F, H)).astype(np.float32)
+    model = DenoisingAutoencoderTriplet(model_name="t3", main_dir="t3", compress_factor=10, enc_act_func="sigmoid",
+                                        dec_act_func="sigmoid", loss_func="cosine_proximity", num_epochs=2, batch_size=40,
+                                        learning_rate=0.05, corr_type="none", verbose=False, verbose_step=1, seed=5, alpha=2,
+                                        precision="fp32", init_weights=W0, results_root=str(tmp_path) + "/")
+    model.fit(data)
+    # oracle: same shuffles (one legacy-RNG shuffle per epoch, shared by the three blocks)
+    np.random.seed(5)
+    W = W0.astype(np.float64); bh = np.zeros(H); bv = np.zeros(F)
+    st = O.OptState("gradient_descent", [W.shape, bh.shape, bv.shape], np.float64)
+    hist = []
+    for e in range(2):
+        order = O.gen_batches_index(N, 40)
+        costs = []
+        for idx in order:
+            xs = [data[k][idx].toarray() for k in ("org", "pos", "neg")]
+            r = O.explicit_triplet_forward_backward(W, bh, bv, xs, xs, loss_func="cosine_proximity", alpha=2.0, dt=np.float64)
+            O.opt_apply(st, [W, bh, bv], [r["dW"], r["dbh"], r["dbv"]], 0.05, 0.5, np.float64)
+            costs.append(float(r["cost"]))
+        hist.append(np.mean(costs))
+    for e in range(2):
+        got = model.epoch_stats(e + 1)["cost"]
+        assert abs(got - hist[e]) <= 1e-4 * abs(hist[e]), (e, got, hist[e])
+    assert np.abs(model.engine.get_params()[0] - W).max() <= 2e-5 * np.abs(W).max()
