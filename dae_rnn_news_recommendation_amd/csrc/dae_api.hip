@@ -2,6 +2,7 @@
 // driver that enqueues one DAE training step (DenoisingAutoencoder._run_train_step's per-batch body,
 // autoencoder.py:223-245) as a fixed sequence of HIP kernels on one stream, with no host sync.
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include <new>
 
@@ -74,6 +75,11 @@ static const char* const kProfNames[PS_COUNT] = {"memset_xct", "gather", "encode
 struct dae_plan {
     bool prof;
     hipEvent_t ev0, ev1;
+    // second stream for the miner chain (gram -> sweep -> finalize -> sym_scale): with batch_all the row weights
+    // depend on the labels only, so the chain is independent of the decode GEMM and runs beside it
+    hipStream_t side;
+    hipEvent_t ev_fork, ev_join;
+    bool overlap_ok;
     double prof_ms[PS_COUNT];
     int prof_n[PS_COUNT];
     dae_config cfg;
@@ -172,6 +178,7 @@ extern "C" int dae_plan_create(const dae_config* cfg, dae_plan** out) {
     if (p->s_dh > kt_f) p->s_dh = kt_f;
     if (p->s_gram > p->Hp * 4 / 128) p->s_gram = p->Hp * 4 / 128;
     p->ws_bytes = carve(p, nullptr);
+    p->overlap_ok = getenv("DAE_OVERLAP") != nullptr;   // measured: running the miner chain beside decode is SLOWER (0.410 vs 0.351 ms/step)
     *out = p;
     return 0;
 }
@@ -180,6 +187,9 @@ extern "C" void dae_plan_destroy(dae_plan* p) {
     if (!p) return;
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
+    if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
+    if (p->ev_join) (void)hipEventDestroy(p->ev_join);
+    if (p->side) (void)hipStreamDestroy(p->side);
     delete p;
 }
 
@@ -318,19 +328,47 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     } else {
         PROF(PS_LABEL, dae_label_stats(s->labels, B, Bp, c.triplet, p->n_same, p->acc, p->nvalid, p->dw_i64, p->cw, stream));
     }
+    bool forked = false;
     if (c.triplet == DAE_TRIPLET_BATCH_ALL || c.triplet == DAE_TRIPLET_BATCH_HARD) {
         const int64_t dslab = (int64_t)Bp * Bp;
-        PROF(PS_GRAM, launch_gemm_f32out(DAE_F32, Bp, Bp, p->h_f32, Hp, p->h_f32, Hp, Hp, nullptr, 0, nullptr, 0, 0, p->D_slabs, Bp, p->s_gram,
-                              dslab, st, GEMM_ROLE_GRAM));
-        if (c.triplet == DAE_TRIPLET_BATCH_ALL)
-            PROF(PS_MINER, dae_triplet_batch_all(p->D_slabs, p->s_gram, dslab, Bp, s->labels, B, Bp, c.pos_triplets_only, p->loss_part,
-                                     p->cnt_part, p->G, p->role_cnt, stream));
-        else
-            PROF(PS_MINER, dae_triplet_batch_hard(p->D_slabs, p->s_gram, dslab, Bp, s->labels, B, Bp, p->loss_part, p->cnt_part, p->dw_i32, p->G,
-                                      stream));
-        PROF(PS_TRI_FIN, dae_triplet_finalize(c.triplet, c.pos_triplets_only, B, Bp, c.alpha, p->loss_part, p->cnt_part, p->nvalid, p->dw_i32,
-                                p->role_cnt, p->dw_f32, p->cw, p->tri_scalars, stream));
-        if (backward) PROF(PS_SYM, dae_sym_scale(p->G, B, Bp, p->tri_scalars, dt, p->Gs, stream));
+        // batch_all (all valid triplets): cw comes from the labels alone -> the miner chain and the decode kernel are
+        // independent until dL/dh; fork the chain onto the side stream (never while profiling: events are per stream)
+        const bool overlap = p->overlap_ok && !p->prof && c.triplet == DAE_TRIPLET_BATCH_ALL && !c.pos_triplets_only;
+        hipStream_t ms = st;
+        if (overlap) {
+            if (!p->side) {
+                DAE_CHECK_HIP(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+                DAE_CHECK_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+                DAE_CHECK_HIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+            }
+            ms = p->side;
+            DAE_CHECK_HIP(hipEventRecord(p->ev_fork, st));
+            DAE_CHECK_HIP(hipStreamWaitEvent(ms, p->ev_fork, 0));
+            forked = true;
+        }
+        void* mstream = (void*)ms;
+        if (forked) {
+            RC(launch_gemm_f32out(DAE_F32, Bp, Bp, p->h_f32, Hp, p->h_f32, Hp, Hp, nullptr, 0, nullptr, 0, 0, p->D_slabs, Bp, p->s_gram, dslab,
+                                  ms, GEMM_ROLE_GRAM));
+            RC(dae_triplet_batch_all(p->D_slabs, p->s_gram, dslab, Bp, s->labels, B, Bp, 0, p->loss_part, p->cnt_part, p->G, p->role_cnt,
+                                     mstream));
+            RC(dae_triplet_finalize(c.triplet, 0, B, Bp, c.alpha, p->loss_part, p->cnt_part, p->nvalid, p->dw_i32, p->role_cnt, p->dw_f32,
+                                    p->cw, p->tri_scalars, mstream));
+            if (backward) RC(dae_sym_scale(p->G, B, Bp, p->tri_scalars, dt, p->Gs, mstream));
+            DAE_CHECK_HIP(hipEventRecord(p->ev_join, ms));
+        } else {
+            PROF(PS_GRAM, launch_gemm_f32out(DAE_F32, Bp, Bp, p->h_f32, Hp, p->h_f32, Hp, Hp, nullptr, 0, nullptr, 0, 0, p->D_slabs, Bp, p->s_gram,
+                                  dslab, st, GEMM_ROLE_GRAM));
+            if (c.triplet == DAE_TRIPLET_BATCH_ALL)
+                PROF(PS_MINER, dae_triplet_batch_all(p->D_slabs, p->s_gram, dslab, Bp, s->labels, B, Bp, c.pos_triplets_only, p->loss_part,
+                                         p->cnt_part, p->G, p->role_cnt, stream));
+            else
+                PROF(PS_MINER, dae_triplet_batch_hard(p->D_slabs, p->s_gram, dslab, Bp, s->labels, B, Bp, p->loss_part, p->cnt_part, p->dw_i32, p->G,
+                                          stream));
+            PROF(PS_TRI_FIN, dae_triplet_finalize(c.triplet, c.pos_triplets_only, B, Bp, c.alpha, p->loss_part, p->cnt_part, p->nvalid, p->dw_i32,
+                                    p->role_cnt, p->dw_f32, p->cw, p->tri_scalars, stream));
+            if (backward) PROF(PS_SYM, dae_sym_scale(p->G, B, Bp, p->tri_scalars, dt, p->Gs, stream));
+        }
     }
     // 7. decode + reconstruction loss + d cost/d z2   (K3/K4)
     const int ncw = 2 * Fp / 128;
@@ -350,6 +388,7 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
         e.cos_pass = 0;
         PROF(PS_DECODE, launch_decode_loss(dt, Bp, Fp, Hp, p->h_lo, Hp, p->b.W_lo, Hp, e, st));
     }
+    if (forked) DAE_CHECK_HIP(hipStreamWaitEvent(st, p->ev_join, 0));   // join: triplet scalars and Gs are ready
     // 8. statistics of this step (autoencoder.py:233 fetch list)
     PROF(PS_STATS, dae_step_stats(is_cos ? p->rowloss_part : nullptr, 1, is_cos ? nullptr : p->tile_part, (Bp / 128) * (Fp / 128), p->cw, B, Bp,
                       c.triplet == 3 ? DAE_TRIPLET_BATCH_HARD : c.triplet, c.alpha,

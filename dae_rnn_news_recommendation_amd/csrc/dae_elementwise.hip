@@ -174,6 +174,50 @@ __global__ void label_weight_kernel(const int32_t* __restrict__ n_same, int B, i
     }
 }
 
+// single-launch variant for B <= 1024 (the usual mini-batch): one 1024-thread block, labels in LDS, integer LDS atomics
+__global__ __launch_bounds__(1024) void label_stats_small_kernel(const int32_t* __restrict__ labels, int B, int Bp, int triplet,
+                                                                 int64_t* __restrict__ nvalid_out, int64_t* __restrict__ dw_out,
+                                                                 float* __restrict__ cw) {
+    __shared__ __attribute__((aligned(16))) int32_t lab[1024];
+    __shared__ unsigned long long accS, accNV;
+    const int i = threadIdx.x;
+    if (triplet == DAE_TRIPLET_NONE) {
+        if (i < Bp) cw[i] = (i < B) ? 1.0f / ((float)B + 1e-16f) : 0.f;
+        return;
+    }
+    if (i == 0) { accS = 0ull; accNV = 0ull; }
+    lab[i] = (i < B) ? labels[i] : (int32_t)0x80000000;      // sentinel never equals a real id (ids are >= 0)
+    __syncthreads();
+    long long n = 0;
+    if (i < B) {
+        const int32_t li = lab[i];
+        int cnt = 0;
+        const int4* l4 = reinterpret_cast<const int4*>(lab);
+        const int n4 = (B + 3) >> 2;
+#pragma unroll 4
+        for (int k = 0; k < n4; ++k) {                       // 16-byte LDS broadcast reads
+            const int4 v = l4[k];
+            cnt += (v.x == li) + (v.y == li) + (v.z == li) + (v.w == li);
+        }
+        n = cnt;
+    }
+    {   // one LDS atomic per wave, not per thread (800 colliding 64-bit LDS atomics cost ~20 us)
+        const unsigned s1 = wave_sum_u32(i < B ? (unsigned)(n - 1) : 0u);
+        const unsigned s2 = wave_sum_u32(i < B ? (unsigned)((n - 1) * (B - n)) : 0u);     // <= 64 * 2.7e5 per wave
+        if ((i & 63) == 0) { atomicAdd(&accS, (unsigned long long)s1); atomicAdd(&accNV, (unsigned long long)s2); }
+    }
+    __syncthreads();
+    const long long S = (long long)accS, NV = (long long)accNV;
+    if (i == 0 && nvalid_out) nvalid_out[0] = NV;
+    if (i < B) {
+        const long long dw = 2 * (n - 1) * (B - n) + (S - n * (n - 1));
+        if (dw_out) dw_out[i] = dw;
+        if (triplet == DAE_TRIPLET_BATCH_ALL) cw[i] = (float)dw / ((float)(3 * NV) + 1e-16f);
+    } else if (i < Bp && triplet == DAE_TRIPLET_BATCH_ALL) {
+        cw[i] = 0.f;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // miner partials -> normalisers / statistics (single 1024-thread block)
 // ------------------------------------------------------------------------------------------------
@@ -457,6 +501,12 @@ extern "C" int dae_sym_scale(const float* G, int32_t B, int32_t Bp, const float*
 extern "C" int dae_label_stats(const int32_t* labels, int32_t B, int32_t Bp, int32_t triplet, int32_t* n_same_scratch,
                                uint64_t* acc_scratch, int64_t* nvalid_out, int64_t* dw_out, float* cw, void* stream) {
     DAE_CHECK_ARG(cw && B > 0 && Bp >= B, "label_stats: bad args");
+    DAE_CHECK_ARG(triplet == DAE_TRIPLET_NONE || labels, "label_stats: labels required");
+    if (Bp <= 1024) {
+        hipLaunchKernelGGL(label_stats_small_kernel, dim3(1), dim3(1024), 0, ST(stream), labels, B, Bp, triplet, nvalid_out, dw_out, cw);
+        DAE_CHECK_LAUNCH();
+        return 0;
+    }
     if (triplet != DAE_TRIPLET_NONE) {
         DAE_CHECK_ARG(labels && n_same_scratch && acc_scratch, "label_stats: labels/scratch required");
         DAE_CHECK_HIP(hipMemsetAsync(acc_scratch, 0, 2 * sizeof(uint64_t), ST(stream)));

@@ -51,6 +51,7 @@ struct GemmParams {
     GemmSeg seg[2];
     int ktiles_total;
     int tiles_m, tiles_n, splits;
+    int probe;              // experiment (env DAE_GEMM_PROBE): 1 = skip the MFMA block (staging-rate probe)
 };
 
 template <typename T> struct Mma;
@@ -126,24 +127,52 @@ __device__ __forceinline__ void stage_glds(const GemmParams& p, int kt, int row0
     }
 }
 
+// One K tile of MFMA work for a wave.  All 16 fragment reads (ds_read_b128, 64 VGPRs) are issued back to back and
+// the four MFMA groups wait with COUNTED lgkmcnt (12/8/4/0): the first MFMAs start as soon as their fragments land
+// and the LDS latency of the rest hides behind them.  rocprofv3 showed ~50 % of wave time parked in lgkmcnt(0) with
+// the compiler's own read->wait(0)->MFMA x4 schedule, and hipcc turns any source-level hoisting back into a full
+// wait, so the reads are inline asm (invisible to its scoreboard) with hand-placed waits; each wait is followed by
+// sched_barrier(0) because register-only MFMAs may otherwise be hoisted above an asm s_waitcnt (guide 5.4 rule 18).
+__device__ __forceinline__ i32x4 lds_read_b128(uint32_t addr) {
+    i32x4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=&v"(v) : "v"(addr));
+    return v;
+}
+__device__ __forceinline__ i32x4 lds_read_b128_off4096(uint32_t addr) {
+    i32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:4096" : "=&v"(v) : "v"(addr));
+    return v;
+}
+
 template <typename T>
 __device__ __forceinline__ void compute_stage(const char* stage, int wm, int wn, int lane, f32x16 (&acc)[2][2]) {
     const int r = lane & 31, g = lane >> 5;
     const int swz = (r >> 1) & 7;
-    const char* pa = stage + (wm * 64 + r) * BKB;
-    const char* pb = stage + TILE_BYTES + (wn * 64 + r) * BKB;
+    const uint32_t base = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)stage;
+    const uint32_t pa = base + (wm * 64 + r) * BKB;
+    const uint32_t pb = base + TILE_BYTES + (wn * 64 + r) * BKB;
+    i32x4 a[4][2], b[4][2];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-        const int so = ((kk * 2 + g) ^ swz) << 4;
-        i32x4 a0 = *reinterpret_cast<const i32x4*>(pa + so);
-        i32x4 a1 = *reinterpret_cast<const i32x4*>(pa + 32 * BKB + so);
-        i32x4 b0 = *reinterpret_cast<const i32x4*>(pb + so);
-        i32x4 b1 = *reinterpret_cast<const i32x4*>(pb + 32 * BKB + so);
-        Mma<T>::run(a0, b0, acc[0][0]);
-        Mma<T>::run(a0, b1, acc[0][1]);
-        Mma<T>::run(a1, b0, acc[1][0]);
-        Mma<T>::run(a1, b1, acc[1][1]);
+        const uint32_t so = ((kk * 2 + g) ^ swz) << 4;
+        a[kk][0] = lds_read_b128(pa + so);
+        a[kk][1] = lds_read_b128_off4096(pa + so);          // + 32 rows * 128 B
+        b[kk][0] = lds_read_b128(pb + so);
+        b[kk][1] = lds_read_b128_off4096(pb + so);
     }
+#define DAE_MMA_GROUP(KK, CNT)                                   \
+    asm volatile("s_waitcnt lgkmcnt(" #CNT ")" ::: "memory");    \
+    __builtin_amdgcn_sched_barrier(0);                           \
+    Mma<T>::run(a[KK][0], b[KK][0], acc[0][0]);                  \
+    Mma<T>::run(a[KK][0], b[KK][1], acc[0][1]);                  \
+    Mma<T>::run(a[KK][1], b[KK][0], acc[1][0]);                  \
+    Mma<T>::run(a[KK][1], b[KK][1], acc[1][1]);
+    DAE_MMA_GROUP(0, 12)
+    DAE_MMA_GROUP(1, 8)
+    DAE_MMA_GROUP(2, 4)
+    DAE_MMA_GROUP(3, 0)
+#undef DAE_MMA_GROUP
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // K loop.  NST >= 2: ring of NST LDS stages filled by global_load_lds with COUNTED vmcnt waits -- tile i+NST-1 is
@@ -181,7 +210,7 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, int tm, int t
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if (i + NST - 1 < nk) stage_glds(p, kt0 + i + NST - 1, row0_m, row0_n, wave, lane, lds + nxt * STAGE_BYTES);
-            compute_stage<T>(lds + cur * STAGE_BYTES, wm, wn, lane, acc);
+            if (!(p.probe & 1)) compute_stage<T>(lds + cur * STAGE_BYTES, wm, wn, lane, acc);
             cur = (cur + 1 == NST) ? 0 : cur + 1;
             nxt = (nxt + 1 == NST) ? 0 : nxt + 1;
         }
@@ -202,14 +231,43 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, int tm, int t
     }
 }
 
-__device__ __forceinline__ void block_to_tile(const GemmParams& p, int& tm, int& tn, int& split, int& kt0, int& kt1) {
+// block -> (tile, K slice).  The dispatcher places block b on XCD b % 8 (each XCD has a private 4 MiB L2), so:
+//   splits > 1 : split = b % splits -- every block of one K slice lands on the same XCD (splits % 8 == 0) and
+//                the slice of both operands (a few MiB) is fetched from HBM once per XCD;
+//   splits == 1: the longer tile dimension is cut into 8 contiguous bands, one per XCD, so a band's operand panel
+//                is read from HBM by ONE XCD and re-used from its L2 by the tiles that share it (rocprofv3
+//                FETCH_SIZE of the dW GEMM: 145 MB with the naive row-major map vs 38 MB of operands).
+// Placement only affects speed, never results.  Returns false for the few padding blocks of the banded map.
+__device__ __forceinline__ bool block_to_tile(const GemmParams& p, int& tm, int& tn, int& split, int& kt0, int& kt1) {
     const int id = blockIdx.x;
-    split = id % p.splits;              // same K-slice -> same XCD when splits % 8 == 0 (block b -> XCD b%8)
-    const int tile = id / p.splits;
-    tn = tile % p.tiles_n;
-    tm = tile / p.tiles_n;
+    if (p.splits > 1) {
+        split = id % p.splits;
+        const int tile = id / p.splits;
+        tn = tile % p.tiles_n;
+        tm = tile / p.tiles_n;
+    } else {
+        split = 0;
+        const int x = id & 7, l = id >> 3;
+        if (p.tiles_m >= p.tiles_n) {
+            const int per = (p.tiles_m + 7) >> 3;
+            tm = x * per + l / p.tiles_n;
+            tn = l % p.tiles_n;
+            if (l >= per * p.tiles_n || tm >= p.tiles_m) return false;
+        } else {
+            const int per = (p.tiles_n + 7) >> 3;
+            tn = x * per + l / p.tiles_m;
+            tm = l % p.tiles_m;
+            if (l >= per * p.tiles_m || tn >= p.tiles_n) return false;
+        }
+    }
     kt0 = (int)(((int64_t)p.ktiles_total * split) / p.splits);
     kt1 = (int)(((int64_t)p.ktiles_total * (split + 1)) / p.splits);
+    return true;
+}
+static int grid_blocks(const GemmParams& p) {
+    if (p.splits > 1) return p.tiles_m * p.tiles_n * p.splits;
+    const int big = p.tiles_m >= p.tiles_n ? p.tiles_m : p.tiles_n, small = p.tiles_m >= p.tiles_n ? p.tiles_n : p.tiles_m;
+    return 8 * ((big + 7) / 8) * small;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -223,7 +281,7 @@ __global__ __launch_bounds__(GEMM_THREADS, wg_per_cu_for(NST)) void gemm_nt_f32o
                                                                                    int64_t slab_stride) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     int tm, tn, split, kt0, kt1;
-    block_to_tile(p, tm, tn, split, kt0, kt1);
+    if (!block_to_tile(p, tm, tn, split, kt0, kt1)) return;
     f32x16 acc[2][2];
     gemm_mainloop<T, NST>(p, tm, tn, kt0, kt1, lds, acc);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -299,7 +357,7 @@ __global__ __launch_bounds__(GEMM_THREADS, wg_per_cu_for(DECODE_NST)) void gemm_
     constexpr bool STAGED = (sizeof(T) == 2);
     constexpr bool IS_COS = (LOSS == DAE_LOSS_COSINE);
     int tm, tn, split, kt0, kt1;
-    block_to_tile(p, tm, tn, split, kt0, kt1);
+    if (!block_to_tile(p, tm, tn, split, kt0, kt1)) return;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, g = lane >> 5, c = lane & 31;
@@ -536,6 +594,8 @@ static int fill_params(GemmParams& p, int dtype, int M, int N, const void* A0, i
     p.ktiles_total = p.seg[0].ktiles + p.seg[1].ktiles;
     p.tiles_m = M / BM; p.tiles_n = N / BN;
     p.splits = splits < 1 ? 1 : splits;
+    static const int probe = [] { const char* v = getenv("DAE_GEMM_PROBE"); return v ? atoi(v) : 0; }();
+    p.probe = probe;
     DAE_CHECK_ARG(p.splits <= p.ktiles_total, "gemm: splits=%d exceeds k-tiles=%d", p.splits, p.ktiles_total);
     return 0;
 }
@@ -597,7 +657,7 @@ int launch_gemm_f32out(int dtype, int M, int N, const void* A0, int64_t lda0, co
     if (int rc = fill_params(p, dtype, M, N, A0, lda0, Bt0, ldb0, K0, A1, lda1, Bt1, ldb1, K1, splits)) return rc;
     DAE_CHECK_ARG(C != nullptr, "gemm: C is null");
     if (int rc = gemm_init()) return rc;
-    dim3 grid(p.tiles_m * p.tiles_n * p.splits), block(GEMM_THREADS);
+    dim3 grid(grid_blocks(p)), block(GEMM_THREADS);
     const int nst = g_nst;
     f32out_fn k = dtype == DAE_BF16 ? f32out_kernel<bf16_t>(nst, role) : f32out_kernel<float>(nst, role);
     hipLaunchKernelGGL(k, grid, block, lds_bytes_for(nst == 0 || nst == 3 || nst == 4 ? nst : 2), st, p, C, ldc, slab_stride);
@@ -614,7 +674,7 @@ int launch_decode_loss(int dtype, int Bp, int Fp, int Hp, const void* h_lo, int6
     DAE_CHECK_ARG(e.ldx % 8 == 0 && (!e.delta2 || e.ldd % 8 == 0) && (!e.delta2_t || e.lddt % 8 == 0),
                   "decode_loss: leading dimensions must be multiples of 8 elements");
     decode_fn k = dtype == DAE_BF16 ? decode_kernel<bf16_t>(e.loss_func, e.dec_act) : decode_kernel<float>(e.loss_func, e.dec_act);
-    dim3 grid(p.tiles_m * p.tiles_n), block(GEMM_THREADS);
+    dim3 grid(grid_blocks(p)), block(GEMM_THREADS);
     hipLaunchKernelGGL(k, grid, block, DECODE_LDS_BYTES, st, p, e);
     DAE_CHECK_LAUNCH();
     return 0;

@@ -74,33 +74,48 @@ __device__ __forceinline__ float sigmoid_only(float t) {
 // so the hot loop needs no masks.
 constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
 
-template <bool POS_ONLY, int Q>
-__device__ __forceinline__ void sweep_pairs(const float* __restrict__ pu, const float* __restrict__ nv, int nP, int nN,
+// FACT = true: exp(v - u) is formed as E_n * F_p with E_n = exp(v_n - m) (one per lane register) and F_p = exp(m - u_p)
+// (one LDS value per positive), m = mid-range of the anchor's D row -- one transcendental less per pair.  Used when
+// the row's range is <= 80 so that neither factor nor the product can overflow; otherwise the direct form runs.
+template <bool POS_ONLY, int Q, bool FACT>
+__device__ __forceinline__ void sweep_pairs(const float* __restrict__ pu, const float* __restrict__ pf, float mid,
+                                            const float* __restrict__ nv, int nP, int nN,
                                             int k0, int wave, int lane, float* __restrict__ gpos,
                                             unsigned* __restrict__ cpos, float* __restrict__ gneg_w,
                                             unsigned* __restrict__ cneg_w, float& loss, unsigned& cnt) {
-    float v[Q], gs[Q];
+    float v[Q], gs[Q], ev[Q];
     unsigned rc[Q];
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
         const int k = k0 + q * 64 + lane;
         v[q] = (k < nN) ? nv[k] : -INFINITY;
+        ev[q] = FACT ? __builtin_amdgcn_exp2f((v[q] - mid) * kLog2e) : 0.f;      // exp(-inf) = 0 for padding lanes
         gs[q] = 0.f; rc[q] = 0u;
     }
 #pragma unroll 2
     for (int p = wave; p < nP; p += 4) {
         const float u = pu[p];
+        const float fp = FACT ? pf[p] : 0.f;
         float sgp = 0.f;
         unsigned cp = 0u;
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             const float t = v[q] - u;                                   // triplet_distance[a,p,n]  (:106)
-            const float en = __builtin_amdgcn_exp2f(-fabsf(t) * kLog2e);    // exp(-|t|) in [0,1]
-            const float w = 1.0f + en;
-            const float r = __builtin_amdgcn_rcpf(w);
-            const float l = en < 1e-4f ? en * (1.0f - 0.5f * en) : kLn2 * __builtin_amdgcn_logf(w);   // log1p(en)
-            const float sp = fmaxf(t, 0.f) + l;                         // softplus(t) = -log_sigmoid(-t)  (:126)
-            const float sg = t >= 0.f ? r : en * r;                     // sigmoid(t) = SoftplusGrad
+            float sp, sg;
+            if constexpr (FACT) {
+                const float e = ev[q] * fp;                             // exp(t)
+                const float w = 1.0f + e;
+                const float r = __builtin_amdgcn_rcpf(w);
+                sp = e < 1e-4f ? e * (1.0f - 0.5f * e) : kLn2 * __builtin_amdgcn_logf(w);   // softplus(t) = log1p(exp(t))  (:126)
+                sg = e * r;                                             // sigmoid(t) = SoftplusGrad
+            } else {
+                const float en = __builtin_amdgcn_exp2f(-fabsf(t) * kLog2e);    // exp(-|t|) in [0,1]
+                const float w = 1.0f + en;
+                const float r = __builtin_amdgcn_rcpf(w);
+                const float l = en < 1e-4f ? en * (1.0f - 0.5f * en) : kLn2 * __builtin_amdgcn_logf(w);   // log1p(en)
+                sp = fmaxf(t, 0.f) + l;                                 // softplus(t) = -log_sigmoid(-t)  (:126)
+                sg = t >= 0.f ? r : en * r;                             // sigmoid(t) = SoftplusGrad
+            }
             const bool pos = t > 1e-16f;                                // (:114)
             loss += POS_ONLY ? (pos ? sp : 0.f) : sp;
             const float sgu = POS_ONLY ? (pos ? sg : 0.f) : sg;
@@ -134,7 +149,8 @@ __global__ __launch_bounds__(TRIP_THREADS) void batch_all_kernel(const float* __
     float* val = reinterpret_cast<float*>(smem);             // [Bp]
     int* idx = reinterpret_cast<int*>(val + Bp);              // [Bp]
     float* gpos = reinterpret_cast<float*>(idx + Bp);         // [Bp]    positive-role gradient sums (one owner wave each)
-    float* gneg = gpos + Bp;                                  // [4][Bp] per-wave negative-role partial sums
+    float* pf = gpos + Bp;                                    // [Bp]    F_p = exp(mid - u_p) of the factorised sweep
+    float* gneg = pf + Bp;                                    // [4][Bp] per-wave negative-role partial sums
     int* scan = reinterpret_cast<int*>(gneg + 4 * Bp);        // [2][TRIP_THREADS + 1]
     float* red = reinterpret_cast<float*>(scan + 2 * (TRIP_THREADS + 1));   // [4]
     unsigned* redu = reinterpret_cast<unsigned*>(red + 4);    // [4]
@@ -187,6 +203,17 @@ __global__ __launch_bounds__(TRIP_THREADS) void batch_all_kernel(const float* __
         }
     }
     __syncthreads();
+    // range of the anchor's D row over its positives and negatives -> factorised or direct sweep (uniform choice)
+    float lo = INFINITY, hi = -INFINITY;
+    for (int k = tid; k < nP; k += TRIP_THREADS) { lo = fminf(lo, pu[k]); hi = fmaxf(hi, pu[k]); }
+    for (int k = tid; k < nN; k += TRIP_THREADS) { lo = fminf(lo, nv[k]); hi = fmaxf(hi, nv[k]); }
+    lo = block_min_f(lo, red);
+    hi = block_max_f(hi, red);
+    const bool fact = (hi - lo) <= 80.0f;                    // also false for NaN/inf rows
+    const float mid = 0.5f * (hi + lo);
+    if (fact)
+        for (int k = tid; k < nP; k += TRIP_THREADS) pf[k] = __builtin_amdgcn_exp2f((mid - pu[k]) * kLog2e);
+    __syncthreads();
 
     float loss = 0.f;
     unsigned cnt = 0u;
@@ -194,7 +221,11 @@ __global__ __launch_bounds__(TRIP_THREADS) void batch_all_kernel(const float* __
     unsigned* cneg_w = POS_ONLY ? cneg + wave * Bp : nullptr;
     for (int k0 = 0; k0 < nN;) {
         const int q = min(8, (nN - k0 + 63) / 64);          // negatives per lane in this chunk
-#define DAE_SWEEP(QV) sweep_pairs<POS_ONLY, QV>(pu, nv, nP, nN, k0, wave, lane, gpos, cpos, gneg_w, cneg_w, loss, cnt)
+#define DAE_SWEEP(QV)                                                                                                  \
+    do {                                                                                                               \
+        if (fact) sweep_pairs<POS_ONLY, QV, true>(pu, pf, mid, nv, nP, nN, k0, wave, lane, gpos, cpos, gneg_w, cneg_w, loss, cnt);  \
+        else sweep_pairs<POS_ONLY, QV, false>(pu, pf, mid, nv, nP, nN, k0, wave, lane, gpos, cpos, gneg_w, cneg_w, loss, cnt);      \
+    } while (0)
         switch (q) {
             case 8: DAE_SWEEP(8); break;
             case 7: DAE_SWEEP(7); break;
@@ -312,7 +343,7 @@ extern "C" int dae_triplet_batch_all(const float* D_slabs, int32_t d_splits, int
     DAE_CHECK_ARG(B > 0 && B <= Bp && Bp <= TRIP_MAX_B, "batch_all: batch %d (padded %d) exceeds the supported %d", B, Bp, TRIP_MAX_B);
     DAE_CHECK_ARG(!pos_only || role_cnt, "batch_all: role_cnt required with pos_triplets_only");
     // val + idx + 4 per-wave gradient rows (+ 4 count rows when pos_only) + scans + reductions
-    const size_t lds = (size_t)Bp * (pos_only ? 48 : 28) + 2 * (TRIP_THREADS + 1) * sizeof(int) + 8 * sizeof(float);
+    const size_t lds = (size_t)Bp * (pos_only ? 52 : 32) + 2 * (TRIP_THREADS + 1) * sizeof(int) + 8 * sizeof(float);
     DAE_CHECK_ARG(lds <= 160 * 1024, "batch_all: batch %d needs %zu B of LDS (> 160 KiB)", B, lds);
     static bool attr_done = false;
     if (!attr_done) {

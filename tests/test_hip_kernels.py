@@ -298,11 +298,13 @@ def test_miners_vs_reference_golden(ops, L, case):
     assert np.allclose(tri[1], G[k + "bh_loss"], rtol=1e-4, atol=1e-6)      # and close to the reference's own value
 
 
-@pytest.mark.parametrize("B,classes,signed", [(200, 4, True), (333, 7, True), (128, 1, False), (257, 50, True)])
-def test_miners_gradients(ops, L, B, classes, signed):
+@pytest.mark.parametrize("B,classes,signed,scale", [(200, 4, True, 2.0), (333, 7, True, 2.0), (128, 1, False, 0.3), (257, 50, True, 2.0),
+                                                     (300, 3, True, 12.0),      # D row range > 80: the direct (non-factorised) sweep
+                                                     (1500, 5, True, 1.0)])     # B > 1024: two-kernel label statistics
+def test_miners_gradients(ops, L, B, classes, signed, scale):
     rng = np.random.default_rng(B)
     H = 40
-    h = (rng.random((B, H)).astype(np.float32) - (0.5 if signed else 0.0)) * (2.0 if signed else 0.3)
+    h = (rng.random((B, H)).astype(np.float32) - (0.5 if signed else 0.0)) * scale
     lab = rng.integers(0, classes, B)
     labels = dev(lab.astype(np.int32))
     D = _gram_slabs(ops, L, h, 3)
