@@ -90,7 +90,8 @@ struct dae_plan {
     int s_enc, s_dh, s_gram;
     uint64_t ws_bytes;
     // carved pointers
-    char *x, *xc, *xct, *h_lo, *h_t, *Gs, *delta2, *delta2_t, *delta1_t;
+    char *x, *xc, *xct, *h_lo, *h_t, *Gs, *delta2, *delta2_t, *delta1_t, *hcat_a, *hcat_b;
+    bool gram_split;                 // Gram matrix as a 3-term split-bf16 MFMA GEMM (bf16 mode) instead of exact-fp32 MFMA
     float *slabs, *h_f32, *D_slabs, *G, *rowloss_part, *dbv_part, *colsum_part, *cos_part, *cos_stats, *cw, *loss_part,
         *dw_f32, *tri_scalars, *dh_extra, *rowsq_scratch, *tile_part;
     uint32_t *cnt_part, *role_cnt;
@@ -129,6 +130,8 @@ static uint64_t carve(dae_plan* p, char* base) {
     p->h_t = take(Hp * Bp * es);
     p->delta1_t = take(Hp * Bp * es);
     p->dh_extra = (float*)take(Bp * Hp * 4);
+    p->hcat_a = take(p->gram_split ? Bp * 3 * Hp * 2 : 256);
+    p->hcat_b = take(p->gram_split ? Bp * 3 * Hp * 2 : 256);
     p->D_slabs = (float*)take((uint64_t)p->s_gram * Bp * Bp * 4);
     p->G = (float*)take(Bp * Bp * 4);
     p->Gs = take(Bp * Bp * es);
@@ -177,6 +180,8 @@ extern "C" int dae_plan_create(const dae_config* cfg, dae_plan** out) {
     if (p->s_enc > kt_f) p->s_enc = kt_f;
     if (p->s_dh > kt_f) p->s_dh = kt_f;
     if (p->s_gram > p->Hp * 4 / 128) p->s_gram = p->Hp * 4 / 128;
+    p->gram_split = (cfg->dtype == DAE_BF16) && (cfg->triplet == DAE_TRIPLET_BATCH_ALL || cfg->triplet == DAE_TRIPLET_BATCH_HARD) &&
+                    getenv("DAE_GRAM_FP32") == nullptr;
     p->ws_bytes = carve(p, nullptr);
     p->overlap_ok = getenv("DAE_OVERLAP") != nullptr;   // measured: running the miner chain beside decode is SLOWER (0.410 vs 0.351 ms/step)
     *out = p;
@@ -239,7 +244,7 @@ extern "C" int dae_plan_sync_shadows(dae_plan* p, void* stream) {
 extern "C" void* dae_plan_buffer(dae_plan* p, const char* name) {
     if (!p || !p->bound || !name) return nullptr;
 #define DAE_BUF(n) if (!strcmp(name, #n)) return (void*)p->n;
-    DAE_BUF(x) DAE_BUF(xc) DAE_BUF(xct) DAE_BUF(h_lo) DAE_BUF(h_t) DAE_BUF(Gs) DAE_BUF(delta2) DAE_BUF(delta2_t) DAE_BUF(delta1_t)
+    DAE_BUF(hcat_a) DAE_BUF(hcat_b) DAE_BUF(x) DAE_BUF(xc) DAE_BUF(xct) DAE_BUF(h_lo) DAE_BUF(h_t) DAE_BUF(Gs) DAE_BUF(delta2) DAE_BUF(delta2_t) DAE_BUF(delta1_t)
     DAE_BUF(slabs) DAE_BUF(h_f32) DAE_BUF(D_slabs) DAE_BUF(G) DAE_BUF(rowloss_part) DAE_BUF(dbv_part) DAE_BUF(colsum_part)
     DAE_BUF(cos_part) DAE_BUF(cos_stats) DAE_BUF(cw) DAE_BUF(loss_part) DAE_BUF(dw_f32) DAE_BUF(tri_scalars) DAE_BUF(dh_extra)
     DAE_BUF(tile_part) DAE_BUF(cnt_part) DAE_BUF(role_cnt) DAE_BUF(dw_i32) DAE_BUF(n_same) DAE_BUF(nvalid) DAE_BUF(dw_i64)
@@ -267,6 +272,15 @@ static int gather_batch(dae_plan* p, const int64_t* indptr, const int32_t* indic
 }
 
 #define RC(expr) do { if (int rc__ = (expr)) return rc__; } while (0)
+// K5: D = h h^T (triplet_loss_utils.py:93,219).  fp32 mode: exact-fp32 MFMA.  bf16 mode: split-bf16 (h = hi + lo,
+// three bf16 MFMA products concatenated along K = 3*Hp), ~2^-17 relative error, 16x the MFMA rate.
+static int launch_gram(dae_plan* p, int Bp, int Hp, int64_t dslab, hipStream_t st) {
+    if (p->gram_split)
+        return launch_gemm_f32out(DAE_BF16, Bp, Bp, p->hcat_a, 3 * Hp, p->hcat_b, 3 * Hp, 3 * Hp, nullptr, 0, nullptr, 0, 0, p->D_slabs, Bp,
+                                  p->s_gram, dslab, st, GEMM_ROLE_GRAM);
+    return launch_gemm_f32out(DAE_F32, Bp, Bp, p->h_f32, Hp, p->h_f32, Hp, Hp, nullptr, 0, nullptr, 0, 0, p->D_slabs, Bp, p->s_gram, dslab, st,
+                              GEMM_ROLE_GRAM);
+}
 // PROF(slot, call): in profile mode bracket the call with HIP events ON THE STEP'S STREAM and accumulate the
 // elapsed GPU time of that slot (costs a host sync per call, so it is never on when throughput is measured).
 #define PROF(slot, expr)                                                            \
@@ -316,7 +330,8 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     const int64_t slab = (int64_t)Bp * Hp;
     PROF(PS_ENC_GEMM, launch_gemm_f32out(dt, Bp, Hp, p->xc, Fp, p->b.Wt_lo, Fp, Fp, nullptr, 0, nullptr, 0, 0, p->slabs, Hp, p->s_enc, slab, st,
                                          GEMM_ROLE_ENCODE));
-    PROF(PS_ENC_FIN, dae_encode_finish(p->slabs, p->s_enc, slab, Hp, p->b.bh, B, H, c.enc_act, dt, p->h_f32, p->h_lo, Hp, p->h_t, ldB, stream));
+    PROF(PS_ENC_FIN, dae_encode_finish(p->slabs, p->s_enc, slab, Hp, p->b.bh, B, H, c.enc_act, dt, p->h_f32, p->h_lo, Hp, p->h_t, ldB,
+                                       p->gram_split ? p->hcat_a : nullptr, p->gram_split ? p->hcat_b : nullptr, stream));
     // 5-6. miners (K5-K7)
     const int Bt = explicit3 ? B / 3 : B;
     if (explicit3) {
@@ -348,8 +363,7 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
         }
         void* mstream = (void*)ms;
         if (forked) {
-            RC(launch_gemm_f32out(DAE_F32, Bp, Bp, p->h_f32, Hp, p->h_f32, Hp, Hp, nullptr, 0, nullptr, 0, 0, p->D_slabs, Bp, p->s_gram, dslab,
-                                  ms, GEMM_ROLE_GRAM));
+            RC(launch_gram(p, Bp, Hp, dslab, ms));
             RC(dae_triplet_batch_all(p->D_slabs, p->s_gram, dslab, Bp, s->labels, B, Bp, 0, p->loss_part, p->cnt_part, p->G, p->role_cnt,
                                      mstream));
             RC(dae_triplet_finalize(c.triplet, 0, B, Bp, c.alpha, p->loss_part, p->cnt_part, p->nvalid, p->dw_i32, p->role_cnt, p->dw_f32,
@@ -357,8 +371,7 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
             if (backward) RC(dae_sym_scale(p->G, B, Bp, p->tri_scalars, dt, p->Gs, mstream));
             DAE_CHECK_HIP(hipEventRecord(p->ev_join, ms));
         } else {
-            PROF(PS_GRAM, launch_gemm_f32out(DAE_F32, Bp, Bp, p->h_f32, Hp, p->h_f32, Hp, Hp, nullptr, 0, nullptr, 0, 0, p->D_slabs, Bp, p->s_gram,
-                                  dslab, st, GEMM_ROLE_GRAM));
+            PROF(PS_GRAM, launch_gram(p, Bp, Hp, dslab, st));
             if (c.triplet == DAE_TRIPLET_BATCH_ALL)
                 PROF(PS_MINER, dae_triplet_batch_all(p->D_slabs, p->s_gram, dslab, Bp, s->labels, B, Bp, c.pos_triplets_only, p->loss_part,
                                          p->cnt_part, p->G, p->role_cnt, stream));
@@ -435,7 +448,8 @@ extern "C" int dae_encode_rows(dae_plan* p, const int32_t* row_idx, int32_t B, f
     const int64_t slab = (int64_t)Bp * Hp;
     RC(launch_gemm_f32out(dt, Bp, Hp, p->xc, Fp, p->b.Wt_lo, Fp, Fp, nullptr, 0, nullptr, 0, 0, p->slabs, Hp, p->s_enc, slab, st,
                           GEMM_ROLE_ENCODE));
-    RC(dae_encode_finish(p->slabs, p->s_enc, slab, Hp, p->b.bh, B, p->H, p->cfg.enc_act, dt, p->h_f32, nullptr, Hp, nullptr, 0, stream));
+    RC(dae_encode_finish(p->slabs, p->s_enc, slab, Hp, p->b.bh, B, p->H, p->cfg.enc_act, dt, p->h_f32, nullptr, Hp, nullptr, 0, nullptr, nullptr,
+                         stream));
     DAE_CHECK_HIP(hipMemcpy2DAsync(out, (size_t)ld_out * 4, p->h_f32, (size_t)Hp * 4, (size_t)p->H * 4, B, hipMemcpyDeviceToDevice, st));
     return 0;
 }

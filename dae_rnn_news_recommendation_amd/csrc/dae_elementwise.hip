@@ -14,7 +14,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void encode_finish_kernel(const float* __restrict__ slabs, int splits, int64_t slab_stride,
                                                             int64_t ld_slab, const float* __restrict__ bh, int B, int H,
                                                             int enc_act, float* __restrict__ h_f32, T* __restrict__ h_lo,
-                                                            int64_t ldh, T* __restrict__ h_t, int64_t ldht) {
+                                                            int64_t ldh, T* __restrict__ h_t, int64_t ldht,
+                                                            bf16_t* __restrict__ hcat_a, bf16_t* __restrict__ hcat_b, int Hp) {
     __shared__ float tile[32][65];
     const int j0 = blockIdx.x * 64, i0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -35,6 +36,13 @@ __global__ __launch_bounds__(256) void encode_finish_kernel(const float* __restr
         const float h = (i < B && j < H) ? act_apply(enc_act, z[k] + b) - ab : 0.f;
         if (h_f32) h_f32[(int64_t)i * ldh + j] = h;
         if (h_lo) h_lo[(int64_t)i * ldh + j] = Elem<T>::from(h);
+        if (hcat_a) {   // split-bf16 operands of the Gram matrix: h = hi + lo, D ~= hi.hi + hi.lo + lo.hi (|err| ~ 2^-17 |h|^2)
+            const bf16_t hi = f2bf(h);
+            const bf16_t lo = f2bf(h - bf2f(hi));
+            const int64_t o = (int64_t)i * (3 * Hp) + j;
+            hcat_a[o] = hi; hcat_a[o + Hp] = hi; hcat_a[o + 2 * Hp] = lo;
+            hcat_b[o] = hi; hcat_b[o + Hp] = lo; hcat_b[o + 2 * Hp] = hi;
+        }
         tile[r][tx] = h;
     }
     __syncthreads();
@@ -174,34 +182,48 @@ __global__ void label_weight_kernel(const int32_t* __restrict__ n_same, int B, i
     }
 }
 
-// single-launch variant for B <= 1024 (the usual mini-batch): one 1024-thread block, labels in LDS, integer LDS atomics
+// single-launch variant for B <= 1024 (the usual mini-batch): one 1024-thread block.  Label multiplicities come
+// from an LDS histogram when every id lies in [0, 4096) (the Python layer always passes dense ids); arbitrary ids
+// fall back to the O(B^2) comparison loop.  Integer arithmetic only -> exact and order-independent.
 __global__ __launch_bounds__(1024) void label_stats_small_kernel(const int32_t* __restrict__ labels, int B, int Bp, int triplet,
                                                                  int64_t* __restrict__ nvalid_out, int64_t* __restrict__ dw_out,
                                                                  float* __restrict__ cw) {
+    constexpr int NBIN = 4096;
     __shared__ __attribute__((aligned(16))) int32_t lab[1024];
+    __shared__ int hist[NBIN];
     __shared__ unsigned long long accS, accNV;
+    __shared__ int out_of_range;
     const int i = threadIdx.x;
     if (triplet == DAE_TRIPLET_NONE) {
         if (i < Bp) cw[i] = (i < B) ? 1.0f / ((float)B + 1e-16f) : 0.f;
         return;
     }
-    if (i == 0) { accS = 0ull; accNV = 0ull; }
-    lab[i] = (i < B) ? labels[i] : (int32_t)0x80000000;      // sentinel never equals a real id (ids are >= 0)
+    if (i == 0) { accS = 0ull; accNV = 0ull; out_of_range = 0; }
+    for (int k = i; k < NBIN; k += 1024) hist[k] = 0;
+    const int32_t li = (i < B) ? labels[i] : 0;
+    lab[i] = (i < B) ? li : (int32_t)0x80000000;
+    __syncthreads();
+    if (i < B) {
+        if (li >= 0 && li < NBIN) atomicAdd(&hist[li], 1);
+        else out_of_range = 1;
+    }
     __syncthreads();
     long long n = 0;
     if (i < B) {
-        const int32_t li = lab[i];
-        int cnt = 0;
-        const int4* l4 = reinterpret_cast<const int4*>(lab);
-        const int n4 = (B + 3) >> 2;
-#pragma unroll 4
-        for (int k = 0; k < n4; ++k) {                       // 16-byte LDS broadcast reads
-            const int4 v = l4[k];
-            cnt += (v.x == li) + (v.y == li) + (v.z == li) + (v.w == li);
+        if (!out_of_range) {
+            n = hist[li];
+        } else {
+            int cnt = 0;
+            const int4* l4 = reinterpret_cast<const int4*>(lab);
+            const int n4 = (B + 3) >> 2;
+            for (int k = 0; k < n4; ++k) {
+                const int4 v = l4[k];
+                cnt += (v.x == li) + (v.y == li) + (v.z == li) + (v.w == li);
+            }
+            n = cnt;
         }
-        n = cnt;
     }
-    {   // one LDS atomic per wave, not per thread (800 colliding 64-bit LDS atomics cost ~20 us)
+    {   // one LDS atomic per wave, not per thread
         const unsigned s1 = wave_sum_u32(i < B ? (unsigned)(n - 1) : 0u);
         const unsigned s2 = wave_sum_u32(i < B ? (unsigned)((n - 1) * (B - n)) : 0u);     // <= 64 * 2.7e5 per wave
         if ((i & 63) == 0) { atomicAdd(&accS, (unsigned long long)s1); atomicAdd(&accNV, (unsigned long long)s2); }
@@ -454,17 +476,18 @@ using namespace dae;
 
 extern "C" int dae_encode_finish(const float* slabs, int32_t splits, int64_t slab_stride, int64_t ld_slab, const float* bh,
                                  int32_t B, int32_t H, int32_t enc_act, int32_t dtype, float* h_f32, void* h_lo, int64_t ldh,
-                                 void* h_t, int64_t ldht, void* stream) {
+                                 void* h_t, int64_t ldht, void* hcat_a, void* hcat_b, void* stream) {
+    DAE_CHECK_ARG((hcat_a == nullptr) == (hcat_b == nullptr), "encode_finish: hcat_a/hcat_b must be given together");
     DAE_CHECK_ARG(slabs && bh && splits >= 1, "encode_finish: null input");
     DAE_CHECK_ARG(B > 0 && H > 0 && ldh >= dae_pad(H) && (!h_t || ldht >= dae_pad(B)), "encode_finish: bad shape");
     const int Bp = (int)dae_pad(B), Hp = (int)dae_pad(H);
     dim3 grid(Hp / 64, Bp / 32), block(256);
     if (dtype == DAE_BF16)
         hipLaunchKernelGGL((encode_finish_kernel<bf16_t>), grid, block, 0, ST(stream), slabs, splits, slab_stride, ld_slab, bh, B,
-                           H, enc_act, h_f32, (bf16_t*)h_lo, ldh, (bf16_t*)h_t, ldht);
+                           H, enc_act, h_f32, (bf16_t*)h_lo, ldh, (bf16_t*)h_t, ldht, (bf16_t*)hcat_a, (bf16_t*)hcat_b, Hp);
     else
         hipLaunchKernelGGL((encode_finish_kernel<float>), grid, block, 0, ST(stream), slabs, splits, slab_stride, ld_slab, bh, B,
-                           H, enc_act, h_f32, (float*)h_lo, ldh, (float*)h_t, ldht);
+                           H, enc_act, h_f32, (float*)h_lo, ldh, (float*)h_t, ldht, (bf16_t*)hcat_a, (bf16_t*)hcat_b, Hp);
     DAE_CHECK_LAUNCH();
     return 0;
 }

@@ -120,6 +120,7 @@ __device__ __forceinline__ void stage_glds(const GemmParams& p, int kt, int row0
         const char* gb = Bt + (int64_t)(row0_n + row) * ldb + kb + sslot * 16;
         char* la = stage + piece * 1024;
         char* lb = stage + TILE_BYTES + piece * 1024;
+        if (!(p.probe & 2))      // probe 2: stage only the B operand (halves the staged bytes)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ga,
                                          (__attribute__((address_space(3))) void*)la, 16, 0, 0);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gb,
@@ -198,18 +199,21 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, int tm, int t
     if (nk <= 0) return;
 
     if constexpr (NST >= 2) {
+        // (measured, no effect: rotating the K order per tile to de-synchronise the tiles of one XCD)
+        auto ktile = [&](int i) { return kt0 + i; };
 #pragma unroll
         for (int s = 0; s < NST - 1; ++s)
-            if (s < nk) stage_glds(p, kt0 + s, row0_m, row0_n, wave, lane, lds + s * STAGE_BYTES);
+            if (s < nk) stage_glds(p, ktile(s), row0_m, row0_n, wave, lane, lds + s * STAGE_BYTES);
         int cur = 0, nxt = NST - 1;                       // ring positions of tile i and of tile i+NST-1
         for (int i = 0; i < nk; ++i) {
             const int ahead = min(NST - 2, nk - 1 - i);   // younger tiles that may stay in flight
-            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            if (p.probe & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (probe: op counts differ)
+            else if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (i + NST - 1 < nk) stage_glds(p, kt0 + i + NST - 1, row0_m, row0_n, wave, lane, lds + nxt * STAGE_BYTES);
+            if (i + NST - 1 < nk) stage_glds(p, ktile(i + NST - 1), row0_m, row0_n, wave, lane, lds + nxt * STAGE_BYTES);
             if (!(p.probe & 1)) compute_stage<T>(lds + cur * STAGE_BYTES, wm, wn, lane, acc);
             cur = (cur + 1 == NST) ? 0 : cur + 1;
             nxt = (nxt + 1 == NST) ? 0 : nxt + 1;

@@ -106,13 +106,17 @@ __device__ __forceinline__ void sweep_pairs(const float* __restrict__ pu, const 
                 const float e = ev[q] * fp;                             // exp(t)
                 const float w = 1.0f + e;
                 const float r = __builtin_amdgcn_rcpf(w);
-                sp = e < 1e-4f ? e * (1.0f - 0.5f * e) : kLn2 * __builtin_amdgcn_logf(w);   // softplus(t) = log1p(exp(t))  (:126)
+                float lg = kLn2 * __builtin_amdgcn_logf(w);
+                asm volatile("" : "+v"(lg));                            // keep the log unconditional: no per-pair branch
+                sp = e < 1e-4f ? e * (1.0f - 0.5f * e) : lg;           // softplus(t) = log1p(exp(t))  (:126)
                 sg = e * r;                                             // sigmoid(t) = SoftplusGrad
             } else {
                 const float en = __builtin_amdgcn_exp2f(-fabsf(t) * kLog2e);    // exp(-|t|) in [0,1]
                 const float w = 1.0f + en;
                 const float r = __builtin_amdgcn_rcpf(w);
-                const float l = en < 1e-4f ? en * (1.0f - 0.5f * en) : kLn2 * __builtin_amdgcn_logf(w);   // log1p(en)
+                float lg = kLn2 * __builtin_amdgcn_logf(w);
+                asm volatile("" : "+v"(lg));
+                const float l = en < 1e-4f ? en * (1.0f - 0.5f * en) : lg;   // log1p(en)
                 sp = fmaxf(t, 0.f) + l;                                 // softplus(t) = -log_sigmoid(-t)  (:126)
                 sg = t >= 0.f ? r : en * r;                             // sigmoid(t) = SoftplusGrad
             }
@@ -170,36 +174,45 @@ __global__ __launch_bounds__(TRIP_THREADS) void batch_all_kernel(const float* __
         if (POS_ONLY) { Rrow[j] = 0u; cpos[j] = 0u; }
     }
 
-    // ---- deterministic compaction: thread t owns the contiguous index range [t*C, (t+1)*C) ----
-    const int C = (B + TRIP_THREADS - 1) / TRIP_THREADS;
-    const int jb = min(B, tid * C), je = min(B, jb + C);
-    int cp = 0, cn = 0;
-    for (int j = jb; j < je; ++j) {
-        const int32_t lj = labels[j];
-        cp += (lj == la && j != a);
-        cn += (lj != la);
-    }
-    scan[tid + 1] = cp; scan[TRIP_THREADS + 1 + tid + 1] = cn;
-    if (tid == 0) { scan[0] = 0; scan[TRIP_THREADS + 1] = 0; }
-    __syncthreads();
-    if (tid < 2) {   // tiny serial scans (2 x 256 adds)
-        int* sc = scan + tid * (TRIP_THREADS + 1);
-        for (int k = 1; k <= TRIP_THREADS; ++k) sc[k] += sc[k - 1];
+    // ---- deterministic compaction in index order (ballot ranks; coalesced label / D-row reads) ----
+    // element j = k*256 + tid; its slot = (#positives before it in index order) = prefix over (k, wave) + rank in wave
+    const int K = (B + TRIP_THREADS - 1) / TRIP_THREADS;           // <= 16 for B <= 4096
+    int* cntP = scan;                                              // [K][4]
+    int* cntN = scan + 64;                                         // [K][4]
+    for (int k = 0; k < K; ++k) {
+        const int j = k * TRIP_THREADS + tid;
+        const int32_t lj = (j < B) ? labels[j] : la;
+        const bool isP = (j < B) && (lj == la) && (j != a);
+        const bool isN = (j < B) && (lj != la);
+        const unsigned long long bp = __ballot(isP), bn = __ballot(isN);
+        if (lane == 0) { cntP[k * 4 + wave] = __popcll(bp); cntN[k * 4 + wave] = __popcll(bn); }
     }
     __syncthreads();
-    const int nP = scan[TRIP_THREADS], nN = scan[TRIP_THREADS + 1 + TRIP_THREADS];
+    int nP = 0, nN = 0;
+    for (int e = 0; e < K * 4; ++e) { nP += cntP[e]; nN += cntN[e]; }
     float* pu = val;                      // positives: val[0 .. nP)
     float* nv = val + (Bp - nN);          // negatives: val[Bp-nN .. Bp)
     int* pidx = idx;
     int* nidx = idx + (Bp - nN);
     {
-        int op = scan[tid], on = scan[TRIP_THREADS + 1 + tid];
-        for (int j = jb; j < je; ++j) {
-            const int32_t lj = labels[j];
+        int offP = 0, offN = 0;           // running prefix over (k', wave') < (k, wave)
+        for (int k = 0; k < K; ++k) {
+            int beforeP = offP, beforeN = offN;
+            for (int w = 0; w < 4; ++w) {
+                if (w < wave) { beforeP += cntP[k * 4 + w]; beforeN += cntN[k * 4 + w]; }
+                offP += cntP[k * 4 + w]; offN += cntN[k * 4 + w];
+            }
+            const int j = k * TRIP_THREADS + tid;
+            const int32_t lj = (j < B) ? labels[j] : la;
+            const bool isP = (j < B) && (lj == la) && (j != a);
+            const bool isN = (j < B) && (lj != la);
+            const unsigned long long bp = __ballot(isP), bn = __ballot(isN);
+            const unsigned long long lt = (1ull << lane) - 1ull;
             float d = 0.f;
-            for (int sl = 0; sl < d_splits; ++sl) d += D_slabs[(int64_t)sl * slab_stride + (int64_t)a * ldd + j];
-            if (lj == la) { if (j != a) { pu[op] = d; pidx[op] = j; ++op; } }
-            else { nv[on] = d; nidx[on] = j; ++on; }
+            if (j < B)
+                for (int sl = 0; sl < d_splits; ++sl) d += D_slabs[(int64_t)sl * slab_stride + (int64_t)a * ldd + j];
+            if (isP) { const int o = beforeP + __popcll(bp & lt); pu[o] = d; pidx[o] = j; }
+            if (isN) { const int o = beforeN + __popcll(bn & lt); nv[o] = d; nidx[o] = j; }
         }
     }
     __syncthreads();

@@ -67,14 +67,18 @@ def gather_dense(data, row_idx, B, F, dtype, *, want_rowsq=False, corr_mode=L.CO
     return x, xc, xct, rowsq
 
 
-def encode_finish(slabs, bh, B, H, enc_act, dtype):
+def encode_finish(slabs, bh, B, H, enc_act, dtype, want_hcat=False):
     S, Bp, Hp = slabs.shape
     dev = slabs.device
     h32 = torch.empty((Bp, Hp), dtype=torch.float32, device=dev)
     hlo = torch.empty((Bp, Hp), dtype=tdtype(dtype), device=dev)
     ht = torch.empty((Hp, Bp), dtype=tdtype(dtype), device=dev)
+    ha = torch.empty((Bp, 3 * Hp), dtype=torch.bfloat16, device=dev) if want_hcat else None
+    hb = torch.empty((Bp, 3 * Hp), dtype=torch.bfloat16, device=dev) if want_hcat else None
     L.call("dae_encode_finish", L.ptr(slabs), S, Bp * Hp, Hp, L.ptr(bh), B, H, enc_act, dtype, L.ptr(h32), L.ptr(hlo),
-           Hp, L.ptr(ht), Bp, L.current_stream())
+           Hp, L.ptr(ht), Bp, L.ptr(ha), L.ptr(hb), L.current_stream())
+    if want_hcat:
+        return h32, hlo, ht, ha, hb
     return h32, hlo, ht
 
 

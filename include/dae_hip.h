@@ -95,10 +95,13 @@ int dae_gemm_nt(int32_t dtype, int32_t M, int32_t N,
 
 /* K2: encode epilogue  h = act(sum_s slab_s + bh) - act(bh)   (autoencoder.py:389)
  * writes h fp32 [Bp x ldh], h in `dtype` [Bp x ldh] and h^T in `dtype` [Hp x ldht]; rows >= B
- * and columns >= H are written as zero.  Any output pointer may be NULL. */
+ * and columns >= H are written as zero.  Any output pointer may be NULL.
+ * hcat_a / hcat_b (both or neither): bf16 [Bp x 3*Hp] = [hi|hi|lo] and [hi|lo|hi] with h = hi + lo, the
+ * operands of the split-bf16 Gram matrix  D ~= hcat_a . hcat_b^T  (one dae_gemm_nt call with K = 3*Hp). */
 int dae_encode_finish(const float* slabs, int32_t splits, int64_t slab_stride, int64_t ld_slab,
                       const float* bh, int32_t B, int32_t H, int32_t enc_act, int32_t dtype,
-                      float* h_f32, void* h_lo, int64_t ldh, void* h_t, int64_t ldht, void* stream);
+                      float* h_f32, void* h_lo, int64_t ldh, void* h_t, int64_t ldht,
+                      void* hcat_a, void* hcat_b, void* stream);
 
 /* K3+K4 (+ seeds of K8): decode GEMM fused with bias, activation, per-row reconstruction loss
  * and d cost / d z2   (autoencoder.py:411; triplet_loss_utils.py:262-277 weighted_loss).
