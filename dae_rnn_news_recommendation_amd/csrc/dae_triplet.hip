@@ -77,7 +77,7 @@ constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
 // FACT = true: exp(v - u) is formed as E_n * F_p with E_n = exp(v_n - m) (one per lane register) and F_p = exp(m - u_p)
 // (one LDS value per positive), m = mid-range of the anchor's D row -- one transcendental less per pair.  Used when
 // the row's range is <= 80 so that neither factor nor the product can overflow; otherwise the direct form runs.
-template <bool POS_ONLY, int Q, bool FACT>
+template <bool POS_ONLY, int Q, bool FACT, bool FIRST>
 __device__ __forceinline__ void sweep_pairs(const float* __restrict__ pu, const float* __restrict__ pf, float mid,
                                             const float* __restrict__ nv, int nP, int nN,
                                             int k0, int wave, int lane, float* __restrict__ gpos,
@@ -92,47 +92,57 @@ __device__ __forceinline__ void sweep_pairs(const float* __restrict__ pu, const 
         ev[q] = FACT ? __builtin_amdgcn_exp2f((v[q] - mid) * kLog2e) : 0.f;      // exp(-inf) = 0 for padding lanes
         gs[q] = 0.f; rc[q] = 0u;
     }
-#pragma unroll 2
-    for (int p = wave; p < nP; p += 4) {
-        const float u = pu[p];
-        const float fp = FACT ? pf[p] : 0.f;
-        float sgp = 0.f;
-        unsigned cp = 0u;
+    // two positives per iteration (p and p+4): their DPP reduction chains and LDS traffic interleave
+    for (int p = wave; p < nP; p += 8) {
+        const bool has2 = (p + 4) < nP;
+        float u[2], fp[2], sgp[2];
+        unsigned cp[2];
+        u[0] = pu[p]; u[1] = has2 ? pu[p + 4] : INFINITY;               // u = +inf -> t = -inf -> contributes nothing
+        fp[0] = FACT ? pf[p] : 0.f; fp[1] = (FACT && has2) ? pf[p + 4] : 0.f;
 #pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            const float t = v[q] - u;                                   // triplet_distance[a,p,n]  (:106)
-            float sp, sg;
-            if constexpr (FACT) {
-                const float e = ev[q] * fp;                             // exp(t)
-                const float w = 1.0f + e;
-                const float r = __builtin_amdgcn_rcpf(w);
-                float lg = kLn2 * __builtin_amdgcn_logf(w);
-                asm volatile("" : "+v"(lg));                            // keep the log unconditional: no per-pair branch
-                sp = e < 1e-4f ? e * (1.0f - 0.5f * e) : lg;           // softplus(t) = log1p(exp(t))  (:126)
-                sg = e * r;                                             // sigmoid(t) = SoftplusGrad
-            } else {
-                const float en = __builtin_amdgcn_exp2f(-fabsf(t) * kLog2e);    // exp(-|t|) in [0,1]
-                const float w = 1.0f + en;
-                const float r = __builtin_amdgcn_rcpf(w);
-                float lg = kLn2 * __builtin_amdgcn_logf(w);
-                asm volatile("" : "+v"(lg));
-                const float l = en < 1e-4f ? en * (1.0f - 0.5f * en) : lg;   // log1p(en)
-                sp = fmaxf(t, 0.f) + l;                                 // softplus(t) = -log_sigmoid(-t)  (:126)
-                sg = t >= 0.f ? r : en * r;                             // sigmoid(t) = SoftplusGrad
+        for (int h = 0; h < 2; ++h) {
+            sgp[h] = 0.f; cp[h] = 0u;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const float t = v[q] - u[h];                            // triplet_distance[a,p,n]  (:106)
+                float sp, sg;
+                if constexpr (FACT) {
+                    const float e = ev[q] * fp[h];                      // exp(t)
+                    const float w = 1.0f + e;
+                    const float r = __builtin_amdgcn_rcpf(w);
+                    float lg = kLn2 * __builtin_amdgcn_logf(w);
+                    asm volatile("" : "+v"(lg));                        // keep the log unconditional: no per-pair branch
+                    sp = e < 1e-4f ? e * (1.0f - 0.5f * e) : lg;       // softplus(t) = log1p(exp(t))  (:126)
+                    sg = e * r;                                         // sigmoid(t) = SoftplusGrad
+                } else {
+                    const float en = __builtin_amdgcn_exp2f(-fabsf(t) * kLog2e);    // exp(-|t|) in [0,1]
+                    const float w = 1.0f + en;
+                    const float r = __builtin_amdgcn_rcpf(w);
+                    float lg = kLn2 * __builtin_amdgcn_logf(w);
+                    asm volatile("" : "+v"(lg));
+                    const float l = en < 1e-4f ? en * (1.0f - 0.5f * en) : lg;   // log1p(en)
+                    sp = fmaxf(t, 0.f) + l;                             // softplus(t) = -log_sigmoid(-t)  (:126)
+                    sg = t >= 0.f ? r : en * r;                         // sigmoid(t) = SoftplusGrad
+                }
+                const bool pos = t > 1e-16f;                            // (:114)
+                loss += POS_ONLY ? (pos ? sp : 0.f) : sp;
+                const float sgu = POS_ONLY ? (pos ? sg : 0.f) : sg;
+                gs[q] += sgu;
+                sgp[h] += sgu;
+                cnt += pos ? 1u : 0u;
+                if (POS_ONLY) { rc[q] += pos ? 1u : 0u; cp[h] += pos ? 1u : 0u; }
             }
-            const bool pos = t > 1e-16f;                                // (:114)
-            loss += POS_ONLY ? (pos ? sp : 0.f) : sp;
-            const float sgu = POS_ONLY ? (pos ? sg : 0.f) : sg;
-            gs[q] += sgu;
-            sgp += sgu;
-            cnt += pos ? 1u : 0u;
-            if (POS_ONLY) { rc[q] += pos ? 1u : 0u; cp += pos ? 1u : 0u; }
         }
-        sgp = wave64_sum_hi(sgp);
-        if (POS_ONLY) cp = wave_sum_u32(cp);
+        sgp[0] = wave64_sum_hi(sgp[0]);
+        sgp[1] = wave64_sum_hi(sgp[1]);
+        if (POS_ONLY) { cp[0] = wave_sum_u32(cp[0]); cp[1] = wave_sum_u32(cp[1]); }
         if (lane == 63) {
-            gpos[p] += sgp;
-            if (POS_ONLY) cpos[p] += cp;
+            if (FIRST) { gpos[p] = sgp[0]; if (has2) gpos[p + 4] = sgp[1]; }
+            else { gpos[p] += sgp[0]; if (has2) gpos[p + 4] += sgp[1]; }
+            if (POS_ONLY) {
+                if (FIRST) { cpos[p] = cp[0]; if (has2) cpos[p + 4] = cp[1]; }
+                else { cpos[p] += cp[0]; if (has2) cpos[p + 4] += cp[1]; }
+            }
         }
     }
 #pragma unroll
@@ -143,7 +153,7 @@ __device__ __forceinline__ void sweep_pairs(const float* __restrict__ pu, const 
 }
 
 template <bool POS_ONLY>
-__global__ __launch_bounds__(TRIP_THREADS) void batch_all_kernel(const float* __restrict__ D_slabs, int d_splits,
+__global__ __launch_bounds__(TRIP_THREADS, 3) void batch_all_kernel(const float* __restrict__ D_slabs, int d_splits,
                                                                  int64_t slab_stride, int64_t ldd,
                                                                  const int32_t* __restrict__ labels, int B, int Bp,
                                                                  float* __restrict__ loss_part, uint32_t* __restrict__ npos_part,
@@ -233,17 +243,24 @@ __global__ __launch_bounds__(TRIP_THREADS) void batch_all_kernel(const float* __
     float* gneg_w = gneg + wave * Bp;
     unsigned* cneg_w = POS_ONLY ? cneg + wave * Bp : nullptr;
     for (int k0 = 0; k0 < nN;) {
-        const int q = min(8, (nN - k0 + 63) / 64);          // negatives per lane in this chunk
-#define DAE_SWEEP(QV)                                                                                                  \
-    do {                                                                                                               \
-        if (fact) sweep_pairs<POS_ONLY, QV, true>(pu, pf, mid, nv, nP, nN, k0, wave, lane, gpos, cpos, gneg_w, cneg_w, loss, cnt);  \
-        else sweep_pairs<POS_ONLY, QV, false>(pu, pf, mid, nv, nP, nN, k0, wave, lane, gpos, cpos, gneg_w, cneg_w, loss, cnt);      \
+        const int need = (nN - k0 + 63) / 64;                 // negatives per lane still to cover
+        // menu of register-resident widths; the smallest one >= need (10 caps a chunk at 640 negatives)
+        const int q = need <= 4 ? need : need <= 6 ? 6 : need <= 8 ? 8 : 10;
+        const bool first = (k0 == 0);
+#define DAE_SWEEP(QV)                                                                                                    \
+    do {                                                                                                                 \
+        if (fact) {                                                                                                      \
+            if (first) sweep_pairs<POS_ONLY, QV, true, true>(pu, pf, mid, nv, nP, nN, k0, wave, lane, gpos, cpos, gneg_w, cneg_w, loss, cnt);   \
+            else sweep_pairs<POS_ONLY, QV, true, false>(pu, pf, mid, nv, nP, nN, k0, wave, lane, gpos, cpos, gneg_w, cneg_w, loss, cnt);       \
+        } else {                                                                                                         \
+            if (first) sweep_pairs<POS_ONLY, QV, false, true>(pu, pf, mid, nv, nP, nN, k0, wave, lane, gpos, cpos, gneg_w, cneg_w, loss, cnt);  \
+            else sweep_pairs<POS_ONLY, QV, false, false>(pu, pf, mid, nv, nP, nN, k0, wave, lane, gpos, cpos, gneg_w, cneg_w, loss, cnt);      \
+        }                                                                                                                \
     } while (0)
         switch (q) {
+            case 10: DAE_SWEEP(10); break;
             case 8: DAE_SWEEP(8); break;
-            case 7: DAE_SWEEP(7); break;
             case 6: DAE_SWEEP(6); break;
-            case 5: DAE_SWEEP(5); break;
             case 4: DAE_SWEEP(4); break;
             case 3: DAE_SWEEP(3); break;
             case 2: DAE_SWEEP(2); break;
