@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--profile-steps", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for N>1 (nccl == RCCL; gloo only to exercise the N>1 code path on one GPU)")
+    ap.add_argument("--single-device", action="store_true", help="testing aid: every rank uses cuda:0")
     return ap.parse_args()
 
 
@@ -133,6 +136,21 @@ def cpu_baseline(a):
             "seconds": dt, "cost": float(r["cost"])}
 
 
+def committed_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc pass (profiles/*_pmc_traffic.json; FETCH_SIZE is
+    doubled per the gfx950 correction of MI355X_MICROARCH.md).  PMC counters cannot be read from inside this process, so
+    this is the last committed measurement of the same workload, or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        t = json.load(open(files[-1])).get(kernel)
+        return None if t is None else t["fetch_bytes"] + t["write_bytes"]
+    except Exception:
+        return None
+
+
 def main():
     a = parse()
     import torch
@@ -140,7 +158,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if world > 1:
-        dp.init_from_env("nccl")
+        if a.single_device:
+            os.environ["LOCAL_RANK"] = "0"
+        dp.init_from_env(a.backend)
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     else:
         torch.cuda.set_device(0)
     assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
@@ -194,7 +215,7 @@ def main():
             us = 1e3 * ms / n
             e = {"avg_us": us, "launches_per_step": n / a.profile_steps, "time_share": ms / tot if tot else 0.0}
             if k in flops:
-                peak = PEAK_F32_MFMA_TFLOPS if (k == "gram" or a.precision == "fp32") else PEAK_BF16_TFLOPS
+                peak = PEAK_F32_MFMA_TFLOPS if a.precision == "fp32" else PEAK_BF16_TFLOPS   # bf16 mode: the Gram matrix is a split-bf16 GEMM
                 e.update(bound="mfma", achieved_tflops=flops[k] / (us * 1e-6) / 1e12, peak_tflops=peak)
                 e["frac"] = e["achieved_tflops"] / peak
             kern[k] = e
@@ -205,13 +226,17 @@ def main():
         if e:
             out["roofline"] = {"kernel": "encode_gemm (gemm_nt_f32out, x~[BxF].W[FxH], split-K)", "bound": "mfma",
                                "achieved": e["achieved_tflops"], "peak": e["peak_tflops"], "unit": "TFLOP/s", "frac": e["frac"],
-                               "traffic": None,
+                               "traffic": committed_traffic("encode_gemm"),
                                "algorithmic": f"2*B*F*H = {2.0 * B * F * H / 1e9:.2f} GFLOP per launch (dense accounting)"}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a)
         out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
     if rank == 0:
         print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dp.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
