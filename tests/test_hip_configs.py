@@ -1,0 +1,112 @@
+"""BASELINE.json configs 3-5 as parity-test cases (one full-shape step each against the CPU oracle); config 2 is
+the bench workload (tests/test_hip_step.py::test_full_size_step_config2), config 1 is its strategy-none form."""
+import numpy as np
+import pytest
+import torch
+from scipy import sparse
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float(np.max(np.abs(np.asarray(a, np.float64) - b)) / (np.max(np.abs(b)) + 1e-30))
+
+
+def test_config1_plain_dae_strategy_none():
+    """configs[0]: 8000x10000 binary CSR, plain DAE, batch 800 (the reference's CPU-runnable case)."""
+    from dae_rnn_news_recommendation_amd import _lib as L
+    from dae_rnn_news_recommendation_amd.engine import Engine
+    from dae_rnn_news_recommendation_amd.synthetic import synthetic_csr, xavier_uniform
+    N, F, H, B = 1600, 10000, 500, 800
+    m = synthetic_csr(N, F, seed=3); W0 = xavier_uniform(F, H)
+    rng = np.random.default_rng(1)
+    keep = rng.random(m.nnz) >= 0.3
+    bits = np.packbits(keep, bitorder="little"); bits = np.concatenate([bits, np.zeros((-len(bits)) % 4, np.uint8)]).view(np.int32)
+    idx = rng.permutation(N)[:B]
+    eng = Engine(F, H, B, dtype="bf16", triplet="none", learning_rate=0.1)
+    eng.upload_csr(m); eng.set_params(W0)
+    stats = torch.zeros(8, device="cuda")
+    eng.train_step(torch.from_numpy(idx.astype(np.int32)).cuda(), None, stats, corr_mode=L.CORR_KEEPBITS,
+                   keep_bits=torch.from_numpy(bits.copy()).cuda(), phase=1)
+    mc = m.copy(); mc.data = mc.data * keep
+    r = O.forward_backward(W0, np.zeros(H, np.float32), np.zeros(F, np.float32), m[idx].toarray(), mc[idx].toarray(), None,
+                           triplet_strategy="none", dt=np.float32)
+    st = stats.cpu().numpy()
+    assert abs(st[0] - r["cost"]) <= 1e-4 * abs(r["cost"])
+    assert _rel(eng.grads()[0], r["dW"]) < 3e-2
+
+
+def test_config4_dense_tfidf_50000_features():
+    """configs[3]: dense fp32 tf-idf ndarray, F=50000, compress_factor 50 (H=1000), cross_entropy, alpha=1, batch_all."""
+    from dae_rnn_news_recommendation_amd import _lib as L
+    from dae_rnn_news_recommendation_amd.engine import Engine
+    from dae_rnn_news_recommendation_amd.synthetic import synthetic_csr, synthetic_labels, xavier_uniform
+    N, F, H, B = 320, 50000, 1000, 256
+    X = synthetic_csr(N, F, nnz_per_row=300, seed=5, tfidf=True).toarray().astype(np.float32)
+    lab = synthetic_labels(N, seed=5)
+    W0 = xavier_uniform(F, H)
+    rng = np.random.default_rng(2)
+    idx = rng.permutation(N)[:B]
+    eng = Engine(F, H, B, dtype="bf16", triplet="batch_all", loss_func="cross_entropy", alpha=1.0, learning_rate=0.1)
+    eng.upload_dense(X); eng.set_params(W0)
+    stats = torch.zeros(8, device="cuda")
+    seed, stream = 77, 1
+    eng.train_step(torch.from_numpy(idx.astype(np.int32)).cuda(), torch.from_numpy(lab[idx].astype(np.int32)).cuda(), stats,
+                   corr_mode=L.CORR_PHILOX_MASK, seed=seed, rng_stream=stream, corr_frac=0.3, phase=1)
+    ii = idx.astype(np.uint64)[:, None] * np.uint64(F) + np.arange(F, dtype=np.uint64)[None, :]
+    keep = O.philox_uniform(ii, seed, stream) >= np.float32(0.3)
+    xb = X[idx]
+    r = O.forward_backward(W0, np.zeros(H, np.float32), np.zeros(F, np.float32), xb, xb * keep, lab[idx],
+                           loss_func="cross_entropy", triplet_strategy="batch_all", alpha=1.0, dt=np.float32)
+    st = stats.cpu().numpy()
+    assert abs(st[1] - r["ae_loss"]) <= 1e-4 * abs(r["ae_loss"]), (st, r["ae_loss"])
+    assert abs(st[2] - r["triplet_loss"]) <= 1e-4 * abs(r["triplet_loss"]) + 1e-9
+    dW, dbh, dbv = eng.grads()
+    assert _rel(dW, r["dW"]) < 3e-2 and _rel(dbv, r["dbv"]) < 3e-2
+
+
+def test_config3_batch_hard_category_labels_dp_shard():
+    """configs[2]: batch_hard + 4 category labels; one rank's 800-row local batch of the 64000x10000 set."""
+    from dae_rnn_news_recommendation_amd import _lib as L
+    from dae_rnn_news_recommendation_amd.engine import Engine
+    from dae_rnn_news_recommendation_amd.synthetic import synthetic_csr, synthetic_labels, xavier_uniform
+    N, F, H, B = 1600, 10000, 500, 800
+    m = synthetic_csr(N, F, seed=11); lab = synthetic_labels(N, seed=11); W0 = xavier_uniform(F, H)
+    rng = np.random.default_rng(3)
+    idx = rng.permutation(N)[:B]
+    eng = Engine(F, H, B, dtype="fp32", triplet="batch_hard", learning_rate=0.1)
+    eng.upload_csr(m); eng.set_params(W0)
+    stats = torch.zeros(8, device="cuda")
+    eng.train_step(torch.from_numpy(idx.astype(np.int32)).cuda(), torch.from_numpy(lab[idx].astype(np.int32)).cuda(), stats, phase=1)
+    xb = m[idx].toarray()
+    D = eng.buffer("D_slabs", (eng.info()["gram_splits"], 896, 896), torch.float32).sum(0).cpu().numpy()[:B, :B]
+    h, _ = O.encode(xb, W0, np.zeros(H, np.float32), "sigmoid", np.float64)
+    # equality-based data_weight must be judged on the kernel's own Gram matrix
+    tl, dw, fr, num = O.batch_hard_triplet_loss(lab[idx], h, np.float32, D=D)
+    st = stats.cpu().numpy()
+    assert abs(st[2] - tl) <= 2e-5 * abs(tl) and st[4] == num and abs(st[3] - fr) < 1e-6
+    dwf = eng.buffer("dw_f32", (896,), torch.float32).cpu().numpy()[:B]
+    assert np.array_equal(dwf, dw)                                   # bit-exact data_weight
+
+
+def test_config5_explicit_triplets_cosine():
+    """configs[4]: explicit (anchor,pos,neg) batches through the same W, cosine_proximity, B=800 per block."""
+    from dae_rnn_news_recommendation_amd.engine import Engine
+    from dae_rnn_news_recommendation_amd.synthetic import synthetic_csr, xavier_uniform
+    N, F, H, Bt = 400, 10000, 500, 320
+    ms = [synthetic_csr(N, F, seed=20 + k, tfidf=True) for k in range(3)]
+    W0 = xavier_uniform(F, H)
+    eng = Engine(F, H, 3 * Bt, dtype="bf16", loss_func="cosine_proximity", triplet="explicit", alpha=1.0, learning_rate=0.1)
+    eng.upload_csr(sparse.vstack(ms).tocsr()); eng.set_params(W0)
+    idx = np.random.default_rng(4).permutation(N)[:Bt]
+    rows = np.concatenate([idx, N + idx, 2 * N + idx]).astype(np.int32)
+    stats = torch.zeros(8, device="cuda")
+    eng.train_step(torch.from_numpy(rows).cuda(), None, stats, phase=1)
+    xs = [mm[idx].toarray() for mm in ms]
+    r = O.explicit_triplet_forward_backward(W0, np.zeros(H, np.float32), np.zeros(F, np.float32), xs, xs, loss_func="cosine_proximity",
+                                            alpha=1.0, dt=np.float32)
+    st = stats.cpu().numpy()
+    assert abs(st[0] - r["cost"]) <= 2e-4 * abs(r["cost"]), (st, r["cost"], r["ae_loss"], r["triplet_loss"])
+    assert _rel(eng.grads()[0], r["dW"]) < 3e-2
