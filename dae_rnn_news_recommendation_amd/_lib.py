@@ -65,15 +65,15 @@ SIGNATURES = {
                               vp, i64, vp, i64, vp]),
     "dae_cos_reduce": (i32, [vp, i32, i32, i32, vp, vp, vp]),
     "dae_gram": (i32, [vp, i64, i32, i32, vp, i32, vp]),
-    "dae_label_stats": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
+    "dae_label_stats": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp, f32, vp, vp]),
     "dae_triplet_batch_all": (i32, [vp, i32, i64, i64, vp, i32, i32, i32, vp, vp, vp, vp, vp]),
     "dae_triplet_batch_hard": (i32, [vp, i32, i64, i64, vp, i32, i32, vp, vp, vp, vp, vp]),
     "dae_triplet_finalize": (i32, [i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "dae_sym_scale": (i32, [vp, i32, i32, vp, i32, vp, vp]),
     "dae_dh_finish": (i32, [vp, i32, i64, i64, vp, vp, i64, vp, i32, i32, i32, i32, vp, i64, vp, vp, vp]),
-    "dae_bias_grads": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp]),
+    "dae_bias_grads": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, i32, i32, f32, f32, f32, vp, vp, vp, vp]),
     "dae_opt_step": (i32, [i32, f32, f32, f32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, i32, vp]),
-    "dae_step_stats": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, f32, vp, vp, vp, vp]),
+    "dae_step_stats": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp]),
     "dae_weighted_loss_rows": (i32, [vp, i64, vp, i64, i32, i32, i32, vp, vp]),
     "dae_explicit_triplet": (i32, [vp, i64, i32, i32, f32, vp, vp, vp, vp]),
     "dae_plan_create": (i32, [C.POINTER(dae_config), C.POINTER(vp)]),

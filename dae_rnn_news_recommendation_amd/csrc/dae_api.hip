@@ -274,6 +274,15 @@ static int gather_batch(dae_plan* p, const int64_t* indptr, const int32_t* indic
 #define RC(expr) do { if (int rc__ = (expr)) return rc__; } while (0)
 // K5: D = h h^T (triplet_loss_utils.py:93,219).  fp32 mode: exact-fp32 MFMA.  bf16 mode: split-bf16 (h = hi + lo,
 // three bf16 MFMA products concatenated along K = 3*Hp), ~2^-17 relative error, 16x the MFMA rate.
+// learning rate handed to the optimizer kernels (Adam: lr_t = lr * sqrt(1-b2^t)/(1-b1^t), TF AdamOptimizer)
+static float plan_lr(const dae_plan* p, int adam_t) {
+    float lr = p->cfg.learning_rate;
+    if (p->cfg.opt == DAE_OPT_ADAM) {
+        const double t = adam_t < 1 ? 1 : adam_t;
+        lr = (float)((double)lr * sqrt(1.0 - pow(0.999, t)) / (1.0 - pow(0.9, t)));
+    }
+    return lr;
+}
 static int launch_gram(dae_plan* p, int Bp, int Hp, int64_t dslab, hipStream_t st) {
     if (p->gram_split)
         return launch_gemm_f32out(DAE_BF16, Bp, Bp, p->hcat_a, 3 * Hp, p->hcat_b, 3 * Hp, 3 * Hp, nullptr, 0, nullptr, 0, 0, p->D_slabs, Bp,
@@ -335,15 +344,16 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     // 5-6. miners (K5-K7)
     const int Bt = explicit3 ? B / 3 : B;
     if (explicit3) {
-        PROF(PS_LABEL, dae_label_stats(nullptr, Bt, Bp, DAE_TRIPLET_NONE, nullptr, nullptr, nullptr, nullptr, p->cw, stream));
+        PROF(PS_LABEL, dae_label_stats(nullptr, Bt, Bp, DAE_TRIPLET_NONE, nullptr, nullptr, nullptr, nullptr, p->cw, 0.f, nullptr, stream));
         // every one of the 3*Bt stacked rows carries weight 1/(Bt + 1e-16): three unweighted row means (:303-305)
         DAE_CHECK_HIP(hipMemcpyAsync(p->cw + Bt, p->cw, (size_t)Bt * 4, hipMemcpyDeviceToDevice, st));
         DAE_CHECK_HIP(hipMemcpyAsync(p->cw + 2 * Bt, p->cw, (size_t)Bt * 4, hipMemcpyDeviceToDevice, st));
         PROF(PS_MINER, dae_explicit_triplet(p->h_f32, Hp, Bt, H, c.alpha, p->dh_extra, p->loss_part, p->tri_scalars, stream));
     } else {
-        PROF(PS_LABEL, dae_label_stats(s->labels, B, Bp, c.triplet, p->n_same, p->acc, p->nvalid, p->dw_i64, p->cw, stream));
+        PROF(PS_LABEL, dae_label_stats(s->labels, B, Bp, c.triplet, p->n_same, p->acc, p->nvalid, p->dw_i64, p->cw, c.alpha, p->tri_scalars, stream));
     }
     bool forked = false;
+    const bool fold_finalize = (c.triplet == DAE_TRIPLET_BATCH_ALL && !c.pos_triplets_only);
     if (c.triplet == DAE_TRIPLET_BATCH_ALL || c.triplet == DAE_TRIPLET_BATCH_HARD) {
         const int64_t dslab = (int64_t)Bp * Bp;
         // batch_all (all valid triplets): cw comes from the labels alone -> the miner chain and the decode kernel are
@@ -366,8 +376,6 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
             RC(launch_gram(p, Bp, Hp, dslab, ms));
             RC(dae_triplet_batch_all(p->D_slabs, p->s_gram, dslab, Bp, s->labels, B, Bp, 0, p->loss_part, p->cnt_part, p->G, p->role_cnt,
                                      mstream));
-            RC(dae_triplet_finalize(c.triplet, 0, B, Bp, c.alpha, p->loss_part, p->cnt_part, p->nvalid, p->dw_i32, p->role_cnt, p->dw_f32,
-                                    p->cw, p->tri_scalars, mstream));
             if (backward) RC(dae_sym_scale(p->G, B, Bp, p->tri_scalars, dt, p->Gs, mstream));
             DAE_CHECK_HIP(hipEventRecord(p->ev_join, ms));
         } else {
@@ -378,8 +386,9 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
             else
                 PROF(PS_MINER, dae_triplet_batch_hard(p->D_slabs, p->s_gram, dslab, Bp, s->labels, B, Bp, p->loss_part, p->cnt_part, p->dw_i32, p->G,
                                           stream));
-            PROF(PS_TRI_FIN, dae_triplet_finalize(c.triplet, c.pos_triplets_only, B, Bp, c.alpha, p->loss_part, p->cnt_part, p->nvalid, p->dw_i32,
-                                    p->role_cnt, p->dw_f32, p->cw, p->tri_scalars, stream));
+            if (!fold_finalize)   // batch_all over all valid triplets: scale comes from label_stats, sums from step_stats
+                PROF(PS_TRI_FIN, dae_triplet_finalize(c.triplet, c.pos_triplets_only, B, Bp, c.alpha, p->loss_part, p->cnt_part, p->nvalid,
+                                        p->dw_i32, p->role_cnt, p->dw_f32, p->cw, p->tri_scalars, stream));
             if (backward) PROF(PS_SYM, dae_sym_scale(p->G, B, Bp, p->tri_scalars, dt, p->Gs, stream));
         }
     }
@@ -405,7 +414,8 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     // 8. statistics of this step (autoencoder.py:233 fetch list)
     PROF(PS_STATS, dae_step_stats(is_cos ? p->rowloss_part : nullptr, 1, is_cos ? nullptr : p->tile_part, (Bp / 128) * (Fp / 128), p->cw, B, Bp,
                       c.triplet == 3 ? DAE_TRIPLET_BATCH_HARD : c.triplet, c.alpha,
-                      p->tri_scalars, c.triplet == DAE_TRIPLET_BATCH_ALL ? p->nvalid : nullptr, s->stats, stream));
+                      p->tri_scalars, c.triplet == DAE_TRIPLET_BATCH_ALL ? p->nvalid : nullptr, fold_finalize ? p->loss_part : nullptr,
+                      fold_finalize ? p->cnt_part : nullptr, s->stats, stream));
     if (!backward) return 0;
     // 9-10. dL/dh = delta2 W + alpha (G+G^T) h ; delta1                     (K8)
     const bool mined = (c.triplet == DAE_TRIPLET_BATCH_ALL || c.triplet == DAE_TRIPLET_BATCH_HARD);
@@ -417,20 +427,21 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     PROF(PS_DW_GEMM, launch_gemm_f32out(dt, Fp, Hp, p->xct, ldB, p->delta1_t, ldB, Bp, p->delta2_t, ldB, p->h_t, ldB, Bp, p->b.grad, Hp, 1, 0, st, GEMM_ROLE_DW));
     // 12. bias gradients
     float* g_bh = p->b.grad + (int64_t)Fp * Hp;
-    PROF(PS_BIAS, dae_bias_grads(p->dbv_part, 2 * Bp / 128, p->colsum_part, Bp / 32, p->b.bh, H, Hp, F, Fp, c.enc_act, g_bh, g_bh + Hp, stream));
+    const int64_t boff = (int64_t)Fp * Hp;
+    const bool fuse_bias = (s->phase == 0);          // single-GPU step: the bias update rides on the bias-gradient kernel
+    PROF(PS_BIAS, dae_bias_grads(p->dbv_part, 2 * Bp / 128, p->colsum_part, Bp / 32, p->b.bh, H, Hp, F, Fp, c.enc_act, g_bh, g_bh + Hp,
+                                 fuse_bias ? 1 : 0, c.opt, plan_lr(p, s->adam_t), c.momentum, s->grad_scale, p->b.bv,
+                                 p->b.opt_s1 ? p->b.opt_s1 + boff : nullptr, p->b.opt_s2 ? p->b.opt_s2 + boff : nullptr, stream));
     if (s->phase == 1) return 0;
-    // 13. optimizer (K9)
-    PROF(PS_OPT, dae_plan_apply(p, s->adam_t, s->grad_scale, stream));
+    // 13. optimizer (K9): W (+ shadows); biases were updated above
+    PROF(PS_OPT, dae_opt_step(c.opt, plan_lr(p, s->adam_t), c.momentum, s->grad_scale, p->b.W, p->b.bh, p->b.bv, p->b.grad, p->b.opt_s1,
+                              p->b.opt_s2, Fp, Hp, dt, p->b.W_lo, p->b.Wt_lo, /*apply=*/2, stream));
     return 0;
 }
 
 extern "C" int dae_plan_apply(dae_plan* p, int32_t adam_t, float grad_scale, void* stream) {
     DAE_CHECK_ARG(p && p->bound, "plan_apply: plan not bound");
-    float lr = p->cfg.learning_rate;
-    if (p->cfg.opt == DAE_OPT_ADAM) {
-        const double t = adam_t < 1 ? 1 : adam_t;
-        lr = (float)((double)lr * sqrt(1.0 - pow(0.999, t)) / (1.0 - pow(0.9, t)));
-    }
+    const float lr = plan_lr(p, adam_t);
     return dae_opt_step(p->cfg.opt, lr, p->cfg.momentum, grad_scale, p->b.W, p->b.bh, p->b.bv, p->b.grad, p->b.opt_s1, p->b.opt_s2,
                         p->Fp, p->Hp, p->cfg.dtype, p->b.W_lo, p->b.Wt_lo, /*apply=*/1, stream);
 }

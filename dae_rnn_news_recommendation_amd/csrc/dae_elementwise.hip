@@ -162,7 +162,8 @@ __global__ __launch_bounds__(256) void label_count_kernel(const int32_t* __restr
 
 __global__ void label_weight_kernel(const int32_t* __restrict__ n_same, int B, int Bp, int triplet,
                                     const unsigned long long* __restrict__ acc, int64_t* __restrict__ nvalid_out,
-                                    int64_t* __restrict__ dw_out, float* __restrict__ cw) {
+                                    int64_t* __restrict__ dw_out, float* __restrict__ cw, float alpha,
+                                    float* __restrict__ tri_scalars) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Bp) return;
     if (triplet == DAE_TRIPLET_NONE) {                    // weighted_loss default weight = ones (:266)
@@ -171,6 +172,7 @@ __global__ void label_weight_kernel(const int32_t* __restrict__ n_same, int B, i
     }
     const long long S = (long long)acc[0], NV = (long long)acc[1];
     if (i == 0 && nvalid_out) nvalid_out[0] = NV;
+    if (i == 0 && tri_scalars && triplet == DAE_TRIPLET_BATCH_ALL) tri_scalars[0] = alpha / ((float)NV + 1e-16f);
     if (i < B) {
         const long long n = n_same[i];
         const long long dw = 2 * (n - 1) * (B - n) + (S - n * (n - 1));
@@ -187,7 +189,7 @@ __global__ void label_weight_kernel(const int32_t* __restrict__ n_same, int B, i
 // fall back to the O(B^2) comparison loop.  Integer arithmetic only -> exact and order-independent.
 __global__ __launch_bounds__(1024) void label_stats_small_kernel(const int32_t* __restrict__ labels, int B, int Bp, int triplet,
                                                                  int64_t* __restrict__ nvalid_out, int64_t* __restrict__ dw_out,
-                                                                 float* __restrict__ cw) {
+                                                                 float* __restrict__ cw, float alpha, float* __restrict__ tri_scalars) {
     constexpr int NBIN = 4096;
     __shared__ __attribute__((aligned(16))) int32_t lab[1024];
     __shared__ int hist[NBIN];
@@ -231,6 +233,7 @@ __global__ __launch_bounds__(1024) void label_stats_small_kernel(const int32_t* 
     __syncthreads();
     const long long S = (long long)accS, NV = (long long)accNV;
     if (i == 0 && nvalid_out) nvalid_out[0] = NV;
+    if (i == 0 && tri_scalars && triplet == DAE_TRIPLET_BATCH_ALL) tri_scalars[0] = alpha / ((float)NV + 1e-16f);
     if (i < B) {
         const long long dw = 2 * (n - 1) * (B - n) + (S - n * (n - 1));
         if (dw_out) dw_out[i] = dw;
@@ -322,32 +325,7 @@ __global__ void cos_reduce_kernel(const float* __restrict__ cos_part, int n_col_
 }
 
 // bias gradients into the flat gradient buffer
-__global__ void bias_grads_kernel(const float* __restrict__ dbv_part, int n_row_waves, const float* __restrict__ colsum_part,
-                                  int n_row_blocks, const float* __restrict__ bh, int H, int Hp, int F, int Fp, int enc_act,
-                                  float* __restrict__ dbh, float* __restrict__ dbv) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < Fp) {
-        float s = 0.f;
-        if (k < F) for (int p = 0; p < n_row_waves; ++p) s += dbv_part[(int64_t)p * Fp + k];
-        dbv[k] = s;
-    } else if (k < Fp + Hp) {
-        const int j = k - Fp;
-        float s1 = 0.f, s2 = 0.f;
-        if (j < H) {
-            for (int p = 0; p < n_row_blocks; ++p) {
-                s1 += colsum_part[(int64_t)p * Hp + j];
-                s2 += colsum_part[((int64_t)n_row_blocks + p) * Hp + j];
-            }
-            const float ab = act_apply(enc_act, bh[j]);
-            s1 -= act_grad(enc_act, ab) * s2;
-        }
-        dbh[j] = s1;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K9 optimizer (autoencoder.py:444-477, tf.train.* semantics)
-// ------------------------------------------------------------------------------------------------
+// optimizer element update (autoencoder.py:444-477, tf.train.* semantics)
 __device__ __forceinline__ float opt_update(int opt, float lr, float mom, float p, float g, float* s1, float* s2, int64_t k) {
     switch (opt) {
         case DAE_OPT_SGD: return p - lr * g;
@@ -362,6 +340,37 @@ __device__ __forceinline__ float opt_update(int opt, float lr, float mom, float 
     }
 }
 
+
+// apply != 0 also performs the optimizer update of the biases (slot layout [bh (Hp) | bv (Fp)] at s1b / s2b)
+__global__ void bias_grads_kernel(const float* __restrict__ dbv_part, int n_row_waves, const float* __restrict__ colsum_part,
+                                  int n_row_blocks, float* __restrict__ bh, int H, int Hp, int F, int Fp, int enc_act,
+                                  float* __restrict__ dbh, float* __restrict__ dbv, int apply, int opt, float lr, float mom,
+                                  float gscale, float* __restrict__ bv, float* __restrict__ s1b, float* __restrict__ s2b) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < Fp) {
+        float s = 0.f;
+        if (k < F) for (int p = 0; p < n_row_waves; ++p) s += dbv_part[(int64_t)p * Fp + k];
+        dbv[k] = s;
+        if (apply) bv[k] = opt_update(opt, lr, mom, bv[k], s * gscale, s1b, s2b, (int64_t)Hp + k);
+    } else if (k < Fp + Hp) {
+        const int j = k - Fp;
+        float s1 = 0.f, s2 = 0.f;
+        if (j < H) {
+            for (int p = 0; p < n_row_blocks; ++p) {
+                s1 += colsum_part[(int64_t)p * Hp + j];
+                s2 += colsum_part[((int64_t)n_row_blocks + p) * Hp + j];
+            }
+            const float ab = act_apply(enc_act, bh[j]);
+            s1 -= act_grad(enc_act, ab) * s2;
+        }
+        dbh[j] = s1;
+        if (apply) bh[j] = opt_update(opt, lr, mom, bh[j], s1 * gscale, s1b, s2b, (int64_t)j);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K9 optimizer (autoencoder.py:444-477, tf.train.* semantics)
+// ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void opt_w_kernel(int opt, float lr, float mom, float gscale, float* __restrict__ W,
                                                     const float* __restrict__ grad, float* __restrict__ s1,
@@ -401,9 +410,18 @@ __global__ void opt_bias_kernel(int opt, float lr, float mom, float gscale, floa
 __global__ __launch_bounds__(1024) void step_stats_kernel(const float* __restrict__ rowloss_part, int n_col_waves,
                                                           const float* __restrict__ tile_part, int n_tiles,
                                                           const float* __restrict__ cw, int B, int Bp, int triplet, float alpha,
-                                                          const float* __restrict__ tri_scalars,
-                                                          const int64_t* __restrict__ nvalid, float* __restrict__ stats) {
+                                                          float* __restrict__ tri_scalars,
+                                                          const int64_t* __restrict__ nvalid, float* __restrict__ stats,
+                                                          const float* __restrict__ loss_part, const uint32_t* __restrict__ cnt_part) {
     __shared__ double sm[1024];
+    // batch_all (all valid triplets): fold triplet_finalize in -- loss = sum/(N_valid+1e-16), num = sum of counts
+    double lsum = 0.0, csum = 0.0;
+    if (loss_part) {
+        double l = 0.0, c = 0.0;
+        for (int i = threadIdx.x; i < B; i += blockDim.x) { l += (double)loss_part[i]; c += (double)cnt_part[i]; }
+        lsum = block_sum_d(l, sm);
+        csum = block_sum_d(c, sm);
+    }
     double s = 0.0;
     if (tile_part) {                                    // per-tile weighted sums from the fused decode epilogue
         for (int i = threadIdx.x; i < n_tiles; i += blockDim.x) s += (double)tile_part[i];
@@ -419,7 +437,13 @@ __global__ __launch_bounds__(1024) void step_stats_kernel(const float* __restric
         const float aef = (float)ae;
         float tl = 0.f, fr = 0.f, nm = 0.f, nv = 0.f;
         if (triplet != DAE_TRIPLET_NONE) {
-            tl = tri_scalars[1]; fr = tri_scalars[2]; nm = tri_scalars[3];
+            if (loss_part) {
+                const float nvf = (float)nvalid[0];
+                tl = (float)lsum / (nvf + 1e-16f); nm = (float)csum; fr = nm / (nvf + 1e-16f);
+                if (tri_scalars) { tri_scalars[1] = tl; tri_scalars[2] = fr; tri_scalars[3] = nm; }
+            } else {
+                tl = tri_scalars[1]; fr = tri_scalars[2]; nm = tri_scalars[3];
+            }
             nv = (triplet == DAE_TRIPLET_BATCH_ALL && nvalid) ? (float)nvalid[0] : nm;
         }
         stats[DAE_STAT_COST] = (triplet != DAE_TRIPLET_NONE) ? aef + alpha * tl : aef;
@@ -522,11 +546,13 @@ extern "C" int dae_sym_scale(const float* G, int32_t B, int32_t Bp, const float*
 }
 
 extern "C" int dae_label_stats(const int32_t* labels, int32_t B, int32_t Bp, int32_t triplet, int32_t* n_same_scratch,
-                               uint64_t* acc_scratch, int64_t* nvalid_out, int64_t* dw_out, float* cw, void* stream) {
+                               uint64_t* acc_scratch, int64_t* nvalid_out, int64_t* dw_out, float* cw, float alpha,
+                               float* tri_scalars, void* stream) {
     DAE_CHECK_ARG(cw && B > 0 && Bp >= B, "label_stats: bad args");
     DAE_CHECK_ARG(triplet == DAE_TRIPLET_NONE || labels, "label_stats: labels required");
     if (Bp <= 1024) {
-        hipLaunchKernelGGL(label_stats_small_kernel, dim3(1), dim3(1024), 0, ST(stream), labels, B, Bp, triplet, nvalid_out, dw_out, cw);
+        hipLaunchKernelGGL(label_stats_small_kernel, dim3(1), dim3(1024), 0, ST(stream), labels, B, Bp, triplet, nvalid_out, dw_out, cw, alpha,
+                           tri_scalars);
         DAE_CHECK_LAUNCH();
         return 0;
     }
@@ -538,7 +564,7 @@ extern "C" int dae_label_stats(const int32_t* labels, int32_t B, int32_t Bp, int
         DAE_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(label_weight_kernel, dim3((Bp + 255) / 256), dim3(256), 0, ST(stream), n_same_scratch, B, Bp, triplet,
-                       (const unsigned long long*)acc_scratch, nvalid_out, dw_out, cw);
+                       (const unsigned long long*)acc_scratch, nvalid_out, dw_out, cw, alpha, tri_scalars);
     DAE_CHECK_LAUNCH();
     return 0;
 }
@@ -568,12 +594,18 @@ extern "C" int dae_cos_reduce(const float* cos_part, int32_t n_col_waves, int32_
 }
 
 extern "C" int dae_bias_grads(const float* dbv_part, int32_t n_row_waves, const float* colsum_part, int32_t n_row_blocks,
-                              const float* bh, int32_t H, int32_t Hp, int32_t F, int32_t Fp, int32_t enc_act, float* dbh,
-                              float* dbv, void* stream) {
+                              float* bh, int32_t H, int32_t Hp, int32_t F, int32_t Fp, int32_t enc_act, float* dbh,
+                              float* dbv, int32_t apply, int32_t opt, float lr, float momentum, float grad_scale, float* bv,
+                              float* s1b, float* s2b, void* stream) {
     DAE_CHECK_ARG(dbv_part && colsum_part && bh && dbh && dbv, "bias_grads: null input");
+    if (apply) {
+        DAE_CHECK_ARG(bv && opt >= DAE_OPT_SGD && opt <= DAE_OPT_ADAM, "bias_grads: bad optimizer arguments");
+        DAE_CHECK_ARG(opt == DAE_OPT_SGD || s1b, "bias_grads: optimizer slot s1 required");
+        DAE_CHECK_ARG(opt != DAE_OPT_ADAM || s2b, "bias_grads: optimizer slot s2 required");
+    }
     const int n = Fp + Hp;
     hipLaunchKernelGGL(bias_grads_kernel, dim3((n + 255) / 256), dim3(256), 0, ST(stream), dbv_part, n_row_waves, colsum_part,
-                       n_row_blocks, bh, H, Hp, F, Fp, enc_act, dbh, dbv);
+                       n_row_blocks, bh, H, Hp, F, Fp, enc_act, dbh, dbv, apply, opt, lr, momentum, grad_scale, bv, s1b, s2b);
     DAE_CHECK_LAUNCH();
     return 0;
 }
@@ -582,6 +614,8 @@ extern "C" int dae_bias_grads(const float* dbv_part, int32_t n_row_waves, const 
 extern "C" int dae_opt_step(int32_t opt, float lr, float momentum, float grad_scale, float* W, float* bh, float* bv,
                             const float* grad, float* s1, float* s2, int32_t Fp, int32_t Hp, int32_t dtype, void* W_lo,
                             void* Wt_lo, int32_t apply, void* stream) {
+    const bool skip_bias = (apply == 2);     // apply: 0 refresh shadows only, 1 update W and biases, 2 update W only
+    if (apply == 2) apply = 1;
     DAE_CHECK_ARG(W && Fp % DAE_PAD == 0 && Hp % DAE_PAD == 0, "opt_step: bad args");
     DAE_CHECK_ARG(opt >= DAE_OPT_SGD && opt <= DAE_OPT_ADAM, "opt_step: unknown optimizer %d", opt);
     if (apply) {
@@ -597,7 +631,7 @@ extern "C" int dae_opt_step(int32_t opt, float lr, float momentum, float grad_sc
         hipLaunchKernelGGL((opt_w_kernel<float>), grid, block, 0, ST(stream), opt, lr, momentum, grad_scale, W, grad, s1, s2, Fp, Hp,
                            (float*)W_lo, (float*)Wt_lo, apply);
     DAE_CHECK_LAUNCH();
-    if (apply) {
+    if (apply && !skip_bias) {
         const int64_t off = (int64_t)Fp * Hp;
         hipLaunchKernelGGL(opt_bias_kernel, dim3((Hp + Fp + 255) / 256), dim3(256), 0, ST(stream), opt, lr, momentum, grad_scale, bh,
                            bv, grad + off, s1 ? s1 + off : nullptr, s2 ? s2 + off : nullptr, Hp, Fp);
@@ -607,12 +641,14 @@ extern "C" int dae_opt_step(int32_t opt, float lr, float momentum, float grad_sc
 }
 
 extern "C" int dae_step_stats(const float* rowloss_part, int32_t n_col_waves, const float* tile_part, int32_t n_tiles,
-                              const float* cw, int32_t B, int32_t Bp, int32_t triplet, float alpha, const float* tri_scalars,
-                              const int64_t* nvalid, float* stats, void* stream) {
+                              const float* cw, int32_t B, int32_t Bp, int32_t triplet, float alpha, float* tri_scalars,
+                              const int64_t* nvalid, const float* loss_part, const uint32_t* cnt_part, float* stats,
+                              void* stream) {
     DAE_CHECK_ARG(((rowloss_part && cw) || tile_part) && stats, "step_stats: null input");
-    DAE_CHECK_ARG(triplet == DAE_TRIPLET_NONE || tri_scalars, "step_stats: tri_scalars required");
+    DAE_CHECK_ARG(triplet == DAE_TRIPLET_NONE || tri_scalars || loss_part, "step_stats: tri_scalars or miner partials required");
+    DAE_CHECK_ARG(!loss_part || (cnt_part && nvalid && triplet == DAE_TRIPLET_BATCH_ALL), "step_stats: miner partials need cnt_part + nvalid");
     hipLaunchKernelGGL(step_stats_kernel, dim3(1), dim3(1024), 0, ST(stream), rowloss_part, n_col_waves, tile_part, n_tiles, cw, B, Bp, triplet, alpha,
-                       tri_scalars, nvalid, stats);
+                       tri_scalars, nvalid, stats, loss_part, cnt_part);
     DAE_CHECK_LAUNCH();
     return 0;
 }

@@ -121,7 +121,7 @@ def label_stats(labels, B, triplet):
     dw = torch.zeros(Bp, dtype=torch.int64, device=dev)
     cw = torch.zeros(Bp, dtype=torch.float32, device=dev)
     L.call("dae_label_stats", L.ptr(labels), B, Bp, triplet, L.ptr(n_same), L.ptr(acc), L.ptr(nvalid), L.ptr(dw),
-           L.ptr(cw), L.current_stream())
+           L.ptr(cw), 1.0, None, L.current_stream())
     return nvalid, dw, cw
 
 
@@ -184,7 +184,7 @@ def bias_grads(dbv_part, colsum_part, bh, H, F, enc_act):
     dbh = torch.empty(Hp, dtype=torch.float32, device=dev)
     dbv = torch.empty(Fp, dtype=torch.float32, device=dev)
     L.call("dae_bias_grads", L.ptr(dbv_part), nrw, L.ptr(colsum_part), nrb, L.ptr(bh), H, Hp, F, Fp, enc_act,
-           L.ptr(dbh), L.ptr(dbv), L.current_stream())
+           L.ptr(dbh), L.ptr(dbv), 0, 0, 0.0, 0.0, 1.0, None, None, None, L.current_stream())
     return dbh, dbv
 
 
@@ -198,7 +198,7 @@ def step_stats(rowloss_part, cw, B, triplet, alpha, tri_scalars, nvalid, tile_pa
     ncw, Bp = rowloss_part.shape
     stats = torch.zeros(L.STATS_STRIDE, dtype=torch.float32, device=rowloss_part.device)
     L.call("dae_step_stats", L.ptr(rowloss_part), ncw, L.ptr(tile_part), 0 if tile_part is None else tile_part.numel(),
-           L.ptr(cw), B, Bp, triplet, alpha, L.ptr(tri_scalars), L.ptr(nvalid), L.ptr(stats), L.current_stream())
+           L.ptr(cw), B, Bp, triplet, alpha, L.ptr(tri_scalars), L.ptr(nvalid), None, None, L.ptr(stats), L.current_stream())
     return stats
 
 

@@ -138,7 +138,9 @@ int dae_gram(const float* h_f32, int64_t ldh, int32_t Bp, int32_t Hp, float* D_s
  * needs no labels/scratch; DAE_TRIPLET_BATCH_HARD only fills nvalid/dw (cw comes from the miner). */
 int dae_label_stats(const int32_t* labels, int32_t B, int32_t Bp, int32_t triplet,
                     int32_t* n_same_scratch, uint64_t* acc_scratch,
-                    int64_t* nvalid_out, int64_t* dw_out, float* cw, void* stream);
+                    int64_t* nvalid_out, int64_t* dw_out, float* cw,
+                    float alpha, float* tri_scalars /* may be NULL; batch_all: [0] = alpha/(N_valid+1e-16) */,
+                    void* stream);
 
 /* K6: batch_all online miner, one fused sweep per anchor (triplet_loss_utils.py:79-131).
  *   loss_part[a] = sum_{p,n valid} softplus(D[a,n]-D[a,p])   (only positive triplets if pos_only)
@@ -184,14 +186,18 @@ int dae_dh_finish(const float* slabs, int32_t splits, int64_t slab_stride, int64
 
 /* Reduce the bias-gradient partials into the flat gradient buffer [dW | dbh | dbv]. */
 int dae_bias_grads(const float* dbv_part, int32_t n_row_waves, const float* colsum_part, int32_t n_row_blocks,
-                   const float* bh, int32_t H, int32_t Hp, int32_t F, int32_t Fp, int32_t enc_act,
-                   float* dbh, float* dbv, void* stream);
+                   float* bh, int32_t H, int32_t Hp, int32_t F, int32_t Fp, int32_t enc_act,
+                   float* dbh, float* dbv,
+                   /* apply != 0: also run the optimizer update of bh / bv here (slots laid out [bh | bv]) */
+                   int32_t apply, int32_t opt, float lr, float momentum, float grad_scale, float* bv,
+                   float* s1_bias, float* s2_bias, void* stream);
 
 /* K9: optimizer step on the padded flat parameter vector [W (Fp*Hp) | bh (Hp) | bv (Fp)] (grad, s1,
  * s2 share that layout), refreshing the low-precision shadows W_lo [Fp x Hp] and W^T_lo [Hp x Fp]
  * (autoencoder.py:444-477; tf.train.* semantics: Adagrad accumulator starts at 0.1, Momentum without
  * Nesterov, Adam with lr = lr_t precomputed by the caller).  grad_scale multiplies the gradient first
- * (1/world_size for data parallel).  apply = 0 only refreshes the shadows. */
+ * (1/world_size for data parallel).  apply: 0 only refreshes the shadows, 1 updates W and the biases,
+ * 2 updates W only (the biases were updated by dae_bias_grads). */
 int dae_opt_step(int32_t opt, float lr, float momentum, float grad_scale,
                  float* W, float* bh, float* bv, const float* grad, float* s1, float* s2,
                  int32_t Fp, int32_t Hp, int32_t dtype, void* W_lo, void* Wt_lo, int32_t apply, void* stream);
@@ -201,7 +207,9 @@ int dae_opt_step(int32_t opt, float lr, float momentum, float grad_scale,
  * cost = ae + alpha * triplet.  stats: float[DAE_STATS_STRIDE]. */
 int dae_step_stats(const float* rowloss_part, int32_t n_col_waves, const float* tile_part, int32_t n_tiles,
                    const float* cw, int32_t B, int32_t Bp, int32_t triplet, float alpha,
-                   const float* tri_scalars, const int64_t* nvalid, float* stats, void* stream);
+                   float* tri_scalars, const int64_t* nvalid,
+                   /* optional batch_all miner partials: reduces them here instead of dae_triplet_finalize */
+                   const float* loss_part, const uint32_t* cnt_part, float* stats, void* stream);
 
 /* Explicit (anchor,pos,neg) triplet term of DenoisingAutoencoderTriplet
  * (autoencoder_triplet.py:308-311): t_i = h_i.hneg_i - h_i.hpos_i; loss = mean softplus(t).
