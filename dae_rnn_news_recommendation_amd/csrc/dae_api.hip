@@ -34,6 +34,11 @@ extern "C" int dae_gemm_nt(int32_t dtype, int32_t M, int32_t N, const void* A0, 
                               (hipStream_t)stream);
 }
 
+extern "C" int dae_encode_bits(const uint32_t* xc_bits, int64_t ldw, const void* Wt_lo, int64_t ldwt, int32_t Bp, int32_t Hp, int32_t Fp,
+                               float* slabs, int64_t ld_slab, int32_t splits, int64_t slab_stride, void* stream) {
+    return launch_encode_bits(Bp, Hp, Fp, xc_bits, ldw, Wt_lo, ldwt, slabs, ld_slab, splits, slab_stride, (hipStream_t)stream);
+}
+
 extern "C" int dae_gram(const float* h_f32, int64_t ldh, int32_t Bp, int32_t Hp, float* D_slabs, int32_t splits, void* stream) {
     return launch_gemm_f32out(DAE_F32, Bp, Bp, h_f32, ldh, h_f32, ldh, Hp, nullptr, 0, nullptr, 0, 0, D_slabs, Bp, splits,
                               (int64_t)Bp * Bp, (hipStream_t)stream);
@@ -94,7 +99,8 @@ struct dae_plan {
     bool gram_split;                 // Gram matrix as a 3-term split-bf16 MFMA GEMM (bf16 mode) instead of exact-fp32 MFMA
     float *slabs, *h_f32, *D_slabs, *G, *rowloss_part, *dbv_part, *colsum_part, *cos_part, *cos_stats, *cw, *loss_part,
         *dw_f32, *tri_scalars, *dh_extra, *rowsq_scratch, *tile_part;
-    uint32_t *cnt_part, *role_cnt;
+    uint32_t *cnt_part, *role_cnt, *xc_bits;
+    bool bits_ok;                    // binary CSR + bf16: x~ handed to the encode GEMM as a bit image (DAE_NO_BITS=1 disables)
     int32_t *dw_i32, *n_same;
     int64_t *nvalid, *dw_i64;
     uint64_t* acc;
@@ -121,6 +127,7 @@ static uint64_t carve(dae_plan* p, char* base) {
     p->x = take(Bp * Fp * es);
     p->xc = take(Bp * Fp * es);
     p->xct = take(Fp * Bp * es);
+    p->xc_bits = (uint32_t*)take(Bp * (Fp / 32) * 4);
     p->delta2 = take(Bp * Fp * es);
     p->delta2_t = take(Fp * Bp * es);
     const int smax = p->s_enc > p->s_dh ? p->s_enc : p->s_dh;
@@ -183,6 +190,7 @@ extern "C" int dae_plan_create(const dae_config* cfg, dae_plan** out) {
     p->gram_split = (cfg->dtype == DAE_BF16) && (cfg->triplet == DAE_TRIPLET_BATCH_ALL || cfg->triplet == DAE_TRIPLET_BATCH_HARD) &&
                     getenv("DAE_GRAM_FP32") == nullptr;
     p->ws_bytes = carve(p, nullptr);
+    p->bits_ok = cfg->dtype == DAE_BF16 && getenv("DAE_NO_BITS") == nullptr;
     p->overlap_ok = getenv("DAE_OVERLAP") != nullptr;   // measured: running the miner chain beside decode is SLOWER (0.410 vs 0.351 ms/step)
     *out = p;
     return 0;
@@ -262,10 +270,10 @@ extern "C" int dae_plan_info(const dae_plan* p, int32_t* out8) {
 static int gather_batch(dae_plan* p, const int64_t* indptr, const int32_t* indices, const float* values, const float* dense,
                         int64_t ld_dense, const int32_t* row_idx, int B, void* x, void* xc, void* xct, float* rowsq,
                         int corr_mode, const uint32_t* keep_bits, uint64_t seed, uint32_t rng_stream, float corr_frac,
-                        float scale, void* stream) {
+                        float scale, void* stream, uint32_t* xc_bits = nullptr) {
     if (indptr)
-        return dae_gather_csr(indptr, indices, values, row_idx, B, p->F, p->cfg.dtype, x, xc, p->Fp, xct, p->Bpm, rowsq, corr_mode,
-                              keep_bits, seed, rng_stream, corr_frac, scale, stream);
+        return dae_gather_csr_bits(indptr, indices, values, row_idx, B, p->F, p->cfg.dtype, x, xc, p->Fp, xct, p->Bpm, rowsq, corr_mode,
+                                   keep_bits, seed, rng_stream, corr_frac, scale, xc_bits, p->Fp / 32, stream);
     DAE_CHECK_ARG(dense, "step: no train set bound");
     return dae_gather_dense(dense, ld_dense, row_idx, B, p->F, p->cfg.dtype, x, xc, p->Fp, xct, p->Bpm, rowsq, p->rowsq_scratch,
                             corr_mode, keep_bits, seed, rng_stream, corr_frac, scale, stream);
@@ -325,20 +333,26 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     // 1-2. corrupt + gather  (K0/K1 front half)
     if (backward) PROF(PS_MEMSET, memset_async(p->xct, (size_t)Fp * ldB * p->es, st));
     float* rowsq = is_cos ? p->cos_stats : nullptr;
+    bool use_bits = false;
     if (s->c_indptr) {   // an explicitly corrupted copy of the train set (salt&pepper, host-side noise)
         PROF(PS_GATHER, gather_batch(p, p->b.indptr, p->b.indices, p->b.values, p->b.dense, p->b.ld_dense, s->row_idx, B, p->x, nullptr, nullptr,
                         rowsq, DAE_CORR_NONE, nullptr, 0, 0, 0.f, 1.f, stream));
         PROF(PS_GATHER, gather_batch(p, s->c_indptr, s->c_indices, s->c_values, nullptr, 0, s->row_idx, B, nullptr, p->xc,
                         backward ? p->xct : nullptr, nullptr, DAE_CORR_NONE, nullptr, 0, 0, 0.f, s->scale, stream));
     } else {
-        PROF(PS_GATHER, gather_batch(p, p->b.indptr, p->b.indices, p->b.values, p->b.dense, p->b.ld_dense, s->row_idx, B, p->x, p->xc,
-                        backward ? p->xct : nullptr, rowsq, s->corr_mode, s->keep_bits, s->seed, s->rng_stream, s->corr_frac,
-                        s->scale, stream));
+        // binary CSR, unit scale, bf16: the corrupted batch goes to the encode GEMM as a BIT image (1.1 MB, not 18 MB of bf16)
+        use_bits = p->bits_ok && p->b.indptr && !p->b.values && s->scale == 1.0f;
+        PROF(PS_GATHER, gather_batch(p, p->b.indptr, p->b.indices, p->b.values, p->b.dense, p->b.ld_dense, s->row_idx, B, p->x,
+                        use_bits ? nullptr : p->xc, backward ? p->xct : nullptr, rowsq, s->corr_mode, s->keep_bits, s->seed, s->rng_stream,
+                        s->corr_frac, s->scale, stream, use_bits ? p->xc_bits : nullptr));
     }
     // 3-4. encode (K1/K2)
     const int64_t slab = (int64_t)Bp * Hp;
-    PROF(PS_ENC_GEMM, launch_gemm_f32out(dt, Bp, Hp, p->xc, Fp, p->b.Wt_lo, Fp, Fp, nullptr, 0, nullptr, 0, 0, p->slabs, Hp, p->s_enc, slab, st,
-                                         GEMM_ROLE_ENCODE));
+    if (use_bits)
+        PROF(PS_ENC_GEMM, launch_encode_bits(Bp, Hp, Fp, p->xc_bits, Fp / 32, p->b.Wt_lo, Fp, p->slabs, Hp, p->s_enc, slab, st));
+    else
+        PROF(PS_ENC_GEMM, launch_gemm_f32out(dt, Bp, Hp, p->xc, Fp, p->b.Wt_lo, Fp, Fp, nullptr, 0, nullptr, 0, 0, p->slabs, Hp, p->s_enc, slab, st,
+                                             GEMM_ROLE_ENCODE));
     PROF(PS_ENC_FIN, dae_encode_finish(p->slabs, p->s_enc, slab, Hp, p->b.bh, B, H, c.enc_act, dt, p->h_f32, p->h_lo, Hp, p->h_t, ldB,
                                        p->gram_split ? p->hcat_a : nullptr, p->gram_split ? p->hcat_b : nullptr, stream));
     // 5-6. miners (K5-K7)
@@ -454,11 +468,15 @@ extern "C" int dae_encode_rows(dae_plan* p, const int32_t* row_idx, int32_t B, f
     DAE_CHECK_ARG((indptr != nullptr) != (dense != nullptr), "encode_rows: give either a CSR or a dense matrix");
     hipStream_t st = (hipStream_t)stream;
     const int Bp = (int)pad128(B), Fp = p->Fp, Hp = p->Hp, dt = p->cfg.dtype;
-    RC(gather_batch(p, indptr, indices, values, dense, ld_dense, row_idx, B, nullptr, p->xc, nullptr, nullptr, DAE_CORR_NONE, nullptr, 0,
-                    0, 0.f, scale, stream));
+    const bool use_bits = p->bits_ok && indptr && !values && scale == 1.0f;
+    RC(gather_batch(p, indptr, indices, values, dense, ld_dense, row_idx, B, nullptr, use_bits ? nullptr : p->xc, nullptr, nullptr,
+                    DAE_CORR_NONE, nullptr, 0, 0, 0.f, scale, stream, use_bits ? p->xc_bits : nullptr));
     const int64_t slab = (int64_t)Bp * Hp;
-    RC(launch_gemm_f32out(dt, Bp, Hp, p->xc, Fp, p->b.Wt_lo, Fp, Fp, nullptr, 0, nullptr, 0, 0, p->slabs, Hp, p->s_enc, slab, st,
-                          GEMM_ROLE_ENCODE));
+    if (use_bits)
+        RC(launch_encode_bits(Bp, Hp, Fp, p->xc_bits, Fp / 32, p->b.Wt_lo, Fp, p->slabs, Hp, p->s_enc, slab, st));
+    else
+        RC(launch_gemm_f32out(dt, Bp, Hp, p->xc, Fp, p->b.Wt_lo, Fp, Fp, nullptr, 0, nullptr, 0, 0, p->slabs, Hp, p->s_enc, slab, st,
+                              GEMM_ROLE_ENCODE));
     RC(dae_encode_finish(p->slabs, p->s_enc, slab, Hp, p->b.bh, B, p->H, p->cfg.enc_act, dt, p->h_f32, nullptr, Hp, nullptr, 0, nullptr, nullptr,
                          stream));
     DAE_CHECK_HIP(hipMemcpy2DAsync(out, (size_t)ld_out * 4, p->h_f32, (size_t)Hp * 4, (size_t)p->H * 4, B, hipMemcpyDeviceToDevice, st));

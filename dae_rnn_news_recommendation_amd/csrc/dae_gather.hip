@@ -31,9 +31,10 @@ __global__ __launch_bounds__(GATHER_THREADS) void gather_csr_kernel(
     const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const float* __restrict__ values,
     const int32_t* __restrict__ row_idx, int B, int F, T* __restrict__ x, T* __restrict__ xc, int64_t ldx,
     T* __restrict__ xct, int64_t ldt, float* __restrict__ rowsq, int corr_mode, const uint32_t* __restrict__ keep_bits,
-    uint64_t seed, uint32_t stream, float corr_frac, float scale) {
+    uint64_t seed, uint32_t stream, float corr_frac, float scale, uint32_t* __restrict__ xc_bits, int64_t ldw) {
     __shared__ __attribute__((aligned(16))) T lx[GATHER_CW];
     __shared__ __attribute__((aligned(16))) T lxc[GATHER_CW];
+    __shared__ uint32_t lbits[GATHER_CW / 32];
     __shared__ float red[GATHER_THREADS / 64];
     const int i = blockIdx.x;            // batch row (0..Bp-1)
     const int c0 = blockIdx.y * GATHER_CW;
@@ -45,6 +46,7 @@ __global__ __launch_bounds__(GATHER_THREADS) void gather_csr_kernel(
         *reinterpret_cast<i32x4*>(&lx[k]) = i32x4{0, 0, 0, 0};
         *reinterpret_cast<i32x4*>(&lxc[k]) = i32x4{0, 0, 0, 0};
     }
+    if (tid < GATHER_CW / 32) lbits[tid] = 0u;
     __syncthreads();
     if (i < B) {
         const int64_t row = row_idx[i];
@@ -68,6 +70,7 @@ __global__ __launch_bounds__(GATHER_THREADS) void gather_csr_kernel(
             if (col < F) {
                 lx[col - c0] = Elem<T>::from(v);
                 lxc[col - c0] = Elem<T>::from(vc);
+                if (xc_bits && keep) atomicOr(&lbits[(col - c0) >> 5], 1u << ((col - c0) & 31));
                 if (xct && keep) xct[(int64_t)col * ldt + i] = Elem<T>::from(vc);
             }
         }
@@ -91,6 +94,8 @@ __global__ __launch_bounds__(GATHER_THREADS) void gather_csr_kernel(
         if (x) *reinterpret_cast<i32x4*>(&x[(int64_t)i * ldx + c0 + k]) = *reinterpret_cast<const i32x4*>(&lx[k]);
         if (xc) *reinterpret_cast<i32x4*>(&xc[(int64_t)i * ldx + c0 + k]) = *reinterpret_cast<const i32x4*>(&lxc[k]);
     }
+    // bit-packed x~ (binary inputs): bit b of word w of row i <=> feature 32*w + b is kept.  Operand of gemm_encode_bits.
+    if (xc_bits && tid < (ncol >> 5)) xc_bits[(int64_t)i * ldw + (c0 >> 5) + tid] = lbits[tid];
 }
 
 // Dense ndarray input (autoencoder.py:143 sparse_input False; dense masking utils.py:107-109).
@@ -147,29 +152,40 @@ __global__ void rowsq_reduce_kernel(const float* __restrict__ part, int nparts, 
 
 using namespace dae;
 
-extern "C" int dae_gather_csr(const int64_t* indptr, const int32_t* indices, const float* values, const int32_t* row_idx,
-                              int32_t B, int32_t F, int32_t dtype, void* x, void* xc, int64_t ldx, void* xct, int64_t ldt,
-                              float* rowsq, int32_t corr_mode, const uint32_t* keep_bits, uint64_t seed,
-                              uint32_t rng_stream, float corr_frac, float scale, void* stream) {
+extern "C" int dae_gather_csr_bits(const int64_t* indptr, const int32_t* indices, const float* values, const int32_t* row_idx,
+                                   int32_t B, int32_t F, int32_t dtype, void* x, void* xc, int64_t ldx, void* xct, int64_t ldt,
+                                   float* rowsq, int32_t corr_mode, const uint32_t* keep_bits, uint64_t seed,
+                                   uint32_t rng_stream, float corr_frac, float scale, uint32_t* xc_bits, int64_t ldw,
+                                   void* stream) {
     DAE_CHECK_ARG(indptr && indices && row_idx, "gather_csr: null CSR / row_idx");
     DAE_CHECK_ARG(B > 0 && F > 0, "gather_csr: B=%d F=%d", B, F);
     DAE_CHECK_ARG(ldx >= F && ldx % DAE_PAD == 0, "gather_csr: ldx=%lld must be the padded feature count", (long long)ldx);
     DAE_CHECK_ARG(dtype == DAE_BF16 || dtype == DAE_F32, "gather_csr: bad dtype");
     DAE_CHECK_ARG(corr_mode != DAE_CORR_KEEPBITS || keep_bits, "gather_csr: keep_bits is null");
     DAE_CHECK_ARG(!xct || ldt >= dae_pad(B), "gather_csr: ldt too small");
+    DAE_CHECK_ARG(!xc_bits || (!values && scale == 1.0f), "gather_csr: the bit-packed x~ needs binary data (values == NULL) and scale == 1");
+    DAE_CHECK_ARG(!xc_bits || ldw >= ldx / 32, "gather_csr: ldw too small");
     const int Bp = (int)dae_pad(B);
     dim3 grid(Bp, (unsigned)((ldx + GATHER_CW - 1) / GATHER_CW)), block(GATHER_THREADS);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == DAE_BF16)
         hipLaunchKernelGGL((gather_csr_kernel<bf16_t>), grid, block, 0, st, indptr, indices, values, row_idx, B, F,
                            (bf16_t*)x, (bf16_t*)xc, ldx, (bf16_t*)xct, ldt, rowsq, corr_mode, keep_bits, seed, rng_stream,
-                           corr_frac, scale);
+                           corr_frac, scale, xc_bits, ldw);
     else
         hipLaunchKernelGGL((gather_csr_kernel<float>), grid, block, 0, st, indptr, indices, values, row_idx, B, F,
                            (float*)x, (float*)xc, ldx, (float*)xct, ldt, rowsq, corr_mode, keep_bits, seed, rng_stream,
-                           corr_frac, scale);
+                           corr_frac, scale, xc_bits, ldw);
     DAE_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int dae_gather_csr(const int64_t* indptr, const int32_t* indices, const float* values, const int32_t* row_idx,
+                              int32_t B, int32_t F, int32_t dtype, void* x, void* xc, int64_t ldx, void* xct, int64_t ldt,
+                              float* rowsq, int32_t corr_mode, const uint32_t* keep_bits, uint64_t seed,
+                              uint32_t rng_stream, float corr_frac, float scale, void* stream) {
+    return dae_gather_csr_bits(indptr, indices, values, row_idx, B, F, dtype, x, xc, ldx, xct, ldt, rowsq, corr_mode, keep_bits,
+                               seed, rng_stream, corr_frac, scale, nullptr, 0, stream);
 }
 
 extern "C" int dae_gather_dense(const float* data, int64_t ld_data, const int32_t* row_idx, int32_t B, int32_t F,

@@ -354,6 +354,7 @@ template <int ACT> __device__ __forceinline__ float act_bwd(float a) {
     else return 1.0f;
 }
 
+constexpr float CE_FAST_ZMAX = 14.0f;               // sigmoid(14) = 1 - 8.3e-7: five fp32 ulps from saturation
 constexpr int DECODE_NST = 2;
 template <typename T, int LOSS, int ACT>
 __global__ __launch_bounds__(GEMM_THREADS, wg_per_cu_for(DECODE_NST)) void gemm_decode_loss(GemmParams p, DecodeEpi e) {
@@ -436,8 +437,17 @@ __global__ __launch_bounds__(GEMM_THREADS, wg_per_cu_for(DECODE_NST)) void gemm_
     T* d2t_lane = D2T ? D2T + (int64_t)(tn * BN + lcol0) * e.lddt + tm * BM + lrow0 : nullptr;
 
     // static (compile-time) accumulator indexing: a runtime-indexed f32x16 would be demoted to scratch
-    auto epi_block = [&](auto MT, auto R4) {
+    // FAST (cross_entropy + sigmoid, every |z| of this wave < CE_FAST_ZMAX): the exact-math identities
+    //   -log y = softplus(-z), -log(1-y) = softplus(z), dL/dy * y(1-y) = y - x
+    // replace the reference's  log(y+1e-16), log((1-y)+1e-16), 1/(y+1e-16), 1/((1-y)+1e-16)  -- 3 transcendentals per
+    // element instead of 6.  In that range the 1e-16 guards are below fp32 resolution (y, 1-y > 3e-7), so the two forms
+    // differ only by fp32 rounding (the softplus form is the more accurate one).  Waves holding a saturated logit take
+    // the reference-literal path, which reproduces TF's fp32 behaviour there (y rounds to 1, log(1e-16) = -36.84).
+    const bool want_rows = e.rowloss_part != nullptr;
+    float wl_acc = 0.f;                                // this lane's share of sum_i cw_i * loss_if
+    auto epi_block = [&](auto MT, auto R4, auto FASTV) {
         constexpr int mt = decltype(MT)::value, r4 = decltype(R4)::value;
+        constexpr bool FAST = decltype(FASTV)::value;
         constexpr int rloc = mt * 32 + 8 * r4;         // local row offset of q = 0 relative to lrow0
         float d2v[2][4];
         float xin[4][2];
@@ -459,11 +469,28 @@ __global__ __launch_bounds__(GEMM_THREADS, wg_per_cu_for(DECODE_NST)) void gemm_
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 const float z = acc[mt][nt][r] + bvv[nt];
-                const float y = act_fwd<ACT>(z);
                 float x;
                 if constexpr (STAGED) x = bf2f(*reinterpret_cast<const bf16_t*>(r0_lane + (rloc + q) * EPI_PITCH + nt * 64));
                 else x = xin[q][nt];
                 float l = 0.f, dy = 0.f;
+                if constexpr (FAST) {
+                    const float en = __builtin_amdgcn_exp2f(-fabsf(z) * kLog2e);          // exp(-|z|)
+                    const float op = 1.0f + en;
+                    const float rr = __builtin_amdgcn_rcpf(op);
+                    const float yv = z >= 0.f ? rr : en * rr;
+                    l = kLn2 * __builtin_amdgcn_logf(op) + fmaxf(z, 0.f) - x * z;
+                    const float d2 = (cwi * cm[nt]) * (yv - x);
+                    rl += cm[nt] * l;
+                    d2v[nt][q] = d2;
+                    colsum[nt] += d2;
+                    if constexpr (STAGED) {
+                        *reinterpret_cast<bf16_t*>(r0_lane + (rloc + q) * EPI_PITCH + nt * 64) = f2bf_hw(d2);
+                    } else {
+                        if (d2_lane) d2_lane[(int64_t)(rloc + q) * e.ldd + nt * 32] = Elem<T>::from(d2);
+                    }
+                    continue;
+                }
+                const float y = act_fwd<ACT>(z);
                 if constexpr (LOSS == DAE_LOSS_CROSS_ENTROPY) {
                     const float a = y + eps, b = (1.0f - y) + eps;          // reference op order: (1.-y)+1e-16
                     const float la = __builtin_amdgcn_logf(a), lb = __builtin_amdgcn_logf(b);   // log2; a, b >= 1e-16 (normal)
@@ -501,8 +528,11 @@ __global__ __launch_bounds__(GEMM_THREADS, wg_per_cu_for(DECODE_NST)) void gemm_
                     if (c == 31) { pyy_l[wn * 128 + lrow] = s_yy; pxy_l[wn * 128 + lrow] = s_xy; }
                 }
             } else {
-                rl = half32_sum_hi(rl);
-                if (c == 31) rowsum_l[wn * 128 + lrow] = rl;
+                wl_acc += cwi * rl;
+                if (want_rows) {
+                    rl = half32_sum_hi(rl);
+                    if (c == 31) rowsum_l[wn * 128 + lrow] = rl;
+                }
             }
         }
 #pragma unroll
@@ -518,13 +548,31 @@ __global__ __launch_bounds__(GEMM_THREADS, wg_per_cu_for(DECODE_NST)) void gemm_
             }
         }
     };
-#define DAE_EPI_ROWS(MTV)                                                                       \
-    epi_block(std::integral_constant<int, MTV>{}, std::integral_constant<int, 0>{});            \
-    epi_block(std::integral_constant<int, MTV>{}, std::integral_constant<int, 1>{});            \
-    epi_block(std::integral_constant<int, MTV>{}, std::integral_constant<int, 2>{});            \
-    epi_block(std::integral_constant<int, MTV>{}, std::integral_constant<int, 3>{});
-    DAE_EPI_ROWS(0)
-    DAE_EPI_ROWS(1)
+#define DAE_EPI_ROWS(MTV, FV)                                                                                              \
+    epi_block(std::integral_constant<int, MTV>{}, std::integral_constant<int, 0>{}, std::integral_constant<bool, FV>{});   \
+    epi_block(std::integral_constant<int, MTV>{}, std::integral_constant<int, 1>{}, std::integral_constant<bool, FV>{});   \
+    epi_block(std::integral_constant<int, MTV>{}, std::integral_constant<int, 2>{}, std::integral_constant<bool, FV>{});   \
+    epi_block(std::integral_constant<int, MTV>{}, std::integral_constant<int, 3>{}, std::integral_constant<bool, FV>{});
+    bool fast = false;
+    if constexpr (LOSS == DAE_LOSS_CROSS_ENTROPY && ACT == DAE_ACT_SIGMOID) {
+        float zmax = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zmax = fmaxf(zmax, fabsf(acc[mt][nt][r] + bvv[nt]));
+        fast = __builtin_amdgcn_ballot_w64(!(zmax < CE_FAST_ZMAX)) == 0ull && !e.ce_literal;   // NaN logits take the literal path
+    }
+    if (fast) {
+        if constexpr (LOSS == DAE_LOSS_CROSS_ENTROPY && ACT == DAE_ACT_SIGMOID) {
+            DAE_EPI_ROWS(0, true)
+            DAE_EPI_ROWS(1, true)
+        }
+    } else {
+        DAE_EPI_ROWS(0, false)
+        DAE_EPI_ROWS(1, false)
+    }
 #undef DAE_EPI_ROWS
     if (!pass1) {                                       // column sums: rows of g = 0 and g = 1, then one lane per column
 #pragma unroll
@@ -565,13 +613,12 @@ __global__ __launch_bounds__(GEMM_THREADS, wg_per_cu_for(DECODE_NST)) void gemm_
         if (e.dbv_part && !pass1) e.dbv_part[(int64_t)(tm * 2 + w) * e.Fp + tn * BN + k] = colsum_l[w * 128 + k];
     }
     if constexpr (!IS_COS) {
-        if (e.tile_part && tid < 128) {                 // this tile's share of sum_i cw_i * rowloss_i (2 waves, fixed order)
-            float v = cw_l[tid] * (rowsum_l[tid] + rowsum_l[128 + tid]);
-            v = wave64_sum_hi(v);
+        if (e.tile_part) {                              // this tile's share of sum_i cw_i * rowloss_i (4 waves, fixed order)
+            const float v = wave64_sum_hi(wl_acc);
             if (lane == 63) pyy_l[wave] = v;            // pyy_l is unused outside cosine
         }
         __syncthreads();
-        if (e.tile_part && tid == 0) e.tile_part[tm * p.tiles_n + tn] = pyy_l[0] + pyy_l[1];
+        if (e.tile_part && tid == 0) e.tile_part[tm * p.tiles_n + tn] = (pyy_l[0] + pyy_l[1]) + (pyy_l[2] + pyy_l[3]);
     }
 }
 
@@ -679,9 +726,188 @@ int launch_decode_loss(int dtype, int Bp, int Fp, int Hp, const void* h_lo, int6
                   "decode_loss: leading dimensions must be multiples of 8 elements");
     decode_fn k = dtype == DAE_BF16 ? decode_kernel<bf16_t>(e.loss_func, e.dec_act) : decode_kernel<float>(e.loss_func, e.dec_act);
     dim3 grid(grid_blocks(p)), block(GEMM_THREADS);
-    hipLaunchKernelGGL(k, grid, block, DECODE_LDS_BYTES, st, p, e);
+    static const int ce_literal = getenv("DAE_CE_LITERAL") != nullptr;
+    DecodeEpi ee = e;
+    ee.ce_literal = ce_literal || e.ce_literal;
+    hipLaunchKernelGGL(k, grid, block, DECODE_LDS_BYTES, st, p, ee);
     DAE_CHECK_LAUNCH();
     return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Fused corrupt+encode GEMM for BINARY inputs: the A operand is the bit-packed corrupted batch
+// (1 bit per feature, written by the gather kernel: 1.1 MB instead of 18 MB of bf16) and is expanded to the
+// bf16 MFMA tile INSIDE LDS; only the W^T tile is streamed (global_load_lds), i.e. half the staged bytes per
+// K tile of the generic kernel -- the generic GEMMs are bound by operand staging, not by MFMA.
+//   z1 slab[split] = bits(x~)[Bp x Fp] . Wt_lo[Hp x Fp]^T          (autoencoder.py:389, tf.sparse.matmul)
+// Wave layout 4x1: wave w owns output rows [32w, 32w+32) of the 128x128 tile, so the A rows it expands are the
+// rows it consumes -- no barrier between expansion and fragment reads.  Raw bits arrive through the same LDS-DMA
+// queue as W^T (one 4-byte global_load_lds per lane: 32 rows x 2 words per wave).
+// ------------------------------------------------------------------------------------------------
+constexpr int EB_STAGE_BYTES = TILE_BYTES + 1024;      // ring stage = [W^T tile 16K | raw bits 1K]; the expanded A tile (16K) is single
+constexpr int eb_lds_bytes(int nst) { return TILE_BYTES + nst * EB_STAGE_BYTES; }
+
+struct EncBitsParams {
+    const char* Bt; int64_t ldb_b;                    // W^T_lo [Hp x Fp] bf16, leading dimension in bytes
+    const uint32_t* bits; int64_t ldw;                // x~ bits [Bp x ldw words], bit b of word w = feature 32*w + b
+    int ktiles_total, tiles_m, tiles_n, splits;
+    int probe;                                        // DAE_EB_PROBE bit mask (timing experiments only; results are garbage when set)
+};
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// NST-deep LDS-DMA ring: the encode grid is <= 1 workgroup per CU (28 tiles x 8 K slices), so the only way to hide the
+// ~1 us global->LDS latency is depth, not occupancy; LDS is otherwise idle (160 KB per CU).
+template <int NST>
+__global__ __launch_bounds__(GEMM_THREADS, 1) void gemm_encode_bits(EncBitsParams p, float* __restrict__ C, int64_t ldc,
+                                                                    int64_t slab_stride) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* const abuf = lds;
+    char* const ring = lds + TILE_BYTES;
+    const int id = blockIdx.x;
+    const int split = id % p.splits, tile = id / p.splits;
+    const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
+    const int kt0 = (int)(((int64_t)p.ktiles_total * split) / p.splits);
+    const int kt1 = (int)(((int64_t)p.ktiles_total * (split + 1)) / p.splits);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rr = lane & 31, g = lane >> 5;
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const int nk = kt1 - kt0;
+    constexpr int LOADS = 5;                                           // global_load_lds per wave per stage
+
+    auto stage = [&](int kt, char* st) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                                  // W^T tile: 16 pieces of 1 KiB, 4 per wave
+            const int piece = i * 4 + wave;
+            const int row = piece * 8 + (lane >> 3);
+            const int sslot = (lane & 7) ^ ((row >> 1) & 7);
+            const char* gb = p.Bt + (int64_t)(tn * BN + row) * p.ldb_b + (int64_t)kt * BKB + sslot * 16;
+            if (p.probe & 1) gb = p.Bt + ((int64_t)tn * p.ktiles_total + kt) * TILE_BYTES + piece * 1024 + lane * 16;
+            if (!(p.probe & 8))
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gb,
+                                             (__attribute__((address_space(3))) void*)(st + piece * 1024), 16, 0, 0);
+        }
+        {                                                              // raw bits of this wave's 32 rows: 2 words per row
+            const uint32_t* gw = p.bits + (int64_t)(tm * BM + wave * 32 + (lane >> 1)) * p.ldw + kt * 2 + (lane & 1);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gw,
+                                             (__attribute__((address_space(3))) void*)(st + TILE_BYTES + wave * 256), 4, 0, 0);
+        }
+    };
+
+    for (int j = 0; j < NST - 1; ++j)
+        if (j < nk) stage(kt0 + j, ring + j * EB_STAGE_BYTES);
+    int slot = 0;
+    for (int i = 0; i < nk; ++i) {
+        // stage i landed when at most `ahead` younger stage groups are still in flight
+        const int ahead = min(NST - 2, nk - 1 - i);
+        if constexpr (NST >= 8) { if (ahead == 6) wait_vm<6 * LOADS>(); if (ahead == 5) wait_vm<5 * LOADS>(); if (ahead == 4) wait_vm<4 * LOADS>(); if (ahead == 3) wait_vm<3 * LOADS>(); }
+        else if constexpr (NST >= 4) { if (ahead > 2) wait_vm<2 * LOADS>(); }
+        if (ahead == 2) wait_vm<2 * LOADS>();
+        if (ahead == 1) wait_vm<1 * LOADS>();
+        if (ahead <= 0) wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        char* cur = ring + slot * EB_STAGE_BYTES;
+        if (i + NST - 1 < nk) {                                        // refill the slot consumed in iteration i-1
+            const int ns = slot == 0 ? NST - 1 : slot - 1;
+            stage(kt0 + i + NST - 1, ring + ns * EB_STAGE_BYTES);
+        }
+        // ---- expand this wave's bits into its 32 private A rows (bf16 1.0 = 0x3F80) ----
+        if (!(p.probe & 4)) {
+            const uint32_t word = *reinterpret_cast<const uint32_t*>(cur + TILE_BYTES + wave * 256 + lane * 4);
+            const int r = wave * 32 + (lane >> 1), half = lane & 1;
+            const int swz = (r >> 1) & 7;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                i32x4 v;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t b2 = (word >> (8 * j + 2 * q)) & 3u;
+                    v[q] = (int)(((b2 & 1u) * 0x3F80u) | ((b2 >> 1) * 0x3F800000u));
+                }
+                *reinterpret_cast<i32x4*>(abuf + r * BKB + (((half * 4 + j) ^ swz) << 4)) = v;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // own ds_writes landed; rows are private to this wave
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- fragments + MFMAs: A rows [32*wave, +32), all 128 B rows ----
+        if (!(p.probe & 2)) {
+            const int swz2 = (rr >> 1) & 7;
+            const uint32_t pa = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)abuf + (wave * 32 + rr) * BKB;
+            const uint32_t pb = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)cur + rr * BKB;
+            i32x4 a[4], b[4][4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const uint32_t so = ((kk * 2 + g) ^ swz2) << 4;
+                a[kk] = lds_read_b128(pa + so);
+                b[kk][0] = lds_read_b128(pb + so);
+                b[kk][1] = lds_read_b128_off4096(pb + so);
+                b[kk][2] = lds_read_b128(pb + 8192 + so);
+                b[kk][3] = lds_read_b128_off4096(pb + 8192 + so);
+            }
+#define DAE_EB_GROUP(KK, CNT)                                      \
+    asm volatile("s_waitcnt lgkmcnt(" #CNT ")" ::: "memory");     \
+    __builtin_amdgcn_sched_barrier(0);                            \
+    Mma<bf16_t>::run(a[KK], b[KK][0], acc[0]);                    \
+    Mma<bf16_t>::run(a[KK], b[KK][1], acc[1]);                    \
+    Mma<bf16_t>::run(a[KK], b[KK][2], acc[2]);                    \
+    Mma<bf16_t>::run(a[KK], b[KK][3], acc[3]);
+            DAE_EB_GROUP(0, 15)
+            DAE_EB_GROUP(1, 10)
+            DAE_EB_GROUP(2, 5)
+            DAE_EB_GROUP(3, 0)
+#undef DAE_EB_GROUP
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        slot = slot + 1 == NST ? 0 : slot + 1;
+    }
+    float* Cs = C + (int64_t)split * slab_stride;
+    const int c = lane & 31;
+    if (p.probe & 16) return;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = tm * BM + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+            const int col = tn * BN + nt * 32 + c;
+            Cs[(int64_t)row * ldc + col] = acc[nt][r];
+        }
+}
+
+template <int NST>
+static int launch_eb(const EncBitsParams& p, float* C, int64_t ldc, int64_t slab_stride, hipStream_t st) {
+    static int attr_rc = [] {
+        return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_encode_bits<NST>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        eb_lds_bytes(NST));
+    }();
+    DAE_CHECK_ARG(attr_rc == 0, "encode_bits: hipFuncSetAttribute failed (%d)", attr_rc);
+    hipLaunchKernelGGL(gemm_encode_bits<NST>, dim3(p.tiles_m * p.tiles_n * p.splits), dim3(GEMM_THREADS), eb_lds_bytes(NST), st, p, C, ldc,
+                       slab_stride);
+    DAE_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_encode_bits(int Bp, int Hp, int Fp, const uint32_t* bits, int64_t ldw, const void* Wt_lo, int64_t ldb, float* C,
+                       int64_t ldc, int splits, int64_t slab_stride, hipStream_t st) {
+    DAE_CHECK_ARG(bits && Wt_lo && C, "encode_bits: null operand");
+    DAE_CHECK_ARG(Bp % BM == 0 && Hp % BN == 0 && Fp % 64 == 0 && ldw >= Fp / 32, "encode_bits: bad shape");
+    DAE_CHECK_ARG(((uintptr_t)Wt_lo % 16) == 0 && (ldb * 2) % 16 == 0 && ((uintptr_t)bits % 4) == 0, "encode_bits: alignment");
+    EncBitsParams p;
+    p.Bt = (const char*)Wt_lo; p.ldb_b = ldb * 2; p.bits = bits; p.ldw = ldw;
+    p.ktiles_total = Fp / 64; p.tiles_m = Bp / BM; p.tiles_n = Hp / BN; p.splits = splits < 1 ? 1 : splits;
+    DAE_CHECK_ARG(p.splits <= p.ktiles_total, "encode_bits: too many splits");
+    static const int nst = [] { const char* v = getenv("DAE_EB_NST"); return v ? atoi(v) : 4; }();
+    static const int probe = [] { const char* v = getenv("DAE_EB_PROBE"); return v ? atoi(v) : 0; }();
+    p.probe = probe;
+    if (nst >= 8) return launch_eb<8>(p, C, ldc, slab_stride, st);
+    if (nst >= 4) return launch_eb<4>(p, C, ldc, slab_stride, st);
+    return launch_eb<2>(p, C, ldc, slab_stride, st);
 }
 
 void set_use_glds(int nst) { g_nst = nst; }

@@ -20,6 +20,7 @@ struct DecodeEpi {
     int B, F, Bp, Fp;
     int dec_act, loss_func;
     int cos_pass;             // 0: not cosine, 1: statistics pass, 2: final pass
+    int ce_literal;           // 1: always evaluate cross_entropy with the reference-literal formula (DAE_CE_LITERAL=1; A/B and tests)
 };
 
 int launch_gemm_f32out(int dtype, int M, int N, const void* A0, int64_t lda0, const void* Bt0, int64_t ldb0, int K0,
@@ -29,5 +30,7 @@ enum { GEMM_ROLE_GENERIC = 0, GEMM_ROLE_ENCODE = 1, GEMM_ROLE_DH = 2, GEMM_ROLE_
 int launch_decode_loss(int dtype, int Bp, int Fp, int Hp, const void* h_lo, int64_t ldh, const void* W_lo, int64_t ldw,
                        const DecodeEpi& e, hipStream_t st);
 void set_use_glds(int nst);
+int launch_encode_bits(int Bp, int Hp, int Fp, const uint32_t* bits, int64_t ldw, const void* Wt_lo, int64_t ldb, float* C,
+                       int64_t ldc, int splits, int64_t slab_stride, hipStream_t st);
 
 }  // namespace dae

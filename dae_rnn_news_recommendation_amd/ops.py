@@ -51,6 +51,30 @@ def gather_csr(indptr, indices, values, row_idx, B, F, dtype, *, want_x=True, wa
     return x, xc, xct, rowsq
 
 
+def gather_csr_bits(indptr, indices, row_idx, B, F, dtype, *, corr_mode=L.CORR_NONE, keep_bits=None, seed=0,
+                    rng_stream=0, corr_frac=0.0):
+    """Binary CSR -> (x, x~ bit image [Bp x Fp/32] int32, x~^T); the operand set of the fused corrupt+encode GEMM."""
+    Bp, Fp = L.pad(B), L.pad(F)
+    td = tdtype(dtype)
+    dev = indptr.device
+    x = torch.empty((Bp, Fp), dtype=td, device=dev)
+    xct = torch.zeros((Fp, Bp), dtype=td, device=dev)
+    bits = torch.empty((Bp, Fp // 32), dtype=torch.int32, device=dev)
+    L.call("dae_gather_csr_bits", L.ptr(indptr), L.ptr(indices), None, L.ptr(row_idx), B, F, dtype, L.ptr(x), None, Fp,
+           L.ptr(xct), Bp, None, corr_mode, L.ptr(keep_bits), seed, rng_stream, corr_frac, 1.0, L.ptr(bits), Fp // 32,
+           L.current_stream())
+    return x, bits, xct
+
+
+def encode_bits(bits, Wt_lo, splits=1):
+    """slabs[s] = bits(x~) . Wt_lo^T  (bf16 MFMA, A expanded from the bit image in LDS)."""
+    Bp, Fp, Hp = bits.shape[0], bits.shape[1] * 32, Wt_lo.shape[0]
+    slabs = torch.empty((splits, Bp, Hp), dtype=torch.float32, device=bits.device)
+    L.call("dae_encode_bits", L.ptr(bits), bits.stride(0), L.ptr(Wt_lo), Wt_lo.stride(0), Bp, Hp, Fp, L.ptr(slabs), Hp,
+           splits, Bp * Hp, L.current_stream())
+    return slabs
+
+
 def gather_dense(data, row_idx, B, F, dtype, *, want_rowsq=False, corr_mode=L.CORR_NONE, keep_bits=None, seed=0,
                  rng_stream=0, corr_frac=0.0, scale=1.0):
     Bp, Fp = L.pad(B), L.pad(F)

@@ -72,6 +72,24 @@ int dae_gather_csr(const int64_t* indptr, const int32_t* indices, const float* v
                    int32_t corr_mode, const uint32_t* keep_bits, uint64_t seed, uint32_t rng_stream,
                    float corr_frac, float scale, void* stream);
 
+/* Same kernel, additionally emitting the corrupted batch as a BIT image for dae_encode_bits:
+ *   xc_bits [Bp x ldw] u32, bit b of word w of row i  <=>  entry (i, 32*w + b) of x~ is kept (value 1.0).
+ * Only for binary matrices (values == NULL) with scale == 1; rows >= B and columns >= F are zero.
+ * xc may then be NULL (the dense x~ image is not needed by the encode GEMM). */
+int dae_gather_csr_bits(const int64_t* indptr, const int32_t* indices, const float* values,
+                        const int32_t* row_idx, int32_t B, int32_t F, int32_t dtype,
+                        void* x, void* xc, int64_t ldx, void* xct, int64_t ldt, float* rowsq,
+                        int32_t corr_mode, const uint32_t* keep_bits, uint64_t seed, uint32_t rng_stream,
+                        float corr_frac, float scale, uint32_t* xc_bits, int64_t ldw, void* stream);
+
+/* K1 for binary inputs: fused corrupt+encode GEMM  slab[s] = bits(x~) . Wt_lo^T  over K range s
+ * (autoencoder.py:389 tf.sparse.matmul(sparse x~, W); the reference multiplies the 0/1 CSR directly).
+ * The A operand is the bit image and is expanded to bf16 MFMA fragments inside LDS; only W^T is streamed.
+ * bf16 only.  Bp, Hp multiples of 128; Fp multiple of 64; slabs as for dae_gemm_nt. */
+int dae_encode_bits(const uint32_t* xc_bits, int64_t ldw, const void* Wt_lo, int64_t ldwt,
+                    int32_t Bp, int32_t Hp, int32_t Fp, float* slabs, int64_t ld_slab,
+                    int32_t splits, int64_t slab_stride, void* stream);
+
 /* Dense-ndarray input (autoencoder.py:143 sparse_input=False; utils.py:107-109 dense masking):
  * gathers fp32 rows data[row_idx[i], :] into x / xc / xct with optional Philox masking. */
 int dae_gather_dense(const float* data, int64_t ld_data, const int32_t* row_idx, int32_t B, int32_t F,

@@ -132,6 +132,37 @@ def test_gather_csr_keepbits(ops, L, dtype, binary):
     assert (rowsq.cpu().numpy()[B:] == 0).all()
 
 
+def test_gather_csr_bits_and_encode_bits(ops, L):
+    """Bit-packed x~ (binary CSR): the bit image equals packbits of the dense x~ image bit for bit, and the fused
+    corrupt+encode GEMM on it reproduces the dense-operand GEMM (same bf16 products, fp32 accumulation)."""
+    rng = np.random.default_rng(11)
+    N, F, B, H = 500, 4500, 200, 250       # two 4096-column chunks, ragged everything
+    m = _rand_csr(rng, N, F, 0.03, True)
+    m = sparse.vstack([m, sparse.csr_matrix((1, F), dtype=np.float32)]).tocsr(); N += 1
+    keep = rng.random(m.nnz) >= 0.3
+    kb = np.packbits(keep, bitorder="little")
+    kb = np.concatenate([kb, np.zeros((-len(kb)) % 4, np.uint8)]).view(np.int32)
+    rows = rng.permutation(N)[:B].astype(np.int32); rows[7] = N - 1
+    ip, ix, rw = dev(m.indptr.astype(np.int64)), dev(m.indices.astype(np.int32)), dev(rows)
+    x, bits, xct = ops.gather_csr_bits(ip, ix, rw, B, F, L.BF16, corr_mode=L.CORR_KEEPBITS, keep_bits=dev(kb))
+    x2, xc2, xct2, _ = ops.gather_csr(ip, ix, None, rw, B, F, L.BF16, corr_mode=L.CORR_KEEPBITS, keep_bits=dev(kb))
+    torch.cuda.synchronize()
+    Bp, Fp, Hp = L.pad(B), L.pad(F), L.pad(H)
+    want = np.packbits(xc2.float().cpu().numpy() != 0, axis=1, bitorder="little").view(np.uint32)
+    assert want.shape == (Bp, Fp // 32)
+    assert np.array_equal(bits.cpu().numpy().view(np.uint32), want)
+    assert torch.equal(x, x2) and torch.equal(xct, xct2)
+    Wt = padded(rng.standard_normal((H, F)).astype(np.float32) * 0.1, Hp, Fp, torch.bfloat16)
+    ref = xc2.double() @ Wt.double().T
+    for splits in (1, 3, 8):
+        z = ops.encode_bits(bits, Wt, splits).sum(0)
+        zd = ops.gemm_nt(xc2, Wt, splits=splits).sum(0)
+        torch.cuda.synchronize()
+        assert rel_err(z.cpu().numpy(), ref.cpu().numpy()) < 2e-6
+        assert rel_err(z.cpu().numpy(), zd.cpu().numpy()) < 2e-6
+        assert (z[B:] == 0).all()
+
+
 def test_gather_csr_philox_matches_oracle(ops, L):
     rng = np.random.default_rng(4)
     N, F, B = 200, 1000, 128
