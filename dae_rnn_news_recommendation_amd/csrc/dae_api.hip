@@ -34,6 +34,13 @@ extern "C" int dae_gemm_nt(int32_t dtype, int32_t M, int32_t N, const void* A0, 
                               (hipStream_t)stream);
 }
 
+extern "C" int dae_gemm_trace(int32_t dtype, int32_t M, int32_t N, const void* A0, int64_t lda0, const void* Bt0, int64_t ldb0,
+                              int32_t K0, const void* A1, int64_t lda1, const void* Bt1, int64_t ldb1, int32_t K1, float* C,
+                              int64_t ldc, int32_t splits, int64_t slab_stride, int32_t nst, uint64_t* trace, void* stream) {
+    return launch_gemm_trace(dtype, M, N, A0, lda0, Bt0, ldb0, K0, A1, lda1, Bt1, ldb1, K1, C, ldc, splits, slab_stride, nst,
+                             (unsigned long long*)trace, (hipStream_t)stream);
+}
+
 extern "C" int dae_encode_bits(const uint32_t* xc_bits, int64_t ldw, const void* Wt_lo, int64_t ldwt, int32_t Bp, int32_t Hp, int32_t Fp,
                                float* slabs, int64_t ld_slab, int32_t splits, int64_t slab_stride, void* stream) {
     return launch_encode_bits(Bp, Hp, Fp, xc_bits, ldw, Wt_lo, ldwt, slabs, ld_slab, splits, slab_stride, (hipStream_t)stream);

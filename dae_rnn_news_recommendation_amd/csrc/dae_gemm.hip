@@ -51,7 +51,7 @@ struct GemmParams {
     GemmSeg seg[2];
     int ktiles_total;
     int tiles_m, tiles_n, splits;
-    int probe;              // experiment (env DAE_GEMM_PROBE): 1 = skip the MFMA block (staging-rate probe)
+    unsigned long long* trace;   // dae_gemm_trace only: [blocks][4 waves][8] shader-clock sums per K-loop phase
 };
 
 template <typename T> struct Mma;
@@ -120,13 +120,14 @@ __device__ __forceinline__ void stage_glds(const GemmParams& p, int kt, int row0
         const char* gb = Bt + (int64_t)(row0_n + row) * ldb + kb + sslot * 16;
         char* la = stage + piece * 1024;
         char* lb = stage + TILE_BYTES + piece * 1024;
-        if (!(p.probe & 2))      // probe 2: stage only the B operand (halves the staged bytes)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ga,
                                          (__attribute__((address_space(3))) void*)la, 16, 0, 0);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gb,
                                          (__attribute__((address_space(3))) void*)lb, 16, 0, 0);
     }
 }
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // One K tile of MFMA work for a wave.  All 16 fragment reads (ds_read_b128, 64 VGPRs) are issued back to back and
 // the four MFMA groups wait with COUNTED lgkmcnt (12/8/4/0): the first MFMAs start as soon as their fragments land
@@ -181,9 +182,19 @@ __device__ __forceinline__ void compute_stage(const char* stage, int wm, int wn,
 // front of the barrier only retires tile i, leaving up to NST-2 younger tiles (8 LDS-DMA ops per wave each) in
 // flight across the barrier.  One raw s_barrier per K tile; __syncthreads() would drain the DMA queue (its
 // fence waits vmcnt(0) while LDS-DMA writes are pending).
-template <typename T, int NST>
+template <typename T, int NST, bool TRACE = false>
 __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, int tm, int tn, int kt0, int kt1, char* lds,
                                               f32x16 (&acc)[2][2]) {
+    // TRACE (dae_gemm_trace): s_memtime stamps between the phases of every K iteration, summed per wave:
+    //   [0] phase (a): 8 MFMAs (+DMA)  [1] waits (vmcnt, lgkmcnt)  [2] barrier  [3] phases (c,d,e): reads, 8 MFMAs + DMA, reads
+    //   [4] iterations
+    unsigned long long tsum[5] = {0, 0, 0, 0, 0}, tprev = 0;
+#define DAE_STAMP(K)                                                         \
+    if constexpr (TRACE) {                                                   \
+        const unsigned long long t__ = __builtin_amdgcn_s_memtime();         \
+        tsum[K] += t__ - tprev;                                              \
+        tprev = t__;                                                         \
+    }
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -199,25 +210,141 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, int tm, int t
     if (nk <= 0) return;
 
     if constexpr (NST >= 2) {
-        // (measured, no effect: rotating the K order per tile to de-synchronise the tiles of one XCD)
-        auto ktile = [&](int i) { return kt0 + i; };
+        // ---- LDS-DMA addressing: this lane's 16-byte chunk of each of its 4 pieces per operand, as a 32-bit byte offset
+        //      from a uniform (SGPR) panel pointer that advances by one K tile per stage ----
+        uint32_t voA[4], voB[4];
+        const char *gA = nullptr, *gB = nullptr;
+        int kt_dma = kt0;
+        auto seg_setup = [&](int kt) {
+            const int sg = kt >= p.seg[0].ktiles ? 1 : 0;
+            const int k = kt - (sg ? p.seg[0].ktiles : 0);
+            const uint32_t lda = (uint32_t)p.seg[sg].lda_b, ldb = (uint32_t)p.seg[sg].ldb_b;
 #pragma unroll
-        for (int s = 0; s < NST - 1; ++s)
-            if (s < nk) stage_glds(p, ktile(s), row0_m, row0_n, wave, lane, lds + s * STAGE_BYTES);
-        int cur = 0, nxt = NST - 1;                       // ring positions of tile i and of tile i+NST-1
+            for (int i = 0; i < 4; ++i) {
+                const int row = (i * 4 + wave) * 8 + (lane >> 3);
+                const uint32_t ss = (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) << 4);
+                voA[i] = (uint32_t)(row0_m + row) * lda + ss;
+                voB[i] = (uint32_t)(row0_n + row) * ldb + ss;
+            }
+            gA = p.seg[sg].A + (int64_t)k * BKB;
+            gB = p.seg[sg].Bt + (int64_t)k * BKB;
+        };
+        seg_setup(kt0);
+        auto dma_piece = [&](int i, char* slot) {        // piece i of both operands of the stage at (gA, gB)
+            const int piece = i * 4 + wave;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gA + voA[i]),
+                                             (__attribute__((address_space(3))) void*)(slot + piece * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gB + voB[i]),
+                                             (__attribute__((address_space(3))) void*)(slot + TILE_BYTES + piece * 1024), 16, 0, 0);
+        };
+        auto dma_advance = [&]() {
+            ++kt_dma;
+            if (kt_dma == p.seg[0].ktiles) seg_setup(kt_dma);
+            else { gA += BKB; gB += BKB; }
+        };
+        // Stage s lives in slot s % NST.  Rolling schedule of iteration i (fragment registers R0 = kk 0,1 and R1 = kk 2,3):
+        //   (a) 8 MFMAs on R0(i)            [NST >= 3: + second half of the DMA of stage i+NST-1]
+        //   (b) wait: stage i+1 landed, my LDS reads of tile i done; s_barrier
+        //   (c) 8 ds_read_b128 of tile i+1 -> R0
+        //   (d) 8 MFMAs on R1(i)            + DMA of stage i+NST into slot i % NST (first half when NST >= 3)
+        //   (e) 8 ds_read_b128 of tile i+1 -> R1
+        // so the fragment reads of the next tile and the LDS-DMA issue run under the MFMAs of this tile; the only exposed
+        // latency per K tile is the barrier.  Reads past the last tile fetch stale LDS and are never consumed.
+        constexpr bool SPLIT = NST >= 3;
+        const int r = lane & 31, g = lane >> 5;
+        const int swz = (r >> 1) & 7;
+        const uint32_t lbase = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)lds;
+        const uint32_t offa = (wm * 64 + r) * BKB, offb = TILE_BYTES + (wn * 64 + r) * BKB;
+        uint32_t so[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) so[kk] = (uint32_t)(((kk * 2 + g) ^ swz) << 4);
+        i32x4 fa[4][2], fb[4][2];
+#define DAE_READ_KK(KK, SLOTBASE)                                          \
+    fa[KK][0] = lds_read_b128((SLOTBASE) + offa + so[KK]);                 \
+    fa[KK][1] = lds_read_b128_off4096((SLOTBASE) + offa + so[KK]);         \
+    fb[KK][0] = lds_read_b128((SLOTBASE) + offb + so[KK]);                 \
+    fb[KK][1] = lds_read_b128_off4096((SLOTBASE) + offb + so[KK]);
+#define DAE_MMA2(KK, MT)                                                   \
+    Mma<T>::run(fa[KK][MT], fb[KK][0], acc[MT][0]);                        \
+    Mma<T>::run(fa[KK][MT], fb[KK][1], acc[MT][1]);                        \
+    __builtin_amdgcn_sched_barrier(0);
+
+        // ---- prologue: request stages 0..NST-2 (+ first half of NST-1 when SPLIT, else all of NST-1) ----
+#pragma unroll
+        for (int st = 0; st < NST; ++st) {
+            if (st < nk) {
+                char* slot = lds + st * STAGE_BYTES;
+                if (SPLIT && st == NST - 1) { dma_piece(0, slot); dma_piece(1, slot); }
+                else { dma_piece(0, slot); dma_piece(1, slot); dma_piece(2, slot); dma_piece(3, slot); dma_advance(); }
+            }
+        }
+        if (nk >= NST) { if constexpr (SPLIT) wait_vm<(NST - 2) * 8 + 4>(); else wait_vm<(NST - 1) * 8>(); }
+        else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        DAE_READ_KK(0, lbase) DAE_READ_KK(1, lbase) DAE_READ_KK(2, lbase) DAE_READ_KK(3, lbase)
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (TRACE) tprev = __builtin_amdgcn_s_memtime();
+        int cur = 0;                                      // slot of tile i
         for (int i = 0; i < nk; ++i) {
-            const int ahead = min(NST - 2, nk - 1 - i);   // younger tiles that may stay in flight
-            if (p.probe & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (probe: op counts differ)
-            else if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int nxt = cur + 1 == NST ? 0 : cur + 1;
+            // (a)
+            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            DAE_MMA2(0, 0)
+            if constexpr (SPLIT) { if (i + NST - 1 < nk) dma_piece(2, lds + (cur == 0 ? NST - 1 : cur - 1) * STAGE_BYTES); __builtin_amdgcn_sched_barrier(0); }
+            DAE_MMA2(0, 1)
+            DAE_MMA2(1, 0)
+            if constexpr (SPLIT) { if (i + NST - 1 < nk) { dma_piece(3, lds + (cur == 0 ? NST - 1 : cur - 1) * STAGE_BYTES); dma_advance(); } __builtin_amdgcn_sched_barrier(0); }
+            DAE_MMA2(1, 1)
+            DAE_STAMP(0)
+            // (b)
+            {
+                const int ahead = min(NST - 2, nk - 2 - i);
+                if (ahead >= 2) wait_vm<16>();
+                else if (ahead == 1) wait_vm<8>();
+                else wait_vm<0>();
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            DAE_STAMP(1)
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (i + NST - 1 < nk) stage_glds(p, ktile(i + NST - 1), row0_m, row0_n, wave, lane, lds + nxt * STAGE_BYTES);
-            if (!(p.probe & 1)) compute_stage<T>(lds + cur * STAGE_BYTES, wm, wn, lane, acc);
-            cur = (cur + 1 == NST) ? 0 : cur + 1;
-            nxt = (nxt + 1 == NST) ? 0 : nxt + 1;
+            DAE_STAMP(2)
+            // (c)
+            {
+                const uint32_t nb = lbase + nxt * STAGE_BYTES;
+                DAE_READ_KK(0, nb) DAE_READ_KK(1, nb)
+                __builtin_amdgcn_sched_barrier(0);
+                // (d): R1 landed at (b)
+                char* slot = lds + cur * STAGE_BYTES;
+                const bool more = i + NST < nk;
+                DAE_MMA2(2, 0)
+                if (more) dma_piece(0, slot);
+                __builtin_amdgcn_sched_barrier(0);
+                DAE_MMA2(2, 1)
+                if (more) dma_piece(1, slot);
+                __builtin_amdgcn_sched_barrier(0);
+                DAE_MMA2(3, 0)
+                if constexpr (!SPLIT) { if (more) dma_piece(2, slot); __builtin_amdgcn_sched_barrier(0); }
+                DAE_MMA2(3, 1)
+                if constexpr (!SPLIT) { if (more) { dma_piece(3, slot); dma_advance(); } __builtin_amdgcn_sched_barrier(0); }
+                // (e)
+                DAE_READ_KK(2, nb) DAE_READ_KK(3, nb)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            DAE_STAMP(3)
+            cur = nxt;
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // drain the stale tail reads before the LDS is reused
+#undef DAE_READ_KK
+#undef DAE_MMA2
+        if constexpr (TRACE) {
+            if (lane == 0) {
+                unsigned long long* o = p.trace + ((size_t)blockIdx.x * 4 + wave) * 8;
+                o[0] = tsum[0]; o[1] = tsum[1]; o[2] = tsum[2]; o[3] = tsum[3]; o[4] = (unsigned long long)nk;
+            }
+        }
+#undef DAE_STAMP
     } else {
         StageRegs regs;
         stage_load(p, kt0, row0_m, row0_n, tid, regs);
@@ -301,6 +428,184 @@ __global__ __launch_bounds__(GEMM_THREADS, wg_per_cu_for(NST)) void gemm_nt_f32o
                 int col = tn * BN + wn * 64 + nt * 32 + c;
                 Cs[(int64_t)row * ldc + col] = acc[mt][nt][r];
             }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Producer/consumer variant for grids of at most one workgroup per CU (the split-K GEMMs: encode, dh, Gram).
+// 8 waves: waves 0-3 compute (rolling fragment schedule of gemm_mainloop, no DMA instructions), waves 4-7 only feed the
+// NST-slot LDS ring with global_load_lds.  Issuing one 1-KiB LDS-DMA piece costs the issuing wave ~60 cycles
+// (gemm_trace: 8 pieces per K tile = as long as the tile's 16 MFMAs), so in the 4-wave kernel the matrix pipe idles
+// during the DMA issue; here the second wave of each SIMD pays that cost.  One s_barrier per K tile for all 8 waves:
+//   BARRIER_i : consumers have read tile i out of LDS (slot i % NST is free)  AND  producers have seen stage i+1 land.
+// ------------------------------------------------------------------------------------------------
+constexpr int PC_THREADS = 512;
+constexpr int PC_NST = 4;                            // 128 KiB of the CU's 160 KiB LDS
+
+template <typename T, int NST, int ROLE>
+__global__ __launch_bounds__(PC_THREADS, 1) void gemm_nt_pc(GemmParams p, float* __restrict__ C, int64_t ldc, int64_t slab_stride) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    int tm, tn, split, kt0, kt1;
+    if (!block_to_tile(p, tm, tn, split, kt0, kt1)) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nk = kt1 - kt0;
+    const int row0_m = tm * BM, row0_n = tn * BN;
+
+    if (wave8 >= 4) {
+        // ================= producer =================
+        if (nk <= 0) return;
+        const int wave = wave8 - 4;
+        uint32_t voA[4], voB[4];
+        const char *gA = nullptr, *gB = nullptr;
+        int kt_dma = kt0;
+        auto seg_setup = [&](int kt) {
+            const int sg = kt >= p.seg[0].ktiles ? 1 : 0;
+            const int k = kt - (sg ? p.seg[0].ktiles : 0);
+            const uint32_t lda = (uint32_t)p.seg[sg].lda_b, ldb = (uint32_t)p.seg[sg].ldb_b;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = (i * 4 + wave) * 8 + (lane >> 3);
+                const uint32_t ss = (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) << 4);
+                voA[i] = (uint32_t)(row0_m + row) * lda + ss;
+                voB[i] = (uint32_t)(row0_n + row) * ldb + ss;
+            }
+            gA = p.seg[sg].A + (int64_t)k * BKB;
+            gB = p.seg[sg].Bt + (int64_t)k * BKB;
+        };
+        seg_setup(kt0);
+        auto dma_stage = [&](char* slot) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int piece = i * 4 + wave;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gA + voA[i]),
+                                                 (__attribute__((address_space(3))) void*)(slot + piece * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gB + voB[i]),
+                                                 (__attribute__((address_space(3))) void*)(slot + TILE_BYTES + piece * 1024), 16, 0, 0);
+            }
+            ++kt_dma;
+            if (kt_dma == p.seg[0].ktiles) seg_setup(kt_dma);
+            else { gA += BKB; gB += BKB; }
+        };
+#pragma unroll
+        for (int st = 0; st < NST; ++st)
+            if (st < nk) dma_stage(lds + st * STAGE_BYTES);
+        if (nk >= NST) wait_vm<(NST - 1) * 8>(); else wait_vm<0>();      // stage 0 landed
+        __builtin_amdgcn_s_barrier();
+        int cur = 0;
+        for (int i = 0; i < nk; ++i) {
+            const int ahead = min(NST - 2, nk - 2 - i);                   // stages younger than i+1 already requested
+            if (ahead >= 2) wait_vm<16>();
+            else if (ahead == 1) wait_vm<8>();
+            else wait_vm<0>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (i + NST < nk) dma_stage(lds + cur * STAGE_BYTES);
+            cur = cur + 1 == NST ? 0 : cur + 1;
+        }
+        return;
+    }
+
+    // ================= consumer =================
+    const int wave = wave8;
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    if (nk > 0) {
+        const int r = lane & 31, g = lane >> 5;
+        const int swz = (r >> 1) & 7;
+        const uint32_t lbase = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)lds;
+        const uint32_t offa = (wm * 64 + r) * BKB, offb = TILE_BYTES + (wn * 64 + r) * BKB;
+        uint32_t so[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) so[kk] = (uint32_t)(((kk * 2 + g) ^ swz) << 4);
+        i32x4 fa[4][2], fb[4][2];
+#define DAE_READ_KK(KK, SLOTBASE)                                          \
+    fa[KK][0] = lds_read_b128((SLOTBASE) + offa + so[KK]);                 \
+    fa[KK][1] = lds_read_b128_off4096((SLOTBASE) + offa + so[KK]);         \
+    fb[KK][0] = lds_read_b128((SLOTBASE) + offb + so[KK]);                 \
+    fb[KK][1] = lds_read_b128_off4096((SLOTBASE) + offb + so[KK]);
+#define DAE_MMA4(KK)                                                       \
+    Mma<T>::run(fa[KK][0], fb[KK][0], acc[0][0]);                          \
+    Mma<T>::run(fa[KK][0], fb[KK][1], acc[0][1]);                          \
+    Mma<T>::run(fa[KK][1], fb[KK][0], acc[1][0]);                          \
+    Mma<T>::run(fa[KK][1], fb[KK][1], acc[1][1]);
+        __builtin_amdgcn_s_barrier();                                     // stage 0 landed (producers waited for it)
+        asm volatile("" ::: "memory");
+        DAE_READ_KK(0, lbase) DAE_READ_KK(1, lbase) DAE_READ_KK(2, lbase) DAE_READ_KK(3, lbase)
+        __builtin_amdgcn_sched_barrier(0);
+        int cur = 0;
+        for (int i = 0; i < nk; ++i) {
+            const int nxt = cur + 1 == NST ? 0 : cur + 1;
+            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");            // R0 (kk 0,1) of tile i
+            __builtin_amdgcn_sched_barrier(0);
+            DAE_MMA4(0) DAE_MMA4(1)
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // R1 landed; every LDS read of tile i is done
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const uint32_t nb = lbase + nxt * STAGE_BYTES;
+            DAE_READ_KK(0, nb) DAE_READ_KK(1, nb)                         // stale (never consumed) after the last tile
+            __builtin_amdgcn_sched_barrier(0);
+            DAE_MMA4(2) DAE_MMA4(3)
+            __builtin_amdgcn_sched_barrier(0);
+            DAE_READ_KK(2, nb) DAE_READ_KK(3, nb)
+            __builtin_amdgcn_sched_barrier(0);
+            cur = nxt;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#undef DAE_READ_KK
+#undef DAE_MMA4
+    }
+    const int g = lane >> 5, c = lane & 31;
+    float* Cs = C + (int64_t)split * slab_stride;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int row = tm * BM + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                int col = tn * BN + wn * 64 + nt * 32 + c;
+                Cs[(int64_t)row * ldc + col] = acc[mt][nt][r];
+            }
+}
+
+// Instrumented twin of gemm_nt_f32out (dae_gemm_trace): same code with shader-clock stamps; o[5] = K loop, o[6] = epilogue,
+// o[7] = s_memtime at kernel entry (block start skew).
+template <typename T, int NST>
+__global__ __launch_bounds__(GEMM_THREADS, wg_per_cu_for(NST)) void gemm_nt_trace(GemmParams p, float* __restrict__ C, int64_t ldc,
+                                                                                  int64_t slab_stride) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    int tm, tn, split, kt0, kt1;
+    if (!block_to_tile(p, tm, tn, split, kt0, kt1)) return;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    f32x16 acc[2][2];
+    gemm_mainloop<T, NST, true>(p, tm, tn, kt0, kt1, lds, acc);
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1, g = lane >> 5, c = lane & 31;
+    float* Cs = C + (int64_t)split * slab_stride;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int row = tm * BM + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                int col = tn * BN + wn * 64 + nt * 32 + c;
+                Cs[(int64_t)row * ldc + col] = acc[mt][nt][r];
+            }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+    if (lane == 0) {
+        unsigned long long* o = p.trace + ((size_t)blockIdx.x * 4 + wave) * 8;
+        o[5] = t1 - t0; o[6] = t2 - t1; o[7] = t0;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -640,13 +945,15 @@ static int fill_params(GemmParams& p, int dtype, int M, int N, const void* A0, i
                   "gemm: leading dimensions must be 16-byte multiples");
     DAE_CHECK_ARG(((uintptr_t)A0 % 16) == 0 && ((uintptr_t)Bt0 % 16) == 0 && ((uintptr_t)A1 % 16) == 0 && ((uintptr_t)Bt1 % 16) == 0,
                   "gemm: operands must be 16-byte aligned");
+    DAE_CHECK_ARG((uint64_t)M * (uint64_t)((lda0 > lda1 ? lda0 : lda1) * es) < (1ull << 32) &&
+                  (uint64_t)N * (uint64_t)((ldb0 > ldb1 ? ldb0 : ldb1) * es) < (1ull << 32),
+                  "gemm: an operand panel (rows x leading dimension) must stay below 4 GiB (32-bit DMA offsets)");
     p.seg[0] = {(const char*)A0, (const char*)Bt0, lda0 * es, ldb0 * es, K0 / kel};
     p.seg[1] = {(const char*)A1, (const char*)Bt1, lda1 * es, ldb1 * es, K1 / kel};
     p.ktiles_total = p.seg[0].ktiles + p.seg[1].ktiles;
     p.tiles_m = M / BM; p.tiles_n = N / BN;
     p.splits = splits < 1 ? 1 : splits;
-    static const int probe = [] { const char* v = getenv("DAE_GEMM_PROBE"); return v ? atoi(v) : 0; }();
-    p.probe = probe;
+    p.trace = nullptr;
     DAE_CHECK_ARG(p.splits <= p.ktiles_total, "gemm: splits=%d exceeds k-tiles=%d", p.splits, p.ktiles_total);
     return 0;
 }
@@ -672,6 +979,17 @@ template <typename T> static f32out_fn f32out_kernel(int nst, int role) {
         default: return gemm_nt_f32out<T, 2, ROLE_GENERIC>;
     }
 }
+template <typename T> static f32out_fn pc_kernel(int role) {
+    switch (role) {
+        case ROLE_ENCODE: return gemm_nt_pc<T, PC_NST, ROLE_ENCODE>;
+        case ROLE_DH: return gemm_nt_pc<T, PC_NST, ROLE_DH>;
+        case ROLE_DW: return gemm_nt_pc<T, PC_NST, ROLE_DW>;
+        case ROLE_GRAM: return gemm_nt_pc<T, PC_NST, ROLE_GRAM>;
+        default: return gemm_nt_pc<T, PC_NST, ROLE_GENERIC>;
+    }
+}
+static int g_cus = 0;        // compute units of the current device (set by gemm_init)
+static int g_use_pc = 1;     // DAE_NO_PC=1 keeps the 4-wave kernel for every grid (A/B)
 typedef void (*decode_fn)(GemmParams, DecodeEpi);
 template <typename T> static decode_fn decode_kernel(int loss, int act) {
 #define DAE_DK(LV, AV) if (loss == LV && act == AV) return gemm_decode_loss<T, LV, AV>;
@@ -689,6 +1007,18 @@ static int gemm_init() {
                 DAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(f32out_kernel<float>(n, role)),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes_for(n)));
             }
+        for (int role = 0; role <= ROLE_GRAM; ++role) {
+            DAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pc_kernel<bf16_t>(role)),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes_for(PC_NST)));
+            DAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pc_kernel<float>(role)),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes_for(PC_NST)));
+        }
+        {
+            int dev = 0;
+            DAE_CHECK_HIP(hipGetDevice(&dev));
+            DAE_CHECK_HIP(hipDeviceGetAttribute(&g_cus, hipDeviceAttributeMultiprocessorCount, dev));
+            g_use_pc = getenv("DAE_NO_PC") == nullptr;
+        }
         for (int l = 0; l < 3; ++l)
             for (int a = 0; a < 3; ++a) {
                 DAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decode_kernel<bf16_t>(l, a)),
@@ -710,6 +1040,12 @@ int launch_gemm_f32out(int dtype, int M, int N, const void* A0, int64_t lda0, co
     if (int rc = gemm_init()) return rc;
     dim3 grid(grid_blocks(p)), block(GEMM_THREADS);
     const int nst = g_nst;
+    if (nst == DEFAULT_NST && (int)grid.x <= g_cus && g_use_pc) {      // at most one workgroup per CU: producer/consumer waves
+        f32out_fn kp = dtype == DAE_BF16 ? pc_kernel<bf16_t>(role) : pc_kernel<float>(role);
+        hipLaunchKernelGGL(kp, grid, dim3(PC_THREADS), lds_bytes_for(PC_NST), st, p, C, ldc, slab_stride);
+        DAE_CHECK_LAUNCH();
+        return 0;
+    }
     f32out_fn k = dtype == DAE_BF16 ? f32out_kernel<bf16_t>(nst, role) : f32out_kernel<float>(nst, role);
     hipLaunchKernelGGL(k, grid, block, lds_bytes_for(nst == 0 || nst == 3 || nst == 4 ? nst : 2), st, p, C, ldc, slab_stride);
     DAE_CHECK_LAUNCH();
@@ -752,10 +1088,8 @@ struct EncBitsParams {
     const char* Bt; int64_t ldb_b;                    // W^T_lo [Hp x Fp] bf16, leading dimension in bytes
     const uint32_t* bits; int64_t ldw;                // x~ bits [Bp x ldw words], bit b of word w = feature 32*w + b
     int ktiles_total, tiles_m, tiles_n, splits;
-    int probe;                                        // DAE_EB_PROBE bit mask (timing experiments only; results are garbage when set)
 };
 
-template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // NST-deep LDS-DMA ring: the encode grid is <= 1 workgroup per CU (28 tiles x 8 K slices), so the only way to hide the
 // ~1 us global->LDS latency is depth, not occupancy; LDS is otherwise idle (160 KB per CU).
@@ -788,8 +1122,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 1) void gemm_encode_bits(EncBitsParam
             const int row = piece * 8 + (lane >> 3);
             const int sslot = (lane & 7) ^ ((row >> 1) & 7);
             const char* gb = p.Bt + (int64_t)(tn * BN + row) * p.ldb_b + (int64_t)kt * BKB + sslot * 16;
-            if (p.probe & 1) gb = p.Bt + ((int64_t)tn * p.ktiles_total + kt) * TILE_BYTES + piece * 1024 + lane * 16;
-            if (!(p.probe & 8))
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gb,
                                              (__attribute__((address_space(3))) void*)(st + piece * 1024), 16, 0, 0);
         }
@@ -819,7 +1151,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 1) void gemm_encode_bits(EncBitsParam
             stage(kt0 + i + NST - 1, ring + ns * EB_STAGE_BYTES);
         }
         // ---- expand this wave's bits into its 32 private A rows (bf16 1.0 = 0x3F80) ----
-        if (!(p.probe & 4)) {
+        {
             const uint32_t word = *reinterpret_cast<const uint32_t*>(cur + TILE_BYTES + wave * 256 + lane * 4);
             const int r = wave * 32 + (lane >> 1), half = lane & 1;
             const int swz = (r >> 1) & 7;
@@ -837,7 +1169,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 1) void gemm_encode_bits(EncBitsParam
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // own ds_writes landed; rows are private to this wave
         __builtin_amdgcn_sched_barrier(0);
         // ---- fragments + MFMAs: A rows [32*wave, +32), all 128 B rows ----
-        if (!(p.probe & 2)) {
+        {
             const int swz2 = (rr >> 1) & 7;
             const uint32_t pa = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)abuf + (wave * 32 + rr) * BKB;
             const uint32_t pb = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)cur + rr * BKB;
@@ -869,7 +1201,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 1) void gemm_encode_bits(EncBitsParam
     }
     float* Cs = C + (int64_t)split * slab_stride;
     const int c = lane & 31;
-    if (p.probe & 16) return;
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
@@ -903,11 +1234,23 @@ int launch_encode_bits(int Bp, int Hp, int Fp, const uint32_t* bits, int64_t ldw
     p.ktiles_total = Fp / 64; p.tiles_m = Bp / BM; p.tiles_n = Hp / BN; p.splits = splits < 1 ? 1 : splits;
     DAE_CHECK_ARG(p.splits <= p.ktiles_total, "encode_bits: too many splits");
     static const int nst = [] { const char* v = getenv("DAE_EB_NST"); return v ? atoi(v) : 4; }();
-    static const int probe = [] { const char* v = getenv("DAE_EB_PROBE"); return v ? atoi(v) : 0; }();
-    p.probe = probe;
     if (nst >= 8) return launch_eb<8>(p, C, ldc, slab_stride, st);
     if (nst >= 4) return launch_eb<4>(p, C, ldc, slab_stride, st);
     return launch_eb<2>(p, C, ldc, slab_stride, st);
+}
+
+int launch_gemm_trace(int dtype, int M, int N, const void* A0, int64_t lda0, const void* Bt0, int64_t ldb0, int K0, const void* A1,
+                      int64_t lda1, const void* Bt1, int64_t ldb1, int K1, float* C, int64_t ldc, int splits, int64_t slab_stride,
+                      int nst, unsigned long long* trace, hipStream_t st) {
+    GemmParams p;
+    if (int rc = fill_params(p, dtype, M, N, A0, lda0, Bt0, ldb0, K0, A1, lda1, Bt1, ldb1, K1, splits)) return rc;
+    DAE_CHECK_ARG(trace && dtype == DAE_BF16 && (nst == 2 || nst == 3), "gemm_trace: bf16, nst 2 or 3, trace buffer required");
+    p.trace = trace;
+    f32out_fn k = nst == 3 ? gemm_nt_trace<bf16_t, 3> : gemm_nt_trace<bf16_t, 2>;
+    DAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes_for(nst)));
+    hipLaunchKernelGGL(k, dim3(grid_blocks(p)), dim3(GEMM_THREADS), lds_bytes_for(nst), st, p, C, ldc, slab_stride);
+    DAE_CHECK_LAUNCH();
+    return 0;
 }
 
 void set_use_glds(int nst) { g_nst = nst; }

@@ -30,6 +30,9 @@ enum { GEMM_ROLE_GENERIC = 0, GEMM_ROLE_ENCODE = 1, GEMM_ROLE_DH = 2, GEMM_ROLE_
 int launch_decode_loss(int dtype, int Bp, int Fp, int Hp, const void* h_lo, int64_t ldh, const void* W_lo, int64_t ldw,
                        const DecodeEpi& e, hipStream_t st);
 void set_use_glds(int nst);
+int launch_gemm_trace(int dtype, int M, int N, const void* A0, int64_t lda0, const void* Bt0, int64_t ldb0, int K0, const void* A1,
+                      int64_t lda1, const void* Bt1, int64_t ldb1, int K1, float* C, int64_t ldc, int splits, int64_t slab_stride,
+                      int nst, unsigned long long* trace, hipStream_t st);
 int launch_encode_bits(int Bp, int Hp, int Fp, const uint32_t* bits, int64_t ldw, const void* Wt_lo, int64_t ldb, float* C,
                        int64_t ldc, int splits, int64_t slab_stride, hipStream_t st);
 

@@ -111,6 +111,14 @@ int dae_gemm_nt(int32_t dtype, int32_t M, int32_t N,
                 const void* A1, int64_t lda1, const void* Bt1, int64_t ldb1, int32_t K1,
                 float* C, int64_t ldc, int32_t splits, int64_t slab_stride, void* stream);
 
+/* Diagnostic twin of dae_gemm_nt (bf16, LDS-DMA ring depth nst = 2 or 3): same arithmetic, and every wave also writes
+ * shader-clock sums of its K-loop phases to trace[(block*4 + wave)*8 + k]:
+ *   k=0 first MFMA half (+DMA issue)  1 waits (vmcnt/lgkmcnt)  2 barrier  3 reads + second MFMA half + DMA issue  4 K iterations
+ *   5 whole K loop  6 epilogue stores  7 s_memtime at entry.    Used by tools/gemm_trace.py; not on the training path. */
+int dae_gemm_trace(int32_t dtype, int32_t M, int32_t N, const void* A0, int64_t lda0, const void* Bt0, int64_t ldb0,
+                   int32_t K0, const void* A1, int64_t lda1, const void* Bt1, int64_t ldb1, int32_t K1, float* C,
+                   int64_t ldc, int32_t splits, int64_t slab_stride, int32_t nst, uint64_t* trace, void* stream);
+
 /* K2: encode epilogue  h = act(sum_s slab_s + bh) - act(bh)   (autoencoder.py:389)
  * writes h fp32 [Bp x ldh], h in `dtype` [Bp x ldh] and h^T in `dtype` [Hp x ldht]; rows >= B
  * and columns >= H are written as zero.  Any output pointer may be NULL.
