@@ -106,7 +106,7 @@ class Runner:
             dp.allreduce_sum_(self.eng.grad)
             self.eng.apply(grad_scale=1.0 / self.world)
         else:
-            self.eng.train_step(rows, labs, self.stats[b], phase=0, **self.plan)
+            self.eng.train_step(rows, labs, self.stats[b], phase=3, **self.plan)
         self.step_i += 1
 
 

@@ -280,7 +280,7 @@ class DenoisingAutoencoder(object):
                 dp.allreduce_sum_(eng.grad)
                 eng.apply(grad_scale=1.0 / world)
             else:
-                eng.train_step(rows, labs, stats[b], phase=0, **plan)
+                eng.train_step(rows, labs, stats[b], phase=3, **plan)
 
     # ------------------------------------------------------------------ reporting (reference :272-320)
     def epoch_stats(self, epoch):

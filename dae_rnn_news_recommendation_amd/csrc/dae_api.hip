@@ -107,7 +107,8 @@ struct dae_plan {
     float *slabs, *h_f32, *D_slabs, *G, *rowloss_part, *dbv_part, *colsum_part, *cos_part, *cos_stats, *cw, *loss_part,
         *dw_f32, *tri_scalars, *dh_extra, *rowsq_scratch, *tile_part;
     uint32_t *cnt_part, *role_cnt, *xc_bits;
-    bool bits_ok;                    // binary CSR + bf16: x~ handed to the encode GEMM as a bit image (DAE_NO_BITS=1 disables)
+    bool fuse_opt_ok;                // DAE_NO_FUSED_OPT=1 keeps the separate optimizer kernel (A/B)
+    bool bits_ok;                    // binary CSR + bf16: x~ handed to the encode GEMM as a bit image (opt-in: DAE_BITS=1)
     int32_t *dw_i32, *n_same;
     int64_t *nvalid, *dw_i64;
     uint64_t* acc;
@@ -197,7 +198,8 @@ extern "C" int dae_plan_create(const dae_config* cfg, dae_plan** out) {
     p->gram_split = (cfg->dtype == DAE_BF16) && (cfg->triplet == DAE_TRIPLET_BATCH_ALL || cfg->triplet == DAE_TRIPLET_BATCH_HARD) &&
                     getenv("DAE_GRAM_FP32") == nullptr;
     p->ws_bytes = carve(p, nullptr);
-    p->bits_ok = cfg->dtype == DAE_BF16 && getenv("DAE_NO_BITS") == nullptr;
+    p->fuse_opt_ok = getenv("DAE_NO_FUSED_OPT") == nullptr;
+    p->bits_ok = cfg->dtype == DAE_BF16 && getenv("DAE_BITS") != nullptr;
     p->overlap_ok = getenv("DAE_OVERLAP") != nullptr;   // measured: running the miner chain beside decode is SLOWER (0.410 vs 0.351 ms/step)
     *out = p;
     return 0;
@@ -445,15 +447,26 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     PROF(PS_DH_FIN, dae_dh_finish(p->slabs, p->s_dh, slab, Hp, explicit3 ? p->dh_extra : nullptr, p->h_f32, Hp, p->b.bh, B, H, c.enc_act, dt,
                      p->delta1_t, ldB, p->colsum_part, nullptr, stream));
     // 11. dW = x~^T delta1 + delta2^T h                                      (K8, tied weights)
-    PROF(PS_DW_GEMM, launch_gemm_f32out(dt, Fp, Hp, p->xct, ldB, p->delta1_t, ldB, Bp, p->delta2_t, ldB, p->h_t, ldB, Bp, p->b.grad, Hp, 1, 0, st, GEMM_ROLE_DW));
+    // phase 0 / 3 in bf16 mode: the optimizer runs in the dW GEMM's epilogue (phase 3 does not materialise the W gradient)
+    const bool apply_now = (s->phase == 0 || s->phase == 3);
+    const bool fuse_opt = apply_now && dt == DAE_BF16 && p->fuse_opt_ok;
+    if (fuse_opt) {
+        OptEpi oe;
+        oe.W = p->b.W; oe.grad = s->phase == 3 ? nullptr : p->b.grad; oe.s1 = p->b.opt_s1; oe.s2 = p->b.opt_s2;
+        oe.W_lo = p->b.W_lo; oe.Wt_lo = p->b.Wt_lo; oe.ldw = Hp; oe.ldwt = Fp; oe.opt = c.opt; oe.lr = plan_lr(p, s->adam_t);
+        oe.mom = c.momentum; oe.gscale = s->grad_scale;
+        PROF(PS_DW_GEMM, launch_dw_opt(Fp, Hp, p->xct, ldB, p->delta1_t, ldB, Bp, p->delta2_t, ldB, p->h_t, ldB, Bp, oe, st));
+    } else {
+        PROF(PS_DW_GEMM, launch_gemm_f32out(dt, Fp, Hp, p->xct, ldB, p->delta1_t, ldB, Bp, p->delta2_t, ldB, p->h_t, ldB, Bp, p->b.grad, Hp, 1, 0, st, GEMM_ROLE_DW));
+    }
     // 12. bias gradients
     float* g_bh = p->b.grad + (int64_t)Fp * Hp;
     const int64_t boff = (int64_t)Fp * Hp;
-    const bool fuse_bias = (s->phase == 0);          // single-GPU step: the bias update rides on the bias-gradient kernel
+    const bool fuse_bias = apply_now;               // single-GPU step: the bias update rides on the bias-gradient kernel
     PROF(PS_BIAS, dae_bias_grads(p->dbv_part, 2 * Bp / 128, p->colsum_part, Bp / 32, p->b.bh, H, Hp, F, Fp, c.enc_act, g_bh, g_bh + Hp,
                                  fuse_bias ? 1 : 0, c.opt, plan_lr(p, s->adam_t), c.momentum, s->grad_scale, p->b.bv,
                                  p->b.opt_s1 ? p->b.opt_s1 + boff : nullptr, p->b.opt_s2 ? p->b.opt_s2 + boff : nullptr, stream));
-    if (s->phase == 1) return 0;
+    if (s->phase == 1 || fuse_opt) return 0;
     // 13. optimizer (K9): W (+ shadows); biases were updated above
     PROF(PS_OPT, dae_opt_step(c.opt, plan_lr(p, s->adam_t), c.momentum, s->grad_scale, p->b.W, p->b.bh, p->b.bv, p->b.grad, p->b.opt_s1,
                               p->b.opt_s2, Fp, Hp, dt, p->b.W_lo, p->b.Wt_lo, /*apply=*/2, stream));

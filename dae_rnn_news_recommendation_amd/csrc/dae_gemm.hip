@@ -431,6 +431,114 @@ __global__ __launch_bounds__(GEMM_THREADS, wg_per_cu_for(NST)) void gemm_nt_f32o
 }
 
 // ------------------------------------------------------------------------------------------------
+// dW GEMM with the optimizer fused into its epilogue (single-GPU step, bf16 mode):
+//   g = x~^T delta1 + delta2^T h  (autoencoder.py:444-477: opt.minimize(cost) -> the W gradient and its apply op)
+// the 128x128 gradient tile never leaves the registers: W (fp32 master), the optimizer slots and both bf16 shadow
+// layouts (W_lo [F x H] for decode, Wt_lo [H x F] for encode / dh) are updated in place -- saves the 20 MB gradient
+// round trip through HBM and one kernel.  The shadows leave the CU as coalesced 16-byte rows staged through LDS
+// (same staging as the decode epilogue).  `grad` is still written when the caller wants to read it (NULL skips it).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float opt_apply_elem(int opt, float lr, float mom, float p, float g, float* __restrict__ s1,
+                                                float* __restrict__ s2, int64_t k) {
+    switch (opt) {
+        case DAE_OPT_SGD: return p - lr * g;
+        case DAE_OPT_ADAGRAD: { const float a = s1[k] + g * g; s1[k] = a; return p - lr * g * rsqrtf(a); }
+        case DAE_OPT_MOMENTUM: { const float a = mom * s1[k] + g; s1[k] = a; return p - lr * a; }
+        default: {   // Adam; lr already holds lr_t
+            const float m = 0.9f * s1[k] + 0.1f * g;
+            const float v = 0.999f * s2[k] + 0.001f * g * g;
+            s1[k] = m; s2[k] = v;
+            return p - lr * m / (sqrtf(v) + 1e-8f);
+        }
+    }
+}
+
+constexpr int DWO_PITCH = 272;                        // staged bf16 row: 128 elements + 16 B pad
+constexpr int DWO_TILE_BYTES = 128 * DWO_PITCH;
+
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_dw_opt(GemmParams p, OptEpi e) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    int tm, tn, split, kt0, kt1;
+    if (!block_to_tile(p, tm, tn, split, kt0, kt1)) return;
+    f32x16 acc[2][2];
+    gemm_mainloop<bf16_t, 2>(p, tm, tn, kt0, kt1, lds, acc);
+    __syncthreads();                                   // the K-loop stages are dead: reuse the LDS for the shadow tiles
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, g = lane >> 5, c = lane & 31;
+    char* R0 = lds;                                    // W_lo tile   [f_local][h_local]
+    char* R1 = lds + DWO_TILE_BYTES;                   // Wt_lo tile  [h_local][f_local]
+    const int lrow0 = wm * 64 + 4 * g, lcol0 = wn * 64 + c;
+    float* __restrict__ Wp = e.W;
+    float* __restrict__ gradp = e.grad;
+    float* __restrict__ s1p = e.s1;
+    float* __restrict__ s2p = e.s2;
+    const int opt = e.opt;
+    const float lr = e.lr, mom = e.mom, gscale = e.gscale;
+    // one (mt) half at a time: all 32 master-weight (and slot) loads of the half are in flight together -- the update is
+    // a load -> FMA -> store chain per element and would otherwise pay one HBM latency 64 times per thread
+    auto half = [&](auto MT) {
+        constexpr int mt = decltype(MT)::value;
+        float wv[2][16], a1[2][16], a2[2][16];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lrow = lrow0 + mt * 32 + (r & 3) + 8 * (r >> 2), lcol = lcol0 + nt * 32;
+                const int64_t k = (int64_t)(tm * BM + lrow) * e.ldw + tn * BN + lcol;
+                wv[nt][r] = Wp[k];
+                a1[nt][r] = (opt != DAE_OPT_SGD) ? s1p[k] : 0.f;
+                a2[nt][r] = (opt == DAE_OPT_ADAM) ? s2p[k] : 0.f;
+            }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                float pv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = r4 * 4 + q;
+                    const int lrow = lrow0 + mt * 32 + 8 * r4 + q, lcol = lcol0 + nt * 32;
+                    const int64_t k = (int64_t)(tm * BM + lrow) * e.ldw + tn * BN + lcol;
+                    const float gr = acc[mt][nt][r];
+                    if (gradp) gradp[k] = gr;
+                    const float g = gr * gscale, p0 = wv[nt][r];
+                    float pn;
+                    if (opt == DAE_OPT_SGD) pn = p0 - lr * g;
+                    else if (opt == DAE_OPT_ADAGRAD) { const float a = a1[nt][r] + g * g; s1p[k] = a; pn = p0 - lr * g * rsqrtf(a); }
+                    else if (opt == DAE_OPT_MOMENTUM) { const float a = mom * a1[nt][r] + g; s1p[k] = a; pn = p0 - lr * a; }
+                    else {
+                        const float m = 0.9f * a1[nt][r] + 0.1f * g;
+                        const float v = 0.999f * a2[nt][r] + 0.001f * g * g;
+                        s1p[k] = m; s2p[k] = v;
+                        pn = p0 - lr * m / (sqrtf(v) + 1e-8f);
+                    }
+                    Wp[k] = pn;
+                    pv[q] = pn;
+                    *reinterpret_cast<bf16_t*>(R0 + lrow * DWO_PITCH + lcol * 2) = f2bf_hw(pn);
+                }
+                uint2 v;
+                v.x = f2bf_pack_hw(pv[0], pv[1]);
+                v.y = f2bf_pack_hw(pv[2], pv[3]);
+                *reinterpret_cast<uint2*>(R1 + (lcol0 + nt * 32) * DWO_PITCH + (lrow0 + mt * 32 + 8 * r4) * 2) = v;
+            }
+    };
+    half(std::integral_constant<int, 0>{});
+    half(std::integral_constant<int, 1>{});
+    __syncthreads();
+    bf16_t* Wlo = reinterpret_cast<bf16_t*>(e.W_lo);
+    bf16_t* Wtlo = reinterpret_cast<bf16_t*>(e.Wt_lo);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int ch = tid + GEMM_THREADS * i;
+        const int row = ch >> 4, c16 = ch & 15;
+        *reinterpret_cast<i32x4*>(Wlo + (int64_t)(tm * BM + row) * e.ldw + tn * BN + c16 * 8) =
+            *reinterpret_cast<const i32x4*>(R0 + row * DWO_PITCH + c16 * 16);
+        *reinterpret_cast<i32x4*>(Wtlo + (int64_t)(tn * BN + row) * e.ldwt + tm * BM + c16 * 8) =
+            *reinterpret_cast<const i32x4*>(R1 + row * DWO_PITCH + c16 * 16);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Producer/consumer variant for grids of at most one workgroup per CU (the split-K GEMMs: encode, dh, Gram).
 // 8 waves: waves 0-3 compute (rolling fragment schedule of gemm_mainloop, no DMA instructions), waves 4-7 only feed the
 // NST-slot LDS ring with global_load_lds.  Issuing one 1-KiB LDS-DMA piece costs the issuing wave ~60 cycles
@@ -1048,6 +1156,25 @@ int launch_gemm_f32out(int dtype, int M, int N, const void* A0, int64_t lda0, co
     }
     f32out_fn k = dtype == DAE_BF16 ? f32out_kernel<bf16_t>(nst, role) : f32out_kernel<float>(nst, role);
     hipLaunchKernelGGL(k, grid, block, lds_bytes_for(nst == 0 || nst == 3 || nst == 4 ? nst : 2), st, p, C, ldc, slab_stride);
+    DAE_CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_dw_opt(int M, int N, const void* A0, int64_t lda0, const void* Bt0, int64_t ldb0, int K0, const void* A1, int64_t lda1,
+                  const void* Bt1, int64_t ldb1, int K1, const OptEpi& e, hipStream_t st) {
+    GemmParams p;
+    if (int rc = fill_params(p, DAE_BF16, M, N, A0, lda0, Bt0, ldb0, K0, A1, lda1, Bt1, ldb1, K1, 1)) return rc;
+    if (int rc = gemm_init()) return rc;
+    DAE_CHECK_ARG(e.W && e.W_lo && e.Wt_lo && e.ldw >= N && e.ldwt >= M && e.ldw % 8 == 0 && e.ldwt % 8 == 0, "dw_opt: bad parameter images");
+    DAE_CHECK_ARG(e.opt >= DAE_OPT_SGD && e.opt <= DAE_OPT_ADAM && (e.opt == DAE_OPT_SGD || e.s1) && (e.opt != DAE_OPT_ADAM || e.s2),
+                  "dw_opt: optimizer slots missing");
+    static int attr_rc = [] {
+        return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dw_opt), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        2 * DWO_TILE_BYTES > lds_bytes_for(2) ? 2 * DWO_TILE_BYTES : lds_bytes_for(2));
+    }();
+    DAE_CHECK_ARG(attr_rc == 0, "dw_opt: hipFuncSetAttribute failed");
+    const int ldsb = 2 * DWO_TILE_BYTES > lds_bytes_for(2) ? 2 * DWO_TILE_BYTES : lds_bytes_for(2);
+    hipLaunchKernelGGL(gemm_dw_opt, dim3(grid_blocks(p)), dim3(GEMM_THREADS), ldsb, st, p, e);
     DAE_CHECK_LAUNCH();
     return 0;
 }

@@ -29,6 +29,18 @@ int launch_gemm_f32out(int dtype, int M, int N, const void* A0, int64_t lda0, co
 enum { GEMM_ROLE_GENERIC = 0, GEMM_ROLE_ENCODE = 1, GEMM_ROLE_DH = 2, GEMM_ROLE_DW = 3, GEMM_ROLE_GRAM = 4 };
 int launch_decode_loss(int dtype, int Bp, int Fp, int Hp, const void* h_lo, int64_t ldh, const void* W_lo, int64_t ldw,
                        const DecodeEpi& e, hipStream_t st);
+// epilogue of the fused dW + optimizer GEMM (gemm_dw_opt): parameters updated in place from the gradient tile
+struct OptEpi {
+    float* W;                 // [Fp x ldw] fp32 master weights
+    float* grad;              // [Fp x ldw] gradient image, or NULL when nobody reads it
+    float *s1, *s2;           // optimizer slots (same layout as W), NULL when unused by `opt`
+    void *W_lo, *Wt_lo;       // bf16 shadows [Fp x ldw] and [Hp x ldwt]
+    int64_t ldw, ldwt;
+    int opt;
+    float lr, mom, gscale;
+};
+int launch_dw_opt(int M, int N, const void* A0, int64_t lda0, const void* Bt0, int64_t ldb0, int K0, const void* A1, int64_t lda1,
+                  const void* Bt1, int64_t ldb1, int K1, const OptEpi& e, hipStream_t st);
 void set_use_glds(int nst);
 int launch_gemm_trace(int dtype, int M, int N, const void* A0, int64_t lda0, const void* Bt0, int64_t ldb0, int K0, const void* A1,
                       int64_t lda1, const void* Bt1, int64_t ldb1, int K1, float* C, int64_t ldc, int splits, int64_t slab_stride,

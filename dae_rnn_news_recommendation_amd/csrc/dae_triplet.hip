@@ -11,6 +11,8 @@
 //   reductions; reproduces the reference's quirks literally (invalid negatives contribute 0, invalid
 //   positives are shifted by the row max, float-equality data_weight, gradient ties split equally,
 //   gradient through the row-max shift).
+#include <stdlib.h>
+
 #include "dae_common.h"
 
 namespace dae {
@@ -152,12 +154,78 @@ __device__ __forceinline__ void sweep_pairs(const float* __restrict__ pu, const 
     }
 }
 
-template <bool POS_ONLY>
-__global__ __launch_bounds__(TRIP_THREADS, 3) void batch_all_kernel(const float* __restrict__ D_slabs, int d_splits,
+// Pair-packed sweep (row range <= 40, all triplets counted): lane registers hold the negatives as float2 pairs so the
+// element-wise work runs on packed-fp32 VALU ops (v_pk_mul/add_f32: two pairs per instruction), and the two
+// transcendentals are SHARED by the two pairs of a register: with w = 1 + exp(t),
+//     log w_a + log w_b = log(w_a w_b),      1/w_a = w_b / (w_a w_b),      1/w_b = w_a / (w_a w_b)
+// -- one v_log_f32 and one v_rcp_f32 (quarter-rate instructions) per TWO triplets instead of two each.  Only sums of
+// log terms are ever needed (the loss is a sum), and range <= 40 bounds w_a w_b by e^80 < FLT_MAX.  log1p accuracy for
+// small exp(t) comes from the first-order correction  log1p(e) = log(fl(1+e)) + (e - (fl(1+e) - 1)) / fl(1+e)
+// instead of a per-pair select.  ~12 issue slots per triplet against ~27 for sweep_pairs (2 x 4 of them transcendental).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int Q2, bool FIRST>
+__device__ __forceinline__ void sweep_pairs2(const float* __restrict__ pu, const float* __restrict__ pf, float mid,
+                                             const float* __restrict__ nv, int nP, int nN, int k0, int wave, int lane,
+                                             float* __restrict__ gpos, float* __restrict__ gneg_w, float& loss_log2,
+                                             float& loss_corr, unsigned& cnt_wave) {
+    f32x2 v2[Q2], ev2[Q2], gs2[Q2];
+#pragma unroll
+    for (int q = 0; q < Q2; ++q) {
+        const int k = k0 + (2 * q) * 64 + lane;
+        v2[q].x = (k < nN) ? nv[k] : -INFINITY;
+        v2[q].y = (k + 64 < nN) ? nv[k + 64] : -INFINITY;
+        ev2[q].x = __builtin_amdgcn_exp2f((v2[q].x - mid) * kLog2e);          // exp(-inf) = 0 for padding lanes
+        ev2[q].y = __builtin_amdgcn_exp2f((v2[q].y - mid) * kLog2e);
+        gs2[q] = f32x2{0.f, 0.f};
+    }
+    f32x2 corr2 = {0.f, 0.f};
+    for (int p = wave; p < nP; p += 8) {
+        const bool has2 = (p + 4) < nP;
+        float u[2], fp[2], sgp[2];
+        u[0] = pu[p]; u[1] = has2 ? pu[p + 4] : INFINITY;               // u = +inf -> t = -inf, F_p = 0 -> contributes nothing
+        fp[0] = pf[p]; fp[1] = has2 ? pf[p + 4] : 0.f;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f32x2 sgp2 = {0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < Q2; ++q) {
+                const f32x2 t2 = v2[q] - u[h];                           // triplet_distance[a,p,n]  (:106)
+                const f32x2 e2 = ev2[q] * fp[h];                         // exp(t)
+                const f32x2 w2 = e2 + 1.0f;
+                const float P = w2.x * w2.y;
+                const float R = __builtin_amdgcn_rcpf(P);
+                loss_log2 += __builtin_amdgcn_logf(P);                   // log2(w_a) + log2(w_b)
+                const f32x2 r2 = f32x2{w2.y, w2.x} * R;                  // 1/w_a, 1/w_b
+                corr2 += (e2 - (w2 - 1.0f)) * r2;                        // log1p correction (natural units)
+                const f32x2 sg2 = e2 * r2;                               // sigmoid(t) = SoftplusGrad
+                gs2[q] += sg2;
+                sgp2 += sg2;
+                cnt_wave += (unsigned)__popcll(__ballot(t2.x > 1e-16f)) + (unsigned)__popcll(__ballot(t2.y > 1e-16f));   // (:114)
+            }
+            sgp[h] = sgp2.x + sgp2.y;
+        }
+        sgp[0] = wave64_sum_hi(sgp[0]);
+        sgp[1] = wave64_sum_hi(sgp[1]);
+        if (lane == 63) {
+            if (FIRST) { gpos[p] = sgp[0]; if (has2) gpos[p + 4] = sgp[1]; }
+            else { gpos[p] += sgp[0]; if (has2) gpos[p + 4] += sgp[1]; }
+        }
+    }
+    loss_corr += corr2.x + corr2.y;
+#pragma unroll
+    for (int q = 0; q < Q2; ++q) {
+        const int k = k0 + (2 * q) * 64 + lane;
+        if (k < nN) gneg_w[k] = gs2[q].x;
+        if (k + 64 < nN) gneg_w[k + 64] = gs2[q].y;
+    }
+}
+
+template <bool POS_ONLY, int OCC>
+__global__ __launch_bounds__(TRIP_THREADS, OCC) void batch_all_kernel(const float* __restrict__ D_slabs, int d_splits,
                                                                  int64_t slab_stride, int64_t ldd,
                                                                  const int32_t* __restrict__ labels, int B, int Bp,
                                                                  float* __restrict__ loss_part, uint32_t* __restrict__ npos_part,
-                                                                 float* __restrict__ G, uint32_t* __restrict__ role_cnt) {
+                                                                 float* __restrict__ G, uint32_t* __restrict__ role_cnt, int probe) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // positives are compacted from the front of val[]/idx[], negatives from the back (nP + nN <= B)
     float* val = reinterpret_cast<float*>(smem);             // [Bp]
@@ -184,11 +252,72 @@ __global__ __launch_bounds__(TRIP_THREADS, 3) void batch_all_kernel(const float*
         if (POS_ONLY) { Rrow[j] = 0u; cpos[j] = 0u; }
     }
 
+    if (probe & 4) return;
     // ---- deterministic compaction in index order (ballot ranks; coalesced label / D-row reads) ----
     // element j = k*256 + tid; its slot = (#positives before it in index order) = prefix over (k, wave) + rank in wave
     const int K = (B + TRIP_THREADS - 1) / TRIP_THREADS;           // <= 16 for B <= 4096
     int* cntP = scan;                                              // [K][4]
     int* cntN = scan + 64;                                         // [K][4]
+    int nP = 0, nN = 0;
+    float* pu = val;                      // positives: val[0 .. nP)
+    float *nv;                            // negatives: val[Bp-nN .. Bp)
+    int *pidx = idx, *nidx;
+    constexpr int KU = 4;
+    if (K <= KU) {
+        // usual mini-batch (B <= 1024): every global load of the prologue is issued up front -- labels and the D row
+        // (d_splits slabs) of all K strips -- so the block pays ONE memory latency instead of 2K dependent ones
+        int32_t lj[KU];
+        float dj[KU];
+#pragma unroll
+        for (int k = 0; k < KU; ++k) {
+            const int j = k * TRIP_THREADS + tid;
+            lj[k] = (j < B) ? labels[j] : la;
+            dj[k] = 0.f;
+        }
+        for (int sl = 0; sl < d_splits; ++sl) {
+            const float* Drow = D_slabs + (int64_t)sl * slab_stride + (int64_t)a * ldd;
+#pragma unroll
+            for (int k = 0; k < KU; ++k) {
+                const int j = k * TRIP_THREADS + tid;
+                if (j < B) dj[k] += Drow[j];
+            }
+        }
+        unsigned long long bp[KU], bn[KU];
+#pragma unroll
+        for (int k = 0; k < KU; ++k) {
+            const int j = k * TRIP_THREADS + tid;
+            const bool isP = (j < B) && (lj[k] == la) && (j != a);
+            const bool isN = (j < B) && (lj[k] != la);
+            bp[k] = __ballot(isP); bn[k] = __ballot(isN);
+            if (lane == 0) { cntP[k * 4 + wave] = __popcll(bp[k]); cntN[k * 4 + wave] = __popcll(bn[k]); }
+        }
+        __syncthreads();
+        int beforeP[KU], beforeN[KU];
+        {
+            int offP = 0, offN = 0;
+#pragma unroll
+            for (int k = 0; k < KU; ++k) {
+                beforeP[k] = offP; beforeN[k] = offN;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const int cp = cntP[k * 4 + w], cn = cntN[k * 4 + w];
+                    if (w < wave) { beforeP[k] += cp; beforeN[k] += cn; }
+                    offP += cp; offN += cn;
+                }
+            }
+            nP = offP; nN = offN;
+        }
+        nv = val + (Bp - nN);
+        nidx = idx + (Bp - nN);
+        const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+        for (int k = 0; k < KU; ++k) {
+            const int j = k * TRIP_THREADS + tid;
+            const bool isP = (bp[k] >> lane) & 1ull, isN = (bn[k] >> lane) & 1ull;
+            if (isP) { const int o = beforeP[k] + __popcll(bp[k] & lt); pu[o] = dj[k]; pidx[o] = j; }
+            if (isN) { const int o = beforeN[k] + __popcll(bn[k] & lt); nv[o] = dj[k]; nidx[o] = j; }
+        }
+    } else {
     for (int k = 0; k < K; ++k) {
         const int j = k * TRIP_THREADS + tid;
         const int32_t lj = (j < B) ? labels[j] : la;
@@ -198,12 +327,9 @@ __global__ __launch_bounds__(TRIP_THREADS, 3) void batch_all_kernel(const float*
         if (lane == 0) { cntP[k * 4 + wave] = __popcll(bp); cntN[k * 4 + wave] = __popcll(bn); }
     }
     __syncthreads();
-    int nP = 0, nN = 0;
     for (int e = 0; e < K * 4; ++e) { nP += cntP[e]; nN += cntN[e]; }
-    float* pu = val;                      // positives: val[0 .. nP)
-    float* nv = val + (Bp - nN);          // negatives: val[Bp-nN .. Bp)
-    int* pidx = idx;
-    int* nidx = idx + (Bp - nN);
+    nv = val + (Bp - nN);
+    nidx = idx + (Bp - nN);
     {
         int offP = 0, offN = 0;           // running prefix over (k', wave') < (k, wave)
         for (int k = 0; k < K; ++k) {
@@ -225,7 +351,9 @@ __global__ __launch_bounds__(TRIP_THREADS, 3) void batch_all_kernel(const float*
             if (isN) { const int o = beforeN + __popcll(bn & lt); nv[o] = d; nidx[o] = j; }
         }
     }
+    }
     __syncthreads();
+    if (probe & 2) return;
     // range of the anchor's D row over its positives and negatives -> factorised or direct sweep (uniform choice)
     float lo = INFINITY, hi = -INFINITY;
     for (int k = tid; k < nP; k += TRIP_THREADS) { lo = fminf(lo, pu[k]); hi = fmaxf(hi, pu[k]); }
@@ -233,6 +361,7 @@ __global__ __launch_bounds__(TRIP_THREADS, 3) void batch_all_kernel(const float*
     lo = block_min_f(lo, red);
     hi = block_max_f(hi, red);
     const bool fact = (hi - lo) <= 80.0f;                    // also false for NaN/inf rows
+    const bool fact2 = !POS_ONLY && (hi - lo) <= 40.0f;      // pair-packed sweep: products of two (1 + exp(t)) stay finite
     const float mid = 0.5f * (hi + lo);
     if (fact)
         for (int k = tid; k < nP; k += TRIP_THREADS) pf[k] = __builtin_amdgcn_exp2f((mid - pu[k]) * kLog2e);
@@ -242,10 +371,37 @@ __global__ __launch_bounds__(TRIP_THREADS, 3) void batch_all_kernel(const float*
     unsigned cnt = 0u;
     float* gneg_w = gneg + wave * Bp;
     unsigned* cneg_w = POS_ONLY ? cneg + wave * Bp : nullptr;
-    for (int k0 = 0; k0 < nN;) {
+    float loss_log2 = 0.f, loss_corr = 0.f;
+    unsigned cnt_wave = 0u;
+    // chunks of 128*q2 negatives, q2 <= 5 register pairs per lane; equal-sized chunks when one is not enough
+    const int need2 = (nN + 127) / 128;
+    const int nch2 = (need2 + 4) / 5;
+    const int q2 = nch2 > 0 ? (need2 + nch2 - 1) / nch2 : 1;
+    if (probe & 1) nN = 0;                                    // DAE_MINER_PROBE=1: everything but the pair sweeps (timing only)
+    for (int k0 = 0; fact2 && k0 < nN; k0 += q2 * 128) {
+        const bool first = (k0 == 0);
+#define DAE_SWEEP2(QV)                                                                                                  \
+    do {                                                                                                                \
+        if (first) sweep_pairs2<QV, true>(pu, pf, mid, nv, nP, nN, k0, wave, lane, gpos, gneg_w, loss_log2, loss_corr, cnt_wave);   \
+        else sweep_pairs2<QV, false>(pu, pf, mid, nv, nP, nN, k0, wave, lane, gpos, gneg_w, loss_log2, loss_corr, cnt_wave);        \
+    } while (0)
+        switch (q2) {
+            case 5: DAE_SWEEP2(5); break;
+            case 4: DAE_SWEEP2(4); break;
+            case 3: DAE_SWEEP2(3); break;
+            case 2: DAE_SWEEP2(2); break;
+            default: DAE_SWEEP2(1); break;
+        }
+#undef DAE_SWEEP2
+    }
+    if (fact2) {
+        loss = kLn2 * loss_log2 + loss_corr;
+        if (lane == 0) cnt = cnt_wave;
+    }
+    for (int k0 = 0; !fact2 && k0 < nN;) {
         const int need = (nN - k0 + 63) / 64;                 // negatives per lane still to cover
-        // menu of register-resident widths; the smallest one >= need (10 caps a chunk at 640 negatives)
-        const int q = need <= 4 ? need : need <= 6 ? 6 : need <= 8 ? 8 : 10;
+        // menu of register-resident widths; the smallest one >= need (6 caps a chunk at 384 negatives; this legacy path shares the register budget of the pair-packed one)
+        const int q = need <= 4 ? need : 6;
         const bool first = (k0 == 0);
 #define DAE_SWEEP(QV)                                                                                                    \
     do {                                                                                                                 \
@@ -258,8 +414,6 @@ __global__ __launch_bounds__(TRIP_THREADS, 3) void batch_all_kernel(const float*
         }                                                                                                                \
     } while (0)
         switch (q) {
-            case 10: DAE_SWEEP(10); break;
-            case 8: DAE_SWEEP(8); break;
             case 6: DAE_SWEEP(6); break;
             case 4: DAE_SWEEP(4); break;
             case 3: DAE_SWEEP(3); break;
@@ -269,6 +423,7 @@ __global__ __launch_bounds__(TRIP_THREADS, 3) void batch_all_kernel(const float*
 #undef DAE_SWEEP
         k0 += q * 64;
     }
+    if (probe & 8) return;
     __syncthreads();
     for (int k = tid; k < nP; k += TRIP_THREADS) {
         Grow[pidx[k]] = -gpos[k];
@@ -375,21 +530,22 @@ extern "C" int dae_triplet_batch_all(const float* D_slabs, int32_t d_splits, int
     // val + idx + 4 per-wave gradient rows (+ 4 count rows when pos_only) + scans + reductions
     const size_t lds = (size_t)Bp * (pos_only ? 52 : 32) + 2 * (TRIP_THREADS + 1) * sizeof(int) + 8 * sizeof(float);
     DAE_CHECK_ARG(lds <= 160 * 1024, "batch_all: batch %d needs %zu B of LDS (> 160 KiB)", B, lds);
+    typedef void (*ba_fn)(const float*, int, int64_t, int64_t, const int32_t*, int, int, float*, uint32_t*, float*, uint32_t*, int);
+    static const int probe = [] { const char* v = getenv("DAE_MINER_PROBE"); return v ? atoi(v) : 0; }();
+    // workgroups per CU the kernel is compiled for (register budget 168 / 128 VGPRs); DAE_MINER_OCC=4 for A/B runs
+    static const int occ = [] { const char* v = getenv("DAE_MINER_OCC"); return (v && atoi(v) == 4) ? 4 : 3; }();
+    ba_fn k = pos_only ? (occ == 4 ? batch_all_kernel<true, 4> : batch_all_kernel<true, 3>)
+                       : (occ == 4 ? batch_all_kernel<false, 4> : batch_all_kernel<false, 3>);
     static bool attr_done = false;
     if (!attr_done) {
-        DAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(batch_all_kernel<false>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        DAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(batch_all_kernel<true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ba_fn all[4] = {batch_all_kernel<true, 3>, batch_all_kernel<true, 4>, batch_all_kernel<false, 3>, batch_all_kernel<false, 4>};
+        for (ba_fn f : all)
+            DAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
     hipStream_t st = (hipStream_t)stream;
-    if (pos_only)
-        hipLaunchKernelGGL((batch_all_kernel<true>), dim3(B), dim3(TRIP_THREADS), lds, st, D_slabs, d_splits, slab_stride, ldd,
-                           labels, B, Bp, loss_part, npos_part, G, role_cnt);
-    else
-        hipLaunchKernelGGL((batch_all_kernel<false>), dim3(B), dim3(TRIP_THREADS), lds, st, D_slabs, d_splits, slab_stride, ldd,
-                           labels, B, Bp, loss_part, npos_part, G, role_cnt);
+    hipLaunchKernelGGL(k, dim3(B), dim3(TRIP_THREADS), lds, st, D_slabs, d_splits, slab_stride, ldd, labels, B, Bp, loss_part, npos_part, G,
+                       role_cnt, probe);
     DAE_CHECK_LAUNCH();
     return 0;
 }

@@ -142,7 +142,9 @@ class Engine:
     # ------------------------------------------------------------------ steps
     def train_step(self, row_idx, labels, stats, *, corr_mode=L.CORR_NONE, keep_bits=None, seed=0, rng_stream=0,
                    corr_frac=0.0, scale=1.0, corrupted_csr=None, phase=0, grad_scale=1.0):
-        """Enqueue one mini-batch step.  row_idx / labels: device int32 tensors; stats: device float32[8]."""
+        """Enqueue one mini-batch step.  row_idx / labels: device int32 tensors; stats: device float32[8].
+        phase: 0 step + update (grads() stays readable), 1 gradients only (DP), 2 forward only, 3 step + update
+        with the optimizer fused into the dW GEMM and no W-gradient image (the training loops use this)."""
         s = L.dae_step()
         s.row_idx = row_idx.data_ptr(); s.labels = None if labels is None else labels.data_ptr()
         s.B = int(row_idx.numel())
@@ -152,7 +154,7 @@ class Engine:
             s.c_indptr = corrupted_csr["indptr"].data_ptr(); s.c_indices = corrupted_csr["indices"].data_ptr()
             s.c_values = None if corrupted_csr["values"] is None else corrupted_csr["values"].data_ptr()
         s.stats = stats.data_ptr(); s.phase = int(phase)
-        if phase == 0 and self.opt == "adam":
+        if phase in (0, 3) and self.opt == "adam":   # 3 = update without materialising the W gradient
             self.adam_t += 1
         s.adam_t = self.adam_t; s.grad_scale = float(grad_scale)
         L.check(self.lib.dae_train_step(self.plan, C.byref(s), L.current_stream()), "dae_train_step")

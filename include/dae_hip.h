@@ -291,7 +291,9 @@ typedef struct {
     const int64_t* c_indptr; const int32_t* c_indices; const float* c_values;
     float* stats;                /* device float[DAE_STATS_STRIDE] for this step */
     int32_t phase;               /* 0 = forward+backward+update, 1 = forward+backward only (DP:
-                                    caller all-reduces `grad` then calls dae_plan_apply), 2 = forward only */
+                                    caller all-reduces `grad` then calls dae_plan_apply), 2 = forward only,
+                                    3 = as 0 but the W part of `grad` is not materialised (bf16: the optimizer
+                                    runs in the dW GEMM's epilogue and nothing reads the gradient image) */
     int32_t adam_t; float grad_scale;
 } dae_step;
 

@@ -108,6 +108,58 @@ def test_step_bf16_matches_oracle(strategy):
     assert _rel(dW, r["dW"]) < 2e-2 and _rel(dbh, r["dbh"]) < 2e-2 and _rel(dbv, r["dbv"]) < 2e-2
 
 
+def test_step_bit_operand_equals_dense_operand(monkeypatch):
+    """DAE_BITS=1 (bf16 + binary CSR) runs the fused corrupt+encode GEMM on the bit image of x~ instead of the dense bf16
+    x~ operand.  Same products, same fp32 accumulation: statistics, gradients and weights must agree."""
+    a, _, pa = _run_case("bf16", "batch_all", "cross_entropy", ("sigmoid", "sigmoid"), "ada_grad", steps=3, seed=5)
+    monkeypatch.setenv("DAE_BITS", "1")
+    b, _, pb = _run_case("bf16", "batch_all", "cross_entropy", ("sigmoid", "sigmoid"), "ada_grad", steps=3, seed=5)
+    for (_, sa, dWa, dbha, dbva), (_, sb, dWb, dbhb, dbvb) in zip(a, b):
+        assert np.allclose(sa[:5], sb[:5], rtol=2e-6, atol=0)
+        assert _rel(dWa, dWb.astype(np.float64)) < 1e-5 and _rel(dbha, dbhb.astype(np.float64)) < 1e-5
+        assert _rel(dbva, dbvb.astype(np.float64)) < 1e-5
+    for u, v in zip(pa, pb):
+        assert _rel(u, np.asarray(v, np.float64)) < 1e-5
+
+
+@pytest.mark.parametrize("opt", ["gradient_descent", "ada_grad", "momentum", "adam"])
+def test_fused_optimizer_equals_separate_kernel(opt, monkeypatch):
+    """bf16 single-GPU steps run the optimizer in the dW GEMM's epilogue; DAE_NO_FUSED_OPT=1 keeps dW -> grad -> opt_step.
+    Same fp32 gradient tile, same update arithmetic: parameters (and the gradient image of phase 0) must agree."""
+    a, _, pa = _run_case("bf16", "batch_all", "cross_entropy", ("sigmoid", "sigmoid"), opt, steps=3, seed=9)
+    monkeypatch.setenv("DAE_NO_FUSED_OPT", "1")
+    b, _, pb = _run_case("bf16", "batch_all", "cross_entropy", ("sigmoid", "sigmoid"), opt, steps=3, seed=9)
+    for (_, sa, dWa, dbha, dbva), (_, sb, dWb, dbhb, dbvb) in zip(a, b):
+        assert np.allclose(sa[:5], sb[:5], rtol=1e-6, atol=0)
+        assert _rel(dWa, dWb.astype(np.float64)) < 1e-6
+    for u, v in zip(pa, pb):
+        assert _rel(u, np.asarray(v, np.float64)) < 1e-6
+
+
+def test_phase3_updates_like_phase0():
+    """phase 3 (no W-gradient image) must leave the same parameters as phase 0."""
+    from dae_rnn_news_recommendation_amd import _lib as L
+    from dae_rnn_news_recommendation_amd.engine import Engine
+    rng = np.random.default_rng(4)
+    N, F, H, B = 300, 500, 70, 130
+    m = _mk(rng, N, F, True); lab = rng.integers(0, 3, N).astype(np.int32)
+    W0 = torch.as_tensor(rng.uniform(-0.3, 0.3, (F, H)).astype(np.float32)).to(torch.bfloat16).float().numpy()
+    outs = []
+    for phase in (0, 3):
+        eng = Engine(F, H, B, dtype="bf16", opt="momentum", learning_rate=0.05, momentum=0.5, triplet="batch_all")
+        eng.upload_csr(m); eng.set_params(W0, np.zeros(H, np.float32), np.zeros(F, np.float32))
+        stats = torch.zeros(8, device="cuda")
+        for s in range(3):
+            ids = np.arange(s * 50, s * 50 + B) % N
+            idx = torch.from_numpy(ids.astype(np.int32)).cuda()
+            labs = torch.from_numpy(lab[ids]).cuda()
+            eng.train_step(idx, labs, stats, corr_mode=L.CORR_PHILOX_MASK, seed=3, rng_stream=s, corr_frac=0.3, phase=phase)
+        torch.cuda.synchronize()
+        outs.append([np.asarray(x) for x in eng.get_params()])
+    for u, v in zip(outs[0], outs[1]):
+        assert np.array_equal(u, v)
+
+
 @pytest.mark.parametrize("opt", ["ada_grad", "momentum", "adam"])
 def test_step_optimizers(opt):
     out, ref, got = _run_case("fp32", "batch_all", "cross_entropy", ("sigmoid", "sigmoid"), opt, steps=3)

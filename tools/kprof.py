@@ -14,7 +14,7 @@ ap.add_argument("--steps", type=int, default=20); ap.add_argument("--rows", type
 ap.add_argument("--features", type=int, default=10000); ap.add_argument("--hidden", type=int, default=500)
 ap.add_argument("--batch", type=int, default=800); ap.add_argument("--loss", default="cross_entropy")
 ap.add_argument("--enc-splits", type=int, default=0); ap.add_argument("--tag", default="")
-ap.add_argument("--nst", type=int, default=-1)
+ap.add_argument("--nst", type=int, default=-1); ap.add_argument("--phase", type=int, default=3)
 a = ap.parse_args()
 if a.nst >= 0:
     L.load().dae_set_glds(a.nst)
@@ -26,11 +26,11 @@ idx = torch.arange(a.batch, dtype=torch.int32, device="cuda"); labs = torch.from
 stats = torch.zeros(8, device="cuda")
 kw = dict(corr_mode=L.CORR_PHILOX_MASK, seed=1, rng_stream=0, corr_frac=0.3)
 for _ in range(5):
-    eng.train_step(idx, labs if a.strategy != "none" else None, stats, **kw)
+    eng.train_step(idx, labs if a.strategy != "none" else None, stats, phase=a.phase, **kw)
 torch.cuda.synchronize()
 eng.profile(True)
 for _ in range(a.steps):
-    eng.train_step(idx, labs if a.strategy != "none" else None, stats, **kw)
+    eng.train_step(idx, labs if a.strategy != "none" else None, stats, phase=a.phase, **kw)
 prof = eng.profile_read(); eng.profile(False)
 tot = sum(ms for ms, n in prof.values())
 print(f"== nst={a.nst} {a.tag} {a.strategy} {a.precision} decode_debug={os.environ.get('DAE_DECODE_DEBUG','0')} total {1e3*tot/a.steps:.1f} us/step  info={eng.info()}")
