@@ -107,6 +107,8 @@ struct dae_plan {
     float *slabs, *h_f32, *D_slabs, *G, *rowloss_part, *dbv_part, *colsum_part, *cos_part, *cos_stats, *cw, *loss_part,
         *dw_f32, *tri_scalars, *dh_extra, *rowsq_scratch, *tile_part;
     uint32_t *cnt_part, *role_cnt, *xc_bits;
+    bool xct_clean;                  // x~^T holds only zeros (every step un-scatters what it wrote; see step_tail_kernel)
+    bool tail_ok;                    // DAE_NO_TAIL=1: separate bias_grads / step_stats launches and a full memset per step (A/B)
     bool fuse_opt_ok;                // DAE_NO_FUSED_OPT=1 keeps the separate optimizer kernel (A/B)
     bool bits_ok;                    // binary CSR + bf16: x~ handed to the encode GEMM as a bit image (opt-in: DAE_BITS=1)
     int32_t *dw_i32, *n_same;
@@ -199,6 +201,8 @@ extern "C" int dae_plan_create(const dae_config* cfg, dae_plan** out) {
                     getenv("DAE_GRAM_FP32") == nullptr;
     p->ws_bytes = carve(p, nullptr);
     p->fuse_opt_ok = getenv("DAE_NO_FUSED_OPT") == nullptr;
+    p->tail_ok = getenv("DAE_NO_TAIL") == nullptr;
+    p->xct_clean = false;
     p->bits_ok = cfg->dtype == DAE_BF16 && getenv("DAE_BITS") != nullptr;
     p->overlap_ok = getenv("DAE_OVERLAP") != nullptr;   // measured: running the miner chain beside decode is SLOWER (0.410 vs 0.351 ms/step)
     *out = p;
@@ -279,10 +283,10 @@ extern "C" int dae_plan_info(const dae_plan* p, int32_t* out8) {
 static int gather_batch(dae_plan* p, const int64_t* indptr, const int32_t* indices, const float* values, const float* dense,
                         int64_t ld_dense, const int32_t* row_idx, int B, void* x, void* xc, void* xct, float* rowsq,
                         int corr_mode, const uint32_t* keep_bits, uint64_t seed, uint32_t rng_stream, float corr_frac,
-                        float scale, void* stream, uint32_t* xc_bits = nullptr) {
+                        float scale, void* stream, uint32_t* xc_bits = nullptr, const LabelJob* label_job = nullptr) {
     if (indptr)
-        return dae_gather_csr_bits(indptr, indices, values, row_idx, B, p->F, p->cfg.dtype, x, xc, p->Fp, xct, p->Bpm, rowsq, corr_mode,
-                                   keep_bits, seed, rng_stream, corr_frac, scale, xc_bits, p->Fp / 32, stream);
+        return launch_gather_csr(indptr, indices, values, row_idx, B, p->F, p->cfg.dtype, x, xc, p->Fp, xct, p->Bpm, rowsq, corr_mode,
+                                 keep_bits, seed, rng_stream, corr_frac, scale, xc_bits, p->Fp / 32, label_job, (hipStream_t)stream);
     DAE_CHECK_ARG(dense, "step: no train set bound");
     return dae_gather_dense(dense, ld_dense, row_idx, B, p->F, p->cfg.dtype, x, xc, p->Fp, xct, p->Bpm, rowsq, p->rowsq_scratch,
                             corr_mode, keep_bits, seed, rng_stream, corr_frac, scale, stream);
@@ -340,7 +344,16 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     const bool backward = s->phase != 2;
 
     // 1-2. corrupt + gather  (K0/K1 front half)
-    if (backward) PROF(PS_MEMSET, memset_async(p->xct, (size_t)Fp * ldB * p->es, st));
+    // x~^T: the CSR gather only scatters kept entries, so the image must be zero beforehand.  The step tail un-scatters
+    // exactly what was written, so the 18 MB memset runs once (or after a failed / foreign step); the dense gather
+    // overwrites whole tiles and never needs it.
+    const bool csr_in = s->c_indptr || p->b.indptr;
+    // label statistics (cw, N_valid, data weights) depend on the labels alone: they ride on the CSR gather launch
+    LabelJob lj{s->labels, B, Bp, c.triplet, p->nvalid, p->dw_i64, p->cw, c.alpha, p->tri_scalars};
+    const bool label_in_gather = p->tail_ok && !explicit3 && !s->c_indptr && p->b.indptr && Bp <= 1024;
+    const bool tail = p->tail_ok;
+    if (backward && csr_in && !(tail && p->xct_clean)) PROF(PS_MEMSET, memset_async(p->xct, (size_t)Fp * ldB * p->es, st));
+    if (backward) p->xct_clean = false;
     float* rowsq = is_cos ? p->cos_stats : nullptr;
     bool use_bits = false;
     if (s->c_indptr) {   // an explicitly corrupted copy of the train set (salt&pepper, host-side noise)
@@ -353,7 +366,7 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
         use_bits = p->bits_ok && p->b.indptr && !p->b.values && s->scale == 1.0f;
         PROF(PS_GATHER, gather_batch(p, p->b.indptr, p->b.indices, p->b.values, p->b.dense, p->b.ld_dense, s->row_idx, B, p->x,
                         use_bits ? nullptr : p->xc, backward ? p->xct : nullptr, rowsq, s->corr_mode, s->keep_bits, s->seed, s->rng_stream,
-                        s->corr_frac, s->scale, stream, use_bits ? p->xc_bits : nullptr));
+                        s->corr_frac, s->scale, stream, use_bits ? p->xc_bits : nullptr, label_in_gather ? &lj : nullptr));
     }
     // 3-4. encode (K1/K2)
     const int64_t slab = (int64_t)Bp * Hp;
@@ -372,7 +385,7 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
         DAE_CHECK_HIP(hipMemcpyAsync(p->cw + Bt, p->cw, (size_t)Bt * 4, hipMemcpyDeviceToDevice, st));
         DAE_CHECK_HIP(hipMemcpyAsync(p->cw + 2 * Bt, p->cw, (size_t)Bt * 4, hipMemcpyDeviceToDevice, st));
         PROF(PS_MINER, dae_explicit_triplet(p->h_f32, Hp, Bt, H, c.alpha, p->dh_extra, p->loss_part, p->tri_scalars, stream));
-    } else {
+    } else if (!label_in_gather) {
         PROF(PS_LABEL, dae_label_stats(s->labels, B, Bp, c.triplet, p->n_same, p->acc, p->nvalid, p->dw_i64, p->cw, c.alpha, p->tri_scalars, stream));
     }
     bool forked = false;
@@ -435,10 +448,14 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     }
     if (forked) DAE_CHECK_HIP(hipStreamWaitEvent(st, p->ev_join, 0));   // join: triplet scalars and Gs are ready
     // 8. statistics of this step (autoencoder.py:233 fetch list)
-    PROF(PS_STATS, dae_step_stats(is_cos ? p->rowloss_part : nullptr, 1, is_cos ? nullptr : p->tile_part, (Bp / 128) * (Fp / 128), p->cw, B, Bp,
-                      c.triplet == 3 ? DAE_TRIPLET_BATCH_HARD : c.triplet, c.alpha,
-                      p->tri_scalars, c.triplet == DAE_TRIPLET_BATCH_ALL ? p->nvalid : nullptr, fold_finalize ? p->loss_part : nullptr,
-                      fold_finalize ? p->cnt_part : nullptr, s->stats, stream));
+    StatsArgs sa{is_cos ? p->rowloss_part : nullptr, 1, is_cos ? nullptr : p->tile_part, (Bp / 128) * (Fp / 128), p->cw, B, Bp,
+                 c.triplet == 3 ? DAE_TRIPLET_BATCH_HARD : c.triplet, c.alpha, p->tri_scalars,
+                 c.triplet == DAE_TRIPLET_BATCH_ALL ? p->nvalid : nullptr, s->stats, fold_finalize ? p->loss_part : nullptr,
+                 fold_finalize ? p->cnt_part : nullptr};
+    const bool stats_in_tail = backward && tail;     // rides on the step-tail launch after the dW GEMM
+    if (!stats_in_tail)
+        PROF(PS_STATS, dae_step_stats(sa.rowloss_part, sa.n_col_waves, sa.tile_part, sa.n_tiles, sa.cw, B, Bp, sa.triplet, sa.alpha, sa.tri_scalars,
+                                      sa.nvalid, sa.loss_part, sa.cnt_part, s->stats, stream));
     if (!backward) return 0;
     // 9-10. dL/dh = delta2 W + alpha (G+G^T) h ; delta1                     (K8)
     const bool mined = (c.triplet == DAE_TRIPLET_BATCH_ALL || c.triplet == DAE_TRIPLET_BATCH_HARD);
@@ -463,9 +480,18 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     float* g_bh = p->b.grad + (int64_t)Fp * Hp;
     const int64_t boff = (int64_t)Fp * Hp;
     const bool fuse_bias = apply_now;               // single-GPU step: the bias update rides on the bias-gradient kernel
-    PROF(PS_BIAS, dae_bias_grads(p->dbv_part, 2 * Bp / 128, p->colsum_part, Bp / 32, p->b.bh, H, Hp, F, Fp, c.enc_act, g_bh, g_bh + Hp,
-                                 fuse_bias ? 1 : 0, c.opt, plan_lr(p, s->adam_t), c.momentum, s->grad_scale, p->b.bv,
-                                 p->b.opt_s1 ? p->b.opt_s1 + boff : nullptr, p->b.opt_s2 ? p->b.opt_s2 + boff : nullptr, stream));
+    if (tail) {
+        BiasArgs ba{p->dbv_part, 2 * Bp / 128, p->colsum_part, Bp / 32, p->b.bh, H, Hp, F, Fp, c.enc_act, g_bh, g_bh + Hp,
+                    fuse_bias ? 1 : 0, c.opt, plan_lr(p, s->adam_t), c.momentum, s->grad_scale, p->b.bv,
+                    p->b.opt_s1 ? p->b.opt_s1 + boff : nullptr, p->b.opt_s2 ? p->b.opt_s2 + boff : nullptr};
+        ClearArgs ca{s->c_indptr ? s->c_indptr : p->b.indptr, s->c_indptr ? s->c_indices : p->b.indices, s->row_idx, B, F, p->xct, ldB, p->es};
+        PROF(PS_BIAS, launch_step_tail(ba, &sa, csr_in ? &ca : nullptr, st));
+        if (csr_in) p->xct_clean = true;
+    } else {
+        PROF(PS_BIAS, dae_bias_grads(p->dbv_part, 2 * Bp / 128, p->colsum_part, Bp / 32, p->b.bh, H, Hp, F, Fp, c.enc_act, g_bh, g_bh + Hp,
+                                     fuse_bias ? 1 : 0, c.opt, plan_lr(p, s->adam_t), c.momentum, s->grad_scale, p->b.bv,
+                                     p->b.opt_s1 ? p->b.opt_s1 + boff : nullptr, p->b.opt_s2 ? p->b.opt_s2 + boff : nullptr, stream));
+    }
     if (s->phase == 1 || fuse_opt) return 0;
     // 13. optimizer (K9): W (+ shadows); biases were updated above
     PROF(PS_OPT, dae_opt_step(c.opt, plan_lr(p, s->adam_t), c.momentum, s->grad_scale, p->b.W, p->b.bh, p->b.bv, p->b.grad, p->b.opt_s1,

@@ -3,6 +3,8 @@
 // optimizer update (with low-precision shadow refresh) and the per-step statistics.
 // All of them are stream-ordered, deterministic (fixed reduction order; only integer atomics).
 #include "dae_common.h"
+#include "dae_kernels.h"
+#include "dae_label.h"
 
 namespace dae {
 
@@ -184,63 +186,9 @@ __global__ void label_weight_kernel(const int32_t* __restrict__ n_same, int B, i
     }
 }
 
-// single-launch variant for B <= 1024 (the usual mini-batch): one 1024-thread block.  Label multiplicities come
-// from an LDS histogram when every id lies in [0, 4096) (the Python layer always passes dense ids); arbitrary ids
-// fall back to the O(B^2) comparison loop.  Integer arithmetic only -> exact and order-independent.
-__global__ __launch_bounds__(1024) void label_stats_small_kernel(const int32_t* __restrict__ labels, int B, int Bp, int triplet,
-                                                                 int64_t* __restrict__ nvalid_out, int64_t* __restrict__ dw_out,
-                                                                 float* __restrict__ cw, float alpha, float* __restrict__ tri_scalars) {
-    constexpr int NBIN = 4096;
-    __shared__ __attribute__((aligned(16))) int32_t lab[1024];
-    __shared__ int hist[NBIN];
-    __shared__ unsigned long long accS, accNV;
-    __shared__ int out_of_range;
-    const int i = threadIdx.x;
-    if (triplet == DAE_TRIPLET_NONE) {
-        if (i < Bp) cw[i] = (i < B) ? 1.0f / ((float)B + 1e-16f) : 0.f;
-        return;
-    }
-    if (i == 0) { accS = 0ull; accNV = 0ull; out_of_range = 0; }
-    for (int k = i; k < NBIN; k += 1024) hist[k] = 0;
-    const int32_t li = (i < B) ? labels[i] : 0;
-    lab[i] = (i < B) ? li : (int32_t)0x80000000;
-    __syncthreads();
-    if (i < B) {
-        if (li >= 0 && li < NBIN) atomicAdd(&hist[li], 1);
-        else out_of_range = 1;
-    }
-    __syncthreads();
-    long long n = 0;
-    if (i < B) {
-        if (!out_of_range) {
-            n = hist[li];
-        } else {
-            int cnt = 0;
-            const int4* l4 = reinterpret_cast<const int4*>(lab);
-            const int n4 = (B + 3) >> 2;
-            for (int k = 0; k < n4; ++k) {
-                const int4 v = l4[k];
-                cnt += (v.x == li) + (v.y == li) + (v.z == li) + (v.w == li);
-            }
-            n = cnt;
-        }
-    }
-    {   // one LDS atomic per wave, not per thread
-        const unsigned s1 = wave_sum_u32(i < B ? (unsigned)(n - 1) : 0u);
-        const unsigned s2 = wave_sum_u32(i < B ? (unsigned)((n - 1) * (B - n)) : 0u);     // <= 64 * 2.7e5 per wave
-        if ((i & 63) == 0) { atomicAdd(&accS, (unsigned long long)s1); atomicAdd(&accNV, (unsigned long long)s2); }
-    }
-    __syncthreads();
-    const long long S = (long long)accS, NV = (long long)accNV;
-    if (i == 0 && nvalid_out) nvalid_out[0] = NV;
-    if (i == 0 && tri_scalars && triplet == DAE_TRIPLET_BATCH_ALL) tri_scalars[0] = alpha / ((float)NV + 1e-16f);
-    if (i < B) {
-        const long long dw = 2 * (n - 1) * (B - n) + (S - n * (n - 1));
-        if (dw_out) dw_out[i] = dw;
-        if (triplet == DAE_TRIPLET_BATCH_ALL) cw[i] = (float)dw / ((float)(3 * NV) + 1e-16f);
-    } else if (i < Bp && triplet == DAE_TRIPLET_BATCH_ALL) {
-        cw[i] = 0.f;
-    }
+__global__ __launch_bounds__(1024) void label_stats_small_kernel(LabelJob j) {
+    __shared__ __attribute__((aligned(16))) char smem[LABEL_SMEM_BYTES];
+    label_stats_block<1024>(j, smem);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -342,31 +290,28 @@ __device__ __forceinline__ float opt_update(int opt, float lr, float mom, float 
 
 
 // apply != 0 also performs the optimizer update of the biases (slot layout [bh (Hp) | bv (Fp)] at s1b / s2b)
-__global__ void bias_grads_kernel(const float* __restrict__ dbv_part, int n_row_waves, const float* __restrict__ colsum_part,
-                                  int n_row_blocks, float* __restrict__ bh, int H, int Hp, int F, int Fp, int enc_act,
-                                  float* __restrict__ dbh, float* __restrict__ dbv, int apply, int opt, float lr, float mom,
-                                  float gscale, float* __restrict__ bv, float* __restrict__ s1b, float* __restrict__ s2b) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < Fp) {
+__device__ __forceinline__ void bias_grads_body(const BiasArgs& a, int k) {
+    if (k < a.Fp) {
         float s = 0.f;
-        if (k < F) for (int p = 0; p < n_row_waves; ++p) s += dbv_part[(int64_t)p * Fp + k];
-        dbv[k] = s;
-        if (apply) bv[k] = opt_update(opt, lr, mom, bv[k], s * gscale, s1b, s2b, (int64_t)Hp + k);
-    } else if (k < Fp + Hp) {
-        const int j = k - Fp;
+        if (k < a.F) for (int p = 0; p < a.n_row_waves; ++p) s += a.dbv_part[(int64_t)p * a.Fp + k];
+        a.dbv[k] = s;
+        if (a.apply) a.bv[k] = opt_update(a.opt, a.lr, a.mom, a.bv[k], s * a.gscale, a.s1b, a.s2b, (int64_t)a.Hp + k);
+    } else if (k < a.Fp + a.Hp) {
+        const int j = k - a.Fp;
         float s1 = 0.f, s2 = 0.f;
-        if (j < H) {
-            for (int p = 0; p < n_row_blocks; ++p) {
-                s1 += colsum_part[(int64_t)p * Hp + j];
-                s2 += colsum_part[((int64_t)n_row_blocks + p) * Hp + j];
+        if (j < a.H) {
+            for (int p = 0; p < a.n_row_blocks; ++p) {
+                s1 += a.colsum_part[(int64_t)p * a.Hp + j];
+                s2 += a.colsum_part[((int64_t)a.n_row_blocks + p) * a.Hp + j];
             }
-            const float ab = act_apply(enc_act, bh[j]);
-            s1 -= act_grad(enc_act, ab) * s2;
+            const float ab = act_apply(a.enc_act, a.bh[j]);
+            s1 -= act_grad(a.enc_act, ab) * s2;
         }
-        dbh[j] = s1;
-        if (apply) bh[j] = opt_update(opt, lr, mom, bh[j], s1 * gscale, s1b, s2b, (int64_t)j);
+        a.dbh[j] = s1;
+        if (a.apply) a.bh[j] = opt_update(a.opt, a.lr, a.mom, a.bh[j], s1 * a.gscale, a.s1b, a.s2b, (int64_t)j);
     }
 }
+__global__ void bias_grads_kernel(BiasArgs a) { bias_grads_body(a, blockIdx.x * blockDim.x + threadIdx.x); }
 
 // ------------------------------------------------------------------------------------------------
 // K9 optimizer (autoencoder.py:444-477, tf.train.* semantics)
@@ -406,53 +351,74 @@ __global__ void opt_bias_kernel(int opt, float lr, float mom, float gscale, floa
     *p = opt_update(opt, lr, mom, *p, grad_b[k] * gscale, s1b, s2b, k);
 }
 
-// per-step statistics (autoencoder.py:233 fetch list)
-__global__ __launch_bounds__(1024) void step_stats_kernel(const float* __restrict__ rowloss_part, int n_col_waves,
-                                                          const float* __restrict__ tile_part, int n_tiles,
-                                                          const float* __restrict__ cw, int B, int Bp, int triplet, float alpha,
-                                                          float* __restrict__ tri_scalars,
-                                                          const int64_t* __restrict__ nvalid, float* __restrict__ stats,
-                                                          const float* __restrict__ loss_part, const uint32_t* __restrict__ cnt_part) {
-    __shared__ double sm[1024];
+// per-step statistics (autoencoder.py:233 fetch list); any block size (sm holds blockDim.x doubles)
+__device__ __forceinline__ void step_stats_body(const StatsArgs& a, double* sm) {
     // batch_all (all valid triplets): fold triplet_finalize in -- loss = sum/(N_valid+1e-16), num = sum of counts
     double lsum = 0.0, csum = 0.0;
-    if (loss_part) {
+    if (a.loss_part) {
         double l = 0.0, c = 0.0;
-        for (int i = threadIdx.x; i < B; i += blockDim.x) { l += (double)loss_part[i]; c += (double)cnt_part[i]; }
+        for (int i = threadIdx.x; i < a.B; i += blockDim.x) { l += (double)a.loss_part[i]; c += (double)a.cnt_part[i]; }
         lsum = block_sum_d(l, sm);
         csum = block_sum_d(c, sm);
     }
     double s = 0.0;
-    if (tile_part) {                                    // per-tile weighted sums from the fused decode epilogue
-        for (int i = threadIdx.x; i < n_tiles; i += blockDim.x) s += (double)tile_part[i];
+    if (a.tile_part) {                                    // per-tile weighted sums from the fused decode epilogue
+        for (int i = threadIdx.x; i < a.n_tiles; i += blockDim.x) s += (double)a.tile_part[i];
     } else {
-        for (int i = threadIdx.x; i < B; i += blockDim.x) {
+        for (int i = threadIdx.x; i < a.B; i += blockDim.x) {
             float r = 0.f;
-            for (int p = 0; p < n_col_waves; ++p) r += rowloss_part[(int64_t)p * Bp + i];
-            s += (double)(r * cw[i]);
+            for (int p = 0; p < a.n_col_waves; ++p) r += a.rowloss_part[(int64_t)p * a.Bp + i];
+            s += (double)(r * a.cw[i]);
         }
     }
     const double ae = block_sum_d(s, sm);
     if (threadIdx.x == 0) {
         const float aef = (float)ae;
         float tl = 0.f, fr = 0.f, nm = 0.f, nv = 0.f;
-        if (triplet != DAE_TRIPLET_NONE) {
-            if (loss_part) {
-                const float nvf = (float)nvalid[0];
+        if (a.triplet != DAE_TRIPLET_NONE) {
+            if (a.loss_part) {
+                const float nvf = (float)a.nvalid[0];
                 tl = (float)lsum / (nvf + 1e-16f); nm = (float)csum; fr = nm / (nvf + 1e-16f);
-                if (tri_scalars) { tri_scalars[1] = tl; tri_scalars[2] = fr; tri_scalars[3] = nm; }
+                if (a.tri_scalars) { a.tri_scalars[1] = tl; a.tri_scalars[2] = fr; a.tri_scalars[3] = nm; }
             } else {
-                tl = tri_scalars[1]; fr = tri_scalars[2]; nm = tri_scalars[3];
+                tl = a.tri_scalars[1]; fr = a.tri_scalars[2]; nm = a.tri_scalars[3];
             }
-            nv = (triplet == DAE_TRIPLET_BATCH_ALL && nvalid) ? (float)nvalid[0] : nm;
+            nv = (a.triplet == DAE_TRIPLET_BATCH_ALL && a.nvalid) ? (float)a.nvalid[0] : nm;
         }
-        stats[DAE_STAT_COST] = (triplet != DAE_TRIPLET_NONE) ? aef + alpha * tl : aef;
-        stats[DAE_STAT_AE] = aef;
-        stats[DAE_STAT_TRIPLET] = tl;
-        stats[DAE_STAT_FRACTION] = fr;
-        stats[DAE_STAT_NUM] = nm;
-        stats[DAE_STAT_NVALID] = nv;
-        stats[6] = 0.f; stats[7] = 0.f;
+        a.stats[DAE_STAT_COST] = (a.triplet != DAE_TRIPLET_NONE) ? aef + a.alpha * tl : aef;
+        a.stats[DAE_STAT_AE] = aef;
+        a.stats[DAE_STAT_TRIPLET] = tl;
+        a.stats[DAE_STAT_FRACTION] = fr;
+        a.stats[DAE_STAT_NUM] = nm;
+        a.stats[DAE_STAT_NVALID] = nv;
+        a.stats[6] = 0.f; a.stats[7] = 0.f;
+    }
+}
+__global__ __launch_bounds__(1024) void step_stats_kernel(StatsArgs a) {
+    __shared__ double sm[1024];
+    step_stats_body(a, sm);
+}
+
+// Tail of a training step in ONE launch (each of these was a separate ~5 us launch):
+//   blocks [0, nb_bias)        bias-gradient reduction (+ bias optimizer update)
+//   block  nb_bias             the step's statistics
+//   blocks (nb_bias, ...)      un-scatter: zero the entries of x~^T this step's gather wrote (one wave per batch row),
+//                              so the next step needs no 18 MB memset of the transposed operand
+__global__ __launch_bounds__(256) void step_tail_kernel(BiasArgs ba, StatsArgs sa, ClearArgs ca, int nb_bias, int stats_on) {
+    __shared__ double sm[256];
+    const int b = blockIdx.x;
+    if (b < nb_bias) { bias_grads_body(ba, b * 256 + threadIdx.x); return; }
+    if (b == nb_bias) { if (stats_on) step_stats_body(sa, sm); return; }
+    const int i = (b - nb_bias - 1) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= ca.B) return;
+    const int64_t row = ca.row_idx[i];
+    const int64_t s0 = ca.indptr[row], e0 = ca.indptr[row + 1];
+    for (int64_t k = s0 + lane; k < e0; k += 64) {
+        const int col = ca.indices[k];
+        if (col < ca.F) {
+            if (ca.es == 2) reinterpret_cast<bf16_t*>(ca.xct)[(int64_t)col * ca.ldt + i] = 0;
+            else reinterpret_cast<float*>(ca.xct)[(int64_t)col * ca.ldt + i] = 0.f;
+        }
     }
 }
 
@@ -551,8 +517,8 @@ extern "C" int dae_label_stats(const int32_t* labels, int32_t B, int32_t Bp, int
     DAE_CHECK_ARG(cw && B > 0 && Bp >= B, "label_stats: bad args");
     DAE_CHECK_ARG(triplet == DAE_TRIPLET_NONE || labels, "label_stats: labels required");
     if (Bp <= 1024) {
-        hipLaunchKernelGGL(label_stats_small_kernel, dim3(1), dim3(1024), 0, ST(stream), labels, B, Bp, triplet, nvalid_out, dw_out, cw, alpha,
-                           tri_scalars);
+        LabelJob j{labels, B, Bp, triplet, nvalid_out, dw_out, cw, alpha, tri_scalars};
+        hipLaunchKernelGGL(label_stats_small_kernel, dim3(1), dim3(1024), 0, ST(stream), j);
         DAE_CHECK_LAUNCH();
         return 0;
     }
@@ -604,8 +570,8 @@ extern "C" int dae_bias_grads(const float* dbv_part, int32_t n_row_waves, const 
         DAE_CHECK_ARG(opt != DAE_OPT_ADAM || s2b, "bias_grads: optimizer slot s2 required");
     }
     const int n = Fp + Hp;
-    hipLaunchKernelGGL(bias_grads_kernel, dim3((n + 255) / 256), dim3(256), 0, ST(stream), dbv_part, n_row_waves, colsum_part,
-                       n_row_blocks, bh, H, Hp, F, Fp, enc_act, dbh, dbv, apply, opt, lr, momentum, grad_scale, bv, s1b, s2b);
+    BiasArgs ba{dbv_part, n_row_waves, colsum_part, n_row_blocks, bh, H, Hp, F, Fp, enc_act, dbh, dbv, apply, opt, lr, momentum, grad_scale, bv, s1b, s2b};
+    hipLaunchKernelGGL(bias_grads_kernel, dim3((n + 255) / 256), dim3(256), 0, ST(stream), ba);
     DAE_CHECK_LAUNCH();
     return 0;
 }
@@ -647,8 +613,19 @@ extern "C" int dae_step_stats(const float* rowloss_part, int32_t n_col_waves, co
     DAE_CHECK_ARG(((rowloss_part && cw) || tile_part) && stats, "step_stats: null input");
     DAE_CHECK_ARG(triplet == DAE_TRIPLET_NONE || tri_scalars || loss_part, "step_stats: tri_scalars or miner partials required");
     DAE_CHECK_ARG(!loss_part || (cnt_part && nvalid && triplet == DAE_TRIPLET_BATCH_ALL), "step_stats: miner partials need cnt_part + nvalid");
-    hipLaunchKernelGGL(step_stats_kernel, dim3(1), dim3(1024), 0, ST(stream), rowloss_part, n_col_waves, tile_part, n_tiles, cw, B, Bp, triplet, alpha,
-                       tri_scalars, nvalid, stats, loss_part, cnt_part);
+    StatsArgs sa{rowloss_part, n_col_waves, tile_part, n_tiles, cw, B, Bp, triplet, alpha, tri_scalars, nvalid, stats, loss_part, cnt_part};
+    hipLaunchKernelGGL(step_stats_kernel, dim3(1), dim3(1024), 0, ST(stream), sa);
+    DAE_CHECK_LAUNCH();
+    return 0;
+}
+
+int dae::launch_step_tail(const BiasArgs& ba, const StatsArgs* sa, const ClearArgs* ca, hipStream_t st) {
+    DAE_CHECK_ARG(ba.dbv_part && ba.colsum_part && ba.bh && ba.dbh && ba.dbv, "step_tail: null bias-gradient input");
+    const int nb_bias = (ba.Fp + ba.Hp + 255) / 256;
+    const int nclear = ca ? (ca->B + 3) / 4 : 0;
+    StatsArgs s0; memset(&s0, 0, sizeof(s0));
+    ClearArgs c0; memset(&c0, 0, sizeof(c0));
+    hipLaunchKernelGGL(step_tail_kernel, dim3(nb_bias + 1 + nclear), dim3(256), 0, st, ba, sa ? *sa : s0, ca ? *ca : c0, nb_bias, sa ? 1 : 0);
     DAE_CHECK_LAUNCH();
     return 0;
 }

@@ -12,6 +12,7 @@
 // and the tiles are streamed out with 16-byte coalesced stores.  Only kept entries touch the
 // (pre-zeroed) transposed operand x~^T.
 #include "dae_common.h"
+#include "dae_label.h"
 #include "dae_rng.h"
 
 namespace dae {
@@ -31,11 +32,19 @@ __global__ __launch_bounds__(GATHER_THREADS) void gather_csr_kernel(
     const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices, const float* __restrict__ values,
     const int32_t* __restrict__ row_idx, int B, int F, T* __restrict__ x, T* __restrict__ xc, int64_t ldx,
     T* __restrict__ xct, int64_t ldt, float* __restrict__ rowsq, int corr_mode, const uint32_t* __restrict__ keep_bits,
-    uint64_t seed, uint32_t stream, float corr_frac, float scale, uint32_t* __restrict__ xc_bits, int64_t ldw) {
-    __shared__ __attribute__((aligned(16))) T lx[GATHER_CW];
-    __shared__ __attribute__((aligned(16))) T lxc[GATHER_CW];
+    uint64_t seed, uint32_t stream, float corr_frac, float scale, uint32_t* __restrict__ xc_bits, int64_t ldw,
+    LabelJob job, int label_slice) {
+    // row tiles; the same LDS serves the label-statistics block (blockIdx.y == label_slice, blockIdx.x == 0)
+    constexpr int TILE_B = 2 * GATHER_CW * (int)sizeof(T);
+    __shared__ __attribute__((aligned(16))) char smem_raw[TILE_B > LABEL_SMEM_BYTES ? TILE_B : LABEL_SMEM_BYTES];
     __shared__ uint32_t lbits[GATHER_CW / 32];
     __shared__ float red[GATHER_THREADS / 64];
+    if ((int)blockIdx.y == label_slice) {
+        if (blockIdx.x == 0) label_stats_block<GATHER_THREADS>(job, smem_raw);
+        return;
+    }
+    T* lx = reinterpret_cast<T*>(smem_raw);
+    T* lxc = lx + GATHER_CW;
     const int i = blockIdx.x;            // batch row (0..Bp-1)
     const int c0 = blockIdx.y * GATHER_CW;
     const int tid = threadIdx.x;
@@ -152,11 +161,10 @@ __global__ void rowsq_reduce_kernel(const float* __restrict__ part, int nparts, 
 
 using namespace dae;
 
-extern "C" int dae_gather_csr_bits(const int64_t* indptr, const int32_t* indices, const float* values, const int32_t* row_idx,
-                                   int32_t B, int32_t F, int32_t dtype, void* x, void* xc, int64_t ldx, void* xct, int64_t ldt,
-                                   float* rowsq, int32_t corr_mode, const uint32_t* keep_bits, uint64_t seed,
-                                   uint32_t rng_stream, float corr_frac, float scale, uint32_t* xc_bits, int64_t ldw,
-                                   void* stream) {
+int dae::launch_gather_csr(const int64_t* indptr, const int32_t* indices, const float* values, const int32_t* row_idx, int B, int F,
+                           int dtype, void* x, void* xc, int64_t ldx, void* xct, int64_t ldt, float* rowsq, int corr_mode,
+                           const uint32_t* keep_bits, uint64_t seed, uint32_t rng_stream, float corr_frac, float scale,
+                           uint32_t* xc_bits, int64_t ldw, const LabelJob* label_job, hipStream_t st) {
     DAE_CHECK_ARG(indptr && indices && row_idx, "gather_csr: null CSR / row_idx");
     DAE_CHECK_ARG(B > 0 && F > 0, "gather_csr: B=%d F=%d", B, F);
     DAE_CHECK_ARG(ldx >= F && ldx % DAE_PAD == 0, "gather_csr: ldx=%lld must be the padded feature count", (long long)ldx);
@@ -165,19 +173,32 @@ extern "C" int dae_gather_csr_bits(const int64_t* indptr, const int32_t* indices
     DAE_CHECK_ARG(!xct || ldt >= dae_pad(B), "gather_csr: ldt too small");
     DAE_CHECK_ARG(!xc_bits || (!values && scale == 1.0f), "gather_csr: the bit-packed x~ needs binary data (values == NULL) and scale == 1");
     DAE_CHECK_ARG(!xc_bits || ldw >= ldx / 32, "gather_csr: ldw too small");
+    DAE_CHECK_ARG(!label_job || label_job->Bp <= 1024, "gather_csr: the in-kernel label statistics need a padded batch <= 1024");
     const int Bp = (int)dae_pad(B);
-    dim3 grid(Bp, (unsigned)((ldx + GATHER_CW - 1) / GATHER_CW)), block(GATHER_THREADS);
-    hipStream_t st = (hipStream_t)stream;
+    const unsigned chunks = (unsigned)((ldx + GATHER_CW - 1) / GATHER_CW);
+    dim3 grid(Bp, chunks + (label_job ? 1u : 0u)), block(GATHER_THREADS);
+    LabelJob job; memset(&job, 0, sizeof(job));
+    if (label_job) job = *label_job;
+    const int label_slice = label_job ? (int)chunks : -1;
     if (dtype == DAE_BF16)
         hipLaunchKernelGGL((gather_csr_kernel<bf16_t>), grid, block, 0, st, indptr, indices, values, row_idx, B, F,
                            (bf16_t*)x, (bf16_t*)xc, ldx, (bf16_t*)xct, ldt, rowsq, corr_mode, keep_bits, seed, rng_stream,
-                           corr_frac, scale, xc_bits, ldw);
+                           corr_frac, scale, xc_bits, ldw, job, label_slice);
     else
         hipLaunchKernelGGL((gather_csr_kernel<float>), grid, block, 0, st, indptr, indices, values, row_idx, B, F,
                            (float*)x, (float*)xc, ldx, (float*)xct, ldt, rowsq, corr_mode, keep_bits, seed, rng_stream,
-                           corr_frac, scale, xc_bits, ldw);
+                           corr_frac, scale, xc_bits, ldw, job, label_slice);
     DAE_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int dae_gather_csr_bits(const int64_t* indptr, const int32_t* indices, const float* values, const int32_t* row_idx,
+                                   int32_t B, int32_t F, int32_t dtype, void* x, void* xc, int64_t ldx, void* xct, int64_t ldt,
+                                   float* rowsq, int32_t corr_mode, const uint32_t* keep_bits, uint64_t seed,
+                                   uint32_t rng_stream, float corr_frac, float scale, uint32_t* xc_bits, int64_t ldw,
+                                   void* stream) {
+    return launch_gather_csr(indptr, indices, values, row_idx, B, F, dtype, x, xc, ldx, xct, ldt, rowsq, corr_mode, keep_bits, seed,
+                             rng_stream, corr_frac, scale, xc_bits, ldw, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int dae_gather_csr(const int64_t* indptr, const int32_t* indices, const float* values, const int32_t* row_idx,

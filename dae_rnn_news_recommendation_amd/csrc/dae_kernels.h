@@ -29,6 +29,30 @@ int launch_gemm_f32out(int dtype, int M, int N, const void* A0, int64_t lda0, co
 enum { GEMM_ROLE_GENERIC = 0, GEMM_ROLE_ENCODE = 1, GEMM_ROLE_DH = 2, GEMM_ROLE_DW = 3, GEMM_ROLE_GRAM = 4 };
 int launch_decode_loss(int dtype, int Bp, int Fp, int Hp, const void* h_lo, int64_t ldh, const void* W_lo, int64_t ldw,
                        const DecodeEpi& e, hipStream_t st);
+// label statistics job (dae_label.h): either its own launch or an extra block of the CSR gather kernel
+struct LabelJob {
+    const int32_t* labels; int B, Bp, triplet; int64_t* nvalid; int64_t* dw; float* cw; float alpha; float* tri_scalars;
+};
+int launch_gather_csr(const int64_t* indptr, const int32_t* indices, const float* values, const int32_t* row_idx, int B, int F, int dtype,
+                      void* x, void* xc, int64_t ldx, void* xct, int64_t ldt, float* rowsq, int corr_mode, const uint32_t* keep_bits,
+                      uint64_t seed, uint32_t rng_stream, float corr_frac, float scale, uint32_t* xc_bits, int64_t ldw,
+                      const LabelJob* label_job, hipStream_t st);
+
+// ---- argument packs of the step-tail kernel (bias gradients + statistics + x~^T un-scatter in one launch) ----
+struct BiasArgs {
+    const float* dbv_part; int n_row_waves; const float* colsum_part; int n_row_blocks;
+    float* bh; int H, Hp, F, Fp, enc_act; float* dbh; float* dbv;
+    int apply, opt; float lr, mom, gscale; float* bv; float* s1b; float* s2b;
+};
+struct StatsArgs {
+    const float* rowloss_part; int n_col_waves; const float* tile_part; int n_tiles; const float* cw; int B, Bp, triplet;
+    float alpha; float* tri_scalars; const int64_t* nvalid; float* stats; const float* loss_part; const uint32_t* cnt_part;
+};
+struct ClearArgs {            // CSR rows whose entries were scattered into x~^T [Fp x ldt] this step
+    const int64_t* indptr; const int32_t* indices; const int32_t* row_idx; int B, F; void* xct; int64_t ldt; int es;
+};
+int launch_step_tail(const BiasArgs& ba, const StatsArgs* sa, const ClearArgs* ca, hipStream_t st);
+
 // epilogue of the fused dW + optimizer GEMM (gemm_dw_opt): parameters updated in place from the gradient tile
 struct OptEpi {
     float* W;                 // [Fp x ldw] fp32 master weights
