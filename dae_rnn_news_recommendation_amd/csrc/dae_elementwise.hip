@@ -122,18 +122,26 @@ __global__ __launch_bounds__(256) void sym_scale_kernel(const float* __restrict_
     __shared__ float tile[64][65];
     const int j0 = blockIdx.x * 64, i0 = blockIdx.y * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const float sc = tri_scalars[0];
-#pragma unroll 4
-    for (int r = ty; r < 64; r += 4) {   // tile of G^T: element (j0+r, i0+tx)
-        const int a = j0 + r, b = i0 + tx;
-        tile[r][tx] = (a < B && b < B) ? G[(int64_t)a * Bp + b] : 0.f;
+    // all 32 loads of a thread are issued before the first use (the kernel is pure latency: 196 blocks, 3 MB)
+    float gt[16], gd[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int r = ty + 4 * k;
+        const int a = j0 + r, b = i0 + tx;             // tile of G^T: element (j0+r, i0+tx)
+        gt[k] = (a < B && b < B) ? G[(int64_t)a * Bp + b] : 0.f;
+        const int i = i0 + r, j = j0 + tx;
+        gd[k] = (i < B && j < B) ? G[(int64_t)i * Bp + j] : 0.f;
     }
+    const float sc = tri_scalars[0];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) tile[ty + 4 * k][tx] = gt[k];
     __syncthreads();
-#pragma unroll 4
-    for (int r = ty; r < 64; r += 4) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int r = ty + 4 * k;
         const int i = i0 + r, j = j0 + tx;
         float v = 0.f;
-        if (i < B && j < B) v = sc * (G[(int64_t)i * Bp + j] + tile[tx][r]);
+        if (i < B && j < B) v = sc * (gd[k] + tile[tx][r]);
         Gs[(int64_t)i * Bp + j] = Elem<T>::from(v);
     }
 }
@@ -293,13 +301,17 @@ __device__ __forceinline__ float opt_update(int opt, float lr, float mom, float 
 __device__ __forceinline__ void bias_grads_body(const BiasArgs& a, int k) {
     if (k < a.Fp) {
         float s = 0.f;
-        if (k < a.F) for (int p = 0; p < a.n_row_waves; ++p) s += a.dbv_part[(int64_t)p * a.Fp + k];
+        if (k < a.F) {
+#pragma unroll 8
+            for (int p = 0; p < a.n_row_waves; ++p) s += a.dbv_part[(int64_t)p * a.Fp + k];
+        }
         a.dbv[k] = s;
         if (a.apply) a.bv[k] = opt_update(a.opt, a.lr, a.mom, a.bv[k], s * a.gscale, a.s1b, a.s2b, (int64_t)a.Hp + k);
     } else if (k < a.Fp + a.Hp) {
         const int j = k - a.Fp;
         float s1 = 0.f, s2 = 0.f;
         if (j < a.H) {
+#pragma unroll 8
             for (int p = 0; p < a.n_row_blocks; ++p) {
                 s1 += a.colsum_part[(int64_t)p * a.Hp + j];
                 s2 += a.colsum_part[((int64_t)a.n_row_blocks + p) * a.Hp + j];

@@ -14,13 +14,13 @@ ap.add_argument("--steps", type=int, default=20); ap.add_argument("--rows", type
 ap.add_argument("--features", type=int, default=10000); ap.add_argument("--hidden", type=int, default=500)
 ap.add_argument("--batch", type=int, default=800); ap.add_argument("--loss", default="cross_entropy")
 ap.add_argument("--enc-splits", type=int, default=0); ap.add_argument("--tag", default="")
-ap.add_argument("--nst", type=int, default=-1); ap.add_argument("--phase", type=int, default=3)
+ap.add_argument("--nst", type=int, default=-1); ap.add_argument("--phase", type=int, default=3); ap.add_argument("--gram-splits", type=int, default=0)
 a = ap.parse_args()
 if a.nst >= 0:
     L.load().dae_set_glds(a.nst)
 m = synthetic_csr(a.rows, a.features, seed=1); lab = synthetic_labels(a.rows, seed=1).astype(np.int32)
 eng = Engine(a.features, a.hidden, a.batch, dtype=a.precision, triplet=a.strategy, loss_func=a.loss, learning_rate=0.1,
-             encode_splits=a.enc_splits, dh_splits=a.enc_splits)
+             encode_splits=a.enc_splits, dh_splits=a.enc_splits, gram_splits=a.gram_splits)
 eng.upload_csr(m); eng.set_params(xavier_uniform(a.features, a.hidden))
 idx = torch.arange(a.batch, dtype=torch.int32, device="cuda"); labs = torch.from_numpy(lab[:a.batch]).cuda()
 stats = torch.zeros(8, device="cuda")
