@@ -224,7 +224,7 @@ def main():
         # headline roofline: the fused encode GEMM named by BASELINE.json's north_star
         e = kern.get("encode_gemm")
         if e:
-            out["roofline"] = {"kernel": "encode_gemm (gemm_nt_f32out, x~[BxF].W[FxH], split-K)", "bound": "mfma",
+            out["roofline"] = {"kernel": "encode_gemm (gemm_nt_pc<bf16, 4, ENCODE>: x~[BxF].W[FxH], split-K 8, 8-wave producer/consumer)", "bound": "mfma",
                                "achieved": e["achieved_tflops"], "peak": e["peak_tflops"], "unit": "TFLOP/s", "frac": e["frac"],
                                "traffic": committed_traffic("encode_gemm"),
                                "algorithmic": f"2*B*F*H = {2.0 * B * F * H / 1e9:.2f} GFLOP per launch (dense accounting)"}

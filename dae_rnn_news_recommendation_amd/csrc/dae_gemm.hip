@@ -456,74 +456,89 @@ __device__ __forceinline__ float opt_apply_elem(int opt, float lr, float mom, fl
 constexpr int DWO_PITCH = 272;                        // staged bf16 row: 128 elements + 16 B pad
 constexpr int DWO_TILE_BYTES = 128 * DWO_PITCH;
 
+template <int OPT>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_dw_opt(GemmParams p, OptEpi e) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     int tm, tn, split, kt0, kt1;
     if (!block_to_tile(p, tm, tn, split, kt0, kt1)) return;
-    f32x16 acc[2][2];
-    gemm_mainloop<bf16_t, 2>(p, tm, tn, kt0, kt1, lds, acc);
-    __syncthreads();                                   // the K-loop stages are dead: reuse the LDS for the shadow tiles
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, g = lane >> 5, c = lane & 31;
-    char* R0 = lds;                                    // W_lo tile   [f_local][h_local]
-    char* R1 = lds + DWO_TILE_BYTES;                   // Wt_lo tile  [h_local][f_local]
     const int lrow0 = wm * 64 + 4 * g, lcol0 = wn * 64 + c;
     float* __restrict__ Wp = e.W;
     float* __restrict__ gradp = e.grad;
     float* __restrict__ s1p = e.s1;
     float* __restrict__ s2p = e.s2;
-    const int opt = e.opt;
     const float lr = e.lr, mom = e.mom, gscale = e.gscale;
-    // one (mt) half at a time: all 32 master-weight (and slot) loads of the half are in flight together -- the update is
-    // a load -> FMA -> store chain per element and would otherwise pay one HBM latency 64 times per thread
-    auto half = [&](auto MT) {
-        constexpr int mt = decltype(MT)::value;
-        float wv[2][16], a1[2][16], a2[2][16];
+    // this lane's 64 master weights are requested BEFORE the K loop: the epilogue is a load -> FMA -> store chain per
+    // element with only 8 waves per CU to hide HBM latency behind, so the loads ride under the 28 K tiles instead
+    // (plain SGD only: the stateful optimizers need the registers for their slots and load W with them, per quarter tile)
+    constexpr bool PREFETCH_W = (OPT == DAE_OPT_SGD);
+    float wv[2][2][16];
+    if constexpr (PREFETCH_W) {
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int lrow = lrow0 + mt * 32 + (r & 3) + 8 * (r >> 2), lcol = lcol0 + nt * 32;
+                    wv[mt][nt][r] = Wp[(int64_t)(tm * BM + lrow) * e.ldw + tn * BN + lcol];
+                }
+    }
+    f32x16 acc[2][2];
+    gemm_mainloop<bf16_t, 2>(p, tm, tn, kt0, kt1, lds, acc);
+    __syncthreads();                                   // the K-loop stages are dead: reuse the LDS for the shadow tiles
+    char* R0 = lds;                                    // W_lo tile   [f_local][h_local]
+    char* R1 = lds + DWO_TILE_BYTES;                   // Wt_lo tile  [h_local][f_local]
+    auto quarter = [&](auto MT, auto NT) {
+        constexpr int mt = decltype(MT)::value, nt = decltype(NT)::value;
+        float a1[16], a2[16];
+        if constexpr (OPT != DAE_OPT_SGD) {            // optimizer slots of the quarter: all loads in flight together
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int lrow = lrow0 + mt * 32 + (r & 3) + 8 * (r >> 2), lcol = lcol0 + nt * 32;
                 const int64_t k = (int64_t)(tm * BM + lrow) * e.ldw + tn * BN + lcol;
-                wv[nt][r] = Wp[k];
-                a1[nt][r] = (opt != DAE_OPT_SGD) ? s1p[k] : 0.f;
-                a2[nt][r] = (opt == DAE_OPT_ADAM) ? s2p[k] : 0.f;
+                wv[mt][nt][r] = Wp[k];
+                a1[r] = s1p[k];
+                a2[r] = (OPT == DAE_OPT_ADAM) ? s2p[k] : 0.f;
             }
+            __builtin_amdgcn_sched_barrier(0);         // keep the next quarter's loads behind this quarter's stores
+        }
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int r4 = 0; r4 < 4; ++r4) {
+            float pv[4];
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                float pv[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int r = r4 * 4 + q;
-                    const int lrow = lrow0 + mt * 32 + 8 * r4 + q, lcol = lcol0 + nt * 32;
-                    const int64_t k = (int64_t)(tm * BM + lrow) * e.ldw + tn * BN + lcol;
-                    const float gr = acc[mt][nt][r];
-                    if (gradp) gradp[k] = gr;
-                    const float g = gr * gscale, p0 = wv[nt][r];
-                    float pn;
-                    if (opt == DAE_OPT_SGD) pn = p0 - lr * g;
-                    else if (opt == DAE_OPT_ADAGRAD) { const float a = a1[nt][r] + g * g; s1p[k] = a; pn = p0 - lr * g * rsqrtf(a); }
-                    else if (opt == DAE_OPT_MOMENTUM) { const float a = mom * a1[nt][r] + g; s1p[k] = a; pn = p0 - lr * a; }
-                    else {
-                        const float m = 0.9f * a1[nt][r] + 0.1f * g;
-                        const float v = 0.999f * a2[nt][r] + 0.001f * g * g;
-                        s1p[k] = m; s2p[k] = v;
-                        pn = p0 - lr * m / (sqrtf(v) + 1e-8f);
-                    }
-                    Wp[k] = pn;
-                    pv[q] = pn;
-                    *reinterpret_cast<bf16_t*>(R0 + lrow * DWO_PITCH + lcol * 2) = f2bf_hw(pn);
+            for (int q = 0; q < 4; ++q) {
+                const int r = r4 * 4 + q;
+                const int lrow = lrow0 + mt * 32 + 8 * r4 + q, lcol = lcol0 + nt * 32;
+                const int64_t k = (int64_t)(tm * BM + lrow) * e.ldw + tn * BN + lcol;
+                const float gr = acc[mt][nt][r];
+                if (gradp) gradp[k] = gr;
+                const float gg = gr * gscale, p0 = wv[mt][nt][r];
+                float pn;
+                if constexpr (OPT == DAE_OPT_SGD) pn = p0 - lr * gg;
+                else if constexpr (OPT == DAE_OPT_ADAGRAD) { const float a = a1[r] + gg * gg; s1p[k] = a; pn = p0 - lr * gg * rsqrtf(a); }
+                else if constexpr (OPT == DAE_OPT_MOMENTUM) { const float a = mom * a1[r] + gg; s1p[k] = a; pn = p0 - lr * a; }
+                else {
+                    const float m = 0.9f * a1[r] + 0.1f * gg;
+                    const float v = 0.999f * a2[r] + 0.001f * gg * gg;
+                    s1p[k] = m; s2p[k] = v;
+                    pn = p0 - lr * m / (sqrtf(v) + 1e-8f);
                 }
-                uint2 v;
-                v.x = f2bf_pack_hw(pv[0], pv[1]);
-                v.y = f2bf_pack_hw(pv[2], pv[3]);
-                *reinterpret_cast<uint2*>(R1 + (lcol0 + nt * 32) * DWO_PITCH + (lrow0 + mt * 32 + 8 * r4) * 2) = v;
+                Wp[k] = pn;
+                pv[q] = pn;
+                *reinterpret_cast<bf16_t*>(R0 + lrow * DWO_PITCH + lcol * 2) = f2bf_hw(pn);
             }
+            uint2 v;
+            v.x = f2bf_pack_hw(pv[0], pv[1]);
+            v.y = f2bf_pack_hw(pv[2], pv[3]);
+            *reinterpret_cast<uint2*>(R1 + (lcol0 + nt * 32) * DWO_PITCH + (lrow0 + mt * 32 + 8 * r4) * 2) = v;
+        }
     };
-    half(std::integral_constant<int, 0>{});
-    half(std::integral_constant<int, 1>{});
+    quarter(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    quarter(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+    quarter(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+    quarter(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
     __syncthreads();
     bf16_t* Wlo = reinterpret_cast<bf16_t*>(e.W_lo);
     bf16_t* Wtlo = reinterpret_cast<bf16_t*>(e.Wt_lo);
@@ -1168,13 +1183,17 @@ int launch_dw_opt(int M, int N, const void* A0, int64_t lda0, const void* Bt0, i
     DAE_CHECK_ARG(e.W && e.W_lo && e.Wt_lo && e.ldw >= N && e.ldwt >= M && e.ldw % 8 == 0 && e.ldwt % 8 == 0, "dw_opt: bad parameter images");
     DAE_CHECK_ARG(e.opt >= DAE_OPT_SGD && e.opt <= DAE_OPT_ADAM && (e.opt == DAE_OPT_SGD || e.s1) && (e.opt != DAE_OPT_ADAM || e.s2),
                   "dw_opt: optimizer slots missing");
+    typedef void (*dwo_fn)(GemmParams, OptEpi);
+    static const dwo_fn fns[4] = {gemm_dw_opt<DAE_OPT_SGD>, gemm_dw_opt<DAE_OPT_ADAGRAD>, gemm_dw_opt<DAE_OPT_MOMENTUM>, gemm_dw_opt<DAE_OPT_ADAM>};
+    constexpr int ldsb = 2 * DWO_TILE_BYTES > lds_bytes_for(2) ? 2 * DWO_TILE_BYTES : lds_bytes_for(2);
     static int attr_rc = [] {
-        return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dw_opt), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        2 * DWO_TILE_BYTES > lds_bytes_for(2) ? 2 * DWO_TILE_BYTES : lds_bytes_for(2));
+        int rc = 0;
+        for (dwo_fn f : fns) rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);
+        return rc;
     }();
     DAE_CHECK_ARG(attr_rc == 0, "dw_opt: hipFuncSetAttribute failed");
-    const int ldsb = 2 * DWO_TILE_BYTES > lds_bytes_for(2) ? 2 * DWO_TILE_BYTES : lds_bytes_for(2);
-    hipLaunchKernelGGL(gemm_dw_opt, dim3(grid_blocks(p)), dim3(GEMM_THREADS), ldsb, st, p, e);
+    static_assert(DAE_OPT_SGD == 0 && DAE_OPT_ADAGRAD == 1 && DAE_OPT_MOMENTUM == 2 && DAE_OPT_ADAM == 3, "optimizer enum order");
+    hipLaunchKernelGGL(fns[e.opt], dim3(grid_blocks(p)), dim3(GEMM_THREADS), ldsb, st, p, e);
     DAE_CHECK_LAUNCH();
     return 0;
 }
