@@ -27,10 +27,20 @@ __global__ __launch_bounds__(256) void encode_finish_kernel(const float* __restr
     float z[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) z[k] = 0.f;
-    for (int s = 0; s < splits; ++s) {                  // 8 independent loads in flight per slab
-        const float* sl = slabs + (int64_t)s * slab_stride + (int64_t)i0 * ld_slab + j;
+    // slabs in groups of 4: 32 independent loads in flight per thread (the kernel is latency-bound: 224 blocks, one HBM
+    // round trip per group instead of one per slab); the summation order over slabs is unchanged
+    for (int s0 = 0; s0 < splits; s0 += 4) {
+        float t[4][8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) z[k] += sl[(int64_t)(ty + 4 * k) * ld_slab];
+        for (int u = 0; u < 4; ++u) {
+            const float* sl = slabs + (int64_t)(s0 + u) * slab_stride + (int64_t)i0 * ld_slab + j;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[u][k] = (s0 + u < splits) ? sl[(int64_t)(ty + 4 * k) * ld_slab] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) z[k] += t[u][k];
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -78,10 +88,18 @@ __global__ __launch_bounds__(256) void dh_finish_kernel(const float* __restrict_
     float dhv[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) dhv[k] = 0.f;
-    for (int s = 0; s < splits; ++s) {
-        const float* sl = slabs + (int64_t)s * slab_stride + (int64_t)i0 * ld_slab + j;
+    for (int s0 = 0; s0 < splits; s0 += 4) {            // 4 slabs = 32 loads in flight (see encode_finish_kernel)
+        float t[4][8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) dhv[k] += sl[(int64_t)(ty + 4 * k) * ld_slab];
+        for (int u = 0; u < 4; ++u) {
+            const float* sl = slabs + (int64_t)(s0 + u) * slab_stride + (int64_t)i0 * ld_slab + j;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[u][k] = (s0 + u < splits) ? sl[(int64_t)(ty + 4 * k) * ld_slab] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) dhv[k] += t[u][k];
     }
     float s_d1 = 0.f, s_dh = 0.f;
 #pragma unroll

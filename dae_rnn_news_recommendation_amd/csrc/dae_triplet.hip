@@ -274,13 +274,21 @@ __global__ __launch_bounds__(TRIP_THREADS, OCC) void batch_all_kernel(const floa
             lj[k] = (j < B) ? labels[j] : la;
             dj[k] = 0.f;
         }
-        for (int sl = 0; sl < d_splits; ++sl) {
-            const float* Drow = D_slabs + (int64_t)sl * slab_stride + (int64_t)a * ldd;
+        for (int s0 = 0; s0 < d_splits; s0 += 4) {          // 4 K-slices of the Gram matrix at a time: 16 loads in flight
+            float dd[4][KU];
 #pragma unroll
-            for (int k = 0; k < KU; ++k) {
-                const int j = k * TRIP_THREADS + tid;
-                if (j < B) dj[k] += Drow[j];
+            for (int u = 0; u < 4; ++u) {
+                const float* Drow = D_slabs + (int64_t)(s0 + u) * slab_stride + (int64_t)a * ldd;
+#pragma unroll
+                for (int k = 0; k < KU; ++k) {
+                    const int j = k * TRIP_THREADS + tid;
+                    dd[u][k] = (j < B && s0 + u < d_splits) ? Drow[j] : 0.f;
+                }
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < KU; ++k) dj[k] += dd[u][k];
         }
         unsigned long long bp[KU], bn[KU];
 #pragma unroll
