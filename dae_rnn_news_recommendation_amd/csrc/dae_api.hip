@@ -106,7 +106,8 @@ struct dae_plan {
     bool gram_split;                 // Gram matrix as a 3-term split-bf16 MFMA GEMM (bf16 mode) instead of exact-fp32 MFMA
     float *slabs, *h_f32, *D_slabs, *G, *rowloss_part, *dbv_part, *colsum_part, *cos_part, *cos_stats, *cw, *loss_part,
         *dw_f32, *tri_scalars, *dh_extra, *rowsq_scratch, *tile_part;
-    uint32_t *cnt_part, *role_cnt, *xc_bits;
+    uint32_t *cnt_part, *role_cnt, *xc_bits, *x_bits;
+    bool xbits_ok;                   // binary CSR + bf16: the decode epilogue reads x as a bit image (DAE_NO_XBITS=1 disables)
     bool xct_clean;                  // x~^T holds only zeros (every step un-scatters what it wrote; see step_tail_kernel)
     bool tail_ok;                    // DAE_NO_TAIL=1: separate bias_grads / step_stats launches and a full memset per step (A/B)
     bool fuse_opt_ok;                // DAE_NO_FUSED_OPT=1 keeps the separate optimizer kernel (A/B)
@@ -138,6 +139,7 @@ static uint64_t carve(dae_plan* p, char* base) {
     p->xc = take(Bp * Fp * es);
     p->xct = take(Fp * Bp * es);
     p->xc_bits = (uint32_t*)take(Bp * (Fp / 32) * 4);
+    p->x_bits = (uint32_t*)take(Bp * (Fp / 32) * 4);
     p->delta2 = take(Bp * Fp * es);
     p->delta2_t = take(Fp * Bp * es);
     const int smax = p->s_enc > p->s_dh ? p->s_enc : p->s_dh;
@@ -202,6 +204,7 @@ extern "C" int dae_plan_create(const dae_config* cfg, dae_plan** out) {
     p->ws_bytes = carve(p, nullptr);
     p->fuse_opt_ok = getenv("DAE_NO_FUSED_OPT") == nullptr;
     p->tail_ok = getenv("DAE_NO_TAIL") == nullptr;
+    p->xbits_ok = cfg->dtype == DAE_BF16 && getenv("DAE_NO_XBITS") == nullptr;
     p->xct_clean = false;
     p->bits_ok = cfg->dtype == DAE_BF16 && getenv("DAE_BITS") != nullptr;
     p->overlap_ok = getenv("DAE_OVERLAP") != nullptr;   // measured: running the miner chain beside decode is SLOWER (0.410 vs 0.351 ms/step)
@@ -283,10 +286,11 @@ extern "C" int dae_plan_info(const dae_plan* p, int32_t* out8) {
 static int gather_batch(dae_plan* p, const int64_t* indptr, const int32_t* indices, const float* values, const float* dense,
                         int64_t ld_dense, const int32_t* row_idx, int B, void* x, void* xc, void* xct, float* rowsq,
                         int corr_mode, const uint32_t* keep_bits, uint64_t seed, uint32_t rng_stream, float corr_frac,
-                        float scale, void* stream, uint32_t* xc_bits = nullptr, const LabelJob* label_job = nullptr) {
+                        float scale, void* stream, uint32_t* xc_bits = nullptr, const LabelJob* label_job = nullptr,
+                        uint32_t* x_bits = nullptr) {
     if (indptr)
         return launch_gather_csr(indptr, indices, values, row_idx, B, p->F, p->cfg.dtype, x, xc, p->Fp, xct, p->Bpm, rowsq, corr_mode,
-                                 keep_bits, seed, rng_stream, corr_frac, scale, xc_bits, p->Fp / 32, label_job, (hipStream_t)stream);
+                                 keep_bits, seed, rng_stream, corr_frac, scale, xc_bits, p->Fp / 32, label_job, (hipStream_t)stream, x_bits);
     DAE_CHECK_ARG(dense, "step: no train set bound");
     return dae_gather_dense(dense, ld_dense, row_idx, B, p->F, p->cfg.dtype, x, xc, p->Fp, xct, p->Bpm, rowsq, p->rowsq_scratch,
                             corr_mode, keep_bits, seed, rng_stream, corr_frac, scale, stream);
@@ -356,17 +360,20 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     if (backward) p->xct_clean = false;
     float* rowsq = is_cos ? p->cos_stats : nullptr;
     bool use_bits = false;
+    // binary CSR train set in bf16 mode: the clean rows reach the decode epilogue as a bit image (1.1 MB, not 18 MB)
+    const bool use_xbits = p->xbits_ok && p->b.indptr && !p->b.values;
     if (s->c_indptr) {   // an explicitly corrupted copy of the train set (salt&pepper, host-side noise)
-        PROF(PS_GATHER, gather_batch(p, p->b.indptr, p->b.indices, p->b.values, p->b.dense, p->b.ld_dense, s->row_idx, B, p->x, nullptr, nullptr,
-                        rowsq, DAE_CORR_NONE, nullptr, 0, 0, 0.f, 1.f, stream));
+        PROF(PS_GATHER, gather_batch(p, p->b.indptr, p->b.indices, p->b.values, p->b.dense, p->b.ld_dense, s->row_idx, B, use_xbits ? nullptr : p->x,
+                        nullptr, nullptr, rowsq, DAE_CORR_NONE, nullptr, 0, 0, 0.f, 1.f, stream, nullptr, nullptr, use_xbits ? p->x_bits : nullptr));
         PROF(PS_GATHER, gather_batch(p, s->c_indptr, s->c_indices, s->c_values, nullptr, 0, s->row_idx, B, nullptr, p->xc,
                         backward ? p->xct : nullptr, nullptr, DAE_CORR_NONE, nullptr, 0, 0, 0.f, s->scale, stream));
     } else {
         // binary CSR, unit scale, bf16: the corrupted batch goes to the encode GEMM as a BIT image (1.1 MB, not 18 MB of bf16)
         use_bits = p->bits_ok && p->b.indptr && !p->b.values && s->scale == 1.0f;
-        PROF(PS_GATHER, gather_batch(p, p->b.indptr, p->b.indices, p->b.values, p->b.dense, p->b.ld_dense, s->row_idx, B, p->x,
-                        use_bits ? nullptr : p->xc, backward ? p->xct : nullptr, rowsq, s->corr_mode, s->keep_bits, s->seed, s->rng_stream,
-                        s->corr_frac, s->scale, stream, use_bits ? p->xc_bits : nullptr, label_in_gather ? &lj : nullptr));
+        PROF(PS_GATHER, gather_batch(p, p->b.indptr, p->b.indices, p->b.values, p->b.dense, p->b.ld_dense, s->row_idx, B,
+                        use_xbits ? nullptr : p->x, use_bits ? nullptr : p->xc, backward ? p->xct : nullptr, rowsq, s->corr_mode, s->keep_bits,
+                        s->seed, s->rng_stream, s->corr_frac, s->scale, stream, use_bits ? p->xc_bits : nullptr, label_in_gather ? &lj : nullptr,
+                        use_xbits ? p->x_bits : nullptr));
     }
     // 3-4. encode (K1/K2)
     const int64_t slab = (int64_t)Bp * Hp;
@@ -432,7 +439,7 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     const int ncw = 2 * Fp / 128;
     DecodeEpi e;
     memset(&e, 0, sizeof(e));
-    e.bv = p->b.bv; e.x = p->x; e.ldx = Fp; e.cw = p->cw; e.cos_stats = is_cos ? p->cos_stats : nullptr;
+    e.bv = p->b.bv; e.x = p->x; e.ldx = Fp; e.x_bits = use_xbits ? p->x_bits : nullptr; e.ldxb = Fp / 32; e.cw = p->cw; e.cos_stats = is_cos ? p->cos_stats : nullptr;
     e.rowloss_part = is_cos ? p->rowloss_part : nullptr; e.tile_part = is_cos ? nullptr : p->tile_part;
     e.dbv_part = backward ? p->dbv_part : nullptr; e.cos_part = p->cos_part;
     e.delta2 = backward ? p->delta2 : nullptr; e.ldd = Fp; e.delta2_t = backward ? p->delta2_t : nullptr; e.lddt = ldB;

@@ -33,11 +33,12 @@ __global__ __launch_bounds__(GATHER_THREADS) void gather_csr_kernel(
     const int32_t* __restrict__ row_idx, int B, int F, T* __restrict__ x, T* __restrict__ xc, int64_t ldx,
     T* __restrict__ xct, int64_t ldt, float* __restrict__ rowsq, int corr_mode, const uint32_t* __restrict__ keep_bits,
     uint64_t seed, uint32_t stream, float corr_frac, float scale, uint32_t* __restrict__ xc_bits, int64_t ldw,
-    LabelJob job, int label_slice) {
+    LabelJob job, int label_slice, uint32_t* __restrict__ x_bits) {
     // row tiles; the same LDS serves the label-statistics block (blockIdx.y == label_slice, blockIdx.x == 0)
     constexpr int TILE_B = 2 * GATHER_CW * (int)sizeof(T);
     __shared__ __attribute__((aligned(16))) char smem_raw[TILE_B > LABEL_SMEM_BYTES ? TILE_B : LABEL_SMEM_BYTES];
     __shared__ uint32_t lbits[GATHER_CW / 32];
+    __shared__ uint32_t lbits_x[GATHER_CW / 32];
     __shared__ float red[GATHER_THREADS / 64];
     if ((int)blockIdx.y == label_slice) {
         if (blockIdx.x == 0) label_stats_block<GATHER_THREADS>(job, smem_raw);
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(GATHER_THREADS) void gather_csr_kernel(
         *reinterpret_cast<i32x4*>(&lx[k]) = i32x4{0, 0, 0, 0};
         *reinterpret_cast<i32x4*>(&lxc[k]) = i32x4{0, 0, 0, 0};
     }
-    if (tid < GATHER_CW / 32) lbits[tid] = 0u;
+    if (tid < GATHER_CW / 32) { lbits[tid] = 0u; lbits_x[tid] = 0u; }
     __syncthreads();
     if (i < B) {
         const int64_t row = row_idx[i];
@@ -80,6 +81,7 @@ __global__ __launch_bounds__(GATHER_THREADS) void gather_csr_kernel(
                 lx[col - c0] = Elem<T>::from(v);
                 lxc[col - c0] = Elem<T>::from(vc);
                 if (xc_bits && keep) atomicOr(&lbits[(col - c0) >> 5], 1u << ((col - c0) & 31));
+                if (x_bits) atomicOr(&lbits_x[(col - c0) >> 5], 1u << ((col - c0) & 31));
                 if (xct && keep) xct[(int64_t)col * ldt + i] = Elem<T>::from(vc);
             }
         }
@@ -105,6 +107,8 @@ __global__ __launch_bounds__(GATHER_THREADS) void gather_csr_kernel(
     }
     // bit-packed x~ (binary inputs): bit b of word w of row i <=> feature 32*w + b is kept.  Operand of gemm_encode_bits.
     if (xc_bits && tid < (ncol >> 5)) xc_bits[(int64_t)i * ldw + (c0 >> 5) + tid] = lbits[tid];
+    // bit image of the CLEAN row (binary inputs): what the decode epilogue reads instead of the dense x tile
+    if (x_bits && tid < (ncol >> 5)) x_bits[(int64_t)i * ldw + (c0 >> 5) + tid] = lbits_x[tid];
 }
 
 // Dense ndarray input (autoencoder.py:143 sparse_input False; dense masking utils.py:107-109).
@@ -164,7 +168,7 @@ using namespace dae;
 int dae::launch_gather_csr(const int64_t* indptr, const int32_t* indices, const float* values, const int32_t* row_idx, int B, int F,
                            int dtype, void* x, void* xc, int64_t ldx, void* xct, int64_t ldt, float* rowsq, int corr_mode,
                            const uint32_t* keep_bits, uint64_t seed, uint32_t rng_stream, float corr_frac, float scale,
-                           uint32_t* xc_bits, int64_t ldw, const LabelJob* label_job, hipStream_t st) {
+                           uint32_t* xc_bits, int64_t ldw, const LabelJob* label_job, hipStream_t st, uint32_t* x_bits) {
     DAE_CHECK_ARG(indptr && indices && row_idx, "gather_csr: null CSR / row_idx");
     DAE_CHECK_ARG(B > 0 && F > 0, "gather_csr: B=%d F=%d", B, F);
     DAE_CHECK_ARG(ldx >= F && ldx % DAE_PAD == 0, "gather_csr: ldx=%lld must be the padded feature count", (long long)ldx);
@@ -173,6 +177,7 @@ int dae::launch_gather_csr(const int64_t* indptr, const int32_t* indices, const 
     DAE_CHECK_ARG(!xct || ldt >= dae_pad(B), "gather_csr: ldt too small");
     DAE_CHECK_ARG(!xc_bits || (!values && scale == 1.0f), "gather_csr: the bit-packed x~ needs binary data (values == NULL) and scale == 1");
     DAE_CHECK_ARG(!xc_bits || ldw >= ldx / 32, "gather_csr: ldw too small");
+    DAE_CHECK_ARG(!x_bits || (!values && ldw >= ldx / 32), "gather_csr: the bit image of x needs binary data (values == NULL) and ldw >= Fp/32");
     DAE_CHECK_ARG(!label_job || label_job->Bp <= 1024, "gather_csr: the in-kernel label statistics need a padded batch <= 1024");
     const int Bp = (int)dae_pad(B);
     const unsigned chunks = (unsigned)((ldx + GATHER_CW - 1) / GATHER_CW);
@@ -183,11 +188,11 @@ int dae::launch_gather_csr(const int64_t* indptr, const int32_t* indices, const 
     if (dtype == DAE_BF16)
         hipLaunchKernelGGL((gather_csr_kernel<bf16_t>), grid, block, 0, st, indptr, indices, values, row_idx, B, F,
                            (bf16_t*)x, (bf16_t*)xc, ldx, (bf16_t*)xct, ldt, rowsq, corr_mode, keep_bits, seed, rng_stream,
-                           corr_frac, scale, xc_bits, ldw, job, label_slice);
+                           corr_frac, scale, xc_bits, ldw, job, label_slice, x_bits);
     else
         hipLaunchKernelGGL((gather_csr_kernel<float>), grid, block, 0, st, indptr, indices, values, row_idx, B, F,
                            (float*)x, (float*)xc, ldx, (float*)xct, ldt, rowsq, corr_mode, keep_bits, seed, rng_stream,
-                           corr_frac, scale, xc_bits, ldw, job, label_slice);
+                           corr_frac, scale, xc_bits, ldw, job, label_slice, x_bits);
     DAE_CHECK_LAUNCH();
     return 0;
 }

@@ -746,7 +746,7 @@ __global__ __launch_bounds__(GEMM_THREADS, wg_per_cu_for(NST)) void gemm_nt_trac
 constexpr int EPI_PITCH = 272;                       // bytes per staged row: 128 bf16 + 16 B pad (bank shift of 4 rows)
 constexpr int EPI_TILE_BYTES = 128 * EPI_PITCH;      // 34816
 constexpr int EPI_AUX_OFF = 2 * EPI_TILE_BYTES;      // 69632 (>= the 64 KiB of the K-loop stages)
-constexpr int EPI_AUX_FLOATS = 13 * 128;
+constexpr int EPI_AUX_FLOATS = 17 * 128;             // 13 x 128 floats + the 128 x 4 words of the x bit tile
 constexpr int DECODE_EPI_BYTES = EPI_AUX_OFF + EPI_AUX_FLOATS * 4;   // 76288 (epilogue footprint; the K loop may need more)
 
 template <typename T> __device__ __forceinline__ void store4(T* p, float a, float b, float c, float d);
@@ -784,10 +784,11 @@ template <int ACT> __device__ __forceinline__ float act_bwd(float a) {
 
 constexpr float CE_FAST_ZMAX = 14.0f;               // sigmoid(14) = 1 - 8.3e-7: five fp32 ulps from saturation
 constexpr int DECODE_NST = 2;
-template <typename T, int LOSS, int ACT>
+template <typename T, int LOSS, int ACT, bool XBITS = false>
 __global__ __launch_bounds__(GEMM_THREADS, wg_per_cu_for(DECODE_NST)) void gemm_decode_loss(GemmParams p, DecodeEpi e) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr bool STAGED = (sizeof(T) == 2);
+    static_assert(!XBITS || STAGED, "the bit image of x is a bf16-mode operand");
     constexpr bool IS_COS = (LOSS == DAE_LOSS_COSINE);
     int tm, tn, split, kt0, kt1;
     if (!block_to_tile(p, tm, tn, split, kt0, kt1)) return;
@@ -800,8 +801,12 @@ __global__ __launch_bounds__(GEMM_THREADS, wg_per_cu_for(DECODE_NST)) void gemm_
     const bool pass1 = IS_COS && e.cos_pass == 1;
 
     // ---- prefetch the clean-input tile (registers now, LDS after the K loop) ----
+    // XBITS (binary input): the tile is 128 rows x 4 words of the gather's bit image -- 2 KB instead of 32 KB
     i32x4 xr[8];
-    if constexpr (STAGED) {
+    uint2 xb = {0u, 0u};
+    if constexpr (XBITS) {
+        xb = *reinterpret_cast<const uint2*>(e.x_bits + (int64_t)(tm * BM + (tid >> 1)) * e.ldxb + tn * 4 + (tid & 1) * 2);
+    } else if constexpr (STAGED) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int ch = tid + GEMM_THREADS * i;
@@ -826,8 +831,11 @@ __global__ __launch_bounds__(GEMM_THREADS, wg_per_cu_for(DECODE_NST)) void gemm_
     float* cxy_l = aux + 1024;                         // [128] sum xhat.y       (cosine pass 2)
     float* pyy_l = aux + 1152;                         // [2][128] partial sum y^2   (cosine pass 1)
     float* pxy_l = aux + 1408;                         // [2][128] partial sum xhat.y
+    uint32_t* xb_l = reinterpret_cast<uint32_t*>(aux + 1664);   // [128][4] bit image of the clean-input tile (XBITS)
 
-    if constexpr (STAGED) {
+    if constexpr (XBITS) {
+        *reinterpret_cast<uint2*>(xb_l + (tid >> 1) * 4 + (tid & 1) * 2) = xb;
+    } else if constexpr (STAGED) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int ch = tid + GEMM_THREADS * i;
@@ -898,7 +906,8 @@ __global__ __launch_bounds__(GEMM_THREADS, wg_per_cu_for(DECODE_NST)) void gemm_
             for (int nt = 0; nt < 2; ++nt) {
                 const float z = acc[mt][nt][r] + bvv[nt];
                 float x;
-                if constexpr (STAGED) x = bf2f(*reinterpret_cast<const bf16_t*>(r0_lane + (rloc + q) * EPI_PITCH + nt * 64));
+                if constexpr (XBITS) x = (float)((xb_l[(lrow0 + rloc + q) * 4 + wn * 2 + nt] >> c) & 1u);
+                else if constexpr (STAGED) x = bf2f(*reinterpret_cast<const bf16_t*>(r0_lane + (rloc + q) * EPI_PITCH + nt * 64));
                 else x = xin[q][nt];
                 float l = 0.f, dy = 0.f;
                 if constexpr (FAST) {
@@ -1114,6 +1123,12 @@ template <typename T> static f32out_fn pc_kernel(int role) {
 static int g_cus = 0;        // compute units of the current device (set by gemm_init)
 static int g_use_pc = 1;     // DAE_NO_PC=1 keeps the 4-wave kernel for every grid (A/B)
 typedef void (*decode_fn)(GemmParams, DecodeEpi);
+static decode_fn decode_kernel_xbits(int loss, int act) {
+#define DAE_DKX(LV, AV) if (loss == LV && act == AV) return gemm_decode_loss<bf16_t, LV, AV, true>;
+    DAE_DKX(0, 0) DAE_DKX(0, 1) DAE_DKX(0, 2) DAE_DKX(1, 0) DAE_DKX(1, 1) DAE_DKX(1, 2) DAE_DKX(2, 0) DAE_DKX(2, 1) DAE_DKX(2, 2)
+#undef DAE_DKX
+    return nullptr;
+}
 template <typename T> static decode_fn decode_kernel(int loss, int act) {
 #define DAE_DK(LV, AV) if (loss == LV && act == AV) return gemm_decode_loss<T, LV, AV>;
     DAE_DK(0, 0) DAE_DK(0, 1) DAE_DK(0, 2) DAE_DK(1, 0) DAE_DK(1, 1) DAE_DK(1, 2) DAE_DK(2, 0) DAE_DK(2, 1) DAE_DK(2, 2)
@@ -1147,6 +1162,8 @@ static int gemm_init() {
                 DAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decode_kernel<bf16_t>(l, a)),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, DECODE_LDS_BYTES));
                 DAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decode_kernel<float>(l, a)),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, DECODE_LDS_BYTES));
+                DAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decode_kernel_xbits(l, a)),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, DECODE_LDS_BYTES));
             }
         return 0;
@@ -1207,6 +1224,10 @@ int launch_decode_loss(int dtype, int Bp, int Fp, int Hp, const void* h_lo, int6
     DAE_CHECK_ARG(e.ldx % 8 == 0 && (!e.delta2 || e.ldd % 8 == 0) && (!e.delta2_t || e.lddt % 8 == 0),
                   "decode_loss: leading dimensions must be multiples of 8 elements");
     decode_fn k = dtype == DAE_BF16 ? decode_kernel<bf16_t>(e.loss_func, e.dec_act) : decode_kernel<float>(e.loss_func, e.dec_act);
+    if (e.x_bits) {
+        DAE_CHECK_ARG(dtype == DAE_BF16 && e.ldxb >= Fp / 32 && e.ldxb % 2 == 0 && ((uintptr_t)e.x_bits % 8) == 0, "decode_loss: bad x bit image");
+        k = decode_kernel_xbits(e.loss_func, e.dec_act);
+    }
     dim3 grid(grid_blocks(p)), block(GEMM_THREADS);
     static const int ce_literal = getenv("DAE_CE_LITERAL") != nullptr;
     DecodeEpi ee = e;

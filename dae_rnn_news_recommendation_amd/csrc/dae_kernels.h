@@ -9,6 +9,8 @@ struct DecodeEpi {
     const float* bv;          // [Fp]
     const void* x;            // [Bp x ldx] clean input, element type T
     int64_t ldx;
+    const uint32_t* x_bits;   // bf16 + binary input: [Bp x ldxb] bit image of x instead (bit b of word w = feature 32w+b); else NULL
+    int64_t ldxb;
     const float* cw;          // [Bp] w_i / (sum w + 1e-16), zero for i >= B
     const float* cos_stats;   // cosine: [3 x Bp] = {sum x^2 | sum y^2 | sum xhat.y}; NULL otherwise
     float* rowloss_part;      // [2*tiles_n x Bp] per-row partial sums (may be NULL)
@@ -36,7 +38,7 @@ struct LabelJob {
 int launch_gather_csr(const int64_t* indptr, const int32_t* indices, const float* values, const int32_t* row_idx, int B, int F, int dtype,
                       void* x, void* xc, int64_t ldx, void* xct, int64_t ldt, float* rowsq, int corr_mode, const uint32_t* keep_bits,
                       uint64_t seed, uint32_t rng_stream, float corr_frac, float scale, uint32_t* xc_bits, int64_t ldw,
-                      const LabelJob* label_job, hipStream_t st);
+                      const LabelJob* label_job, hipStream_t st, uint32_t* x_bits = nullptr);
 
 // ---- argument packs of the step-tail kernel (bias gradients + statistics + x~^T un-scatter in one launch) ----
 struct BiasArgs {

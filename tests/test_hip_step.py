@@ -122,6 +122,20 @@ def test_step_bit_operand_equals_dense_operand(monkeypatch):
         assert _rel(u, np.asarray(v, np.float64)) < 1e-5
 
 
+@pytest.mark.parametrize("strategy", ["none", "batch_all"])
+def test_x_bit_image_equals_dense_x_tile(strategy, monkeypatch):
+    """bf16 + binary CSR: the decode epilogue reads the clean rows from the gather's bit image (default); DAE_NO_XBITS=1
+    keeps the dense bf16 x tile.  x is exactly 0/1 either way: every statistic and gradient must be identical."""
+    a, _, pa = _run_case("bf16", strategy, "cross_entropy", ("sigmoid", "sigmoid"), "gradient_descent", steps=2, seed=11)
+    monkeypatch.setenv("DAE_NO_XBITS", "1")
+    b, _, pb = _run_case("bf16", strategy, "cross_entropy", ("sigmoid", "sigmoid"), "gradient_descent", steps=2, seed=11)
+    for (_, sa, dWa, dbha, dbva), (_, sb, dWb, dbhb, dbvb) in zip(a, b):
+        assert np.array_equal(sa[:5], sb[:5])
+        assert np.array_equal(dWa, dWb) and np.array_equal(dbha, dbhb) and np.array_equal(dbva, dbvb)
+    for u, v in zip(pa, pb):
+        assert np.array_equal(np.asarray(u), np.asarray(v))
+
+
 @pytest.mark.parametrize("opt", ["gradient_descent", "ada_grad", "momentum", "adam"])
 def test_fused_optimizer_equals_separate_kernel(opt, monkeypatch):
     """bf16 single-GPU steps run the optimizer in the dW GEMM's epilogue; DAE_NO_FUSED_OPT=1 keeps dW -> grad -> opt_step.
