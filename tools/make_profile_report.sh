@@ -17,5 +17,7 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_G
 python tools/rocprof_summary.py $OUT/trace/t_results.db > $OUT/kernel_stats.md
 python tools/pmc_summary.py $OUT/pmc_fetch/f_results.db $OUT/pmc_write/w_results.db $OUT/pmc_sq/s_results.db > $OUT/pmc_counters.md
 rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq
+python tools/gemm_trace.py --nst 2 > $OUT/gemm_trace.txt 2>/dev/null
+python tools/kprof.py > $OUT/kprof.txt 2>/dev/null
 nproc > $OUT/host.txt; lscpu | grep "Model name" >> $OUT/host.txt; rocminfo | grep -E "gfx|Compute Unit" | head -4 >> $OUT/host.txt
 ls -la $OUT
