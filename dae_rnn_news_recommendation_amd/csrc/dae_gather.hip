@@ -53,8 +53,8 @@ __global__ __launch_bounds__(GATHER_THREADS) void gather_csr_kernel(
     constexpr int VEC = 16 / sizeof(T);
     // zero the tiles
     for (int k = tid * VEC; k < GATHER_CW; k += GATHER_THREADS * VEC) {
-        *reinterpret_cast<i32x4*>(&lx[k]) = i32x4{0, 0, 0, 0};
-        *reinterpret_cast<i32x4*>(&lxc[k]) = i32x4{0, 0, 0, 0};
+        if (x) *reinterpret_cast<i32x4*>(&lx[k]) = i32x4{0, 0, 0, 0};
+        if (xc) *reinterpret_cast<i32x4*>(&lxc[k]) = i32x4{0, 0, 0, 0};
     }
     if (tid < GATHER_CW / 32) { lbits[tid] = 0u; lbits_x[tid] = 0u; }
     __syncthreads();
@@ -78,8 +78,8 @@ __global__ __launch_bounds__(GATHER_THREADS) void gather_csr_kernel(
             const bool keep = keep_entry(corr_mode, keep_bits, (uint64_t)k, seed, stream, corr_frac);
             const float vc = keep ? v * scale : 0.0f;
             if (col < F) {
-                lx[col - c0] = Elem<T>::from(v);
-                lxc[col - c0] = Elem<T>::from(vc);
+                if (x) lx[col - c0] = Elem<T>::from(v);
+                if (xc) lxc[col - c0] = Elem<T>::from(vc);
                 if (xc_bits && keep) atomicOr(&lbits[(col - c0) >> 5], 1u << ((col - c0) & 31));
                 if (x_bits) atomicOr(&lbits_x[(col - c0) >> 5], 1u << ((col - c0) & 31));
                 if (xct && keep) xct[(int64_t)col * ldt + i] = Elem<T>::from(vc);

@@ -247,9 +247,12 @@ __global__ __launch_bounds__(TRIP_THREADS, OCC) void batch_all_kernel(const floa
     uint32_t* Rrow = POS_ONLY ? role_cnt + (int64_t)a * Bp : nullptr;
 
     // zero the gradient row (covers j == a and j >= B) and the positive-role accumulators
+    // every j < B other than the anchor is a positive or a negative and is written at the end: only the anchor's own
+    // entry and the padding columns need zeros
     for (int j = tid; j < Bp; j += TRIP_THREADS) {
-        Grow[j] = 0.f; gpos[j] = 0.f;
-        if (POS_ONLY) { Rrow[j] = 0u; cpos[j] = 0u; }
+        if (j >= B || j == a) { Grow[j] = 0.f; if (POS_ONLY) Rrow[j] = 0u; }
+        gpos[j] = 0.f;
+        if (POS_ONLY) cpos[j] = 0u;
     }
 
     if (probe & 4) return;

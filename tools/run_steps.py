@@ -15,6 +15,6 @@ stats = torch.zeros(8, device="cuda")
 for s in range(steps):
     idx = torch.arange((s % 2) * 800, (s % 2) * 800 + 800, dtype=torch.int32, device="cuda")
     labs = torch.from_numpy(lab[(s % 2) * 800:(s % 2) * 800 + 800]).cuda()
-    eng.train_step(idx, labs if strategy != "none" else None, stats, corr_mode=L.CORR_PHILOX_MASK, seed=1, rng_stream=s, corr_frac=0.3)
+    eng.train_step(idx, labs if strategy != "none" else None, stats, corr_mode=L.CORR_PHILOX_MASK, seed=1, rng_stream=s, corr_frac=0.3, phase=3)
 torch.cuda.synchronize()
 print("done", stats.cpu().numpy()[:3])
