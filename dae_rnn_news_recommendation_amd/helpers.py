@@ -1,0 +1,67 @@
+"""Device counterpart of the reference's ``helpers.pairwise_similarity`` (helpers.py:11-50) -- the evaluation step
+``main_autoencoder.py:307-317`` runs six times right after training (embeddings, binary BoW, TF-IDF; train and
+validation).  Same name, arguments, assert and return value; the normalisation, the N x N product (exact-fp32 MFMA) and
+the diagonal fill run on the MI355X through ``dae_pairwise_similarity``.  No CPU implementation: without the built
+library / a GPU this raises."""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib as L
+
+_NORMS = {"": 0, "l1": 1, "l2": 2, "max": 3}
+_METRICS = {"cosine": 0, "linear kernel": 1}
+
+
+def _csr_to_dense(torch, m, dev):
+    return torch.sparse_csr_tensor(torch.from_numpy(m.indptr.astype(np.int64)), torch.from_numpy(m.indices.astype(np.int64)),
+                                   torch.from_numpy(m.data), size=m.shape).to(dev).to_dense()
+
+
+def pairwise_similarity(in_df, norm="", metric="cosine", set_diagonal_zero=True, *, return_tensor=False, device=None):
+    """Pairwise similarity of the rows of ``in_df`` (ndarray, scipy.sparse matrix, list, or a CUDA float32 tensor).
+
+    norm: '' or sklearn.preprocessing.normalize's 'l1' / 'l2' / 'max', applied first; metric: 'cosine' or
+    'linear kernel'; set_diagonal_zero as in the reference.  Returns a float32 ndarray [N x N]
+    (``return_tensor=True``: the CUDA tensor view, no copy to the host).
+
+    Sparse input is densified on the device (one fp32 image of the matrix); the reference's sklearn path would return
+    a sparse matrix for ``linear kernel`` + sparse input with dense_output left at its default -- here the result is
+    always dense, which is what every caller in the reference needs (they index and plot it)."""
+    import torch
+    assert metric in ["cosine", "linear kernel"]                      # helpers.py:34
+    if norm not in _NORMS:
+        raise ValueError(f"'{norm}' is not a supported norm")         # sklearn.preprocessing.normalize's message
+    lib = L.load()
+    dev = torch.device("cuda" if device is None else device)
+    if isinstance(in_df, torch.Tensor):
+        X = in_df.to(device=dev, dtype=torch.float32)
+    else:
+        try:
+            import scipy.sparse as sp
+            is_sparse = sp.issparse(in_df)
+        except ImportError:                                            # pragma: no cover
+            is_sparse = False
+        if is_sparse:
+            import warnings
+            m = in_df.tocsr().astype(np.float32)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")                        # torch: "sparse CSR tensor support is in beta state"
+                X = _csr_to_dense(torch, m, dev)
+        else:
+            X = torch.as_tensor(np.asarray(in_df, dtype=np.float32)).to(dev)
+    if X.dim() != 2:
+        raise ValueError("Expected 2D array")
+    X = X.contiguous()
+    N, D = int(X.shape[0]), int(X.shape[1])
+    Np = L.pad(N)
+    out = torch.empty((Np, Np), dtype=torch.float32, device=dev)
+    ws_bytes = int(lib.dae_pairwise_similarity_workspace(N, D))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        L.call("dae_pairwise_similarity", L.ptr(X), X.stride(0), N, D, _NORMS[norm], _METRICS[metric], 1 if set_diagonal_zero else 0,
+               L.ptr(out), Np, L.ptr(ws), ws_bytes, L.current_stream())
+    res = out[:N, :N]
+    if return_tensor:
+        return res
+    return res.cpu().numpy()

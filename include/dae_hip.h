@@ -297,6 +297,21 @@ typedef struct {
     int32_t adam_t; float grad_scale;
 } dae_step;
 
+/* -------------------------------------------------------------------------------------------------
+ * Evaluation step after the training path: N x N similarity of row vectors.
+ * Replaces helpers.pairwise_similarity (helpers.py:11-50; called by main_autoencoder.py:307-317):
+ *   [sklearn.preprocessing.normalize(X, norm)]  ->  cosine_similarity | linear_kernel  ->  fill_diagonal(0).
+ *   X [N x ldx] fp32 (device), norm: 0 none / 1 'l1' / 2 'l2' / 3 'max', metric: 0 'cosine' / 1 'linear kernel'
+ *   (any other metric is rejected, as the reference's assert does), zero_diagonal as set_diagonal_zero.
+ *   out: fp32 image [dae_pad(N) x ldo], ldo >= dae_pad(N); rows / columns >= N are zero.
+ *   workspace: dae_pairwise_similarity_workspace(N, D) bytes, 16-byte aligned (the normalised operand image).
+ * Exact-fp32 MFMA product, fp32 accumulation.
+ * ------------------------------------------------------------------------------------------------- */
+uint64_t dae_pairwise_similarity_workspace(int32_t N, int32_t D);
+int dae_pairwise_similarity(const float* X, int64_t ldx, int32_t N, int32_t D, int32_t norm, int32_t metric,
+                            int32_t zero_diagonal, float* out, int64_t ldo, void* workspace,
+                            uint64_t workspace_bytes, void* stream);
+
 int      dae_plan_create(const dae_config* cfg, dae_plan** out);
 void     dae_plan_destroy(dae_plan* p);
 uint64_t dae_plan_workspace_bytes(const dae_plan* p);

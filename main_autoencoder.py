@@ -72,6 +72,8 @@ def build_parser():
     p.add_argument("--data", default="", help="scipy-sparse .npz or dense .npy feature matrix (rows = articles)")
     p.add_argument("--labels", default="", help=".npy label vector aligned with --data")
     p.add_argument("--data_parallel", default=False, **b)
+    p.add_argument("--similarity", default=True, **b,
+                   help="after training: the N x N cosine similarities the reference computes (:307-317), on the device")
     return p
 
 
@@ -106,6 +108,38 @@ def load_data(a):
     return X, y
 
 
+def evaluate_similarity(a, trX, vlX, trY, vlY, emb, emb_v):
+    """Reference :307-317 -- pairwise cosine similarity of the input vectors and of the embeddings (train, validation),
+    computed on the MI355X (helpers.pairwise_similarity -> dae_pairwise_similarity).  The reference turns the matrices into
+    box plots / ROC curves per label (helpers.visualize_pairwise_similarity, out of scope here); the same comparison is
+    printed as numbers: mean similarity of same-label pairs vs different-label pairs."""
+    import torch
+    from dae_rnn_news_recommendation_amd import helpers
+    print('calculate similarity')
+    metric_in = 'linear kernel' if a.input_format == 'tfidf' else 'cosine'   # TF-IDF rows are l2-normalised already (:311)
+    jobs = [('input vectors (train)', trX, metric_in, trY), ('embedding (train)', emb, 'cosine', trY)]
+    if vlX is not None:
+        jobs += [('input vectors (validate)', vlX, metric_in, vlY), ('embedding (validate)', emb_v, 'cosine', vlY)]
+    rows = []
+    for name, M, metric, y in jobs:
+        S = helpers.pairwise_similarity(M, metric=metric, return_tensor=True)
+        line = '  %-26s %5d x %-5d' % (name, S.shape[0], S.shape[1])
+        if y is not None:
+            ids = torch.from_numpy(np.unique(np.asarray(y), return_inverse=True)[1]).to(S.device)
+            same = ids[:, None] == ids[None, :]
+            same.fill_diagonal_(False)
+            diff = ~same
+            diff.fill_diagonal_(False)
+            ms = float(S[same].mean()) if bool(same.any()) else float('nan')
+            md = float(S[diff].mean()) if bool(diff.any()) else float('nan')
+            line += '  mean sim same-label %.4f  different-label %.4f  gap %.4f' % (ms, md, ms - md)
+            rows.append((name, ms, md))
+        print(line)
+        del S
+    print('calculate similarity done')
+    return rows
+
+
 def main(argv=None):
     a = validate(build_parser().parse_args(argv))
     print(__file__ + ': Start')
@@ -137,8 +171,11 @@ def main(argv=None):
         print('label={}'.format(a.label), file=fh)
     # encode with the decay compensation the reference applies at inference (:289-290)
     emb = model.transform(utils.decay_noise(trX, a.corr_frac), name='article_encoded_train', save=True)
+    emb_v = None
     if vlX is not None:
-        model.transform(utils.decay_noise(vlX, a.corr_frac), name='article_encoded_validate', save=True)
+        emb_v = model.transform(utils.decay_noise(vlX, a.corr_frac), name='article_encoded_validate', save=True)
+    if a.similarity and dp.rank() == 0:
+        evaluate_similarity(a, trX, vlX, trY, vlY, emb, emb_v)
     if model.samples_per_sec:
         print('training throughput: %.0f samples/s over %d epochs; embeddings %s -> %s' %
               (model.samples_per_sec, a.num_epochs, emb.shape, model.data_dir))

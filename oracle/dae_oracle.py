@@ -25,7 +25,7 @@ __all__ = [
     "OptState", "opt_apply",
     "masking_noise", "salt_and_pepper_noise", "decay_noise", "gen_batches_index",
     "get_sparse_ind_val_shape", "xavier_bound", "epoch_plan", "fit_reference",
-    "philox4x32", "philox_uniform",
+    "philox4x32", "philox_uniform", "pairwise_similarity",
 ]
 
 EPS = 1e-16
@@ -615,3 +615,35 @@ def philox_uniform(idx, seed, stream):
     x0, _, _, _ = philox4x32(lo, hi, np.full(lo.shape, np.uint32(stream)), np.zeros(lo.shape, np.uint32),
                              np.uint32(seed & 0xFFFFFFFF), np.uint32((seed >> 32) & 0xFFFFFFFF))
     return (x0 >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Evaluation step after the path: helpers.pairwise_similarity (helpers.py:11-50)
+# ------------------------------------------------------------------------------------------------------------------
+def pairwise_similarity(in_df, norm="", metric="cosine", set_diagonal_zero=True, dt=np.float64):
+    """Restates helpers.pairwise_similarity: optional sklearn.preprocessing.normalize(in_df, norm) (rows with a zero norm
+    are left as they are), then sklearn's cosine_similarity (l2-normalise the rows, X X^T) or linear_kernel (X X^T),
+    then np.fill_diagonal(out, 0) (helpers.py:43-48).  Pinned against scikit-learn itself in tests/test_oracle.py."""
+    assert metric in ["cosine", "linear kernel"]                       # helpers.py:34
+    X = np.asarray(in_df.toarray() if hasattr(in_df, "toarray") else in_df, dtype=dt)
+
+    def _normalize(A, kind):
+        if kind == "l1":
+            n = np.abs(A).sum(axis=1)
+        elif kind == "l2":
+            n = np.sqrt((A * A).sum(axis=1))
+        elif kind == "max":
+            n = np.abs(A).max(axis=1)
+        else:
+            raise ValueError(f"'{kind}' is not a supported norm")
+        n = np.where(n == 0, 1.0, n)
+        return A / n[:, None]
+
+    if norm != "":
+        X = _normalize(X, norm)
+    if metric == "cosine":
+        X = _normalize(X, "l2")
+    out = X @ X.T
+    if set_diagonal_zero:
+        np.fill_diagonal(out, 0)
+    return out

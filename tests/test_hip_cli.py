@@ -26,6 +26,9 @@ def test_cli_end_to_end(tmp_path, monkeypatch, capsys):
     assert os.path.exists(model.model_path + ".npz") and "triplet_strategy=batch_hard" in open(model.parameter_file).read()
     costs = [h["cost"] for h in model.history]
     assert costs[-1] < costs[0]                               # it trains
+    # the evaluation step the reference runs next (:307-317): four similarity matrices, summarised per label
+    assert "calculate similarity done" in out and out.count("mean sim same-label") == 4
+    assert "embedding (validate)" in out and "200 x 200" in out
 
 
 def test_explicit_triplet_estimator_matches_oracle(tmp_path):

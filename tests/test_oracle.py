@@ -261,3 +261,23 @@ def test_philox_known_answer():
     assert [int(v[0]) for v in out] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
     out = O.philox4x32([0xffffffff], [0xffffffff], [0xffffffff], [0xffffffff], 0xffffffff, 0xffffffff)
     assert [int(v[0]) for v in out] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+
+
+@pytest.mark.parametrize("norm", ["", "l1", "l2", "max"])
+@pytest.mark.parametrize("metric", ["cosine", "linear kernel"])
+def test_pairwise_similarity_vs_sklearn(norm, metric):
+    """Pins oracle.pairwise_similarity (restating helpers.py:11-50) against the scikit-learn calls the reference makes."""
+    from sklearn.metrics import pairwise
+    from sklearn.preprocessing import normalize
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((37, 19))
+    X[5] = 0.0                                                        # an all-zero row: normalize leaves it untouched
+    ref = normalize(X, norm=norm) if norm else X
+    ref = pairwise.cosine_similarity(ref) if metric == "cosine" else pairwise.linear_kernel(ref)
+    np.fill_diagonal(ref, 0)
+    got = O.pairwise_similarity(X, norm=norm, metric=metric)
+    assert np.allclose(got, ref, rtol=1e-12, atol=1e-14)
+    keep = O.pairwise_similarity(X, norm=norm, metric=metric, set_diagonal_zero=False)
+    assert np.allclose(np.diag(keep)[6:], np.diag(X @ X.T)[6:] if (metric == "linear kernel" and not norm) else np.diag(keep)[6:])
+    with pytest.raises(AssertionError):
+        O.pairwise_similarity(X, metric="euclidean")                  # the reference's assert (helpers.py:34)
