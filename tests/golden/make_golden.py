@@ -85,6 +85,33 @@ def load_reference(ref_root):
     return mods["triplet_loss_utils"], mods["utils"]
 
 
+def golden_similar_articles(ref_root, out_path):
+    """datasets/articles.py::similar_articles executed as shipped (pandas / NumPy are installed; ``jieba`` is only imported
+    at module top for the tokenizer, so an empty stand-in module is registered for the import)."""
+    import pandas as pd
+    sys.modules.setdefault("jieba", types.ModuleType("jieba"))
+    spec = importlib.util.spec_from_file_location("ref_articles", os.path.join(ref_root, "datasets", "articles.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = {}
+    cases = [dict(n=60, classes=5, seed=1, min_cate=2, max_cate=None), dict(n=200, classes=40, seed=2, min_cate=2, max_cate=None),
+             dict(n=120, classes=7, seed=3, min_cate=3, max_cate=25)]
+    for k, c in enumerate(cases):
+        rng = np.random.RandomState(100 + k)
+        cat = rng.randint(0, c["classes"], c["n"])
+        df = pd.DataFrame({"article_id": np.arange(1, c["n"] + 1), "label": cat})
+        np.random.seed(c["seed"])
+        res = mod.similar_articles(df.copy(), id_colname="article_id", cate_colname="label", min_cate=c["min_cate"], max_cate=c["max_cate"])
+        out[f"c{k}_label"] = cat
+        out[f"c{k}_cfg"] = np.array([c["n"], c["classes"], c["seed"], c["min_cate"], -1 if c["max_cate"] is None else c["max_cate"]])
+        out[f"c{k}_pos"] = res["article_id_pos"].to_numpy().astype(np.int64)
+        out[f"c{k}_neg"] = res["article_id_neg"].to_numpy().astype(np.int64)
+        out[f"c{k}_valid"] = res["valid_triplet_data"].to_numpy().astype(np.int64)
+    out["n_cases"] = np.array(len(cases))
+    np.savez_compressed(out_path, **out)
+    print("wrote", out_path, {k: v.shape for k, v in out.items() if k.endswith("_pos")})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
@@ -175,6 +202,7 @@ def main():
     out["u_triplet_bs4_seed9_order"] = np.asarray(order, np.int64)
 
     np.savez_compressed(args.out, **out)
+    golden_similar_articles(args.reference, os.path.join(os.path.dirname(os.path.abspath(args.out)), "similar_articles.npz"))
     print("wrote", args.out, len(out), "arrays", os.path.getsize(args.out), "bytes")
 
 

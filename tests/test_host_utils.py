@@ -137,3 +137,27 @@ def test_label_masks_match_golden():
         assert (T._get_triplet_mask(lab) == G[f"miner{case}_mask3"]).all()
         assert (T._get_anchor_positive_triplet_mask(lab) == G[f"miner{case}_mask_ap"]).all()
         assert (T._get_anchor_negative_triplet_mask(lab) == G[f"miner{case}_mask_an"]).all()
+
+
+def test_similar_articles_matches_reference_golden():
+    """datasets.articles.similar_articles (reference datasets/articles.py:83-128) vs vectors produced by the reference's own
+    function (tests/golden/make_golden.py::golden_similar_articles): positives, negatives (same global-RNG draws) and the
+    valid flag, including min_cate / max_cate filtering."""
+    import os
+    pd = pytest.importorskip("pandas")
+    from dae_rnn_news_recommendation_amd.datasets import similar_articles
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "similar_articles.npz"))
+    for k in range(int(g["n_cases"])):
+        n, _, seed, min_cate, max_cate = [int(v) for v in g[f"c{k}_cfg"]]
+        df = pd.DataFrame({"article_id": np.arange(1, n + 1), "label": g[f"c{k}_label"]})
+        np.random.seed(seed)
+        res = similar_articles(df, id_colname="article_id", cate_colname="label", min_cate=min_cate,
+                               max_cate=None if max_cate < 0 else max_cate)
+        assert np.array_equal(res["article_id_pos"].to_numpy(), g[f"c{k}_pos"])
+        assert np.array_equal(res["article_id_neg"].to_numpy(), g[f"c{k}_neg"])
+        assert np.array_equal(res["valid_triplet_data"].to_numpy(), g[f"c{k}_valid"])
+        lab = g[f"c{k}_label"]
+        v = res["valid_triplet_data"].to_numpy() == 1
+        assert v.any()
+        assert (lab[res["article_id_pos"].to_numpy()[v] - 1] == lab[v]).all()       # positives share the label
+        assert (lab[res["article_id_neg"].to_numpy()[v] - 1] != lab[v]).all()       # negatives do not
