@@ -1,4 +1,9 @@
-"""Device counterpart of the reference's ``helpers.pairwise_similarity`` (helpers.py:11-50) -- the evaluation step
+"""Mirror of the parts of the reference's ``helpers.py`` either side of the training path.
+
+* ``save_file`` / ``read_file`` (helpers.py:138-264): the on-disk artefact conventions -- format picked from the file
+  extension, writer / reader picked from the container type (ndarray: csv, tsv, npy; scipy.sparse: npz, and csv / tsv
+  after densifying; DataFrame: csv, tsv, parquet, pkl; Series: csv, tsv, pkl).  Host code.
+* ``pairwise_similarity`` (helpers.py:11-50) -- the evaluation step
 ``main_autoencoder.py:307-317`` runs six times right after training (embeddings, binary BoW, TF-IDF; train and
 validation).  Same name, arguments, assert and return value; the normalisation, the N x N product (exact-fp32 MFMA) and
 the diagonal fill run on the MI355X through ``dae_pairwise_similarity``.  No CPU implementation: without the built
@@ -8,6 +13,87 @@ from __future__ import annotations
 import numpy as np
 
 from . import _lib as L
+
+def _container_kind(data):
+    import scipy.sparse as sp
+    try:
+        import pandas as pd
+    except ImportError:                                                # pragma: no cover
+        pd = None
+    if isinstance(data, np.ndarray):
+        return "numpy"
+    if sp.issparse(data):
+        return "scipy"
+    if pd is not None and isinstance(data, pd.DataFrame):
+        return "pandas_df"
+    if pd is not None and isinstance(data, pd.Series):
+        return "pandas_series"
+    return None
+
+
+_WRITABLE = {"numpy": ("csv", "tsv", "npy"), "scipy": ("npz",), "pandas_df": ("csv", "tsv", "parquet", "pkl"),
+             "pandas_series": ("csv", "tsv", "pkl")}
+_READABLE = {"numpy": ("csv", "tsv", "npy"), "scipy": ("csv", "tsv", "npz"), "pandas_df": ("csv", "tsv", "parquet", "pkl"),
+             "pandas_series": ("csv", "tsv", "pkl")}
+
+
+def save_file(data, path, format=None, **savekwargs):
+    """Write ``data`` to ``path``; the format is the lower-cased extension unless given (helpers.py:138-199)."""
+    import scipy.sparse as sp
+    path = str(path)
+    if format is None:
+        format = path.lower().split(".")[-1]
+    if sp.issparse(data) and format in ("csv", "tsv"):                 # text formats of a sparse matrix: densify first (:146-147)
+        data = data.toarray()
+    kind = _container_kind(data)
+    assert kind is not None and format in _WRITABLE[kind], \
+        "Shoule be one of following format {}".format(list(_WRITABLE.get(kind, ())))      # the reference's message (:198)
+    sep = "," if format == "csv" else "\t"
+    if kind == "numpy":
+        if format == "npy":
+            np.save(path, data, **savekwargs)
+        else:
+            np.savetxt(path, data, delimiter=sep, **savekwargs)
+    elif kind == "scipy":
+        sp.save_npz(path, data, **savekwargs)
+    elif format in ("csv", "tsv"):
+        data.to_csv(path, sep=sep, **savekwargs)
+    elif format == "parquet":
+        data.to_parquet(path, **savekwargs)
+    else:
+        data.to_pickle(path, **savekwargs)
+
+
+def read_file(path, data_type=None, format=None, **readkwargs):
+    """Read what ``save_file`` wrote.  ``data_type`` defaults from the format: npy -> 'numpy', npz -> 'scipy', everything
+    else -> 'pandas_df' (helpers.py:202-264); pass 'pandas_series' for pickled / csv label vectors as the reference's
+    scripts do (main_autoencoder.py:167-170)."""
+    import os
+    import scipy.sparse as sp
+    path = str(path)
+    assert os.path.isfile(path), "[Error] {} is not a file".format(path)
+    if format is None:
+        format = path.lower().split(".")[-1]
+    if data_type is None:
+        data_type = {"npy": "numpy", "npz": "scipy"}.get(format, "pandas_df")
+    assert data_type in _READABLE
+    assert format in _READABLE[data_type]
+    sep = "," if format == "csv" else "\t"
+    if data_type == "numpy":
+        return np.load(path, **readkwargs) if format == "npy" else np.loadtxt(path, delimiter=sep, **readkwargs)
+    if data_type == "scipy":
+        return sp.load_npz(path, **readkwargs) if format == "npz" else sp.csr_matrix(np.loadtxt(path, delimiter=sep, **readkwargs))
+    import pandas as pd
+    if format == "parquet":
+        return pd.read_parquet(path, **readkwargs)
+    if format == "pkl":
+        return pd.read_pickle(path, **readkwargs)
+    if data_type == "pandas_df":
+        return pd.read_csv(path, sep=sep, index_col=0, parse_dates=True, **readkwargs)
+    # a Series written by to_csv: no header row, first column is the index (the reference asks read_csv for squeeze=True,
+    # which current pandas spells .squeeze("columns"))
+    return pd.read_csv(path, sep=sep, index_col=0, parse_dates=True, header=None, **readkwargs).squeeze("columns")
+
 
 _NORMS = {"": 0, "l1": 1, "l2": 2, "max": 3}
 _METRICS = {"cosine": 0, "linear kernel": 1}

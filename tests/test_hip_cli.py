@@ -31,6 +31,30 @@ def test_cli_end_to_end(tmp_path, monkeypatch, capsys):
     assert "embedding (validate)" in out and "200 x 200" in out
 
 
+def test_cli_artefacts_and_restore(tmp_path, monkeypatch, capsys):
+    """Reference artefact names / formats in the model's data directory (main_autoencoder.py:227-240) and
+    --restore_previous_data / --restore_previous_model (:161-174): a second run picks the data and the weights up."""
+    import main_autoencoder as cli
+    from dae_rnn_news_recommendation_amd import helpers
+    monkeypatch.chdir(tmp_path)
+    common = ["--model_name", "keep", "--train_row", "300", "--validate_row", "100", "--validation", "--max_features", "600",
+              "--seed", "2", "--triplet_strategy", "batch_all", "--similarity", "false"]
+    m1 = cli.main(common + ["--num_epochs", "2", "--save_tsv"])
+    d = m1.data_dir
+    X = helpers.read_file(d + "article_binary_count_vectorized.npz")
+    assert sparse.issparse(X) and X.shape == (300, 600)
+    assert helpers.read_file(d + "article_binary_count_vectorized_validate.npz").shape == (100, 600)
+    lab = helpers.read_file(d + "article_label_category_publish_name.pkl", data_type="pandas_series")
+    assert len(lab) == 300
+    assert os.path.exists(m1.tsv_dir + "article_encoded.tsv") and os.path.exists(m1.tsv_dir + "article_label.tsv")
+    e1 = np.load(d + "article_encoded_train.npy")
+    w1 = m1.get_model_parameters()
+    m2 = cli.main(common + ["--num_epochs", "0", "--restore_previous_data", "--restore_previous_model"])
+    w2 = m2.get_model_parameters()
+    assert all(np.array_equal(w1[k], w2[k]) for k in w1)                # --num_epochs 0: the restored model is not trained further
+    assert np.allclose(np.load(m2.data_dir + "article_encoded_train.npy"), e1, rtol=1e-5, atol=1e-6)   # same data, same weights
+
+
 def test_triplet_cli_end_to_end(tmp_path, monkeypatch, capsys):
     """main_autoencoder_triplet.py: similar_articles -> {'org','pos','neg'} -> DenoisingAutoencoderTriplet.fit -> transform ->
     device similarity (reference main_autoencoder_triplet.py:44-59, 236-290)."""

@@ -161,3 +161,31 @@ def test_similar_articles_matches_reference_golden():
         assert v.any()
         assert (lab[res["article_id_pos"].to_numpy()[v] - 1] == lab[v]).all()       # positives share the label
         assert (lab[res["article_id_neg"].to_numpy()[v] - 1] != lab[v]).all()       # negatives do not
+
+
+def test_save_file_read_file_round_trips(tmp_path):
+    """helpers.save_file / read_file (reference helpers.py:138-264): format from the extension, reader / writer from the
+    container type, the reference's assert on unsupported combinations."""
+    from dae_rnn_news_recommendation_amd import helpers as H
+    d = str(tmp_path) + "/"
+    a = np.arange(12.).reshape(3, 4)
+    for ext in ("npy", "csv", "tsv"):
+        H.save_file(a, d + "a." + ext)
+        assert np.allclose(H.read_file(d + "a." + ext, data_type="numpy"), a)
+    m = sparse.random(5, 7, density=0.3, format="csr", dtype=np.float32, random_state=np.random.RandomState(0))
+    H.save_file(m, d + "m.npz")
+    assert (H.read_file(d + "m.npz") != m).nnz == 0
+    H.save_file(m, d + "m.tsv")                                       # text formats densify the sparse matrix first
+    assert np.allclose(H.read_file(d + "m.tsv", data_type="scipy").toarray(), m.toarray())
+    s = pd.Series([3, 1, 2], name="label_story")
+    H.save_file(s, d + "s.pkl")
+    assert H.read_file(d + "s.pkl", data_type="pandas_series").equals(s)
+    df = pd.DataFrame({"a": [1, 2], "b": [3.5, 4.5]})
+    H.save_file(df, d + "d.pkl")
+    assert H.read_file(d + "d.pkl").equals(df)
+    H.save_file(df, d + "d.tsv")
+    assert np.allclose(H.read_file(d + "d.tsv").to_numpy(), df.to_numpy())
+    with pytest.raises(AssertionError):
+        H.save_file(m, d + "m.npy")                                   # scipy matrices only go to .npz
+    with pytest.raises(AssertionError):
+        H.read_file(d + "missing.npy")
