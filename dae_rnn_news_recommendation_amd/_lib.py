@@ -65,6 +65,8 @@ SIGNATURES = {
     "dae_gemm_nt": (i32, [i32, i32, i32, vp, i64, vp, i64, i32, vp, i64, vp, i64, i32, vp, i64, i32, i64, vp]),
     "dae_pairwise_similarity_workspace": (u64, [i32, i32]),
     "dae_pairwise_similarity": (i32, [vp, i64, i32, i32, i32, i32, i32, vp, i64, vp, u64, vp]),
+    "dae_pair_stats_workspace": (u64, [i32]),
+    "dae_pair_stats": (i32, [vp, i64, vp, i32, vp, vp, u64, vp]),
     "dae_gemm_trace": (i32, [i32, i32, i32, vp, i64, vp, i64, i32, vp, i64, vp, i64, i32, vp, i64, i32, i64, i32, vp, vp]),
     "dae_encode_finish": (i32, [vp, i32, i64, i64, vp, i32, i32, i32, i32, vp, vp, i64, vp, i64, vp, vp, vp]),
     "dae_decode_loss": (i32, [i32, i32, i32, i32, vp, i64, vp, i64, vp, vp, i64, vp, i32, i32, i32, vp, vp, vp, vp, vp,

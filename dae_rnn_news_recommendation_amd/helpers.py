@@ -151,3 +151,53 @@ def pairwise_similarity(in_df, norm="", metric="cosine", set_diagonal_zero=True,
     if return_tensor:
         return res
     return res.cpu().numpy()
+
+
+_STAT_KEYS = ("auroc", "n_related", "n_unrelated", "mean_related", "mean_unrelated")
+
+
+def visualize_pairwise_similarity(labels, pairwise_similarity_metrics, plot='boxplot', title=None, figsize=(16, 9), save_path=None,
+                                  **plot_kwargs):
+    """The numbers behind the reference's ROC + box plot figure (helpers.py:79-135), computed on the device.
+
+    Same arguments and asserts.  Pairs (i, j), j < i, with both labels >= 0 are 'related' when the labels are equal,
+    'unrelated' otherwise; returns a dict with the AUROC of related-vs-unrelated scores (what ``roc_curve`` + ``auc`` give
+    the reference), the population sizes, means and the box-plot five-number summaries.  Nothing is drawn (matplotlib is
+    not part of this stack): with ``save_path`` the dict is written as JSON next to where the figure would have gone
+    (``.png`` -> ``.json``).  ``pairwise_similarity_metrics`` may be an ndarray or a CUDA tensor (e.g. from
+    ``pairwise_similarity(..., return_tensor=True)``)."""
+    import ctypes
+    import json
+    import torch
+    labels = np.asarray(labels)
+    assert labels.shape[0] == pairwise_similarity_metrics.shape[0]
+    assert pairwise_similarity_metrics.shape[0] == pairwise_similarity_metrics.shape[1]
+    assert plot in ['scatter', 'boxplot']
+    lib = L.load()
+    S = pairwise_similarity_metrics
+    if not isinstance(S, torch.Tensor):
+        S = torch.as_tensor(np.asarray(S, dtype=np.float32))
+    S = S.to(device="cuda" if not S.is_cuda else S.device, dtype=torch.float32)
+    if S.stride(1) != 1:
+        S = S.contiguous()
+    N = int(S.shape[0])
+    lab = np.ascontiguousarray(labels.reshape(N, -1)[:, 0].astype(np.int32))
+    ws_bytes = int(lib.dae_pair_stats_workspace(N))
+    ws = torch.empty(ws_bytes + 256, dtype=torch.uint8, device=S.device)
+    off = (-ws.data_ptr()) % 256
+    out = (ctypes.c_double * 16)()
+    with torch.cuda.device(S.device):
+        L.call("dae_pair_stats", L.ptr(S), S.stride(0), lab.ctypes.data_as(ctypes.c_void_p), N, ctypes.cast(out, ctypes.c_void_p),
+               ctypes.c_void_p(ws.data_ptr() + off), ws_bytes, L.current_stream())
+    v = [float(x) for x in out]
+    res = dict(zip(_STAT_KEYS, v[:5]))
+    res["n_related"], res["n_unrelated"] = int(v[1]), int(v[2])
+    res["related"] = dict(zip(("min", "q1", "median", "q3", "max"), v[5:10]))
+    res["unrelated"] = dict(zip(("min", "q1", "median", "q3", "max"), v[10:15]))
+    res["title"] = title
+    if save_path is not None:
+        path = str(save_path)
+        path = path[:-4] + ".json" if path.lower().endswith(".png") else path + ".json"
+        with open(path, "w") as fh:
+            json.dump(res, fh, indent=1)
+    return res

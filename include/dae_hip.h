@@ -312,6 +312,19 @@ int dae_pairwise_similarity(const float* X, int64_t ldx, int32_t N, int32_t D, i
                             int32_t zero_diagonal, float* out, int64_t ldo, void* workspace,
                             uint64_t workspace_bytes, void* stream);
 
+/* Related / unrelated pair statistics of an N x N similarity matrix: the numbers behind
+ * helpers.visualize_pairwise_similarity (helpers.py:79-135) -- AUROC of "same label" vs "different label" over the strict
+ * lower triangle (labels < 0 are missing and drop their pairs; ties count half, as sklearn's roc_curve + auc do) and the
+ * box-plot statistics of the two score populations.
+ *   S [N x lds] fp32 on the device; labels_host int32[N] on the HOST (the class sizes come from its histogram);
+ *   out16 (host): [0] auroc, [1] n_related, [2] n_unrelated, [3] mean related, [4] mean unrelated,
+ *                 [5..9] related min, q1, median, q3, max, [10..14] unrelated min, q1, median, q3, max (numpy 'linear'
+ *                 percentiles); NaN where a population is empty.
+ * Synchronises the stream (returns host numbers).  workspace: dae_pair_stats_workspace(N) bytes, 256-byte aligned. */
+uint64_t dae_pair_stats_workspace(int32_t N);
+int dae_pair_stats(const float* S, int64_t lds, const int32_t* labels_host, int32_t N, double* out16, void* workspace,
+                   uint64_t workspace_bytes, void* stream);
+
 int      dae_plan_create(const dae_config* cfg, dae_plan** out);
 void     dae_plan_destroy(dae_plan* p);
 uint64_t dae_plan_workspace_bytes(const dae_plan* p);

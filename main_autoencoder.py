@@ -108,32 +108,32 @@ def load_data(a):
     return X, y
 
 
-def evaluate_similarity(a, trX, vlX, trY, vlY, emb, emb_v):
-    """Reference :307-317 -- pairwise cosine similarity of the input vectors and of the embeddings (train, validation),
-    computed on the MI355X (helpers.pairwise_similarity -> dae_pairwise_similarity).  The reference turns the matrices into
-    box plots / ROC curves per label (helpers.visualize_pairwise_similarity, out of scope here); the same comparison is
-    printed as numbers: mean similarity of same-label pairs vs different-label pairs."""
-    import torch
+def evaluate_similarity(a, trX, vlX, trY, vlY, emb, emb_v, plot_dir=None):
+    """Reference :307-317 + :322-345 -- pairwise cosine similarity of the input vectors and of the embeddings (train,
+    validation) and, per label, the related-vs-unrelated comparison the reference draws as ROC curve + box plot
+    (helpers.visualize_pairwise_similarity).  Both run on the MI355X (dae_pairwise_similarity, dae_pair_stats); the figure's
+    numbers are printed and, with ``plot_dir``, written as JSON under the reference's figure names."""
     from dae_rnn_news_recommendation_amd import helpers
     print('calculate similarity')
     metric_in = 'linear kernel' if a.input_format == 'tfidf' else 'cosine'   # TF-IDF rows are l2-normalised already (:311)
-    jobs = [('input vectors (train)', trX, metric_in, trY), ('embedding (train)', emb, 'cosine', trY)]
+    stem_in = 'tfidf' if a.input_format == 'tfidf' else 'binary_count'
+    jobs = [('input vectors (train)', trX, metric_in, trY, 'similarity_boxplot_' + stem_in),
+            ('embedding (train)', emb, 'cosine', trY, 'similarity_boxplot_encoded')]
     if vlX is not None:
-        jobs += [('input vectors (validate)', vlX, metric_in, vlY), ('embedding (validate)', emb_v, 'cosine', vlY)]
+        jobs += [('input vectors (validate)', vlX, metric_in, vlY, 'similarity_boxplot_' + stem_in + '_validate'),
+                 ('embedding (validate)', emb_v, 'cosine', vlY, 'similarity_boxplot_encoded_validate')]
     rows = []
-    for name, M, metric, y in jobs:
+    for name, M, metric, y, fig in jobs:
         S = helpers.pairwise_similarity(M, metric=metric, return_tensor=True)
         line = '  %-26s %5d x %-5d' % (name, S.shape[0], S.shape[1])
         if y is not None:
-            ids = torch.from_numpy(np.unique(np.asarray(y), return_inverse=True)[1]).to(S.device)
-            same = ids[:, None] == ids[None, :]
-            same.fill_diagonal_(False)
-            diff = ~same
-            diff.fill_diagonal_(False)
-            ms = float(S[same].mean()) if bool(same.any()) else float('nan')
-            md = float(S[diff].mean()) if bool(diff.any()) else float('nan')
-            line += '  mean sim same-label %.4f  different-label %.4f  gap %.4f' % (ms, md, ms - md)
-            rows.append((name, ms, md))
+            ids = np.unique(np.asarray(y), return_inverse=True)[1]
+            st = helpers.visualize_pairwise_similarity(ids, S, plot='boxplot', title=name,
+                                                       save_path=None if plot_dir is None else plot_dir + fig + '.png')
+            line += '  AUROC %.4f  median sim related %.4f  unrelated %.4f  (%d / %d pairs)' % (
+                st['auroc'], st['related']['median'] if st['n_related'] else float('nan'),
+                st['unrelated']['median'] if st['n_unrelated'] else float('nan'), st['n_related'], st['n_unrelated'])
+            rows.append((name, st))
         print(line)
         del S
     print('calculate similarity done')
@@ -212,7 +212,7 @@ def main(argv=None):
         if vlY is not None:
             helpers.save_file(pd.DataFrame({'label_' + a.label: vlY}), model.tsv_dir + 'article_label_validate.tsv')
     if a.similarity and dp.rank() == 0:
-        evaluate_similarity(a, trX, vlX, trY, vlY, emb, emb_v)
+        evaluate_similarity(a, trX, vlX, trY, vlY, emb, emb_v, model.plot_dir)
     if model.samples_per_sec:
         print('training throughput: %.0f samples/s over %d epochs; embeddings %s -> %s' %
               (model.samples_per_sec, a.num_epochs, emb.shape, model.data_dir))

@@ -79,7 +79,7 @@ def main(argv=None):
     if val is not None:
         emb_v = model.transform(utils.decay_noise(val["org"], a.corr_frac), name='article_encoded_validate', save=a.encode_full)
     if a.similarity:
-        base.evaluate_similarity(a, train["org"], None if val is None else val["org"], ytr, yvl, emb, emb_v)
+        base.evaluate_similarity(a, train["org"], None if val is None else val["org"], ytr, yvl, emb, emb_v, model.plot_dir)
     if model.samples_per_sec:
         print('training throughput: %.0f rows/s (org+pos+neg) over %d epochs' % (model.samples_per_sec, a.num_epochs))
     print(__file__ + ': End')

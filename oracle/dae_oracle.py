@@ -25,7 +25,7 @@ __all__ = [
     "OptState", "opt_apply",
     "masking_noise", "salt_and_pepper_noise", "decay_noise", "gen_batches_index",
     "get_sparse_ind_val_shape", "xavier_bound", "epoch_plan", "fit_reference",
-    "philox4x32", "philox_uniform", "pairwise_similarity",
+    "philox4x32", "philox_uniform", "pairwise_similarity", "pair_stats",
 ]
 
 EPS = 1e-16
@@ -646,4 +646,38 @@ def pairwise_similarity(in_df, norm="", metric="cosine", set_diagonal_zero=True,
     out = X @ X.T
     if set_diagonal_zero:
         np.fill_diagonal(out, 0)
+    return out
+
+
+def pair_stats(labels, S):
+    """Numeric content of helpers.visualize_pairwise_similarity (helpers.py:79-135): related / unrelated scores of the strict
+    lower triangle (labels < 0 missing), AUROC with ties counted half (= sklearn roc_curve + auc, pinned in
+    tests/test_oracle.py), and the box-plot numbers."""
+    labels = np.asarray(labels).reshape(len(labels), -1)[:, 0]
+    S = np.asarray(S, np.float64)
+    ok = (labels[None, :] >= 0) & (labels[:, None] >= 0)
+    same = (labels[None, :] == labels[:, None]) & ok
+    low = np.tril(np.ones_like(same, dtype=bool), -1)
+    rel = S[same & low]
+    un = S[(~same) & ok & low]
+    out = dict(n_related=len(rel), n_unrelated=len(un), auroc=float("nan"))
+    if len(rel) and len(un):
+        allv = np.concatenate([rel, un])
+        order = np.argsort(allv, kind="mergesort")
+        ranks = np.empty(len(allv))
+        sv = allv[order]
+        i = 0
+        while i < len(sv):                                   # average ranks over ties
+            j = i
+            while j + 1 < len(sv) and sv[j + 1] == sv[i]:
+                j += 1
+            ranks[order[i:j + 1]] = 0.5 * (i + j) + 1.0
+            i = j + 1
+        u = ranks[:len(rel)].sum() - len(rel) * (len(rel) + 1) / 2.0
+        out["auroc"] = float(u / (len(rel) * len(un)))
+    for name, v in (("related", rel), ("unrelated", un)):
+        if len(v):
+            out["mean_" + name] = float(v.mean())
+            out[name] = dict(min=float(v.min()), q1=float(np.percentile(v, 25)), median=float(np.percentile(v, 50)),
+                             q3=float(np.percentile(v, 75)), max=float(v.max()))
     return out

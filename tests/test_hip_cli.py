@@ -27,8 +27,11 @@ def test_cli_end_to_end(tmp_path, monkeypatch, capsys):
     costs = [h["cost"] for h in model.history]
     assert costs[-1] < costs[0]                               # it trains
     # the evaluation step the reference runs next (:307-317): four similarity matrices, summarised per label
-    assert "calculate similarity done" in out and out.count("mean sim same-label") == 4
+    assert "calculate similarity done" in out and out.count("AUROC") == 4
     assert "embedding (validate)" in out and "200 x 200" in out
+    import json
+    st = json.load(open(model.plot_dir + "similarity_boxplot_encoded.json"))     # the figure's numbers, under the figure's name
+    assert 0.0 <= st["auroc"] <= 1.0 and st["n_related"] + st["n_unrelated"] == 600 * 599 // 2
 
 
 def test_cli_artefacts_and_restore(tmp_path, monkeypatch, capsys):
@@ -65,7 +68,7 @@ def test_triplet_cli_end_to_end(tmp_path, monkeypatch, capsys):
                       "--encode_full"])
     out = capsys.readouterr().out
     assert "similar_articles:" in out and "fit done" in out and out.count("At step") == 3
-    assert "calculate similarity done" in out and out.count("mean sim same-label") == 4
+    assert "calculate similarity done" in out and out.count("AUROC") == 4
     emb = np.load(model.data_dir + "article_encoded.npy")
     assert emb.shape == (400, 40) and np.isfinite(emb).all()
     costs = [h["cost"] for h in model.history]

@@ -53,3 +53,28 @@ def test_pairwise_similarity_rejects_other_metrics():
         helpers.pairwise_similarity(np.eye(4, dtype=np.float32), metric="euclidean")
     with pytest.raises(ValueError):
         helpers.pairwise_similarity(np.eye(4, dtype=np.float32), norm="l3")
+
+
+@pytest.mark.parametrize("n,classes,missing", [(300, 5, True), (129, 2, False), (64, 64, False)])
+def test_pair_stats_matches_oracle(n, classes, missing):
+    """dae_pair_stats (AUROC + box-plot numbers of related vs unrelated pairs) vs the oracle that test_oracle.py pins against
+    scikit-learn; tied scores (coarse embeddings) and missing labels included."""
+    from dae_rnn_news_recommendation_amd import helpers
+    rng = np.random.default_rng(n)
+    lab = rng.integers(0, classes, n)
+    if missing:
+        lab[rng.choice(n, n // 10, replace=False)] = -1
+    X = np.round(rng.standard_normal((n, 8)), 1).astype(np.float32)
+    S = helpers.pairwise_similarity(X, metric="linear kernel", return_tensor=True)
+    got = helpers.visualize_pairwise_similarity(lab, S)
+    want = O.pair_stats(lab, S.cpu().numpy())
+    assert got["n_related"] == want["n_related"] and got["n_unrelated"] == want["n_unrelated"]
+    if want["n_related"] and want["n_unrelated"]:
+        assert abs(got["auroc"] - want["auroc"]) < 1e-12             # integer counting: exact up to the final division
+    for pop in ("related", "unrelated"):
+        if want["n_" + pop]:
+            for k in ("min", "q1", "median", "q3", "max"):
+                assert abs(got[pop][k] - want[pop][k]) <= 1e-6 * (1 + abs(want[pop][k]))
+            assert abs(got["mean_" + pop] - want["mean_" + pop]) <= 1e-6 * (1 + abs(want["mean_" + pop]))
+        else:
+            assert np.isnan(got["auroc"])

@@ -281,3 +281,23 @@ def test_pairwise_similarity_vs_sklearn(norm, metric):
     assert np.allclose(np.diag(keep)[6:], np.diag(X @ X.T)[6:] if (metric == "linear kernel" and not norm) else np.diag(keep)[6:])
     with pytest.raises(AssertionError):
         O.pairwise_similarity(X, metric="euclidean")                  # the reference's assert (helpers.py:34)
+
+
+def test_pair_stats_auroc_vs_sklearn():
+    """Pins oracle.pair_stats against the scikit-learn calls of helpers.visualize_pairwise_similarity (roc_curve + auc on the
+    related / unrelated score lists), including ties and missing (-1) labels."""
+    from sklearn.metrics import auc, roc_curve
+    rng = np.random.default_rng(8)
+    n = 60
+    lab = rng.integers(-1, 4, n)
+    X = np.round(rng.standard_normal((n, 6)), 1)                      # coarse values -> many tied similarities
+    S = X @ X.T
+    got = O.pair_stats(lab, S)
+    ok = (lab[None, :] >= 0) & (lab[:, None] >= 0)
+    same = (lab[None, :] == lab[:, None]) & ok
+    low = np.tril(np.ones((n, n), bool), -1)
+    rel, un = S[same & low], S[(~same) & ok & low]
+    fpr, tpr, _ = roc_curve(["Related"] * len(rel) + ["Unrelated"] * len(un), list(rel) + list(un), pos_label="Related")
+    assert got["n_related"] == len(rel) and got["n_unrelated"] == len(un)
+    assert abs(got["auroc"] - auc(fpr, tpr)) < 1e-12
+    assert abs(got["related"]["median"] - np.median(rel)) < 1e-12
