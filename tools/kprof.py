@@ -33,6 +33,6 @@ for _ in range(a.steps):
     eng.train_step(idx, labs if a.strategy != "none" else None, stats, phase=a.phase, **kw)
 prof = eng.profile_read(); eng.profile(False)
 tot = sum(ms for ms, n in prof.values())
-print(f"== nst={a.nst} {a.tag} {a.strategy} {a.precision} decode_debug={os.environ.get('DAE_DECODE_DEBUG','0')} total {1e3*tot/a.steps:.1f} us/step  info={eng.info()}")
+print(f"== nst={a.nst} {a.tag} {a.strategy} {a.precision} total {1e3*tot/a.steps:.1f} us/step  info={eng.info()}")
 for k, (ms, n) in prof.items():
     if n: print(f"   {k:18s} {1e3*ms/n:9.1f} us  x{n/a.steps:.0f}")
