@@ -256,6 +256,7 @@ extern "C" int dae_plan_bind(dae_plan* p, const dae_buffers* bufs) {
     p->b = *bufs;
     carve(p, (char*)bufs->workspace);
     p->bound = true;
+    p->xct_clean = false;            // a (re)bound workspace has not been cleared: the next backward step memsets x~^T once
     return 0;
 }
 
