@@ -355,7 +355,10 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     const bool csr_in = s->c_indptr || p->b.indptr;
     // label statistics (cw, N_valid, data weights) depend on the labels alone: they ride on the CSR gather launch
     LabelJob lj{s->labels, B, Bp, c.triplet, p->nvalid, p->dw_i64, p->cw, c.alpha, p->tri_scalars};
-    const bool label_in_gather = p->tail_ok && !explicit3 && !s->c_indptr && p->b.indptr && Bp <= 1024;
+    // ... on the encode GEMM's launch when that grid leaves a CU free (else on the CSR gather's, else their own)
+    static const bool label_enc_ok = getenv("DAE_LABEL_IN_GATHER") == nullptr;                   // A/B switch
+    const bool label_with_encode = p->tail_ok && !explicit3 && Bp <= 1024 && label_enc_ok;
+    const bool label_in_gather = p->tail_ok && !label_with_encode && !explicit3 && !s->c_indptr && p->b.indptr && Bp <= 1024;
     const bool tail = p->tail_ok;
     if (backward && csr_in && !(tail && p->xct_clean)) PROF(PS_MEMSET, memset_async(p->xct, (size_t)Fp * ldB * p->es, st));
     if (backward) p->xct_clean = false;
@@ -378,11 +381,12 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     }
     // 3-4. encode (K1/K2)
     const int64_t slab = (int64_t)Bp * Hp;
+    int enc_label_done = 0;
     if (use_bits)
         PROF(PS_ENC_GEMM, launch_encode_bits(Bp, Hp, Fp, p->xc_bits, Fp / 32, p->b.Wt_lo, Fp, p->slabs, Hp, p->s_enc, slab, st));
     else
         PROF(PS_ENC_GEMM, launch_gemm_f32out(dt, Bp, Hp, p->xc, Fp, p->b.Wt_lo, Fp, Fp, nullptr, 0, nullptr, 0, 0, p->slabs, Hp, p->s_enc, slab, st,
-                                             GEMM_ROLE_ENCODE));
+                                             GEMM_ROLE_ENCODE, label_with_encode ? &lj : nullptr, label_with_encode ? &enc_label_done : nullptr));
     PROF(PS_ENC_FIN, dae_encode_finish(p->slabs, p->s_enc, slab, Hp, p->b.bh, B, H, c.enc_act, dt, p->h_f32, p->h_lo, Hp, p->h_t, ldB,
                                        p->gram_split ? p->hcat_a : nullptr, p->gram_split ? p->hcat_b : nullptr, stream));
     // 5-6. miners (K5-K7)
@@ -393,7 +397,7 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
         DAE_CHECK_HIP(hipMemcpyAsync(p->cw + Bt, p->cw, (size_t)Bt * 4, hipMemcpyDeviceToDevice, st));
         DAE_CHECK_HIP(hipMemcpyAsync(p->cw + 2 * Bt, p->cw, (size_t)Bt * 4, hipMemcpyDeviceToDevice, st));
         PROF(PS_MINER, dae_explicit_triplet(p->h_f32, Hp, Bt, H, c.alpha, p->dh_extra, p->loss_part, p->tri_scalars, stream));
-    } else if (!label_in_gather) {
+    } else if (!(label_in_gather || enc_label_done)) {
         PROF(PS_LABEL, dae_label_stats(s->labels, B, Bp, c.triplet, p->n_same, p->acc, p->nvalid, p->dw_i64, p->cw, c.alpha, p->tri_scalars, stream));
     }
     bool forked = false;

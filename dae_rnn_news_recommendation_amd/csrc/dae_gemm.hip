@@ -24,6 +24,7 @@
 // to the per-lane SOURCE address); GLDS=false stages through registers (global_load_dwordx4 ->
 // ds_write_b128) with the loads issued before the MFMA block and the LDS write after it.
 #include "dae_kernels.h"
+#include "dae_label.h"
 
 #include <stdlib.h>
 
@@ -565,8 +566,12 @@ constexpr int PC_THREADS = 512;
 constexpr int PC_NST = 4;                            // 128 KiB of the CU's 160 KiB LDS
 
 template <typename T, int NST, int ROLE>
-__global__ __launch_bounds__(PC_THREADS, 1) void gemm_nt_pc(GemmParams p, float* __restrict__ C, int64_t ldc, int64_t slab_stride) {
+__global__ __launch_bounds__(PC_THREADS, 1) void gemm_nt_pc(GemmParams p, float* __restrict__ C, int64_t ldc, int64_t slab_stride,
+                                                            LabelJob job, int label_block) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    // the grid leaves CUs idle (28 x 8 = 224 workgroups of the encode GEMM on 256 CUs): one extra workgroup computes the
+    // batch's label statistics (dae_label.h) there, hidden under the GEMM instead of lengthening another launch
+    if ((int)blockIdx.x == label_block) { label_stats_block<PC_THREADS>(job, lds); return; }
     int tm, tn, split, kt0, kt1;
     if (!block_to_tile(p, tm, tn, split, kt0, kt1)) return;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1111,7 +1116,8 @@ template <typename T> static f32out_fn f32out_kernel(int nst, int role) {
         default: return gemm_nt_f32out<T, 2, ROLE_GENERIC>;
     }
 }
-template <typename T> static f32out_fn pc_kernel(int role) {
+typedef void (*pc_fn)(GemmParams, float*, int64_t, int64_t, LabelJob, int);
+template <typename T> static pc_fn pc_kernel(int role) {
     switch (role) {
         case ROLE_ENCODE: return gemm_nt_pc<T, PC_NST, ROLE_ENCODE>;
         case ROLE_DH: return gemm_nt_pc<T, PC_NST, ROLE_DH>;
@@ -1173,7 +1179,8 @@ static int gemm_init() {
 
 int launch_gemm_f32out(int dtype, int M, int N, const void* A0, int64_t lda0, const void* Bt0, int64_t ldb0, int K0,
                        const void* A1, int64_t lda1, const void* Bt1, int64_t ldb1, int K1, float* C, int64_t ldc,
-                       int splits, int64_t slab_stride, hipStream_t st, int role) {
+                       int splits, int64_t slab_stride, hipStream_t st, int role, const LabelJob* label_job, int* label_done) {
+    if (label_done) *label_done = 0;
     GemmParams p;
     if (int rc = fill_params(p, dtype, M, N, A0, lda0, Bt0, ldb0, K0, A1, lda1, Bt1, ldb1, K1, splits)) return rc;
     DAE_CHECK_ARG(C != nullptr, "gemm: C is null");
@@ -1181,9 +1188,14 @@ int launch_gemm_f32out(int dtype, int M, int N, const void* A0, int64_t lda0, co
     dim3 grid(grid_blocks(p)), block(GEMM_THREADS);
     const int nst = g_nst;
     if (nst == DEFAULT_NST && (int)grid.x <= g_cus && g_use_pc) {      // at most one workgroup per CU: producer/consumer waves
-        f32out_fn kp = dtype == DAE_BF16 ? pc_kernel<bf16_t>(role) : pc_kernel<float>(role);
-        hipLaunchKernelGGL(kp, grid, dim3(PC_THREADS), lds_bytes_for(PC_NST), st, p, C, ldc, slab_stride);
+        pc_fn kp = dtype == DAE_BF16 ? pc_kernel<bf16_t>(role) : pc_kernel<float>(role);
+        LabelJob job; memset(&job, 0, sizeof(job));
+        const bool with_labels = label_job && label_job->Bp <= 1024 && (int)grid.x < g_cus;      // a CU must be free for it
+        if (with_labels) job = *label_job;
+        hipLaunchKernelGGL(kp, dim3(grid.x + (with_labels ? 1 : 0)), dim3(PC_THREADS), lds_bytes_for(PC_NST), st, p, C, ldc, slab_stride, job,
+                           with_labels ? (int)grid.x : -1);
         DAE_CHECK_LAUNCH();
+        if (with_labels && label_done) *label_done = 1;
         return 0;
     }
     f32out_fn k = dtype == DAE_BF16 ? f32out_kernel<bf16_t>(nst, role) : f32out_kernel<float>(nst, role);

@@ -25,9 +25,13 @@ struct DecodeEpi {
     int ce_literal;           // 1: always evaluate cross_entropy with the reference-literal formula (DAE_CE_LITERAL=1; A/B and tests)
 };
 
+struct LabelJob;
+// label_job: when the launch uses the 8-wave kernel and leaves a CU free, one extra workgroup computes the label statistics
+// (*label_done = 1); otherwise the caller launches them itself
 int launch_gemm_f32out(int dtype, int M, int N, const void* A0, int64_t lda0, const void* Bt0, int64_t ldb0, int K0,
                        const void* A1, int64_t lda1, const void* Bt1, int64_t ldb1, int K1, float* C, int64_t ldc, int splits,
-                       int64_t slab_stride, hipStream_t st, int role = 0);
+                       int64_t slab_stride, hipStream_t st, int role = 0, const struct LabelJob* label_job = nullptr,
+                       int* label_done = nullptr);
 enum { GEMM_ROLE_GENERIC = 0, GEMM_ROLE_ENCODE = 1, GEMM_ROLE_DH = 2, GEMM_ROLE_DW = 3, GEMM_ROLE_GRAM = 4 };
 int launch_decode_loss(int dtype, int Bp, int Fp, int Hp, const void* h_lo, int64_t ldh, const void* W_lo, int64_t ldw,
                        const DecodeEpi& e, hipStream_t st);
