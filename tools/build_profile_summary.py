@@ -11,7 +11,7 @@ SLOT_KERNEL = [("gather", "gather_csr_kernel"), ("encode_gemm", "gemm_nt_pc<unsi
                ("gram", "gemm_nt_pc<unsigned short, 4, 4>"), ("miner", "batch_all_kernel"), ("sym_scale", "sym_scale_kernel"),
                ("decode_loss", "gemm_decode_loss"), ("dh_gemm", "gemm_nt_pc<unsigned short, 4, 2>"), ("dh_finish", "dh_finish_kernel"),
                ("dw_gemm", "gemm_dw_opt"), ("bias_grads", "step_tail_kernel")]
-NOTE = {"gather": "CSR rows -> x~ tile, x bit image, x~^T scatter; + label statistics block", "encode_gemm": "8-wave producer/consumer, split-K 8",
+NOTE = {"gather": "CSR rows -> x~ tile, x bit image, x~^T scatter", "encode_gemm": "8-wave producer/consumer, split-K 8; + label statistics workgroup",
         "encode_finish": "slab reduction, bias, act, h / h^T / split-bf16 images", "gram": "split-bf16 (3 products), split-K 4",
         "miner": "batch_all, pair-packed sweep", "sym_scale": "Gs = a/Nv (G + G^T) -> bf16", "decode_loss": "GEMM + loss + delta2 (two layouts), x from bits",
         "dh_gemm": "delta2.W + Gs.h, split-K 8", "dh_finish": "slab reduction, act', delta1^T, column sums",
