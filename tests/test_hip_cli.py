@@ -110,3 +110,24 @@ def test_explicit_triplet_estimator_matches_oracle(tmp_path):
         got = model.epoch_stats(e + 1)["cost"]
         assert abs(got - hist[e]) <= 1e-4 * abs(hist[e]), (e, got, hist[e])
     assert np.abs(model.engine.get_params()[0] - W).max() <= 2e-5 * np.abs(W).max()
+
+
+def test_bench_two_ranks_on_one_gpu(tmp_path):
+    """The N > 1 path of bench.py (phase-1 step -> all-reduce of the flat gradient -> dae_plan_apply) with two processes
+    sharing this box's single GPU (gloo collectives; RCCL needs one GPU per rank): launch line exactly as the driver's,
+    one JSON line from rank 0, n_gpus = 2, a finite loss that went down."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29617", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "3",
+           "--backend", "gloo", "--single-device", "--no-cpu-baseline", "--no-roofline", "--rows", "1600"]
+    out = subprocess.run(cmd, cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 12 and d["scaling"] == "weak" and d["config"]["parallelism"] == "dp2"
+    assert d["value"] > 0 and np.isfinite(d["final_losses"]["cost"])
