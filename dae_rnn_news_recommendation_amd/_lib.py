@@ -71,6 +71,7 @@ SIGNATURES = {
     "dae_encode_finish": (i32, [vp, i32, i64, i64, vp, i32, i32, i32, i32, vp, vp, i64, vp, i64, vp, vp, vp]),
     "dae_decode_loss": (i32, [i32, i32, i32, i32, vp, i64, vp, i64, vp, vp, i64, vp, i32, i32, i32, vp, vp, vp, vp, vp,
                               vp, i64, vp, i64, vp]),
+    "dae_decode_tile_n": (i32, [i32]),
     "dae_cos_reduce": (i32, [vp, i32, i32, i32, vp, vp, vp]),
     "dae_gram": (i32, [vp, i64, i32, i32, vp, i32, vp]),
     "dae_label_stats": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp, f32, vp, vp]),

@@ -143,7 +143,9 @@ class DenoisingAutoencoder(object):
             bv0 = iw[2] if isinstance(iw, (tuple, list)) and len(iw) > 2 else None
             assert np.shape(W0) == (n_features, self.n_components), (np.shape(W0), (n_features, self.n_components))
             return W0, bh0, bv0
-        return utils.xavier_init(n_features, self.n_components, self.xavier_init), None, None   # reference :365-367
+        # reference :365-367; a private stream seeded like tf.set_random_seed(seed) would be (:74), never the global one
+        rng = np.random.RandomState(self.seed) if self.seed >= 0 else None
+        return utils.xavier_init(n_features, self.n_components, self.xavier_init, rng=rng), None, None
 
     # ------------------------------------------------------------------ fit
     def fit(self, train_set, validation_set=None, train_set_label=None, validation_set_label=None,

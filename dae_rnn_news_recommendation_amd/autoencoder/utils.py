@@ -18,14 +18,19 @@ except Exception:  # pragma: no cover
     pd = None
 
 
+_XAVIER_RNG = np.random.RandomState()      # private stream: the weight draw must not consume the global legacy stream
+
+
 def xavier_init(fan_in, fan_out, const=1, rng=None):
     """U(-c*sqrt(6/(fan_in+fan_out)), +c*sqrt(...)) as a float32 ndarray  (reference utils.py:16-26).
 
-    The reference draws from ``tf.random_uniform`` under the TF graph seed; that stream cannot be
-    reproduced without TensorFlow, so the draw here comes from NumPy (the legacy global RandomState by
-    default, i.e. it follows ``np.random.seed(seed)`` like everything else in the reference)."""
+    The reference draws from ``tf.random_uniform`` under the TF graph seed: a stream of its own that cannot be
+    reproduced without TensorFlow and that does NOT touch NumPy's global RandomState.  The draw here therefore comes
+    from a private ``RandomState`` (``rng``, or a module-level one), so that with the same ``seed`` the global legacy
+    stream -- masking decisions and shuffles of every epoch -- stays exactly the reference's (autoencoder.py:72-73,
+    218-220) whether or not ``init_weights`` is injected."""
     bound = const * np.sqrt(6.0 / (fan_in + fan_out))
-    draw = np.random.uniform if rng is None else rng.uniform
+    draw = (_XAVIER_RNG if rng is None else rng).uniform
     return draw(-bound, bound, (fan_in, fan_out)).astype(np.float32)
 
 

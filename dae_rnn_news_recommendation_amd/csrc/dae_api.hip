@@ -26,6 +26,7 @@ extern "C" int dae_abi_version(void) { return DAE_ABI_VERSION; }
 extern "C" const char* dae_last_error(void) { return g_err; }
 extern "C" int64_t dae_pad(int64_t n) { return pad128(n); }
 extern "C" void dae_set_glds(int32_t nst) { set_use_glds(nst); }
+extern "C" int32_t dae_decode_tile_n(int32_t dtype) { return decode_tile_n(dtype); }
 
 extern "C" int dae_gemm_nt(int32_t dtype, int32_t M, int32_t N, const void* A0, int64_t lda0, const void* Bt0, int64_t ldb0,
                            int32_t K0, const void* A1, int64_t lda1, const void* Bt1, int64_t ldb1, int32_t K1, float* C,
@@ -155,13 +156,14 @@ static uint64_t carve(dae_plan* p, char* base) {
     p->G = (float*)take(Bp * Bp * 4);
     p->Gs = take(Bp * Bp * es);
     p->role_cnt = (uint32_t*)take(p->cfg.pos_triplets_only ? Bp * Bp * 4 : 256);
-    p->rowloss_part = (float*)take((2 * Fp / 128) * Bp * 4);
+    const uint64_t dbn = decode_tile_n(p->cfg.dtype);   // tile width of the decode kernel: lays out its partial-sum arrays
+    p->rowloss_part = (float*)take((2 * Fp / dbn) * Bp * 4);
     p->dbv_part = (float*)take((2 * Bp / 128) * Fp * 4);
     p->colsum_part = (float*)take(2 * (Bp / 32) * Hp * 4);
-    p->cos_part = (float*)take(2 * (2 * Fp / 128) * Bp * 4);
+    p->cos_part = (float*)take(2 * (2 * Fp / dbn) * Bp * 4);
     p->cos_stats = (float*)take(3 * Bp * 4);
     p->rowsq_scratch = (float*)take((Fp / 64) * Bp * 4);
-    p->tile_part = (float*)take((Bp / 128) * (Fp / 128) * 4);
+    p->tile_part = (float*)take((Bp / 128) * (Fp / dbn) * 4);
     p->cw = (float*)take(Bp * 4);
     p->loss_part = (float*)take(Bp * 4);
     p->dw_f32 = (float*)take(Bp * 4);
@@ -422,14 +424,15 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
         void* mstream = (void*)ms;
         if (forked) {
             RC(launch_gram(p, Bp, Hp, dslab, ms));
-            RC(dae_triplet_batch_all(p->D_slabs, p->s_gram, dslab, Bp, s->labels, B, Bp, 0, p->loss_part, p->cnt_part, p->G, p->role_cnt,
+            RC(dae_triplet_batch_all(p->D_slabs, p->s_gram, dslab, Bp, s->labels, B, Bp, dt == DAE_BF16 ? DAE_MINER_FAST : 0, p->loss_part, p->cnt_part, p->G, p->role_cnt,
                                      mstream));
             if (backward) RC(dae_sym_scale(p->G, B, Bp, p->tri_scalars, dt, p->Gs, mstream));
             DAE_CHECK_HIP(hipEventRecord(p->ev_join, ms));
         } else {
             PROF(PS_GRAM, launch_gram(p, Bp, Hp, dslab, st));
             if (c.triplet == DAE_TRIPLET_BATCH_ALL)
-                PROF(PS_MINER, dae_triplet_batch_all(p->D_slabs, p->s_gram, dslab, Bp, s->labels, B, Bp, c.pos_triplets_only, p->loss_part,
+                PROF(PS_MINER, dae_triplet_batch_all(p->D_slabs, p->s_gram, dslab, Bp, s->labels, B, Bp,
+                                         (c.pos_triplets_only ? DAE_MINER_POS_ONLY : 0) | (dt == DAE_BF16 ? DAE_MINER_FAST : 0), p->loss_part,
                                          p->cnt_part, p->G, p->role_cnt, stream));
             else
                 PROF(PS_MINER, dae_triplet_batch_hard(p->D_slabs, p->s_gram, dslab, Bp, s->labels, B, Bp, p->loss_part, p->cnt_part, p->dw_i32, p->G,
@@ -441,7 +444,8 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
         }
     }
     // 7. decode + reconstruction loss + d cost/d z2   (K3/K4)
-    const int ncw = 2 * Fp / 128;
+    const int dbn = decode_tile_n(dt);
+    const int ncw = 2 * Fp / dbn;
     DecodeEpi e;
     memset(&e, 0, sizeof(e));
     e.bv = p->b.bv; e.x = p->x; e.ldx = Fp; e.x_bits = use_xbits ? p->x_bits : nullptr; e.ldxb = Fp / 32; e.cw = p->cw; e.cos_stats = is_cos ? p->cos_stats : nullptr;
@@ -460,7 +464,7 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     }
     if (forked) DAE_CHECK_HIP(hipStreamWaitEvent(st, p->ev_join, 0));   // join: triplet scalars and Gs are ready
     // 8. statistics of this step (autoencoder.py:233 fetch list)
-    StatsArgs sa{is_cos ? p->rowloss_part : nullptr, 1, is_cos ? nullptr : p->tile_part, (Bp / 128) * (Fp / 128), p->cw, B, Bp,
+    StatsArgs sa{is_cos ? p->rowloss_part : nullptr, 1, is_cos ? nullptr : p->tile_part, (Bp / 128) * (Fp / dbn), p->cw, B, Bp,
                  c.triplet == 3 ? DAE_TRIPLET_BATCH_HARD : c.triplet, c.alpha, p->tri_scalars,
                  c.triplet == DAE_TRIPLET_BATCH_ALL ? p->nvalid : nullptr, s->stats, fold_finalize ? p->loss_part : nullptr,
                  fold_finalize ? p->cnt_part : nullptr};

@@ -748,11 +748,24 @@ __global__ __launch_bounds__(GEMM_THREADS, wg_per_cu_for(NST)) void gemm_nt_trac
 // addition order -- and the result -- is deterministic.  fp32 (parity mode) keeps direct global accesses.
 // LOSS / ACT are compile-time so the hot specialisation (cross_entropy + sigmoid) carries no dead code.
 // ------------------------------------------------------------------------------------------------
-constexpr int EPI_PITCH = 272;                       // bytes per staged row: 128 bf16 + 16 B pad (bank shift of 4 rows)
-constexpr int EPI_TILE_BYTES = 128 * EPI_PITCH;      // 34816
-constexpr int EPI_AUX_OFF = 2 * EPI_TILE_BYTES;      // 69632 (>= the 64 KiB of the K-loop stages)
-constexpr int EPI_AUX_FLOATS = 17 * 128;             // 13 x 128 floats + the 128 x 4 words of the x bit tile
-constexpr int DECODE_EPI_BYTES = EPI_AUX_OFF + EPI_AUX_FLOATS * 4;   // 76288 (epilogue footprint; the K loop may need more)
+// Tile geometry of the decode kernel: 128 rows x BN_T columns.  BN_T = 64 (bf16) gives 7 x 158 = 1106 tiles of 48 KB LDS
+// and <= 168 VGPRs, i.e. THREE workgroups per CU and 768 resident slots: the 128 x 128 form had 553 tiles on 512 slots
+// (2 per CU), so 41 stragglers doubled the kernel time (rocprofv3: wave lifetime 15.6 us, kernel 32 us).
+template <int BN_T> struct DecGeo {
+    static constexpr int NTB = BN_T / 64;                  // 32-column MFMA blocks per wave along N (waves are 2 x 2)
+    static constexpr int WCOLS = BN_T / 2;                 // columns per wave
+    static constexpr int P0 = BN_T * 2 + 16;               // staged row pitch of the [128][BN_T] delta2 tile (bf16 + 16 B pad)
+    static constexpr int P1 = 128 * 2 + 16;                // staged row pitch of the [BN_T][128] delta2^T tile
+    static constexpr int R0_BYTES = 128 * P0;
+    static constexpr int R1_BYTES = BN_T * P1;
+    static constexpr int AUX_OFF = R0_BYTES + R1_BYTES;
+    static constexpr int AUX_FLOATS = 13 * 128 + 128 * (BN_T / 32);   // 13 x 128 floats + the 128 x (BN_T/32) words of the x bit tile
+    static constexpr int EPI_BYTES = AUX_OFF + AUX_FLOATS * 4;
+    static constexpr int STAGE = TILE_BYTES + BN_T * BKB;  // K-loop stage: A tile 16 KB + B tile
+    static constexpr int LOOP_BYTES = BN_T == 128 ? lds_bytes_for(2) : 2 * STAGE;
+    static constexpr int LDS_BYTES = LOOP_BYTES > EPI_BYTES ? LOOP_BYTES : EPI_BYTES;
+    static constexpr int WG_PER_CU = BN_T == 128 ? 2 : 3;
+};
 
 template <typename T> __device__ __forceinline__ void store4(T* p, float a, float b, float c, float d);
 template <> __device__ __forceinline__ void store4<float>(float* p, float a, float b, float c, float d) {
@@ -787,13 +800,98 @@ template <int ACT> __device__ __forceinline__ float act_bwd(float a) {
     else return 1.0f;
 }
 
+// K loop of the 128 x 64 decode tile: two LDS stages filled by global_load_lds (A 4 + B 2 pieces of 1 KiB per wave), two
+// raw barriers per K tile.  With three workgroups per CU the DMA latency and the barriers of one workgroup hide behind the
+// MFMAs / epilogue VALU of the other two, so the loop itself stays simple; K = Hp is only 8 tiles deep.
+// Waves 2 x 2: wave (wm, wn) owns rows [64 wm, +64) x columns [32 wn, +32) = 2 MFMA 32x32 accumulators.
+template <typename T>
+__device__ __forceinline__ void mainloop_n64(const GemmParams& p, int tm, int tn, char* lds, f32x16 (&acc)[2][1]) {
+    constexpr int BN_T = 64, STAGE = DecGeo<64>::STAGE;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int row0_m = tm * BM, row0_n = tn * BN_T;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+    const int nk = p.seg[0].ktiles;                    // single segment, no split-K
+    if (nk <= 0) return;
+    uint32_t voA[4], voB[2];
+    {
+        const uint32_t lda = (uint32_t)p.seg[0].lda_b, ldb = (uint32_t)p.seg[0].ldb_b;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (i * 4 + wave) * 8 + (lane >> 3);
+            voA[i] = (uint32_t)(row0_m + row) * lda + (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) << 4);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (i * 4 + wave) * 8 + (lane >> 3);
+            voB[i] = (uint32_t)(row0_n + row) * ldb + (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) << 4);
+        }
+    }
+    const char* gA = p.seg[0].A;
+    const char* gB = p.seg[0].Bt;
+    auto dma_stage = [&](char* slot) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gA + voA[i]),
+                                             (__attribute__((address_space(3))) void*)(slot + (i * 4 + wave) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gB + voB[i]),
+                                             (__attribute__((address_space(3))) void*)(slot + TILE_BYTES + (i * 4 + wave) * 1024), 16, 0, 0);
+        gA += BKB; gB += BKB;
+    };
+    const int r = lane & 31, g = lane >> 5;
+    const int swz = (r >> 1) & 7;
+    const uint32_t lbase = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)lds;
+    const uint32_t offa = (wm * 64 + r) * BKB, offb = TILE_BYTES + (wn * 32 + r) * BKB;
+    uint32_t so[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) so[kk] = (uint32_t)(((kk * 2 + g) ^ swz) << 4);
+    dma_stage(lds);
+    for (int i = 0; i < nk; ++i) {
+        if (i + 1 < nk) { dma_stage(lds + ((i + 1) & 1) * STAGE); wait_vm<6>(); }
+        else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();                  // stage i landed for every wave
+        asm volatile("" ::: "memory");
+        const uint32_t sb = lbase + (i & 1) * STAGE;
+        i32x4 fa[4][2], fb[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            fa[kk][0] = lds_read_b128(sb + offa + so[kk]);
+            fa[kk][1] = lds_read_b128_off4096(sb + offa + so[kk]);
+            fb[kk] = lds_read_b128(sb + offb + so[kk]);
+        }
+#define DAE_N64_GROUP(KK, CNT)                                   \
+    asm volatile("s_waitcnt lgkmcnt(" #CNT ")" ::: "memory");    \
+    __builtin_amdgcn_sched_barrier(0);                           \
+    Mma<T>::run(fa[KK][0], fb[KK], acc[0][0]);                   \
+    Mma<T>::run(fa[KK][1], fb[KK], acc[1][0]);
+        DAE_N64_GROUP(0, 9)
+        DAE_N64_GROUP(1, 6)
+        DAE_N64_GROUP(2, 3)
+        DAE_N64_GROUP(3, 0)
+#undef DAE_N64_GROUP
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();                  // every wave has read slot i & 1: iteration i+1 may refill it
+        asm volatile("" ::: "memory");
+    }
+}
+
 constexpr float CE_FAST_ZMAX = 14.0f;               // sigmoid(14) = 1 - 8.3e-7: five fp32 ulps from saturation
 constexpr int DECODE_NST = 2;
-template <typename T, int LOSS, int ACT, bool XBITS = false>
-__global__ __launch_bounds__(GEMM_THREADS, wg_per_cu_for(DECODE_NST)) void gemm_decode_loss(GemmParams p, DecodeEpi e) {
+template <typename T, int LOSS, int ACT, bool XBITS = false, int BN_T = 128>
+__global__ __launch_bounds__(GEMM_THREADS, DecGeo<BN_T>::WG_PER_CU) void gemm_decode_loss(GemmParams p, DecodeEpi e) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    using Geo = DecGeo<BN_T>;
+    constexpr int NTB = Geo::NTB, WCOLS = Geo::WCOLS, P0 = Geo::P0, P1 = Geo::P1;
+    constexpr int WPR = BN_T / 32;                     // words of the x bit tile per row
     constexpr bool STAGED = (sizeof(T) == 2);
     static_assert(!XBITS || STAGED, "the bit image of x is a bf16-mode operand");
+    static_assert(BN_T == 128 || STAGED, "the 64-column tile is a bf16-mode kernel");
     constexpr bool IS_COS = (LOSS == DAE_LOSS_COSINE);
     int tm, tn, split, kt0, kt1;
     if (!block_to_tile(p, tm, tn, split, kt0, kt1)) return;
@@ -806,52 +904,57 @@ __global__ __launch_bounds__(GEMM_THREADS, wg_per_cu_for(DECODE_NST)) void gemm_
     const bool pass1 = IS_COS && e.cos_pass == 1;
 
     // ---- prefetch the clean-input tile (registers now, LDS after the K loop) ----
-    // XBITS (binary input): the tile is 128 rows x 4 words of the gather's bit image -- 2 KB instead of 32 KB
-    i32x4 xr[8];
-    uint2 xb = {0u, 0u};
+    // XBITS (binary input): the tile is 128 rows x BN_T/32 words of the gather's bit image instead of 128 x BN_T bf16
+    constexpr int XCH = BN_T / 16;                     // 16-byte chunks per thread of the [128][BN_T] bf16 tile
+    i32x4 xr[XCH];
+    uint32_t xb[WPR / 2] = {};
     if constexpr (XBITS) {
-        xb = *reinterpret_cast<const uint2*>(e.x_bits + (int64_t)(tm * BM + (tid >> 1)) * e.ldxb + tn * 4 + (tid & 1) * 2);
+#pragma unroll
+        for (int w = 0; w < WPR / 2; ++w)
+            xb[w] = e.x_bits[(int64_t)(tm * BM + (tid >> 1)) * e.ldxb + tn * WPR + (tid & 1) * (WPR / 2) + w];
     } else if constexpr (STAGED) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < XCH; ++i) {
             const int ch = tid + GEMM_THREADS * i;
-            const int row = ch >> 4, c16 = ch & 15;
-            xr[i] = *reinterpret_cast<const i32x4*>(X + (int64_t)(tm * BM + row) * e.ldx + tn * BN + c16 * 8);
+            const int row = ch / (BN_T / 8), c16 = ch % (BN_T / 8);
+            xr[i] = *reinterpret_cast<const i32x4*>(X + (int64_t)(tm * BM + row) * e.ldx + tn * BN_T + c16 * 8);
         }
     }
 
-    f32x16 acc[2][2];
-    gemm_mainloop<T, DECODE_NST>(p, tm, tn, kt0, kt1, lds, acc);
+    f32x16 acc[2][NTB];
+    if constexpr (BN_T == 128) gemm_mainloop<T, DECODE_NST>(p, tm, tn, kt0, kt1, lds, acc);
+    else mainloop_n64<T>(p, tm, tn, lds, acc);
     __syncthreads();                                   // every wave is done with the K-loop stages
 
-    char* R0 = lds;                                    // x tile, overwritten in place by delta2   [128][EPI_PITCH]
-    char* R1 = lds + EPI_TILE_BYTES;                   // delta2^T tile                             [128][EPI_PITCH]
-    float* aux = reinterpret_cast<float*>(lds + EPI_AUX_OFF);
+    char* R0 = lds;                                    // x tile, overwritten in place by delta2   [128][P0]
+    char* R1 = lds + Geo::R0_BYTES;                    // delta2^T tile                             [BN_T][P1]
+    float* aux = reinterpret_cast<float*>(lds + Geo::AUX_OFF);
     float* cw_l = aux;                                 // [128] row weights
-    float* bv_l = aux + 128;                           // [128] visible bias
+    float* bv_l = aux + 128;                           // [BN_T] visible bias
     float* rowsum_l = aux + 256;                       // [2 (wn)][128]
-    float* colsum_l = aux + 512;                       // [2 (wm)][128]
+    float* colsum_l = aux + 512;                       // [2 (wm)][BN_T]
     float* inx_l = aux + 768;                          // [128] 1/|x|            (cosine)
     float* cyy_l = aux + 896;                          // [128] sum y^2          (cosine pass 2)
     float* cxy_l = aux + 1024;                         // [128] sum xhat.y       (cosine pass 2)
     float* pyy_l = aux + 1152;                         // [2][128] partial sum y^2   (cosine pass 1)
     float* pxy_l = aux + 1408;                         // [2][128] partial sum xhat.y
-    uint32_t* xb_l = reinterpret_cast<uint32_t*>(aux + 1664);   // [128][4] bit image of the clean-input tile (XBITS)
+    uint32_t* xb_l = reinterpret_cast<uint32_t*>(aux + 1664);   // [128][WPR] bit image of the clean-input tile (XBITS)
 
     if constexpr (XBITS) {
-        *reinterpret_cast<uint2*>(xb_l + (tid >> 1) * 4 + (tid & 1) * 2) = xb;
+#pragma unroll
+        for (int w = 0; w < WPR / 2; ++w) xb_l[(tid >> 1) * WPR + (tid & 1) * (WPR / 2) + w] = xb[w];
     } else if constexpr (STAGED) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < XCH; ++i) {
             const int ch = tid + GEMM_THREADS * i;
-            const int row = ch >> 4, c16 = ch & 15;
-            *reinterpret_cast<i32x4*>(R0 + row * EPI_PITCH + c16 * 16) = xr[i];
+            const int row = ch / (BN_T / 8), c16 = ch % (BN_T / 8);
+            *reinterpret_cast<i32x4*>(R0 + row * P0 + c16 * 16) = xr[i];
         }
     }
     if (tid < 128) {
-        const int row = tm * BM + tid, col = tn * BN + tid;
+        const int row = tm * BM + tid, col = tn * BN_T + tid;
         cw_l[tid] = e.cw[row];                         // zero beyond B by construction
-        bv_l[tid] = col < e.F ? e.bv[col] : 0.f;
+        if (tid < BN_T) bv_l[tid] = col < e.F ? e.bv[col] : 0.f;
         if constexpr (IS_COS) {
             inx_l[tid] = rsqrtf(fmaxf(e.cos_stats[row], 1e-12f));
             cyy_l[tid] = e.cos_pass == 2 ? e.cos_stats[e.Bp + row] : 0.f;
@@ -860,22 +963,23 @@ __global__ __launch_bounds__(GEMM_THREADS, wg_per_cu_for(DECODE_NST)) void gemm_
     }
     __syncthreads();
 
-    const int lcol0 = wn * 64 + c;                     // local column of nt = 0
+    const int lcol0 = wn * WCOLS + c;                  // local column of nt = 0
     const int lrow0 = wm * 64 + 4 * g;                 // local row of (mt = 0, r = 0)
     const float eps = 1e-16f;
-    float colsum[2] = {0.f, 0.f};
-    float cm[2], bvv[2];                               // column mask as a multiplier: padded features contribute nothing
+    float colsum[NTB];
+    float cm[NTB], bvv[NTB];                           // column mask as a multiplier: padded features contribute nothing
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        cm[nt] = (tn * BN + lcol0 + nt * 32) < e.F ? 1.f : 0.f;
+    for (int nt = 0; nt < NTB; ++nt) {
+        colsum[nt] = 0.f;
+        cm[nt] = (tn * BN_T + lcol0 + nt * 32) < e.F ? 1.f : 0.f;
         bvv[nt] = bv_l[lcol0 + nt * 32];
     }
     // per-lane base addresses; everything else is a compile-time offset
-    char* r0_lane = R0 + lrow0 * EPI_PITCH + lcol0 * 2;
-    char* r1_lane = R1 + lcol0 * EPI_PITCH + lrow0 * 2;
-    const T* x_lane = X + (int64_t)(tm * BM + lrow0) * e.ldx + tn * BN + lcol0;
-    T* d2_lane = D2 ? D2 + (int64_t)(tm * BM + lrow0) * e.ldd + tn * BN + lcol0 : nullptr;
-    T* d2t_lane = D2T ? D2T + (int64_t)(tn * BN + lcol0) * e.lddt + tm * BM + lrow0 : nullptr;
+    char* r0_lane = R0 + lrow0 * P0 + lcol0 * 2;
+    char* r1_lane = R1 + lcol0 * P1 + lrow0 * 2;
+    const T* x_lane = X + (int64_t)(tm * BM + lrow0) * e.ldx + tn * BN_T + lcol0;
+    T* d2_lane = D2 ? D2 + (int64_t)(tm * BM + lrow0) * e.ldd + tn * BN_T + lcol0 : nullptr;
+    T* d2t_lane = D2T ? D2T + (int64_t)(tn * BN_T + lcol0) * e.lddt + tm * BM + lrow0 : nullptr;
 
     // static (compile-time) accumulator indexing: a runtime-indexed f32x16 would be demoted to scratch
     // FAST (cross_entropy + sigmoid, every |z| of this wave < CE_FAST_ZMAX): the exact-math identities
@@ -890,13 +994,13 @@ __global__ __launch_bounds__(GEMM_THREADS, wg_per_cu_for(DECODE_NST)) void gemm_
         constexpr int mt = decltype(MT)::value, r4 = decltype(R4)::value;
         constexpr bool FAST = decltype(FASTV)::value;
         constexpr int rloc = mt * 32 + 8 * r4;         // local row offset of q = 0 relative to lrow0
-        float d2v[2][4];
-        float xin[4][2];
-        if constexpr (!STAGED) {                       // fp32: batch the 8 global loads of this block
+        float d2v[NTB][4];
+        float xin[4][NTB];
+        if constexpr (!STAGED) {                       // fp32: batch the global loads of this block
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) xin[q][nt] = Elem<T>::to(x_lane[(int64_t)(rloc + q) * e.ldx + nt * 32]);
+                for (int nt = 0; nt < NTB; ++nt) xin[q][nt] = Elem<T>::to(x_lane[(int64_t)(rloc + q) * e.ldx + nt * 32]);
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -908,11 +1012,11 @@ __global__ __launch_bounds__(GEMM_THREADS, wg_per_cu_for(DECODE_NST)) void gemm_
             float inx = 0.f, cs_yy = 0.f, cs_xy = 0.f;
             if constexpr (IS_COS) { inx = inx_l[lrow]; cs_yy = cyy_l[lrow]; cs_xy = cxy_l[lrow]; }
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
+            for (int nt = 0; nt < NTB; ++nt) {
                 const float z = acc[mt][nt][r] + bvv[nt];
                 float x;
-                if constexpr (XBITS) x = (float)((xb_l[(lrow0 + rloc + q) * 4 + wn * 2 + nt] >> c) & 1u);
-                else if constexpr (STAGED) x = bf2f(*reinterpret_cast<const bf16_t*>(r0_lane + (rloc + q) * EPI_PITCH + nt * 64));
+                if constexpr (XBITS) x = (float)((xb_l[(lrow0 + rloc + q) * WPR + wn * NTB + nt] >> c) & 1u);
+                else if constexpr (STAGED) x = bf2f(*reinterpret_cast<const bf16_t*>(r0_lane + (rloc + q) * P0 + nt * 64));
                 else x = xin[q][nt];
                 float l = 0.f, dy = 0.f;
                 if constexpr (FAST) {
@@ -926,7 +1030,7 @@ __global__ __launch_bounds__(GEMM_THREADS, wg_per_cu_for(DECODE_NST)) void gemm_
                     d2v[nt][q] = d2;
                     colsum[nt] += d2;
                     if constexpr (STAGED) {
-                        *reinterpret_cast<bf16_t*>(r0_lane + (rloc + q) * EPI_PITCH + nt * 64) = f2bf_hw(d2);
+                        *reinterpret_cast<bf16_t*>(r0_lane + (rloc + q) * P0 + nt * 64) = f2bf_hw(d2);
                     } else {
                         if (d2_lane) d2_lane[(int64_t)(rloc + q) * e.ldd + nt * 32] = Elem<T>::from(d2);
                     }
@@ -958,7 +1062,7 @@ __global__ __launch_bounds__(GEMM_THREADS, wg_per_cu_for(DECODE_NST)) void gemm_
                 d2v[nt][q] = d2;
                 colsum[nt] += d2;
                 if constexpr (STAGED) {
-                    *reinterpret_cast<bf16_t*>(r0_lane + (rloc + q) * EPI_PITCH + nt * 64) = f2bf_hw(d2);
+                    *reinterpret_cast<bf16_t*>(r0_lane + (rloc + q) * P0 + nt * 64) = f2bf_hw(d2);
                 } else {
                     if (d2_lane && !pass1) d2_lane[(int64_t)(rloc + q) * e.ldd + nt * 32] = Elem<T>::from(d2);
                 }
@@ -978,12 +1082,12 @@ __global__ __launch_bounds__(GEMM_THREADS, wg_per_cu_for(DECODE_NST)) void gemm_
             }
         }
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
+        for (int nt = 0; nt < NTB; ++nt) {
             if constexpr (STAGED) {
                 uint2 v;
                 v.x = f2bf_pack_hw(d2v[nt][0], d2v[nt][1]);
                 v.y = f2bf_pack_hw(d2v[nt][2], d2v[nt][3]);
-                *reinterpret_cast<uint2*>(r1_lane + nt * 32 * EPI_PITCH + rloc * 2) = v;
+                *reinterpret_cast<uint2*>(r1_lane + nt * 32 * P1 + rloc * 2) = v;
             } else {
                 if (d2t_lane && !pass1)
                     store4<T>(d2t_lane + (int64_t)nt * 32 * e.lddt + rloc, d2v[nt][0], d2v[nt][1], d2v[nt][2], d2v[nt][3]);
@@ -1001,7 +1105,7 @@ __global__ __launch_bounds__(GEMM_THREADS, wg_per_cu_for(DECODE_NST)) void gemm_
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < NTB; ++nt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) zmax = fmaxf(zmax, fabsf(acc[mt][nt][r] + bvv[nt]));
         fast = __builtin_amdgcn_ballot_w64(!(zmax < CE_FAST_ZMAX)) == 0ull && !e.ce_literal;   // NaN logits take the literal path
@@ -1018,9 +1122,9 @@ __global__ __launch_bounds__(GEMM_THREADS, wg_per_cu_for(DECODE_NST)) void gemm_
 #undef DAE_EPI_ROWS
     if (!pass1) {                                       // column sums: rows of g = 0 and g = 1, then one lane per column
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
+        for (int nt = 0; nt < NTB; ++nt) {
             const float v = colsum[nt] + __shfl_xor(colsum[nt], 32, 64);
-            if (g == 0) colsum_l[wm * 128 + lcol0 + nt * 32] = v;
+            if (g == 0) colsum_l[wm * BN_T + lcol0 + nt * 32] = v;
         }
     }
     __syncthreads();
@@ -1029,15 +1133,18 @@ __global__ __launch_bounds__(GEMM_THREADS, wg_per_cu_for(DECODE_NST)) void gemm_
     if constexpr (STAGED) {
         if (!pass1) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < XCH; ++i) {
                 const int ch = tid + GEMM_THREADS * i;
-                const int row = ch >> 4, c16 = ch & 15;
-                if (D2)
-                    *reinterpret_cast<i32x4*>(D2 + (int64_t)(tm * BM + row) * e.ldd + tn * BN + c16 * 8) =
-                        *reinterpret_cast<const i32x4*>(R0 + row * EPI_PITCH + c16 * 16);
-                if (D2T)
-                    *reinterpret_cast<i32x4*>(D2T + (int64_t)(tn * BN + row) * e.lddt + tm * BM + c16 * 8) =
-                        *reinterpret_cast<const i32x4*>(R1 + row * EPI_PITCH + c16 * 16);
+                if (D2) {
+                    const int row = ch / (BN_T / 8), c16 = ch % (BN_T / 8);
+                    *reinterpret_cast<i32x4*>(D2 + (int64_t)(tm * BM + row) * e.ldd + tn * BN_T + c16 * 8) =
+                        *reinterpret_cast<const i32x4*>(R0 + row * P0 + c16 * 16);
+                }
+                if (D2T) {
+                    const int row = ch >> 4, c16 = ch & 15;
+                    *reinterpret_cast<i32x4*>(D2T + (int64_t)(tn * BN_T + row) * e.lddt + tm * BM + c16 * 8) =
+                        *reinterpret_cast<const i32x4*>(R1 + row * P1 + c16 * 16);
+                }
             }
         }
     }
@@ -1052,7 +1159,10 @@ __global__ __launch_bounds__(GEMM_THREADS, wg_per_cu_for(DECODE_NST)) void gemm_
         } else {
             if (e.rowloss_part) e.rowloss_part[(int64_t)(tn * 2 + w) * e.Bp + tm * BM + k] = rowok ? rowsum_l[w * 128 + k] : 0.f;
         }
-        if (e.dbv_part && !pass1) e.dbv_part[(int64_t)(tm * 2 + w) * e.Fp + tn * BN + k] = colsum_l[w * 128 + k];
+        if (e.dbv_part && !pass1 && tid < 2 * BN_T) {
+            const int w2 = tid / BN_T, k2 = tid % BN_T;
+            e.dbv_part[(int64_t)(tm * 2 + w2) * e.Fp + tn * BN_T + k2] = colsum_l[w2 * BN_T + k2];
+        }
     }
     if constexpr (!IS_COS) {
         if (e.tile_part) {                              // this tile's share of sum_i cw_i * rowloss_i (4 waves, fixed order)
@@ -1071,11 +1181,11 @@ static int g_nst = 2;   // staging variant of the plain GEMM: 0 register-staged,
 
 static int fill_params(GemmParams& p, int dtype, int M, int N, const void* A0, int64_t lda0, const void* Bt0,
                        int64_t ldb0, int K0, const void* A1, int64_t lda1, const void* Bt1, int64_t ldb1, int K1,
-                       int splits) {
+                       int splits, int bn = BN) {
     const int es = (dtype == DAE_BF16) ? 2 : 4;
     const int kel = BKB / es;
     DAE_CHECK_ARG(dtype == DAE_BF16 || dtype == DAE_F32, "gemm: bad dtype %d", dtype);
-    DAE_CHECK_ARG(M > 0 && N > 0 && M % BM == 0 && N % BN == 0, "gemm: M=%d N=%d must be positive multiples of 128", M, N);
+    DAE_CHECK_ARG(M > 0 && N > 0 && M % BM == 0 && N % bn == 0, "gemm: M=%d N=%d must be positive multiples of %d / %d", M, N, BM, bn);
     DAE_CHECK_ARG(K0 > 0 && K0 % kel == 0 && K1 >= 0 && K1 % kel == 0, "gemm: K0=%d K1=%d must be multiples of %d", K0, K1, kel);
     DAE_CHECK_ARG(A0 && Bt0 && (K1 == 0 || (A1 && Bt1)), "gemm: null operand");
     DAE_CHECK_ARG((lda0 * es) % 16 == 0 && (ldb0 * es) % 16 == 0 && (lda1 * es) % 16 == 0 && (ldb1 * es) % 16 == 0,
@@ -1088,14 +1198,16 @@ static int fill_params(GemmParams& p, int dtype, int M, int N, const void* A0, i
     p.seg[0] = {(const char*)A0, (const char*)Bt0, lda0 * es, ldb0 * es, K0 / kel};
     p.seg[1] = {(const char*)A1, (const char*)Bt1, lda1 * es, ldb1 * es, K1 / kel};
     p.ktiles_total = p.seg[0].ktiles + p.seg[1].ktiles;
-    p.tiles_m = M / BM; p.tiles_n = N / BN;
+    p.tiles_m = M / BM; p.tiles_n = N / bn;
     p.splits = splits < 1 ? 1 : splits;
     p.trace = nullptr;
     DAE_CHECK_ARG(p.splits <= p.ktiles_total, "gemm: splits=%d exceeds k-tiles=%d", p.splits, p.ktiles_total);
     return 0;
 }
 
-constexpr int DECODE_LDS_BYTES = lds_bytes_for(DECODE_NST) > DECODE_EPI_BYTES ? lds_bytes_for(DECODE_NST) : DECODE_EPI_BYTES;
+// bf16 decode runs on 128 x 64 tiles (three workgroups per CU), fp32 (parity mode) keeps the 128 x 128 tile
+constexpr int DECODE_BN_BF16 = 64;
+int decode_tile_n(int dtype) { return dtype == DAE_BF16 ? DECODE_BN_BF16 : BN; }
 
 typedef void (*f32out_fn)(GemmParams, float*, int64_t, int64_t);
 constexpr int DEFAULT_NST = 2;
@@ -1130,13 +1242,13 @@ static int g_cus = 0;        // compute units of the current device (set by gemm
 static int g_use_pc = 1;     // DAE_NO_PC=1 keeps the 4-wave kernel for every grid (A/B)
 typedef void (*decode_fn)(GemmParams, DecodeEpi);
 static decode_fn decode_kernel_xbits(int loss, int act) {
-#define DAE_DKX(LV, AV) if (loss == LV && act == AV) return gemm_decode_loss<bf16_t, LV, AV, true>;
+#define DAE_DKX(LV, AV) if (loss == LV && act == AV) return gemm_decode_loss<bf16_t, LV, AV, true, DECODE_BN_BF16>;
     DAE_DKX(0, 0) DAE_DKX(0, 1) DAE_DKX(0, 2) DAE_DKX(1, 0) DAE_DKX(1, 1) DAE_DKX(1, 2) DAE_DKX(2, 0) DAE_DKX(2, 1) DAE_DKX(2, 2)
 #undef DAE_DKX
     return nullptr;
 }
 template <typename T> static decode_fn decode_kernel(int loss, int act) {
-#define DAE_DK(LV, AV) if (loss == LV && act == AV) return gemm_decode_loss<T, LV, AV>;
+#define DAE_DK(LV, AV) if (loss == LV && act == AV) return gemm_decode_loss<T, LV, AV, false, (sizeof(T) == 2 ? DECODE_BN_BF16 : BN)>;
     DAE_DK(0, 0) DAE_DK(0, 1) DAE_DK(0, 2) DAE_DK(1, 0) DAE_DK(1, 1) DAE_DK(1, 2) DAE_DK(2, 0) DAE_DK(2, 1) DAE_DK(2, 2)
 #undef DAE_DK
     return nullptr;
@@ -1166,11 +1278,11 @@ static int gemm_init() {
         for (int l = 0; l < 3; ++l)
             for (int a = 0; a < 3; ++a) {
                 DAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decode_kernel<bf16_t>(l, a)),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, DECODE_LDS_BYTES));
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, DecGeo<DECODE_BN_BF16>::LDS_BYTES));
                 DAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decode_kernel<float>(l, a)),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, DECODE_LDS_BYTES));
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, DecGeo<BN>::LDS_BYTES));
                 DAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decode_kernel_xbits(l, a)),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, DECODE_LDS_BYTES));
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, DecGeo<DECODE_BN_BF16>::LDS_BYTES));
             }
         return 0;
     }();
@@ -1230,21 +1342,22 @@ int launch_dw_opt(int M, int N, const void* A0, int64_t lda0, const void* Bt0, i
 int launch_decode_loss(int dtype, int Bp, int Fp, int Hp, const void* h_lo, int64_t ldh, const void* W_lo, int64_t ldw,
                        const DecodeEpi& e, hipStream_t st) {
     GemmParams p;
-    if (int rc = fill_params(p, dtype, Bp, Fp, h_lo, ldh, W_lo, ldw, Hp, nullptr, 0, nullptr, 0, 0, 1)) return rc;
+    const int bn = decode_tile_n(dtype);
+    if (int rc = fill_params(p, dtype, Bp, Fp, h_lo, ldh, W_lo, ldw, Hp, nullptr, 0, nullptr, 0, 0, 1, bn)) return rc;
     if (int rc = gemm_init()) return rc;
     DAE_CHECK_ARG(e.dec_act >= 0 && e.dec_act <= 2 && e.loss_func >= 0 && e.loss_func <= 2, "decode_loss: bad act/loss");
     DAE_CHECK_ARG(e.ldx % 8 == 0 && (!e.delta2 || e.ldd % 8 == 0) && (!e.delta2_t || e.lddt % 8 == 0),
                   "decode_loss: leading dimensions must be multiples of 8 elements");
     decode_fn k = dtype == DAE_BF16 ? decode_kernel<bf16_t>(e.loss_func, e.dec_act) : decode_kernel<float>(e.loss_func, e.dec_act);
     if (e.x_bits) {
-        DAE_CHECK_ARG(dtype == DAE_BF16 && e.ldxb >= Fp / 32 && e.ldxb % 2 == 0 && ((uintptr_t)e.x_bits % 8) == 0, "decode_loss: bad x bit image");
+        DAE_CHECK_ARG(dtype == DAE_BF16 && e.ldxb >= Fp / 32 && ((uintptr_t)e.x_bits % 4) == 0, "decode_loss: bad x bit image");
         k = decode_kernel_xbits(e.loss_func, e.dec_act);
     }
     dim3 grid(grid_blocks(p)), block(GEMM_THREADS);
     static const int ce_literal = getenv("DAE_CE_LITERAL") != nullptr;
     DecodeEpi ee = e;
     ee.ce_literal = ce_literal || e.ce_literal;
-    hipLaunchKernelGGL(k, grid, block, DECODE_LDS_BYTES, st, p, ee);
+    hipLaunchKernelGGL(k, grid, block, dtype == DAE_BF16 ? DecGeo<DECODE_BN_BF16>::LDS_BYTES : DecGeo<BN>::LDS_BYTES, st, p, ee);
     DAE_CHECK_LAUNCH();
     return 0;
 }

@@ -35,6 +35,9 @@ int launch_gemm_f32out(int dtype, int M, int N, const void* A0, int64_t lda0, co
 enum { GEMM_ROLE_GENERIC = 0, GEMM_ROLE_ENCODE = 1, GEMM_ROLE_DH = 2, GEMM_ROLE_DW = 3, GEMM_ROLE_GRAM = 4 };
 int launch_decode_loss(int dtype, int Bp, int Fp, int Hp, const void* h_lo, int64_t ldh, const void* W_lo, int64_t ldw,
                        const DecodeEpi& e, hipStream_t st);
+// tile width (columns of y per workgroup) of the decode kernel for `dtype`: the partial-sum arrays it writes
+// (rowloss_part / cos_part: 2 * Fp / width rows; tile_part: (Bp/128) * (Fp/width) entries) are laid out by it
+int decode_tile_n(int dtype);
 // label statistics job (dae_label.h): either its own launch or an extra block of the CSR gather kernel
 struct LabelJob {
     const int32_t* labels; int B, Bp, triplet; int64_t* nvalid; int64_t* dw; float* cw; float alpha; float* tri_scalars;

@@ -11,7 +11,7 @@
 //   reductions; reproduces the reference's quirks literally (invalid negatives contribute 0, invalid
 //   positives are shifted by the row max, float-equality data_weight, gradient ties split equally,
 //   gradient through the row-max shift).
-#include <stdlib.h>
+#include <type_traits>
 
 #include "dae_common.h"
 
@@ -163,7 +163,12 @@ __device__ __forceinline__ void sweep_pairs(const float* __restrict__ pu, const 
 // small exp(t) comes from the first-order correction  log1p(e) = log(fl(1+e)) + (e - (fl(1+e) - 1)) / fl(1+e)
 // instead of a per-pair select.  ~12 issue slots per triplet against ~27 for sweep_pairs (2 x 4 of them transcendental).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-template <int Q2, bool FIRST>
+// FAST (bf16 training mode): sigmoid(t) = e/(1+e) = 1 - 1/w, so only the sums of r = 1/w are accumulated and turned into
+// sums of sigmoids at the end (count of lane slots minus sum r; padding slots have e = 0 -> r = 1 -> sigmoid 0, so they need
+// no mask), and the first-order log1p correction is dropped: log(fl(1+e)) is within 2^-24 ABSOLUTE of log1p(e) per triplet.
+// 11 issue slots per triplet instead of 18.  The caller checks the anchor's mean term against that absolute bound and
+// re-runs the anchor with FAST = false when it could exceed 2e-6 relative (well-separated embeddings: every term tiny).
+template <int Q2, bool FIRST, bool FAST>
 __device__ __forceinline__ void sweep_pairs2(const float* __restrict__ pu, const float* __restrict__ pf, float mid,
                                              const float* __restrict__ nv, int nP, int nN, int k0, int wave, int lane,
                                              float* __restrict__ gpos, float* __restrict__ gneg_w, float& loss_log2,
@@ -179,7 +184,9 @@ __device__ __forceinline__ void sweep_pairs2(const float* __restrict__ pu, const
         gs2[q] = f32x2{0.f, 0.f};
     }
     f32x2 corr2 = {0.f, 0.f};
+    int iters = 0;
     for (int p = wave; p < nP; p += 8) {
+        ++iters;
         const bool has2 = (p + 4) < nP;
         float u[2], fp[2], sgp[2];
         u[0] = pu[p]; u[1] = has2 ? pu[p + 4] : INFINITY;               // u = +inf -> t = -inf, F_p = 0 -> contributes nothing
@@ -190,33 +197,48 @@ __device__ __forceinline__ void sweep_pairs2(const float* __restrict__ pu, const
 #pragma unroll
             for (int q = 0; q < Q2; ++q) {
                 const f32x2 t2 = v2[q] - u[h];                           // triplet_distance[a,p,n]  (:106)
-                const f32x2 e2 = ev2[q] * fp[h];                         // exp(t)
-                const f32x2 w2 = e2 + 1.0f;
-                const float P = w2.x * w2.y;
-                const float R = __builtin_amdgcn_rcpf(P);
-                loss_log2 += __builtin_amdgcn_logf(P);                   // log2(w_a) + log2(w_b)
-                const f32x2 r2 = f32x2{w2.y, w2.x} * R;                  // 1/w_a, 1/w_b
-                corr2 += (e2 - (w2 - 1.0f)) * r2;                        // log1p correction (natural units)
-                const f32x2 sg2 = e2 * r2;                               // sigmoid(t) = SoftplusGrad
-                gs2[q] += sg2;
-                sgp2 += sg2;
+                if constexpr (FAST) {
+                    const f32x2 w2 = ev2[q] * fp[h] + 1.0f;              // 1 + exp(t)   (one packed fma)
+                    const float P = w2.x * w2.y;
+                    const float R = __builtin_amdgcn_rcpf(P);
+                    loss_log2 += __builtin_amdgcn_logf(P);               // log2(w_a) + log2(w_b)
+                    const f32x2 r2 = f32x2{w2.y, w2.x} * R;              // 1/w_a, 1/w_b  = 1 - sigmoid(t)
+                    gs2[q] += r2;
+                    sgp2 += r2;
+                } else {
+                    const f32x2 e2 = ev2[q] * fp[h];                     // exp(t)
+                    const f32x2 w2 = e2 + 1.0f;
+                    const float P = w2.x * w2.y;
+                    const float R = __builtin_amdgcn_rcpf(P);
+                    loss_log2 += __builtin_amdgcn_logf(P);               // log2(w_a) + log2(w_b)
+                    const f32x2 r2 = f32x2{w2.y, w2.x} * R;              // 1/w_a, 1/w_b
+                    corr2 += (e2 - (w2 - 1.0f)) * r2;                    // log1p correction (natural units)
+                    const f32x2 sg2 = e2 * r2;                           // sigmoid(t) = SoftplusGrad
+                    gs2[q] += sg2;
+                    sgp2 += sg2;
+                }
                 cnt_wave += (unsigned)__popcll(__ballot(t2.x > 1e-16f)) + (unsigned)__popcll(__ballot(t2.y > 1e-16f));   // (:114)
             }
             sgp[h] = sgp2.x + sgp2.y;
         }
         sgp[0] = wave64_sum_hi(sgp[0]);
         sgp[1] = wave64_sum_hi(sgp[1]);
+        if constexpr (FAST) {                                            // sum of sigmoids = lane slots - sum of r
+            sgp[0] = (float)(128 * Q2) - sgp[0];
+            sgp[1] = (float)(128 * Q2) - sgp[1];
+        }
         if (lane == 63) {
             if (FIRST) { gpos[p] = sgp[0]; if (has2) gpos[p + 4] = sgp[1]; }
             else { gpos[p] += sgp[0]; if (has2) gpos[p + 4] += sgp[1]; }
         }
     }
     loss_corr += corr2.x + corr2.y;
+    const float slots = (float)(2 * iters);                              // positives walked by this wave (incl. the u = +inf filler)
 #pragma unroll
     for (int q = 0; q < Q2; ++q) {
         const int k = k0 + (2 * q) * 64 + lane;
-        if (k < nN) gneg_w[k] = gs2[q].x;
-        if (k + 64 < nN) gneg_w[k + 64] = gs2[q].y;
+        if (k < nN) gneg_w[k] = FAST ? slots - gs2[q].x : gs2[q].x;
+        if (k + 64 < nN) gneg_w[k + 64] = FAST ? slots - gs2[q].y : gs2[q].y;
     }
 }
 
@@ -225,7 +247,7 @@ __global__ __launch_bounds__(TRIP_THREADS, OCC) void batch_all_kernel(const floa
                                                                  int64_t slab_stride, int64_t ldd,
                                                                  const int32_t* __restrict__ labels, int B, int Bp,
                                                                  float* __restrict__ loss_part, uint32_t* __restrict__ npos_part,
-                                                                 float* __restrict__ G, uint32_t* __restrict__ role_cnt, int probe) {
+                                                                 float* __restrict__ G, uint32_t* __restrict__ role_cnt, int fast) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // positives are compacted from the front of val[]/idx[], negatives from the back (nP + nN <= B)
     float* val = reinterpret_cast<float*>(smem);             // [Bp]
@@ -255,7 +277,6 @@ __global__ __launch_bounds__(TRIP_THREADS, OCC) void batch_all_kernel(const floa
         if (POS_ONLY) cpos[j] = 0u;
     }
 
-    if (probe & 4) return;
     // ---- deterministic compaction in index order (ballot ranks; coalesced label / D-row reads) ----
     // element j = k*256 + tid; its slot = (#positives before it in index order) = prefix over (k, wave) + rank in wave
     const int K = (B + TRIP_THREADS - 1) / TRIP_THREADS;           // <= 16 for B <= 4096
@@ -364,7 +385,6 @@ __global__ __launch_bounds__(TRIP_THREADS, OCC) void batch_all_kernel(const floa
     }
     }
     __syncthreads();
-    if (probe & 2) return;
     // range of the anchor's D row over its positives and negatives -> factorised or direct sweep (uniform choice)
     float lo = INFINITY, hi = -INFINITY;
     for (int k = tid; k < nP; k += TRIP_THREADS) { lo = fminf(lo, pu[k]); hi = fmaxf(hi, pu[k]); }
@@ -382,32 +402,45 @@ __global__ __launch_bounds__(TRIP_THREADS, OCC) void batch_all_kernel(const floa
     unsigned cnt = 0u;
     float* gneg_w = gneg + wave * Bp;
     unsigned* cneg_w = POS_ONLY ? cneg + wave * Bp : nullptr;
-    float loss_log2 = 0.f, loss_corr = 0.f;
-    unsigned cnt_wave = 0u;
     // chunks of 128*q2 negatives, q2 <= 5 register pairs per lane; equal-sized chunks when one is not enough
     const int need2 = (nN + 127) / 128;
     const int nch2 = (need2 + 4) / 5;
     const int q2 = nch2 > 0 ? (need2 + nch2 - 1) / nch2 : 1;
-    if (probe & 1) nN = 0;                                    // DAE_MINER_PROBE=1: everything but the pair sweeps (timing only)
-    for (int k0 = 0; fact2 && k0 < nN; k0 += q2 * 128) {
-        const bool first = (k0 == 0);
+    auto packed_sweeps = [&](auto FASTV) {
+        constexpr bool FAST = decltype(FASTV)::value;
+        float loss_log2 = 0.f, loss_corr = 0.f;
+        unsigned cnt_wave = 0u;
+        for (int k0 = 0; k0 < nN; k0 += q2 * 128) {
+            const bool first = (k0 == 0);
 #define DAE_SWEEP2(QV)                                                                                                  \
     do {                                                                                                                \
-        if (first) sweep_pairs2<QV, true>(pu, pf, mid, nv, nP, nN, k0, wave, lane, gpos, gneg_w, loss_log2, loss_corr, cnt_wave);   \
-        else sweep_pairs2<QV, false>(pu, pf, mid, nv, nP, nN, k0, wave, lane, gpos, gneg_w, loss_log2, loss_corr, cnt_wave);        \
+        if (first) sweep_pairs2<QV, true, FAST>(pu, pf, mid, nv, nP, nN, k0, wave, lane, gpos, gneg_w, loss_log2, loss_corr, cnt_wave);   \
+        else sweep_pairs2<QV, false, FAST>(pu, pf, mid, nv, nP, nN, k0, wave, lane, gpos, gneg_w, loss_log2, loss_corr, cnt_wave);        \
     } while (0)
-        switch (q2) {
-            case 5: DAE_SWEEP2(5); break;
-            case 4: DAE_SWEEP2(4); break;
-            case 3: DAE_SWEEP2(3); break;
-            case 2: DAE_SWEEP2(2); break;
-            default: DAE_SWEEP2(1); break;
-        }
+            switch (q2) {
+                case 5: DAE_SWEEP2(5); break;
+                case 4: DAE_SWEEP2(4); break;
+                case 3: DAE_SWEEP2(3); break;
+                case 2: DAE_SWEEP2(2); break;
+                default: DAE_SWEEP2(1); break;
+            }
 #undef DAE_SWEEP2
-    }
-    if (fact2) {
+        }
         loss = kLn2 * loss_log2 + loss_corr;
-        if (lane == 0) cnt = cnt_wave;
+        cnt = lane == 0 ? cnt_wave : 0u;
+    };
+    bool redo = false;
+    if (fact2) {
+        if (fast) {
+            packed_sweeps(std::true_type{});
+            // |log(fl(1+e)) - log1p(e)| <= 2^-24 per triplet: accept when that is below 2e-6 of the anchor's sum, i.e. the mean
+            // term is >= 0.03 (softplus(t) at t = -3.5); otherwise (every triplet far on the satisfied side) take the exact form
+            const float lsum = block_sum_f(loss, red);
+            redo = !(lsum >= 0.03f * (float)nP * (float)nN);
+            if (redo) { __syncthreads(); packed_sweeps(std::false_type{}); }
+        } else {
+            packed_sweeps(std::false_type{});
+        }
     }
     for (int k0 = 0; !fact2 && k0 < nN;) {
         const int need = (nN - k0 + 63) / 64;                 // negatives per lane still to cover
@@ -434,7 +467,6 @@ __global__ __launch_bounds__(TRIP_THREADS, OCC) void batch_all_kernel(const floa
 #undef DAE_SWEEP
         k0 += q * 64;
     }
-    if (probe & 8) return;
     __syncthreads();
     for (int k = tid; k < nP; k += TRIP_THREADS) {
         Grow[pidx[k]] = -gpos[k];
@@ -533,8 +565,9 @@ __global__ __launch_bounds__(TRIP_THREADS) void batch_hard_kernel(const float* _
 using namespace dae;
 
 extern "C" int dae_triplet_batch_all(const float* D_slabs, int32_t d_splits, int64_t slab_stride, int64_t ldd,
-                                     const int32_t* labels, int32_t B, int32_t Bp, int32_t pos_only, float* loss_part,
+                                     const int32_t* labels, int32_t B, int32_t Bp, int32_t mode, float* loss_part,
                                      uint32_t* npos_part, float* G, uint32_t* role_cnt, void* stream) {
+    const int pos_only = mode & DAE_MINER_POS_ONLY, fast = (mode & DAE_MINER_FAST) ? 1 : 0;
     DAE_CHECK_ARG(D_slabs && labels && loss_part && npos_part && G, "batch_all: null input");
     DAE_CHECK_ARG(B > 0 && B <= Bp && Bp <= TRIP_MAX_B, "batch_all: batch %d (padded %d) exceeds the supported %d", B, Bp, TRIP_MAX_B);
     DAE_CHECK_ARG(!pos_only || role_cnt, "batch_all: role_cnt required with pos_triplets_only");
@@ -542,21 +575,17 @@ extern "C" int dae_triplet_batch_all(const float* D_slabs, int32_t d_splits, int
     const size_t lds = (size_t)Bp * (pos_only ? 52 : 32) + 2 * (TRIP_THREADS + 1) * sizeof(int) + 8 * sizeof(float);
     DAE_CHECK_ARG(lds <= 160 * 1024, "batch_all: batch %d needs %zu B of LDS (> 160 KiB)", B, lds);
     typedef void (*ba_fn)(const float*, int, int64_t, int64_t, const int32_t*, int, int, float*, uint32_t*, float*, uint32_t*, int);
-    static const int probe = [] { const char* v = getenv("DAE_MINER_PROBE"); return v ? atoi(v) : 0; }();
-    // workgroups per CU the kernel is compiled for (register budget 168 / 128 VGPRs); DAE_MINER_OCC=4 for A/B runs
-    static const int occ = [] { const char* v = getenv("DAE_MINER_OCC"); return (v && atoi(v) == 4) ? 4 : 3; }();
-    ba_fn k = pos_only ? (occ == 4 ? batch_all_kernel<true, 4> : batch_all_kernel<true, 3>)
-                       : (occ == 4 ? batch_all_kernel<false, 4> : batch_all_kernel<false, 3>);
+    ba_fn k = pos_only ? batch_all_kernel<true, 3> : batch_all_kernel<false, 3>;      // 3 workgroups per CU (168 VGPRs)
     static bool attr_done = false;
     if (!attr_done) {
-        ba_fn all[4] = {batch_all_kernel<true, 3>, batch_all_kernel<true, 4>, batch_all_kernel<false, 3>, batch_all_kernel<false, 4>};
+        ba_fn all[2] = {batch_all_kernel<true, 3>, batch_all_kernel<false, 3>};
         for (ba_fn f : all)
             DAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k, dim3(B), dim3(TRIP_THREADS), lds, st, D_slabs, d_splits, slab_stride, ldd, labels, B, Bp, loss_part, npos_part, G,
-                       role_cnt, probe);
+                       role_cnt, fast);
     DAE_CHECK_LAUNCH();
     return 0;
 }

@@ -109,11 +109,12 @@ def encode_finish(slabs, bh, B, H, enc_act, dtype, want_hcat=False):
 def decode_loss(h_lo, W_lo, bv, x, cw, B, F, H, dec_act, loss_func, dtype, *, cos_pass=0, cos_stats=None):
     Bp, Fp, Hp = L.pad(B), L.pad(F), L.pad(H)
     dev = h_lo.device
-    ncw, nrw = 2 * Fp // 128, 2 * Bp // 128
+    bn = int(L.load().dae_decode_tile_n(dtype))         # tile width of the decode kernel lays out its partial sums
+    ncw, nrw = 2 * Fp // bn, 2 * Bp // 128
     rowloss_part = torch.zeros((ncw, Bp), dtype=torch.float32, device=dev)
     dbv_part = torch.zeros((nrw, Fp), dtype=torch.float32, device=dev)
     cos_part = torch.zeros((2, ncw, Bp), dtype=torch.float32, device=dev) if loss_func == 2 else None
-    tile_part = torch.zeros((Bp // 128) * (Fp // 128), dtype=torch.float32, device=dev)
+    tile_part = torch.zeros((Bp // 128) * (Fp // bn), dtype=torch.float32, device=dev)
     d2 = torch.zeros((Bp, Fp), dtype=tdtype(dtype), device=dev)
     d2t = torch.zeros((Fp, Bp), dtype=tdtype(dtype), device=dev)
     L.call("dae_decode_loss", dtype, B, F, H, L.ptr(h_lo), Hp, L.ptr(W_lo), Hp, L.ptr(bv), L.ptr(x), Fp, L.ptr(cw),

@@ -38,6 +38,8 @@ enum { DAE_OPT_SGD = 0, DAE_OPT_ADAGRAD = 1, DAE_OPT_MOMENTUM = 2, DAE_OPT_ADAM 
 enum { DAE_TRIPLET_NONE = 0, DAE_TRIPLET_BATCH_ALL = 1, DAE_TRIPLET_BATCH_HARD = 2,
        DAE_TRIPLET_EXPLICIT = 3 /* DenoisingAutoencoderTriplet: rows stacked [org; pos; neg] */ };
 enum { DAE_CORR_NONE = 0, DAE_CORR_KEEPBITS = 1, DAE_CORR_PHILOX_MASK = 2 };
+/* `mode` bits of dae_triplet_batch_all */
+enum { DAE_MINER_POS_ONLY = 1, DAE_MINER_FAST = 2 };
 
 /* slots of the per-step statistics record (float[DAE_STATS_STRIDE]) -- the values the reference
  * fetches at autoencoder.py:233 and averages per epoch at :283-294 */
@@ -133,8 +135,8 @@ int dae_encode_finish(const float* slabs, int32_t splits, int64_t slab_stride, i
  * and d cost / d z2   (autoencoder.py:411; triplet_loss_utils.py:262-277 weighted_loss).
  *   y = act(h W^T + bv);  rowloss_i = sum_f loss(x_if, y_if);
  *   delta2_if = cw_i * dloss/dy * act'(z2)      with cw_i = w_i / (sum w + 1e-16)
- * outputs: rowloss_part [n_col_waves x Bp] partial row sums (n_col_waves = 2*Fp/128; may be NULL),
- *          tile_part [(Bp/128)*(Fp/128)] each tile's share of sum_i cw_i * rowloss_i (may be NULL),
+ * outputs: rowloss_part [n_col_waves x Bp] partial row sums (n_col_waves = 2*Fp/dae_decode_tile_n(dtype); may be NULL),
+ *          tile_part [(Bp/128)*(Fp/dae_decode_tile_n(dtype))] each tile's share of sum_i cw_i * rowloss_i (may be NULL),
  *          dbv_part [n_row_waves x Fp] partial column sums of delta2 (n_row_waves = 2*Bp/128),
  *          delta2 [Bp x ldd] and delta2^T [Fp x lddt] in `dtype` (any of these may be NULL).
  * cosine_proximity needs whole-row statistics and runs as two passes over the same GEMM:
@@ -148,6 +150,10 @@ int dae_decode_loss(int32_t dtype, int32_t B, int32_t F, int32_t H,
                     int32_t dec_act, int32_t loss_func, int32_t cos_pass, const float* cos_stats,
                     float* cos_part, float* rowloss_part, float* tile_part, float* dbv_part,
                     void* delta2, int64_t ldd, void* delta2_t, int64_t lddt, void* stream);
+/* columns of y per workgroup of dae_decode_loss for `dtype` (64 for DAE_BF16, 128 for DAE_F32): rowloss_part / cos_part hold
+ * 2 * Fp / width partial rows, tile_part (Bp/128) * (Fp/width) entries */
+int32_t dae_decode_tile_n(int32_t dtype);
+
 int dae_cos_reduce(const float* cos_part, int32_t n_col_waves, int32_t B, int32_t Bp,
                    float* cos_stats, float* rowloss, void* stream);
 
@@ -173,9 +179,12 @@ int dae_label_stats(const int32_t* labels, int32_t B, int32_t Bp, int32_t triple
  *   npos_part[a] = #{valid (p,n): D[a,n]-D[a,p] > 1e-16}
  *   G[a,:]       = d(sum softplus)/dD[a,:]   (un-normalised, [Bp x Bp], row stride Bp)
  *   role_cnt[a,:] (pos_only): per-column positive-triplet counts (NULL otherwise)
- * D is given as `d_splits` slabs (stride slab_stride) that are summed on load. */
+ * D is given as `d_splits` slabs (stride slab_stride) that are summed on load.
+ * mode: DAE_MINER_POS_ONLY (the reference's pos_triplets_only=True) | DAE_MINER_FAST (bf16 training mode: sigmoid as
+ *       1 - 1/(1+e) and log(fl(1+e)) without the log1p correction -- per-anchor error bound 2e-6 relative, enforced by an
+ *       in-kernel fallback to the exact form; counts stay bit-exact). */
 int dae_triplet_batch_all(const float* D_slabs, int32_t d_splits, int64_t slab_stride, int64_t ldd,
-                          const int32_t* labels, int32_t B, int32_t Bp, int32_t pos_only,
+                          const int32_t* labels, int32_t B, int32_t Bp, int32_t mode,
                           float* loss_part, uint32_t* npos_part, float* G, uint32_t* role_cnt,
                           void* stream);
 
