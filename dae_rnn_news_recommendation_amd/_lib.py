@@ -90,6 +90,7 @@ SIGNATURES = {
     "dae_plan_workspace_bytes": (u64, [vp]),
     "dae_plan_bind": (i32, [vp, C.POINTER(dae_buffers)]),
     "dae_plan_sync_shadows": (i32, [vp, vp]),
+    "dae_plan_set_option": (i32, [vp, C.c_char_p, i32]),
     "dae_train_step": (i32, [vp, C.POINTER(dae_step), vp]),
     "dae_plan_apply": (i32, [vp, i32, f32, vp]),
     "dae_encode_rows": (i32, [vp, vp, i32, f32, vp, vp, vp, vp, i64, vp, i64, vp]),

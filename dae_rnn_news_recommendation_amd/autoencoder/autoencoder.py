@@ -163,6 +163,7 @@ class DenoisingAutoencoder(object):
         self.sparse_input = not isinstance(train_set, np.ndarray)
         self.n_components = int(np.floor(n_features / self.compress_factor))
         batch = self._resolve_batch(train_set.shape[0])
+        self._val_engine = None            # a cached validation engine would keep the previous fit's data and configuration
 
         world, rank = self._dist()
         local_batch = -(-batch // world)
@@ -174,14 +175,32 @@ class DenoisingAutoencoder(object):
         W0, bh0, bv0 = self._initial_parameters(n_features)
         if world > 1:
             from .. import dp
+            # every rank must draw the SAME corruption masks and shuffles (each rank slices its shard out of one global
+            # permutation): with seed >= 0 the constructor seeded the legacy stream identically everywhere; with seed < 0
+            # rank 0's entropy is shared.  Parameters (W0 and any injected biases) are rank 0's.
+            if self.seed < 0:
+                shared = dp.broadcast_array(np.array([np.random.randint(0, 2 ** 31 - 1)], np.int64))
+                np.random.seed(int(shared[0]))
             W0 = dp.broadcast_array(np.asarray(W0, np.float32))
+            bh0 = dp.broadcast_array(np.zeros(self.n_components, np.float32) if bh0 is None else np.asarray(bh0, np.float32))
+            bv0 = dp.broadcast_array(np.zeros(n_features, np.float32) if bv0 is None else np.asarray(bv0, np.float32))
+            if self.triplet_strategy != 'none' and rank == 0:
+                import warnings
+                warnings.warn("data_parallel with triplet_strategy=%r mines WITHIN each rank's shard of the mini-batch "
+                              "(SURVEY 8e mode ii): this is the reference objective at batch size B/world on a different row "
+                              "order, not the reference at batch size B" % (self.triplet_strategy,))
         eng.set_params(W0, bh0, bv0)
         if restore_previous_model:
             self._restore(self.model_path)
-        self._write_parameter_to_file(restore_previous_model)
+        if rank == 0:
+            self._write_parameter_to_file(restore_previous_model)
 
         self._train_model(train_set, validation_set, train_set_label, validation_set_label)
-        self._save(self.model_path)
+        if rank == 0:                      # one writer: every rank holds identical parameters
+            self._save(self.model_path)
+        if world > 1:
+            from .. import dp
+            dp.barrier()                   # nobody reads the checkpoint / artefacts before rank 0 has written them
         return None
 
     def _dist(self):
@@ -265,6 +284,7 @@ class DenoisingAutoencoder(object):
         if label_ids is not None:
             labels_dev = torch.from_numpy(label_ids[order]).to(eng.device, non_blocking=True)
         stats = self._stats[epoch]
+        shard_w = []
         for b, start in enumerate(range(0, N, batch)):
             stop = min(N, start + batch)
             if world > 1:                                               # contiguous shard of every global batch
@@ -275,14 +295,25 @@ class DenoisingAutoencoder(object):
             rows = order_dev[lo:hi]
             labs = None if labels_dev is None else labels_dev[lo:hi]
             if world > 1:
+                # the global-batch mean is sum_r (rows_r / rows) * mean_r: every rank's gradient (and statistics) is weighted
+                # by its share of the rows, so ragged tails (37 rows on 4 ranks = 10/10/10/7) and empty shards stay exact
+                w = (hi - lo) / float(stop - start)
+                shard_w.append(w)
                 if hi > lo:
                     eng.train_step(rows, labs, stats[b], phase=1, **plan)
+                    if abs(w * world - 1.0) > 1e-12:
+                        eng.grad.mul_(w * world)
                 else:
-                    eng.grad.zero_()                                    # ragged tail: this rank has no rows
+                    eng.grad.zero_()
+                    stats[b].zero_()
                 dp.allreduce_sum_(eng.grad)
                 eng.apply(grad_scale=1.0 / world)
             else:
                 eng.train_step(rows, labs, stats[b], phase=3, **plan)
+        if world > 1:                                                   # statistics of the GLOBAL batches, on every rank
+            wt = torch.tensor(shard_w, dtype=torch.float32, device=eng.device)[:, None]
+            stats.mul_(wt)
+            dp.allreduce_sum_(stats)
 
     # ------------------------------------------------------------------ reporting (reference :272-320)
     def epoch_stats(self, epoch):
@@ -295,7 +326,8 @@ class DenoisingAutoencoder(object):
     def _run_validation_error_and_summaries(self, epoch, validation_set, validation_set_label):
         st = self.epoch_stats(epoch)
         rec = dict(epoch=epoch, seconds=self.train_time, **{k: st[k] for k in ('cost', 'ae', 'triplet', 'fraction', 'num')})
-        if self.verbose == 1:
+        main = self._dist()[1] == 0                                     # data parallel: rank 0 reports (statistics are global)
+        if self.verbose == 1 and main:
             print('At step %d (%.2f seconds): ' % (epoch, self.train_time), end='')
             print('[Train Stat (average over past steps)] - ', end='')
             if self.triplet_strategy != 'none':
@@ -308,13 +340,13 @@ class DenoisingAutoencoder(object):
                 print('Autoencoder=%.4f\t' % st['ae'], end='')
                 print('Triplet=%.4f\t' % st['triplet'], end='')
         if validation_set is None:
-            if self.verbose == 1:
+            if self.verbose == 1 and main:
                 print()
             self.history.append(rec)
             return
         v = self._validation_forward(validation_set, validation_set_label)
         rec.update(val_cost=v[L.STAT_COST], val_ae=v[L.STAT_AE], val_triplet=v[L.STAT_TRIPLET])
-        if self.verbose:
+        if self.verbose and main:
             print("[Validation Stat (at this step)] - Cost: ")
             print('Overall=%.4f' % v[L.STAT_COST], end='')
             if self.triplet_strategy != 'none':
@@ -367,7 +399,7 @@ class DenoisingAutoencoder(object):
             idx = torch.arange(i0, min(n, i0 + step), dtype=torch.int32, device=dev)
             eng.encode_rows(idx, out[i0:i0 + idx.numel()], **src)
         encoded = out.cpu().numpy()
-        if save:
+        if save and self._dist()[1] == 0:
             np.save(self.data_dir + name, encoded)
             np.save(self.data_dir + 'weights', eng.get_params()[0])
         return encoded

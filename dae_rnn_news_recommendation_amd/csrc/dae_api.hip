@@ -2,8 +2,6 @@
 // driver that enqueues one DAE training step (DenoisingAutoencoder._run_train_step's per-batch body,
 // autoencoder.py:223-245) as a fixed sequence of HIP kernels on one stream, with no host sync.
 #include <stdarg.h>
-#include <stdlib.h>
-
 #include <new>
 
 #include "dae_kernels.h"
@@ -108,11 +106,13 @@ struct dae_plan {
     float *slabs, *h_f32, *D_slabs, *G, *rowloss_part, *dbv_part, *colsum_part, *cos_part, *cos_stats, *cw, *loss_part,
         *dw_f32, *tri_scalars, *dh_extra, *rowsq_scratch, *tile_part;
     uint32_t *cnt_part, *role_cnt, *xc_bits, *x_bits;
-    bool xbits_ok;                   // binary CSR + bf16: the decode epilogue reads x as a bit image (DAE_NO_XBITS=1 disables)
+    bool xbits_ok;                   // binary CSR + bf16: the decode epilogue reads x as a bit image (option "x_bits" = 0 disables)
     bool xct_clean;                  // x~^T holds only zeros (every step un-scatters what it wrote; see step_tail_kernel)
-    bool tail_ok;                    // DAE_NO_TAIL=1: separate bias_grads / step_stats launches and a full memset per step (A/B)
-    bool fuse_opt_ok;                // DAE_NO_FUSED_OPT=1 keeps the separate optimizer kernel (A/B)
-    bool bits_ok;                    // binary CSR + bf16: x~ handed to the encode GEMM as a bit image (opt-in: DAE_BITS=1)
+    bool tail_ok;                    // option "tail" = 0: separate bias_grads / step_stats launches and a full memset per step (A/B)
+    bool fuse_opt_ok;                // option "fused_opt" = 0 keeps the separate optimizer kernel (A/B, equivalence tests)
+    bool label_enc_ok;               // option "label_with_encode" = 0: label statistics ride on the gather launch / their own
+    bool ce_literal;                 // option "ce_literal" = 1: cross_entropy always by the reference-literal formula
+    bool bits_ok;                    // binary CSR + bf16: x~ handed to the encode GEMM as a bit image (dae_plan_set_option("encode_bits", 0) disables)
     int32_t *dw_i32, *n_same;
     int64_t *nvalid, *dw_i64;
     uint64_t* acc;
@@ -201,15 +201,18 @@ extern "C" int dae_plan_create(const dae_config* cfg, dae_plan** out) {
     if (p->s_enc > kt_f) p->s_enc = kt_f;
     if (p->s_dh > kt_f) p->s_dh = kt_f;
     if (p->s_gram > p->Hp * 4 / 128) p->s_gram = p->Hp * 4 / 128;
-    p->gram_split = (cfg->dtype == DAE_BF16) && (cfg->triplet == DAE_TRIPLET_BATCH_ALL || cfg->triplet == DAE_TRIPLET_BATCH_HARD) &&
-                    getenv("DAE_GRAM_FP32") == nullptr;
+    p->gram_split = (cfg->dtype == DAE_BF16) && (cfg->triplet == DAE_TRIPLET_BATCH_ALL || cfg->triplet == DAE_TRIPLET_BATCH_HARD);
     p->ws_bytes = carve(p, nullptr);
-    p->fuse_opt_ok = getenv("DAE_NO_FUSED_OPT") == nullptr;
-    p->tail_ok = getenv("DAE_NO_TAIL") == nullptr;
-    p->xbits_ok = cfg->dtype == DAE_BF16 && getenv("DAE_NO_XBITS") == nullptr;
+    // code-path choices below are plan state (dae_plan_set_option), never read from the environment
+    p->fuse_opt_ok = true;
+    p->tail_ok = true;
+    p->label_enc_ok = true;
+    p->ce_literal = false;
+    p->xbits_ok = cfg->dtype == DAE_BF16;
     p->xct_clean = false;
-    p->bits_ok = cfg->dtype == DAE_BF16 && getenv("DAE_BITS") != nullptr;
-    p->overlap_ok = getenv("DAE_OVERLAP") != nullptr;   // measured: running the miner chain beside decode is SLOWER (0.410 vs 0.351 ms/step)
+    // binary CSR + bf16: x~ goes to the encode GEMM as a bit image whenever the 8-wave bit kernel can run the shape
+    p->bits_ok = cfg->dtype == DAE_BF16 && encode_bits_fits(p->Bpm, p->Hp, p->Fp, p->s_enc);
+    p->overlap_ok = false;                              // measured: running the miner chain beside decode is SLOWER (0.410 vs 0.351 ms/step)
     *out = p;
     return 0;
 }
@@ -222,6 +225,29 @@ extern "C" void dae_plan_destroy(dae_plan* p) {
     if (p->ev_join) (void)hipEventDestroy(p->ev_join);
     if (p->side) (void)hipStreamDestroy(p->side);
     delete p;
+}
+
+// Code-path choices of a plan (A/B measurements and equivalence tests).  Every option selects between implementations of
+// the SAME arithmetic; nothing here is read from the environment, so a stray variable can never change a training run.
+extern "C" int dae_plan_set_option(dae_plan* p, const char* name, int32_t value) {
+    DAE_CHECK_ARG(p && name, "plan_set_option: null argument");
+    const bool on = value != 0;
+    if (!strcmp(name, "encode_bits")) p->bits_ok = on && p->cfg.dtype == DAE_BF16 && encode_bits_fits(p->Bpm, p->Hp, p->Fp, p->s_enc);
+    else if (!strcmp(name, "x_bits")) p->xbits_ok = on && p->cfg.dtype == DAE_BF16;
+    else if (!strcmp(name, "fused_opt")) p->fuse_opt_ok = on;
+    else if (!strcmp(name, "tail")) p->tail_ok = on;
+    else if (!strcmp(name, "label_with_encode")) p->label_enc_ok = on;
+    else if (!strcmp(name, "ce_literal")) p->ce_literal = on;
+    else if (!strcmp(name, "overlap")) p->overlap_ok = on;
+    else if (!strcmp(name, "gram_fp32")) {
+        DAE_CHECK_ARG(!p->bound, "plan_set_option: gram_fp32 changes the workspace layout, set it before dae_plan_bind");
+        p->gram_split = !on && p->cfg.dtype == DAE_BF16 && (p->cfg.triplet == DAE_TRIPLET_BATCH_ALL || p->cfg.triplet == DAE_TRIPLET_BATCH_HARD);
+        p->ws_bytes = carve(p, nullptr);
+    } else {
+        set_error("plan_set_option: unknown option '%s'", name);
+        return 1;
+    }
+    return 0;
 }
 
 extern "C" int dae_plan_profile(dae_plan* p, int32_t enable) {
@@ -358,8 +384,7 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     // label statistics (cw, N_valid, data weights) depend on the labels alone: they ride on the CSR gather launch
     LabelJob lj{s->labels, B, Bp, c.triplet, p->nvalid, p->dw_i64, p->cw, c.alpha, p->tri_scalars};
     // ... on the encode GEMM's launch when that grid leaves a CU free (else on the CSR gather's, else their own)
-    static const bool label_enc_ok = getenv("DAE_LABEL_IN_GATHER") == nullptr;                   // A/B switch
-    const bool label_with_encode = p->tail_ok && !explicit3 && Bp <= 1024 && label_enc_ok;
+    const bool label_with_encode = p->tail_ok && !explicit3 && Bp <= 1024 && p->label_enc_ok;
     const bool label_in_gather = p->tail_ok && !label_with_encode && !explicit3 && !s->c_indptr && p->b.indptr && Bp <= 1024;
     const bool tail = p->tail_ok;
     if (backward && csr_in && !(tail && p->xct_clean)) PROF(PS_MEMSET, memset_async(p->xct, (size_t)Fp * ldB * p->es, st));
@@ -385,7 +410,8 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     const int64_t slab = (int64_t)Bp * Hp;
     int enc_label_done = 0;
     if (use_bits)
-        PROF(PS_ENC_GEMM, launch_encode_bits(Bp, Hp, Fp, p->xc_bits, Fp / 32, p->b.Wt_lo, Fp, p->slabs, Hp, p->s_enc, slab, st));
+        PROF(PS_ENC_GEMM, launch_encode_bits(Bp, Hp, Fp, p->xc_bits, Fp / 32, p->b.Wt_lo, Fp, p->slabs, Hp, p->s_enc, slab, st,
+                                             label_with_encode ? &lj : nullptr, label_with_encode ? &enc_label_done : nullptr));
     else
         PROF(PS_ENC_GEMM, launch_gemm_f32out(dt, Bp, Hp, p->xc, Fp, p->b.Wt_lo, Fp, Fp, nullptr, 0, nullptr, 0, 0, p->slabs, Hp, p->s_enc, slab, st,
                                              GEMM_ROLE_ENCODE, label_with_encode ? &lj : nullptr, label_with_encode ? &enc_label_done : nullptr));
@@ -452,7 +478,7 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     e.rowloss_part = is_cos ? p->rowloss_part : nullptr; e.tile_part = is_cos ? nullptr : p->tile_part;
     e.dbv_part = backward ? p->dbv_part : nullptr; e.cos_part = p->cos_part;
     e.delta2 = backward ? p->delta2 : nullptr; e.ldd = Fp; e.delta2_t = backward ? p->delta2_t : nullptr; e.lddt = ldB;
-    e.B = B; e.F = F; e.Bp = Bp; e.Fp = Fp; e.dec_act = c.dec_act; e.loss_func = c.loss_func;
+    e.B = B; e.F = F; e.Bp = Bp; e.Fp = Fp; e.dec_act = c.dec_act; e.loss_func = c.loss_func; e.ce_literal = p->ce_literal ? 1 : 0;
     if (is_cos) {
         e.cos_pass = 1;
         PROF(PS_DECODE, launch_decode_loss(dt, Bp, Fp, Hp, p->h_lo, Hp, p->b.W_lo, Hp, e, st));

@@ -26,8 +26,6 @@
 #include "dae_kernels.h"
 #include "dae_label.h"
 
-#include <stdlib.h>
-
 #include <type_traits>
 
 namespace dae {
@@ -1239,7 +1237,7 @@ template <typename T> static pc_fn pc_kernel(int role) {
     }
 }
 static int g_cus = 0;        // compute units of the current device (set by gemm_init)
-static int g_use_pc = 1;     // DAE_NO_PC=1 keeps the 4-wave kernel for every grid (A/B)
+static int g_use_pc = 1;     // dae_set_glds(-1) keeps the 4-wave kernel for every grid (A/B)
 typedef void (*decode_fn)(GemmParams, DecodeEpi);
 static decode_fn decode_kernel_xbits(int loss, int act) {
 #define DAE_DKX(LV, AV) if (loss == LV && act == AV) return gemm_decode_loss<bf16_t, LV, AV, true, DECODE_BN_BF16>;
@@ -1273,7 +1271,6 @@ static int gemm_init() {
             int dev = 0;
             DAE_CHECK_HIP(hipGetDevice(&dev));
             DAE_CHECK_HIP(hipDeviceGetAttribute(&g_cus, hipDeviceAttributeMultiprocessorCount, dev));
-            g_use_pc = getenv("DAE_NO_PC") == nullptr;
         }
         for (int l = 0; l < 3; ++l)
             for (int a = 0; a < 3; ++a) {
@@ -1354,181 +1351,238 @@ int launch_decode_loss(int dtype, int Bp, int Fp, int Hp, const void* h_lo, int6
         k = decode_kernel_xbits(e.loss_func, e.dec_act);
     }
     dim3 grid(grid_blocks(p)), block(GEMM_THREADS);
-    static const int ce_literal = getenv("DAE_CE_LITERAL") != nullptr;
-    DecodeEpi ee = e;
-    ee.ce_literal = ce_literal || e.ce_literal;
-    hipLaunchKernelGGL(k, grid, block, dtype == DAE_BF16 ? DecGeo<DECODE_BN_BF16>::LDS_BYTES : DecGeo<BN>::LDS_BYTES, st, p, ee);
+    hipLaunchKernelGGL(k, grid, block, dtype == DAE_BF16 ? DecGeo<DECODE_BN_BF16>::LDS_BYTES : DecGeo<BN>::LDS_BYTES, st, p, e);
     DAE_CHECK_LAUNCH();
     return 0;
 }
 
 
 // ------------------------------------------------------------------------------------------------
-// Fused corrupt+encode GEMM for BINARY inputs: the A operand is the bit-packed corrupted batch
-// (1 bit per feature, written by the gather kernel: 1.1 MB instead of 18 MB of bf16) and is expanded to the
-// bf16 MFMA tile INSIDE LDS; only the W^T tile is streamed (global_load_lds), i.e. half the staged bytes per
-// K tile of the generic kernel -- the generic GEMMs are bound by operand staging, not by MFMA.
-//   z1 slab[split] = bits(x~)[Bp x Fp] . Wt_lo[Hp x Fp]^T          (autoencoder.py:389, tf.sparse.matmul)
-// Wave layout 4x1: wave w owns output rows [32w, 32w+32) of the 128x128 tile, so the A rows it expands are the
-// rows it consumes -- no barrier between expansion and fragment reads.  Raw bits arrive through the same LDS-DMA
-// queue as W^T (one 4-byte global_load_lds per lane: 32 rows x 2 words per wave).
+// Fused corrupt+encode GEMM for BINARY inputs (autoencoder.py:389: tf.sparse.matmul(x~, W) on a 0/1 CSR):
+//   z1 slab[split] = bits(x~)[Bp x Fp] . Wt_lo[Hp x Fp]^T
+// The corrupted batch reaches the kernel as the gather's BIT image (1 bit per feature: 1.1 MB instead of 18 MB of bf16);
+// the dense x~ operand is never written to or read from HBM.  Producer/consumer structure of gemm_nt_pc:
+//   consumer waves 0-3: fragment reads + MFMAs, byte-for-byte the loop of gemm_nt_pc (the LDS image is identical);
+//   producer waves 4-7: W^T tile by LDS-DMA (4 x 1 KiB pieces per wave per K tile -- HALF the DMA instructions of the dense
+//     kernel, whose ~70-cycle issue cost per piece is what paces its K loop), and the x~ tile BUILT in LDS from the bits:
+//     zero-fill of the wave's 32 rows (4 ds_write_b128) + one ds_write_b16 of bf16 1.0 per set bit (x~ is ~1.4 % dense:
+//     ~0.5 set bits per lane and K tile); words with many bits (dense rows, salt-and-pepper) are expanded arithmetically.
+// The workgroup's slice of the bit image (128 rows x 2 words per K tile) is copied into LDS once, before the K loop, so the
+// loop itself issues no ordinary global load (hipcc drains the LDS-DMA queue at every use of one).
 // ------------------------------------------------------------------------------------------------
-constexpr int EB_STAGE_BYTES = TILE_BYTES + 1024;      // ring stage = [W^T tile 16K | raw bits 1K]; the expanded A tile (16K) is single
-constexpr int eb_lds_bytes(int nst) { return TILE_BYTES + nst * EB_STAGE_BYTES; }
+constexpr int EB_NST = 4;
+constexpr int eb_slice_stride(int nk) { return 2 * ((nk | 1)); }            // words per row: 2 * odd >= 2 nk -> conflict-free ds_read_b32
+constexpr int eb_lds_bytes(int nk) { return EB_NST * STAGE_BYTES + 128 * eb_slice_stride(nk) * 4; }
 
 struct EncBitsParams {
     const char* Bt; int64_t ldb_b;                    // W^T_lo [Hp x Fp] bf16, leading dimension in bytes
     const uint32_t* bits; int64_t ldw;                // x~ bits [Bp x ldw words], bit b of word w = feature 32*w + b
-    int ktiles_total, tiles_m, tiles_n, splits;
+    int ktiles_total, tiles_m, tiles_n, splits, nk_max;
 };
 
-
-// NST-deep LDS-DMA ring: the encode grid is <= 1 workgroup per CU (28 tiles x 8 K slices), so the only way to hide the
-// ~1 us global->LDS latency is depth, not occupancy; LDS is otherwise idle (160 KB per CU).
-template <int NST>
-__global__ __launch_bounds__(GEMM_THREADS, 1) void gemm_encode_bits(EncBitsParams p, float* __restrict__ C, int64_t ldc,
-                                                                    int64_t slab_stride) {
+__global__ __launch_bounds__(PC_THREADS, 1) void gemm_encode_bits_pc(EncBitsParams p, float* __restrict__ C, int64_t ldc, int64_t slab_stride,
+                                                                     LabelJob job, int label_block) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    char* const abuf = lds;
-    char* const ring = lds + TILE_BYTES;
+    constexpr int NST = EB_NST;
+    if ((int)blockIdx.x == label_block) { label_stats_block<PC_THREADS>(job, lds); return; }
     const int id = blockIdx.x;
-    const int split = id % p.splits, tile = id / p.splits;
+    const int split = id % p.splits, tile = id / p.splits;          // a K slice stays on one XCD (block b runs on XCD b % 8)
     const int tn = tile % p.tiles_n, tm = tile / p.tiles_n;
     const int kt0 = (int)(((int64_t)p.ktiles_total * split) / p.splits);
     const int kt1 = (int)(((int64_t)p.ktiles_total * (split + 1)) / p.splits);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int rr = lane & 31, g = lane >> 5;
-    f32x16 acc[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     const int nk = kt1 - kt0;
-    constexpr int LOADS = 5;                                           // global_load_lds per wave per stage
-
-    auto stage = [&](int kt, char* st) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {                                  // W^T tile: 16 pieces of 1 KiB, 4 per wave
-            const int piece = i * 4 + wave;
-            const int row = piece * 8 + (lane >> 3);
-            const int sslot = (lane & 7) ^ ((row >> 1) & 7);
-            const char* gb = p.Bt + (int64_t)(tn * BN + row) * p.ldb_b + (int64_t)kt * BKB + sslot * 16;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gb,
-                                             (__attribute__((address_space(3))) void*)(st + piece * 1024), 16, 0, 0);
-        }
-        {                                                              // raw bits of this wave's 32 rows: 2 words per row
-            const uint32_t* gw = p.bits + (int64_t)(tm * BM + wave * 32 + (lane >> 1)) * p.ldw + kt * 2 + (lane & 1);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gw,
-                                             (__attribute__((address_space(3))) void*)(st + TILE_BYTES + wave * 256), 4, 0, 0);
-        }
-    };
-
-    for (int j = 0; j < NST - 1; ++j)
-        if (j < nk) stage(kt0 + j, ring + j * EB_STAGE_BYTES);
-    int slot = 0;
-    for (int i = 0; i < nk; ++i) {
-        // stage i landed when at most `ahead` younger stage groups are still in flight
-        const int ahead = min(NST - 2, nk - 1 - i);
-        if constexpr (NST >= 8) { if (ahead == 6) wait_vm<6 * LOADS>(); if (ahead == 5) wait_vm<5 * LOADS>(); if (ahead == 4) wait_vm<4 * LOADS>(); if (ahead == 3) wait_vm<3 * LOADS>(); }
-        else if constexpr (NST >= 4) { if (ahead > 2) wait_vm<2 * LOADS>(); }
-        if (ahead == 2) wait_vm<2 * LOADS>();
-        if (ahead == 1) wait_vm<1 * LOADS>();
-        if (ahead <= 0) wait_vm<0>();
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        char* cur = ring + slot * EB_STAGE_BYTES;
-        if (i + NST - 1 < nk) {                                        // refill the slot consumed in iteration i-1
-            const int ns = slot == 0 ? NST - 1 : slot - 1;
-            stage(kt0 + i + NST - 1, ring + ns * EB_STAGE_BYTES);
-        }
-        // ---- expand this wave's bits into its 32 private A rows (bf16 1.0 = 0x3F80) ----
-        {
-            const uint32_t word = *reinterpret_cast<const uint32_t*>(cur + TILE_BYTES + wave * 256 + lane * 4);
-            const int r = wave * 32 + (lane >> 1), half = lane & 1;
-            const int swz = (r >> 1) & 7;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                i32x4 v;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const uint32_t b2 = (word >> (8 * j + 2 * q)) & 3u;
-                    v[q] = (int)(((b2 & 1u) * 0x3F80u) | ((b2 >> 1) * 0x3F800000u));
-                }
-                *reinterpret_cast<i32x4*>(abuf + r * BKB + (((half * 4 + j) ^ swz) << 4)) = v;
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // own ds_writes landed; rows are private to this wave
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- fragments + MFMAs: A rows [32*wave, +32), all 128 B rows ----
-        {
-            const int swz2 = (rr >> 1) & 7;
-            const uint32_t pa = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)abuf + (wave * 32 + rr) * BKB;
-            const uint32_t pb = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)cur + rr * BKB;
-            i32x4 a[4], b[4][4];
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const uint32_t so = ((kk * 2 + g) ^ swz2) << 4;
-                a[kk] = lds_read_b128(pa + so);
-                b[kk][0] = lds_read_b128(pb + so);
-                b[kk][1] = lds_read_b128_off4096(pb + so);
-                b[kk][2] = lds_read_b128(pb + 8192 + so);
-                b[kk][3] = lds_read_b128_off4096(pb + 8192 + so);
-            }
-#define DAE_EB_GROUP(KK, CNT)                                      \
-    asm volatile("s_waitcnt lgkmcnt(" #CNT ")" ::: "memory");     \
-    __builtin_amdgcn_sched_barrier(0);                            \
-    Mma<bf16_t>::run(a[KK], b[KK][0], acc[0]);                    \
-    Mma<bf16_t>::run(a[KK], b[KK][1], acc[1]);                    \
-    Mma<bf16_t>::run(a[KK], b[KK][2], acc[2]);                    \
-    Mma<bf16_t>::run(a[KK], b[KK][3], acc[3]);
-            DAE_EB_GROUP(0, 15)
-            DAE_EB_GROUP(1, 10)
-            DAE_EB_GROUP(2, 5)
-            DAE_EB_GROUP(3, 0)
-#undef DAE_EB_GROUP
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        slot = slot + 1 == NST ? 0 : slot + 1;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int row0_m = tm * BM, row0_n = tn * BN;
+    uint32_t* const slice = reinterpret_cast<uint32_t*>(lds + NST * STAGE_BYTES);
+    const int sstride = eb_slice_stride(p.nk_max);
+    // ---- the workgroup's slice of the bit image -> LDS (all 8 waves; 4 threads per row) ----
+    {
+        const int row = tid >> 2, part = tid & 3;
+        const uint32_t* src = p.bits + (int64_t)(row0_m + row) * p.ldw + 2 * kt0;
+        for (int w = part; w < 2 * nk; w += 4) slice[row * sstride + w] = src[w];
     }
-    float* Cs = C + (int64_t)split * slab_stride;
-    const int c = lane & 31;
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = tm * BM + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-            const int col = tn * BN + nt * 32 + c;
-            Cs[(int64_t)row * ldc + col] = acc[nt][r];
-        }
-}
 
-template <int NST>
-static int launch_eb(const EncBitsParams& p, float* C, int64_t ldc, int64_t slab_stride, hipStream_t st) {
-    static int attr_rc = [] {
-        return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_encode_bits<NST>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        eb_lds_bytes(NST));
-    }();
-    DAE_CHECK_ARG(attr_rc == 0, "encode_bits: hipFuncSetAttribute failed (%d)", attr_rc);
-    hipLaunchKernelGGL(gemm_encode_bits<NST>, dim3(p.tiles_m * p.tiles_n * p.splits), dim3(GEMM_THREADS), eb_lds_bytes(NST), st, p, C, ldc,
-                       slab_stride);
-    DAE_CHECK_LAUNCH();
-    return 0;
+    if (wave8 >= 4) {
+        // ================= producer =================
+        if (nk <= 0) { __builtin_amdgcn_s_barrier(); return; }
+        const int wave = wave8 - 4;
+        uint32_t voB[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (i * 4 + wave) * 8 + (lane >> 3);
+            voB[i] = (uint32_t)(row0_n + row) * (uint32_t)p.ldb_b + (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) << 4);
+        }
+        const char* gB = p.Bt + (int64_t)kt0 * BKB;
+        auto dma_stage = [&](char* slot) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gB + voB[i]),
+                                                 (__attribute__((address_space(3))) void*)(slot + TILE_BYTES + (i * 4 + wave) * 1024), 16, 0, 0);
+            gB += BKB;
+        };
+        // A tile of K tile t (relative to kt0) into `slot`: this wave's rows [32 wave, +32); lane = (row, 32-feature half)
+        const int arow = wave * 32 + (lane >> 1), half = lane & 1;
+        const uint32_t aswz = (uint32_t)((arow >> 1) & 7);
+        const uint32_t* const myword = slice + arow * sstride + half;
+        auto build_a = [&](int t, char* slot) {
+            uint32_t word = myword[2 * t];
+            const bool dense = __builtin_amdgcn_ballot_w64(__builtin_popcount(word) > 6) != 0ull;
+            if (dense) {                                   // arithmetic expansion: 8 bits -> 8 bf16 (0 / 1.0) per 16-byte slot
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    i32x4 v;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const uint32_t b2 = (word >> (8 * j + 2 * q)) & 3u;
+                        v[q] = (int)(((b2 & 1u) * 0x3F80u) | ((b2 >> 1) * 0x3F800000u));
+                    }
+                    *reinterpret_cast<i32x4*>(slot + arow * BKB + (((uint32_t)(half * 4 + j) ^ aswz) << 4)) = v;
+                }
+            } else {
+                const i32x4 z = {0, 0, 0, 0};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) *reinterpret_cast<i32x4*>(slot + (wave * 4 + i) * 1024 + lane * 16) = z;
+                while (word) {                             // one 2-byte store per set bit (in-order LDS: lands after the zero fill)
+                    const int b = __builtin_ctz(word);
+                    word &= word - 1;
+                    const uint32_t k = (uint32_t)(half * 32 + b);
+                    *reinterpret_cast<bf16_t*>(slot + arow * BKB + (((k >> 3) ^ aswz) << 4) + (k & 7) * 2) = (bf16_t)0x3F80;
+                }
+            }
+        };
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // my part of the bit slice is in LDS
+        __builtin_amdgcn_s_barrier();                                     // ... and everybody else's
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int st = 0; st < NST; ++st)
+            if (st < nk) { dma_stage(lds + st * STAGE_BYTES); build_a(st, lds + st * STAGE_BYTES); }
+        if (nk >= NST) wait_vm<(NST - 1) * 4>(); else wait_vm<0>();      // stage 0's W^T tile landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // ... and every A tile written so far
+        __builtin_amdgcn_s_barrier();
+        int cur = 0;
+        for (int i = 0; i < nk; ++i) {
+            const int ahead = min(NST - 2, nk - 2 - i);                   // stages younger than i+1 already requested
+            if (ahead >= 2) wait_vm<8>();
+            else if (ahead == 1) wait_vm<4>();
+            else wait_vm<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (i + NST < nk) { dma_stage(lds + cur * STAGE_BYTES); build_a(i + NST, lds + cur * STAGE_BYTES); }
+            cur = cur + 1 == NST ? 0 : cur + 1;
+        }
+        return;
+    }
+
+    // ================= consumer (same loop as gemm_nt_pc) =================
+    const int wave = wave8;
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");          // my part of the bit slice is in LDS
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (nk > 0) {
+        const int r = lane & 31, g = lane >> 5;
+        const int swz = (r >> 1) & 7;
+        const uint32_t lbase = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)lds;
+        const uint32_t offa = (wm * 64 + r) * BKB, offb = TILE_BYTES + (wn * 64 + r) * BKB;
+        uint32_t so[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) so[kk] = (uint32_t)(((kk * 2 + g) ^ swz) << 4);
+        i32x4 fa[4][2], fb[4][2];
+#define DAE_READ_KK(KK, SLOTBASE)                                          \
+    fa[KK][0] = lds_read_b128((SLOTBASE) + offa + so[KK]);                 \
+    fa[KK][1] = lds_read_b128_off4096((SLOTBASE) + offa + so[KK]);         \
+    fb[KK][0] = lds_read_b128((SLOTBASE) + offb + so[KK]);                 \
+    fb[KK][1] = lds_read_b128_off4096((SLOTBASE) + offb + so[KK]);
+#define DAE_MMA4(KK)                                                       \
+    Mma<bf16_t>::run(fa[KK][0], fb[KK][0], acc[0][0]);                     \
+    Mma<bf16_t>::run(fa[KK][0], fb[KK][1], acc[0][1]);                     \
+    Mma<bf16_t>::run(fa[KK][1], fb[KK][0], acc[1][0]);                     \
+    Mma<bf16_t>::run(fa[KK][1], fb[KK][1], acc[1][1]);
+        __builtin_amdgcn_s_barrier();                                     // stage 0 complete (producers waited for it)
+        asm volatile("" ::: "memory");
+        DAE_READ_KK(0, lbase) DAE_READ_KK(1, lbase) DAE_READ_KK(2, lbase) DAE_READ_KK(3, lbase)
+        __builtin_amdgcn_sched_barrier(0);
+        int cur = 0;
+        for (int i = 0; i < nk; ++i) {
+            const int nxt = cur + 1 == NST ? 0 : cur + 1;
+            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");            // R0 (kk 0,1) of tile i
+            __builtin_amdgcn_sched_barrier(0);
+            DAE_MMA4(0) DAE_MMA4(1)
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // R1 landed; every LDS read of tile i is done
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const uint32_t nb = lbase + nxt * STAGE_BYTES;
+            DAE_READ_KK(0, nb) DAE_READ_KK(1, nb)                         // stale (never consumed) after the last tile
+            __builtin_amdgcn_sched_barrier(0);
+            DAE_MMA4(2) DAE_MMA4(3)
+            __builtin_amdgcn_sched_barrier(0);
+            DAE_READ_KK(2, nb) DAE_READ_KK(3, nb)
+            __builtin_amdgcn_sched_barrier(0);
+            cur = nxt;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#undef DAE_READ_KK
+#undef DAE_MMA4
+    }
+    const int g = lane >> 5, c = lane & 31;
+    float* Cs = C + (int64_t)split * slab_stride;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int row = tm * BM + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                int col = tn * BN + wn * 64 + nt * 32 + c;
+                Cs[(int64_t)row * ldc + col] = acc[mt][nt][r];
+            }
 }
 
 int launch_encode_bits(int Bp, int Hp, int Fp, const uint32_t* bits, int64_t ldw, const void* Wt_lo, int64_t ldb, float* C,
-                       int64_t ldc, int splits, int64_t slab_stride, hipStream_t st) {
+                       int64_t ldc, int splits, int64_t slab_stride, hipStream_t st, const LabelJob* label_job, int* label_done) {
+    if (label_done) *label_done = 0;
     DAE_CHECK_ARG(bits && Wt_lo && C, "encode_bits: null operand");
     DAE_CHECK_ARG(Bp % BM == 0 && Hp % BN == 0 && Fp % 64 == 0 && ldw >= Fp / 32, "encode_bits: bad shape");
     DAE_CHECK_ARG(((uintptr_t)Wt_lo % 16) == 0 && (ldb * 2) % 16 == 0 && ((uintptr_t)bits % 4) == 0, "encode_bits: alignment");
+    DAE_CHECK_ARG((uint64_t)Hp * (uint64_t)ldb * 2 < (1ull << 32), "encode_bits: W^T panel must stay below 4 GiB (32-bit DMA offsets)");
+    if (int rc = gemm_init()) return rc;
     EncBitsParams p;
     p.Bt = (const char*)Wt_lo; p.ldb_b = ldb * 2; p.bits = bits; p.ldw = ldw;
     p.ktiles_total = Fp / 64; p.tiles_m = Bp / BM; p.tiles_n = Hp / BN; p.splits = splits < 1 ? 1 : splits;
     DAE_CHECK_ARG(p.splits <= p.ktiles_total, "encode_bits: too many splits");
-    static const int nst = [] { const char* v = getenv("DAE_EB_NST"); return v ? atoi(v) : 4; }();
-    if (nst >= 8) return launch_eb<8>(p, C, ldc, slab_stride, st);
-    if (nst >= 4) return launch_eb<4>(p, C, ldc, slab_stride, st);
-    return launch_eb<2>(p, C, ldc, slab_stride, st);
+    p.nk_max = (p.ktiles_total + p.splits - 1) / p.splits;
+    const int ldsb = eb_lds_bytes(p.nk_max);
+    const int grid = p.tiles_m * p.tiles_n * p.splits;
+    DAE_CHECK_ARG(ldsb <= 160 * 1024, "encode_bits: %d K tiles per slice need %d B of LDS (> 160 KiB): raise encode_splits", p.nk_max, ldsb);
+    DAE_CHECK_ARG(grid <= g_cus, "encode_bits: %d workgroups exceed the %d CUs (the 8-wave kernel runs one per CU)", grid, g_cus);
+    static int attr_rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_encode_bits_pc), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    DAE_CHECK_ARG(attr_rc == 0, "encode_bits: hipFuncSetAttribute failed (%d)", attr_rc);
+    LabelJob job; memset(&job, 0, sizeof(job));
+    const bool with_labels = label_job && label_job->Bp <= 1024 && grid < g_cus;
+    if (with_labels) job = *label_job;
+    hipLaunchKernelGGL(gemm_encode_bits_pc, dim3(grid + (with_labels ? 1 : 0)), dim3(PC_THREADS), ldsb, st, p, C, ldc, slab_stride, job,
+                       with_labels ? grid : -1);
+    DAE_CHECK_LAUNCH();
+    if (with_labels && label_done) *label_done = 1;
+    return 0;
+}
+
+// can the 8-wave bit-image encode kernel run this shape?  (one workgroup per CU; the K slice's bits + the ring fit the LDS)
+bool encode_bits_fits(int Bp, int Hp, int Fp, int splits) {
+    if (gemm_init()) return false;
+    const int kt = Fp / 64;
+    if (splits < 1 || splits > kt || Fp % 64 || Bp % BM || Hp % BN) return false;
+    return (Bp / BM) * (Hp / BN) * splits <= g_cus && eb_lds_bytes((kt + splits - 1) / splits) <= 160 * 1024;
 }
 
 int launch_gemm_trace(int dtype, int M, int N, const void* A0, int64_t lda0, const void* Bt0, int64_t ldb0, int K0, const void* A1,
@@ -1545,6 +1599,10 @@ int launch_gemm_trace(int dtype, int M, int N, const void* A0, int64_t lda0, con
     return 0;
 }
 
-void set_use_glds(int nst) { g_nst = nst; }
+void set_use_glds(int nst) {
+    if (nst == -1) { g_use_pc = 0; return; }          // A/B: 4-wave kernel for every grid
+    if (nst == -2) { g_use_pc = 1; return; }
+    g_nst = nst;
+}
 
 }  // namespace dae

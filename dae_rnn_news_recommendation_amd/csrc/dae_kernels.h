@@ -79,6 +79,8 @@ int launch_gemm_trace(int dtype, int M, int N, const void* A0, int64_t lda0, con
                       int64_t lda1, const void* Bt1, int64_t ldb1, int K1, float* C, int64_t ldc, int splits, int64_t slab_stride,
                       int nst, unsigned long long* trace, hipStream_t st);
 int launch_encode_bits(int Bp, int Hp, int Fp, const uint32_t* bits, int64_t ldw, const void* Wt_lo, int64_t ldb, float* C,
-                       int64_t ldc, int splits, int64_t slab_stride, hipStream_t st);
+                       int64_t ldc, int splits, int64_t slab_stride, hipStream_t st, const LabelJob* label_job = nullptr,
+                       int* label_done = nullptr);
+bool encode_bits_fits(int Bp, int Hp, int Fp, int splits);
 
 }  // namespace dae

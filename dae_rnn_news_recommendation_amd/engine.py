@@ -185,6 +185,10 @@ class Engine:
         n = int(np.prod(shape)) * torch.tensor([], dtype=dtype).element_size()
         return self.workspace[off:off + n].view(dtype).view(*shape)
 
+    def set_option(self, name, value):
+        """Code-path choice of the plan (A/B measurements, equivalence tests): see dae_plan_set_option in include/dae_hip.h."""
+        L.check(self.lib.dae_plan_set_option(self.plan, name.encode(), int(value)), "dae_plan_set_option")
+
     def profile(self, enable):
         L.check(self.lib.dae_plan_profile(self.plan, int(bool(enable))), "dae_plan_profile")
 

@@ -260,7 +260,8 @@ int dae_weighted_loss_rows(const float* x, int64_t ldx, const float* y, int64_t 
                            int32_t loss_func, float* rowloss, void* stream);
 
 /* A/B switch for the plain GEMM's staging: 0 = register staging (2 LDS buffers), 2/3/4 = depth of the
- * global_load_lds ring with counted vmcnt waits (default 2). */
+ * global_load_lds ring with counted vmcnt waits (default 2); -1 / -2 = 4-wave kernel for every grid / 8-wave
+ * producer-consumer kernel for grids of at most one workgroup per CU (default). */
 void dae_set_glds(int32_t nst);
 
 /* ---------------------------------------------------------------------------------------------
@@ -340,6 +341,13 @@ uint64_t dae_plan_workspace_bytes(const dae_plan* p);
 int      dae_plan_bind(dae_plan* p, const dae_buffers* bufs);
 /* refresh W_lo / Wt_lo from W (after set_params / checkpoint restore) */
 int      dae_plan_sync_shadows(dae_plan* p, void* stream);
+/* Code-path choice of a plan, for A/B measurements and equivalence tests (every option selects between implementations of the
+ * same arithmetic; the library never reads the environment).  Names: "encode_bits" (x~ as a bit image into the encode GEMM; on
+ * by default for binary CSR + bf16), "x_bits" (clean rows as a bit image into the decode epilogue), "fused_opt" (optimizer in the
+ * dW GEMM's epilogue), "tail" (bias gradients + statistics + x~^T un-scatter in one launch), "label_with_encode", "ce_literal"
+ * (cross_entropy always by the reference-literal formula), "overlap" (miner chain on a side stream), "gram_fp32" (exact-fp32 Gram
+ * matrix in bf16 mode; before dae_plan_bind only).  Unknown names are an error. */
+int      dae_plan_set_option(dae_plan* p, const char* name, int32_t value);
 int      dae_train_step(dae_plan* p, const dae_step* step, void* stream);
 int      dae_plan_apply(dae_plan* p, int32_t adam_t, float grad_scale, void* stream);
 /* transform(): out[B x H] fp32 (ld_out) = encode of rows row_idx (autoencoder.py:479-505) */

@@ -164,6 +164,9 @@ def load_or_restore(a, data_dir, helpers):
     trX, vlX = X[:a.train_row], (X[a.train_row:a.train_row + a.validate_row] if a.validation else None)
     trY = None if y is None else np.asarray(y[:a.train_row])
     vlY = None if (y is None or not a.validation) else np.asarray(y[a.train_row:a.train_row + a.validate_row])
+    from dae_rnn_news_recommendation_amd import dp
+    if dp.rank() != 0:                     # data parallel: rank 0 is the only writer of the shared artefact directory
+        return trX, vlX, trY, vlY
     for M, val in ((trX, False), (vlX, True)):
         if M is not None:
             helpers.save_file(M if sparse.issparse(M) else np.asarray(M), data_dir + (_artefact("features", a, val) if sparse.issparse(M)
@@ -192,11 +195,12 @@ def main(argv=None):
     need_labels = a.triplet_strategy != 'none'
     model.fit(trX, vlX, trY if need_labels else None, vlY if need_labels else None,
               restore_previous_model=a.restore_previous_model)
-    with open(model.parameter_file, 'a+') as fh:                        # reference :279-285
-        print('train_row={}'.format(a.train_row), file=fh)
-        print('validate_row={}'.format(a.validate_row), file=fh)
-        print('input_format={}'.format(a.input_format), file=fh)
-        print('label={}'.format(a.label), file=fh)
+    if dp.rank() == 0:
+        with open(model.parameter_file, 'a+') as fh:                    # reference :279-285
+            print('train_row={}'.format(a.train_row), file=fh)
+            print('validate_row={}'.format(a.validate_row), file=fh)
+            print('input_format={}'.format(a.input_format), file=fh)
+            print('label={}'.format(a.label), file=fh)
     # encode with the decay compensation the reference applies at inference (:289-290)
     emb = model.transform(utils.decay_noise(trX, a.corr_frac), name='article_encoded_train', save=True)
     emb_v = None

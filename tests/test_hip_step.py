@@ -26,7 +26,7 @@ def _keep_bits(keep):
 
 
 def _run_case(dtype, strategy, loss_func, acts, opt, *, N=400, F=700, H=90, B=150, steps=2, seed=0, dense=False,
-              alpha=0.7, tol=None):
+              alpha=0.7, tol=None, options=None):
     from dae_rnn_news_recommendation_amd import _lib as L
     from dae_rnn_news_recommendation_amd.engine import Engine
     rng = np.random.default_rng(seed)
@@ -39,6 +39,8 @@ def _run_case(dtype, strategy, loss_func, acts, opt, *, N=400, F=700, H=90, B=15
         W0 = torch.as_tensor(W0).to(torch.bfloat16).float().numpy()     # start from bf16-representable weights
     eng = Engine(F, H, B, dtype=dtype, enc_act=acts[0], dec_act=acts[1], loss_func=loss_func, opt=opt,
                  learning_rate=0.05, momentum=0.5, alpha=alpha, triplet=strategy)
+    for name, value in (options or {}).items():          # code-path choices of the plan (dae_plan_set_option)
+        eng.set_option(name, value)
     if dense:
         eng.upload_dense(m.toarray())
     else:
@@ -108,11 +110,11 @@ def test_step_bf16_matches_oracle(strategy):
     assert _rel(dW, r["dW"]) < 2e-2 and _rel(dbh, r["dbh"]) < 2e-2 and _rel(dbv, r["dbv"]) < 2e-2
 
 
-def test_step_bit_operand_equals_dense_operand(monkeypatch):
-    """DAE_BITS=1 (bf16 + binary CSR) runs the fused corrupt+encode GEMM on the bit image of x~ instead of the dense bf16
-    x~ operand.  Same products, same fp32 accumulation: statistics, gradients and weights must agree."""
-    a, _, pa = _run_case("bf16", "batch_all", "cross_entropy", ("sigmoid", "sigmoid"), "ada_grad", steps=3, seed=5)
-    monkeypatch.setenv("DAE_BITS", "1")
+def test_step_bit_operand_equals_dense_operand():
+    """bf16 + binary CSR runs the fused corrupt+encode GEMM on the BIT image of x~ (default); option encode_bits = 0 keeps
+    the dense bf16 x~ operand.  Same products, same fp32 accumulation: statistics, gradients and weights must agree."""
+    a, _, pa = _run_case("bf16", "batch_all", "cross_entropy", ("sigmoid", "sigmoid"), "ada_grad", steps=3, seed=5,
+                         options={"encode_bits": 0})
     b, _, pb = _run_case("bf16", "batch_all", "cross_entropy", ("sigmoid", "sigmoid"), "ada_grad", steps=3, seed=5)
     for (_, sa, dWa, dbha, dbva), (_, sb, dWb, dbhb, dbvb) in zip(a, b):
         assert np.allclose(sa[:5], sb[:5], rtol=2e-6, atol=0)
@@ -123,12 +125,12 @@ def test_step_bit_operand_equals_dense_operand(monkeypatch):
 
 
 @pytest.mark.parametrize("strategy", ["none", "batch_all"])
-def test_x_bit_image_equals_dense_x_tile(strategy, monkeypatch):
-    """bf16 + binary CSR: the decode epilogue reads the clean rows from the gather's bit image (default); DAE_NO_XBITS=1
+def test_x_bit_image_equals_dense_x_tile(strategy):
+    """bf16 + binary CSR: the decode epilogue reads the clean rows from the gather's bit image (default); option x_bits = 0
     keeps the dense bf16 x tile.  x is exactly 0/1 either way: every statistic and gradient must be identical."""
     a, _, pa = _run_case("bf16", strategy, "cross_entropy", ("sigmoid", "sigmoid"), "gradient_descent", steps=2, seed=11)
-    monkeypatch.setenv("DAE_NO_XBITS", "1")
-    b, _, pb = _run_case("bf16", strategy, "cross_entropy", ("sigmoid", "sigmoid"), "gradient_descent", steps=2, seed=11)
+    b, _, pb = _run_case("bf16", strategy, "cross_entropy", ("sigmoid", "sigmoid"), "gradient_descent", steps=2, seed=11,
+                         options={"x_bits": 0})
     for (_, sa, dWa, dbha, dbva), (_, sb, dWb, dbhb, dbvb) in zip(a, b):
         assert np.array_equal(sa[:5], sb[:5])
         assert np.array_equal(dWa, dWb) and np.array_equal(dbha, dbhb) and np.array_equal(dbva, dbvb)
@@ -137,12 +139,12 @@ def test_x_bit_image_equals_dense_x_tile(strategy, monkeypatch):
 
 
 @pytest.mark.parametrize("opt", ["gradient_descent", "ada_grad", "momentum", "adam"])
-def test_fused_optimizer_equals_separate_kernel(opt, monkeypatch):
-    """bf16 single-GPU steps run the optimizer in the dW GEMM's epilogue; DAE_NO_FUSED_OPT=1 keeps dW -> grad -> opt_step.
+def test_fused_optimizer_equals_separate_kernel(opt):
+    """bf16 single-GPU steps run the optimizer in the dW GEMM's epilogue; option fused_opt = 0 keeps dW -> grad -> opt_step.
     Same fp32 gradient tile, same update arithmetic: parameters (and the gradient image of phase 0) must agree."""
     a, _, pa = _run_case("bf16", "batch_all", "cross_entropy", ("sigmoid", "sigmoid"), opt, steps=3, seed=9)
-    monkeypatch.setenv("DAE_NO_FUSED_OPT", "1")
-    b, _, pb = _run_case("bf16", "batch_all", "cross_entropy", ("sigmoid", "sigmoid"), opt, steps=3, seed=9)
+    b, _, pb = _run_case("bf16", "batch_all", "cross_entropy", ("sigmoid", "sigmoid"), opt, steps=3, seed=9,
+                         options={"fused_opt": 0})
     for (_, sa, dWa, dbha, dbva), (_, sb, dWb, dbhb, dbvb) in zip(a, b):
         assert np.allclose(sa[:5], sb[:5], rtol=1e-6, atol=0)
         assert _rel(dWa, dWb.astype(np.float64)) < 1e-6

@@ -15,12 +15,15 @@ ap.add_argument("--features", type=int, default=10000); ap.add_argument("--hidde
 ap.add_argument("--batch", type=int, default=800); ap.add_argument("--loss", default="cross_entropy")
 ap.add_argument("--enc-splits", type=int, default=0); ap.add_argument("--tag", default="")
 ap.add_argument("--nst", type=int, default=-1); ap.add_argument("--phase", type=int, default=3); ap.add_argument("--gram-splits", type=int, default=0)
+ap.add_argument("--opt", action="append", default=[], help="plan option name=value (dae_plan_set_option), repeatable")
 a = ap.parse_args()
 if a.nst >= 0:
     L.load().dae_set_glds(a.nst)
 m = synthetic_csr(a.rows, a.features, seed=1); lab = synthetic_labels(a.rows, seed=1).astype(np.int32)
 eng = Engine(a.features, a.hidden, a.batch, dtype=a.precision, triplet=a.strategy, loss_func=a.loss, learning_rate=0.1,
              encode_splits=a.enc_splits, dh_splits=a.enc_splits, gram_splits=a.gram_splits)
+for o in a.opt:
+    k, v = o.split("="); eng.set_option(k, int(v))
 eng.upload_csr(m); eng.set_params(xavier_uniform(a.features, a.hidden))
 idx = torch.arange(a.batch, dtype=torch.int32, device="cuda"); labs = torch.from_numpy(lab[:a.batch]).cuda()
 stats = torch.zeros(8, device="cuda")
@@ -33,6 +36,6 @@ for _ in range(a.steps):
     eng.train_step(idx, labs if a.strategy != "none" else None, stats, phase=a.phase, **kw)
 prof = eng.profile_read(); eng.profile(False)
 tot = sum(ms for ms, n in prof.values())
-print(f"== nst={a.nst} {a.tag} {a.strategy} {a.precision} total {1e3*tot/a.steps:.1f} us/step  info={eng.info()}")
+print(f"== nst={a.nst} {a.tag} {a.opt} {a.strategy} {a.precision} total {1e3*tot/a.steps:.1f} us/step  info={eng.info()}")
 for k, (ms, n) in prof.items():
     if n: print(f"   {k:18s} {1e3*ms/n:9.1f} us  x{n/a.steps:.0f}")
