@@ -112,6 +112,7 @@ struct dae_plan {
     bool fuse_opt_ok;                // option "fused_opt" = 0 keeps the separate optimizer kernel (A/B, equivalence tests)
     bool label_enc_ok;               // option "label_with_encode" = 0: label statistics ride on the gather launch / their own
     bool ce_literal;                 // option "ce_literal" = 1: cross_entropy always by the reference-literal formula
+    bool sparse_ok;                  // CSR input: fused corrupt + gather + encode on the stored entries (option "encode_sparse" = 0: dense MFMA GEMM)
     bool bits_ok;                    // binary CSR + bf16: x~ handed to the encode GEMM as a bit image (dae_plan_set_option("encode_bits", 0) disables)
     int32_t *dw_i32, *n_same;
     int64_t *nvalid, *dw_i64;
@@ -212,6 +213,7 @@ extern "C" int dae_plan_create(const dae_config* cfg, dae_plan** out) {
     p->xct_clean = false;
     // binary CSR + bf16: x~ goes to the encode GEMM as a bit image whenever the 8-wave bit kernel can run the shape
     p->bits_ok = cfg->dtype == DAE_BF16 && encode_bits_fits(p->Bpm, p->Hp, p->Fp, p->s_enc);
+    p->sparse_ok = true;
     p->overlap_ok = false;                              // measured: running the miner chain beside decode is SLOWER (0.410 vs 0.351 ms/step)
     *out = p;
     return 0;
@@ -232,7 +234,8 @@ extern "C" void dae_plan_destroy(dae_plan* p) {
 extern "C" int dae_plan_set_option(dae_plan* p, const char* name, int32_t value) {
     DAE_CHECK_ARG(p && name, "plan_set_option: null argument");
     const bool on = value != 0;
-    if (!strcmp(name, "encode_bits")) p->bits_ok = on && p->cfg.dtype == DAE_BF16 && encode_bits_fits(p->Bpm, p->Hp, p->Fp, p->s_enc);
+    if (!strcmp(name, "encode_sparse")) p->sparse_ok = on;
+    else if (!strcmp(name, "encode_bits")) p->bits_ok = on && p->cfg.dtype == DAE_BF16 && encode_bits_fits(p->Bpm, p->Hp, p->Fp, p->s_enc);
     else if (!strcmp(name, "x_bits")) p->xbits_ok = on && p->cfg.dtype == DAE_BF16;
     else if (!strcmp(name, "fused_opt")) p->fuse_opt_ok = on;
     else if (!strcmp(name, "tail")) p->tail_ok = on;
@@ -393,30 +396,58 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     bool use_bits = false;
     // binary CSR train set in bf16 mode: the clean rows reach the decode epilogue as a bit image (1.1 MB, not 18 MB)
     const bool use_xbits = p->xbits_ok && p->b.indptr && !p->b.values;
-    if (s->c_indptr) {   // an explicitly corrupted copy of the train set (salt&pepper, host-side noise)
-        PROF(PS_GATHER, gather_batch(p, p->b.indptr, p->b.indices, p->b.values, p->b.dense, p->b.ld_dense, s->row_idx, B, use_xbits ? nullptr : p->x,
-                        nullptr, nullptr, rowsq, DAE_CORR_NONE, nullptr, 0, 0, 0.f, 1.f, stream, nullptr, nullptr, use_xbits ? p->x_bits : nullptr));
-        PROF(PS_GATHER, gather_batch(p, s->c_indptr, s->c_indices, s->c_values, nullptr, 0, s->row_idx, B, nullptr, p->xc,
-                        backward ? p->xct : nullptr, nullptr, DAE_CORR_NONE, nullptr, 0, 0, 0.f, s->scale, stream));
-    } else {
-        // binary CSR, unit scale, bf16: the corrupted batch goes to the encode GEMM as a BIT image (1.1 MB, not 18 MB of bf16)
-        use_bits = p->bits_ok && p->b.indptr && !p->b.values && s->scale == 1.0f;
-        PROF(PS_GATHER, gather_batch(p, p->b.indptr, p->b.indices, p->b.values, p->b.dense, p->b.ld_dense, s->row_idx, B,
-                        use_xbits ? nullptr : p->x, use_bits ? nullptr : p->xc, backward ? p->xct : nullptr, rowsq, s->corr_mode, s->keep_bits,
-                        s->seed, s->rng_stream, s->corr_frac, s->scale, stream, use_bits ? p->xc_bits : nullptr, label_in_gather ? &lj : nullptr,
-                        use_xbits ? p->x_bits : nullptr));
-    }
-    // 3-4. encode (K1/K2)
+    const bool use_sparse = p->sparse_ok && csr_in;
     const int64_t slab = (int64_t)Bp * Hp;
     int enc_label_done = 0;
-    if (use_bits)
-        PROF(PS_ENC_GEMM, launch_encode_bits(Bp, Hp, Fp, p->xc_bits, Fp / 32, p->b.Wt_lo, Fp, p->slabs, Hp, p->s_enc, slab, st,
-                                             label_with_encode ? &lj : nullptr, label_with_encode ? &enc_label_done : nullptr));
-    else
-        PROF(PS_ENC_GEMM, launch_gemm_f32out(dt, Bp, Hp, p->xc, Fp, p->b.Wt_lo, Fp, Fp, nullptr, 0, nullptr, 0, 0, p->slabs, Hp, p->s_enc, slab, st,
-                                             GEMM_ROLE_ENCODE, label_with_encode ? &lj : nullptr, label_with_encode ? &enc_label_done : nullptr));
-    PROF(PS_ENC_FIN, dae_encode_finish(p->slabs, p->s_enc, slab, Hp, p->b.bh, B, H, c.enc_act, dt, p->h_f32, p->h_lo, Hp, p->h_t, ldB,
-                                       p->gram_split ? p->hcat_a : nullptr, p->gram_split ? p->hcat_b : nullptr, stream));
+    bool labels_done = false;                  // label statistics already produced by a workgroup of an earlier launch
+    if (use_sparse) {
+        // CSR input: corrupt + gather + encode in one launch on the stored entries (tf.sparse.matmul, autoencoder.py:377,389);
+        // the dense x~ image is never formed.  The clean rows reach the decode epilogue as a bit image written by the same
+        // launch (binary data) or as a dense tile from the gather kernel (valued data / explicitly corrupted copy).
+        const bool own_clean = !s->c_indptr && use_xbits;            // the encode launch also emits the clean-row images
+        if (!own_clean)
+            PROF(PS_GATHER, gather_batch(p, p->b.indptr, p->b.indices, p->b.values, p->b.dense, p->b.ld_dense, s->row_idx, B,
+                            use_xbits ? nullptr : p->x, nullptr, nullptr, rowsq, DAE_CORR_NONE, nullptr, 0, 0, 0.f, 1.f, stream, nullptr, nullptr,
+                            use_xbits ? p->x_bits : nullptr));
+        EncCsrLaunch q;
+        memset(&q, 0, sizeof(q));
+        q.indptr = s->c_indptr ? s->c_indptr : p->b.indptr; q.indices = s->c_indptr ? s->c_indices : p->b.indices;
+        q.values = s->c_indptr ? s->c_values : p->b.values; q.row_idx = s->row_idx; q.B = B; q.F = F; q.H = H; q.dtype = dt;
+        q.W = p->b.W_lo; q.ldw = Hp; q.bh = p->b.bh; q.enc_act = c.enc_act;
+        q.corr_mode = s->c_indptr ? DAE_CORR_NONE : s->corr_mode; q.keep_bits = s->keep_bits; q.seed = s->seed; q.rng_stream = s->rng_stream;
+        q.corr_frac = s->corr_frac; q.scale = s->scale;
+        q.h_f32 = p->h_f32; q.h_lo = p->h_lo; q.ldh = Hp; q.h_t = p->h_t; q.ldht = ldB;
+        q.hcat_a = p->gram_split ? p->hcat_a : nullptr; q.hcat_b = p->gram_split ? p->hcat_b : nullptr;
+        q.x_bits = own_clean ? p->x_bits : nullptr; q.ldxb = Fp / 32; q.xct = backward ? p->xct : nullptr; q.ldt = ldB;
+        q.rowsq = own_clean ? rowsq : nullptr;
+        q.label_job = label_with_encode ? &lj : nullptr;
+        PROF(PS_ENC_GEMM, launch_encode_csr(q, st));
+        labels_done = label_with_encode;
+    } else {
+        if (s->c_indptr) {   // an explicitly corrupted copy of the train set (salt&pepper, host-side noise)
+            PROF(PS_GATHER, gather_batch(p, p->b.indptr, p->b.indices, p->b.values, p->b.dense, p->b.ld_dense, s->row_idx, B, use_xbits ? nullptr : p->x,
+                            nullptr, nullptr, rowsq, DAE_CORR_NONE, nullptr, 0, 0, 0.f, 1.f, stream, nullptr, nullptr, use_xbits ? p->x_bits : nullptr));
+            PROF(PS_GATHER, gather_batch(p, s->c_indptr, s->c_indices, s->c_values, nullptr, 0, s->row_idx, B, nullptr, p->xc,
+                            backward ? p->xct : nullptr, nullptr, DAE_CORR_NONE, nullptr, 0, 0, 0.f, s->scale, stream));
+        } else {
+            // binary CSR, unit scale, bf16: the corrupted batch goes to the encode GEMM as a BIT image (1.1 MB, not 18 MB of bf16)
+            use_bits = p->bits_ok && p->b.indptr && !p->b.values && s->scale == 1.0f;
+            PROF(PS_GATHER, gather_batch(p, p->b.indptr, p->b.indices, p->b.values, p->b.dense, p->b.ld_dense, s->row_idx, B,
+                            use_xbits ? nullptr : p->x, use_bits ? nullptr : p->xc, backward ? p->xct : nullptr, rowsq, s->corr_mode, s->keep_bits,
+                            s->seed, s->rng_stream, s->corr_frac, s->scale, stream, use_bits ? p->xc_bits : nullptr, label_in_gather ? &lj : nullptr,
+                            use_xbits ? p->x_bits : nullptr));
+        }
+        // 3-4. encode (K1/K2)
+        if (use_bits)
+            PROF(PS_ENC_GEMM, launch_encode_bits(Bp, Hp, Fp, p->xc_bits, Fp / 32, p->b.Wt_lo, Fp, p->slabs, Hp, p->s_enc, slab, st,
+                                                 label_with_encode ? &lj : nullptr, label_with_encode ? &enc_label_done : nullptr));
+        else
+            PROF(PS_ENC_GEMM, launch_gemm_f32out(dt, Bp, Hp, p->xc, Fp, p->b.Wt_lo, Fp, Fp, nullptr, 0, nullptr, 0, 0, p->slabs, Hp, p->s_enc, slab, st,
+                                                 GEMM_ROLE_ENCODE, label_with_encode ? &lj : nullptr, label_with_encode ? &enc_label_done : nullptr));
+        PROF(PS_ENC_FIN, dae_encode_finish(p->slabs, p->s_enc, slab, Hp, p->b.bh, B, H, c.enc_act, dt, p->h_f32, p->h_lo, Hp, p->h_t, ldB,
+                                           p->gram_split ? p->hcat_a : nullptr, p->gram_split ? p->hcat_b : nullptr, stream));
+        labels_done = (label_in_gather && !s->c_indptr) || enc_label_done;
+    }
     // 5-6. miners (K5-K7)
     const int Bt = explicit3 ? B / 3 : B;
     if (explicit3) {
@@ -425,7 +456,7 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
         DAE_CHECK_HIP(hipMemcpyAsync(p->cw + Bt, p->cw, (size_t)Bt * 4, hipMemcpyDeviceToDevice, st));
         DAE_CHECK_HIP(hipMemcpyAsync(p->cw + 2 * Bt, p->cw, (size_t)Bt * 4, hipMemcpyDeviceToDevice, st));
         PROF(PS_MINER, dae_explicit_triplet(p->h_f32, Hp, Bt, H, c.alpha, p->dh_extra, p->loss_part, p->tri_scalars, stream));
-    } else if (!(label_in_gather || enc_label_done)) {
+    } else if (!labels_done) {
         PROF(PS_LABEL, dae_label_stats(s->labels, B, Bp, c.triplet, p->n_same, p->acc, p->nvalid, p->dw_i64, p->cw, c.alpha, p->tri_scalars, stream));
     }
     bool forked = false;
@@ -556,6 +587,16 @@ extern "C" int dae_encode_rows(dae_plan* p, const int32_t* row_idx, int32_t B, f
     DAE_CHECK_ARG((indptr != nullptr) != (dense != nullptr), "encode_rows: give either a CSR or a dense matrix");
     hipStream_t st = (hipStream_t)stream;
     const int Bp = (int)pad128(B), Fp = p->Fp, Hp = p->Hp, dt = p->cfg.dtype;
+    if (indptr && p->sparse_ok) {        // CSR: one launch on the stored entries, straight into the caller's [B x H] matrix when it is padded like h
+        EncCsrLaunch q;
+        memset(&q, 0, sizeof(q));
+        q.indptr = indptr; q.indices = indices; q.values = values; q.row_idx = row_idx; q.B = B; q.F = p->F; q.H = p->H; q.dtype = dt;
+        q.W = p->b.W_lo; q.ldw = Hp; q.bh = p->b.bh; q.enc_act = p->cfg.enc_act; q.corr_mode = DAE_CORR_NONE; q.scale = scale;
+        q.h_f32 = p->h_f32; q.ldh = Hp;
+        RC(launch_encode_csr(q, st));
+        DAE_CHECK_HIP(hipMemcpy2DAsync(out, (size_t)ld_out * 4, p->h_f32, (size_t)Hp * 4, (size_t)p->H * 4, B, hipMemcpyDeviceToDevice, st));
+        return 0;
+    }
     const bool use_bits = p->bits_ok && indptr && !values && scale == 1.0f;
     RC(gather_batch(p, indptr, indices, values, dense, ld_dense, row_idx, B, nullptr, use_bits ? nullptr : p->xc, nullptr, nullptr,
                     DAE_CORR_NONE, nullptr, 0, 0, 0.f, scale, stream, use_bits ? p->xc_bits : nullptr));

@@ -153,6 +153,177 @@ __global__ __launch_bounds__(256) void gather_dense_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused corrupt + gather + encode for CSR inputs -- what the reference's graph does in ONE op,
+// tf.sparse.matmul(x~, W) (autoencoder.py:377,389), followed by + b_h, the activation and - act(b_h):
+//     h[i, :] = act( sum_{e in row(i), kept(e)} scale * v_e * W[col_e, :] + b_h ) - act(b_h)
+// The dense [B x F] image of x~ is never formed: a batch row holds ~200 of 10^4 features, so the kernel sums ~140 rows
+// of W per batch row (0.11 GFLOP instead of the 8 GFLOP of the dense contraction) and is bound by the L2 -> VGPR rate of
+// those W-row reads, not by MFMA.  Decomposition for the L2: the H columns are cut into slices of 64 (128 bytes of a bf16 W
+// row); block b works on slice b % n_slices, and the dispatcher places block b on XCD b % 8, so with 8 slices every XCD
+// re-reads only ITS 1.3 MB column slice of W_lo from its private 4 MiB L2 (placement affects speed only).
+// Work split: one workgroup = 8 batch rows x one slice, 2 rows per wave.  A lane owns one stored entry of the row
+// (coalesced index / value / keep-decision reads, 64 entries per pass); entries are then walked 8 at a time: lane (sub, part)
+// loads 16 bytes (part) of the W row of entry `sub`, so one wave instruction fetches 8 W-row slices (1 KiB) and 8 of them are
+// in flight per lane.  Per-lane fp32 accumulators (8 columns), one butterfly over the 8 entry groups at the end of the row,
+// fixed order -> deterministic.  Epilogue: bias, activation, and every image of h the step needs (fp32, low precision, h^T
+// via an LDS transpose, split-bf16 Gram operands).
+// The workgroups of a row group also produce the batch's side images, one task per slice: the bit image of the CLEAN rows
+// (decode epilogue), the scatter of kept entries into x~^T (dW GEMM operand), sum of squares (cosine_proximity).
+// ------------------------------------------------------------------------------------------------
+struct EncCsrArgs {
+    const int64_t* indptr; const int32_t* indices; const float* values; const int32_t* row_idx;
+    int B, Bp, F, H, Hp;
+    const void* W; int64_t ldw;                 // [Fp x ldw] row-major, element type WT
+    const float* bh;
+    int corr_mode; const uint32_t* keep_bits; uint64_t seed; uint32_t stream; float corr_frac, scale;
+    int enc_act;
+    float* h_f32; void* h_lo; int64_t ldh; void* h_t; int64_t ldht; bf16_t* hcat_a; bf16_t* hcat_b;
+    uint32_t* x_bits; int64_t ldxb;             // clean bit image [Bp x ldxb] (binary data) or NULL
+    void* xct; int64_t ldt;                     // x~^T [Fp x ldt] scatter target (pre-zeroed) or NULL
+    float* rowsq;                               // [Bp] or NULL
+    int n_slices;
+    LabelJob job; int label_block;
+};
+
+constexpr int ENC_ROWS = 8;                     // batch rows per workgroup (2 per wave)
+
+template <typename WT> struct WRow;
+template <> struct WRow<bf16_t> {               // 64 columns = 128 B: lane part reads 16 B = 8 bf16
+    static __device__ __forceinline__ void fma8(const char* p, float w, float (&acc)[8]) {
+        const i32x4 v = *reinterpret_cast<const i32x4*>(p);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            acc[2 * q] = fmaf(w, __uint_as_float(((uint32_t)v[q]) << 16), acc[2 * q]);
+            acc[2 * q + 1] = fmaf(w, __uint_as_float(((uint32_t)v[q]) & 0xffff0000u), acc[2 * q + 1]);
+        }
+    }
+};
+template <> struct WRow<float> {                // 64 columns = 256 B: lane part reads 32 B = 8 fp32
+    static __device__ __forceinline__ void fma8(const char* p, float w, float (&acc)[8]) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { acc[q] = fmaf(w, a[q], acc[q]); acc[4 + q] = fmaf(w, b[q], acc[4 + q]); }
+    }
+};
+
+template <typename WT, typename T>
+__global__ __launch_bounds__(256) void encode_csr_kernel(EncCsrArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((int)blockIdx.x == a.label_block) { label_stats_block<256>(a.job, smem); return; }
+    float* zt = reinterpret_cast<float*>(smem);                          // [ENC_ROWS][64] pre-activations of this slice
+    T* ht = reinterpret_cast<T*>(smem + ENC_ROWS * 64 * 4);              // [64][ENC_ROWS] transposed low-precision h
+    uint32_t* xb = reinterpret_cast<uint32_t*>(smem + ENC_ROWS * 64 * 4 + 64 * ENC_ROWS * 4);   // [ENC_ROWS][ldxb] clean bit rows
+    const int slice = blockIdx.x % a.n_slices, i0 = (blockIdx.x / a.n_slices) * ENC_ROWS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sub = lane >> 3, part = lane & 7;
+    // side images: task t is produced by the workgroups of slice t % n_slices
+    const bool do_xbits = a.x_bits && slice == 0;
+    const bool do_xct = a.xct && slice == 1 % a.n_slices;
+    const bool do_rowsq = a.rowsq && slice == 2 % a.n_slices;
+    if (do_xbits) {
+        for (int k = tid; k < ENC_ROWS * (int)a.ldxb; k += 256) xb[k] = 0u;
+        __syncthreads();
+    }
+    const char* Wb = reinterpret_cast<const char*>(a.W) + (int64_t)slice * 64 * sizeof(WT) + part * (8 * sizeof(WT));
+    const int64_t ldw_b = a.ldw * (int64_t)sizeof(WT);
+    T* xct = reinterpret_cast<T*>(a.xct);
+#pragma unroll 1
+    for (int rr = 0; rr < 2; ++rr) {
+        const int r = wave * 2 + rr, i = i0 + r;
+        float acc[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+        float sq = 0.f;
+        if (i < a.B) {
+            const int64_t row = a.row_idx[i];
+            const int64_t s0 = a.indptr[row], e0 = a.indptr[row + 1];
+            for (int64_t base = s0; base < e0; base += 64) {
+                const int64_t k = base + lane;
+                const bool valid = k < e0;
+                const int col = valid ? a.indices[k] : 0;
+                const float v = valid ? (a.values ? a.values[k] : 1.0f) : 0.f;
+                const bool keep = valid && col < a.F && keep_entry(a.corr_mode, a.keep_bits, (uint64_t)k, a.seed, a.stream, a.corr_frac);
+                const float vc = keep ? v * a.scale : 0.f;
+                if (do_xbits && valid && col < a.F) atomicOr(&xb[r * a.ldxb + (col >> 5)], 1u << (col & 31));
+                if (do_xct && keep) xct[(int64_t)col * a.ldt + i] = Elem<T>::from(vc);
+                if (do_rowsq) sq += v * v;
+                const int nent = (int)min((int64_t)64, e0 - base);
+                // 8 entries per step (one per 8-lane group); all W-row loads of the pass are issued before the first use
+                int cj[8]; float wj[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    cj[j] = __shfl(col, j * 8 + sub, 64);
+                    wj[j] = __shfl(vc, j * 8 + sub, 64);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (j * 8 < nent && wj[j] != 0.f) WRow<WT>::fma8(Wb + (int64_t)cj[j] * ldw_b, wj[j], acc);
+                }
+            }
+        }
+        // butterfly over the 8 entry groups (lane bits 3..5); lanes 0..7 (sub == 0) end up with the row's sums
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            float t = acc[q];
+            t += __shfl_xor(t, 8, 64);
+            t += __shfl_xor(t, 16, 64);
+            t += __shfl_xor(t, 32, 64);
+            acc[q] = t;
+        }
+        if (sub == 0) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) zt[r * 64 + part * 8 + q] = acc[q];
+        }
+        if (do_rowsq) {
+            sq = wave_sum(sq);
+            if (lane == 0 && i < a.Bp) a.rowsq[i] = (i < a.B) ? sq : 0.f;
+        }
+    }
+    __syncthreads();
+    // ---- epilogue on the [8 rows x 64 columns] tile: thread = (row, column pair) ----
+    {
+        const int r = tid >> 5, cp = tid & 31, i = i0 + r;
+        float hv[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int cl = cp * 2 + u, col = slice * 64 + cl;
+            const float b = col < a.Hp ? a.bh[col] : 0.f;
+            const float z = zt[r * 64 + cl] + b;
+            hv[u] = (i < a.B && col < a.H) ? act_apply(a.enc_act, z) - act_apply(a.enc_act, b) : 0.f;
+            ht[cl * ENC_ROWS + r] = Elem<T>::from(hv[u]);
+        }
+        const int col0 = slice * 64 + cp * 2;
+        if (a.h_f32) *reinterpret_cast<float2*>(a.h_f32 + (int64_t)i * a.ldh + col0) = make_float2(hv[0], hv[1]);
+        if (a.h_lo) {
+            T* hl = reinterpret_cast<T*>(a.h_lo) + (int64_t)i * a.ldh + col0;
+            hl[0] = Elem<T>::from(hv[0]); hl[1] = Elem<T>::from(hv[1]);
+        }
+        if (a.hcat_a) {   // split-bf16 operands of the Gram matrix: h = hi + lo, D ~= hi.hi + hi.lo + lo.hi
+            const bf16_t hi0 = f2bf(hv[0]), hi1 = f2bf(hv[1]);
+            const bf16_t lo0 = f2bf(hv[0] - bf2f(hi0)), lo1 = f2bf(hv[1] - bf2f(hi1));
+            const uint32_t hi = (uint32_t)hi0 | ((uint32_t)hi1 << 16), lo = (uint32_t)lo0 | ((uint32_t)lo1 << 16);
+            uint32_t* pa = reinterpret_cast<uint32_t*>(a.hcat_a + (int64_t)i * (3 * a.Hp) + col0);
+            uint32_t* pb = reinterpret_cast<uint32_t*>(a.hcat_b + (int64_t)i * (3 * a.Hp) + col0);
+            pa[0] = hi; pa[a.Hp / 2] = hi; pa[a.Hp] = lo;
+            pb[0] = hi; pb[a.Hp / 2] = lo; pb[a.Hp] = hi;
+        }
+    }
+    __syncthreads();
+    if (a.h_t && tid < 64) {                         // h^T: 8 batch columns of one feature row = one 16-byte (bf16) / 32-byte store
+        T* dst = reinterpret_cast<T*>(a.h_t) + (int64_t)(slice * 64 + tid) * a.ldht + i0;
+        const T* src = ht + tid * ENC_ROWS;
+        if constexpr (sizeof(T) == 2) *reinterpret_cast<i32x4*>(dst) = *reinterpret_cast<const i32x4*>(src);
+        else { *reinterpret_cast<i32x4*>(dst) = *reinterpret_cast<const i32x4*>(src); *reinterpret_cast<i32x4*>(dst + 4) = *reinterpret_cast<const i32x4*>(src + 4); }
+    }
+    if (do_xbits) {
+        for (int k = tid; k < ENC_ROWS * (int)a.ldxb; k += 256) {
+            const int r = k / (int)a.ldxb, w = k % (int)a.ldxb;
+            a.x_bits[(int64_t)(i0 + r) * a.ldxb + w] = xb[k];
+        }
+    }
+}
+
 __global__ void rowsq_reduce_kernel(const float* __restrict__ part, int nparts, int Bp, float* __restrict__ rowsq) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Bp) return;
@@ -195,6 +366,54 @@ int dae::launch_gather_csr(const int64_t* indptr, const int32_t* indices, const 
                            corr_frac, scale, xc_bits, ldw, job, label_slice, x_bits);
     DAE_CHECK_LAUNCH();
     return 0;
+}
+
+int dae::launch_encode_csr(const EncCsrLaunch& q, hipStream_t st) {
+    DAE_CHECK_ARG(q.indptr && q.indices && q.row_idx && q.W && q.bh, "encode_csr: null input");
+    DAE_CHECK_ARG(q.B > 0 && q.F > 0 && q.H > 0, "encode_csr: bad shape");
+    DAE_CHECK_ARG(q.dtype == DAE_BF16 || q.dtype == DAE_F32, "encode_csr: bad dtype");
+    DAE_CHECK_ARG(q.corr_mode != DAE_CORR_KEEPBITS || q.keep_bits, "encode_csr: keep_bits is null");
+    const int Bp = (int)dae_pad(q.B), Hp = (int)dae_pad(q.H);
+    DAE_CHECK_ARG(q.ldw >= Hp && q.ldh >= Hp && (!q.h_t || q.ldht >= Bp), "encode_csr: leading dimensions too small");
+    DAE_CHECK_ARG(!q.x_bits || (!q.values && q.ldxb >= dae_pad(q.F) / 32), "encode_csr: the bit image of x needs binary data and ldxb >= Fp/32");
+    DAE_CHECK_ARG(!q.xct || q.ldt >= Bp, "encode_csr: ldt too small");
+    DAE_CHECK_ARG(!q.label_job || q.label_job->Bp <= 1024, "encode_csr: in-kernel label statistics need a padded batch <= 1024");
+    DAE_CHECK_ARG((q.hcat_a == nullptr) == (q.hcat_b == nullptr), "encode_csr: hcat_a/hcat_b must be given together");
+    EncCsrArgs a;
+    memset(&a, 0, sizeof(a));
+    a.indptr = q.indptr; a.indices = q.indices; a.values = q.values; a.row_idx = q.row_idx;
+    a.B = q.B; a.Bp = Bp; a.F = q.F; a.H = q.H; a.Hp = Hp; a.W = q.W; a.ldw = q.ldw; a.bh = q.bh;
+    a.corr_mode = q.corr_mode; a.keep_bits = q.keep_bits; a.seed = q.seed; a.stream = q.rng_stream; a.corr_frac = q.corr_frac; a.scale = q.scale;
+    a.enc_act = q.enc_act; a.h_f32 = q.h_f32; a.h_lo = q.h_lo; a.ldh = q.ldh; a.h_t = q.h_t; a.ldht = q.ldht;
+    a.hcat_a = (bf16_t*)q.hcat_a; a.hcat_b = (bf16_t*)q.hcat_b; a.x_bits = q.x_bits; a.ldxb = q.ldxb; a.xct = q.xct; a.ldt = q.ldt;
+    a.rowsq = q.rowsq; a.n_slices = Hp / 64;
+    const int nblk = a.n_slices * (Bp / ENC_ROWS);
+    a.label_block = q.label_job ? nblk : -1;
+    if (q.label_job) a.job = *q.label_job;
+    size_t lds = ENC_ROWS * 64 * 4 + 64 * ENC_ROWS * 4 + (q.x_bits ? (size_t)ENC_ROWS * q.ldxb * 4 : 0);
+    if (q.label_job && lds < (size_t)LABEL_SMEM_BYTES) lds = LABEL_SMEM_BYTES;
+    DAE_CHECK_ARG(lds <= 64 * 1024, "encode_csr: %zu B of LDS for the bit rows of %d features", lds, q.F);
+    dim3 grid(nblk + (q.label_job ? 1 : 0)), block(256);
+    // element type of the weight image follows the activation type: bf16 shadow W_lo, or the fp32 image in parity mode
+    if (q.dtype == DAE_BF16) hipLaunchKernelGGL((encode_csr_kernel<bf16_t, bf16_t>), grid, block, lds, st, a);
+    else hipLaunchKernelGGL((encode_csr_kernel<float, float>), grid, block, lds, st, a);
+    DAE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dae_encode_csr(const int64_t* indptr, const int32_t* indices, const float* values, const int32_t* row_idx,
+                              int32_t B, int32_t F, int32_t H, int32_t dtype, const void* W_lo, int64_t ldw, const float* bh,
+                              int32_t enc_act, int32_t corr_mode, const uint32_t* keep_bits, uint64_t seed, uint32_t rng_stream,
+                              float corr_frac, float scale, float* h_f32, void* h_lo, int64_t ldh, void* h_t, int64_t ldht,
+                              void* hcat_a, void* hcat_b, uint32_t* x_bits, int64_t ldxb, void* xct, int64_t ldt, float* rowsq,
+                              void* stream) {
+    EncCsrLaunch q;
+    memset(&q, 0, sizeof(q));
+    q.indptr = indptr; q.indices = indices; q.values = values; q.row_idx = row_idx; q.B = B; q.F = F; q.H = H; q.dtype = dtype;
+    q.W = W_lo; q.ldw = ldw; q.bh = bh; q.enc_act = enc_act; q.corr_mode = corr_mode; q.keep_bits = keep_bits; q.seed = seed;
+    q.rng_stream = rng_stream; q.corr_frac = corr_frac; q.scale = scale; q.h_f32 = h_f32; q.h_lo = h_lo; q.ldh = ldh; q.h_t = h_t;
+    q.ldht = ldht; q.hcat_a = hcat_a; q.hcat_b = hcat_b; q.x_bits = x_bits; q.ldxb = ldxb; q.xct = xct; q.ldt = ldt; q.rowsq = rowsq;
+    return launch_encode_csr(q, (hipStream_t)stream);
 }
 
 extern "C" int dae_gather_csr_bits(const int64_t* indptr, const int32_t* indices, const float* values, const int32_t* row_idx,

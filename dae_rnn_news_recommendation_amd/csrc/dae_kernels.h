@@ -47,6 +47,18 @@ int launch_gather_csr(const int64_t* indptr, const int32_t* indices, const float
                       uint64_t seed, uint32_t rng_stream, float corr_frac, float scale, uint32_t* xc_bits, int64_t ldw,
                       const LabelJob* label_job, hipStream_t st, uint32_t* x_bits = nullptr);
 
+// fused corrupt + gather + encode for CSR inputs (dae_gather.hip: encode_csr_kernel)
+struct EncCsrLaunch {
+    const int64_t* indptr; const int32_t* indices; const float* values; const int32_t* row_idx;
+    int B, F, H, dtype;
+    const void* W; int64_t ldw; const float* bh; int enc_act;
+    int corr_mode; const uint32_t* keep_bits; uint64_t seed; uint32_t rng_stream; float corr_frac, scale;
+    float* h_f32; void* h_lo; int64_t ldh; void* h_t; int64_t ldht; void* hcat_a; void* hcat_b;
+    uint32_t* x_bits; int64_t ldxb; void* xct; int64_t ldt; float* rowsq;
+    const LabelJob* label_job;
+};
+int launch_encode_csr(const EncCsrLaunch& q, hipStream_t st);
+
 // ---- argument packs of the step-tail kernel (bias gradients + statistics + x~^T un-scatter in one launch) ----
 struct BiasArgs {
     const float* dbv_part; int n_row_waves; const float* colsum_part; int n_row_blocks;

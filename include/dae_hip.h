@@ -92,6 +92,22 @@ int dae_encode_bits(const uint32_t* xc_bits, int64_t ldw, const void* Wt_lo, int
                     int32_t Bp, int32_t Hp, int32_t Fp, float* slabs, int64_t ld_slab,
                     int32_t splits, int64_t slab_stride, void* stream);
 
+/* K0+K1+K2 for CSR inputs in ONE launch: corrupt + gather + encode on the stored entries -- the reference's own
+ * formulation, tf.sparse.matmul(x~, W) + b_h -> activation -> - act(b_h) (autoencoder.py:377,389):
+ *     h[i,:] = act( sum_{e in row_idx[i], kept(e)} scale * v_e * W_lo[col_e, :] + bh ) - act(bh)
+ * The dense x~ image is never formed (a row holds ~2 % of the features): the kernel reads ~140 W rows per batch row and is
+ * bound by L2 -> register bandwidth, not by MFMA.  W_lo: [Fp x ldw] row-major in `dtype` (the bf16 shadow, or fp32 in parity
+ * mode); fp32 accumulation in stored-entry order.  Outputs (any may be NULL): h_f32 / h_lo [Bp x ldh], h_t [Hp x ldht],
+ * hcat_a / hcat_b split-bf16 Gram operands [Bp x 3Hp]; side images of the batch: x_bits [Bp x ldxb] (bit image of the CLEAN
+ * rows, binary data only), xct [Fp x ldt] (kept entries scattered into the pre-zeroed x~^T), rowsq [Bp] (sum of squares of
+ * the clean row).  Corruption arguments as for dae_gather_csr. */
+int dae_encode_csr(const int64_t* indptr, const int32_t* indices, const float* values, const int32_t* row_idx,
+                   int32_t B, int32_t F, int32_t H, int32_t dtype, const void* W_lo, int64_t ldw, const float* bh,
+                   int32_t enc_act, int32_t corr_mode, const uint32_t* keep_bits, uint64_t seed, uint32_t rng_stream,
+                   float corr_frac, float scale, float* h_f32, void* h_lo, int64_t ldh, void* h_t, int64_t ldht,
+                   void* hcat_a, void* hcat_b, uint32_t* x_bits, int64_t ldxb, void* xct, int64_t ldt, float* rowsq,
+                   void* stream);
+
 /* Dense-ndarray input (autoencoder.py:143 sparse_input=False; utils.py:107-109 dense masking):
  * gathers fp32 rows data[row_idx[i], :] into x / xc / xct with optional Philox masking. */
 int dae_gather_dense(const float* data, int64_t ld_data, const int32_t* row_idx, int32_t B, int32_t F,
@@ -342,8 +358,9 @@ int      dae_plan_bind(dae_plan* p, const dae_buffers* bufs);
 /* refresh W_lo / Wt_lo from W (after set_params / checkpoint restore) */
 int      dae_plan_sync_shadows(dae_plan* p, void* stream);
 /* Code-path choice of a plan, for A/B measurements and equivalence tests (every option selects between implementations of the
- * same arithmetic; the library never reads the environment).  Names: "encode_bits" (x~ as a bit image into the encode GEMM; on
- * by default for binary CSR + bf16), "x_bits" (clean rows as a bit image into the decode epilogue), "fused_opt" (optimizer in the
+ * same arithmetic; the library never reads the environment).  Names: "encode_sparse" (CSR inputs: fused corrupt + gather + encode on the stored
+ * entries, dae_encode_csr -- default on; 0 = dense MFMA encode GEMM), "encode_bits" (dense path: x~ as a bit image into the encode
+ * GEMM; on by default for binary CSR + bf16), "x_bits" (clean rows as a bit image into the decode epilogue), "fused_opt" (optimizer in the
  * dW GEMM's epilogue), "tail" (bias gradients + statistics + x~^T un-scatter in one launch), "label_with_encode", "ce_literal"
  * (cross_entropy always by the reference-literal formula), "overlap" (miner chain on a side stream), "gram_fp32" (exact-fp32 Gram
  * matrix in bf16 mode; before dae_plan_bind only).  Unknown names are an error. */

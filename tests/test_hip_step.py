@@ -114,14 +114,31 @@ def test_step_bit_operand_equals_dense_operand():
     """bf16 + binary CSR runs the fused corrupt+encode GEMM on the BIT image of x~ (default); option encode_bits = 0 keeps
     the dense bf16 x~ operand.  Same products, same fp32 accumulation: statistics, gradients and weights must agree."""
     a, _, pa = _run_case("bf16", "batch_all", "cross_entropy", ("sigmoid", "sigmoid"), "ada_grad", steps=3, seed=5,
-                         options={"encode_bits": 0})
-    b, _, pb = _run_case("bf16", "batch_all", "cross_entropy", ("sigmoid", "sigmoid"), "ada_grad", steps=3, seed=5)
+                         options={"encode_sparse": 0, "encode_bits": 0})
+    b, _, pb = _run_case("bf16", "batch_all", "cross_entropy", ("sigmoid", "sigmoid"), "ada_grad", steps=3, seed=5,
+                         options={"encode_sparse": 0})
     for (_, sa, dWa, dbha, dbva), (_, sb, dWb, dbhb, dbvb) in zip(a, b):
         assert np.allclose(sa[:5], sb[:5], rtol=2e-6, atol=0)
         assert _rel(dWa, dWb.astype(np.float64)) < 1e-5 and _rel(dbha, dbhb.astype(np.float64)) < 1e-5
         assert _rel(dbva, dbvb.astype(np.float64)) < 1e-5
     for u, v in zip(pa, pb):
         assert _rel(u, np.asarray(v, np.float64)) < 1e-5
+
+
+@pytest.mark.parametrize("dtype,loss,acts,binary_tol", [("bf16", "cross_entropy", ("sigmoid", "sigmoid"), 2e-6),
+                                                        ("fp32", "mean_squared", ("tanh", "none"), 2e-6)])
+def test_sparse_encode_equals_dense_gemm_encode(dtype, loss, acts, binary_tol):
+    """CSR inputs take the fused corrupt + gather + encode kernel (sum over the stored entries, dae_encode_csr); option
+    encode_sparse = 0 runs gather -> dense MFMA GEMM -> finish.  Same products (bf16 W x fp32 value), fp32 accumulation in a
+    different order: statistics, gradients and weights agree to fp32 rounding."""
+    a, _, pa = _run_case(dtype, "batch_all", loss, acts, "gradient_descent", steps=2, seed=13, options={"encode_sparse": 0})
+    b, _, pb = _run_case(dtype, "batch_all", loss, acts, "gradient_descent", steps=2, seed=13)
+    for (_, sa, dWa, dbha, dbva), (_, sb, dWb, dbhb, dbvb) in zip(a, b):
+        assert np.allclose(sa[:3], sb[:3], rtol=5e-6, atol=0), (sa, sb)
+        assert abs(sa[4] - sb[4]) <= 2                                   # near-tie flips of the positive-triplet count
+        assert _rel(dWa, dWb.astype(np.float64)) < 2e-5 and _rel(dbva, dbvb.astype(np.float64)) < 2e-5
+    for u, v in zip(pa, pb):
+        assert _rel(u, np.asarray(v, np.float64)) < 2e-5
 
 
 @pytest.mark.parametrize("strategy", ["none", "batch_all"])
