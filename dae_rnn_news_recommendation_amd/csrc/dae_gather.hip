@@ -186,12 +186,14 @@ struct EncCsrArgs {
     LabelJob job; int label_block;
 };
 
-constexpr int ENC_ROWS = 8;                     // batch rows per workgroup (2 per wave)
+constexpr int ENC_ROWS = 8;                     // batch rows per workgroup: one per wave (8 waves = 512 threads)
+constexpr int ENC_THREADS = 64 * ENC_ROWS;
 
 template <typename WT> struct WRow;
 template <> struct WRow<bf16_t> {               // 64 columns = 128 B: lane part reads 16 B = 8 bf16
-    static __device__ __forceinline__ void fma8(const char* p, float w, float (&acc)[8]) {
-        const i32x4 v = *reinterpret_cast<const i32x4*>(p);
+    typedef i32x4 Raw;
+    static __device__ __forceinline__ Raw load(const char* p) { return *reinterpret_cast<const i32x4*>(p); }
+    static __device__ __forceinline__ void fma8(const Raw& v, float w, float (&acc)[8]) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             acc[2 * q] = fmaf(w, __uint_as_float(((uint32_t)v[q]) << 16), acc[2 * q]);
@@ -200,126 +202,125 @@ template <> struct WRow<bf16_t> {               // 64 columns = 128 B: lane part
     }
 };
 template <> struct WRow<float> {                // 64 columns = 256 B: lane part reads 32 B = 8 fp32
-    static __device__ __forceinline__ void fma8(const char* p, float w, float (&acc)[8]) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 16);
+    struct Raw { f32x4 a, b; };
+    static __device__ __forceinline__ Raw load(const char* p) {
+        Raw r; r.a = *reinterpret_cast<const f32x4*>(p); r.b = *reinterpret_cast<const f32x4*>(p + 16); return r;
+    }
+    static __device__ __forceinline__ void fma8(const Raw& v, float w, float (&acc)[8]) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { acc[q] = fmaf(w, a[q], acc[q]); acc[4 + q] = fmaf(w, b[q], acc[4 + q]); }
+        for (int q = 0; q < 4; ++q) { acc[q] = fmaf(w, v.a[q], acc[q]); acc[4 + q] = fmaf(w, v.b[q], acc[4 + q]); }
     }
 };
 
 template <typename WT, typename T>
-__global__ __launch_bounds__(256) void encode_csr_kernel(EncCsrArgs a) {
+__global__ __launch_bounds__(ENC_THREADS, 6) void encode_csr_kernel(EncCsrArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if ((int)blockIdx.x == a.label_block) { label_stats_block<256>(a.job, smem); return; }
+    if ((int)blockIdx.x == a.label_block) { label_stats_block<ENC_THREADS>(a.job, smem); return; }
     float* zt = reinterpret_cast<float*>(smem);                          // [ENC_ROWS][64] pre-activations of this slice
     T* ht = reinterpret_cast<T*>(smem + ENC_ROWS * 64 * 4);              // [64][ENC_ROWS] transposed low-precision h
     uint32_t* xb = reinterpret_cast<uint32_t*>(smem + ENC_ROWS * 64 * 4 + 64 * ENC_ROWS * 4);   // [ENC_ROWS][ldxb] clean bit rows
     const int slice = blockIdx.x % a.n_slices, i0 = (blockIdx.x / a.n_slices) * ENC_ROWS;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int r = __builtin_amdgcn_readfirstlane(tid >> 6), i = i0 + r;  // this wave's batch row
     const int sub = lane >> 3, part = lane & 7;
     // side images: task t is produced by the workgroups of slice t % n_slices
     const bool do_xbits = a.x_bits && slice == 0;
     const bool do_xct = a.xct && slice == 1 % a.n_slices;
     const bool do_rowsq = a.rowsq && slice == 2 % a.n_slices;
     if (do_xbits) {
-        for (int k = tid; k < ENC_ROWS * (int)a.ldxb; k += 256) xb[k] = 0u;
+        for (int k = tid; k < ENC_ROWS * (int)a.ldxb; k += ENC_THREADS) xb[k] = 0u;
         __syncthreads();
     }
     const char* Wb = reinterpret_cast<const char*>(a.W) + (int64_t)slice * 64 * sizeof(WT) + part * (8 * sizeof(WT));
-    const int64_t ldw_b = a.ldw * (int64_t)sizeof(WT);
+    const uint32_t ldw_b = (uint32_t)(a.ldw * (int64_t)sizeof(WT));
     T* xct = reinterpret_cast<T*>(a.xct);
-#pragma unroll 1
-    for (int rr = 0; rr < 2; ++rr) {
-        const int r = wave * 2 + rr, i = i0 + r;
-        float acc[8];
+    float acc[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) acc[q] = 0.f;
-        float sq = 0.f;
-        if (i < a.B) {
-            const int64_t row = a.row_idx[i];
-            const int64_t s0 = a.indptr[row], e0 = a.indptr[row + 1];
-            for (int64_t base = s0; base < e0; base += 64) {
-                const int64_t k = base + lane;
+    for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+    float sq = 0.f;
+    if (i < a.B) {
+        const int64_t row = a.row_idx[i];
+        const int64_t s0 = a.indptr[row], e0 = a.indptr[row + 1];
+        for (int64_t base = s0; base < e0; base += 256) {
+            // a lane owns 4 stored entries of the pass (coalesced reads of ids / values / keep decisions, issued together)
+            int col[4]; float vc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t k = base + u * 64 + lane;
                 const bool valid = k < e0;
-                const int col = valid ? a.indices[k] : 0;
+                col[u] = valid ? a.indices[k] : 0;
                 const float v = valid ? (a.values ? a.values[k] : 1.0f) : 0.f;
-                const bool keep = valid && col < a.F && keep_entry(a.corr_mode, a.keep_bits, (uint64_t)k, a.seed, a.stream, a.corr_frac);
-                const float vc = keep ? v * a.scale : 0.f;
-                if (do_xbits && valid && col < a.F) atomicOr(&xb[r * a.ldxb + (col >> 5)], 1u << (col & 31));
-                if (do_xct && keep) xct[(int64_t)col * a.ldt + i] = Elem<T>::from(vc);
+                const bool keep = valid && col[u] < a.F && keep_entry(a.corr_mode, a.keep_bits, (uint64_t)k, a.seed, a.stream, a.corr_frac);
+                vc[u] = keep ? v * a.scale : 0.f;
+                if (do_xbits && valid && col[u] < a.F) atomicOr(&xb[r * a.ldxb + (col[u] >> 5)], 1u << (col[u] & 31));
+                if (do_xct && keep) xct[(int64_t)col[u] * a.ldt + i] = Elem<T>::from(vc[u]);
                 if (do_rowsq) sq += v * v;
-                const int nent = (int)min((int64_t)64, e0 - base);
-                // 8 entries per step (one per 8-lane group); all W-row loads of the pass are issued before the first use
-                int cj[8]; float wj[8];
+            }
+            const int nent = (int)min((int64_t)256, e0 - base);
+            // entries are walked 8 at a time (one per 8-lane group); the 8 W-row loads of a block of 64 are issued back to back
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    cj[j] = __shfl(col, j * 8 + sub, 64);
-                    wj[j] = __shfl(vc, j * 8 + sub, 64);
-                }
+            for (int u = 0; u < 4; ++u) {
+                if (u * 64 < nent) {
+                    typename WRow<WT>::Raw wr[8];
+                    float wj[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    if (j * 8 < nent && wj[j] != 0.f) WRow<WT>::fma8(Wb + (int64_t)cj[j] * ldw_b, wj[j], acc);
+                    for (int j = 0; j < 8; ++j) {
+                        const int cj = __shfl(col[u], j * 8 + sub, 64);
+                        wj[j] = __shfl(vc[u], j * 8 + sub, 64);
+                        wr[j] = WRow<WT>::load(Wb + (uint64_t)((uint32_t)cj * ldw_b));     // dropped / padding entries read row 0 and add 0 * W
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) WRow<WT>::fma8(wr[j], wj[j], acc);
                 }
             }
         }
-        // butterfly over the 8 entry groups (lane bits 3..5); lanes 0..7 (sub == 0) end up with the row's sums
+    }
+    // butterfly over the 8 entry groups (lane bits 3..5); lanes 0..7 (sub == 0) end up with the row's sums
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            float t = acc[q];
-            t += __shfl_xor(t, 8, 64);
-            t += __shfl_xor(t, 16, 64);
-            t += __shfl_xor(t, 32, 64);
-            acc[q] = t;
-        }
-        if (sub == 0) {
+    for (int q = 0; q < 8; ++q) {
+        float t = acc[q];
+        t += __shfl_xor(t, 8, 64);
+        t += __shfl_xor(t, 16, 64);
+        t += __shfl_xor(t, 32, 64);
+        acc[q] = t;
+    }
+    if (sub == 0) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) zt[r * 64 + part * 8 + q] = acc[q];
-        }
-        if (do_rowsq) {
-            sq = wave_sum(sq);
-            if (lane == 0 && i < a.Bp) a.rowsq[i] = (i < a.B) ? sq : 0.f;
-        }
+        for (int q = 0; q < 8; ++q) zt[r * 64 + part * 8 + q] = acc[q];
+    }
+    if (do_rowsq) {
+        sq = wave_sum(sq);
+        if (lane == 0) a.rowsq[i] = (i < a.B) ? sq : 0.f;
     }
     __syncthreads();
-    // ---- epilogue on the [8 rows x 64 columns] tile: thread = (row, column pair) ----
+    // ---- epilogue on the [8 rows x 64 columns] tile: thread = (row, column) ----
     {
-        const int r = tid >> 5, cp = tid & 31, i = i0 + r;
-        float hv[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int cl = cp * 2 + u, col = slice * 64 + cl;
-            const float b = col < a.Hp ? a.bh[col] : 0.f;
-            const float z = zt[r * 64 + cl] + b;
-            hv[u] = (i < a.B && col < a.H) ? act_apply(a.enc_act, z) - act_apply(a.enc_act, b) : 0.f;
-            ht[cl * ENC_ROWS + r] = Elem<T>::from(hv[u]);
-        }
-        const int col0 = slice * 64 + cp * 2;
-        if (a.h_f32) *reinterpret_cast<float2*>(a.h_f32 + (int64_t)i * a.ldh + col0) = make_float2(hv[0], hv[1]);
-        if (a.h_lo) {
-            T* hl = reinterpret_cast<T*>(a.h_lo) + (int64_t)i * a.ldh + col0;
-            hl[0] = Elem<T>::from(hv[0]); hl[1] = Elem<T>::from(hv[1]);
-        }
+        const int cl = lane, col = slice * 64 + cl;
+        const float b = a.bh[col];
+        const float z = zt[r * 64 + cl] + b;
+        const float hv = (i < a.B && col < a.H) ? act_apply(a.enc_act, z) - act_apply(a.enc_act, b) : 0.f;
+        ht[cl * ENC_ROWS + r] = Elem<T>::from(hv);
+        if (a.h_f32) a.h_f32[(int64_t)i * a.ldh + col] = hv;
+        if (a.h_lo) reinterpret_cast<T*>(a.h_lo)[(int64_t)i * a.ldh + col] = Elem<T>::from(hv);
         if (a.hcat_a) {   // split-bf16 operands of the Gram matrix: h = hi + lo, D ~= hi.hi + hi.lo + lo.hi
-            const bf16_t hi0 = f2bf(hv[0]), hi1 = f2bf(hv[1]);
-            const bf16_t lo0 = f2bf(hv[0] - bf2f(hi0)), lo1 = f2bf(hv[1] - bf2f(hi1));
-            const uint32_t hi = (uint32_t)hi0 | ((uint32_t)hi1 << 16), lo = (uint32_t)lo0 | ((uint32_t)lo1 << 16);
-            uint32_t* pa = reinterpret_cast<uint32_t*>(a.hcat_a + (int64_t)i * (3 * a.Hp) + col0);
-            uint32_t* pb = reinterpret_cast<uint32_t*>(a.hcat_b + (int64_t)i * (3 * a.Hp) + col0);
-            pa[0] = hi; pa[a.Hp / 2] = hi; pa[a.Hp] = lo;
-            pb[0] = hi; pb[a.Hp / 2] = lo; pb[a.Hp] = hi;
+            const bf16_t hi = f2bf(hv);
+            const bf16_t lo = f2bf(hv - bf2f(hi));
+            const int64_t o = (int64_t)i * (3 * a.Hp) + col;
+            a.hcat_a[o] = hi; a.hcat_a[o + a.Hp] = hi; a.hcat_a[o + 2 * a.Hp] = lo;
+            a.hcat_b[o] = hi; a.hcat_b[o + a.Hp] = lo; a.hcat_b[o + 2 * a.Hp] = hi;
         }
     }
     __syncthreads();
     if (a.h_t && tid < 64) {                         // h^T: 8 batch columns of one feature row = one 16-byte (bf16) / 32-byte store
         T* dst = reinterpret_cast<T*>(a.h_t) + (int64_t)(slice * 64 + tid) * a.ldht + i0;
         const T* src = ht + tid * ENC_ROWS;
-        if constexpr (sizeof(T) == 2) *reinterpret_cast<i32x4*>(dst) = *reinterpret_cast<const i32x4*>(src);
-        else { *reinterpret_cast<i32x4*>(dst) = *reinterpret_cast<const i32x4*>(src); *reinterpret_cast<i32x4*>(dst + 4) = *reinterpret_cast<const i32x4*>(src + 4); }
+        *reinterpret_cast<i32x4*>(dst) = *reinterpret_cast<const i32x4*>(src);
+        if constexpr (sizeof(T) == 4) *reinterpret_cast<i32x4*>(dst + 4) = *reinterpret_cast<const i32x4*>(src + 4);
     }
     if (do_xbits) {
-        for (int k = tid; k < ENC_ROWS * (int)a.ldxb; k += 256) {
-            const int r = k / (int)a.ldxb, w = k % (int)a.ldxb;
-            a.x_bits[(int64_t)(i0 + r) * a.ldxb + w] = xb[k];
+        for (int k = tid; k < ENC_ROWS * (int)a.ldxb; k += ENC_THREADS) {
+            const int rr = k / (int)a.ldxb, w = k % (int)a.ldxb;
+            a.x_bits[(int64_t)(i0 + rr) * a.ldxb + w] = xb[k];
         }
     }
 }
@@ -393,7 +394,7 @@ int dae::launch_encode_csr(const EncCsrLaunch& q, hipStream_t st) {
     size_t lds = ENC_ROWS * 64 * 4 + 64 * ENC_ROWS * 4 + (q.x_bits ? (size_t)ENC_ROWS * q.ldxb * 4 : 0);
     if (q.label_job && lds < (size_t)LABEL_SMEM_BYTES) lds = LABEL_SMEM_BYTES;
     DAE_CHECK_ARG(lds <= 64 * 1024, "encode_csr: %zu B of LDS for the bit rows of %d features", lds, q.F);
-    dim3 grid(nblk + (q.label_job ? 1 : 0)), block(256);
+    dim3 grid(nblk + (q.label_job ? 1 : 0)), block(ENC_THREADS);
     // element type of the weight image follows the activation type: bf16 shadow W_lo, or the fp32 image in parity mode
     if (q.dtype == DAE_BF16) hipLaunchKernelGGL((encode_csr_kernel<bf16_t, bf16_t>), grid, block, lds, st, a);
     else hipLaunchKernelGGL((encode_csr_kernel<float, float>), grid, block, lds, st, a);

@@ -1370,9 +1370,9 @@ int launch_decode_loss(int dtype, int Bp, int Fp, int Hp, const void* h_lo, int6
 // The workgroup's slice of the bit image (128 rows x 2 words per K tile) is copied into LDS once, before the K loop, so the
 // loop itself issues no ordinary global load (hipcc drains the LDS-DMA queue at every use of one).
 // ------------------------------------------------------------------------------------------------
-constexpr int EB_NST = 4;
 constexpr int eb_slice_stride(int nk) { return 2 * ((nk | 1)); }            // words per row: 2 * odd >= 2 nk -> conflict-free ds_read_b32
-constexpr int eb_lds_bytes(int nk) { return EB_NST * STAGE_BYTES + 128 * eb_slice_stride(nk) * 4; }
+constexpr int eb_lds_bytes(int nst, int nk) { return nst * STAGE_BYTES + 128 * eb_slice_stride(nk) * 4; }
+static int eb_ring_depth(int nk) { return eb_lds_bytes(4, nk) <= 160 * 1024 ? 4 : (eb_lds_bytes(2, nk) <= 160 * 1024 ? 2 : 0); }
 
 struct EncBitsParams {
     const char* Bt; int64_t ldb_b;                    // W^T_lo [Hp x Fp] bf16, leading dimension in bytes
@@ -1380,10 +1380,10 @@ struct EncBitsParams {
     int ktiles_total, tiles_m, tiles_n, splits, nk_max;
 };
 
+template <int NST>
 __global__ __launch_bounds__(PC_THREADS, 1) void gemm_encode_bits_pc(EncBitsParams p, float* __restrict__ C, int64_t ldc, int64_t slab_stride,
                                                                      LabelJob job, int label_block) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    constexpr int NST = EB_NST;
     if ((int)blockIdx.x == label_block) { label_stats_block<PC_THREADS>(job, lds); return; }
     const int id = blockIdx.x;
     const int split = id % p.splits, tile = id / p.splits;          // a K slice stays on one XCD (block b runs on XCD b % 8)
@@ -1462,7 +1462,7 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_encode_bits_pc(EncBitsPara
         __builtin_amdgcn_s_barrier();
         int cur = 0;
         for (int i = 0; i < nk; ++i) {
-            const int ahead = min(NST - 2, nk - 2 - i);                   // stages younger than i+1 already requested
+            const int ahead = min(NST - 2, nk - 2 - i);                   // stages younger than i+1 already requested (4 DMAs each)
             if (ahead >= 2) wait_vm<8>();
             else if (ahead == 1) wait_vm<4>();
             else wait_vm<0>();
@@ -1561,17 +1561,18 @@ int launch_encode_bits(int Bp, int Hp, int Fp, const uint32_t* bits, int64_t ldw
     p.ktiles_total = Fp / 64; p.tiles_m = Bp / BM; p.tiles_n = Hp / BN; p.splits = splits < 1 ? 1 : splits;
     DAE_CHECK_ARG(p.splits <= p.ktiles_total, "encode_bits: too many splits");
     p.nk_max = (p.ktiles_total + p.splits - 1) / p.splits;
-    const int ldsb = eb_lds_bytes(p.nk_max);
+    const int nst = eb_ring_depth(p.nk_max);
     const int grid = p.tiles_m * p.tiles_n * p.splits;
-    DAE_CHECK_ARG(ldsb <= 160 * 1024, "encode_bits: %d K tiles per slice need %d B of LDS (> 160 KiB): raise encode_splits", p.nk_max, ldsb);
-    DAE_CHECK_ARG(grid <= g_cus, "encode_bits: %d workgroups exceed the %d CUs (the 8-wave kernel runs one per CU)", grid, g_cus);
-    static int attr_rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_encode_bits_pc), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    DAE_CHECK_ARG(nst != 0, "encode_bits: %d K tiles per slice do not fit the LDS: raise the number of splits", p.nk_max);
+    const int ldsb = eb_lds_bytes(nst, p.nk_max);
+    static int attr_rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_encode_bits_pc<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) |
+                         (int)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_encode_bits_pc<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     DAE_CHECK_ARG(attr_rc == 0, "encode_bits: hipFuncSetAttribute failed (%d)", attr_rc);
     LabelJob job; memset(&job, 0, sizeof(job));
     const bool with_labels = label_job && label_job->Bp <= 1024 && grid < g_cus;
     if (with_labels) job = *label_job;
-    hipLaunchKernelGGL(gemm_encode_bits_pc, dim3(grid + (with_labels ? 1 : 0)), dim3(PC_THREADS), ldsb, st, p, C, ldc, slab_stride, job,
-                       with_labels ? grid : -1);
+    auto k = nst == 4 ? gemm_encode_bits_pc<4> : gemm_encode_bits_pc<2>;
+    hipLaunchKernelGGL(k, dim3(grid + (with_labels ? 1 : 0)), dim3(PC_THREADS), ldsb, st, p, C, ldc, slab_stride, job, with_labels ? grid : -1);
     DAE_CHECK_LAUNCH();
     if (with_labels && label_done) *label_done = 1;
     return 0;
@@ -1582,7 +1583,7 @@ bool encode_bits_fits(int Bp, int Hp, int Fp, int splits) {
     if (gemm_init()) return false;
     const int kt = Fp / 64;
     if (splits < 1 || splits > kt || Fp % 64 || Bp % BM || Hp % BN) return false;
-    return (Bp / BM) * (Hp / BN) * splits <= g_cus && eb_lds_bytes((kt + splits - 1) / splits) <= 160 * 1024;
+    return (Bp / BM) * (Hp / BN) * splits <= g_cus && eb_ring_depth((kt + splits - 1) / splits) == 4;
 }
 
 int launch_gemm_trace(int dtype, int M, int N, const void* A0, int64_t lda0, const void* Bt0, int64_t ldb0, int K0, const void* A1,
