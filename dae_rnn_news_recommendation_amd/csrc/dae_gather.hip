@@ -213,7 +213,7 @@ template <> struct WRow<float> {                // 64 columns = 256 B: lane part
 };
 
 template <typename WT, typename T>
-__global__ __launch_bounds__(ENC_THREADS, 6) void encode_csr_kernel(EncCsrArgs a) {
+__global__ __launch_bounds__(ENC_THREADS, 4) void encode_csr_kernel(EncCsrArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if ((int)blockIdx.x == a.label_block) { label_stats_block<ENC_THREADS>(a.job, smem); return; }
     float* zt = reinterpret_cast<float*>(smem);                          // [ENC_ROWS][64] pre-activations of this slice
@@ -242,35 +242,58 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void encode_csr_kernel(EncCsrArgs a
         const int64_t row = a.row_idx[i];
         const int64_t s0 = a.indptr[row], e0 = a.indptr[row + 1];
         for (int64_t base = s0; base < e0; base += 256) {
-            // a lane owns 4 stored entries of the pass (coalesced reads of ids / values / keep decisions, issued together)
-            int col[4]; float vc[4];
+            // a lane owns 4 stored entries of the pass.  All reads (ids, values, keep words) are issued UNCONDITIONALLY on clamped
+            // addresses, group by group, so that they are in flight together: a per-entry branch around a load makes hipcc wait
+            // vmcnt(0) per entry, i.e. four dependent L2 round trips instead of one.
+            int col[4]; float vc[4], vv[4];
+            int64_t kc[4];
+            uint32_t kw[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int64_t k = base + u * 64 + lane;
-                const bool valid = k < e0;
-                col[u] = valid ? a.indices[k] : 0;
-                const float v = valid ? (a.values ? a.values[k] : 1.0f) : 0.f;
-                const bool keep = valid && col[u] < a.F && keep_entry(a.corr_mode, a.keep_bits, (uint64_t)k, a.seed, a.stream, a.corr_frac);
+                kc[u] = min(base + u * 64 + lane, e0 - 1);
+                col[u] = a.indices[kc[u]];
+            }
+            if (a.values) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) vv[u] = a.values[kc[u]];
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) vv[u] = 1.0f;
+            }
+            if (a.corr_mode == DAE_CORR_KEEPBITS) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) kw[u] = a.keep_bits[kc[u] >> 5];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool valid = base + u * 64 + lane < e0 && col[u] < a.F;
+                bool keep = valid;
+                if (a.corr_mode == DAE_CORR_KEEPBITS) keep = valid && ((kw[u] >> (kc[u] & 31)) & 1u);
+                else if (a.corr_mode == DAE_CORR_PHILOX_MASK) keep = valid && philox_uniform((uint64_t)kc[u], a.seed, a.stream) >= a.corr_frac;
+                const float v = valid ? vv[u] : 0.f;
                 vc[u] = keep ? v * a.scale : 0.f;
-                if (do_xbits && valid && col[u] < a.F) atomicOr(&xb[r * a.ldxb + (col[u] >> 5)], 1u << (col[u] & 31));
+                if (!valid) col[u] = 0;
+                if (do_xbits && valid) atomicOr(&xb[r * a.ldxb + (col[u] >> 5)], 1u << (col[u] & 31));
                 if (do_xct && keep) xct[(int64_t)col[u] * a.ldt + i] = Elem<T>::from(vc[u]);
                 if (do_rowsq) sq += v * v;
             }
             const int nent = (int)min((int64_t)256, e0 - base);
-            // entries are walked 8 at a time (one per 8-lane group); the 8 W-row loads of a block of 64 are issued back to back
+            // entries are walked 8 at a time (one per 8-lane group); the 16 W-row loads of two blocks of 64 entries are issued
+            // back to back (16 KiB per wave in flight: the kernel is bound by L2 latency x bytes in flight, not by issue rate)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (u * 64 < nent) {
-                    typename WRow<WT>::Raw wr[8];
-                    float wj[8];
+            for (int u2 = 0; u2 < 4; u2 += 2) {
+                if (u2 * 64 < nent) {
+                    typename WRow<WT>::Raw wr[16];
+                    float wj[16];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int cj = __shfl(col[u], j * 8 + sub, 64);
-                        wj[j] = __shfl(vc[u], j * 8 + sub, 64);
+                    for (int j = 0; j < 16; ++j) {
+                        const int u = u2 + (j >> 3), src = (j & 7) * 8 + sub;
+                        const int cj = __shfl(col[u], src, 64);
+                        wj[j] = __shfl(vc[u], src, 64);
                         wr[j] = WRow<WT>::load(Wb + (uint64_t)((uint32_t)cj * ldw_b));     // dropped / padding entries read row 0 and add 0 * W
                     }
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) WRow<WT>::fma8(wr[j], wj[j], acc);
+                    for (int j = 0; j < 16; ++j) WRow<WT>::fma8(wr[j], wj[j], acc);
                 }
             }
         }
