@@ -192,6 +192,7 @@ constexpr int ENC_THREADS = 64 * ENC_ROWS;
 template <typename WT> struct WRow;
 template <> struct WRow<bf16_t> {               // 64 columns = 128 B: lane part reads 16 B = 8 bf16
     typedef i32x4 Raw;
+    static constexpr int BATCH = 9;            // W-row loads in flight per lane (4 VGPRs each)
     static __device__ __forceinline__ Raw load(const char* p) { return *reinterpret_cast<const i32x4*>(p); }
     static __device__ __forceinline__ void fma8(const Raw& v, float w, float (&acc)[8]) {
 #pragma unroll
@@ -203,6 +204,7 @@ template <> struct WRow<bf16_t> {               // 64 columns = 128 B: lane part
 };
 template <> struct WRow<float> {                // 64 columns = 256 B: lane part reads 32 B = 8 fp32
     struct Raw { f32x4 a, b; };
+    static constexpr int BATCH = 5;               // 8 VGPRs each
     static __device__ __forceinline__ Raw load(const char* p) {
         Raw r; r.a = *reinterpret_cast<const f32x4*>(p); r.b = *reinterpret_cast<const f32x4*>(p + 16); return r;
     }
@@ -213,12 +215,13 @@ template <> struct WRow<float> {                // 64 columns = 256 B: lane part
 };
 
 template <typename WT, typename T>
-__global__ __launch_bounds__(ENC_THREADS, 4) void encode_csr_kernel(EncCsrArgs a) {
+__global__ __launch_bounds__(ENC_THREADS, 6) void encode_csr_kernel(EncCsrArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if ((int)blockIdx.x == a.label_block) { label_stats_block<ENC_THREADS>(a.job, smem); return; }
     float* zt = reinterpret_cast<float*>(smem);                          // [ENC_ROWS][64] pre-activations of this slice
     T* ht = reinterpret_cast<T*>(smem + ENC_ROWS * 64 * 4);              // [64][ENC_ROWS] transposed low-precision h
-    uint32_t* xb = reinterpret_cast<uint32_t*>(smem + ENC_ROWS * 64 * 4 + 64 * ENC_ROWS * 4);   // [ENC_ROWS][ldxb] clean bit rows
+    int2* const lists = reinterpret_cast<int2*>(smem + ENC_ROWS * 64 * 4 + 64 * ENC_ROWS * 4);   // [ENC_ROWS][256] kept (column, value) of a pass
+    uint32_t* xb = reinterpret_cast<uint32_t*>(smem + ENC_ROWS * 64 * 4 + 64 * ENC_ROWS * 4 + ENC_ROWS * 256 * 8);   // [ENC_ROWS][ldxb] clean bit rows
     const int slice = blockIdx.x % a.n_slices, i0 = (blockIdx.x / a.n_slices) * ENC_ROWS;
     const int tid = threadIdx.x, lane = tid & 63;
     const int r = __builtin_amdgcn_readfirstlane(tid >> 6), i = i0 + r;  // this wave's batch row
@@ -234,6 +237,7 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void encode_csr_kernel(EncCsrArgs a
     const char* Wb = reinterpret_cast<const char*>(a.W) + (int64_t)slice * 64 * sizeof(WT) + part * (8 * sizeof(WT));
     const uint32_t ldw_b = (uint32_t)(a.ldw * (int64_t)sizeof(WT));
     T* xct = reinterpret_cast<T*>(a.xct);
+    int2* const mylist = lists + r * 256;
     float acc[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) acc[q] = 0.f;
@@ -277,24 +281,32 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void encode_csr_kernel(EncCsrArgs a
                 if (do_xct && keep) xct[(int64_t)col[u] * a.ldt + i] = Elem<T>::from(vc[u]);
                 if (do_rowsq) sq += v * v;
             }
-            const int nent = (int)min((int64_t)256, e0 - base);
-            // entries are walked 8 at a time (one per 8-lane group); the 16 W-row loads of two blocks of 64 entries are issued
-            // back to back (16 KiB per wave in flight: the kernel is bound by L2 latency x bytes in flight, not by issue rate)
+            // compact the KEPT entries of the pass into this wave's LDS list (ballot ranks: storage order is preserved, so the
+            // summation order -- and the result -- is deterministic); dropped and padding entries cost no W-row read
+            int nkept = 0;
 #pragma unroll
-            for (int u2 = 0; u2 < 4; u2 += 2) {
-                if (u2 * 64 < nent) {
-                    typename WRow<WT>::Raw wr[16];
-                    float wj[16];
+            for (int u = 0; u < 4; ++u) {
+                const bool kp = vc[u] != 0.f;
+                const unsigned long long m = __ballot(kp);
+                if (kp) mylist[nkept + __popcll(m & ((1ull << lane) - 1ull))] = make_int2(col[u], __float_as_int(vc[u]));
+                nkept += __popcll(m);
+            }
+            // walk the list 8 entries at a time (one per 8-lane group): lane (sub, part) reads 16 bytes (part) of the W row of
+            // entry `sub`; BATCH W-row loads (10 KiB per wave) are issued back to back before the first use
+            constexpr int NB = WRow<WT>::BATCH;
+            for (int t0 = 0; t0 * 8 < nkept; t0 += NB) {
+                typename WRow<WT>::Raw wr[NB];
+                float wj[NB];
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) {
-                        const int u = u2 + (j >> 3), src = (j & 7) * 8 + sub;
-                        const int cj = __shfl(col[u], src, 64);
-                        wj[j] = __shfl(vc[u], src, 64);
-                        wr[j] = WRow<WT>::load(Wb + (uint64_t)((uint32_t)cj * ldw_b));     // dropped / padding entries read row 0 and add 0 * W
-                    }
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) WRow<WT>::fma8(wr[j], wj[j], acc);
+                for (int j = 0; j < NB; ++j) {
+                    const int e = (t0 + j) * 8 + sub;
+                    const int2 cw = mylist[min(e, 255)];
+                    const bool on = e < nkept;
+                    wj[j] = on ? __int_as_float(cw.y) : 0.f;
+                    wr[j] = WRow<WT>::load(Wb + (uint64_t)((uint32_t)(on ? cw.x : 0) * ldw_b));
                 }
+#pragma unroll
+                for (int j = 0; j < NB; ++j) WRow<WT>::fma8(wr[j], wj[j], acc);
             }
         }
     }
@@ -414,7 +426,7 @@ int dae::launch_encode_csr(const EncCsrLaunch& q, hipStream_t st) {
     const int nblk = a.n_slices * (Bp / ENC_ROWS);
     a.label_block = q.label_job ? nblk : -1;
     if (q.label_job) a.job = *q.label_job;
-    size_t lds = ENC_ROWS * 64 * 4 + 64 * ENC_ROWS * 4 + (q.x_bits ? (size_t)ENC_ROWS * q.ldxb * 4 : 0);
+    size_t lds = ENC_ROWS * 64 * 4 + 64 * ENC_ROWS * 4 + ENC_ROWS * 256 * 8 + (q.x_bits ? (size_t)ENC_ROWS * q.ldxb * 4 : 0);
     if (q.label_job && lds < (size_t)LABEL_SMEM_BYTES) lds = LABEL_SMEM_BYTES;
     DAE_CHECK_ARG(lds <= 64 * 1024, "encode_csr: %zu B of LDS for the bit rows of %d features", lds, q.F);
     dim3 grid(nblk + (q.label_job ? 1 : 0)), block(ENC_THREADS);
