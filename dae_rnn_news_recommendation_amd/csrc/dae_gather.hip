@@ -159,14 +159,14 @@ __global__ __launch_bounds__(256) void gather_dense_kernel(
 //     h[i, :] = act( sum_{e in row(i), kept(e)} scale * v_e * W[col_e, :] + b_h ) - act(b_h)
 // The dense [B x F] image of x~ is never formed: a batch row holds ~200 of 10^4 features, so the kernel sums ~140 rows
 // of W per batch row (0.11 GFLOP instead of the 8 GFLOP of the dense contraction) and is bound by the L2 -> VGPR rate of
-// those W-row reads, not by MFMA.  Decomposition for the L2: the H columns are cut into slices of 64 (128 bytes of a bf16 W
-// row); block b works on slice b % n_slices, and the dispatcher places block b on XCD b % 8, so with 8 slices every XCD
-// re-reads only ITS 1.3 MB column slice of W_lo from its private 4 MiB L2 (placement affects speed only).
-// Work split: one workgroup = 8 batch rows x one slice, 2 rows per wave.  A lane owns one stored entry of the row
-// (coalesced index / value / keep-decision reads, 64 entries per pass); entries are then walked 8 at a time: lane (sub, part)
-// loads 16 bytes (part) of the W row of entry `sub`, so one wave instruction fetches 8 W-row slices (1 KiB) and 8 of them are
-// in flight per lane.  Per-lane fp32 accumulators (8 columns), one butterfly over the 8 entry groups at the end of the row,
-// fixed order -> deterministic.  Epilogue: bias, activation, and every image of h the step needs (fp32, low precision, h^T
+// those W-row reads, not by MFMA.  Decomposition for the L2: the H columns are cut into slices of 128 (256 bytes of a bf16 W
+// row); block b works on slice b % n_slices, and the dispatcher places block b on XCD b % 8, so with 4 slices every XCD
+// re-reads only ITS 2.6 MB column slice of W_lo from its private 4 MiB L2 (placement affects speed only).
+// Work split: one workgroup = 8 batch rows x one slice, one row per wave (448 workgroups at B = 800, H = 500: one resident
+// round on 256 CUs).  A lane owns stored entries of the row (coalesced id / value / keep-decision reads, 256 entries per pass);
+// the kept ones are compacted into an LDS list and walked 4 at a time: lane (sub, part) loads 16 bytes (part) of the W-row
+// slice of entry `sub`, so one wave instruction fetches 4 W-row slices (1 KiB) and 18 of them are in flight per lane.  Per-lane
+// fp32 accumulators (8 columns), one butterfly over the 4 entry groups at the end of the row, fixed order -> deterministic.  Epilogue: bias, activation, and every image of h the step needs (fp32, low precision, h^T
 // via an LDS transpose, split-bf16 Gram operands).
 // The workgroups of a row group also produce the batch's side images, one task per slice: the bit image of the CLEAN rows
 // (decode epilogue), the scatter of kept entries into x~^T (dW GEMM operand), sum of squares (cosine_proximity).
@@ -188,11 +188,12 @@ struct EncCsrArgs {
 
 constexpr int ENC_ROWS = 8;                     // batch rows per workgroup: one per wave (8 waves = 512 threads)
 constexpr int ENC_THREADS = 64 * ENC_ROWS;
+constexpr int ENC_COLS = 128;                   // H columns per workgroup ("slice": 256 B of a bf16 W row, two cache lines)
 
 template <typename WT> struct WRow;
-template <> struct WRow<bf16_t> {               // 64 columns = 128 B: lane part reads 16 B = 8 bf16
+template <> struct WRow<bf16_t> {               // 128 columns = 256 B: lane part (0..15) reads 16 B = 8 bf16
     typedef i32x4 Raw;
-    static constexpr int BATCH = 9;            // W-row loads in flight per lane (4 VGPRs each)
+    static constexpr int BATCH = 18;              // W-row loads in flight per lane (4 VGPRs each)
     static __device__ __forceinline__ Raw load(const char* p) { return *reinterpret_cast<const i32x4*>(p); }
     static __device__ __forceinline__ void fma8(const Raw& v, float w, float (&acc)[8]) {
 #pragma unroll
@@ -202,9 +203,9 @@ template <> struct WRow<bf16_t> {               // 64 columns = 128 B: lane part
         }
     }
 };
-template <> struct WRow<float> {                // 64 columns = 256 B: lane part reads 32 B = 8 fp32
+template <> struct WRow<float> {                // 128 columns = 512 B: lane part reads 32 B = 8 fp32
     struct Raw { f32x4 a, b; };
-    static constexpr int BATCH = 5;               // 8 VGPRs each
+    static constexpr int BATCH = 9;               // 8 VGPRs each
     static __device__ __forceinline__ Raw load(const char* p) {
         Raw r; r.a = *reinterpret_cast<const f32x4*>(p); r.b = *reinterpret_cast<const f32x4*>(p + 16); return r;
     }
@@ -215,17 +216,17 @@ template <> struct WRow<float> {                // 64 columns = 256 B: lane part
 };
 
 template <typename WT, typename T>
-__global__ __launch_bounds__(ENC_THREADS, 6) void encode_csr_kernel(EncCsrArgs a) {
+__global__ __launch_bounds__(ENC_THREADS, 4) void encode_csr_kernel(EncCsrArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if ((int)blockIdx.x == a.label_block) { label_stats_block<ENC_THREADS>(a.job, smem); return; }
-    float* zt = reinterpret_cast<float*>(smem);                          // [ENC_ROWS][64] pre-activations of this slice
-    T* ht = reinterpret_cast<T*>(smem + ENC_ROWS * 64 * 4);              // [64][ENC_ROWS] transposed low-precision h
-    int2* const lists = reinterpret_cast<int2*>(smem + ENC_ROWS * 64 * 4 + 64 * ENC_ROWS * 4);   // [ENC_ROWS][256] kept (column, value) of a pass
-    uint32_t* xb = reinterpret_cast<uint32_t*>(smem + ENC_ROWS * 64 * 4 + 64 * ENC_ROWS * 4 + ENC_ROWS * 256 * 8);   // [ENC_ROWS][ldxb] clean bit rows
+    float* zt = reinterpret_cast<float*>(smem);                                           // [ENC_ROWS][128] pre-activations of this slice
+    T* ht = reinterpret_cast<T*>(smem + ENC_ROWS * ENC_COLS * 4);                         // [128][ENC_ROWS] transposed low-precision h
+    int2* const lists = reinterpret_cast<int2*>(smem + 2 * ENC_ROWS * ENC_COLS * 4);      // [ENC_ROWS][256] kept (column, value) of a pass
+    uint32_t* xb = reinterpret_cast<uint32_t*>(smem + 2 * ENC_ROWS * ENC_COLS * 4 + ENC_ROWS * 256 * 8);   // [ENC_ROWS][ldxb] clean bit rows
     const int slice = blockIdx.x % a.n_slices, i0 = (blockIdx.x / a.n_slices) * ENC_ROWS;
     const int tid = threadIdx.x, lane = tid & 63;
     const int r = __builtin_amdgcn_readfirstlane(tid >> 6), i = i0 + r;  // this wave's batch row
-    const int sub = lane >> 3, part = lane & 7;
+    const int sub = lane >> 4, part = lane & 15;                         // 4 entries per load instruction, 16 x 16 B per W-row slice
     // side images: task t is produced by the workgroups of slice t % n_slices
     const bool do_xbits = a.x_bits && slice == 0;
     const bool do_xct = a.xct && slice == 1 % a.n_slices;
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void encode_csr_kernel(EncCsrArgs a
         for (int k = tid; k < ENC_ROWS * (int)a.ldxb; k += ENC_THREADS) xb[k] = 0u;
         __syncthreads();
     }
-    const char* Wb = reinterpret_cast<const char*>(a.W) + (int64_t)slice * 64 * sizeof(WT) + part * (8 * sizeof(WT));
+    const char* Wb = reinterpret_cast<const char*>(a.W) + (int64_t)slice * ENC_COLS * sizeof(WT) + part * (8 * sizeof(WT));
     const uint32_t ldw_b = (uint32_t)(a.ldw * (int64_t)sizeof(WT));
     T* xct = reinterpret_cast<T*>(a.xct);
     int2* const mylist = lists + r * 256;
@@ -242,7 +243,12 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void encode_csr_kernel(EncCsrArgs a
 #pragma unroll
     for (int q = 0; q < 8; ++q) acc[q] = 0.f;
     float sq = 0.f;
-    if (i < a.B) {
+#ifdef DAE_ENC_PROBE
+    const bool probe_skip_rows = (DAE_ENC_PROBE & 2) != 0;              // probe: no entry phase at all
+#else
+    const bool probe_skip_rows = false;
+#endif
+    if (i < a.B && !probe_skip_rows) {
         const int64_t row = a.row_idx[i];
         const int64_t s0 = a.indptr[row], e0 = a.indptr[row + 1];
         for (int64_t base = s0; base < e0; base += 256) {
@@ -268,6 +274,10 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void encode_csr_kernel(EncCsrArgs a
 #pragma unroll
                 for (int u = 0; u < 4; ++u) kw[u] = a.keep_bits[kc[u] >> 5];
             }
+            // keep decisions, side images, and compaction of the KEPT entries into this wave's LDS list (ballot ranks: storage
+            // order is preserved, so the summation order -- and the result -- is deterministic); dropped and padding entries
+            // cost no W-row read
+            int nkept = 0;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const bool valid = base + u * 64 + lane < e0 && col[u] < a.F;
@@ -275,31 +285,27 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void encode_csr_kernel(EncCsrArgs a
                 if (a.corr_mode == DAE_CORR_KEEPBITS) keep = valid && ((kw[u] >> (kc[u] & 31)) & 1u);
                 else if (a.corr_mode == DAE_CORR_PHILOX_MASK) keep = valid && philox_uniform((uint64_t)kc[u], a.seed, a.stream) >= a.corr_frac;
                 const float v = valid ? vv[u] : 0.f;
-                vc[u] = keep ? v * a.scale : 0.f;
-                if (!valid) col[u] = 0;
+                const float w = keep ? v * a.scale : 0.f;
                 if (do_xbits && valid) atomicOr(&xb[r * a.ldxb + (col[u] >> 5)], 1u << (col[u] & 31));
-                if (do_xct && keep) xct[(int64_t)col[u] * a.ldt + i] = Elem<T>::from(vc[u]);
+                if (do_xct && keep) xct[(int64_t)col[u] * a.ldt + i] = Elem<T>::from(w);
                 if (do_rowsq) sq += v * v;
-            }
-            // compact the KEPT entries of the pass into this wave's LDS list (ballot ranks: storage order is preserved, so the
-            // summation order -- and the result -- is deterministic); dropped and padding entries cost no W-row read
-            int nkept = 0;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const bool kp = vc[u] != 0.f;
+                const bool kp = w != 0.f;
                 const unsigned long long m = __ballot(kp);
-                if (kp) mylist[nkept + __popcll(m & ((1ull << lane) - 1ull))] = make_int2(col[u], __float_as_int(vc[u]));
+                if (kp) mylist[nkept + __popcll(m & ((1ull << lane) - 1ull))] = make_int2(col[u], __float_as_int(w));
                 nkept += __popcll(m);
             }
-            // walk the list 8 entries at a time (one per 8-lane group): lane (sub, part) reads 16 bytes (part) of the W row of
-            // entry `sub`; BATCH W-row loads (10 KiB per wave) are issued back to back before the first use
+#ifdef DAE_ENC_PROBE
+            if (DAE_ENC_PROBE & 1) nkept = 0;                            // probe: no W-row reads
+#endif
+            // walk the list 4 entries at a time (one per 16-lane group): lane (sub, part) reads 16 bytes (part) of the W-row slice
+            // of entry `sub`; BATCH loads (1 KiB each per wave) are issued back to back before the first use
             constexpr int NB = WRow<WT>::BATCH;
-            for (int t0 = 0; t0 * 8 < nkept; t0 += NB) {
+            for (int t0 = 0; t0 * 4 < nkept; t0 += NB) {
                 typename WRow<WT>::Raw wr[NB];
                 float wj[NB];
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
-                    const int e = (t0 + j) * 8 + sub;
+                    const int e = (t0 + j) * 4 + sub;
                     const int2 cw = mylist[min(e, 255)];
                     const bool on = e < nkept;
                     wj[j] = on ? __int_as_float(cw.y) : 0.f;
@@ -310,44 +316,57 @@ __global__ __launch_bounds__(ENC_THREADS, 6) void encode_csr_kernel(EncCsrArgs a
             }
         }
     }
-    // butterfly over the 8 entry groups (lane bits 3..5); lanes 0..7 (sub == 0) end up with the row's sums
+    // butterfly over the 4 entry groups (lane bits 4, 5); lanes 0..15 (sub == 0) end up with the row's sums
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         float t = acc[q];
-        t += __shfl_xor(t, 8, 64);
         t += __shfl_xor(t, 16, 64);
         t += __shfl_xor(t, 32, 64);
         acc[q] = t;
     }
     if (sub == 0) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) zt[r * 64 + part * 8 + q] = acc[q];
+        for (int q = 0; q < 8; ++q) zt[r * ENC_COLS + part * 8 + q] = acc[q];
     }
     if (do_rowsq) {
         sq = wave_sum(sq);
         if (lane == 0) a.rowsq[i] = (i < a.B) ? sq : 0.f;
     }
     __syncthreads();
-    // ---- epilogue on the [8 rows x 64 columns] tile: thread = (row, column) ----
+    // ---- epilogue on the [8 rows x 128 columns] tile: thread = (row, column pair) ----
+#ifdef DAE_ENC_PROBE
+    if (DAE_ENC_PROBE & 4) return;                                       // probe: no epilogue
+#endif
     {
-        const int cl = lane, col = slice * 64 + cl;
-        const float b = a.bh[col];
-        const float z = zt[r * 64 + cl] + b;
-        const float hv = (i < a.B && col < a.H) ? act_apply(a.enc_act, z) - act_apply(a.enc_act, b) : 0.f;
-        ht[cl * ENC_ROWS + r] = Elem<T>::from(hv);
-        if (a.h_f32) a.h_f32[(int64_t)i * a.ldh + col] = hv;
-        if (a.h_lo) reinterpret_cast<T*>(a.h_lo)[(int64_t)i * a.ldh + col] = Elem<T>::from(hv);
+        float hv[2];
+        const int col0 = slice * ENC_COLS + lane * 2;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int cl = lane * 2 + u, col = col0 + u;
+            const float b = a.bh[col];
+            const float z = zt[r * ENC_COLS + cl] + b;
+            hv[u] = (i < a.B && col < a.H) ? act_apply(a.enc_act, z) - act_apply(a.enc_act, b) : 0.f;
+            ht[cl * ENC_ROWS + r] = Elem<T>::from(hv[u]);
+        }
+        if (a.h_f32) *reinterpret_cast<float2*>(a.h_f32 + (int64_t)i * a.ldh + col0) = make_float2(hv[0], hv[1]);
+        if (a.h_lo) {
+            T* hl = reinterpret_cast<T*>(a.h_lo) + (int64_t)i * a.ldh + col0;
+            if constexpr (sizeof(T) == 2) *reinterpret_cast<uint32_t*>(hl) = (uint32_t)f2bf(hv[0]) | ((uint32_t)f2bf(hv[1]) << 16);
+            else { hl[0] = Elem<T>::from(hv[0]); hl[1] = Elem<T>::from(hv[1]); }
+        }
         if (a.hcat_a) {   // split-bf16 operands of the Gram matrix: h = hi + lo, D ~= hi.hi + hi.lo + lo.hi
-            const bf16_t hi = f2bf(hv);
-            const bf16_t lo = f2bf(hv - bf2f(hi));
-            const int64_t o = (int64_t)i * (3 * a.Hp) + col;
-            a.hcat_a[o] = hi; a.hcat_a[o + a.Hp] = hi; a.hcat_a[o + 2 * a.Hp] = lo;
-            a.hcat_b[o] = hi; a.hcat_b[o + a.Hp] = lo; a.hcat_b[o + 2 * a.Hp] = hi;
+            const bf16_t hi0 = f2bf(hv[0]), hi1 = f2bf(hv[1]);
+            const bf16_t lo0 = f2bf(hv[0] - bf2f(hi0)), lo1 = f2bf(hv[1] - bf2f(hi1));
+            const uint32_t hi = (uint32_t)hi0 | ((uint32_t)hi1 << 16), lo = (uint32_t)lo0 | ((uint32_t)lo1 << 16);
+            uint32_t* pa = reinterpret_cast<uint32_t*>(a.hcat_a + (int64_t)i * (3 * a.Hp) + col0);
+            uint32_t* pb = reinterpret_cast<uint32_t*>(a.hcat_b + (int64_t)i * (3 * a.Hp) + col0);
+            pa[0] = hi; pa[a.Hp / 2] = hi; pa[a.Hp] = lo;
+            pb[0] = hi; pb[a.Hp / 2] = lo; pb[a.Hp] = hi;
         }
     }
     __syncthreads();
-    if (a.h_t && tid < 64) {                         // h^T: 8 batch columns of one feature row = one 16-byte (bf16) / 32-byte store
-        T* dst = reinterpret_cast<T*>(a.h_t) + (int64_t)(slice * 64 + tid) * a.ldht + i0;
+    if (a.h_t && tid < ENC_COLS) {                   // h^T: 8 batch columns of one feature row = one 16-byte (bf16) / 32-byte store
+        T* dst = reinterpret_cast<T*>(a.h_t) + (int64_t)(slice * ENC_COLS + tid) * a.ldht + i0;
         const T* src = ht + tid * ENC_ROWS;
         *reinterpret_cast<i32x4*>(dst) = *reinterpret_cast<const i32x4*>(src);
         if constexpr (sizeof(T) == 4) *reinterpret_cast<i32x4*>(dst + 4) = *reinterpret_cast<const i32x4*>(src + 4);
@@ -422,11 +441,11 @@ int dae::launch_encode_csr(const EncCsrLaunch& q, hipStream_t st) {
     a.corr_mode = q.corr_mode; a.keep_bits = q.keep_bits; a.seed = q.seed; a.stream = q.rng_stream; a.corr_frac = q.corr_frac; a.scale = q.scale;
     a.enc_act = q.enc_act; a.h_f32 = q.h_f32; a.h_lo = q.h_lo; a.ldh = q.ldh; a.h_t = q.h_t; a.ldht = q.ldht;
     a.hcat_a = (bf16_t*)q.hcat_a; a.hcat_b = (bf16_t*)q.hcat_b; a.x_bits = q.x_bits; a.ldxb = q.ldxb; a.xct = q.xct; a.ldt = q.ldt;
-    a.rowsq = q.rowsq; a.n_slices = Hp / 64;
+    a.rowsq = q.rowsq; a.n_slices = Hp / ENC_COLS;
     const int nblk = a.n_slices * (Bp / ENC_ROWS);
     a.label_block = q.label_job ? nblk : -1;
     if (q.label_job) a.job = *q.label_job;
-    size_t lds = ENC_ROWS * 64 * 4 + 64 * ENC_ROWS * 4 + ENC_ROWS * 256 * 8 + (q.x_bits ? (size_t)ENC_ROWS * q.ldxb * 4 : 0);
+    size_t lds = 2 * ENC_ROWS * ENC_COLS * 4 + ENC_ROWS * 256 * 8 + (q.x_bits ? (size_t)ENC_ROWS * q.ldxb * 4 : 0);
     if (q.label_job && lds < (size_t)LABEL_SMEM_BYTES) lds = LABEL_SMEM_BYTES;
     DAE_CHECK_ARG(lds <= 64 * 1024, "encode_csr: %zu B of LDS for the bit rows of %d features", lds, q.F);
     dim3 grid(nblk + (q.label_job ? 1 : 0)), block(ENC_THREADS);

@@ -15,8 +15,12 @@ ap.add_argument("--features", type=int, default=10000); ap.add_argument("--hidde
 ap.add_argument("--batch", type=int, default=800); ap.add_argument("--loss", default="cross_entropy")
 ap.add_argument("--enc-splits", type=int, default=0); ap.add_argument("--tag", default="")
 ap.add_argument("--nst", type=int, default=-1); ap.add_argument("--phase", type=int, default=3); ap.add_argument("--gram-splits", type=int, default=0)
+ap.add_argument("--corr", default="philox", choices=["philox", "bits", "none"])
 ap.add_argument("--opt", action="append", default=[], help="plan option name=value (dae_plan_set_option), repeatable")
+ap.add_argument("--lib", default="", help="alternative libdae_hip build (probe variants; tools only)")
 a = ap.parse_args()
+if a.lib:
+    L.LIB_PATH = os.path.abspath(a.lib)
 if a.nst >= 0:
     L.load().dae_set_glds(a.nst)
 m = synthetic_csr(a.rows, a.features, seed=1); lab = synthetic_labels(a.rows, seed=1).astype(np.int32)
@@ -28,6 +32,12 @@ eng.upload_csr(m); eng.set_params(xavier_uniform(a.features, a.hidden))
 idx = torch.arange(a.batch, dtype=torch.int32, device="cuda"); labs = torch.from_numpy(lab[:a.batch]).cuda()
 stats = torch.zeros(8, device="cuda")
 kw = dict(corr_mode=L.CORR_PHILOX_MASK, seed=1, rng_stream=0, corr_frac=0.3)
+if a.corr == "none":
+    kw = dict()
+elif a.corr == "bits":
+    keep = np.random.default_rng(0).random(m.nnz) >= 0.3
+    kb = np.packbits(keep, bitorder="little"); kb = np.concatenate([kb, np.zeros((-len(kb)) % 4, np.uint8)]).view(np.int32)
+    kw = dict(corr_mode=L.CORR_KEEPBITS, keep_bits=torch.from_numpy(kb.copy()).cuda())
 for _ in range(5):
     eng.train_step(idx, labs if a.strategy != "none" else None, stats, phase=a.phase, **kw)
 torch.cuda.synchronize()
@@ -36,6 +46,6 @@ for _ in range(a.steps):
     eng.train_step(idx, labs if a.strategy != "none" else None, stats, phase=a.phase, **kw)
 prof = eng.profile_read(); eng.profile(False)
 tot = sum(ms for ms, n in prof.values())
-print(f"== nst={a.nst} {a.tag} {a.opt} {a.strategy} {a.precision} total {1e3*tot/a.steps:.1f} us/step  info={eng.info()}")
+print(f"== corr={a.corr} {a.tag} {a.opt} {a.strategy} {a.precision} total {1e3*tot/a.steps:.1f} us/step  info={eng.info()}")
 for k, (ms, n) in prof.items():
     if n: print(f"   {k:18s} {1e3*ms/n:9.1f} us  x{n/a.steps:.0f}")
