@@ -95,6 +95,11 @@ SIGNATURES = {
     "dae_plan_set_option": (i32, [vp, C.c_char_p, i32]),
     "dae_train_step": (i32, [vp, C.POINTER(dae_step), vp]),
     "dae_plan_apply": (i32, [vp, i32, f32, vp]),
+    "dae_plan_apply_rows": (i32, [vp, i32, f32, vp, i32, i32, i32, vp]),
+    "dae_plan_refresh_wt": (i32, [vp, vp]),
+    "dae_opt_step_rows": (i32, [i32, f32, f32, f32, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
+    "dae_opt_bias": (i32, [i32, f32, f32, f32, vp, vp, vp, vp, vp, i32, i32, vp]),
+    "dae_transpose_shadow": (i32, [vp, i32, i32, i32, vp, vp]),
     "dae_encode_rows": (i32, [vp, vp, i32, f32, vp, vp, vp, vp, i64, vp, i64, vp]),
     "dae_plan_buffer": (vp, [vp, C.c_char_p]),
     "dae_plan_info": (i32, [vp, vp]),

@@ -42,7 +42,7 @@ class DenoisingAutoencoder(object):
                  xavier_init=1, opt='gradient_descent', learning_rate=0.01, momentum=0.5, corr_type='none',
                  corr_frac=0., verbose=True, verbose_step=5, seed=-1, alpha=1, triplet_strategy='batch_all',
                  *, precision='bf16', rng='numpy', init_weights=None, device=None, data_parallel=False,
-                 results_root='results/'):
+                 dp_grad_dtype='fp32', results_root='results/'):
         self.algo_name = algo_name
         self.model_name = model_name
         self.compress_factor = compress_factor
@@ -68,6 +68,7 @@ class DenoisingAutoencoder(object):
         self.init_weights = init_weights
         self.device = device
         self.data_parallel = data_parallel
+        self.dp_grad_dtype = dp_grad_dtype       # 'fp32' | 'bf16': element type of the gradient in the reduce-scatter (data parallel)
         self.results_root = results_root
 
         assert type(self.verbose_step) == int                      # reference :68
@@ -123,7 +124,7 @@ class DenoisingAutoencoder(object):
             bs = max(round(n_rows * bs), 1)                         # reference utils.py:47
         return int(bs)
 
-    def _build_engine(self, n_features, max_batch):
+    def _build_engine(self, n_features, max_batch, dp_world=1):
         from ..engine import Engine                                # raises loudly without a GPU / the library
         if self.opt not in L.OPT:
             raise ValueError("unknown optimizer %r (reference :444-475 silently builds no train step)" % (self.opt,))
@@ -132,7 +133,7 @@ class DenoisingAutoencoder(object):
                              dtype=self.precision, enc_act=act(self.enc_act_func), dec_act=act(self.dec_act_func),
                              loss_func=self.loss_func, opt=self.opt, learning_rate=self.learning_rate,
                              momentum=self.momentum, alpha=float(self.alpha), triplet=self._strategy_key(),
-                             device=self.device)
+                             device=self.device, dp_world=dp_world)
         return self.engine
 
     def _initial_parameters(self, n_features):
@@ -167,7 +168,8 @@ class DenoisingAutoencoder(object):
 
         world, rank = self._dist()
         local_batch = -(-batch // world)
-        eng = self._build_engine(n_features, local_batch)
+        eng = self._build_engine(n_features, local_batch, dp_world=world)
+        self._exchange = None
         if self.sparse_input:
             eng.upload_csr(train_set)
         else:
@@ -194,8 +196,13 @@ class DenoisingAutoencoder(object):
             self._restore(self.model_path)
         if rank == 0:
             self._write_parameter_to_file(restore_previous_model)
+        if world > 1:
+            from .. import dp
+            self._exchange = dp.ShardedExchange(eng, grad_dtype=self.dp_grad_dtype)
 
         self._train_model(train_set, validation_set, train_set_label, validation_set_label)
+        if world > 1:
+            self._exchange.gather_master()  # the fp32 masters are sharded over the ranks during training
         if rank == 0:                      # one writer: every rank holds identical parameters
             self._save(self.model_path)
         if world > 1:
@@ -306,8 +313,7 @@ class DenoisingAutoencoder(object):
                 else:
                     eng.grad.zero_()
                     stats[b].zero_()
-                dp.allreduce_sum_(eng.grad)
-                eng.apply(grad_scale=1.0 / world)
+                self._exchange.step(grad_scale=1.0 / world)   # reduce-scatter -> sharded optimizer -> all-gather of W_lo
             else:
                 eng.train_step(rows, labs, stats[b], phase=3, **plan)
         if world > 1:                                                   # statistics of the GLOBAL batches, on every rank
@@ -344,6 +350,8 @@ class DenoisingAutoencoder(object):
                 print()
             self.history.append(rec)
             return
+        if getattr(self, '_exchange', None) is not None:
+            self._exchange.gather_master()
         v = self._validation_forward(validation_set, validation_set_label)
         rec.update(val_cost=v[L.STAT_COST], val_ae=v[L.STAT_AE], val_triplet=v[L.STAT_TRIPLET])
         if self.verbose and main:

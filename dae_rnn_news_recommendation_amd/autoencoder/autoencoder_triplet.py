@@ -61,6 +61,11 @@ class DenoisingAutoencoderTriplet(DenoisingAutoencoder):
         if restore_previous_model:
             self._restore(self.model_path)
         self._write_parameter_to_file(restore_previous_model)
+        if validation_set is not None:
+            assert isinstance(validation_set, dict) and all(k in validation_set for k in ('org', 'pos', 'neg'))
+            assert validation_set['pos'].shape == validation_set['org'].shape == validation_set['neg'].shape
+            assert validation_set['org'].shape[1] == n_features
+        self._val_engine = None
         self._train_triplet(stacked, N, batch, validation_set)
         self._save(self.model_path)
 
@@ -81,16 +86,45 @@ class DenoisingAutoencoderTriplet(DenoisingAutoencoder):
             if (i + 1) % self.verbose_step == 0 or i + 1 == self.num_epochs:
                 torch.cuda.synchronize()
                 self.train_time = time.time() - t0
-                self._run_validation_error_and_summaries(i + 1, None, None)
+                self._run_validation_error_and_summaries(i + 1, validation_set, None)
         torch.cuda.synchronize()
         wall = time.time() - t_fit
         if self.num_epochs > 0 and wall > 0:
             self.samples_per_sec = 3 * N * self.num_epochs / wall
 
+    def _validation_forward_triplet(self, validation_set):
+        """Forward pass of the whole validation dict as ONE stacked batch, uncorrupted (reference :160-199)."""
+        import torch
+        from ..engine import Engine
+        stacked = self._stack(validation_set)
+        nv = validation_set['org'].shape[0]
+        if getattr(self, '_val_engine', None) is None:
+            act = lambda a: a if a in ('sigmoid', 'tanh') else 'none'
+            self._val_engine = Engine(stacked.shape[1], self.n_components, 3 * nv, dtype=self.precision, enc_act=act(self.enc_act_func),
+                                      dec_act=act(self.dec_act_func), loss_func=self.loss_func, opt='gradient_descent',
+                                      alpha=float(self.alpha), triplet='explicit', device=self.device)
+            self._val_engine.upload_dense(stacked) if isinstance(stacked, np.ndarray) else self._val_engine.upload_csr(stacked)
+        ve = self._val_engine
+        ve.set_params(*self.engine.get_params())
+        stats = torch.zeros(L.STATS_STRIDE, dtype=torch.float32, device=ve.device)
+        ve.train_step(torch.arange(3 * nv, dtype=torch.int32, device=ve.device), None, stats, phase=2)
+        return stats.cpu().numpy()
+
     def _run_validation_error_and_summaries(self, epoch, validation_set, validation_set_label):
         st = self.epoch_stats(epoch)
-        self.history.append(dict(epoch=epoch, seconds=self.train_time, cost=st['cost'], ae=st['ae'], triplet=st['triplet']))
+        rec = dict(epoch=epoch, seconds=self.train_time, cost=st['cost'], ae=st['ae'], triplet=st['triplet'])
         if self.verbose == 1:
             print('At step %d (%.2f seconds): ' % (epoch, self.train_time), end='')
             print('[Train Stat (average over past steps)] - Cost: ', end='')
-            print('Overall=%.4f\tAutoencoder=%.4f\tTriplet=%.4f\t' % (st['cost'], st['ae'], st['triplet']))
+            print('Overall=%.4f\tAutoencoder=%.4f\tTriplet=%.4f\t' % (st['cost'], st['ae'], st['triplet']), end='')
+        if validation_set is None:
+            if self.verbose == 1:
+                print()
+            self.history.append(rec)
+            return
+        v = self._validation_forward_triplet(validation_set)          # reference :186-199
+        rec.update(val_cost=float(v[L.STAT_COST]), val_ae=float(v[L.STAT_AE]), val_triplet=float(v[L.STAT_TRIPLET]))
+        if self.verbose:
+            print("[Validation Stat (at this step)] - Cost: ", end='')
+            print('Overall=%.4f\tAutoencoder=%.4f\tTriplet=%.4f\t' % (v[L.STAT_COST], v[L.STAT_AE], v[L.STAT_TRIPLET]))
+        self.history.append(rec)

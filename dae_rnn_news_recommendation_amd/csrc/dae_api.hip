@@ -579,6 +579,31 @@ extern "C" int dae_plan_apply(dae_plan* p, int32_t adam_t, float grad_scale, voi
                         p->Fp, p->Hp, p->cfg.dtype, p->b.W_lo, p->b.Wt_lo, /*apply=*/1, stream);
 }
 
+// Data-parallel second half with a SHARDED optimizer: this rank owns rows [f0, f1) of W.  grad_rows holds the
+// rank-summed gradient of those rows (fp32 [f1-f0 x Hp], the output of the reduce-scatter); biases are updated on every rank
+// from the all-reduced bias part of the plan's flat gradient when update_bias != 0.  Afterwards the ranks all-gather W_lo and
+// call dae_plan_refresh_wt.
+extern "C" int dae_plan_apply_rows(dae_plan* p, int32_t adam_t, float grad_scale, const float* grad_rows, int32_t f0, int32_t f1,
+                                   int32_t update_bias, void* stream) {
+    DAE_CHECK_ARG(p && p->bound && grad_rows, "plan_apply_rows: plan not bound / null gradient");
+    DAE_CHECK_ARG(f0 >= 0 && f0 <= f1 && f1 <= p->Fp && f0 % 64 == 0 && f1 % 64 == 0, "plan_apply_rows: rows [%d, %d) outside [0, %d] or not multiples of 64", f0, f1, p->Fp);
+    const float lr = plan_lr(p, adam_t);
+    RC(dae_opt_step_rows(p->cfg.opt, lr, p->cfg.momentum, grad_scale, p->b.W, grad_rows, p->b.opt_s1, p->b.opt_s2, p->Hp, f0, f1, p->cfg.dtype,
+                         p->b.W_lo, stream));
+    if (update_bias) {
+        const int64_t off = (int64_t)p->Fp * p->Hp;
+        dim3 grid((p->Hp + p->Fp + 255) / 256), block(256);
+        RC(dae_opt_bias(p->cfg.opt, lr, p->cfg.momentum, grad_scale, p->b.bh, p->b.bv, p->b.grad + off, p->b.opt_s1 ? p->b.opt_s1 + off : nullptr,
+                        p->b.opt_s2 ? p->b.opt_s2 + off : nullptr, p->Hp, p->Fp, stream));
+    }
+    return 0;
+}
+
+extern "C" int dae_plan_refresh_wt(dae_plan* p, void* stream) {
+    DAE_CHECK_ARG(p && p->bound, "plan_refresh_wt: plan not bound");
+    return dae_transpose_shadow(p->b.W_lo, p->Fp, p->Hp, p->cfg.dtype, p->b.Wt_lo, stream);
+}
+
 extern "C" int dae_encode_rows(dae_plan* p, const int32_t* row_idx, int32_t B, float scale, const int64_t* indptr,
                                const int32_t* indices, const float* values, const float* dense, int64_t ld_dense, float* out,
                                int64_t ld_out, void* stream) {

@@ -372,6 +372,20 @@ __global__ __launch_bounds__(256) void opt_w_kernel(int opt, float lr, float mom
     }
 }
 
+// Wt_lo = W_lo^T (64 x 64 tiles through LDS): after a sharded optimizer step + all-gather of W_lo every rank rebuilds the
+// transposed shadow locally instead of receiving it (halves the all-gather)
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_lo_kernel(const T* __restrict__ W_lo, int Fp, int Hp, T* __restrict__ Wt_lo) {
+    __shared__ T tile[64][66];
+    const int j0 = blockIdx.x * 64, f0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll 4
+    for (int r = ty; r < 64; r += 4) tile[r][tx] = W_lo[(int64_t)(f0 + r) * Hp + j0 + tx];
+    __syncthreads();
+#pragma unroll 4
+    for (int r = ty; r < 64; r += 4) Wt_lo[(int64_t)(j0 + r) * Fp + f0 + tx] = tile[tx][r];
+}
+
 __global__ void opt_bias_kernel(int opt, float lr, float mom, float gscale, float* __restrict__ bh, float* __restrict__ bv,
                                 const float* __restrict__ grad_b, float* __restrict__ s1b, float* __restrict__ s2b, int Hp,
                                 int Fp) {
@@ -633,6 +647,44 @@ extern "C" int dae_opt_step(int32_t opt, float lr, float momentum, float grad_sc
                            bv, grad + off, s1 ? s1 + off : nullptr, s2 ? s2 + off : nullptr, Hp, Fp);
         DAE_CHECK_LAUNCH();
     }
+    return 0;
+}
+
+extern "C" int dae_opt_bias(int32_t opt, float lr, float momentum, float grad_scale, float* bh, float* bv, const float* grad_b, float* s1b,
+                            float* s2b, int32_t Hp, int32_t Fp, void* stream) {
+    DAE_CHECK_ARG(bh && bv && grad_b && opt >= DAE_OPT_SGD && opt <= DAE_OPT_ADAM && (opt == DAE_OPT_SGD || s1b) && (opt != DAE_OPT_ADAM || s2b),
+                  "opt_bias: bad args");
+    hipLaunchKernelGGL(opt_bias_kernel, dim3((Hp + Fp + 255) / 256), dim3(256), 0, ST(stream), opt, lr, momentum, grad_scale, bh, bv, grad_b, s1b, s2b, Hp, Fp);
+    DAE_CHECK_LAUNCH();
+    return 0;
+}
+
+// data-parallel second half on a ROW RANGE of W (sharded optimizer): rows [f0, f1) of W / slots / W_lo are updated from
+// grad_rows (fp32 [f1-f0 x Hp], already summed over the ranks); Wt_lo is NOT touched (dae_transpose_shadow after the all-gather)
+extern "C" int dae_opt_step_rows(int32_t opt, float lr, float momentum, float grad_scale, float* W, const float* grad_rows, float* s1,
+                                 float* s2, int32_t Hp, int32_t f0, int32_t f1, int32_t dtype, void* W_lo, void* stream) {
+    DAE_CHECK_ARG(W && grad_rows && W_lo && Hp % 64 == 0 && f0 >= 0 && f1 >= f0 && f0 % 64 == 0 && f1 % 64 == 0, "opt_step_rows: bad args");
+    DAE_CHECK_ARG(opt >= DAE_OPT_SGD && opt <= DAE_OPT_ADAM && (opt == DAE_OPT_SGD || s1) && (opt != DAE_OPT_ADAM || s2), "opt_step_rows: optimizer slots");
+    if (f1 == f0) return 0;
+    const int64_t off = (int64_t)f0 * Hp;
+    const size_t es = dtype == DAE_BF16 ? 2 : 4;
+    dim3 grid(Hp / 64, (f1 - f0) / 64), block(256);
+    if (dtype == DAE_BF16)
+        hipLaunchKernelGGL((opt_w_kernel<bf16_t>), grid, block, 0, ST(stream), opt, lr, momentum, grad_scale, W + off, grad_rows, s1 ? s1 + off : nullptr,
+                           s2 ? s2 + off : nullptr, 0, Hp, (bf16_t*)((char*)W_lo + off * es), (bf16_t*)nullptr, 1);
+    else
+        hipLaunchKernelGGL((opt_w_kernel<float>), grid, block, 0, ST(stream), opt, lr, momentum, grad_scale, W + off, grad_rows, s1 ? s1 + off : nullptr,
+                           s2 ? s2 + off : nullptr, 0, Hp, (float*)((char*)W_lo + off * es), (float*)nullptr, 1);
+    DAE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dae_transpose_shadow(const void* W_lo, int32_t Fp, int32_t Hp, int32_t dtype, void* Wt_lo, void* stream) {
+    DAE_CHECK_ARG(W_lo && Wt_lo && Fp % 64 == 0 && Hp % 64 == 0, "transpose_shadow: bad args");
+    dim3 grid(Hp / 64, Fp / 64), block(256);
+    if (dtype == DAE_BF16) hipLaunchKernelGGL((transpose_lo_kernel<bf16_t>), grid, block, 0, ST(stream), (const bf16_t*)W_lo, Fp, Hp, (bf16_t*)Wt_lo);
+    else hipLaunchKernelGGL((transpose_lo_kernel<float>), grid, block, 0, ST(stream), (const float*)W_lo, Fp, Hp, (float*)Wt_lo);
+    DAE_CHECK_LAUNCH();
     return 0;
 }
 

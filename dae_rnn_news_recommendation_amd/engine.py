@@ -20,7 +20,7 @@ from . import _lib as L
 class Engine:
     def __init__(self, n_features, n_components, max_batch, *, dtype="bf16", enc_act="sigmoid", dec_act="sigmoid",
                  loss_func="cross_entropy", opt="gradient_descent", learning_rate=0.1, momentum=0.5, alpha=1.0,
-                 triplet="none", pos_triplets_only=False, device=None, encode_splits=0, dh_splits=0, gram_splits=0):
+                 triplet="none", pos_triplets_only=False, device=None, encode_splits=0, dh_splits=0, gram_splits=0, dp_world=1):
         if not torch.cuda.is_available():
             raise RuntimeError("dae_rnn_news_recommendation_amd.Engine needs a ROCm GPU (MI355X): no CPU fallback exists")
         self.lib = L.load()
@@ -39,10 +39,16 @@ class Engine:
         self.Fp, self.Hp, self.Bpm = L.pad(self.F), L.pad(self.H), L.pad(self.Bmax)
         dev = self.device
         n_flat = self.Fp * self.Hp + self.Hp + self.Fp
+        # data parallel with a sharded optimizer (dp.ShardedExchange): W is cut into `dp_world` equal chunks of whole 64-row
+        # blocks; the gradient buffer and W_lo are over-allocated so that every chunk exists (rows >= Fp stay zero)
+        self.dp_world = int(dp_world)
+        self.chunk_rows = -(-self.Fp // (64 * self.dp_world)) * 64
+        self.rows_alloc = self.chunk_rows * self.dp_world
+        self.n_flat = n_flat
         self.W = torch.zeros((self.Fp, self.Hp), dtype=torch.float32, device=dev)
         self.bh = torch.zeros(self.Hp, dtype=torch.float32, device=dev)
         self.bv = torch.zeros(self.Fp, dtype=torch.float32, device=dev)
-        self.grad = torch.zeros(n_flat, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(max(n_flat, self.rows_alloc * self.Hp), dtype=torch.float32, device=dev)
         self.s1 = self.s2 = None
         if opt == "ada_grad":
             self.s1 = torch.full((n_flat,), 0.1, dtype=torch.float32, device=dev)   # TF initial_accumulator_value
@@ -51,7 +57,8 @@ class Engine:
         elif opt == "adam":
             self.s1 = torch.zeros(n_flat, dtype=torch.float32, device=dev)
             self.s2 = torch.zeros(n_flat, dtype=torch.float32, device=dev)
-        self.W_lo = torch.zeros((self.Fp, self.Hp), dtype=self.td, device=dev)
+        self.W_lo_full = torch.zeros((self.rows_alloc, self.Hp), dtype=self.td, device=dev)
+        self.W_lo = self.W_lo_full[:self.Fp]
         self.Wt_lo = torch.zeros((self.Hp, self.Fp), dtype=self.td, device=dev)
         ws_bytes = int(self.lib.dae_plan_workspace_bytes(self.plan))
         self.workspace = torch.zeros(ws_bytes, dtype=torch.uint8, device=dev)
@@ -133,7 +140,7 @@ class Engine:
         n = self.Fp * self.Hp
         dW = self.grad[:n].view(self.Fp, self.Hp)[:self.F, :self.H].cpu().numpy()
         dbh = self.grad[n:n + self.Hp][:self.H].cpu().numpy()
-        dbv = self.grad[n + self.Hp:][:self.F].cpu().numpy()
+        dbv = self.grad[n + self.Hp:n + self.Hp + self.Fp][:self.F].cpu().numpy()
         return dW, dbh, dbv
 
     def optimizer_state(self):
@@ -158,6 +165,14 @@ class Engine:
             self.adam_t += 1
         s.adam_t = self.adam_t; s.grad_scale = float(grad_scale)
         L.check(self.lib.dae_train_step(self.plan, C.byref(s), L.current_stream()), "dae_train_step")
+
+    def apply_rows(self, grad_rows, f0, f1, grad_scale=1.0, update_bias=True):
+        """Sharded-optimizer step on the rows [f0, f1) this rank owns (dp.ShardedExchange); W_lo rows refreshed, Wt_lo not."""
+        L.check(self.lib.dae_plan_apply_rows(self.plan, self.adam_t, float(grad_scale), L.ptr(grad_rows), int(f0), int(f1),
+                                             int(bool(update_bias)), L.current_stream()), "dae_plan_apply_rows")
+
+    def refresh_wt(self):
+        L.check(self.lib.dae_plan_refresh_wt(self.plan, L.current_stream()), "dae_plan_refresh_wt")
 
     def apply(self, grad_scale=1.0):
         """Optimizer step on the (all-reduced) flat gradient -- the second half of a DP step."""

@@ -181,7 +181,10 @@ def visualize_pairwise_similarity(labels, pairwise_similarity_metrics, plot='box
     if S.stride(1) != 1:
         S = S.contiguous()
     N = int(S.shape[0])
-    lab = np.ascontiguousarray(labels.reshape(N, -1)[:, 0].astype(np.int32))
+    lab = np.asarray(labels).reshape(N, -1)[:, 0]
+    if lab.dtype.kind == 'f':                      # NaN / inf 'missing' labels: the reference filters them with labels >= 0
+        lab = np.where(np.isfinite(lab), lab, -1.0)
+    lab = np.ascontiguousarray(lab.astype(np.int32))
     ws_bytes = int(lib.dae_pair_stats_workspace(N))
     ws = torch.empty(ws_bytes + 256, dtype=torch.uint8, device=S.device)
     off = (-ws.data_ptr()) % 256

@@ -256,6 +256,14 @@ int dae_opt_step(int32_t opt, float lr, float momentum, float grad_scale,
 /* Final per-step statistics (autoencoder.py:233 fetch list):
  * ae = sum_i cw_i * rowloss_i (from rowloss_part + cw, or from the decode kernel's tile_part if given);
  * cost = ae + alpha * triplet.  stats: float[DAE_STATS_STRIDE]. */
+/* Pieces of the data-parallel (sharded-optimizer) second half, see dae_plan_apply_rows: the optimizer on rows [f0, f1) of W
+ * (W_lo rows refreshed, Wt_lo untouched), the bias update alone, and Wt_lo = W_lo^T. */
+int dae_opt_step_rows(int32_t opt, float lr, float momentum, float grad_scale, float* W, const float* grad_rows, float* s1,
+                      float* s2, int32_t Hp, int32_t f0, int32_t f1, int32_t dtype, void* W_lo, void* stream);
+int dae_opt_bias(int32_t opt, float lr, float momentum, float grad_scale, float* bh, float* bv, const float* grad_b, float* s1b,
+                 float* s2b, int32_t Hp, int32_t Fp, void* stream);
+int dae_transpose_shadow(const void* W_lo, int32_t Fp, int32_t Hp, int32_t dtype, void* Wt_lo, void* stream);
+
 int dae_step_stats(const float* rowloss_part, int32_t n_col_waves, const float* tile_part, int32_t n_tiles,
                    const float* cw, int32_t B, int32_t Bp, int32_t triplet, float alpha,
                    float* tri_scalars, const int64_t* nvalid,
@@ -367,6 +375,13 @@ int      dae_plan_sync_shadows(dae_plan* p, void* stream);
 int      dae_plan_set_option(dae_plan* p, const char* name, int32_t value);
 int      dae_train_step(dae_plan* p, const dae_step* step, void* stream);
 int      dae_plan_apply(dae_plan* p, int32_t adam_t, float grad_scale, void* stream);
+/* Data parallel with a SHARDED optimizer: after dae_train_step(phase = 1) the ranks reduce-scatter the W part of the flat gradient
+ * by row chunks and all-reduce its (small) bias part; every rank then updates the rows [f0, f1) it owns from grad_rows (fp32
+ * [f1-f0 x Hp], rank-summed) and -- update_bias != 0 -- the biases, all-gathers W_lo and rebuilds Wt_lo = W_lo^T locally
+ * (dae_plan_refresh_wt).  Per step and rank this moves 1/2 (fp32 gradients) to 1/4 (bf16 gradients) of an fp32 all-reduce. */
+int      dae_plan_apply_rows(dae_plan* p, int32_t adam_t, float grad_scale, const float* grad_rows, int32_t f0, int32_t f1,
+                             int32_t update_bias, void* stream);
+int      dae_plan_refresh_wt(dae_plan* p, void* stream);
 /* transform(): out[B x H] fp32 (ld_out) = encode of rows row_idx (autoencoder.py:479-505) */
 int      dae_encode_rows(dae_plan* p, const int32_t* row_idx, int32_t B, float scale,
                          const int64_t* indptr, const int32_t* indices, const float* values,

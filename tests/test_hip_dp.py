@@ -1,0 +1,114 @@
+"""Data parallel THROUGH THE ESTIMATOR on the GPU: two ranks (two processes sharing this box's one GPU, gloo collectives --
+RCCL needs a GPU per rank) run ``DenoisingAutoencoder.fit(data_parallel=True)`` -- phase-1 HIP step on the rank's shard of
+every global mini-batch, reduce-scatter of the W gradient, sharded optimizer (dae_plan_apply_rows), all-gather of W_lo,
+local rebuild of Wt_lo -- and must reproduce ONE rank training on the global batches: same per-batch statistics, same
+parameters.  Ragged shards (37 rows on 2 ranks = 19 / 18; a 2-row tail batch) are included."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _data():
+    from scipy import sparse
+    rng = np.random.default_rng(3)
+    N, F = 150, 700
+    m = sparse.random(N, F, density=0.04, random_state=np.random.RandomState(3), format="csr", dtype=np.float32)
+    m.data = np.ones_like(m.data); m.sort_indices()
+    lab = rng.integers(0, 3, N)
+    W0 = rng.uniform(-0.2, 0.2, (F, F // 10)).astype(np.float32)
+    return m, lab, W0
+
+
+def _fit(tmp, strategy, opt, dp_flag, grad_dtype="fp32", seed=11):
+    from dae_rnn_news_recommendation_amd.autoencoder import DenoisingAutoencoder
+    m, lab, W0 = _data()
+    model = DenoisingAutoencoder(model_name="dp", main_dir="dp%d" % os.getpid(), compress_factor=10, enc_act_func="sigmoid",
+                                 dec_act_func="sigmoid", loss_func="cross_entropy", num_epochs=2, batch_size=37, opt=opt,
+                                 learning_rate=0.05, momentum=0.5, corr_type="masking", corr_frac=0.3, verbose=0, verbose_step=1,
+                                 seed=seed, alpha=1, triplet_strategy=strategy, precision="fp32", rng="numpy", init_weights=W0,
+                                 data_parallel=dp_flag, dp_grad_dtype=grad_dtype, results_root=tmp + "/")
+    model.fit(m, train_set_label=lab if strategy != "none" else None)
+    stats = np.stack([model.epoch_stats(e + 1)["per_batch"] for e in range(2)])
+    return stats, model.engine.get_params()
+
+
+def _worker(rank, world, port, tmp, strategy, opt, grad_dtype, seed, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK="0")
+    import torch
+    from dae_rnn_news_recommendation_amd import dp
+    torch.cuda.set_device(0)
+    dp.init_from_env("gloo")
+    stats, params = _fit(tmp, strategy, opt, True, grad_dtype, seed)
+    out[rank] = (stats, params)
+    dp.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def _run_dp(tmp, strategy, opt, grad_dtype="fp32", seed=11):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager(); out = mgr.dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, tmp, strategy, opt, grad_dtype, seed, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0, "rank exited with %r" % (p.exitcode,)
+    return dict(out)
+
+
+def _rel(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max() / (np.abs(b).max() + 1e-30))
+
+
+@pytest.mark.parametrize("opt", ["gradient_descent", "adam"])
+def test_fit_two_ranks_equal_one_rank_strategy_none(tmp_path, opt):
+    ref_stats, ref_p = _fit(str(tmp_path), "none", opt, False)
+    out = _run_dp(str(tmp_path), "none", opt)
+    for r in range(2):
+        stats, p = out[r]
+        assert _rel(stats[..., 0], ref_stats[..., 0]) < 1e-5, (r, stats[..., 0], ref_stats[..., 0])   # global-batch cost on every rank
+        for a, b in zip(p, ref_p):
+            assert _rel(a, b) < (1e-5 if opt == "gradient_descent" else 2e-4)
+    assert np.array_equal(out[0][1][0], out[1][1][0])                      # both ranks end with the same weights, bit for bit
+
+
+def test_fit_two_ranks_seed_is_shared_when_unseeded(tmp_path):
+    """seed < 0: rank 0's entropy is broadcast, so both ranks draw the same masks / shuffles: the shards partition
+    every global batch and the ranks stay bit-identical."""
+    out = _run_dp(str(tmp_path), "none", "gradient_descent", seed=-1)
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1][0], out[1][1][0])
+    assert np.isfinite(out[0][0]).all()
+
+
+def test_fit_two_ranks_bf16_gradients(tmp_path):
+    """perf mode of the exchange: the reduce-scatter carries bf16 gradients (half the bytes); the update stays within bf16
+    rounding of the fp32 exchange."""
+    ref_stats, ref_p = _fit(str(tmp_path), "none", "gradient_descent", False)
+    out = _run_dp(str(tmp_path), "none", "gradient_descent", grad_dtype="bf16")
+    stats, p = out[0]
+    assert _rel(stats[..., 0], ref_stats[..., 0]) < 2e-3
+    assert _rel(p[0], ref_p[0]) < 2e-3
+
+
+def test_fit_two_ranks_local_mining_runs(tmp_path):
+    """triplet strategies under data parallel mine within each rank's shard (documented, warned): finite, decreasing cost and
+    identical weights on both ranks."""
+    out = _run_dp(str(tmp_path), "batch_all", "gradient_descent")
+    assert np.isfinite(out[0][0]).all()
+    assert np.array_equal(out[0][1][0], out[1][1][0])
+    assert out[0][0][1, :, 0].mean() < out[0][0][0, :, 0].mean()
