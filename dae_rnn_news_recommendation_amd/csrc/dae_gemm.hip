@@ -701,6 +701,257 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_nt_pc(GemmParams p, float*
             }
 }
 
+// ------------------------------------------------------------------------------------------------
+// dW GEMM + optimizer as an 8-wave producer/consumer kernel on 160 x 128 tiles.
+// gemm_dw_opt above runs 79 x 4 = 316 tiles of 128 x 128 with four waves that both feed the LDS ring and issue the MFMAs
+// (K loop at ~30 % of the MFMA rate) on 2 workgroups per CU -- 316 tiles leave most CUs with ONE workgroup, so nothing hides
+// the DMA issue.  Here the 10112 x 512 gradient is cut into 64 x 4 = 256 tiles of 160 x 128 -- exactly one per CU, one
+// round -- and each workgroup is specialised like gemm_nt_pc: waves 4-7 only issue LDS-DMA (9 pieces of 1 KiB per wave and
+// K tile into a 4-slot ring), waves 0-3 only read fragments and issue MFMAs.  Consumer wave w owns all 160 rows x columns
+// [32 w, +32): 5 accumulators, per 16-deep k step 5 A fragments + 1 B fragment for 5 MFMAs; fragments are double buffered
+// one k step ahead (48 VGPRs) so that the master weights of the tile can stay prefetched in registers (80 VGPRs, SGD).
+// The last row tile is partial (10112 = 63 x 160 + 32): its out-of-range rows load row Fp-1 and are never stored.
+// ------------------------------------------------------------------------------------------------
+constexpr int DW_BM = 160, DW_MB = DW_BM / 32;                         // rows per tile, MFMA row blocks per consumer wave
+constexpr int DW_A_BYTES = DW_BM * BKB;                                // 20 KiB
+constexpr int DW_STAGE = DW_A_BYTES + TILE_BYTES;                      // + 16 KiB B tile = 36 KiB
+constexpr int DW_NST = 4;
+constexpr int DW_P0 = 128 * 2 + 16;                                    // staged W_lo row [160][128 bf16 + pad]
+constexpr int DW_P1 = DW_BM * 2 + 16;                                  // staged Wt_lo row [128][160 bf16 + pad]
+constexpr int DW_LDS = DW_NST * DW_STAGE;                              // 144 KiB (the epilogue tiles, 86 KiB, reuse it)
+
+template <int OPT>
+__global__ __launch_bounds__(PC_THREADS, 1) void gemm_dw_pc(GemmParams p, OptEpi e, int Mrows) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    // XCD-banded tile map: XCD x = b % 8 owns 8 consecutive row tiles (all column tiles), so a band's A panel is read from
+    // HBM by one XCD and re-used from its L2 by the 4 column tiles
+    const int b = blockIdx.x, xcd = b & 7, l = b >> 3;
+    const int per = (p.tiles_m + 7) >> 3;
+    const int tm = xcd * per + l / p.tiles_n, tn = l % p.tiles_n;
+    if (l >= per * p.tiles_n || tm >= p.tiles_m) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nk = p.ktiles_total;
+    const int row0_m = tm * DW_BM, row0_n = tn * BN;
+
+    if (wave8 >= 4) {
+        // ================= producer: 5 A pieces + 4 B pieces per K tile =================
+        const int wave = wave8 - 4;
+        uint32_t voA[5], voB[4];
+        const char *gA = nullptr, *gB = nullptr;
+        int kt_dma = 0;
+        auto seg_setup = [&](int kt) {
+            const int sg = kt >= p.seg[0].ktiles ? 1 : 0;
+            const int k = kt - (sg ? p.seg[0].ktiles : 0);
+            const uint32_t lda = (uint32_t)p.seg[sg].lda_b, ldb = (uint32_t)p.seg[sg].ldb_b;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int row = (i * 4 + wave) * 8 + (lane >> 3);
+                const int grow = min(row0_m + row, Mrows - 1);
+                voA[i] = (uint32_t)grow * lda + (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) << 4);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = (i * 4 + wave) * 8 + (lane >> 3);
+                voB[i] = (uint32_t)(row0_n + row) * ldb + (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) << 4);
+            }
+            gA = p.seg[sg].A + (int64_t)k * BKB;
+            gB = p.seg[sg].Bt + (int64_t)k * BKB;
+        };
+        seg_setup(0);
+        auto dma_stage = [&](char* slot) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gA + voA[i]),
+                                                 (__attribute__((address_space(3))) void*)(slot + (i * 4 + wave) * 1024), 16, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gB + voB[i]),
+                                                 (__attribute__((address_space(3))) void*)(slot + DW_A_BYTES + (i * 4 + wave) * 1024), 16, 0, 0);
+            ++kt_dma;
+            if (kt_dma == p.seg[0].ktiles) seg_setup(kt_dma);
+            else { gA += BKB; gB += BKB; }
+        };
+#pragma unroll
+        for (int st = 0; st < DW_NST; ++st)
+            if (st < nk) dma_stage(lds + st * DW_STAGE);
+        if (nk >= DW_NST) wait_vm<(DW_NST - 1) * 9>(); else wait_vm<0>();   // stage 0 landed
+        __builtin_amdgcn_s_barrier();
+        int cur = 0;
+        for (int i = 0; i < nk; ++i) {
+            const int ahead = min(DW_NST - 2, nk - 2 - i);                  // stages younger than i+1 already requested
+            if (ahead >= 2) wait_vm<18>();
+            else if (ahead == 1) wait_vm<9>();
+            else wait_vm<0>();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (i + DW_NST < nk) dma_stage(lds + cur * DW_STAGE);
+            cur = cur + 1 == DW_NST ? 0 : cur + 1;
+        }
+    } else {
+        // ================= consumer =================
+        const int wave = wave8;                                             // column block
+        const int g = lane >> 5, c = lane & 31;
+        float* __restrict__ Wp = e.W;
+        // master weights of this lane's 80 elements, requested before the K loop (plain SGD; see gemm_dw_opt)
+        constexpr bool PREFETCH_W = (OPT == DAE_OPT_SGD);
+        float wv[DW_MB][16];
+        if constexpr (PREFETCH_W) {
+#pragma unroll
+            for (int m = 0; m < DW_MB; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int grow = min(row0_m + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * g, Mrows - 1);
+                    wv[m][r] = Wp[(int64_t)grow * e.ldw + row0_n + wave * 32 + c];
+                }
+        }
+        f32x16 acc[DW_MB];
+#pragma unroll
+        for (int m = 0; m < DW_MB; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+        const int r = lane & 31;
+        const int swz = (r >> 1) & 7;
+        const uint32_t lbase = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)lds;
+        const uint32_t offa = r * BKB, offb = DW_A_BYTES + (wave * 32 + r) * BKB;
+        uint32_t so[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) so[kk] = (uint32_t)(((kk * 2 + g) ^ swz) << 4);
+        i32x4 fa[2][DW_MB], fb[2];
+#define DAE_DW_READ(S, KK, SLOTBASE)                                                   \
+    fb[S] = lds_read_b128((SLOTBASE) + offb + so[KK]);                                 \
+    fa[S][0] = lds_read_b128((SLOTBASE) + offa + so[KK]);                              \
+    fa[S][1] = lds_read_b128_off4096((SLOTBASE) + offa + so[KK]);                      \
+    fa[S][2] = lds_read_b128((SLOTBASE) + offa + 8192 + so[KK]);                       \
+    fa[S][3] = lds_read_b128_off4096((SLOTBASE) + offa + 8192 + so[KK]);               \
+    fa[S][4] = lds_read_b128((SLOTBASE) + offa + 16384 + so[KK]);
+#define DAE_DW_MMA(S)                                                                  \
+    Mma<bf16_t>::run(fa[S][0], fb[S], acc[0]);                                         \
+    Mma<bf16_t>::run(fa[S][1], fb[S], acc[1]);                                         \
+    Mma<bf16_t>::run(fa[S][2], fb[S], acc[2]);                                         \
+    Mma<bf16_t>::run(fa[S][3], fb[S], acc[3]);                                         \
+    Mma<bf16_t>::run(fa[S][4], fb[S], acc[4]);
+        __builtin_amdgcn_s_barrier();                                       // stage 0 landed (producers waited for it)
+        asm volatile("" ::: "memory");
+        DAE_DW_READ(0, 0, lbase)
+        __builtin_amdgcn_sched_barrier(0);
+        int cur = 0;
+        for (int i = 0; i < nk; ++i) {
+            const int nxt = cur + 1 == DW_NST ? 0 : cur + 1;
+            const uint32_t sb = lbase + cur * DW_STAGE, nb = lbase + nxt * DW_STAGE;
+            DAE_DW_READ(1, 1, sb)                                            // k step 1 -> set 1
+            asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");              // k step 0 (set 0) landed
+            __builtin_amdgcn_sched_barrier(0);
+            DAE_DW_MMA(0)
+            __builtin_amdgcn_sched_barrier(0);
+            DAE_DW_READ(0, 2, sb)
+            asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            DAE_DW_MMA(1)
+            __builtin_amdgcn_sched_barrier(0);
+            DAE_DW_READ(1, 3, sb)
+            asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            DAE_DW_MMA(0)
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // every LDS read of tile i is done
+            __builtin_amdgcn_s_barrier();                                   // slot free for the producers; stage i+1 landed
+            asm volatile("" ::: "memory");
+            DAE_DW_READ(0, 0, nb)                                            // stale (never consumed) after the last tile
+            __builtin_amdgcn_sched_barrier(0);
+            DAE_DW_MMA(1)
+            __builtin_amdgcn_sched_barrier(0);
+            cur = nxt;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#undef DAE_DW_READ
+#undef DAE_DW_MMA
+        // ---- optimizer on the gradient tile in registers; both bf16 shadows staged in LDS (the ring is dead for this wave's
+        //      columns only after the barrier below, which all 8 waves reach) ----
+        __builtin_amdgcn_s_barrier();                                       // B1: every consumer is out of the K loop
+        char* R0 = lds;                                                     // W_lo tile   [160][DW_P0]
+        char* R1 = lds + DW_BM * DW_P0;                                     // Wt_lo tile  [128][DW_P1]
+        float* __restrict__ gradp = e.grad;
+        float* __restrict__ s1p = e.s1;
+        float* __restrict__ s2p = e.s2;
+        const float lr = e.lr, mom = e.mom, gscale = e.gscale;
+        const int lcol = wave * 32 + c;
+        auto block = [&](auto MB) {
+            constexpr int m = decltype(MB)::value;
+            float a1[16], a2[16];
+            if constexpr (OPT != DAE_OPT_SGD) {
+#pragma unroll
+                for (int r2 = 0; r2 < 16; ++r2) {
+                    const int grow = min(row0_m + m * 32 + (r2 & 3) + 8 * (r2 >> 2) + 4 * g, Mrows - 1);
+                    const int64_t k = (int64_t)grow * e.ldw + row0_n + lcol;
+                    wv[m][r2] = Wp[k];
+                    a1[r2] = s1p[k];
+                    a2[r2] = (OPT == DAE_OPT_ADAM) ? s2p[k] : 0.f;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                float pv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r2 = r4 * 4 + q;
+                    const int lrow = m * 32 + 8 * r4 + q + 4 * g;
+                    const bool ok = row0_m + lrow < Mrows;
+                    const int64_t k = (int64_t)(row0_m + lrow) * e.ldw + row0_n + lcol;
+                    const float gr = acc[m][r2];
+                    const float gg = gr * gscale, p0 = wv[m][r2];
+                    float pn;
+                    if constexpr (OPT == DAE_OPT_SGD) pn = p0 - lr * gg;
+                    else if constexpr (OPT == DAE_OPT_ADAGRAD) { const float a = a1[r2] + gg * gg; if (ok) s1p[k] = a; pn = p0 - lr * gg * rsqrtf(a); }
+                    else if constexpr (OPT == DAE_OPT_MOMENTUM) { const float a = mom * a1[r2] + gg; if (ok) s1p[k] = a; pn = p0 - lr * a; }
+                    else {
+                        const float mm = 0.9f * a1[r2] + 0.1f * gg;
+                        const float vv = 0.999f * a2[r2] + 0.001f * gg * gg;
+                        if (ok) { s1p[k] = mm; s2p[k] = vv; }
+                        pn = p0 - lr * mm / (sqrtf(vv) + 1e-8f);
+                    }
+                    if (ok) { Wp[k] = pn; if (gradp) gradp[k] = gr; }
+                    pv[q] = pn;
+                    *reinterpret_cast<bf16_t*>(R0 + lrow * DW_P0 + lcol * 2) = f2bf_hw(pn);
+                }
+                uint2 v;
+                v.x = f2bf_pack_hw(pv[0], pv[1]);
+                v.y = f2bf_pack_hw(pv[2], pv[3]);
+                *reinterpret_cast<uint2*>(R1 + lcol * DW_P1 + (m * 32 + 8 * r4 + 4 * g) * 2) = v;
+            }
+        };
+        block(std::integral_constant<int, 0>{});
+        block(std::integral_constant<int, 1>{});
+        block(std::integral_constant<int, 2>{});
+        block(std::integral_constant<int, 3>{});
+        block(std::integral_constant<int, 4>{});
+    }
+    if (wave8 >= 4) __builtin_amdgcn_s_barrier();                           // B1 (producers): the consumers have left the K loop
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                           // B2: both staged tiles are complete
+    asm volatile("" ::: "memory");
+    // ---- all 8 waves: coalesced 16-byte stores of the two shadow tiles ----
+    {
+        const char* R0 = lds;
+        const char* R1 = lds + DW_BM * DW_P0;
+        bf16_t* Wlo = reinterpret_cast<bf16_t*>(e.W_lo);
+        bf16_t* Wtlo = reinterpret_cast<bf16_t*>(e.Wt_lo);
+        for (int ch = tid; ch < DW_BM * 16; ch += PC_THREADS) {              // W_lo: 160 rows x 16 chunks
+            const int row = ch >> 4, c16 = ch & 15;
+            if (row0_m + row < Mrows)
+                *reinterpret_cast<i32x4*>(Wlo + (int64_t)(row0_m + row) * e.ldw + row0_n + c16 * 8) =
+                    *reinterpret_cast<const i32x4*>(R0 + row * DW_P0 + c16 * 16);
+        }
+        for (int ch = tid; ch < 128 * 20; ch += PC_THREADS) {                // Wt_lo: 128 rows x 20 chunks of 8 features
+            const int row = ch / 20, c16 = ch % 20;
+            if (row0_m + c16 * 8 < Mrows)
+                *reinterpret_cast<i32x4*>(Wtlo + (int64_t)(row0_n + row) * e.ldwt + row0_m + c16 * 8) =
+                    *reinterpret_cast<const i32x4*>(R1 + row * DW_P1 + c16 * 16);
+        }
+    }
+}
+
 // Instrumented twin of gemm_nt_f32out (dae_gemm_trace): same code with shader-clock stamps; o[5] = K loop, o[6] = epilogue,
 // o[7] = s_memtime at kernel entry (block start skew).
 template <typename T, int NST>
@@ -1237,6 +1488,7 @@ template <typename T> static pc_fn pc_kernel(int role) {
     }
 }
 static int g_cus = 0;        // compute units of the current device (set by gemm_init)
+static int g_dw_pc = 1;      // dW + optimizer on the 160 x 128 producer/consumer kernel when its grid fills one round (dae_set_glds(-3/-4))
 static int g_use_pc = 1;     // dae_set_glds(-1) keeps the 4-wave kernel for every grid (A/B)
 typedef void (*decode_fn)(GemmParams, DecodeEpi);
 static decode_fn decode_kernel_xbits(int loss, int act) {
@@ -1321,6 +1573,25 @@ int launch_dw_opt(int M, int N, const void* A0, int64_t lda0, const void* Bt0, i
     DAE_CHECK_ARG(e.W && e.W_lo && e.Wt_lo && e.ldw >= N && e.ldwt >= M && e.ldw % 8 == 0 && e.ldwt % 8 == 0, "dw_opt: bad parameter images");
     DAE_CHECK_ARG(e.opt >= DAE_OPT_SGD && e.opt <= DAE_OPT_ADAM && (e.opt == DAE_OPT_SGD || e.s1) && (e.opt != DAE_OPT_ADAM || e.s2),
                   "dw_opt: optimizer slots missing");
+    {   // 160 x 128 tiles, 8-wave producer/consumer: one workgroup per CU in a single round when the tile count fits the chip
+        const int tiles_m = (M + DW_BM - 1) / DW_BM, tiles_n = N / BN;
+        const int per = (tiles_m + 7) / 8;
+        if (g_dw_pc && K0 % 64 == 0 && K1 % 64 == 0 && 8 * per * tiles_n <= g_cus && (g_dw_pc == 2 || 8 * per * tiles_n > (3 * g_cus) / 4)) {
+            typedef void (*dwpc_fn)(GemmParams, OptEpi, int);
+            static const dwpc_fn pcs[4] = {gemm_dw_pc<DAE_OPT_SGD>, gemm_dw_pc<DAE_OPT_ADAGRAD>, gemm_dw_pc<DAE_OPT_MOMENTUM>, gemm_dw_pc<DAE_OPT_ADAM>};
+            static int pc_rc = [] {
+                int rc = 0;
+                for (dwpc_fn f : pcs) rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS);
+                return rc;
+            }();
+            DAE_CHECK_ARG(pc_rc == 0, "dw_pc: hipFuncSetAttribute failed");
+            GemmParams q = p;
+            q.tiles_m = tiles_m; q.tiles_n = tiles_n;
+            hipLaunchKernelGGL(pcs[e.opt], dim3(8 * per * tiles_n), dim3(PC_THREADS), DW_LDS, st, q, e, M);
+            DAE_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     typedef void (*dwo_fn)(GemmParams, OptEpi);
     static const dwo_fn fns[4] = {gemm_dw_opt<DAE_OPT_SGD>, gemm_dw_opt<DAE_OPT_ADAGRAD>, gemm_dw_opt<DAE_OPT_MOMENTUM>, gemm_dw_opt<DAE_OPT_ADAM>};
     constexpr int ldsb = 2 * DWO_TILE_BYTES > lds_bytes_for(2) ? 2 * DWO_TILE_BYTES : lds_bytes_for(2);
@@ -1603,6 +1874,9 @@ int launch_gemm_trace(int dtype, int M, int N, const void* A0, int64_t lda0, con
 void set_use_glds(int nst) {
     if (nst == -1) { g_use_pc = 0; return; }          // A/B: 4-wave kernel for every grid
     if (nst == -2) { g_use_pc = 1; return; }
+    if (nst == -3) { g_dw_pc = 0; return; }          // A/B: dW on the 4-wave 128 x 128 kernel
+    if (nst == -4) { g_dw_pc = 1; return; }
+    if (nst == -5) { g_dw_pc = 2; return; }          // tests: the 160 x 128 kernel for every grid that fits one round
     g_nst = nst;
 }
 

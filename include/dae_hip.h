@@ -285,7 +285,8 @@ int dae_weighted_loss_rows(const float* x, int64_t ldx, const float* y, int64_t 
 
 /* A/B switch for the plain GEMM's staging: 0 = register staging (2 LDS buffers), 2/3/4 = depth of the
  * global_load_lds ring with counted vmcnt waits (default 2); -1 / -2 = 4-wave kernel for every grid / 8-wave
- * producer-consumer kernel for grids of at most one workgroup per CU (default). */
+ * producer-consumer kernel for grids of at most one workgroup per CU (default); -3 / -4 / -5 = dW + optimizer on the 4-wave
+ * 128 x 128 kernel / on the 8-wave 160 x 128 kernel when its grid fills one round of the chip (default) / whenever it fits. */
 void dae_set_glds(int32_t nst);
 
 /* ---------------------------------------------------------------------------------------------

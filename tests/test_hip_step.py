@@ -169,6 +169,26 @@ def test_fused_optimizer_equals_separate_kernel(opt):
         assert _rel(u, np.asarray(v, np.float64)) < 1e-6
 
 
+@pytest.mark.parametrize("opt", ["gradient_descent", "ada_grad", "momentum", "adam"])
+def test_dw_producer_consumer_kernel_equals_four_wave_kernel(opt):
+    """dW + optimizer on 160 x 128 tiles (8-wave producer/consumer, partial last row tile: Fp = 768 = 4 x 160 + 128) against
+    the 4-wave 128 x 128 kernel: same bf16 operands, same fp32 accumulation order along K -> identical parameters."""
+    from dae_rnn_news_recommendation_amd import _lib as L
+    lib = L.load()
+    try:
+        lib.dae_set_glds(-3)
+        a, _, pa = _run_case("bf16", "batch_all", "cross_entropy", ("sigmoid", "sigmoid"), opt, steps=3, seed=21)
+        lib.dae_set_glds(-5)
+        b, _, pb = _run_case("bf16", "batch_all", "cross_entropy", ("sigmoid", "sigmoid"), opt, steps=3, seed=21)
+    finally:
+        lib.dae_set_glds(-4)
+    for (_, sa, dWa, dbha, dbva), (_, sb, dWb, dbhb, dbvb) in zip(a, b):
+        assert np.allclose(sa[:5], sb[:5], rtol=1e-6, atol=0)
+        assert _rel(dWa, dWb.astype(np.float64)) < 1e-6
+    for u, v in zip(pa, pb):
+        assert _rel(u, np.asarray(v, np.float64)) < 1e-6
+
+
 def test_phase3_updates_like_phase0():
     """phase 3 (no W-gradient image) must leave the same parameters as phase 0."""
     from dae_rnn_news_recommendation_amd import _lib as L
