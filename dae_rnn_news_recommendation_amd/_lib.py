@@ -78,6 +78,8 @@ SIGNATURES = {
     "dae_gram": (i32, [vp, i64, i32, i32, vp, i32, vp]),
     "dae_label_stats": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp, f32, vp, vp]),
     "dae_triplet_batch_all": (i32, [vp, i32, i64, i64, vp, i32, i32, i32, vp, vp, vp, vp, vp]),
+    "dae_triplet_batch_all_rows": (i32, [vp, i32, i64, i64, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
+    "dae_triplet_batch_hard_rows": (i32, [vp, i32, i64, i64, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp]),
     "dae_triplet_batch_hard": (i32, [vp, i32, i64, i64, vp, i32, i32, vp, vp, vp, vp, vp]),
     "dae_triplet_finalize": (i32, [i32, i32, i32, i32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "dae_sym_scale": (i32, [vp, i32, i32, vp, i32, vp, vp]),

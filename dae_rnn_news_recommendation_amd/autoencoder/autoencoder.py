@@ -42,7 +42,7 @@ class DenoisingAutoencoder(object):
                  xavier_init=1, opt='gradient_descent', learning_rate=0.01, momentum=0.5, corr_type='none',
                  corr_frac=0., verbose=True, verbose_step=5, seed=-1, alpha=1, triplet_strategy='batch_all',
                  *, precision='bf16', rng='numpy', init_weights=None, device=None, data_parallel=False,
-                 dp_grad_dtype='fp32', results_root='results/'):
+                 dp_grad_dtype='fp32', dp_mining='local', results_root='results/'):
         self.algo_name = algo_name
         self.model_name = model_name
         self.compress_factor = compress_factor
@@ -69,6 +69,8 @@ class DenoisingAutoencoder(object):
         self.device = device
         self.data_parallel = data_parallel
         self.dp_grad_dtype = dp_grad_dtype       # 'fp32' | 'bf16': element type of the gradient in the reduce-scatter (data parallel)
+        self.dp_mining = dp_mining               # data parallel + triplet strategy: 'local' (each rank mines its shard) | 'global'
+        assert self.dp_mining in ('local', 'global')
         self.results_root = results_root
 
         assert type(self.verbose_step) == int                      # reference :68
@@ -186,11 +188,12 @@ class DenoisingAutoencoder(object):
             W0 = dp.broadcast_array(np.asarray(W0, np.float32))
             bh0 = dp.broadcast_array(np.zeros(self.n_components, np.float32) if bh0 is None else np.asarray(bh0, np.float32))
             bv0 = dp.broadcast_array(np.zeros(n_features, np.float32) if bv0 is None else np.asarray(bv0, np.float32))
-            if self.triplet_strategy != 'none' and rank == 0:
+            if self.triplet_strategy != 'none' and self.dp_mining == 'local' and rank == 0:
                 import warnings
                 warnings.warn("data_parallel with triplet_strategy=%r mines WITHIN each rank's shard of the mini-batch "
                               "(SURVEY 8e mode ii): this is the reference objective at batch size B/world on a different row "
-                              "order, not the reference at batch size B" % (self.triplet_strategy,))
+                              "order, not the reference at batch size B; dp_mining='global' mines over the all-gathered batch" %
+                              (self.triplet_strategy,))
         eng.set_params(W0, bh0, bv0)
         if restore_previous_model:
             self._restore(self.model_path)
@@ -199,6 +202,9 @@ class DenoisingAutoencoder(object):
         if world > 1:
             from .. import dp
             self._exchange = dp.ShardedExchange(eng, grad_dtype=self.dp_grad_dtype)
+            self._miner = None
+            if self.triplet_strategy != 'none' and self.dp_mining == 'global':
+                self._miner = dp.GlobalMiner(eng, self.triplet_strategy, float(self.alpha), batch)
 
         self._train_model(train_set, validation_set, train_set_label, validation_set_label)
         if world > 1:
@@ -301,7 +307,20 @@ class DenoisingAutoencoder(object):
                 lo, hi = start, stop
             rows = order_dev[lo:hi]
             labs = None if labels_dev is None else labels_dev[lo:hi]
-            if world > 1:
+            if world > 1 and getattr(self, '_miner', None) is not None:
+                # global-batch mining: encode my rows, mine over the all-gathered batch, resume; the ranks' gradients SUM to
+                # the gradient of the reference cost at the global batch size
+                if hi > lo:
+                    eng.train_step(rows, labs, stats[b], phase=4, **plan)
+                tl, fr, num = self._miner.mine(label_ids[order[start:stop]], start, stop)
+                if hi > lo:
+                    eng.train_step(rows, labs, stats[b], phase=5, **plan)
+                else:
+                    eng.grad.zero_()
+                    stats[b].zero_()
+                stats[b, L.STAT_TRIPLET] = tl; stats[b, L.STAT_FRACTION] = fr; stats[b, L.STAT_NUM] = num
+                self._exchange.step(grad_scale=1.0)
+            elif world > 1:
                 # the global-batch mean is sum_r (rows_r / rows) * mean_r: every rank's gradient (and statistics) is weighted
                 # by its share of the rows, so ragged tails (37 rows on 4 ranks = 10/10/10/7) and empty shards stay exact
                 w = (hi - lo) / float(stop - start)
@@ -316,7 +335,12 @@ class DenoisingAutoencoder(object):
                 self._exchange.step(grad_scale=1.0 / world)   # reduce-scatter -> sharded optimizer -> all-gather of W_lo
             else:
                 eng.train_step(rows, labs, stats[b], phase=3, **plan)
-        if world > 1:                                                   # statistics of the GLOBAL batches, on every rank
+        if world > 1 and getattr(self, '_miner', None) is not None:      # AE legs add up (cw is globally normalised); triplet stats are global
+            ae = stats[:, L.STAT_AE].clone()
+            dp.allreduce_sum_(ae)
+            stats[:, L.STAT_AE] = ae
+            stats[:, L.STAT_COST] = ae + float(self.alpha) * stats[:, L.STAT_TRIPLET]
+        elif world > 1:                                                 # statistics of the GLOBAL batches, on every rank
             wt = torch.tensor(shard_w, dtype=torch.float32, device=eng.device)[:, None]
             stats.mul_(wt)
             dp.allreduce_sum_(stats)

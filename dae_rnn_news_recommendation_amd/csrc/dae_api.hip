@@ -378,6 +378,11 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     const int B = s->B, Bp = (int)pad128(B), F = p->F, H = p->H, Fp = p->Fp, Hp = p->Hp, ldB = p->Bpm, dt = c.dtype;
     const bool is_cos = c.loss_func == DAE_LOSS_COSINE;
     const bool backward = s->phase != 2;
+    // phases 4 / 5 split the step around an EXTERNAL miner (data parallel with global-batch mining, dp.GlobalMiner): phase 4
+    // stops after the encode (h_f32 / h_lo / h_t and the side images stay in the workspace); the caller mines over the
+    // all-gathered batch and writes the row weights (cw), the triplet scalars and d(triplet)/dh (dh_extra) into the plan's
+    // buffers; phase 5 resumes at the decode and ends like phase 1 (gradients in the flat buffer).
+    const bool h_only = s->phase == 4, resume = s->phase == 5, ext_mine = h_only || resume;
 
     // 1-2. corrupt + gather  (K0/K1 front half)
     // x~^T: the CSR gather only scatters kept entries, so the image must be zero beforehand.  The step tail un-scatters
@@ -387,10 +392,10 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     // label statistics (cw, N_valid, data weights) depend on the labels alone: they ride on the CSR gather launch
     LabelJob lj{s->labels, B, Bp, c.triplet, p->nvalid, p->dw_i64, p->cw, c.alpha, p->tri_scalars};
     // ... on the encode GEMM's launch when that grid leaves a CU free (else on the CSR gather's, else their own)
-    const bool label_with_encode = p->tail_ok && !explicit3 && Bp <= 1024 && p->label_enc_ok;
-    const bool label_in_gather = p->tail_ok && !label_with_encode && !explicit3 && !s->c_indptr && p->b.indptr && Bp <= 1024;
+    const bool label_with_encode = p->tail_ok && !explicit3 && !ext_mine && Bp <= 1024 && p->label_enc_ok;
+    const bool label_in_gather = p->tail_ok && !label_with_encode && !explicit3 && !ext_mine && !s->c_indptr && p->b.indptr && Bp <= 1024;
     const bool tail = p->tail_ok;
-    if (backward && csr_in && !(tail && p->xct_clean)) PROF(PS_MEMSET, memset_async(p->xct, (size_t)Fp * ldB * p->es, st));
+    if (!resume && backward && csr_in && !(tail && p->xct_clean)) PROF(PS_MEMSET, memset_async(p->xct, (size_t)Fp * ldB * p->es, st));
     if (backward) p->xct_clean = false;
     float* rowsq = is_cos ? p->cos_stats : nullptr;
     bool use_bits = false;
@@ -399,8 +404,10 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     const bool use_sparse = p->sparse_ok && csr_in;
     const int64_t slab = (int64_t)Bp * Hp;
     int enc_label_done = 0;
-    bool labels_done = false;                  // label statistics already produced by a workgroup of an earlier launch
-    if (use_sparse) {
+    bool labels_done = ext_mine;               // label statistics already produced by a workgroup of an earlier launch (or by the caller)
+    if (resume) {
+        // h and the side images are those of the preceding phase-4 call
+    } else if (use_sparse) {
         // CSR input: corrupt + gather + encode in one launch on the stored entries (tf.sparse.matmul, autoencoder.py:377,389);
         // the dense x~ image is never formed.  The clean rows reach the decode epilogue as a bit image written by the same
         // launch (binary data) or as a dense tile from the gather kernel (valued data / explicitly corrupted copy).
@@ -448,9 +455,12 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
                                            p->gram_split ? p->hcat_a : nullptr, p->gram_split ? p->hcat_b : nullptr, stream));
         labels_done = (label_in_gather && !s->c_indptr) || enc_label_done;
     }
+    if (h_only) return 0;
     // 5-6. miners (K5-K7)
     const int Bt = explicit3 ? B / 3 : B;
-    if (explicit3) {
+    if (ext_mine) {
+        // mined by the caller
+    } else if (explicit3) {
         PROF(PS_LABEL, dae_label_stats(nullptr, Bt, Bp, DAE_TRIPLET_NONE, nullptr, nullptr, nullptr, nullptr, p->cw, 0.f, nullptr, stream));
         // every one of the 3*Bt stacked rows carries weight 1/(Bt + 1e-16): three unweighted row means (:303-305)
         DAE_CHECK_HIP(hipMemcpyAsync(p->cw + Bt, p->cw, (size_t)Bt * 4, hipMemcpyDeviceToDevice, st));
@@ -460,8 +470,8 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
         PROF(PS_LABEL, dae_label_stats(s->labels, B, Bp, c.triplet, p->n_same, p->acc, p->nvalid, p->dw_i64, p->cw, c.alpha, p->tri_scalars, stream));
     }
     bool forked = false;
-    const bool fold_finalize = (c.triplet == DAE_TRIPLET_BATCH_ALL && !c.pos_triplets_only);
-    if (c.triplet == DAE_TRIPLET_BATCH_ALL || c.triplet == DAE_TRIPLET_BATCH_HARD) {
+    const bool fold_finalize = (c.triplet == DAE_TRIPLET_BATCH_ALL && !c.pos_triplets_only) && !ext_mine;
+    if (!ext_mine && (c.triplet == DAE_TRIPLET_BATCH_ALL || c.triplet == DAE_TRIPLET_BATCH_HARD)) {
         const int64_t dslab = (int64_t)Bp * Bp;
         // batch_all (all valid triplets): cw comes from the labels alone -> the miner chain and the decode kernel are
         // independent until dL/dh; fork the chain onto the side stream (never while profiling: events are per stream)
@@ -523,7 +533,7 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     // 8. statistics of this step (autoencoder.py:233 fetch list)
     StatsArgs sa{is_cos ? p->rowloss_part : nullptr, 1, is_cos ? nullptr : p->tile_part, (Bp / 128) * (Fp / dbn), p->cw, B, Bp,
                  c.triplet == 3 ? DAE_TRIPLET_BATCH_HARD : c.triplet, c.alpha, p->tri_scalars,
-                 c.triplet == DAE_TRIPLET_BATCH_ALL ? p->nvalid : nullptr, s->stats, fold_finalize ? p->loss_part : nullptr,
+                 (c.triplet == DAE_TRIPLET_BATCH_ALL && !ext_mine) ? p->nvalid : nullptr, s->stats, fold_finalize ? p->loss_part : nullptr,
                  fold_finalize ? p->cnt_part : nullptr};
     const bool stats_in_tail = backward && tail;     // rides on the step-tail launch after the dW GEMM
     if (!stats_in_tail)
@@ -531,10 +541,10 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
                                       sa.nvalid, sa.loss_part, sa.cnt_part, s->stats, stream));
     if (!backward) return 0;
     // 9-10. dL/dh = delta2 W + alpha (G+G^T) h ; delta1                     (K8)
-    const bool mined = (c.triplet == DAE_TRIPLET_BATCH_ALL || c.triplet == DAE_TRIPLET_BATCH_HARD);
+    const bool mined = !ext_mine && (c.triplet == DAE_TRIPLET_BATCH_ALL || c.triplet == DAE_TRIPLET_BATCH_HARD);
     PROF(PS_DH_GEMM, launch_gemm_f32out(dt, Bp, Hp, p->delta2, Fp, p->b.Wt_lo, Fp, Fp, mined ? p->Gs : nullptr, Bp, mined ? p->h_t : nullptr, ldB,
                           mined ? Bp : 0, p->slabs, Hp, p->s_dh, slab, st, GEMM_ROLE_DH));
-    PROF(PS_DH_FIN, dae_dh_finish(p->slabs, p->s_dh, slab, Hp, explicit3 ? p->dh_extra : nullptr, p->h_f32, Hp, p->b.bh, B, H, c.enc_act, dt,
+    PROF(PS_DH_FIN, dae_dh_finish(p->slabs, p->s_dh, slab, Hp, (explicit3 || ext_mine) ? p->dh_extra : nullptr, p->h_f32, Hp, p->b.bh, B, H, c.enc_act, dt,
                      p->delta1_t, ldB, p->colsum_part, nullptr, stream));
     // 11. dW = x~^T delta1 + delta2^T h                                      (K8, tied weights)
     // phase 0 / 3 in bf16 mode: the optimizer runs in the dW GEMM's epilogue (phase 3 does not materialise the W gradient)
@@ -565,7 +575,7 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
                                      fuse_bias ? 1 : 0, c.opt, plan_lr(p, s->adam_t), c.momentum, s->grad_scale, p->b.bv,
                                      p->b.opt_s1 ? p->b.opt_s1 + boff : nullptr, p->b.opt_s2 ? p->b.opt_s2 + boff : nullptr, stream));
     }
-    if (s->phase == 1 || fuse_opt) return 0;
+    if (s->phase == 1 || s->phase == 5 || fuse_opt) return 0;
     // 13. optimizer (K9): W (+ shadows); biases were updated above
     PROF(PS_OPT, dae_opt_step(c.opt, plan_lr(p, s->adam_t), c.momentum, s->grad_scale, p->b.W, p->b.bh, p->b.bv, p->b.grad, p->b.opt_s1,
                               p->b.opt_s2, Fp, Hp, dt, p->b.W_lo, p->b.Wt_lo, /*apply=*/2, stream));

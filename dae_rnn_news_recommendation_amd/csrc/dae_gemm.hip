@@ -731,7 +731,11 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_dw_pc(GemmParams p, OptEpi
     if (l >= per * p.tiles_n || tm >= p.tiles_m) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef DAE_DW_PROBE
+    const int nk = (DAE_DW_PROBE & 1) ? 1 : p.ktiles_total;                 // probe: one K tile only
+#else
     const int nk = p.ktiles_total;
+#endif
     const int row0_m = tm * DW_BM, row0_n = tn * BN;
 
     if (wave8 >= 4) {
@@ -794,8 +798,12 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_dw_pc(GemmParams p, OptEpi
         const int g = lane >> 5, c = lane & 31;
         float* __restrict__ Wp = e.W;
         // master weights of this lane's 80 elements, requested before the K loop (plain SGD; see gemm_dw_opt)
+#ifdef DAE_DW_PROBE
+        constexpr bool PREFETCH_W = (OPT == DAE_OPT_SGD) && !(DAE_DW_PROBE & 8);   // probe: no master-weight read
+#else
         constexpr bool PREFETCH_W = (OPT == DAE_OPT_SGD);
-        float wv[DW_MB][16];
+#endif
+        float wv[DW_MB][16] = {};
         if constexpr (PREFETCH_W) {
 #pragma unroll
             for (int m = 0; m < DW_MB; ++m)
@@ -911,6 +919,9 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_dw_pc(GemmParams p, OptEpi
                         if (ok) { s1p[k] = mm; s2p[k] = vv; }
                         pn = p0 - lr * mm / (sqrtf(vv) + 1e-8f);
                     }
+#ifdef DAE_DW_PROBE
+                    if (!(DAE_DW_PROBE & 2))                                 // probe: no master-weight store
+#endif
                     if (ok) { Wp[k] = pn; if (gradp) gradp[k] = gr; }
                     pv[q] = pn;
                     *reinterpret_cast<bf16_t*>(R0 + lrow * DW_P0 + lcol * 2) = f2bf_hw(pn);
@@ -932,6 +943,9 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_dw_pc(GemmParams p, OptEpi
     __builtin_amdgcn_s_barrier();                                           // B2: both staged tiles are complete
     asm volatile("" ::: "memory");
     // ---- all 8 waves: coalesced 16-byte stores of the two shadow tiles ----
+#ifdef DAE_DW_PROBE
+    if (DAE_DW_PROBE & 4) return;                                           // probe: no shadow stores
+#endif
     {
         const char* R0 = lds;
         const char* R1 = lds + DW_BM * DW_P0;

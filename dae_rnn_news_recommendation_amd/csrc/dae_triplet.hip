@@ -247,7 +247,7 @@ __global__ __launch_bounds__(TRIP_THREADS, OCC) void batch_all_kernel(const floa
                                                                  int64_t slab_stride, int64_t ldd,
                                                                  const int32_t* __restrict__ labels, int B, int Bp,
                                                                  float* __restrict__ loss_part, uint32_t* __restrict__ npos_part,
-                                                                 float* __restrict__ G, uint32_t* __restrict__ role_cnt, int fast) {
+                                                                 float* __restrict__ G, uint32_t* __restrict__ role_cnt, int fast, int a0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // positives are compacted from the front of val[]/idx[], negatives from the back (nP + nN <= B)
     float* val = reinterpret_cast<float*>(smem);             // [Bp]
@@ -261,12 +261,14 @@ __global__ __launch_bounds__(TRIP_THREADS, OCC) void batch_all_kernel(const floa
     unsigned* cpos = POS_ONLY ? redu + 4 : nullptr;           // [Bp]    (pos_only role counts)
     unsigned* cneg = POS_ONLY ? cpos + Bp : nullptr;          // [4][Bp]
 
-    const int a = blockIdx.x;
+    // anchors [a0, a0 + gridDim.x) of the batch: row `ar` of D / G / the partial arrays belongs to batch element a = a0 + ar
+    // (a0 = 0 and a square D for a whole batch; a0 > 0 when a rank mines ITS anchors against an all-gathered batch)
+    const int ar = blockIdx.x, a = a0 + ar;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int32_t la = labels[a];
-    float* Grow = G + (int64_t)a * Bp;
-    uint32_t* Rrow = POS_ONLY ? role_cnt + (int64_t)a * Bp : nullptr;
+    float* Grow = G + (int64_t)ar * Bp;
+    uint32_t* Rrow = POS_ONLY ? role_cnt + (int64_t)ar * Bp : nullptr;
 
     // zero the gradient row (covers j == a and j >= B) and the positive-role accumulators
     // every j < B other than the anchor is a positive or a negative and is written at the end: only the anchor's own
@@ -302,7 +304,7 @@ __global__ __launch_bounds__(TRIP_THREADS, OCC) void batch_all_kernel(const floa
             float dd[4][KU];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const float* Drow = D_slabs + (int64_t)(s0 + u) * slab_stride + (int64_t)a * ldd;
+                const float* Drow = D_slabs + (int64_t)(s0 + u) * slab_stride + (int64_t)ar * ldd;
 #pragma unroll
                 for (int k = 0; k < KU; ++k) {
                     const int j = k * TRIP_THREADS + tid;
@@ -378,7 +380,7 @@ __global__ __launch_bounds__(TRIP_THREADS, OCC) void batch_all_kernel(const floa
             const unsigned long long lt = (1ull << lane) - 1ull;
             float d = 0.f;
             if (j < B)
-                for (int sl = 0; sl < d_splits; ++sl) d += D_slabs[(int64_t)sl * slab_stride + (int64_t)a * ldd + j];
+                for (int sl = 0; sl < d_splits; ++sl) d += D_slabs[(int64_t)sl * slab_stride + (int64_t)ar * ldd + j];
             if (isP) { const int o = beforeP + __popcll(bp & lt); pu[o] = d; pidx[o] = j; }
             if (isN) { const int o = beforeN + __popcll(bn & lt); nv[o] = d; nidx[o] = j; }
         }
@@ -478,7 +480,7 @@ __global__ __launch_bounds__(TRIP_THREADS, OCC) void batch_all_kernel(const floa
     }
     const float ltot = block_sum_f(loss, red);
     const unsigned ctot = block_sum_u(cnt, redu);
-    if (tid == 0) { loss_part[a] = ltot; npos_part[a] = ctot; }
+    if (tid == 0) { loss_part[ar] = ltot; npos_part[ar] = ctot; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -488,19 +490,19 @@ __global__ __launch_bounds__(TRIP_THREADS) void batch_hard_kernel(const float* _
                                                                   int64_t slab_stride, int64_t ldd,
                                                                   const int32_t* __restrict__ labels, int B, int Bp,
                                                                   float* __restrict__ loss_part, uint32_t* __restrict__ cnt_part,
-                                                                  int32_t* __restrict__ dw, float* __restrict__ G) {
+                                                                  int32_t* __restrict__ dw, float* __restrict__ G, int a0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* drow = reinterpret_cast<float*>(smem);            // [Bp]
     float* red = drow + Bp;                                   // [4]
     unsigned* redu = reinterpret_cast<unsigned*>(red + 4);    // [4]
-    const int a = blockIdx.x, tid = threadIdx.x;
+    const int ar = blockIdx.x, a = a0 + ar, tid = threadIdx.x;        // see batch_all_kernel
     const int32_t la = labels[a];
-    float* Grow = G + (int64_t)a * Bp;
+    float* Grow = G + (int64_t)ar * Bp;
 
     float mx = -INFINITY;
     for (int j = tid; j < B; j += TRIP_THREADS) {
         float d = 0.f;
-        for (int s = 0; s < d_splits; ++s) d += D_slabs[(int64_t)s * slab_stride + (int64_t)a * ldd + j];
+        for (int s = 0; s < d_splits; ++s) d += D_slabs[(int64_t)s * slab_stride + (int64_t)ar * ldd + j];
         drow[j] = d;
         mx = fmaxf(mx, d);
     }
@@ -555,8 +557,8 @@ __global__ __launch_bounds__(TRIP_THREADS) void batch_hard_kernel(const float* _
         Grow[j] = g;
     }
     if (tid == 0) {
-        loss_part[a] = cnt ? softplus_tf(dist) : 0.f;                        // :256
-        cnt_part[a] = cnt ? 1u : 0u;
+        loss_part[ar] = cnt ? softplus_tf(dist) : 0.f;                       // :256
+        cnt_part[ar] = cnt ? 1u : 0u;
     }
 }
 
@@ -567,6 +569,13 @@ using namespace dae;
 extern "C" int dae_triplet_batch_all(const float* D_slabs, int32_t d_splits, int64_t slab_stride, int64_t ldd,
                                      const int32_t* labels, int32_t B, int32_t Bp, int32_t mode, float* loss_part,
                                      uint32_t* npos_part, float* G, uint32_t* role_cnt, void* stream) {
+    return dae_triplet_batch_all_rows(D_slabs, d_splits, slab_stride, ldd, labels, B, Bp, 0, B, mode, loss_part, npos_part, G, role_cnt, stream);
+}
+
+extern "C" int dae_triplet_batch_all_rows(const float* D_slabs, int32_t d_splits, int64_t slab_stride, int64_t ldd,
+                                          const int32_t* labels, int32_t B, int32_t Bp, int32_t a0, int32_t n_anchors, int32_t mode,
+                                          float* loss_part, uint32_t* npos_part, float* G, uint32_t* role_cnt, void* stream) {
+    DAE_CHECK_ARG(a0 >= 0 && n_anchors > 0 && a0 + n_anchors <= B, "batch_all: anchors [%d, %d) outside the batch of %d", a0, a0 + n_anchors, B);
     const int pos_only = mode & DAE_MINER_POS_ONLY, fast = (mode & DAE_MINER_FAST) ? 1 : 0;
     DAE_CHECK_ARG(D_slabs && labels && loss_part && npos_part && G, "batch_all: null input");
     DAE_CHECK_ARG(B > 0 && B <= Bp && Bp <= TRIP_MAX_B, "batch_all: batch %d (padded %d) exceeds the supported %d", B, Bp, TRIP_MAX_B);
@@ -574,7 +583,7 @@ extern "C" int dae_triplet_batch_all(const float* D_slabs, int32_t d_splits, int
     // val + idx + 4 per-wave gradient rows (+ 4 count rows when pos_only) + scans + reductions
     const size_t lds = (size_t)Bp * (pos_only ? 52 : 32) + 2 * (TRIP_THREADS + 1) * sizeof(int) + 8 * sizeof(float);
     DAE_CHECK_ARG(lds <= 160 * 1024, "batch_all: batch %d needs %zu B of LDS (> 160 KiB)", B, lds);
-    typedef void (*ba_fn)(const float*, int, int64_t, int64_t, const int32_t*, int, int, float*, uint32_t*, float*, uint32_t*, int);
+    typedef void (*ba_fn)(const float*, int, int64_t, int64_t, const int32_t*, int, int, float*, uint32_t*, float*, uint32_t*, int, int);
     ba_fn k = pos_only ? batch_all_kernel<true, 3> : batch_all_kernel<false, 3>;      // 3 workgroups per CU (168 VGPRs)
     static bool attr_done = false;
     if (!attr_done) {
@@ -584,8 +593,8 @@ extern "C" int dae_triplet_batch_all(const float* D_slabs, int32_t d_splits, int
         attr_done = true;
     }
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k, dim3(B), dim3(TRIP_THREADS), lds, st, D_slabs, d_splits, slab_stride, ldd, labels, B, Bp, loss_part, npos_part, G,
-                       role_cnt, fast);
+    hipLaunchKernelGGL(k, dim3(n_anchors), dim3(TRIP_THREADS), lds, st, D_slabs, d_splits, slab_stride, ldd, labels, B, Bp, loss_part, npos_part, G,
+                       role_cnt, fast, a0);
     DAE_CHECK_LAUNCH();
     return 0;
 }
@@ -593,13 +602,20 @@ extern "C" int dae_triplet_batch_all(const float* D_slabs, int32_t d_splits, int
 extern "C" int dae_triplet_batch_hard(const float* D_slabs, int32_t d_splits, int64_t slab_stride, int64_t ldd,
                                       const int32_t* labels, int32_t B, int32_t Bp, float* loss_part, uint32_t* cnt_part,
                                       int32_t* dw, float* G, void* stream) {
+    return dae_triplet_batch_hard_rows(D_slabs, d_splits, slab_stride, ldd, labels, B, Bp, 0, B, loss_part, cnt_part, dw, G, stream);
+}
+
+extern "C" int dae_triplet_batch_hard_rows(const float* D_slabs, int32_t d_splits, int64_t slab_stride, int64_t ldd,
+                                           const int32_t* labels, int32_t B, int32_t Bp, int32_t a0, int32_t n_anchors,
+                                           float* loss_part, uint32_t* cnt_part, int32_t* dw, float* G, void* stream) {
+    DAE_CHECK_ARG(a0 >= 0 && n_anchors > 0 && a0 + n_anchors <= B, "batch_hard: anchors [%d, %d) outside the batch of %d", a0, a0 + n_anchors, B);
     DAE_CHECK_ARG(D_slabs && labels && loss_part && cnt_part && dw && G, "batch_hard: null input");
     DAE_CHECK_ARG(B > 0 && B <= Bp && Bp <= 4 * TRIP_MAX_B, "batch_hard: batch %d too large", B);
     hipStream_t st = (hipStream_t)stream;
     DAE_CHECK_HIP(hipMemsetAsync(dw, 0, (size_t)Bp * sizeof(int32_t), st));
     const size_t lds = (size_t)Bp * 4 + 64;
-    hipLaunchKernelGGL(batch_hard_kernel, dim3(B), dim3(TRIP_THREADS), lds, st, D_slabs, d_splits, slab_stride, ldd, labels, B, Bp,
-                       loss_part, cnt_part, dw, G);
+    hipLaunchKernelGGL(batch_hard_kernel, dim3(n_anchors), dim3(TRIP_THREADS), lds, st, D_slabs, d_splits, slab_stride, ldd, labels, B, Bp,
+                       loss_part, cnt_part, dw, G, a0);
     DAE_CHECK_LAUNCH();
     return 0;
 }

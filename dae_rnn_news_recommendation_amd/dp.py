@@ -171,6 +171,133 @@ class ShardedExchange:
         eng.W.copy_(full[:eng.Fp])
 
 
+class GlobalMiner:
+    """Global-batch triplet mining under data parallel (SURVEY 8e mode i): the reference objective at the GLOBAL batch size.
+
+    Per global mini-batch every rank
+      1. encodes ITS rows (Engine.train_step phase 4) and all-gathers the embeddings h (equal blocks of `per` rows; the
+         shards are contiguous, so the gathered rows [0, B_glob) are the global batch in order);
+      2. computes the rows of D = h h^T that belong to its anchors (exact-fp32 MFMA GEMM, dae_gemm_nt) and runs the miner on
+         them against ALL columns (dae_triplet_batch_{all,hard}_rows);
+      3. normalisers: N_valid and data_weight of batch_all are closed forms of the global label histogram (host integers);
+         batch_hard all-reduces its count and its data_weight vector; the loss sum is all-reduced;
+      4. dL/dh of its rows = scale * (G_loc h_all + reduce_scatter(G_loc^T h_loc)): G = dL/dD restricted to the rank's anchor
+         rows, (G + G^T) h split into the local product and the one exchanged by reduce-scatter (12.8 MB at 8 x 800 x 500);
+      5. writes cw / tri_scalars / dh_extra into the plan and resumes the step (phase 5).
+    The flat gradients of the ranks then SUM to the gradient of the global-batch cost (grad_scale = 1 in the exchange)."""
+
+    def __init__(self, eng, strategy, alpha, max_global_batch):
+        import ctypes as C
+        import torch
+        import torch.distributed as dist
+        from . import _lib as L
+        assert strategy in ("batch_all", "batch_hard")
+        self.eng, self.torch, self.dist, self.L, self.C = eng, torch, dist, L, C
+        self.strategy, self.alpha = strategy, float(alpha)
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        self.per_max = -(-int(max_global_batch) // self.world)
+        self.Mp = L.pad(self.per_max)
+        self.Gp = L.pad(self.per_max * self.world)
+        dev, Hp = eng.device, eng.Hp
+        z = lambda *shape, dtype=torch.float32: torch.zeros(shape, dtype=dtype, device=dev)
+        self.h_blocks = z(self.world * self.per_max, Hp)
+        self.h_all = z(self.Gp, Hp); self.h_allT = z(Hp, self.Gp)
+        self.h_loc = z(self.Mp, Hp); self.h_locT = z(Hp, self.Mp)
+        self.D = z(self.Mp, self.Gp); self.G = z(self.Mp, self.Gp); self.GT = z(self.Gp, self.Mp)
+        self.T1 = z(self.Mp, Hp); self.T2 = z(self.Gp, Hp); self.T2blk = z(self.world * self.per_max, Hp); self.rs = z(self.per_max, Hp)
+        self.loss_part = z(self.Mp); self.cnt_part = z(self.Mp, dtype=torch.int32); self.dw = z(self.Gp, dtype=torch.int32)
+        self.role_cnt = None
+        self.cw = eng.buffer("cw", (eng.Bpm,), torch.float32)
+        self.dh_extra = eng.buffer("dh_extra", (eng.Bpm, Hp), torch.float32)
+        self.tri = eng.buffer("tri_scalars", (64,), torch.float32)
+        self.h_f32 = eng.buffer("h_f32", (eng.Bpm, Hp), torch.float32)
+
+    def _gemm(self, M, N, A, lda, Bt, ldb, K, Cm):
+        L = self.L
+        L.call("dae_gemm_nt", L.F32, M, N, L.ptr(A), lda, L.ptr(Bt), ldb, K, None, 0, None, 0, 0, L.ptr(Cm), N, 1, 0, L.current_stream())
+
+    def _transpose(self, src, rows, cols, dst):
+        L = self.L
+        L.call("dae_transpose_shadow", L.ptr(src), rows, cols, L.F32, L.ptr(dst), L.current_stream())
+
+    def mine(self, labels_host, start, stop):
+        """labels_host: int ids of the global batch rows [start, stop) (NumPy, identical on every rank).  Returns the global
+        (triplet_loss, fraction, num) after writing cw / dh_extra / tri_scalars for this rank's rows."""
+        torch, dist, L, eng = self.torch, self.dist, self.L, self.eng
+        Bg = stop - start
+        per = -(-Bg // self.world)
+        lo = min(Bg, self.rank * per); hi = min(Bg, lo + per)
+        nA = hi - lo
+        Hp, Gp, Mp = eng.Hp, self.Gp, self.Mp
+        labels = torch.from_numpy(np.ascontiguousarray(labels_host, dtype=np.int32)).to(eng.device)
+        # 1. all-gather the embeddings (equal blocks of `per_max` rows; only the first `per` of a block are used)
+        self.h_loc.zero_()
+        if nA:
+            self.h_loc[:nA] = self.h_f32[:nA]
+        dist.all_gather_into_tensor(self.h_blocks.view(-1), self.h_loc[:self.per_max].contiguous().view(-1))
+        self.h_all.zero_()
+        hb = self.h_blocks.view(self.world, self.per_max, Hp)
+        for r in range(self.world):
+            r0 = min(Bg, r * per); r1 = min(Bg, r0 + per)
+            if r1 > r0:
+                self.h_all[r0:r1] = hb[r, :r1 - r0]
+        # 2. D rows of my anchors, miner on them
+        self.G.zero_(); self.loss_part.zero_(); self.cnt_part.zero_()
+        loss_sum = torch.zeros(2, dtype=torch.float64, device=eng.device)
+        if nA:
+            self._gemm(Mp, Gp, self.h_loc, Hp, self.h_all, Hp, Hp, self.D)
+            if self.strategy == "batch_all":
+                L.call("dae_triplet_batch_all_rows", L.ptr(self.D), 1, 0, Gp, L.ptr(labels), Bg, Gp, lo, nA, 0, L.ptr(self.loss_part),
+                       L.ptr(self.cnt_part), L.ptr(self.G), None, L.current_stream())
+            else:
+                L.call("dae_triplet_batch_hard_rows", L.ptr(self.D), 1, 0, Gp, L.ptr(labels), Bg, Gp, lo, nA, L.ptr(self.loss_part),
+                       L.ptr(self.cnt_part), L.ptr(self.dw), L.ptr(self.G), L.current_stream())
+            loss_sum[0] = self.loss_part[:nA].double().sum(); loss_sum[1] = self.cnt_part[:nA].double().sum()
+        elif self.strategy == "batch_hard":
+            self.dw.zero_()
+        dist.all_reduce(loss_sum)
+        # 3. normalisers and row weights
+        lab = np.asarray(labels_host).astype(np.int64)
+        if self.strategy == "batch_all":
+            _, inv, cnt = np.unique(lab, return_inverse=True, return_counts=True)
+            n = cnt[inv].astype(np.int64)
+            S = int((cnt * (cnt - 1)).sum())
+            NV = int((cnt * (cnt - 1) * (Bg - cnt)).sum())                       # triplet_loss_utils.py:110-111 as a closed form
+            dw = 2 * (n - 1) * (Bg - n) + (S - n * (n - 1))                      # :129
+            N = float(NV)
+            cw = dw[lo:hi].astype(np.float64) / (3.0 * NV + 1e-16)
+            cw_t = torch.from_numpy(cw.astype(np.float32)).to(eng.device)
+            num = float(loss_sum[1].item()); frac = num / (NV + 1e-16)
+        else:
+            dist.all_reduce(self.dw)
+            dwf = self.dw[:Bg].float()
+            N = float(loss_sum[1].item())
+            cw_t = dwf[lo:hi] / (dwf.sum() + 1e-16)
+            num = N; frac = N / float(Bg)
+        tl = float(loss_sum[0].item()) / (N + 1e-16)
+        scale = self.alpha / (N + 1e-16)
+        # 4. dL/dh of my rows
+        self._transpose(self.h_all, Gp, Hp, self.h_allT)
+        self._transpose(self.h_loc, Mp, Hp, self.h_locT)
+        self._transpose(self.G, Mp, Gp, self.GT)
+        self._gemm(Mp, Hp, self.G, Gp, self.h_allT, Gp, Gp, self.T1)
+        self._gemm(Gp, Hp, self.GT, Mp, self.h_locT, Mp, Mp, self.T2)
+        self.T2blk.zero_()
+        tb = self.T2blk.view(self.world, self.per_max, Hp)
+        for r in range(self.world):
+            r0 = min(Bg, r * per); r1 = min(Bg, r0 + per)
+            if r1 > r0:
+                tb[r, :r1 - r0] = self.T2[r0:r1]
+        dist.reduce_scatter_tensor(self.rs.view(-1), self.T2blk.view(-1), op=dist.ReduceOp.SUM)
+        # 5. hand over to the resumed step
+        self.cw.zero_(); self.dh_extra.zero_()
+        if nA:
+            self.cw[:nA] = cw_t
+            self.dh_extra[:nA] = scale * (self.T1[:nA] + self.rs[:nA])
+        self.tri[1] = tl; self.tri[2] = frac; self.tri[3] = num
+        return tl, frac, num
+
+
 def shard_bounds(start, stop, world, r):
     """Contiguous shard [lo, hi) of the global mini-batch [start, stop) owned by rank r."""
     per = -(-(stop - start) // world)

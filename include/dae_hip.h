@@ -204,6 +204,13 @@ int dae_triplet_batch_all(const float* D_slabs, int32_t d_splits, int64_t slab_s
                           float* loss_part, uint32_t* npos_part, float* G, uint32_t* role_cnt,
                           void* stream);
 
+/* The same miner for the anchors [a0, a0 + n_anchors) of the batch only: row r of D_slabs / G / loss_part / npos_part belongs
+ * to batch element a0 + r, D is [n_anchors x ldd] (its columns are the WHOLE batch of B rows, labels[B] likewise).  This is what
+ * a data-parallel rank runs on ITS rows against the all-gathered embeddings (global-batch mining, SURVEY 8e mode i). */
+int dae_triplet_batch_all_rows(const float* D_slabs, int32_t d_splits, int64_t slab_stride, int64_t ldd,
+                               const int32_t* labels, int32_t B, int32_t Bp, int32_t a0, int32_t n_anchors, int32_t mode,
+                               float* loss_part, uint32_t* npos_part, float* G, uint32_t* role_cnt, void* stream);
+
 /* K7: batch_hard online miner (triplet_loss_utils.py:202-259) incl. its quirks.
  *   dist_a = max(hn_a - hp_a, 0); cnt_a = dist_a > 0;
  *   loss_part[a] = softplus(dist_a)*cnt_a;  cnt_part[a] = cnt_a;
@@ -212,6 +219,11 @@ int dae_triplet_batch_all(const float* D_slabs, int32_t d_splits, int64_t slab_s
 int dae_triplet_batch_hard(const float* D_slabs, int32_t d_splits, int64_t slab_stride, int64_t ldd,
                            const int32_t* labels, int32_t B, int32_t Bp,
                            float* loss_part, uint32_t* cnt_part, int32_t* dw, float* G, void* stream);
+
+/* batch_hard for the anchors [a0, a0 + n_anchors) only (see dae_triplet_batch_all_rows); dw[B] accumulates over all launches. */
+int dae_triplet_batch_hard_rows(const float* D_slabs, int32_t d_splits, int64_t slab_stride, int64_t ldd,
+                                const int32_t* labels, int32_t B, int32_t Bp, int32_t a0, int32_t n_anchors,
+                                float* loss_part, uint32_t* cnt_part, int32_t* dw, float* G, void* stream);
 
 /* Reduce miner partials into the normalisers / statistics:
  *   tri_scalars[0] = alpha / (N + 1e-16)  (N = N_valid | N_pos | sum cnt) -> scale of (G+G^T)
@@ -328,7 +340,13 @@ typedef struct {
     int32_t phase;               /* 0 = forward+backward+update, 1 = forward+backward only (DP:
                                     caller all-reduces `grad` then calls dae_plan_apply), 2 = forward only,
                                     3 = as 0 but the W part of `grad` is not materialised (bf16: the optimizer
-                                    runs in the dW GEMM's epilogue and nothing reads the gradient image) */
+                                    runs in the dW GEMM's epilogue and nothing reads the gradient image),
+                                    4 / 5 = the step split around an EXTERNAL miner (data parallel, global-batch mining):
+                                    4 stops after the encode (h_f32, h_lo, h_t and the side images stay in the workspace);
+                                    the caller mines over the all-gathered batch and writes the plan buffers `cw` (row
+                                    weights), `tri_scalars`[1..3] (triplet loss, fraction, num) and `dh_extra`
+                                    (d alpha*triplet / dh of its rows); 5 resumes at the decode with the same row_idx
+                                    and ends like 1 */
     int32_t adam_t; float grad_scale;
 } dae_step;
 

@@ -31,38 +31,38 @@ def _data():
     return m, lab, W0
 
 
-def _fit(tmp, strategy, opt, dp_flag, grad_dtype="fp32", seed=11):
+def _fit(tmp, strategy, opt, dp_flag, grad_dtype="fp32", seed=11, mining="local"):
     from dae_rnn_news_recommendation_amd.autoencoder import DenoisingAutoencoder
     m, lab, W0 = _data()
     model = DenoisingAutoencoder(model_name="dp", main_dir="dp%d" % os.getpid(), compress_factor=10, enc_act_func="sigmoid",
                                  dec_act_func="sigmoid", loss_func="cross_entropy", num_epochs=2, batch_size=37, opt=opt,
                                  learning_rate=0.05, momentum=0.5, corr_type="masking", corr_frac=0.3, verbose=0, verbose_step=1,
                                  seed=seed, alpha=1, triplet_strategy=strategy, precision="fp32", rng="numpy", init_weights=W0,
-                                 data_parallel=dp_flag, dp_grad_dtype=grad_dtype, results_root=tmp + "/")
+                                 data_parallel=dp_flag, dp_grad_dtype=grad_dtype, dp_mining=mining, results_root=tmp + "/")
     model.fit(m, train_set_label=lab if strategy != "none" else None)
     stats = np.stack([model.epoch_stats(e + 1)["per_batch"] for e in range(2)])
     return stats, model.engine.get_params()
 
 
-def _worker(rank, world, port, tmp, strategy, opt, grad_dtype, seed, out):
+def _worker(rank, world, port, tmp, strategy, opt, grad_dtype, seed, mining, out):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK="0")
     import torch
     from dae_rnn_news_recommendation_amd import dp
     torch.cuda.set_device(0)
     dp.init_from_env("gloo")
-    stats, params = _fit(tmp, strategy, opt, True, grad_dtype, seed)
+    stats, params = _fit(tmp, strategy, opt, True, grad_dtype, seed, mining)
     out[rank] = (stats, params)
     dp.barrier()
     torch.distributed.destroy_process_group()
 
 
-def _run_dp(tmp, strategy, opt, grad_dtype="fp32", seed=11):
+def _run_dp(tmp, strategy, opt, grad_dtype="fp32", seed=11, mining="local"):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     mgr = ctx.Manager(); out = mgr.dict()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, tmp, strategy, opt, grad_dtype, seed, out)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, tmp, strategy, opt, grad_dtype, seed, mining, out)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
@@ -114,3 +114,20 @@ def test_fit_two_ranks_local_mining_runs(tmp_path):
     assert np.isfinite(out[0][0]).all()
     assert np.array_equal(out[0][1][0], out[1][1][0])
     assert out[0][0][1, :, 0].mean() < out[0][0][0, :, 0].mean()
+
+
+@pytest.mark.parametrize("strategy", ["batch_all", "batch_hard"])
+def test_fit_two_ranks_global_mining_equals_one_rank(tmp_path, strategy):
+    """dp_mining='global' (SURVEY 8e mode i): every rank mines ITS anchors against the all-gathered embeddings, the (G + G^T) h
+    cross term is exchanged by reduce-scatter, normalisers come from the global batch -- two ranks reproduce ONE rank at the
+    global batch size: triplet loss, AE loss (globally normalised data weights), counts and parameters."""
+    ref_stats, ref_p = _fit(str(tmp_path), strategy, "gradient_descent", False)
+    out = _run_dp(str(tmp_path), strategy, "gradient_descent", mining="global")
+    for r in range(2):
+        stats, p = out[r]
+        assert _rel(stats[..., 2], ref_stats[..., 2]) < 2e-5, (stats[..., 2], ref_stats[..., 2])      # triplet loss
+        assert _rel(stats[..., 1], ref_stats[..., 1]) < 2e-5 and _rel(stats[..., 0], ref_stats[..., 0]) < 2e-5
+        assert np.abs(stats[..., 4] - ref_stats[..., 4]).max() <= 2                                 # num (near-tie flips of the fp32 Gram)
+        for a, b in zip(p, ref_p):
+            assert _rel(a, b) < 5e-5
+    assert np.array_equal(out[0][1][0], out[1][1][0])
