@@ -1,23 +1,32 @@
 #!/usr/bin/env python3
 """bench.py -- training samples/sec of the DAE hot path on MI355X (BASELINE.json's metric).
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--config c1|c2|c3|c4|c5]
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
 
-A "step" is one mini-batch pass of the hot path (corrupt+gather -> encode -> batch_all miner -> decode +
-loss -> backward GEMMs -> SGD update) over B=800 rows of the HBM-resident synthetic train set; every 10th
-step also pays the per-epoch host work (new permutation; in --rng numpy mode the reference-exact keep-bit
-draw).  Workload at N=1 = BASELINE.json configs[1]: synthetic 8000x10000 binary CSR (~200 nnz/row),
-compress_factor 20 (H=500), batch_all, bf16 MFMA operands, masking 0.3, SGD lr 0.1.  N>1: weak scaling --
-every rank owns its own 8000-row shard and a B=800 local batch (configs[2]'s sharding), gradients are
-all-reduced with RCCL every step, mining is per rank.
+A "step" is one mini-batch pass of the hot path (corrupt + gather + encode -> miner -> decode + loss -> backward GEMMs ->
+optimizer) over one batch of the HBM-resident synthetic train set; every 10th step also pays the per-epoch host work (new
+permutation; in --rng numpy mode the reference-exact keep-bit draw, prepared one epoch ahead by a feeder thread).
 
-Prints ONE JSON line (rank 0).  `roofline` comes from HIP events recorded on the step's stream around each
-kernel (dae_plan_profile), in a second pass so that `value` is never measured with profiling on;
-`cpu_baseline` times the NumPy oracle ("port" of the reference arithmetic; TF 1.12 cannot run here) on a
-bounded sample of the same workload.
+Workloads (BASELINE.json configs; SURVEY.md 8(d) inputs), --config:
+  c2 (default, the headline): synthetic 8000x10000 binary CSR (~200 nnz/row), compress_factor 20 (H=500), B=800, batch_all,
+     masking 0.3, cross_entropy, SGD lr 0.1, bf16 MFMA operands + fp32 accumulate / master weights.
+  c1: same matrix, --triplet_strategy none (the reference's CPU-runnable case).
+  c3: batch_hard + 4 category labels, 8000 rows and B=800 per rank (64000 rows over 8 ranks: weak scaling).
+  c4: dense fp32 tf-idf ndarray 8000x50000, compress_factor 50 (H=1000), cross_entropy, alpha 1, batch_all -- HBM roofline.
+  c5: explicit (anchor, pos, neg) triplets, 3 x 8000x10000 tf-idf CSR per rank, cosine_proximity, B=800 triplets (2400 rows).
+N > 1: weak scaling -- every rank owns its own shard and a local batch; per step the ranks reduce-scatter the W gradient, run
+the optimizer on their row chunk, all-gather the bf16 shadow and rebuild its transpose locally (dp.ShardedExchange); mining is
+per rank (SURVEY 8e mode ii).
+
+Prints ONE JSON line (rank 0).  `kernels` / `roofline` come from HIP events recorded on the step's stream around each kernel
+(dae_plan_profile), in a second pass so that `value` is never measured with profiling on; `fit` is the same workload through
+DenoisingAutoencoder.fit() (N * timed epochs / wall, first epoch excluded); `cpu_baseline` times the PyTorch-CPU fp32
+restatement of the reference step (oracle/torch_baseline.py; TF 1.12 cannot run here) on a bounded sample.
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -32,6 +41,20 @@ if ROOT not in sys.path:
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, MI355X_MICROARCH.md
 PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
+PEAK_VALU_TLANEOPS = 78.6      # 256 CUs x 4 SIMDs x 32 lanes/clk x 2.4 GHz (one fp32 VALU op per lane per clock)
+
+CONFIGS = {
+    "c1": dict(rows=8000, features=10000, cf=20, batch=800, strategy="none", kind="csr_binary", loss="cross_entropy",
+               baseline="configs[0]: UCI-shape 8000x10000 binary CSR, plain DAE, batch 800"),
+    "c2": dict(rows=8000, features=10000, cf=20, batch=800, strategy="batch_all", kind="csr_binary", loss="cross_entropy",
+               baseline="configs[1]: synthetic 8000x10000 CSR, compress_factor 20, batch_all, bf16"),
+    "c3": dict(rows=8000, features=10000, cf=20, batch=800, strategy="batch_hard", kind="csr_binary", loss="cross_entropy",
+               baseline="configs[2]: 64000x10000 CSR over 8 ranks (8000 rows / rank), batch_hard + category labels"),
+    "c4": dict(rows=8000, features=50000, cf=50, batch=800, strategy="batch_all", kind="dense_tfidf", loss="cross_entropy",
+               baseline="configs[3]: 8000x50000 tf-idf dense ndarray, compress_factor 50, cross_entropy + alpha=1"),
+    "c5": dict(rows=8000, features=10000, cf=20, batch=800, strategy="explicit", kind="csr_tfidf", loss="cosine_proximity",
+               baseline="configs[4]: explicit (anchor,pos,neg) path, 3x32000x10000 over 4 ranks (8000 rows / rank), cosine_proximity"),
+}
 
 
 def parse():
@@ -39,20 +62,49 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--rows", type=int, default=8000)
-    ap.add_argument("--features", type=int, default=10000)
-    ap.add_argument("--compress-factor", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=800)
-    ap.add_argument("--strategy", default="batch_all", choices=["batch_all", "batch_hard", "none"])
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--rows", type=int, default=0)
+    ap.add_argument("--features", type=int, default=0)
+    ap.add_argument("--compress-factor", type=int, default=0)
+    ap.add_argument("--batch", type=int, default=0)
+    ap.add_argument("--strategy", default="", choices=["", "batch_all", "batch_hard", "none"])
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--rng", default="philox", choices=["philox", "numpy"])
+    ap.add_argument("--grad-dtype", default="fp32", choices=["fp32", "bf16"], help="N>1: element type of the reduce-scattered gradient")
     ap.add_argument("--profile-steps", type=int, default=20)
+    ap.add_argument("--fit-epochs", type=int, default=6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-fit", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N>1 (nccl == RCCL; gloo only to exercise the N>1 code path on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="testing aid: every rank uses cuda:0")
-    return ap.parse_args()
+    a = ap.parse_args()
+    c = dict(CONFIGS[a.config])
+    for k, v in (("rows", a.rows), ("features", a.features), ("cf", a.compress_factor), ("batch", a.batch)):
+        if v:
+            c[k] = v
+    if a.strategy:
+        c["strategy"] = a.strategy
+    a.cfg = c
+    return a
+
+
+def make_data(c, rank):
+    """Seeded synthetic inputs of the config's shape.  Returns (train_set, labels or None)."""
+    from scipy import sparse
+    from dae_rnn_news_recommendation_amd.synthetic import synthetic_csr, synthetic_labels
+    N, F = c["rows"], c["features"]
+    labels = synthetic_labels(N, kind="category", seed=1234 + rank).astype(np.int32)
+    if c["kind"] == "csr_binary":
+        return synthetic_csr(N, F, nnz_per_row=200, seed=1234 + rank), labels
+    if c["kind"] == "dense_tfidf":
+        m = synthetic_csr(N, F, nnz_per_row=300, seed=1234 + rank, tfidf=True)
+        return np.ascontiguousarray(m.toarray(), dtype=np.float32), labels
+    if c["kind"] == "csr_tfidf":        # explicit triplets: org / pos / neg blocks
+        blocks = [synthetic_csr(N, F, nnz_per_row=200, seed=1234 + 10 * rank + k, tfidf=True) for k in range(3)]
+        return blocks, None
+    raise ValueError(c["kind"])
 
 
 class Runner:
@@ -60,95 +112,201 @@ class Runner:
 
     def __init__(self, a, rank, world):
         import torch
+        from scipy import sparse
         from dae_rnn_news_recommendation_amd import _lib as L
+        from dae_rnn_news_recommendation_amd.autoencoder.autoencoder import _EpochFeeder
         from dae_rnn_news_recommendation_amd.engine import Engine
-        from dae_rnn_news_recommendation_amd.synthetic import synthetic_csr, synthetic_labels, xavier_uniform
-        self.L, self.torch, self.a, self.rank, self.world = L, torch, a, rank, world
-        F, H = a.features, a.features // a.compress_factor
-        self.F, self.H, self.B, self.N = F, H, a.batch, a.rows
-        self.m = synthetic_csr(a.rows, F, nnz_per_row=200, seed=1234 + rank)
-        self.labels = synthetic_labels(a.rows, kind="category", seed=1234 + rank).astype(np.int32)
-        self.eng = Engine(F, H, a.batch, dtype=a.precision, enc_act="sigmoid", dec_act="sigmoid", loss_func="cross_entropy",
-                          opt="gradient_descent", learning_rate=0.1, alpha=1.0, triplet=a.strategy)
-        self.eng.upload_csr(self.m)
+        from dae_rnn_news_recommendation_amd.synthetic import xavier_uniform
+        c = a.cfg
+        self.L, self.torch, self.a, self.c, self.rank, self.world = L, torch, a, c, rank, world
+        F, H = c["features"], c["features"] // c["cf"]
+        self.F, self.H, self.B, self.N = F, H, c["batch"], c["rows"]
+        self.explicit = c["strategy"] == "explicit"
+        data, self.labels = make_data(c, rank)
+        self.eng = Engine(F, H, self.B * (3 if self.explicit else 1), dtype=a.precision, enc_act="sigmoid", dec_act="sigmoid",
+                          loss_func=c["loss"], opt="gradient_descent", learning_rate=0.1, alpha=1.0, triplet=c["strategy"],
+                          dp_world=world)
+        if self.explicit:
+            self.m = sparse.vstack(data).tocsr()
+            self.eng.upload_csr(self.m)
+        elif isinstance(data, np.ndarray):
+            self.m = data
+            self.eng.upload_dense(data)
+        else:
+            self.m = data
+            self.eng.upload_csr(data)
         self.eng.set_params(xavier_uniform(F, H, seed=42))
-        self.nb = -(-a.rows // a.batch)
+        self.exchange = None
+        if world > 1:
+            from dae_rnn_news_recommendation_amd import dp
+            self.exchange = dp.ShardedExchange(self.eng, grad_dtype=a.grad_dtype)
+        self.nb = -(-self.N // self.B)
         self.stats = torch.zeros((self.nb, L.STATS_STRIDE), dtype=torch.float32, device=self.eng.device)
         self.step_i = 0
         self.epoch = 0
         np.random.seed(0)
+        self.feeder = _EpochFeeder(self._draw, 1 << 30)
         self._prep_epoch()
+
+    def _draw(self, e):
+        """Host randomness of an epoch in the reference's order (keep decisions of the whole set, then the shuffle)."""
+        from dae_rnn_news_recommendation_amd.autoencoder import utils
+        d = {}
+        if self.a.rng == "numpy":
+            n = self.m.size if isinstance(self.m, np.ndarray) else self.m.nnz
+            d["bits"] = utils.pack_keep_bits(utils.masking_keep(n, 0.3)).view(np.int32)
+        d["order"] = utils.epoch_permutation(self.N)
+        return d
 
     def _prep_epoch(self):
         torch, L = self.torch, self.L
-        from dae_rnn_news_recommendation_amd.autoencoder import utils
+        d = self.feeder.get()
         if self.a.rng == "numpy":
-            keep = utils.masking_keep(self.m.nnz, 0.3)
-            self.bits = torch.from_numpy(utils.pack_keep_bits(keep).view(np.int32)).to(self.eng.device, non_blocking=True)
+            self.bits = torch.from_numpy(d["bits"]).to(self.eng.device, non_blocking=True)
             self.plan = dict(corr_mode=L.CORR_KEEPBITS, keep_bits=self.bits)
         else:
             self.plan = dict(corr_mode=L.CORR_PHILOX_MASK, seed=1234, rng_stream=self.epoch, corr_frac=0.3)
-        order = utils.epoch_permutation(self.N)
-        self.order = torch.from_numpy(order.astype(np.int32)).to(self.eng.device, non_blocking=True)
-        self.lab = torch.from_numpy(self.labels[order]).to(self.eng.device, non_blocking=True)
+        order = d["order"]
+        if self.explicit:
+            o = order.astype(np.int32)
+            self.order = torch.from_numpy(np.stack([o, o + self.N, o + 2 * self.N])).to(self.eng.device, non_blocking=True)
+            self.lab = None
+        else:
+            self.order = torch.from_numpy(order.astype(np.int32)).to(self.eng.device, non_blocking=True)
+            self.lab = torch.from_numpy(self.labels[order]).to(self.eng.device, non_blocking=True)
+
+    def batch(self, b):
+        lo = b * self.B
+        hi = min(self.N, lo + self.B)
+        if self.explicit:
+            return self.order[:, lo:hi].reshape(-1), None
+        return self.order[lo:hi], (self.lab[lo:hi] if self.c["strategy"] != "none" else None)
 
     def step(self):
         b = self.step_i % self.nb
         if b == 0 and self.step_i > 0:
             self.epoch += 1
             self._prep_epoch()
-        lo = b * self.B
-        hi = min(self.N, lo + self.B)
-        rows, labs = self.order[lo:hi], (self.lab[lo:hi] if self.a.strategy != "none" else None)
+        rows, labs = self.batch(b)
         if self.world > 1:
-            from dae_rnn_news_recommendation_amd import dp
             self.eng.train_step(rows, labs, self.stats[b], phase=1, **self.plan)
-            dp.allreduce_sum_(self.eng.grad)
-            self.eng.apply(grad_scale=1.0 / self.world)
+            self.exchange.step(grad_scale=1.0 / self.world)
         else:
             self.eng.train_step(rows, labs, self.stats[b], phase=3, **self.plan)
         self.step_i += 1
 
+    def close(self):
+        self.feeder.close()
+
+
+def fit_leg(a, rng):
+    """The same workload through the drop-in estimator: samples/s = N * timed epochs / wall, first epoch excluded."""
+    import tempfile
+    from dae_rnn_news_recommendation_amd.autoencoder import DenoisingAutoencoder, DenoisingAutoencoderTriplet
+    from dae_rnn_news_recommendation_amd.synthetic import xavier_uniform
+    c = a.cfg
+    data, labels = make_data(c, 0)
+    F, H = c["features"], c["features"] // c["cf"]
+    kw = dict(compress_factor=c["cf"], enc_act_func="sigmoid", dec_act_func="sigmoid", loss_func=c["loss"], num_epochs=a.fit_epochs,
+              batch_size=c["batch"], opt="gradient_descent", learning_rate=0.1, corr_type="masking", corr_frac=0.3, verbose=0,
+              verbose_step=1 << 20, seed=0, alpha=1, precision=a.precision, rng=rng, init_weights=xavier_uniform(F, H, seed=42))
+    with tempfile.TemporaryDirectory() as tmp:
+        if c["strategy"] == "explicit":
+            m = DenoisingAutoencoderTriplet(model_name="b", main_dir="b", results_root=tmp + "/", **kw)
+            m.fit({"org": data[0], "pos": data[1], "neg": data[2]})
+        else:
+            m = DenoisingAutoencoder(model_name="b", main_dir="b", triplet_strategy=c["strategy"], results_root=tmp + "/", **kw)
+            m.fit(data, train_set_label=labels if c["strategy"] != "none" else None)
+        st = m.epoch_stats(a.fit_epochs)
+    return {"samples_per_s": m.samples_per_sec, "epochs_timed": a.fit_epochs - 1, "final_cost": st["cost"], "final_ae": st["ae"],
+            "final_triplet": st["triplet"]}
+
 
 def cpu_baseline(a):
-    """The NumPy oracle (restated reference arithmetic) on a bounded sample: ONE step of the same workload."""
-    import oracle as O
-    from threadpoolctl import threadpool_limits
-    from dae_rnn_news_recommendation_amd.synthetic import synthetic_csr, synthetic_labels, xavier_uniform
-    F, H, B = a.features, a.features // a.compress_factor, a.batch
-    m = synthetic_csr(2 * B, F, nnz_per_row=200, seed=1234)
-    lab = synthetic_labels(2 * B, seed=1234)
-    W = xavier_uniform(F, H, seed=42); bh = np.zeros(H, np.float32); bv = np.zeros(F, np.float32)
-    np.random.seed(0)
+    """PyTorch-CPU fp32 restatement of the reference step on a bounded sample of the same workload: the literal
+    B^3-materialising batch_all for 2 steps (what a TF-CPU run pays) and the chunked form for one epoch."""
+    from oracle import torch_baseline as TB
+    from dae_rnn_news_recommendation_amd.synthetic import xavier_uniform
+    c = a.cfg
+    if c["strategy"] == "explicit":
+        return {"value": None, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port",
+                "sample": "not timed for the explicit-triplet configuration (the restated baseline covers configs c1-c4)"}
+    data, labels = make_data(dict(c, rows=2 * c["batch"]), 0)
+    F, H, B = c["features"], c["features"] // c["cf"], c["batch"]
     threads = os.cpu_count() or 1
-    with threadpool_limits(limits=threads):
-        t0 = time.time()
-        xc = O.masking_noise(m, 0.3)
-        idx = O.gen_batches_index(2 * B, B)[0]
-        r = O.forward_backward(W, bh, bv, m[idx], xc[idx], lab[idx], triplet_strategy=a.strategy, alpha=1.0, dt=np.float32)
-        st = O.OptState("gradient_descent", [W.shape, bh.shape, bv.shape])
-        O.opt_apply(st, [W, bh, bv], [r["dW"], r["dbh"], r["dbv"]], 0.1)
-        dt = time.time() - t0
-    return {"value": B / dt, "unit": "samples/s", "cores": threads, "kind": "port",
-            "sample": f"1 step of the same workload (B={B}, {F}x{H}, {a.strategy}, fp32 NumPy oracle incl. masking+shuffle "
-                      f"of a {2 * B}-row set); BLAS GEMMs use {threads} threads, the B^3 miner sweep is single-threaded NumPy; "
-                      f"{dt:.1f} s",
-            "seconds": dt, "cost": float(r["cost"])}
+    lit = 2 if c["strategy"] == "batch_all" else 0
+    t = TB.time_baseline(data, labels, xavier_uniform(F, H, seed=42), batch=B, strategy=c["strategy"], literal_steps=lit,
+                         chunked_steps=10 if F <= 10000 else 4, threads=threads)
+    main = t.get("literal", t["chunked"])
+    return {"value": main["samples_per_s"], "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": (f"PyTorch-CPU fp32 restatement of the reference step (oracle/torch_baseline.py; tensorflow 1.12 cannot run here), "
+                       f"{threads} threads, B={B}, {F}x{H}, {c['strategy']}, masking + shuffle of a {2 * B}-row set included: "
+                       + ("`value` = the literal form (B^3 tensors materialised as triplet_loss_utils.py:96-129 does), "
+                          f"{main['steps']} steps in {main['seconds']:.1f} s; " if "literal" in t else "")
+                       + f"chunked (memory-lean, same arithmetic) form: {t['chunked']['steps']} steps in {t['chunked']['seconds']:.1f} s"),
+            "literal": t.get("literal"), "chunked": t["chunked"]}
 
 
-def committed_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc pass (profiles/*_pmc_traffic.json; FETCH_SIZE is
-    doubled per the gfx950 correction of MI355X_MICROARCH.md).  PMC counters cannot be read from inside this process, so
-    this is the last committed measurement of the same workload, or None."""
-    import glob
+def source_hash():
+    """Hash of the kernel sources: the committed PMC traffic file must come from the same kernels."""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "dae_rnn_news_recommendation_amd", "csrc", "*.h*"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def committed_traffic(kernel, cfg_name):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/*_pmc_traffic.json; FETCH_SIZE doubled
+    per the gfx950 correction of MI355X_MICROARCH.md).  PMC counters cannot be read from inside this process; the file records
+    the hash of the kernel sources it was measured on -- a stale file is refused (None + reason) instead of being quoted."""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
     if not files:
-        return None
+        return None, "no committed PMC pass"
     try:
-        t = json.load(open(files[-1])).get(kernel)
-        return None if t is None else t["fetch_bytes"] + t["write_bytes"]
-    except Exception:
-        return None
+        t = json.load(open(files[-1]))
+    except Exception as e:        # noqa: BLE001
+        return None, "unreadable %s: %s" % (os.path.basename(files[-1]), e)
+    if t.get("_source_hash") != source_hash():
+        return None, "%s was measured on other kernel sources (hash %s, now %s): re-run tools/make_profile_report.sh" % (
+            os.path.basename(files[-1]), t.get("_source_hash"), source_hash())
+    if t.get("_config", "c2") != cfg_name or kernel not in t:
+        return None, "no PMC pass for %s / %s" % (cfg_name, kernel)
+    return t[kernel]["fetch_bytes"] + t[kernel]["write_bytes"], os.path.basename(files[-1])
+
+
+def kernel_table(a, prof, nsteps):
+    """Per-kernel averages + the roofline each kernel is priced against (algorithmic work per launch)."""
+    c = a.cfg
+    B, F, H = c["batch"] * (3 if c["strategy"] == "explicit" else 1), c["features"], c["features"] // c["cf"]
+    es = 2 if a.precision == "bf16" else 4
+    dense_in = c["kind"] == "dense_tfidf"
+    nnz_row = 300 if dense_in else 200
+    mfma = {"decode_loss": 2.0 * B * F * H, "dh_gemm": 2.0 * B * F * H + (2.0 * B * B * H if c["strategy"] in ("batch_all", "batch_hard") else 0),
+            "dw_gemm": 4.0 * B * F * H, "gram": 2.0 * B * B * H}
+    hbm = {}
+    if dense_in:      # dense ndarray: gather reads the fp32 rows, the encode GEMM runs on MFMA
+        mfma["encode_gemm"] = 2.0 * B * F * H
+        hbm["gather"] = B * F * 4.0 + 2.0 * B * F * es          # fp32 rows in, x~ and x~^T out (x stays fp32 in HBM)
+    else:             # CSR: the fused corrupt + gather + encode kernel reads the stored entries and W_lo once per XCD slice
+        hbm["encode_gemm"] = B * nnz_row * 8.0 + F * H * es + B * H * (4 + 3 * es)
+    peak_mfma = PEAK_F32_MFMA_TFLOPS if a.precision == "fp32" else PEAK_BF16_TFLOPS
+    kern = {}
+    tot = sum(ms for ms, n in prof.values())
+    for k, (ms, n) in prof.items():
+        if n == 0:
+            continue
+        us = 1e3 * ms / n
+        e = {"avg_us": us, "launches_per_step": n / nsteps, "time_share": ms / tot if tot else 0.0}
+        if k in mfma:
+            e.update(bound="mfma", achieved=mfma[k] / (us * 1e-6) / 1e12, peak=peak_mfma, unit="TFLOP/s")
+        elif k in hbm:
+            e.update(bound="hbm", achieved=hbm[k] / (us * 1e-6) / 1e9, peak=PEAK_HBM_GBS, unit="GB/s")
+        elif k == "miner" and c["strategy"] == "batch_all":
+            e["bound"] = "valu"       # priced below, once N_valid of the profiled batches is known
+        if "achieved" in e:
+            e["frac"] = e["achieved"] / e["peak"]
+        kern[k] = e
+    return kern, 1e3 * tot / nsteps, (mfma, hbm)
 
 
 def main():
@@ -165,10 +323,13 @@ def main():
     else:
         torch.cuda.set_device(0)
     assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    c = a.cfg
     run = Runner(a, rank, world)
 
     for _ in range(a.warmup):
         run.step()
+    if run.exchange:
+        run.exchange.collect_time(); run.exchange.collective_ms = 0.0; run.exchange.steps = 0
     dp.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -176,61 +337,88 @@ def main():
     torch.cuda.synchronize(); dp.barrier(); torch.cuda.synchronize()
     dt = dp.allreduce_max_float(time.perf_counter() - t0)
     last = run.stats.cpu().numpy()
-    value = a.steps * a.batch * world / dt
+    value = a.steps * c["batch"] * world / dt
+    H = c["features"] // c["cf"]
 
     out = {
-        "metric": "training samples/sec (8000x10000 batch_all)", "value": value, "unit": "samples/s",
+        "metric": "training samples/sec (8000x10000 batch_all)" if a.config == "c2" else f"training samples/sec ({a.config})",
+        "value": value, "unit": "samples/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
-        "config": {"workload": f"synthetic {a.rows}x{a.features} binary CSR (~200 nnz/row) per GPU, compress_factor "
-                               f"{a.compress_factor} (H={a.features // a.compress_factor}), B={a.batch}/GPU, {a.strategy}, "
-                               f"masking 0.3, cross_entropy, SGD lr 0.1, {a.precision} MFMA operands + fp32 accumulate/master "
-                               f"weights; BASELINE.json configs[1]" + ("" if world == 1 else " sharded as configs[2] (weak)"),
-                   "global_batch": a.batch * world, "parallelism": f"dp{world}", "rng": a.rng,
-                   "collective": None if world == 1 else "RCCL all-reduce of the flat fp32 gradient per step"},
+        "config": {"workload": f"{a.config} = BASELINE.json {c['baseline']}; per GPU: synthetic {c['rows']}x{c['features']} {c['kind']}, "
+                               f"compress_factor {c['cf']} (H={H}), B={c['batch']}" + (" triplets (3 row blocks)" if c["strategy"] == "explicit" else "")
+                               + f", strategy {c['strategy']}, masking 0.3, {c['loss']}, SGD lr 0.1, {a.precision} MFMA operands + fp32 "
+                               "accumulate / master weights",
+                   "global_batch": c["batch"] * world, "parallelism": f"dp{world}", "rng": a.rng,
+                   "collective": None if world == 1 else f"per step: reduce-scatter of the W gradient ({a.grad_dtype}) + all-reduce of the "
+                                                         "bias gradients, sharded optimizer, all-gather of the low-precision W shadow (RCCL)"},
         "final_losses": {"cost": float(last[:, 0].mean()), "autoencoder": float(last[:, 1].mean()),
                          "triplet": float(last[:, 2].mean()), "fraction": float(last[:, 3].mean()),
                          "note": "means over the last epoch's batches, as the reference prints them (autoencoder.py:283-294)"},
     }
+    if run.exchange:
+        # the collectives of the LAST `steps` steps, timed by events on the step's stream (a second, short pass keeps the host
+        # event synchronisation out of the timed region above)
+        for _ in range(min(20, a.steps)):
+            run.step(); run.exchange.collect_time()
+        out["collective_us"] = 1e3 * run.exchange.collective_ms / max(1, min(20, a.steps))
+        out["config"]["exchange_bytes_per_rank"] = int((world - 1) / world * (run.eng.rows_alloc * run.eng.Hp * (4 if a.grad_dtype == "fp32" else 2)
+                                                                               + run.eng.rows_alloc * run.eng.Hp * (2 if a.precision == "bf16" else 4)))
 
     if rank == 0 and not a.no_roofline:
         eng = run.eng
         eng.profile(True)
-        for _ in range(a.profile_steps):
+        for s in range(a.profile_steps):
             if world == 1:
                 run.step()
             else:          # profile the local step only (no collective inside the event brackets)
-                run.eng.train_step(run.order[:a.batch], run.lab[:a.batch] if a.strategy != "none" else None, run.stats[0],
-                                   phase=1, **run.plan)
+                rows, labs = run.batch(s % run.nb)
+                run.eng.train_step(rows, labs, run.stats[s % run.nb], phase=1, **run.plan)
         prof = eng.profile_read()
         eng.profile(False)
-        B, F, H = a.batch, a.features, a.features // a.compress_factor
-        flops = {"encode_gemm": 2.0 * B * F * H, "decode_loss": 2.0 * B * F * H, "dh_gemm": 2.0 * B * F * H + 2.0 * B * B * H,
-                 "dw_gemm": 4.0 * B * F * H, "gram": 2.0 * B * B * H}
-        kern = {}
-        tot = sum(ms for ms, n in prof.values())
-        for k, (ms, n) in prof.items():
-            if n == 0:
-                continue
-            us = 1e3 * ms / n
-            e = {"avg_us": us, "launches_per_step": n / a.profile_steps, "time_share": ms / tot if tot else 0.0}
-            if k in flops:
-                peak = PEAK_F32_MFMA_TFLOPS if a.precision == "fp32" else PEAK_BF16_TFLOPS   # bf16 mode: the Gram matrix is a split-bf16 GEMM
-                e.update(bound="mfma", achieved_tflops=flops[k] / (us * 1e-6) / 1e12, peak_tflops=peak)
-                e["frac"] = e["achieved_tflops"] / peak
-            kern[k] = e
+        kern, step_us, (mfma, hbm) = kernel_table(a, prof, a.profile_steps)
+        if "miner" in kern and kern["miner"].get("bound") == "valu":
+            nv = float(np.mean(run.stats.cpu().numpy()[:, 5]))        # N_valid of the last epoch's batches
+            ops = 11.0                                                # VALU issue slots per triplet of the packed sweep
+            e = kern["miner"]
+            e.update(achieved=nv * ops / (e["avg_us"] * 1e-6) / 1e12, peak=PEAK_VALU_TLANEOPS, unit="T lane-ops/s",
+                     note=f"N_valid = {nv:.3g} triplets x {ops:.0f} VALU slots")
+            e["frac"] = e["achieved"] / e["peak"]
         out["kernels"] = kern
-        out["profiled_step_us"] = 1e3 * tot / a.profile_steps
-        # headline roofline: the fused encode GEMM named by BASELINE.json's north_star
-        e = kern.get("encode_gemm")
-        if e:
-            out["roofline"] = {"kernel": "encode_gemm (gemm_nt_pc<bf16, 4, ENCODE>: x~[BxF].W[FxH], split-K 8, 8-wave producer/consumer)", "bound": "mfma",
-                               "achieved": e["achieved_tflops"], "peak": e["peak_tflops"], "unit": "TFLOP/s", "frac": e["frac"],
-                               "traffic": committed_traffic("encode_gemm"),
-                               "algorithmic": f"2*B*F*H = {2.0 * B * F * H / 1e9:.2f} GFLOP per launch (dense accounting)"}
+        out["profiled_step_us"] = step_us
+        # whole-step rooflines (dense accounting of the north star): 10*B*F*H FLOP and SURVEY 8(d)'s minimum HBM bytes per step
+        B, F = c["batch"] * (3 if c["strategy"] == "explicit" else 1), c["features"]
+        es = 2 if a.precision == "bf16" else 4
+        step_flop = 10.0 * B * F * H
+        step_bytes = 3.0 * F * H * es + 2 * F * H * 4.0 + F * H * es + (B * F * 4.0 if c["kind"] == "dense_tfidf" else B * 200 * 8.0 * 2)
+        out["step_roofline"] = {"mfma_frac_dense_accounting": step_flop / (1e-3 * out["ms_per_step"]) / 1e12 / (PEAK_F32_MFMA_TFLOPS if a.precision == "fp32" else PEAK_BF16_TFLOPS),
+                                "hbm_frac_min_bytes": step_bytes / (1e-3 * out["ms_per_step"]) / 1e9 / PEAK_HBM_GBS,
+                                "flop_per_step": step_flop, "min_hbm_bytes_per_step": step_bytes}
+        # headline roofline object: the dominant MFMA kernel of the step (dense input: the encode GEMM the north star names;
+        # CSR input: encode runs on the stored entries, the largest MFMA kernel is the dW GEMM + optimizer) -- or, for the
+        # HBM-bound config c4, the dense gather that streams the fp32 input
+        key = "gather" if a.config == "c4" else ("encode_gemm" if "encode_gemm" in mfma else "dw_gemm")
+        e = kern.get(key)
+        if e and "achieved" in e:
+            traffic, src = committed_traffic(key, a.config)
+            what = {"dw_gemm": "dW GEMM + optimizer (gemm_dw_pc: [x~^T | delta2^T].[delta1^T ; h^T], 160x128 tiles, 8-wave producer/consumer)",
+                    "encode_gemm": "encode GEMM (gemm_nt_pc<ENCODE>: x~[BxF].W[FxH], split-K, 8-wave producer/consumer)",
+                    "gather": "gather_dense_kernel (fp32 rows -> masked x~ / x~^T tiles): the HBM stream of the dense input"}[key]
+            alg = (f"{mfma[key] / 1e9:.2f} GFLOP per launch (dense accounting)" if key in mfma else f"{hbm[key] / 1e6:.1f} MB per launch")
+            out["roofline"] = {"kernel": what, "bound": e["bound"], "achieved": e["achieved"], "peak": e["peak"], "unit": e["unit"],
+                               "frac": e["frac"], "traffic": traffic, "traffic_source": src, "algorithmic": alg}
+    run.close()
+    if rank == 0 and world == 1 and not a.no_fit:
+        out["fit"] = {a.rng: fit_leg(a, a.rng)}
+        other = "numpy" if a.rng == "philox" else "philox"
+        if not (other == "numpy" and c["kind"] == "dense_tfidf"):      # the legacy dense draw is 4*10^8 host choices per epoch
+            out["fit"][other] = fit_leg(a, other)
+        out["fit"]["note"] = ("DenoisingAutoencoder.fit() on the same workload: N * timed epochs / wall, first epoch excluded; rng=numpy is the "
+                              "reference-exact legacy stream (keep decisions drawn one epoch ahead on a feeder thread)")
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a)
-        out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        if out["cpu_baseline"]["value"]:
+            out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -31,6 +31,45 @@ from .. import _lib as L
 __all__ = ["DenoisingAutoencoder"]
 
 
+class _EpochFeeder(object):
+    """Produces the per-epoch host draws one epoch AHEAD of the device, on a thread, in epoch order -- so the legacy global
+    NumPy stream is consumed exactly as the reference consumes it (corruption of epoch e, shuffle of epoch e, corruption of
+    epoch e+1, ...) while the draw of epoch e+1 (a 1.6 M-element ``rand`` at 8000 x 10000) overlaps the GPU's epoch e.
+    NumPy releases the GIL inside its generators.  Nothing else may draw from ``np.random`` while a fit is running."""
+
+    def __init__(self, draw_fn, n_epochs):
+        import queue
+        import threading
+        self._q = queue.Queue(maxsize=2)
+        self._stop = False
+
+        def run():
+            try:
+                for e in range(n_epochs):
+                    if self._stop:
+                        return
+                    self._q.put(("ok", draw_fn(e)))
+            except BaseException as exc:          # surfaces in the training thread
+                self._q.put(("err", exc))
+        self._t = threading.Thread(target=run, name="dae-epoch-feeder", daemon=True)
+        self._t.start()
+
+    def get(self):
+        tag, val = self._q.get()
+        if tag == "err":
+            raise val
+        return val
+
+    def close(self):
+        self._stop = True
+        try:
+            while self._t.is_alive():
+                self._q.get_nowait()
+        except Exception:
+            pass
+        self._t.join(timeout=5)
+
+
 class DenoisingAutoencoder(object):
     """Denoising autoencoder with tied weights, h = f(W x~ + b) - f(b), optional online triplet mining.
     The interface is sklearn-like (reference autoencoder.py:14-18)."""
@@ -223,7 +262,8 @@ class DenoisingAutoencoder(object):
         return dp.world_size(), dp.rank()
 
     def _train_model(self, train_set, validation_set, train_set_label, validation_set_label):
-        """Epoch loop (reference :175-204)."""
+        """Epoch loop (reference :175-204).  The host randomness of epoch e+1 (keep decisions of the whole set, then the shuffle
+        -- the reference's draw order, :218-220) is produced by a feeder thread while the GPU runs epoch e."""
         import torch
         eng = self.engine
         N = train_set.shape[0]
@@ -237,61 +277,82 @@ class DenoisingAutoencoder(object):
         self._stats = torch.zeros((max(self.num_epochs, 1), n_batches, L.STATS_STRIDE), dtype=torch.float32,
                                   device=eng.device)
         self._epoch_seconds = []
+        feeder = _EpochFeeder(lambda e: self._draw_epoch(train_set, e), self.num_epochs)
         t_fit = time.time()
+        t_first = None
         i = -1
-        for i in range(self.num_epochs):
-            t0 = time.time()
-            self._run_train_step(train_set, label_ids, i, batch, world, rank)
-            if (i + 1) % self.verbose_step == 0:
-                torch.cuda.synchronize()
-                self.train_time = time.time() - t0
-                self._run_validation_error_and_summaries(i + 1, validation_set, validation_set_label)
-            self._epoch_seconds.append(time.time() - t0)
-        else:
-            if self.num_epochs != 0 and (i + 1) % self.verbose_step != 0:
-                torch.cuda.synchronize()
-                self.train_time = self._epoch_seconds[-1]
-                self._run_validation_error_and_summaries(i + 1, validation_set, validation_set_label)
+        try:
+            for i in range(self.num_epochs):
+                t0 = time.time()
+                self._run_train_step(train_set, label_ids, i, batch, world, rank, feeder.get())
+                if (i + 1) % self.verbose_step == 0:
+                    torch.cuda.synchronize()
+                    self.train_time = time.time() - t0
+                    self._run_validation_error_and_summaries(i + 1, validation_set, validation_set_label)
+                self._epoch_seconds.append(time.time() - t0)
+                if i == 0:
+                    torch.cuda.synchronize()
+                    t_first = time.time()
+            else:
+                if self.num_epochs != 0 and (i + 1) % self.verbose_step != 0:
+                    torch.cuda.synchronize()
+                    self.train_time = self._epoch_seconds[-1]
+                    self._run_validation_error_and_summaries(i + 1, validation_set, validation_set_label)
+        finally:
+            feeder.close()
         torch.cuda.synchronize()
-        wall = time.time() - t_fit
-        if self.num_epochs > 0 and wall > 0:
-            self.samples_per_sec = N * self.num_epochs / wall
+        t_end = time.time()
+        if self.num_epochs > 1 and t_end > t_first:        # N * timed epochs / wall, first epoch excluded as warm-up
+            self.samples_per_sec = N * (self.num_epochs - 1) / (t_end - t_first)
+        elif self.num_epochs > 0 and t_end > t_fit:
+            self.samples_per_sec = N * self.num_epochs / (t_end - t_fit)
 
-    def _corruption_plan(self, train_set, epoch):
-        """Per-epoch corruption, BEFORE the shuffle, like the reference (:218-220).  Returns the keyword
-        arguments of Engine.train_step that realise ``self.corr_type`` for this epoch."""
+    def _draw_epoch(self, train_set, epoch, n_shuffle=None):
+        """Host randomness of one epoch in the reference's order: corrupt the WHOLE set, then shuffle (:218-220).  Runs on the
+        feeder thread; everything it returns is host data (the uploads happen on the training thread)."""
+        draw = dict(kind=self.corr_type)
+        if self.corr_type == 'masking':
+            if self.rng == 'numpy':
+                if self.sparse_input:
+                    keep = utils.masking_keep(self.engine.csr["nnz"], self.corr_frac)        # np.random.rand(nnz) >= v
+                else:
+                    keep = np.random.choice(a=[0, 1], size=train_set.shape, p=[self.corr_frac, 1 - self.corr_frac]).ravel() != 0
+                draw['bits'] = utils.pack_keep_bits(keep).view(np.int32)
+        elif self.corr_type == 'salt_and_pepper':
+            v = int(np.round(self.corr_frac * train_set.shape[1]))                           # reference :187
+            draw['xc'] = sparse.csr_matrix(utils.salt_and_pepper_noise(train_set, v))
+        elif self.corr_type not in ('decay', 'none'):
+            raise ValueError("unknown corr_type %r (reference :268 returns None and fails later)" % (self.corr_type,))
+        n_rows = train_set.shape[0] if n_shuffle is None else n_shuffle
+        draw['order'] = utils.epoch_permutation(n_rows)                                      # np.random.shuffle, after the corruption draws
+        return draw
+
+    def _corruption_plan(self, draw, epoch):
+        """Keyword arguments of Engine.train_step that realise this epoch's corruption (uploads what the feeder drew)."""
         import torch
         eng = self.engine
-        if self.corr_type == 'masking':
+        if draw['kind'] == 'masking':
             if self.rng == 'philox':
                 seed = self.seed if self.seed >= 0 else 0x5EED
                 return dict(corr_mode=L.CORR_PHILOX_MASK, seed=seed, rng_stream=epoch, corr_frac=float(self.corr_frac))
-            if self.sparse_input:
-                keep = utils.masking_keep(eng.csr["nnz"], self.corr_frac)            # np.random.rand(nnz) >= v
-            else:
-                keep = np.random.choice(a=[0, 1], size=train_set.shape, p=[self.corr_frac, 1 - self.corr_frac]).ravel() != 0
-            bits = torch.from_numpy(utils.pack_keep_bits(keep).view(np.int32)).to(eng.device, non_blocking=True)
-            self._keep_bits = bits                                                       # keep alive while steps run
+            bits = torch.from_numpy(draw['bits']).to(eng.device, non_blocking=True)
+            self._keep_bits = bits                                                           # keep alive while steps run
             return dict(corr_mode=L.CORR_KEEPBITS, keep_bits=bits)
-        if self.corr_type == 'decay':
+        if draw['kind'] == 'decay':
             return dict(scale=1.0 - float(self.corr_frac))
-        if self.corr_type == 'salt_and_pepper':
-            v = int(np.round(self.corr_frac * train_set.shape[1]))                       # reference :187
-            xc = utils.salt_and_pepper_noise(train_set, v)
+        if draw['kind'] == 'salt_and_pepper':
             from ..engine import Engine
-            self._corrupted = Engine.to_device_csr(sparse.csr_matrix(xc), eng.device)
+            self._corrupted = Engine.to_device_csr(draw['xc'], eng.device)
             return dict(corrupted_csr=self._corrupted)
-        if self.corr_type == 'none':
-            return dict()
-        raise ValueError("unknown corr_type %r (reference :268 returns None and fails later)" % (self.corr_type,))
+        return dict()
 
-    def _run_train_step(self, train_set, label_ids, epoch, batch, world, rank):
+    def _run_train_step(self, train_set, label_ids, epoch, batch, world, rank, draw):
         """One epoch: corrupt, shuffle, then one fused device step per mini-batch (reference :206-246)."""
         import torch
         eng = self.engine
         N = train_set.shape[0]
-        plan = self._corruption_plan(train_set, epoch)
-        order = utils.epoch_permutation(N)                              # np.random.shuffle, after the corruption draws
+        plan = self._corruption_plan(draw, epoch)
+        order = draw['order']
         order_dev = torch.from_numpy(order.astype(np.int32)).to(eng.device, non_blocking=True)
         labels_dev = None
         if label_ids is not None:

@@ -77,8 +77,9 @@ class DenoisingAutoencoderTriplet(DenoisingAutoencoder):
         t_fit = time.time()
         for i in range(self.num_epochs):
             t0 = time.time()
-            plan = self._corruption_plan(stacked, i)        # one corruption draw over the stacked set
-            order = utils.epoch_permutation(N)               # ONE shuffle shared by the three blocks (utils.py:87-91)
+            draw = self._draw_epoch(stacked, i, n_shuffle=N)  # one corruption draw over the stacked set (org, pos, neg in order),
+            plan = self._corruption_plan(draw, i)            # then ONE shuffle shared by the three blocks (utils.py:87-91)
+            order = draw['order']
             for b, start in enumerate(range(0, N, batch)):
                 idx = order[start:start + batch]
                 rows = np.concatenate([idx, N + idx, 2 * N + idx]).astype(np.int32)
