@@ -123,9 +123,10 @@ def train_step(W, bh, bv, x, xc, labels, strategy, alpha, lr, form="literal"):
 
 
 def time_baseline(m, labels, W0, *, batch, strategy, corr_frac=0.3, lr=0.1, alpha=1.0, literal_steps=2, chunked_steps=10, seed=0,
-                  threads=None):
-    """Times ``literal_steps`` literal steps and ``chunked_steps`` chunked steps (incl. the per-epoch masking + shuffle of
-    the reference, utils.py) on ``threads`` host threads.  Returns a dict for bench.py's cpu_baseline object."""
+                  threads=None, budget_s=25.0):
+    """Times up to ``literal_steps`` literal steps and ``chunked_steps`` chunked steps (incl. the per-epoch masking + shuffle of
+    the reference, utils.py) on ``threads`` host threads; each form stops early once it has used ``budget_s`` seconds (at least
+    one step is always timed).  Returns a dict for bench.py's cpu_baseline object."""
     import os
     threads = threads or os.cpu_count() or 1
     torch.set_num_threads(threads)
@@ -146,10 +147,13 @@ def time_baseline(m, labels, W0, *, batch, strategy, corr_frac=0.3, lr=0.1, alph
         order = np.arange(N); np.random.shuffle(order)                         # gen_batches (utils.py:50-51)
         done = 0
         costs = []
+        ran = 0
         for s in range(steps):
             idx = order[(s * batch) % N:(s * batch) % N + batch]
             c, _ = train_step(W, bh, bv, m[idx], mc[idx], None if labels is None else labels[idx], strategy, alpha, lr, form)
-            costs.append(c); done += len(idx)
+            costs.append(c); done += len(idx); ran += 1
+            if time.time() - t0 > budget_s:
+                break
         dt = time.time() - t0
-        out[form] = dict(samples_per_s=done / dt, seconds=dt, steps=steps, first_cost=costs[0], last_cost=costs[-1])
+        out[form] = dict(samples_per_s=done / dt, seconds=dt, steps=ran, first_cost=costs[0], last_cost=costs[-1])
     return out
