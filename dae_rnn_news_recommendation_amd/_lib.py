@@ -46,7 +46,7 @@ class dae_step(C.Structure):
     _fields_ = [("row_idx", vp), ("labels", vp), ("B", i32),
                 ("corr_mode", i32), ("keep_bits", vp), ("seed", u64), ("rng_stream", u32),
                 ("corr_frac", f32), ("scale", f32),
-                ("c_indptr", vp), ("c_indices", vp), ("c_values", vp),
+                ("c_indptr", vp), ("c_indices", vp), ("c_values", vp), ("c_row_idx", vp),
                 ("stats", vp), ("phase", i32), ("adam_t", i32), ("grad_scale", f32)]
 
 
@@ -62,6 +62,7 @@ SIGNATURES = {
                                   i64, vp]),
     "dae_encode_csr": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, i64, vp, i32, i32, vp, u64, u32, f32, f32, vp, vp, i64, vp, i64, vp, vp,
                              vp, i64, vp, i64, vp, vp]),
+    "dae_salt_pepper_batch": (i32, [vp, vp, vp, vp, i32, i32, i32, f32, f32, u64, u32, vp, vp, vp, i32, vp]),
     "dae_encode_bits": (i32, [vp, i64, vp, i64, i32, i32, i32, vp, i64, i32, i64, vp]),
     "dae_gather_dense": (i32, [vp, i64, vp, i32, i32, i32, vp, vp, i64, vp, i64, vp, vp, i32, vp, u64, u32, f32, f32, vp]),
     "dae_gemm_nt": (i32, [i32, i32, i32, vp, i64, vp, i64, i32, vp, i64, vp, i64, i32, vp, i64, i32, i64, vp]),

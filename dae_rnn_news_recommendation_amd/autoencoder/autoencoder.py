@@ -320,7 +320,10 @@ class DenoisingAutoencoder(object):
                 draw['bits'] = utils.pack_keep_bits(keep).view(np.int32)
         elif self.corr_type == 'salt_and_pepper':
             v = int(np.round(self.corr_frac * train_set.shape[1]))                           # reference :187
-            draw['xc'] = sparse.csr_matrix(utils.salt_and_pepper_noise(train_set, v))
+            if self.rng == 'philox' and self.sparse_input:
+                draw['sp_v'] = v                                                             # flipped per batch on the device
+            else:
+                draw['xc'] = sparse.csr_matrix(utils.salt_and_pepper_noise(train_set, v))    # reference-exact host stream
         elif self.corr_type not in ('decay', 'none'):
             raise ValueError("unknown corr_type %r (reference :268 returns None and fails later)" % (self.corr_type,))
         n_rows = train_set.shape[0] if n_shuffle is None else n_shuffle
@@ -341,6 +344,8 @@ class DenoisingAutoencoder(object):
         if draw['kind'] == 'decay':
             return dict(scale=1.0 - float(self.corr_frac))
         if draw['kind'] == 'salt_and_pepper':
+            if 'sp_v' in draw:                                                               # device salt-and-pepper (rng='philox')
+                return dict(_sp=(draw['sp_v'], self.seed if self.seed >= 0 else 0x5EED, epoch))
             from ..engine import Engine
             self._corrupted = Engine.to_device_csr(draw['xc'], eng.device)
             return dict(corrupted_csr=self._corrupted)
@@ -359,6 +364,12 @@ class DenoisingAutoencoder(object):
             labels_dev = torch.from_numpy(label_ids[order]).to(eng.device, non_blocking=True)
         stats = self._stats[epoch]
         shard_w = []
+        sp = plan.pop('_sp', None)
+        if sp is not None and not hasattr(self, '_sp_range'):
+            # global minimum / maximum of the train set (utils.py:131-132); implicit zeros of a sparse matrix count
+            d = train_set.data if train_set.nnz else np.zeros(1)
+            full = train_set.nnz == train_set.shape[0] * train_set.shape[1]
+            self._sp_range = (float(d.min() if full else min(d.min(), 0.0)), float(d.max() if full else max(d.max(), 0.0)))
         for b, start in enumerate(range(0, N, batch)):
             stop = min(N, start + batch)
             if world > 1:                                               # contiguous shard of every global batch
@@ -368,6 +379,8 @@ class DenoisingAutoencoder(object):
                 lo, hi = start, stop
             rows = order_dev[lo:hi]
             labs = None if labels_dev is None else labels_dev[lo:hi]
+            if sp is not None and hi > lo:
+                plan['corrupted_csr'] = eng.salt_pepper_batch(rows, sp[0], self._sp_range[0], self._sp_range[1], sp[1], sp[2])
             if world > 1 and getattr(self, '_miner', None) is not None:
                 # global-batch mining: encode my rows, mine over the all-gathered batch, resume; the ranks' gradients SUM to
                 # the gradient of the reference cost at the global batch size

@@ -419,7 +419,7 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
         EncCsrLaunch q;
         memset(&q, 0, sizeof(q));
         q.indptr = s->c_indptr ? s->c_indptr : p->b.indptr; q.indices = s->c_indptr ? s->c_indices : p->b.indices;
-        q.values = s->c_indptr ? s->c_values : p->b.values; q.row_idx = s->row_idx; q.B = B; q.F = F; q.H = H; q.dtype = dt;
+        q.values = s->c_indptr ? s->c_values : p->b.values; q.row_idx = (s->c_indptr && s->c_row_idx) ? s->c_row_idx : s->row_idx; q.B = B; q.F = F; q.H = H; q.dtype = dt;
         q.W = p->b.W_lo; q.ldw = Hp; q.bh = p->b.bh; q.enc_act = c.enc_act;
         q.corr_mode = s->c_indptr ? DAE_CORR_NONE : s->corr_mode; q.keep_bits = s->keep_bits; q.seed = s->seed; q.rng_stream = s->rng_stream;
         q.corr_frac = s->corr_frac; q.scale = s->scale;
@@ -434,7 +434,7 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
         if (s->c_indptr) {   // an explicitly corrupted copy of the train set (salt&pepper, host-side noise)
             PROF(PS_GATHER, gather_batch(p, p->b.indptr, p->b.indices, p->b.values, p->b.dense, p->b.ld_dense, s->row_idx, B, use_xbits ? nullptr : p->x,
                             nullptr, nullptr, rowsq, DAE_CORR_NONE, nullptr, 0, 0, 0.f, 1.f, stream, nullptr, nullptr, use_xbits ? p->x_bits : nullptr));
-            PROF(PS_GATHER, gather_batch(p, s->c_indptr, s->c_indices, s->c_values, nullptr, 0, s->row_idx, B, nullptr, p->xc,
+            PROF(PS_GATHER, gather_batch(p, s->c_indptr, s->c_indices, s->c_values, nullptr, 0, s->c_row_idx ? s->c_row_idx : s->row_idx, B, nullptr, p->xc,
                             backward ? p->xct : nullptr, nullptr, DAE_CORR_NONE, nullptr, 0, 0, 0.f, s->scale, stream));
         } else {
             // binary CSR, unit scale, bf16: the corrupted batch goes to the encode GEMM as a BIT image (1.1 MB, not 18 MB of bf16)
@@ -567,7 +567,8 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
         BiasArgs ba{p->dbv_part, 2 * Bp / 128, p->colsum_part, Bp / 32, p->b.bh, H, Hp, F, Fp, c.enc_act, g_bh, g_bh + Hp,
                     fuse_bias ? 1 : 0, c.opt, plan_lr(p, s->adam_t), c.momentum, s->grad_scale, p->b.bv,
                     p->b.opt_s1 ? p->b.opt_s1 + boff : nullptr, p->b.opt_s2 ? p->b.opt_s2 + boff : nullptr};
-        ClearArgs ca{s->c_indptr ? s->c_indptr : p->b.indptr, s->c_indptr ? s->c_indices : p->b.indices, s->row_idx, B, F, p->xct, ldB, p->es};
+        ClearArgs ca{s->c_indptr ? s->c_indptr : p->b.indptr, s->c_indptr ? s->c_indices : p->b.indices,
+                     (s->c_indptr && s->c_row_idx) ? s->c_row_idx : s->row_idx, B, F, p->xct, ldB, p->es};
         PROF(PS_BIAS, launch_step_tail(ba, &sa, csr_in ? &ca : nullptr, st));
         if (csr_in) p->xct_clean = true;
     } else {

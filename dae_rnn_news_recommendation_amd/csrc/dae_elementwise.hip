@@ -283,19 +283,34 @@ __global__ __launch_bounds__(1024) void triplet_finalize_kernel(int triplet, int
     for (int j = t; j < Bp; j += blockDim.x) cw[j] = (j < B) ? dw_f32_out[j] / wsf : 0.f;
 }
 
-// cosine_proximity: reduce the first pass' partials into per-row statistics and the row loss
-__global__ void cos_reduce_kernel(const float* __restrict__ cos_part, int n_col_waves, int B, int Bp,
-                                  float* __restrict__ cos_stats, float* __restrict__ rowloss) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= Bp) return;
+// cosine_proximity: reduce the first pass' partials into per-row statistics and the row loss.
+// One wave per 64 rows x one eighth of the partial rows at a time would still be a serial chain of n_col_waves (316 at
+// F = 10000) dependent-free but strided loads per thread; instead a workgroup owns 64 rows and its 4 waves split the partial
+// rows (coalesced 256-byte reads, 8 loads in flight), combined through LDS in a fixed order.
+__global__ __launch_bounds__(256) void cos_reduce_kernel(const float* __restrict__ cos_part, int n_col_waves, int B, int Bp,
+                                                         float* __restrict__ cos_stats, float* __restrict__ rowloss) {
+    __shared__ float sm[2][4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
     float yy = 0.f, xy = 0.f;
-    for (int p = 0; p < n_col_waves; ++p) {
-        yy += cos_part[(int64_t)p * Bp + i];
-        xy += cos_part[(int64_t)(n_col_waves + p) * Bp + i];
+    if (i < Bp) {
+        const int per = (n_col_waves + 3) / 4;
+        const int p0 = w * per, p1 = min(n_col_waves, p0 + per);
+#pragma unroll 8
+        for (int p = p0; p < p1; ++p) {
+            yy += cos_part[(int64_t)p * Bp + i];
+            xy += cos_part[(int64_t)(n_col_waves + p) * Bp + i];
+        }
     }
-    cos_stats[Bp + i] = yy;
-    cos_stats[2 * Bp + i] = xy;
-    rowloss[i] = (i < B) ? -xy * rsqrtf(fmaxf(yy, 1e-12f)) : 0.f;    // -sum xhat*yhat (:273)
+    sm[0][w][lane] = yy; sm[1][w][lane] = xy;
+    __syncthreads();
+    if (w == 0 && i < Bp) {
+        yy = (sm[0][0][lane] + sm[0][1][lane]) + (sm[0][2][lane] + sm[0][3][lane]);
+        xy = (sm[1][0][lane] + sm[1][1][lane]) + (sm[1][2][lane] + sm[1][3][lane]);
+        cos_stats[Bp + i] = yy;
+        cos_stats[2 * Bp + i] = xy;
+        rowloss[i] = (i < B) ? -xy * rsqrtf(fmaxf(yy, 1e-12f)) : 0.f;    // -sum xhat*yhat (:273)
+    }
 }
 
 // bias gradients into the flat gradient buffer
@@ -597,7 +612,7 @@ extern "C" int dae_triplet_finalize(int32_t triplet, int32_t pos_only, int32_t B
 extern "C" int dae_cos_reduce(const float* cos_part, int32_t n_col_waves, int32_t B, int32_t Bp, float* cos_stats,
                               float* rowloss, void* stream) {
     DAE_CHECK_ARG(cos_part && cos_stats && rowloss, "cos_reduce: null input");
-    hipLaunchKernelGGL(cos_reduce_kernel, dim3((Bp + 255) / 256), dim3(256), 0, ST(stream), cos_part, n_col_waves, B, Bp,
+    hipLaunchKernelGGL(cos_reduce_kernel, dim3((Bp + 63) / 64), dim3(256), 0, ST(stream), cos_part, n_col_waves, B, Bp,
                        cos_stats, rowloss);
     DAE_CHECK_LAUNCH();
     return 0;

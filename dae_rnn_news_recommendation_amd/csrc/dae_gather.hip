@@ -154,6 +154,67 @@ __global__ __launch_bounds__(256) void gather_dense_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// Salt-and-pepper corruption of one mini-batch on the device (utils.salt_and_pepper_noise, utils.py:118-144).
+// One workgroup per batch row.  An LDS table of F entries records, per column, the LAST draw that hit it (atomicMax of
+// t*2 + coin, t = draw index: "later writes win", as the reference's sequential loop); the row is then rebuilt in column
+// order: overridden columns take lo / hi, the others keep their stored value, zeros are dropped, and the ordered compaction
+// (ballot ranks per 256-column strip) writes a sorted CSR row.
+// ------------------------------------------------------------------------------------------------
+constexpr int SP_THREADS = 256;
+
+__global__ __launch_bounds__(SP_THREADS) void salt_pepper_kernel(const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+                                                                 const float* __restrict__ values, const int32_t* __restrict__ row_idx, int F,
+                                                                 int v, float lo, float hi, uint64_t seed, uint32_t stream,
+                                                                 int64_t* __restrict__ out_span, int32_t* __restrict__ out_indices,
+                                                                 float* __restrict__ out_values, int cap) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint32_t* hit = reinterpret_cast<uint32_t*>(smem);               // [F]  0 = untouched, else (t + 1) * 2 + coin of the last draw
+    float* val = reinterpret_cast<float*>(smem + (size_t)F * 4);     // [F]  stored value of the clean row (0 where nothing is stored)
+    __shared__ int wave_cnt[SP_THREADS / 64];
+    __shared__ int base_s;
+    const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t row = row_idx[i];
+    for (int k = tid; k < F; k += SP_THREADS) { hit[k] = 0u; val[k] = 0.f; }
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    const int64_t s0 = indptr[row], e0 = indptr[row + 1];
+    for (int64_t k = s0 + tid; k < e0; k += SP_THREADS) {
+        const int c = indices[k];
+        if (c < F) val[c] = values ? values[k] : 1.0f;
+    }
+    for (int t = tid; t < v; t += SP_THREADS) {
+        const uint4 o = philox4x32_10(make_uint4((uint32_t)row, (uint32_t)t, stream, 1u), make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+        const uint32_t c = __umulhi(o.x, (uint32_t)F);               // floor(u * F), u = o.x / 2^32
+        const uint32_t coin = o.y >> 31;                             // 0: u2 < 0.5 -> lo, 1: hi
+        atomicMax(&hit[c], (uint32_t)(t + 1) * 2u + coin);
+    }
+    __syncthreads();
+    const int64_t obase = (int64_t)i * cap;
+    for (int c0 = 0; c0 < F; c0 += SP_THREADS) {
+        const int c = c0 + tid;
+        float x = 0.f;
+        if (c < F) {
+            const uint32_t h = hit[c];
+            x = h ? ((h & 1u) ? hi : lo) : val[c];
+        }
+        const bool nz = x != 0.f;
+        const unsigned long long m = __ballot(nz);
+        if (lane == 0) wave_cnt[wave] = __popcll(m);
+        __syncthreads();
+        int before = base_s;
+        for (int w = 0; w < wave; ++w) before += wave_cnt[w];
+        if (nz) {
+            const int o = before + __popcll(m & ((1ull << lane) - 1ull));
+            if (o < cap) { out_indices[obase + o] = c; out_values[obase + o] = x; }
+        }
+        __syncthreads();
+        if (tid == 0) base_s += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        __syncthreads();
+    }
+    if (tid == 0) { out_span[2 * i] = obase; out_span[2 * i + 1] = obase + min(base_s, cap); }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Fused corrupt + gather + encode for CSR inputs -- what the reference's graph does in ONE op,
 // tf.sparse.matmul(x~, W) (autoencoder.py:377,389), followed by + b_h, the activation and - act(b_h):
 //     h[i, :] = act( sum_{e in row(i), kept(e)} scale * v_e * W[col_e, :] + b_h ) - act(b_h)
@@ -469,6 +530,21 @@ extern "C" int dae_encode_csr(const int64_t* indptr, const int32_t* indices, con
     q.rng_stream = rng_stream; q.corr_frac = corr_frac; q.scale = scale; q.h_f32 = h_f32; q.h_lo = h_lo; q.ldh = ldh; q.h_t = h_t;
     q.ldht = ldht; q.hcat_a = hcat_a; q.hcat_b = hcat_b; q.x_bits = x_bits; q.ldxb = ldxb; q.xct = xct; q.ldt = ldt; q.rowsq = rowsq;
     return launch_encode_csr(q, (hipStream_t)stream);
+}
+
+extern "C" int dae_salt_pepper_batch(const int64_t* indptr, const int32_t* indices, const float* values, const int32_t* row_idx,
+                                     int32_t B, int32_t F, int32_t v, float lo, float hi, uint64_t seed, uint32_t rng_stream,
+                                     int64_t* out_span, int32_t* out_indices, float* out_values, int32_t cap, void* stream) {
+    DAE_CHECK_ARG(indptr && indices && row_idx && out_span && out_indices && out_values, "salt_pepper_batch: null argument");
+    DAE_CHECK_ARG(B > 0 && F > 0 && v >= 0 && cap > 0, "salt_pepper_batch: bad sizes");
+    const size_t lds = (size_t)F * 8;
+    DAE_CHECK_ARG(lds <= 150 * 1024, "salt_pepper_batch: %d features need %zu B of LDS", F, lds);
+    static int attr_rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(salt_pepper_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    DAE_CHECK_ARG(attr_rc == 0, "salt_pepper_batch: hipFuncSetAttribute failed");
+    hipLaunchKernelGGL(salt_pepper_kernel, dim3(B), dim3(SP_THREADS), lds, (hipStream_t)stream, indptr, indices, values, row_idx, F, v, lo, hi,
+                       seed, rng_stream, out_span, out_indices, out_values, cap);
+    DAE_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int dae_gather_csr_bits(const int64_t* indptr, const int32_t* indices, const float* values, const int32_t* row_idx,

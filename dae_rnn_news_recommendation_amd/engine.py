@@ -82,6 +82,8 @@ class Engine:
             indices=torch.from_numpy(m.indices.astype(np.int32)).to(dev),
             values=None if binary else torch.from_numpy(m.data.astype(np.float32)).to(dev),
             n_rows=m.shape[0], nnz=int(m.nnz))
+        self._max_row_nnz = int(np.diff(m.indptr).max()) if m.shape[0] else 0
+        self._sp = None
         self.dense = None
         self._bind()
         return self.csr
@@ -149,6 +151,7 @@ class Engine:
     # ------------------------------------------------------------------ steps
     def train_step(self, row_idx, labels, stats, *, corr_mode=L.CORR_NONE, keep_bits=None, seed=0, rng_stream=0,
                    corr_frac=0.0, scale=1.0, corrupted_csr=None, phase=0, grad_scale=1.0):
+        # corrupted_csr may carry "row_idx": the rows of the corrupted CSR to take (batch-local CSR of salt_pepper_batch)
         """Enqueue one mini-batch step.  row_idx / labels: device int32 tensors; stats: device float32[8].
         phase: 0 step + update (grads() stays readable), 1 gradients only (DP), 2 forward only, 3 step + update
         with the optimizer fused into the dW GEMM and no W-gradient image (the training loops use this)."""
@@ -160,11 +163,31 @@ class Engine:
         if corrupted_csr is not None:
             s.c_indptr = corrupted_csr["indptr"].data_ptr(); s.c_indices = corrupted_csr["indices"].data_ptr()
             s.c_values = None if corrupted_csr["values"] is None else corrupted_csr["values"].data_ptr()
+            if corrupted_csr.get("row_idx") is not None:
+                s.c_row_idx = corrupted_csr["row_idx"].data_ptr()
         s.stats = stats.data_ptr(); s.phase = int(phase)
         if phase in (0, 3) and self.opt == "adam":   # 3 = update without materialising the W gradient
             self.adam_t += 1
         s.adam_t = self.adam_t; s.grad_scale = float(grad_scale)
         L.check(self.lib.dae_train_step(self.plan, C.byref(s), L.current_stream()), "dae_train_step")
+
+    def salt_pepper_batch(self, row_idx, v, lo, hi, seed, rng_stream):
+        """Salt-and-pepper corruption of the batch rows on the device (dae_salt_pepper_batch): returns the batch-local corrupted CSR
+        as the ``corrupted_csr`` argument of train_step."""
+        assert self.csr is not None, "salt_pepper_batch needs a CSR train set"
+        B = int(row_idx.numel())
+        if getattr(self, "_sp", None) is None:
+            cap = int(self._max_row_nnz + v)
+            dev = self.device
+            self._sp = dict(cap=cap, span=torch.zeros(2 * self.Bmax, dtype=torch.int64, device=dev),
+                            indices=torch.zeros(self.Bmax * cap, dtype=torch.int32, device=dev),
+                            values=torch.zeros(self.Bmax * cap, dtype=torch.float32, device=dev),
+                            rows=torch.arange(0, 2 * self.Bmax, 2, dtype=torch.int32, device=dev))
+        sp = self._sp
+        L.check(self.lib.dae_salt_pepper_batch(L.ptr(self.csr["indptr"]), L.ptr(self.csr["indices"]), L.ptr(self.csr["values"]), L.ptr(row_idx),
+                                               B, self.F, int(v), float(lo), float(hi), int(seed), int(rng_stream), L.ptr(sp["span"]),
+                                               L.ptr(sp["indices"]), L.ptr(sp["values"]), sp["cap"], L.current_stream()), "dae_salt_pepper_batch")
+        return dict(indptr=sp["span"], indices=sp["indices"], values=sp["values"], row_idx=sp["rows"][:B])
 
     def apply_rows(self, grad_rows, f0, f1, grad_scale=1.0, update_bias=True):
         """Sharded-optimizer step on the rows [f0, f1) this rank owns (dp.ShardedExchange); W_lo rows refreshed, Wt_lo not."""

@@ -108,6 +108,17 @@ int dae_encode_csr(const int64_t* indptr, const int32_t* indices, const float* v
                    void* hcat_a, void* hcat_b, uint32_t* x_bits, int64_t ldxb, void* xct, int64_t ldt, float* rowsq,
                    void* stream);
 
+/* Salt-and-pepper corruption of a mini-batch ON THE DEVICE (utils.salt_and_pepper_noise, utils.py:118-144, with a counter
+ * RNG instead of the host stream): for batch row i (train-set row row_idx[i]) `v` column ids are drawn with replacement,
+ * col_t = floor(u * F), and each is set to `lo` (coin < 0.5) or `hi`; later draws win.  (u, coin) = the first two words of
+ * Philox4x32-10 at counter (row_idx[i], t, rng_stream, 1), key = seed -- restated by oracle.salt_and_pepper_philox.
+ * Output: a batch-local CSR with a fixed row capacity `cap` (>= longest row + v): row i occupies out_indices / out_values
+ * [i*cap, i*cap + len_i), sorted by column, zeros dropped; out_span[2i], out_span[2i+1] = its start and end, so the arrays
+ * serve as (c_indptr = out_span, c_row_idx[i] = 2i) of dae_train_step. */
+int dae_salt_pepper_batch(const int64_t* indptr, const int32_t* indices, const float* values, const int32_t* row_idx,
+                          int32_t B, int32_t F, int32_t v, float lo, float hi, uint64_t seed, uint32_t rng_stream,
+                          int64_t* out_span, int32_t* out_indices, float* out_values, int32_t cap, void* stream);
+
 /* Dense-ndarray input (autoencoder.py:143 sparse_input=False; utils.py:107-109 dense masking):
  * gathers fp32 rows data[row_idx[i], :] into x / xc / xct with optional Philox masking. */
 int dae_gather_dense(const float* data, int64_t ld_data, const int32_t* row_idx, int32_t B, int32_t F,
@@ -336,6 +347,7 @@ typedef struct {
     float corr_frac, scale;
     /* optional second CSR holding an already-corrupted copy of the train set (salt&pepper etc.) */
     const int64_t* c_indptr; const int32_t* c_indices; const float* c_values;
+    const int32_t* c_row_idx;    /* rows of the corrupted CSR to take (NULL: the same row_idx as the clean set) */
     float* stats;                /* device float[DAE_STATS_STRIDE] for this step */
     int32_t phase;               /* 0 = forward+backward+update, 1 = forward+backward only (DP:
                                     caller all-reduces `grad` then calls dae_plan_apply), 2 = forward only,

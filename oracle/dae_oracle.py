@@ -617,6 +617,27 @@ def philox_uniform(idx, seed, stream):
     return (x0 >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)
 
 
+def salt_and_pepper_philox(X, rows, v, seed, stream, lo=None, hi=None):
+    """utils.salt_and_pepper_noise (utils.py:118-144) with the device's counter RNG instead of the host stream: for train-set
+    row r the t-th draw is Philox4x32-10 at counter (r, t, stream, 1): column = floor(x0 / 2^32 * F), coin = top bit of x1
+    (0 -> global min, 1 -> global max); later draws win.  Mirrors csrc/dae_gather.hip::salt_pepper_kernel.  Returns the dense
+    corrupted rows [len(rows) x F]."""
+    Xd = X.toarray() if sparse.issparse(X) else np.asarray(X)
+    F = Xd.shape[1]
+    lo = Xd.min() if lo is None else lo
+    hi = Xd.max() if hi is None else hi
+    out = Xd[np.asarray(rows)].astype(np.float64).copy()
+    t = np.arange(v, dtype=np.uint32)
+    for i, r in enumerate(np.asarray(rows)):
+        x0, x1, _, _ = philox4x32(np.full(v, np.uint32(r)), t, np.full(v, np.uint32(stream)), np.ones(v, np.uint32),
+                                  np.uint32(seed & 0xFFFFFFFF), np.uint32((seed >> 32) & 0xFFFFFFFF))
+        cols = ((x0.astype(np.uint64) * np.uint64(F)) >> np.uint64(32)).astype(np.int64)
+        coin = (x1 >> np.uint32(31)).astype(np.int64)
+        for c, k in zip(cols, coin):                       # sequential: later draws win
+            out[i, c] = hi if k else lo
+    return out
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # Evaluation step after the path (SURVEY 8(f) rank 1): helpers.pairwise_similarity (helpers.py:11-50)
 # ------------------------------------------------------------------------------------------------------------------

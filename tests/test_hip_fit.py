@@ -94,6 +94,34 @@ def test_fit_other_corruptions_match_oracle(tmp_path, corr_type):
         assert abs(got - want) <= 1e-4 * abs(want), (corr_type, e, got, want)
 
 
+def test_fit_device_salt_and_pepper_matches_oracle(tmp_path):
+    """corr_type='salt_and_pepper' with rng='philox': the flips are drawn per batch row on the device (dae_salt_pepper_batch);
+    the oracle applies the same Philox flips (oracle.salt_and_pepper_philox) to the whole set, epoch by epoch."""
+    from dae_rnn_news_recommendation_amd.autoencoder import DenoisingAutoencoder
+    m, lab = _data(N=160, F=400, seed=9, binary=True)
+    F = m.shape[1]; H = F // 10
+    W0 = np.random.default_rng(2).uniform(-0.2, 0.2, (F, H)).astype(np.float32)
+    model = DenoisingAutoencoder(model_name="sp", main_dir="sp", verbose=False, verbose_step=1, compress_factor=10,
+                                 enc_act_func="sigmoid", dec_act_func="sigmoid", loss_func="cross_entropy", num_epochs=2,
+                                 batch_size=40, learning_rate=0.05, corr_type="salt_and_pepper", corr_frac=0.1, seed=13,
+                                 triplet_strategy="batch_all", precision="fp32", rng="philox", init_weights=W0,
+                                 results_root=str(tmp_path) + "/")
+    model.fit(m, None, lab)
+    np.random.seed(13)
+    v = int(np.round(0.1 * F))
+    plans = []
+    for e in range(2):
+        xc = sparse.csr_matrix(O.salt_and_pepper_philox(m, np.arange(m.shape[0]), v, 13, e, lo=0.0, hi=1.0))
+        plans.append((xc, O.gen_batches_index(m.shape[0], 40)))
+    ref = O.fit_reference(m, lab, W0, enc_act="sigmoid", dec_act="sigmoid", loss_func="cross_entropy", num_epochs=2, batch_size=40,
+                          learning_rate=0.05, corr_type="salt_and_pepper", corr_frac=0.1, seed=-1, alpha=1.0,
+                          triplet_strategy="batch_all", dt=np.float64, plans=plans)
+    for e in range(2):
+        got = model.epoch_stats(e + 1)["per_batch"][:, 0]
+        want = np.array(ref["history"][e]["cost"])
+        assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max(), (e, got, want)
+
+
 def test_function_surface_matches_golden():
     """triplet_loss_utils function names / return tuples, evaluated on the GPU, vs the reference's own outputs."""
     import os

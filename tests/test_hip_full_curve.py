@@ -1,0 +1,41 @@
+"""Full-shape loss curve of BASELINE.json configs[1] (north star: "loss curve matching reference within 1e-4" on
+8000 x 10000 batch_all): DenoisingAutoencoder.fit() for 2 epochs = 20 steps against the float64 oracle's per-batch costs
+frozen by tests/golden/make_full_curve.py (same regenerated inputs, reference-exact legacy RNG, injected W0)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PATH = os.path.join(HERE, "golden", "full_curve_c2.npz")
+
+
+@pytest.mark.skipif(not os.path.exists(PATH), reason="tests/golden/full_curve_c2.npz not generated")
+@pytest.mark.parametrize("precision,tol", [("fp32", 2e-5), ("bf16", 1e-4)])
+def test_full_shape_loss_curve(tmp_path, precision, tol):
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import make_full_curve as M
+    from dae_rnn_news_recommendation_amd.autoencoder import DenoisingAutoencoder
+    G = np.load(PATH)
+    c = M.CFG
+    m, lab, W0 = M.inputs()
+    assert [m.nnz, int(m.indices[::997].astype(np.int64).sum()), int(lab.sum())] == G["indices_checksum"].tolist()   # same inputs
+    model = DenoisingAutoencoder(model_name="full", main_dir="full", compress_factor=c["compress_factor"], enc_act_func="sigmoid",
+                                 dec_act_func="sigmoid", loss_func="cross_entropy", num_epochs=c["epochs"], batch_size=c["batch"],
+                                 opt="gradient_descent", learning_rate=c["learning_rate"], corr_type="masking", corr_frac=c["corr_frac"],
+                                 verbose=0, verbose_step=1, seed=c["seed"], alpha=c["alpha"], triplet_strategy="batch_all",
+                                 precision=precision, rng="numpy", init_weights=W0, results_root=str(tmp_path) + "/")
+    model.fit(m, train_set_label=lab)
+    for e in range(c["epochs"]):
+        pb = model.epoch_stats(e + 1)["per_batch"]
+        for col, key in ((0, "cost"), (1, "ae"), (2, "triplet")):
+            rel = np.abs(pb[:, col] - G[key][e]) / np.abs(G[key][e])
+            assert rel.max() <= tol, (precision, e, key, rel)
+        if precision == "fp32":
+            assert np.abs(pb[:, 4] - G["num"][e]).max() <= 200        # of ~5*10^7 positive triplets: near-ties of the fp32 Gram matrix
+    W = model.engine.get_params()[0].astype(np.float64)
+    got = np.array([np.abs(W).sum(), (W ** 2).sum(), W[17, 3], W[9999, 499]])
+    assert np.abs(got - G["W_checksum"]).max() <= (1e-5 if precision == "fp32" else 2e-3) * np.abs(G["W_checksum"]).max()

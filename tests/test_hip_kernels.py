@@ -163,6 +163,32 @@ def test_gather_csr_bits_and_encode_bits(ops, L):
         assert (z[B:] == 0).all()
 
 
+def test_salt_pepper_batch_matches_oracle(L):
+    """Device salt-and-pepper (dae_salt_pepper_batch) == the oracle's restatement of utils.salt_and_pepper_noise with the
+    Philox stream: same flipped columns, later draws win, sorted batch-local CSR, zeros dropped."""
+    from dae_rnn_news_recommendation_amd.engine import Engine
+    rng = np.random.default_rng(8)
+    N, F, B, v = 90, 1200, 50, 300
+    for binary in (True, False):
+        m = _rand_csr(rng, N, F, 0.04, binary)
+        eng = Engine(F, 64, B, dtype="fp32")
+        eng.upload_csr(m)
+        rows = rng.permutation(N)[:B].astype(np.int32)
+        lo, hi = 0.0, float(m.data.max())
+        c = eng.salt_pepper_batch(dev(rows), v, lo, hi, seed=0x1234ABCD5678, rng_stream=3)
+        torch.cuda.synchronize()
+        span = c["indptr"].cpu().numpy(); ci = c["indices"].cpu().numpy(); cv = c["values"].cpu().numpy()
+        want = O.salt_and_pepper_philox(m, rows, v, 0x1234ABCD5678, 3, lo=lo, hi=hi)
+        got = np.zeros((B, F))
+        for i in range(B):
+            s0, e0 = span[2 * i], span[2 * i + 1]
+            cols = ci[s0:e0]
+            assert (np.diff(cols) > 0).all() and (cv[s0:e0] != 0).all()
+            got[i, cols] = cv[s0:e0]
+        assert np.array_equal(got.astype(np.float32), want.astype(np.float32))
+        assert (got != m[rows].toarray()).any()
+
+
 def test_gather_csr_philox_matches_oracle(ops, L):
     rng = np.random.default_rng(4)
     N, F, B = 200, 1000, 128
