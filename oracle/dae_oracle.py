@@ -25,7 +25,7 @@ __all__ = [
     "OptState", "opt_apply",
     "masking_noise", "salt_and_pepper_noise", "decay_noise", "gen_batches_index",
     "get_sparse_ind_val_shape", "xavier_bound", "epoch_plan", "fit_reference",
-    "philox4x32", "philox_uniform", "pairwise_similarity", "pair_stats",
+    "philox4x32", "philox_uniform", "salt_and_pepper_philox", "pairwise_similarity", "pair_stats",
 ]
 
 EPS = 1e-16
