@@ -156,7 +156,7 @@ static uint64_t carve(dae_plan* p, char* base) {
     p->D_slabs = (float*)take((uint64_t)p->s_gram * Bp * Bp * 4);
     p->G = (float*)take(Bp * Bp * 4);
     p->Gs = take(Bp * Bp * es);
-    p->role_cnt = (uint32_t*)take(p->cfg.pos_triplets_only ? Bp * Bp * 4 : 256);
+    p->role_cnt = (uint32_t*)take(Bp * Bp * 4);        // pos_triplets_only role counts (probe builds: the miner's timeline stamps)
     const uint64_t dbn = decode_tile_n(p->cfg.dtype);   // tile width of the decode kernel: lays out its partial-sum arrays
     p->rowloss_part = (float*)take((2 * Fp / dbn) * Bp * 4);
     p->dbv_part = (float*)take((2 * Bp / 128) * Fp * 4);

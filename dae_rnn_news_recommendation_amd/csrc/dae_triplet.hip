@@ -242,6 +242,13 @@ __device__ __forceinline__ void sweep_pairs2(const float* __restrict__ pu, const
     }
 }
 
+#if defined(DAE_MINER_PROBE) && (DAE_MINER_PROBE & 4)
+// probe build (tools only): thread 0 stamps the 100 MHz wall clock at each stage into role_cnt (8 x uint64 per workgroup;
+// the plan's role_cnt buffer is large enough) -- read back by tools/miner_timeline.py
+#define MINER_STAMP(i) do { if (!POS_ONLY && threadIdx.x == 0) reinterpret_cast<unsigned long long*>(role_cnt)[(size_t)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define MINER_STAMP(i) do { } while (0)
+#endif
 template <bool POS_ONLY, int OCC>
 __global__ __launch_bounds__(TRIP_THREADS, OCC) void batch_all_kernel(const float* __restrict__ D_slabs, int d_splits,
                                                                  int64_t slab_stride, int64_t ldd,
@@ -266,6 +273,7 @@ __global__ __launch_bounds__(TRIP_THREADS, OCC) void batch_all_kernel(const floa
     const int ar = blockIdx.x, a = a0 + ar;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
+    MINER_STAMP(0);
     const int32_t la = labels[a];
     float* Grow = G + (int64_t)ar * Bp;
     uint32_t* Rrow = POS_ONLY ? role_cnt + (int64_t)ar * Bp : nullptr;
@@ -387,6 +395,7 @@ __global__ __launch_bounds__(TRIP_THREADS, OCC) void batch_all_kernel(const floa
     }
     }
     __syncthreads();
+    MINER_STAMP(1);
     // range of the anchor's D row over its positives and negatives -> factorised or direct sweep (uniform choice)
     float lo = INFINITY, hi = -INFINITY;
     for (int k = tid; k < nP; k += TRIP_THREADS) { lo = fminf(lo, pu[k]); hi = fmaxf(hi, pu[k]); }
@@ -400,6 +409,7 @@ __global__ __launch_bounds__(TRIP_THREADS, OCC) void batch_all_kernel(const floa
         for (int k = tid; k < nP; k += TRIP_THREADS) pf[k] = __builtin_amdgcn_exp2f((mid - pu[k]) * kLog2e);
     __syncthreads();
 
+    MINER_STAMP(2);
     float loss = 0.f;
     unsigned cnt = 0u;
     float* gneg_w = gneg + wave * Bp;
@@ -470,6 +480,7 @@ __global__ __launch_bounds__(TRIP_THREADS, OCC) void batch_all_kernel(const floa
         k0 += q * 64;
     }
     __syncthreads();
+    MINER_STAMP(3);
     for (int k = tid; k < nP; k += TRIP_THREADS) {
         Grow[pidx[k]] = -gpos[k];
         if (POS_ONLY) Rrow[pidx[k]] = cpos[k];
@@ -481,6 +492,15 @@ __global__ __launch_bounds__(TRIP_THREADS, OCC) void batch_all_kernel(const floa
     const float ltot = block_sum_f(loss, red);
     const unsigned ctot = block_sum_u(cnt, redu);
     if (tid == 0) { loss_part[ar] = ltot; npos_part[ar] = ctot; }
+    MINER_STAMP(4);
+#if defined(DAE_MINER_PROBE) && (DAE_MINER_PROBE & 4)
+    if (!POS_ONLY && tid == 0) {
+        unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        reinterpret_cast<unsigned long long*>(role_cnt)[(size_t)blockIdx.x * 8 + 5] = ((unsigned long long)xcc << 32) | hw;
+        reinterpret_cast<unsigned long long*>(role_cnt)[(size_t)blockIdx.x * 8 + 6] = ((unsigned long long)nP << 32) | (unsigned)nN;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

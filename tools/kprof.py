@@ -45,7 +45,16 @@ eng.profile(True)
 for _ in range(a.steps):
     eng.train_step(idx, labs if a.strategy != "none" else None, stats, phase=a.phase, **kw)
 prof = eng.profile_read(); eng.profile(False)
+# the un-profiled step (kernels back to back, side streams allowed): events around a run of steps
+e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+for _ in range(10):
+    eng.train_step(idx, labs if a.strategy != "none" else None, stats, phase=a.phase, **kw)
+torch.cuda.synchronize(); e0.record()
+for _ in range(200):
+    eng.train_step(idx, labs if a.strategy != "none" else None, stats, phase=a.phase, **kw)
+e1.record(); torch.cuda.synchronize()
+free_us = 1e3 * e0.elapsed_time(e1) / 200
 tot = sum(ms for ms, n in prof.values())
-print(f"== corr={a.corr} {a.tag} {a.opt} {a.strategy} {a.precision} total {1e3*tot/a.steps:.1f} us/step  info={eng.info()}")
+print(f"== corr={a.corr} {a.tag} {a.opt} {a.strategy} {a.precision} total {1e3*tot/a.steps:.1f} us/step (bracketed kernels), {free_us:.1f} us/step un-profiled  info={eng.info()}")
 for k, (ms, n) in prof.items():
     if n: print(f"   {k:18s} {1e3*ms/n:9.1f} us  x{n/a.steps:.0f}")

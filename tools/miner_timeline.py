@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Timeline of the batch_all miner's workgroups from a probe build (-DDAE_MINER_PROBE=4; thread 0 stamps the 100 MHz wall clock
+at each stage into the plan's role_cnt buffer).  Build the probe library with
+  make -C dae_rnn_news_recommendation_amd/csrc BUILD=build_mp4 OUT=../libdae_mp4.so CXXFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-pass-failed -DDAE_MINER_PROBE=4"
+usage: python tools/miner_timeline.py --lib dae_rnn_news_recommendation_amd/libdae_mp4.so"""
+import argparse, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from dae_rnn_news_recommendation_amd import _lib as L
+ap = argparse.ArgumentParser()
+ap.add_argument("--lib", required=True); ap.add_argument("--batch", type=int, default=800)
+a = ap.parse_args()
+L.LIB_PATH = os.path.abspath(a.lib)
+from dae_rnn_news_recommendation_amd.engine import Engine
+from dae_rnn_news_recommendation_amd.synthetic import synthetic_csr, synthetic_labels, xavier_uniform
+F, H, B = 10000, 500, a.batch
+m = synthetic_csr(2 * B, F, seed=1); lab = synthetic_labels(2 * B, seed=1).astype(np.int32)
+eng = Engine(F, H, B, dtype="bf16", triplet="batch_all", loss_func="cross_entropy", learning_rate=0.1)
+eng.upload_csr(m); eng.set_params(xavier_uniform(F, H))
+idx = torch.arange(B, dtype=torch.int32, device="cuda"); labs = torch.from_numpy(lab[:B]).cuda(); stats = torch.zeros(8, device="cuda")
+for _ in range(4):
+    eng.train_step(idx, labs, stats, phase=3, corr_mode=L.CORR_PHILOX_MASK, seed=1, rng_stream=0, corr_frac=0.3)
+torch.cuda.synchronize()
+nb = B
+Bp = eng.info()["Bpm"]
+t = eng.buffer("role_cnt", (Bp * Bp // 2,), torch.int64)[: nb * 8].cpu().numpy().reshape(nb, 8)
+st = t[:, :5].astype(np.float64) * 0.01          # us
+t0 = st[:, 0].min()
+print(f"workgroups {nb}; kernel span {st[:, 4].max() - t0:.1f} us (first start -> last end)")
+names = ["start (rel.)", "prologue: loads+compaction", "range + exp(pf)", "sweeps", "epilogue"]
+d = np.stack([st[:, 0] - t0, st[:, 1] - st[:, 0], st[:, 2] - st[:, 1], st[:, 3] - st[:, 2], st[:, 4] - st[:, 3]], 1)
+for i, n in enumerate(names):
+    q = np.percentile(d[:, i], [0, 10, 50, 90, 100])
+    print(f"  {n:28s} min {q[0]:6.2f}  p10 {q[1]:6.2f}  med {q[2]:6.2f}  p90 {q[3]:6.2f}  max {q[4]:6.2f} us")
+end = st[:, 4] - t0
+print("  end time percentiles:", np.round(np.percentile(end, [10, 50, 90, 99, 100]), 1))
+late = np.argsort(st[:, 0])[-40:]
+print("  40 latest starters: start", np.round(d[late, 0].min(), 1), "-", np.round(d[late, 0].max(), 1), "us; their sweeps med", np.round(np.median(d[late, 3]), 1))
+xcc = (t[:, 5] >> 32) & 0xF; hw = t[:, 5] & 0xFFFFFFFF
+cu = (hw >> 8) & 0xF; se = (hw >> 13) & 0x7
+key = xcc * 1000 + se * 16 + cu
+u, c = np.unique(key, return_counts=True)
+print(f"  distinct (xcc,se,cu) = {len(u)}; workgroups per CU: min {c.min()} max {c.max()}; histogram {np.bincount(c)}")
+nP = t[:, 6] >> 32; nN = t[:, 6] & 0xFFFFFFFF
+work = (nP * nN).astype(np.float64)
+print("  sweep us per 1e5 triplets (med):", np.round(np.median(d[:, 3] / np.maximum(work, 1) * 1e5), 2))
