@@ -171,7 +171,8 @@ class Runner:
         d = {}
         if self.a.rng == "numpy":
             n = self.m.size if isinstance(self.m, np.ndarray) else self.m.nnz
-            d["bits"] = utils.pack_keep_bits(utils.masking_keep(n, 0.3)).view(np.int32)
+            v = 0.3 if not isinstance(self.m, np.ndarray) else utils.dense_masking_threshold(0.3)
+            d["bits"] = utils.masking_keep_bits(n, v).view(np.int32)
         d["order"] = utils.epoch_permutation(self.N)
         return d
 

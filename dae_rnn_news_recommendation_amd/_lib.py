@@ -63,6 +63,7 @@ SIGNATURES = {
     "dae_encode_csr": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, i64, vp, i32, i32, vp, u64, u32, f32, f32, vp, vp, i64, vp, i64, vp, vp,
                              vp, i64, vp, i64, vp, vp]),
     "dae_salt_pepper_batch": (i32, [vp, vp, vp, vp, i32, i32, i32, f32, f32, u64, u32, vp, vp, vp, i32, vp]),
+    "dae_host_mt19937_keep_bits": (i32, [vp, vp, i64, C.c_double, vp]),
     "dae_encode_bits": (i32, [vp, i64, vp, i64, i32, i32, i32, vp, i64, i32, i64, vp]),
     "dae_gather_dense": (i32, [vp, i64, vp, i32, i32, i32, vp, vp, i64, vp, i64, vp, vp, i32, vp, u64, u32, f32, f32, vp]),
     "dae_gemm_nt": (i32, [i32, i32, i32, vp, i64, vp, i64, i32, vp, i64, vp, i64, i32, vp, i64, i32, i64, vp]),

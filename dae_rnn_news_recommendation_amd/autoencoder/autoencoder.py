@@ -313,11 +313,13 @@ class DenoisingAutoencoder(object):
         draw = dict(kind=self.corr_type)
         if self.corr_type == 'masking':
             if self.rng == 'numpy':
+                # the legacy stream, continued natively (bit-identical to np.random.rand(nnz) >= v, utils.py:111, resp. the
+                # np.random.choice([0, 1], size, p=[v, 1 - v]) of the dense path, utils.py:108)
                 if self.sparse_input:
-                    keep = utils.masking_keep(self.engine.csr["nnz"], self.corr_frac)        # np.random.rand(nnz) >= v
+                    bits = utils.masking_keep_bits(self.engine.csr["nnz"], self.corr_frac)
                 else:
-                    keep = np.random.choice(a=[0, 1], size=train_set.shape, p=[self.corr_frac, 1 - self.corr_frac]).ravel() != 0
-                draw['bits'] = utils.pack_keep_bits(keep).view(np.int32)
+                    bits = utils.masking_keep_bits(train_set.shape[0] * train_set.shape[1], utils.dense_masking_threshold(self.corr_frac))
+                draw['bits'] = bits.view(np.int32)
         elif self.corr_type == 'salt_and_pepper':
             v = int(np.round(self.corr_frac * train_set.shape[1]))                           # reference :187
             if self.rng == 'philox' and self.sparse_input:

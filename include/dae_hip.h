@@ -119,6 +119,14 @@ int dae_salt_pepper_batch(const int64_t* indptr, const int32_t* indices, const f
                           int32_t B, int32_t F, int32_t v, float lo, float hi, uint64_t seed, uint32_t rng_stream,
                           int64_t* out_span, int32_t* out_indices, float* out_values, int32_t cap, void* stream);
 
+/* Reference-exact masking noise on the HOST, continuing NumPy's legacy global stream natively (autoencoder/utils.py:111
+ * `np.random.rand(nnz) >= v`; dense input utils.py:108 `np.random.choice([0,1], size, p=[v,1-v])` consumes the same doubles):
+ * key[624] / *pos are the ('MT19937', key, pos, ...) fields of np.random.get_state(); n doubles are drawn (2 words each, a>>5
+ * and b>>6 as randomkit does) and bit e of bits_out (little-endian uint32 words, (n+31)/32 of them) = (double_e >= corr_frac),
+ * decided by an exact integer comparison.  key / *pos come back advanced: np.random.set_state with them continues the stream as
+ * if NumPy had drawn the n doubles.  HOST pointers; no stream; thread-safe for distinct states.  Returns 0, or 1 on bad input. */
+int dae_host_mt19937_keep_bits(uint32_t* key, int32_t* pos, int64_t n, double corr_frac, uint32_t* bits_out);
+
 /* Dense-ndarray input (autoencoder.py:143 sparse_input=False; utils.py:107-109 dense masking):
  * gathers fp32 rows data[row_idx[i], :] into x / xc / xct with optional Philox masking. */
 int dae_gather_dense(const float* data, int64_t ld_data, const int32_t* row_idx, int32_t B, int32_t F,

@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Freeze the per-batch loss curve of BASELINE.json configs[1] at FULL shape (8000 x 10000 binary CSR, H = 500, B = 800,
 batch_all, masking 0.3 with the reference-exact legacy-RNG stream, injected W0, SGD lr 0.1): 2 epochs = 20 steps of the
-float64 oracle (oracle.fit_reference, pinned to the reference's own fit loop by tests/test_golden_graph.py).
+oracle (oracle.fit_reference, pinned to the reference's own fit loop by tests/test_golden_graph.py) IN FLOAT32, the
+reference's dtype.  That matters at this shape: with lr 0.1 the decoder saturates from the 4th step on (y rounds to exactly
+1.0f for z > ~17), where TF's literal cross entropy evaluates log(1 - y + 1e-16) = log(1e-16) and its autodiff yields
+d loss/d z = 1e16 * y * (1 - y) = 0 for those units -- float64 arithmetic does neither (a float64 run of the same loop is
+5 % away at step 4 and 120 % away at step 10), so the float32 restatement is the oracle here.
 The GPU test (tests/test_hip_full_curve.py) runs DenoisingAutoencoder.fit() on the same regenerated inputs and compares
 batch by batch.  Takes a few minutes of CPU; the matrix is NOT stored (it is regenerated from the seeded generator).
 
@@ -39,7 +43,7 @@ def main():
     t0 = time.time()
     r = O.fit_reference(m, lab, W0, enc_act="sigmoid", dec_act="sigmoid", loss_func="cross_entropy", num_epochs=c["epochs"],
                         batch_size=c["batch"], opt="gradient_descent", learning_rate=c["learning_rate"], corr_type="masking",
-                        corr_frac=c["corr_frac"], seed=c["seed"], alpha=c["alpha"], triplet_strategy="batch_all", dt=np.float64)
+                        corr_frac=c["corr_frac"], seed=c["seed"], alpha=c["alpha"], triplet_strategy="batch_all", dt=np.float32)
     out = {k: np.array([h[k] for h in r["history"]], np.float64) for k in ("cost", "ae", "triplet", "fraction", "num")}
     out["W_checksum"] = np.array([np.abs(r["W"]).sum(), (r["W"] ** 2).sum(), r["W"][17, 3], r["W"][9999, 499]])
     out["indices_checksum"] = np.array([m.nnz, int(m.indices[::997].astype(np.int64).sum()), int(lab.sum())], np.int64)
