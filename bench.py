@@ -173,25 +173,29 @@ class Runner:
             n = self.m.size if isinstance(self.m, np.ndarray) else self.m.nnz
             v = 0.3 if not isinstance(self.m, np.ndarray) else utils.dense_masking_threshold(0.3)
             d["bits"] = utils.masking_keep_bits(n, v).view(np.int32)
-        d["order"] = utils.epoch_permutation(self.N)
+        order = utils.epoch_permutation(self.N)
+        # staged like DenoisingAutoencoder._stage_epoch: pinned tensors, uploaded asynchronously by the stepping thread
+        t = self.torch
+        if "bits" in d:
+            d["bits"] = t.from_numpy(d["bits"]).pin_memory()
+        o = order.astype(np.int32)
+        if self.explicit:
+            d["order"] = t.from_numpy(np.stack([o, o + self.N, o + 2 * self.N])).pin_memory()
+        else:
+            d["order"] = t.from_numpy(o).pin_memory()
+            d["labels"] = t.from_numpy(np.ascontiguousarray(self.labels[order])).pin_memory()
         return d
 
     def _prep_epoch(self):
         torch, L = self.torch, self.L
         d = self.feeder.get()
         if self.a.rng == "numpy":
-            self.bits = torch.from_numpy(d["bits"]).to(self.eng.device, non_blocking=True)
+            self.bits = d["bits"].to(self.eng.device, non_blocking=True)
             self.plan = dict(corr_mode=L.CORR_KEEPBITS, keep_bits=self.bits)
         else:
             self.plan = dict(corr_mode=L.CORR_PHILOX_MASK, seed=1234, rng_stream=self.epoch, corr_frac=0.3)
-        order = d["order"]
-        if self.explicit:
-            o = order.astype(np.int32)
-            self.order = torch.from_numpy(np.stack([o, o + self.N, o + 2 * self.N])).to(self.eng.device, non_blocking=True)
-            self.lab = None
-        else:
-            self.order = torch.from_numpy(order.astype(np.int32)).to(self.eng.device, non_blocking=True)
-            self.lab = torch.from_numpy(self.labels[order]).to(self.eng.device, non_blocking=True)
+        self.order = d["order"].to(self.eng.device, non_blocking=True)
+        self.lab = None if self.explicit else d["labels"].to(self.eng.device, non_blocking=True)
 
     def batch(self, b):
         lo = b * self.B

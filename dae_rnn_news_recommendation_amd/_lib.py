@@ -131,7 +131,7 @@ def load():
         fn = getattr(lib, name)      # AttributeError here == stale library
         fn.restype = res
         fn.argtypes = args
-    if lib.dae_abi_version() != 1:
+    if lib.dae_abi_version() != 2:
         raise RuntimeError("libdae_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -277,7 +277,7 @@ class DenoisingAutoencoder(object):
         self._stats = torch.zeros((max(self.num_epochs, 1), n_batches, L.STATS_STRIDE), dtype=torch.float32,
                                   device=eng.device)
         self._epoch_seconds = []
-        feeder = _EpochFeeder(lambda e: self._draw_epoch(train_set, e), self.num_epochs)
+        feeder = _EpochFeeder(lambda e: self._stage_epoch(self._draw_epoch(train_set, e), label_ids), self.num_epochs)
         t_fit = time.time()
         t_first = None
         i = -1
@@ -332,6 +332,20 @@ class DenoisingAutoencoder(object):
         draw['order'] = utils.epoch_permutation(n_rows)                                      # np.random.shuffle, after the corruption draws
         return draw
 
+    @staticmethod
+    def _stage_epoch(draw, label_ids):
+        """Feeder thread: the epoch's host arrays as PINNED tensors (row order, labels in that order, keep bits), so the training
+        thread's uploads are asynchronous copies instead of staged pageable ones."""
+        import torch
+        pin = (lambda t: t.pin_memory()) if torch.cuda.is_available() else (lambda t: t)
+        order = draw['order']
+        draw['order_t'] = pin(torch.from_numpy(order.astype(np.int32)))
+        if label_ids is not None:
+            draw['labels_t'] = pin(torch.from_numpy(np.ascontiguousarray(label_ids[order])))
+        if 'bits' in draw:
+            draw['bits_t'] = pin(torch.from_numpy(draw['bits']))
+        return draw
+
     def _corruption_plan(self, draw, epoch):
         """Keyword arguments of Engine.train_step that realise this epoch's corruption (uploads what the feeder drew)."""
         import torch
@@ -340,7 +354,7 @@ class DenoisingAutoencoder(object):
             if self.rng == 'philox':
                 seed = self.seed if self.seed >= 0 else 0x5EED
                 return dict(corr_mode=L.CORR_PHILOX_MASK, seed=seed, rng_stream=epoch, corr_frac=float(self.corr_frac))
-            bits = torch.from_numpy(draw['bits']).to(eng.device, non_blocking=True)
+            bits = (draw['bits_t'] if 'bits_t' in draw else torch.from_numpy(draw['bits'])).to(eng.device, non_blocking=True)
             self._keep_bits = bits                                                           # keep alive while steps run
             return dict(corr_mode=L.CORR_KEEPBITS, keep_bits=bits)
         if draw['kind'] == 'decay':
@@ -360,10 +374,10 @@ class DenoisingAutoencoder(object):
         N = train_set.shape[0]
         plan = self._corruption_plan(draw, epoch)
         order = draw['order']
-        order_dev = torch.from_numpy(order.astype(np.int32)).to(eng.device, non_blocking=True)
+        order_dev = (draw['order_t'] if 'order_t' in draw else torch.from_numpy(order.astype(np.int32))).to(eng.device, non_blocking=True)
         labels_dev = None
         if label_ids is not None:
-            labels_dev = torch.from_numpy(label_ids[order]).to(eng.device, non_blocking=True)
+            labels_dev = (draw['labels_t'] if 'labels_t' in draw else torch.from_numpy(label_ids[order])).to(eng.device, non_blocking=True)
         stats = self._stats[epoch]
         shard_w = []
         sp = plan.pop('_sp', None)

@@ -1,9 +1,9 @@
 """Data-parallel glue: one process per GPU, torch.distributed (backend "nccl" == RCCL on ROCm, over xGMI).
 
-The reference is single-process; the only exchange a data-parallel DAE step needs is the sum of the flat
-gradient [dW | dbh | dbv].  It is one bucket (20 MB at 10000x500) so a single all-reduce per step
-moves it; the optimizer kernel then applies ``grad_scale = 1/world`` (mean of the per-rank mean losses ==
-the global-batch mean for equal shards).  Mining is per-rank ("local mining", SURVEY 8e mode ii)."""
+The reference is single-process.  A data-parallel DAE step exchanges the W gradient, and xGMI is point-to-point (no switch), so
+the exchange is a reduce-scatter by row chunks + a sharded optimizer + an all-gather of the low-precision shadow
+(``ShardedExchange``) rather than one ring all-reduce of the flat gradient; the bias gradients (10.6 K floats) are all-reduced.
+Mining is per rank ("local", SURVEY 8e mode ii) or over the all-gathered global batch (``GlobalMiner``, mode i)."""
 from __future__ import annotations
 
 import os

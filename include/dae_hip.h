@@ -29,7 +29,7 @@ extern "C" {
 #endif
 
 #define DAE_PAD 128
-#define DAE_ABI_VERSION 1
+#define DAE_ABI_VERSION 2   /* 2: dae_step.c_row_idx, plan options replace environment switches, phases 4/5, sharded apply */
 
 enum { DAE_BF16 = 0, DAE_F32 = 1 };
 enum { DAE_ACT_NONE = 0, DAE_ACT_SIGMOID = 1, DAE_ACT_TANH = 2 };
