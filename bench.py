@@ -41,7 +41,8 @@ if ROOT not in sys.path:
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, MI355X_MICROARCH.md
 PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
-PEAK_VALU_TLANEOPS = 78.6      # 256 CUs x 4 SIMDs x 32 lanes/clk x 2.4 GHz (one fp32 VALU op per lane per clock)
+PEAK_VALU_TLANEOPS = 39.3      # 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz: one wave64 VALU instruction per SIMD per 4 clocks
+                               # (packed-fp32 instructions count once; they issue at this rate too on this part)
 
 CONFIGS = {
     "c1": dict(rows=8000, features=10000, cf=20, batch=800, strategy="none", kind="csr_binary", loss="cross_entropy",
@@ -278,10 +279,8 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
-def committed_traffic(kernel, cfg_name):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/*_pmc_traffic.json; FETCH_SIZE doubled
-    per the gfx950 correction of MI355X_MICROARCH.md).  PMC counters cannot be read from inside this process; the file records
-    the hash of the kernel sources it was measured on -- a stale file is refused (None + reason) instead of being quoted."""
+def _committed_pmc():
+    """The newest committed PMC file, if it was measured on the kernel sources of this checkout (else None + the reason)."""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
     if not files:
         return None, "no committed PMC pass"
@@ -292,9 +291,21 @@ def committed_traffic(kernel, cfg_name):
     if t.get("_source_hash") != source_hash():
         return None, "%s was measured on other kernel sources (hash %s, now %s): re-run tools/make_profile_report.sh" % (
             os.path.basename(files[-1]), t.get("_source_hash"), source_hash())
-    if t.get("_config", "c2") != cfg_name or kernel not in t:
-        return None, "no PMC pass for %s / %s" % (cfg_name, kernel)
-    return t[kernel]["fetch_bytes"] + t[kernel]["write_bytes"], os.path.basename(files[-1])
+    t["_file"] = os.path.basename(files[-1])
+    return t, None
+
+
+def committed_traffic(kernel, cfg_name):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/*_pmc_traffic.json; FETCH_SIZE doubled
+    per the gfx950 correction of MI355X_MICROARCH.md).  PMC counters cannot be read from inside this process; the file records
+    the hash of the kernel sources it was measured on -- a stale file is refused (None + reason) instead of being quoted."""
+    t, why = _committed_pmc()
+    if t is None:
+        return None, why
+    sec = t.get(cfg_name)
+    if not sec or kernel not in sec:
+        return None, "no PMC pass for %s / %s in %s" % (cfg_name, kernel, t["_file"])
+    return sec[kernel]["fetch_bytes"] + sec[kernel]["write_bytes"], t["_file"]
 
 
 def kernel_table(a, prof, nsteps):
@@ -404,10 +415,13 @@ def main():
         kern, step_us, (mfma, hbm) = kernel_table(a, prof, a.profile_steps)
         if "miner" in kern and kern["miner"].get("bound") == "valu":
             nv = float(np.mean(run.stats.cpu().numpy()[:, 5]))        # N_valid of the last epoch's batches
-            ops = 11.0                                                # VALU issue slots per triplet of the packed sweep
+            pmc, _ = _committed_pmc()
+            mv = (pmc or {}).get("miner_valu")
+            ops = mv["insts_per_triplet_lane"] if mv else 10.8        # VALU instructions per triplet-lane: SQ_INSTS_VALU x 64 / N_valid
             e = kern["miner"]
             e.update(achieved=nv * ops / (e["avg_us"] * 1e-6) / 1e12, peak=PEAK_VALU_TLANEOPS, unit="T lane-ops/s",
-                     note=f"N_valid = {nv:.3g} triplets x {ops:.0f} VALU slots")
+                     note=f"N_valid = {nv:.3g} triplets x {ops:.1f} VALU instructions per triplet-lane "
+                          + (f"(SQ_INSTS_VALU, {pmc['_file']})" if mv else "(round-2 PMC value; no PMC file for these sources)"))
             e["frac"] = e["achieved"] / e["peak"]
         out["kernels"] = kern
         out["profiled_step_us"] = step_us

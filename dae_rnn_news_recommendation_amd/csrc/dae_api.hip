@@ -91,6 +91,8 @@ struct dae_plan {
     hipStream_t side;
     hipEvent_t ev_fork, ev_join;
     bool overlap_ok;
+    bool miner_order_ok;              // dispatch the batch_all workgroups by descending sweep cost (LabelJob::order)
+    int32_t* miner_order;
     double prof_ms[PS_COUNT];
     int prof_n[PS_COUNT];
     dae_config cfg;
@@ -175,6 +177,7 @@ static uint64_t carve(dae_plan* p, char* base) {
     p->nvalid = (int64_t*)take(256);
     p->acc = (uint64_t*)take(256);
     p->tri_scalars = (float*)take(256);
+    p->miner_order = (int32_t*)take(Bp * 4);
     return off;
 }
 
@@ -214,6 +217,7 @@ extern "C" int dae_plan_create(const dae_config* cfg, dae_plan** out) {
     // binary CSR + bf16: x~ goes to the encode GEMM as a bit image whenever the 8-wave bit kernel can run the shape
     p->bits_ok = cfg->dtype == DAE_BF16 && encode_bits_fits(p->Bpm, p->Hp, p->Fp, p->s_enc);
     p->sparse_ok = true;
+    p->miner_order_ok = true;
     p->overlap_ok = false;                              // measured: running the miner chain beside decode is SLOWER (0.410 vs 0.351 ms/step)
     *out = p;
     return 0;
@@ -242,6 +246,7 @@ extern "C" int dae_plan_set_option(dae_plan* p, const char* name, int32_t value)
     else if (!strcmp(name, "label_with_encode")) p->label_enc_ok = on;
     else if (!strcmp(name, "ce_literal")) p->ce_literal = on;
     else if (!strcmp(name, "overlap")) p->overlap_ok = on;
+    else if (!strcmp(name, "miner_order")) p->miner_order_ok = on;
     else if (!strcmp(name, "gram_fp32")) {
         DAE_CHECK_ARG(!p->bound, "plan_set_option: gram_fp32 changes the workspace layout, set it before dae_plan_bind");
         p->gram_split = !on && p->cfg.dtype == DAE_BF16 && (p->cfg.triplet == DAE_TRIPLET_BATCH_ALL || p->cfg.triplet == DAE_TRIPLET_BATCH_HARD);
@@ -390,7 +395,7 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     // overwrites whole tiles and never needs it.
     const bool csr_in = s->c_indptr || p->b.indptr;
     // label statistics (cw, N_valid, data weights) depend on the labels alone: they ride on the CSR gather launch
-    LabelJob lj{s->labels, B, Bp, c.triplet, p->nvalid, p->dw_i64, p->cw, c.alpha, p->tri_scalars};
+    LabelJob lj{s->labels, B, Bp, c.triplet, p->nvalid, p->dw_i64, p->cw, c.alpha, p->tri_scalars, p->miner_order_ok ? p->miner_order : nullptr};
     // ... on the encode GEMM's launch when that grid leaves a CU free (else on the CSR gather's, else their own)
     const bool label_with_encode = p->tail_ok && !explicit3 && !ext_mine && Bp <= 1024 && p->label_enc_ok;
     const bool label_in_gather = p->tail_ok && !label_with_encode && !explicit3 && !ext_mine && !s->c_indptr && p->b.indptr && Bp <= 1024;
@@ -473,6 +478,8 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     const bool fold_finalize = (c.triplet == DAE_TRIPLET_BATCH_ALL && !c.pos_triplets_only) && !ext_mine;
     if (!ext_mine && (c.triplet == DAE_TRIPLET_BATCH_ALL || c.triplet == DAE_TRIPLET_BATCH_HARD)) {
         const int64_t dslab = (int64_t)Bp * Bp;
+        // the label block of this step's encode launch also ranked the anchors by sweep cost (only then is the buffer current)
+        const int32_t* order = (labels_done && !ext_mine && p->miner_order_ok && c.triplet == DAE_TRIPLET_BATCH_ALL) ? p->miner_order : nullptr;
         // batch_all (all valid triplets): cw comes from the labels alone -> the miner chain and the decode kernel are
         // independent until dL/dh; fork the chain onto the side stream (never while profiling: events are per stream)
         const bool overlap = p->overlap_ok && !p->prof && c.triplet == DAE_TRIPLET_BATCH_ALL && !c.pos_triplets_only;
@@ -491,16 +498,16 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
         void* mstream = (void*)ms;
         if (forked) {
             RC(launch_gram(p, Bp, Hp, dslab, ms));
-            RC(dae_triplet_batch_all(p->D_slabs, p->s_gram, dslab, Bp, s->labels, B, Bp, dt == DAE_BF16 ? DAE_MINER_FAST : 0, p->loss_part, p->cnt_part, p->G, p->role_cnt,
-                                     mstream));
+            RC(launch_batch_all(p->D_slabs, p->s_gram, dslab, Bp, s->labels, B, Bp, 0, B, dt == DAE_BF16 ? DAE_MINER_FAST : 0, p->loss_part, p->cnt_part, p->G,
+                                p->role_cnt, order, ms));
             if (backward) RC(dae_sym_scale(p->G, B, Bp, p->tri_scalars, dt, p->Gs, mstream));
             DAE_CHECK_HIP(hipEventRecord(p->ev_join, ms));
         } else {
             PROF(PS_GRAM, launch_gram(p, Bp, Hp, dslab, st));
             if (c.triplet == DAE_TRIPLET_BATCH_ALL)
-                PROF(PS_MINER, dae_triplet_batch_all(p->D_slabs, p->s_gram, dslab, Bp, s->labels, B, Bp,
+                PROF(PS_MINER, launch_batch_all(p->D_slabs, p->s_gram, dslab, Bp, s->labels, B, Bp, 0, B,
                                          (c.pos_triplets_only ? DAE_MINER_POS_ONLY : 0) | (dt == DAE_BF16 ? DAE_MINER_FAST : 0), p->loss_part,
-                                         p->cnt_part, p->G, p->role_cnt, stream));
+                                         p->cnt_part, p->G, p->role_cnt, order, st));
             else
                 PROF(PS_MINER, dae_triplet_batch_hard(p->D_slabs, p->s_gram, dslab, Bp, s->labels, B, Bp, p->loss_part, p->cnt_part, p->dw_i32, p->G,
                                           stream));

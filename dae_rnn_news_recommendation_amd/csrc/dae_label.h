@@ -73,6 +73,40 @@ __device__ __forceinline__ void label_stats_block(const LabelJob& j, char* smem)
         if ((t & 63) == 0) { atomicAdd(&acc[0], (unsigned long long)w1); atomicAdd(&acc[1], (unsigned long long)w2); }
     }
     __syncthreads();
+    if (j.order && triplet == DAE_TRIPLET_BATCH_ALL) {
+        // Counting sort of the rows by sweep cost (n-1)(B-n), descending.  The cost is a parabola in the class size n, so
+        // key = |2n - (B+1)| in [0, B) orders it (smaller key = longer sweep).  Slots inside a bucket are handed out by an LDS
+        // atomic: the order among equal-cost anchors is arbitrary, which is fine -- it only decides which workgroup runs first.
+        int* cntK = hist;                                                  // [1024]; the label histogram is no longer needed
+        for (int k = t; k < 1024; k += NT) cntK[k] = 0;
+        __syncthreads();
+        int key[E], slot[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int i = t + e * NT;
+            key[e] = 0; slot[e] = 0;
+            if (i < B) {
+                const int d = 2 * (int)n[e] - (B + 1);
+                key[e] = d < 0 ? -d : d;
+                slot[e] = atomicAdd(&cntK[key[e]], 1);
+            }
+        }
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {                         // inclusive scan of the 1024 bucket counts
+            int tmp[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) { const int i = t + e * NT; tmp[e] = (i >= off) ? cntK[i - off] : 0; }
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < E; ++e) { const int i = t + e * NT; cntK[i] += tmp[e]; }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int i = t + e * NT;
+            if (i < B) j.order[(key[e] > 0 ? cntK[key[e] - 1] : 0) + slot[e]] = i;
+        }
+    }
     const long long S = (long long)acc[0], NV = (long long)acc[1];
     if (t == 0 && j.nvalid) j.nvalid[0] = NV;
     if (t == 0 && j.tri_scalars && triplet == DAE_TRIPLET_BATCH_ALL) j.tri_scalars[0] = j.alpha / ((float)NV + 1e-16f);

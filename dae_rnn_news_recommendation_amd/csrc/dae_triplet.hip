@@ -14,6 +14,7 @@
 #include <type_traits>
 
 #include "dae_common.h"
+#include "dae_kernels.h"
 
 namespace dae {
 
@@ -254,7 +255,8 @@ __global__ __launch_bounds__(TRIP_THREADS, OCC) void batch_all_kernel(const floa
                                                                  int64_t slab_stride, int64_t ldd,
                                                                  const int32_t* __restrict__ labels, int B, int Bp,
                                                                  float* __restrict__ loss_part, uint32_t* __restrict__ npos_part,
-                                                                 float* __restrict__ G, uint32_t* __restrict__ role_cnt, int fast, int a0) {
+                                                                 float* __restrict__ G, uint32_t* __restrict__ role_cnt, int fast, int a0,
+                                                                 const int32_t* __restrict__ order) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // positives are compacted from the front of val[]/idx[], negatives from the back (nP + nN <= B)
     float* val = reinterpret_cast<float*>(smem);             // [Bp]
@@ -270,7 +272,9 @@ __global__ __launch_bounds__(TRIP_THREADS, OCC) void batch_all_kernel(const floa
 
     // anchors [a0, a0 + gridDim.x) of the batch: row `ar` of D / G / the partial arrays belongs to batch element a = a0 + ar
     // (a0 = 0 and a square D for a whole batch; a0 > 0 when a rank mines ITS anchors against an all-gathered batch)
-    const int ar = blockIdx.x, a = a0 + ar;
+    // `order` (whole-batch launches of the training step): workgroup b takes the b-th most expensive anchor, so the 3.1
+    // workgroups per CU start with the long sweeps and the ones that only get a slot late are the short ones
+    const int ar = order ? order[blockIdx.x] : blockIdx.x, a = a0 + ar;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     MINER_STAMP(0);
@@ -595,6 +599,15 @@ extern "C" int dae_triplet_batch_all(const float* D_slabs, int32_t d_splits, int
 extern "C" int dae_triplet_batch_all_rows(const float* D_slabs, int32_t d_splits, int64_t slab_stride, int64_t ldd,
                                           const int32_t* labels, int32_t B, int32_t Bp, int32_t a0, int32_t n_anchors, int32_t mode,
                                           float* loss_part, uint32_t* npos_part, float* G, uint32_t* role_cnt, void* stream) {
+    return launch_batch_all(D_slabs, d_splits, slab_stride, ldd, labels, B, Bp, a0, n_anchors, mode, loss_part, npos_part, G, role_cnt, nullptr,
+                            (hipStream_t)stream);
+}
+
+// order: optional dispatch order of the anchors (LabelJob::order; whole-batch launches only)
+int dae::launch_batch_all(const float* D_slabs, int d_splits, int64_t slab_stride, int64_t ldd, const int32_t* labels, int B, int Bp, int a0,
+                          int n_anchors, int mode, float* loss_part, uint32_t* npos_part, float* G, uint32_t* role_cnt, const int32_t* order,
+                          hipStream_t st) {
+    DAE_CHECK_ARG(!order || (a0 == 0 && n_anchors == B), "batch_all: a dispatch order needs the whole batch");
     DAE_CHECK_ARG(a0 >= 0 && n_anchors > 0 && a0 + n_anchors <= B, "batch_all: anchors [%d, %d) outside the batch of %d", a0, a0 + n_anchors, B);
     const int pos_only = mode & DAE_MINER_POS_ONLY, fast = (mode & DAE_MINER_FAST) ? 1 : 0;
     DAE_CHECK_ARG(D_slabs && labels && loss_part && npos_part && G, "batch_all: null input");
@@ -603,7 +616,7 @@ extern "C" int dae_triplet_batch_all_rows(const float* D_slabs, int32_t d_splits
     // val + idx + 4 per-wave gradient rows (+ 4 count rows when pos_only) + scans + reductions
     const size_t lds = (size_t)Bp * (pos_only ? 52 : 32) + 2 * (TRIP_THREADS + 1) * sizeof(int) + 8 * sizeof(float);
     DAE_CHECK_ARG(lds <= 160 * 1024, "batch_all: batch %d needs %zu B of LDS (> 160 KiB)", B, lds);
-    typedef void (*ba_fn)(const float*, int, int64_t, int64_t, const int32_t*, int, int, float*, uint32_t*, float*, uint32_t*, int, int);
+    typedef void (*ba_fn)(const float*, int, int64_t, int64_t, const int32_t*, int, int, float*, uint32_t*, float*, uint32_t*, int, int, const int32_t*);
     ba_fn k = pos_only ? batch_all_kernel<true, 3> : batch_all_kernel<false, 3>;      // 3 workgroups per CU (168 VGPRs)
     static bool attr_done = false;
     if (!attr_done) {
@@ -612,9 +625,8 @@ extern "C" int dae_triplet_batch_all_rows(const float* D_slabs, int32_t d_splits
             DAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
-    hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k, dim3(n_anchors), dim3(TRIP_THREADS), lds, st, D_slabs, d_splits, slab_stride, ldd, labels, B, Bp, loss_part, npos_part, G,
-                       role_cnt, fast, a0);
+                       role_cnt, fast, a0, order);
     DAE_CHECK_LAUNCH();
     return 0;
 }

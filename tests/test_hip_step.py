@@ -189,6 +189,21 @@ def test_dw_producer_consumer_kernel_equals_four_wave_kernel(opt):
         assert _rel(u, np.asarray(v, np.float64)) < 1e-6
 
 
+@pytest.mark.parametrize("dtype,B", [("bf16", 150), ("fp32", 333), ("bf16", 800)])
+def test_miner_dispatch_order_changes_nothing(dtype, B):
+    """The label block ranks the anchors by sweep cost and the batch_all workgroups are dispatched in that order (option
+    miner_order, default on).  Every anchor is still computed by one workgroup in the same way: statistics, gradients and
+    parameters must be bit-identical with the order off."""
+    kw = dict(steps=2, seed=41, B=B, N=max(400, 2 * B), F=700, H=90)
+    a, _, pa = _run_case(dtype, "batch_all", "cross_entropy", ("sigmoid", "sigmoid"), "gradient_descent", **kw)
+    b, _, pb = _run_case(dtype, "batch_all", "cross_entropy", ("sigmoid", "sigmoid"), "gradient_descent", options={"miner_order": 0}, **kw)
+    for (_, sa, dWa, dbha, dbva), (_, sb, dWb, dbhb, dbvb) in zip(a, b):
+        assert np.array_equal(sa[:6], sb[:6])
+        assert np.array_equal(dWa, dWb) and np.array_equal(dbha, dbhb) and np.array_equal(dbva, dbvb)
+    for u, v in zip(pa, pb):
+        assert np.array_equal(np.asarray(u), np.asarray(v))
+
+
 def test_phase3_updates_like_phase0():
     """phase 3 (no W-gradient image) must leave the same parameters as phase 0."""
     from dae_rnn_news_recommendation_amd import _lib as L

@@ -1,43 +1,50 @@
 #!/usr/bin/env python3
 """Turn one `tools/make_profile_report.sh <tag>` run (gpurun_out/<tag>/) into the committed round artefacts under profiles/:
-bench JSON lines, the rocprofv3 kernel-trace and PMC tables, the per-launch HBM traffic JSON bench.py reads back, and a summary.
+the bench JSON lines of the five configs, the rocprofv3 kernel-trace and PMC tables, the per-launch HBM traffic JSON bench.py
+reads back (stamped with the hash of the kernel sources it was measured on) and a summary.
 
-usage: python tools/build_profile_summary.py gpurun_out/r01c r01"""
-import json, os, re, shutil, sys
+usage: python tools/build_profile_summary.py gpurun_out/r02 r02"""
+import json, os, shutil, sys
 
 src, rnd = sys.argv[1], sys.argv[2]
-dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
-SLOT_KERNEL = [("gather", "gather_csr_kernel"), ("encode_gemm", "gemm_nt_pc<unsigned short, 4, 1>"), ("encode_finish", "encode_finish_kernel"),
-               ("gram", "gemm_nt_pc<unsigned short, 4, 4>"), ("miner", "batch_all_kernel"), ("sym_scale", "sym_scale_kernel"),
-               ("decode_loss", "gemm_decode_loss"), ("dh_gemm", "gemm_nt_pc<unsigned short, 4, 2>"), ("dh_finish", "dh_finish_kernel"),
-               ("dw_gemm", "gemm_dw_opt"), ("bias_grads", "step_tail_kernel")]
-NOTE = {"gather": "CSR rows -> x~ tile, x bit image, x~^T scatter", "encode_gemm": "8-wave producer/consumer, split-K 8; + label statistics workgroup",
-        "encode_finish": "slab reduction, bias, act, h / h^T / split-bf16 images", "gram": "split-bf16 (3 products), split-K 4",
-        "miner": "batch_all, pair-packed sweep", "sym_scale": "Gs = a/Nv (G + G^T) -> bf16", "decode_loss": "GEMM + loss + delta2 (two layouts), x from bits",
-        "dh_gemm": "delta2.W + Gs.h, split-K 8", "dh_finish": "slab reduction, act', delta1^T, column sums",
-        "dw_gemm": "dW GEMM + SGD update of W and both bf16 shadows", "bias_grads": "step tail: bias grads + update, statistics, x~^T un-scatter"}
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+dst = os.path.join(root, "profiles")
+# step slot (bench.py `kernels` key) -> kernel symbol prefix in the rocprofv3 tables
+SLOT_KERNEL = [("encode_gemm", "encode_csr_kernel"), ("gram", "gemm_nt_pc<unsigned short, 4, 4>"), ("miner", "batch_all_kernel"),
+               ("sym_scale", "sym_scale_kernel"), ("decode_loss", "gemm_decode_loss"), ("dh_gemm", "gemm_nt_pc<unsigned short, 4, 2>"),
+               ("dh_finish", "dh_finish_kernel"), ("dw_gemm", "gemm_dw_pc"), ("bias_grads", "step_tail_kernel")]
+SLOT_KERNEL_C4 = [("gather", "gather_dense_kernel"), ("encode_gemm", "gemm_nt_pc<unsigned short, 4, 1>"), ("encode_finish", "encode_finish_kernel"),
+                  ("decode_loss", "gemm_decode_loss"), ("dh_gemm", "gemm_nt_pc<unsigned short, 4, 2>"), ("dw_gemm", "gemm_dw")]
+NOTE = {"encode_gemm": "corrupt + gather + sparse x~.W + bias + act, all images of h, x bit image, x~^T scatter, label statistics",
+        "gram": "split-bf16 (3 products), split-K 4", "miner": "batch_all, pair-packed FAST sweep", "sym_scale": "Gs = a/Nv (G + G^T) -> bf16",
+        "decode_loss": "128 x 64 tiles: GEMM + loss + delta2 (two layouts), x from bits", "dh_gemm": "delta2.W + Gs.h, split-K 8",
+        "dh_finish": "slab reduction, act', delta1^T, column sums", "dw_gemm": "160 x 128 tiles: dW GEMM + SGD update of W and both bf16 shadows",
+        "bias_grads": "step tail: bias grads + update, statistics, x~^T un-scatter"}
+
 
 def copy(a, b):
     if os.path.exists(os.path.join(src, a)):
         shutil.copy(os.path.join(src, a), os.path.join(dst, f"{rnd}_{b}"))
 
-copy("bench.json", "bench_n1.json"); copy("bench_numpy_rng.json", "bench_n1_numpy_rng.json"); copy("bench_none.json", "bench_n1_strategy_none.json")
-copy("bench_batch_hard.json", "bench_n1_batch_hard.json"); copy("bench_under_rocprof.json", "bench_under_rocprof.json")
-copy("kernel_stats.md", "rocprofv3_kernel_stats.md"); copy("pmc_counters.md", "rocprofv3_pmc_counters.md"); copy("host.txt", "host.txt")
-copy("gemm_trace.txt", "gemm_trace.txt"); copy("kprof.txt", "kprof.txt")
+
+for c in ("c1", "c2", "c3", "c4", "c5"):
+    copy(f"bench_{c}.json", f"bench_n1_{c}.json")
+copy("bench_under_rocprof.json", "bench_under_rocprof.json")
+copy("kernel_stats.md", "rocprofv3_kernel_stats.md"); copy("pmc_counters.md", "rocprofv3_pmc_counters.md")
+copy("pmc_counters_c4.md", "rocprofv3_pmc_counters_c4.md"); copy("host.txt", "host.txt")
+copy("kprof.txt", "kprof.txt"); copy("miner_timeline.txt", "miner_timeline.txt")
+
 
 def table(path):
     rows = []
+    if not os.path.exists(path):
+        return rows
     for line in open(path):
         c = [x.strip() for x in line.strip().strip("|").split("|")]
         if len(c) >= 4 and c[0].startswith("`"):
             rows.append(c)
     return rows
 
-stats = {r[0].strip("`"): float(r[3]) for r in table(os.path.join(src, "kernel_stats.md"))}
-pmc = {}
-for r in table(os.path.join(src, "pmc_counters.md")):
-    pmc.setdefault(r[0].strip("`"), {})[r[1]] = float(r[3])
 
 def find(d, key):
     for k, v in d.items():
@@ -45,52 +52,95 @@ def find(d, key):
             return v
     return None
 
+
+def load(name):
+    p = os.path.join(src, name)
+    try:
+        return json.loads(open(p).read().strip().splitlines()[-1])
+    except Exception:       # noqa: BLE001
+        return None
+
+
+stats = {r[0].strip("`"): float(r[3]) for r in table(os.path.join(src, "kernel_stats.md"))}
+
+
+def pmc_of(fname):
+    out = {}
+    for r in table(os.path.join(src, fname)):
+        out.setdefault(r[0].strip("`"), {})[r[1]] = float(r[3])
+    return out
+
+
+pmc, pmc4 = pmc_of("pmc_counters.md"), pmc_of("pmc_counters_c4.md")
 traffic = {"_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), per launch, KB->bytes, FETCH_SIZE doubled (gfx950 "
-                    "correction, MI355X_MICROARCH.md); workload = tools/run_steps.py (BASELINE configs[1] step)"}
-for slot, kern in SLOT_KERNEL:
-    c = find(pmc, kern)
-    if c and "FETCH_SIZE" in c:
-        traffic[slot] = {"fetch_bytes": int(c["FETCH_SIZE"] * 1024 * 2), "write_bytes": int(c.get("WRITE_SIZE", 0) * 1024)}
+                    "correction, MI355X_MICROARCH.md); workload = tools/run_steps.py (c2: BASELINE configs[1] step; c4: dense F = 50000)",
+           "_source_hash": open(os.path.join(src, "source_hash.txt")).read().strip()}
+for cfg, slots, tab in (("c2", SLOT_KERNEL, pmc), ("c4", SLOT_KERNEL_C4, pmc4)):
+    traffic[cfg] = {}
+    for slot, kern in slots:
+        c = find(tab, kern)
+        if c and "FETCH_SIZE" in c:
+            traffic[cfg][slot] = {"fetch_bytes": int(c["FETCH_SIZE"] * 1024 * 2), "write_bytes": int(c.get("WRITE_SIZE", 0) * 1024)}
+# miner: VALU instructions per triplet-lane (SQ_INSTS_VALU counts wave instructions)
+m = find(pmc, "batch_all_kernel")
+try:
+    nv = float(open(os.path.join(src, "run_steps.txt")).read().split("mean_n_valid")[1].split()[0])
+except Exception:       # noqa: BLE001
+    nv = None
+if m and nv and "SQ_INSTS_VALU" in m:
+    traffic["miner_valu"] = {"wave_insts_per_launch": m["SQ_INSTS_VALU"], "n_valid": nv, "insts_per_triplet_lane": m["SQ_INSTS_VALU"] * 64.0 / nv,
+                             "active_quad_cycles": m.get("SQ_ACTIVE_INST_VALU")}
 json.dump(traffic, open(os.path.join(dst, f"{rnd}_pmc_traffic.json"), "w"), indent=1)
 
-b = json.load(open(os.path.join(src, "bench.json")))
-def val(name):
-    p = os.path.join(src, name)
-    return json.load(open(p)) if os.path.exists(p) else None
-bn, b0, bh = val("bench_numpy_rng.json"), val("bench_none.json"), val("bench_batch_hard.json")
+b = load("bench_c2.json")
 host = open(os.path.join(src, "host.txt")).read().split("\n")
 L = []
 L.append(f"# Round {rnd[1:]} -- measured on 1x MI355X (gfx950), ROCm 7.2, host: {host[1].split(':')[-1].strip() if len(host) > 1 else '?'} ({host[0]} hw threads)\n")
-L.append("Workload: BASELINE.json configs[1] -- synthetic 8000x10000 binary CSR (~200 nnz/row), H=500, B=800, batch_all, masking 0.3,\n"
-         "cross_entropy, SGD lr 0.1, bf16 MFMA operands + fp32 accumulate/master weights.  Command: `python bench.py --steps 300 --warmup 30`\n"
-         "(all files of this set come from ONE `tools/make_profile_report.sh` run, i.e. one box; boxes of the pool differ by up to 1.5x on the\n"
-         "memory-bound kernels -- the same binary measured 210 us/step on this box and ~300 us/step on the slowest one seen).\n")
-L.append("\n## Headline\n\n| metric | value |\n|---|---|")
+L.append("All files of this set come from ONE `tools/make_profile_report.sh` run (one box; boxes of the pool differ by up to 1.4x on the same\n"
+         f"binary).  Kernel sources hash `{traffic['_source_hash']}` (bench.source_hash).\n")
+L.append("\n## Headline (`python bench.py --steps 300 --warmup 30`, default config c2 = BASELINE configs[1])\n\n| metric | value |\n|---|---|")
 L.append(f"| training samples/s (device-Philox masking, `value`) | **{b['value']:,.0f}** ({1e3 * b['ms_per_step']:.1f} us/step) |")
-if bn: L.append(f"| same, reference-exact NumPy legacy RNG stream (`--rng numpy`) | {bn['value']:,.0f} ({1e3 * bn['ms_per_step']:.1f} us/step; host RNG per epoch) |")
-if b0: L.append(f"| `--strategy none` (BASELINE configs[0] shape on the GPU) | {b0['value']:,.0f} ({1e3 * b0['ms_per_step']:.1f} us/step) |")
-if bh: L.append(f"| `--strategy batch_hard` | {bh['value']:,.0f} ({1e3 * bh['ms_per_step']:.1f} us/step) |")
+f = b.get("fit", {})
+if "philox" in f: L.append(f"| through `DenoisingAutoencoder.fit()` (N x timed epochs / wall, first epoch excluded), Philox | {f['philox']['samples_per_s']:,.0f} |")
+if "numpy" in f: L.append(f"| same, reference-exact NumPy legacy stream (native MT19937 continuation, feeder thread) | {f['numpy']['samples_per_s']:,.0f} |")
 cb = b.get("cpu_baseline")
-if cb: L.append(f"| CPU baseline: NumPy oracle ('{cb['kind']}'; TF 1.12 cannot run here), 1 step, {cb['cores']} host threads | {cb['value']:.1f} samples/s ({cb['seconds']:.1f} s/step) |")
+if cb and cb.get("value"):
+    L.append(f"| CPU baseline: PyTorch-CPU fp32 restatement, literal B^3 batch_all, {cb['cores']} threads | {cb['value']:.1f} samples/s |")
+    if cb.get("chunked"): L.append(f"| CPU baseline, chunked (memory-lean) form | {cb['chunked']['samples_per_s']:.1f} samples/s |")
 fl = b["final_losses"]
 L.append(f"| final losses (means over the last epoch's batches) | cost {fl['cost']:.2f}, AE {fl['autoencoder']:.2f}, triplet {fl['triplet']:.4f}, fraction {fl['fraction']:.4f} |")
-r = b["roofline"]
-L.append(f"| roofline of the fused-encode GEMM (2BFH = 8.0 GFLOP / launch) | {r['achieved']:.0f} TFLOP/s = **{100 * r['frac']:.1f} %** of 2.5 PFLOP/s dense bf16 (HIP events); "
-         f"{8.0e9 / (find(stats, 'gemm_nt_pc<unsigned short, 4, 1>') * 1e-6) / 1e12:.0f} TFLOP/s by the rocprofv3 duration |")
-L.append("\n## Per-kernel breakdown of one step (HIP events on the step's stream vs rocprofv3 --kernel-trace of the same bench)\n")
-L.append("| step slot | kernel symbol | HIP-event avg us | rocprofv3 avg us | MFMA frac of peak (events) | HBM read MB (FETCH_SIZE x2) | HBM write MB | what it does |")
-L.append("|---|---|---:|---:|---:|---:|---:|---|")
+r = b.get("roofline")
+if r: L.append(f"| `roofline` ({r['kernel'].split(' (')[0]}) | {r['achieved']:.0f} {r['unit']} = **{100 * r['frac']:.1f} %** of {r['peak']:.0f}; traffic {r['traffic']} B ({r.get('traffic_source')}) |")
+sr = b.get("step_roofline")
+if sr: L.append(f"| whole step | {100 * sr['mfma_frac_dense_accounting']:.1f} % of bf16 MFMA peak by dense accounting (10.B.F.H), {100 * sr['hbm_frac_min_bytes']:.1f} % of HBM peak by minimum bytes |")
+L.append("\n## The other named configs (one JSON line each in this directory)\n\n| config | samples/s | us/step | fit() Philox | fit() numpy RNG | roofline |\n|---|---:|---:|---:|---:|---|")
+for c in ("c1", "c2", "c3", "c4", "c5"):
+    x = load(f"bench_{c}.json")
+    if not x: continue
+    ff = x.get("fit", {})
+    rr = x.get("roofline") or {}
+    L.append(f"| {c} | {x['value']:,.0f} | {1e3 * x['ms_per_step']:.1f} | {ff.get('philox', {}).get('samples_per_s', float('nan')):,.0f} | "
+             f"{ff.get('numpy', {}).get('samples_per_s', float('nan')):,.0f} | {rr.get('bound', '')} {100 * rr.get('frac', 0):.1f} % ({rr.get('kernel', '').split(' (')[0]}) |")
+L.append("\n## Per-kernel breakdown of one c2 step (HIP events on the step's stream vs rocprofv3 --kernel-trace of the same bench)\n")
+L.append("| step slot | kernel symbol | HIP-event avg us | rocprofv3 avg us | roofline (events) | HBM read MB (FETCH_SIZE x2) | HBM write MB | what it does |")
+L.append("|---|---|---:|---:|---|---:|---:|---|")
 tot_ev = 0.0; tot_rp = 0.0
 for slot, kern in SLOT_KERNEL:
-    k = b["kernels"].get(slot)
+    k = b.get("kernels", {}).get(slot)
     if not k: continue
-    rp = find(stats, kern); t = traffic.get(slot)
-    tot_ev += k["avg_us"]; tot_rp += rp or 0.0
-    L.append(f"| {slot} | `{kern}` | {k['avg_us']:.1f} | {rp:.1f} | {('%.1f %%' % (100 * k['frac'])) if 'frac' in k else ''} | "
+    rp = find(stats, kern) or float("nan"); t = traffic["c2"].get(slot)
+    tot_ev += k["avg_us"]; tot_rp += rp
+    roof = f"{k['bound']} {100 * k['frac']:.1f} %" if "frac" in k else ""
+    L.append(f"| {slot} | `{kern}` | {k['avg_us']:.1f} | {rp:.1f} | {roof} | "
              f"{(t['fetch_bytes'] / 1e6 if t else float('nan')):.1f} | {(t['write_bytes'] / 1e6 if t else float('nan')):.1f} | {NOTE[slot]} |")
-L.append(f"\nSums: {tot_ev:.0f} us with event brackets (each bracket adds a host sync and ~2 us), {tot_rp:.0f} us of rocprofv3 kernel time; the\n"
-         f"un-profiled step is {1e3 * b['ms_per_step']:.1f} us -- the stream is back-to-back kernels, there is no launch gap left to remove.\n")
-L.append("PMC detail (MFMA busy, wave cycles, waits, LDS bank conflicts per kernel): `%s_rocprofv3_pmc_counters.md`; K-loop phase clocks of the\n"
-         "4-wave GEMM kernel: `%s_gemm_trace.txt`; what was tried and what it bought: `%s_experiments.md`.\n" % (rnd, rnd, rnd))
+tb = sum(v["fetch_bytes"] + v["write_bytes"] for v in traffic["c2"].values())
+L.append(f"\nSums: {tot_ev:.0f} us with event brackets (each adds a host sync and ~2 us), {tot_rp:.0f} us of rocprofv3 kernel time; the un-profiled\n"
+         f"step is {1e3 * b['ms_per_step']:.1f} us (ramp and tail of consecutive kernels overlap).  PMC bytes per step: {tb / 1e6:.0f} MB.\n")
+if "miner_valu" in traffic:
+    mv = traffic["miner_valu"]
+    L.append(f"Miner VALU accounting (PMC): {mv['wave_insts_per_launch']:.3g} wave instructions per launch for N_valid = {mv['n_valid']:.3g} triplets = "
+             f"**{mv['insts_per_triplet_lane']:.1f} VALU instructions per triplet-lane**.\n")
+L.append(f"PMC detail: `{rnd}_rocprofv3_pmc_counters.md` (c4: `{rnd}_rocprofv3_pmc_counters_c4.md`); per-workgroup timeline of the miner: `{rnd}_miner_timeline.txt`;\n"
+         f"`tools/kprof.py` output: `{rnd}_kprof.txt`; what was tried and what it bought: `{rnd}_experiments.md`.\n")
 open(os.path.join(dst, f"{rnd}_summary.md"), "w").write("\n".join(L))
 print("\n".join(L))
