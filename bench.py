@@ -87,6 +87,9 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N>1 (nccl == RCCL; gloo only to exercise the N>1 code path on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="testing aid: every rank uses cuda:0")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="diagnostic: with --gpus 1, run the data-parallel step form (phase-1 step + reduce-scatter / sharded optimizer / "
+                         "all-gather over a one-rank RCCL group): the cost of the N>1 step without its communication")
     a = ap.parse_args()
     c = dict(CONFIGS[a.config])
     for k, v in (("rows", a.rows), ("features", a.features), ("cf", a.compress_factor), ("batch", a.batch)):
@@ -155,7 +158,7 @@ class Runner:
             self.eng.upload_csr(data)
         self.eng.set_params(xavier_uniform(F, H, seed=42))
         self.exchange = None
-        if world > 1:
+        if world > 1 or a.force_exchange:
             from dae_rnn_news_recommendation_amd import dp
             self.exchange = dp.ShardedExchange(self.eng, grad_dtype=a.grad_dtype)
         self.nb = -(-self.N // self.B)
@@ -211,7 +214,7 @@ class Runner:
             self.epoch += 1
             self._prep_epoch()
         rows, labs = self.batch(b)
-        if self.world > 1:
+        if self.exchange is not None:
             self.eng.train_step(rows, labs, self.stats[b], phase=1, **self.plan)
             self.exchange.step(grad_scale=1.0 / self.world)
         else:
@@ -349,6 +352,12 @@ def main():
     from dae_rnn_news_recommendation_amd import dp
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if world == 1 and a.force_exchange:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        torch.cuda.set_device(0)
+        dist.init_process_group(backend=a.backend, rank=0, world_size=1)
+        dp.quiet_first_collective()
     if world > 1:
         if a.single_device:
             os.environ["LOCAL_RANK"] = "0"
@@ -464,7 +473,7 @@ def main():
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if dp.is_initialized():
         import torch.distributed as dist
         dp.barrier()
         dist.destroy_process_group()

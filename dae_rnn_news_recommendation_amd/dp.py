@@ -42,6 +42,33 @@ def init_from_env(backend=None):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
     dist.init_process_group(backend=backend, rank=int(os.environ["RANK"]), world_size=ws)
+    quiet_first_collective()
+
+
+def quiet_first_collective():
+    """RCCL creates its communicator at the first collective and prints a version banner to STDOUT while doing so (C stdio,
+    flushed at exit -- i.e. after anything Python printed).  Callers like bench.py promise ONE JSON line on stdout, so the first
+    collective is issued here with file descriptor 1 pointed at stderr, and the C buffers are flushed before it is restored."""
+    import ctypes
+    import sys
+    import torch
+    import torch.distributed as dist
+    if not is_initialized():
+        return
+    sys.stdout.flush()
+    libc = ctypes.CDLL(None)
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        t = torch.zeros(1, device=dev)
+        dist.all_reduce(t)
+        if dev == "cuda":
+            torch.cuda.synchronize()
+        libc.fflush(None)
+    finally:
+        os.dup2(saved, 1)
+        os.close(saved)
 
 
 def allreduce_sum_(flat):

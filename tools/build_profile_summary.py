@@ -32,7 +32,7 @@ for c in ("c1", "c2", "c3", "c4", "c5"):
 copy("bench_under_rocprof.json", "bench_under_rocprof.json")
 copy("kernel_stats.md", "rocprofv3_kernel_stats.md"); copy("pmc_counters.md", "rocprofv3_pmc_counters.md")
 copy("pmc_counters_c4.md", "rocprofv3_pmc_counters_c4.md"); copy("host.txt", "host.txt")
-copy("kprof.txt", "kprof.txt"); copy("miner_timeline.txt", "miner_timeline.txt")
+copy("kprof.txt", "kprof.txt"); copy("miner_timeline.txt", "miner_timeline.txt"); copy("dp_step_breakdown.txt", "dp_step_breakdown.txt")
 
 
 def table(path):
@@ -140,6 +140,9 @@ if "miner_valu" in traffic:
     mv = traffic["miner_valu"]
     L.append(f"Miner VALU accounting (PMC): {mv['wave_insts_per_launch']:.3g} wave instructions per launch for N_valid = {mv['n_valid']:.3g} triplets = "
              f"**{mv['insts_per_triplet_lane']:.1f} VALU instructions per triplet-lane**.\n")
+if os.path.exists(os.path.join(src, "dp_step_breakdown.txt")):
+    L.append("## Data-parallel step form without communication (one-rank RCCL group, `tools/dp_step_breakdown.py`)\n\n```\n"
+             + "".join(l for l in open(os.path.join(src, "dp_step_breakdown.txt")) if "us" in l or "step" in l or "rank" in l) + "```\n")
 L.append(f"PMC detail: `{rnd}_rocprofv3_pmc_counters.md` (c4: `{rnd}_rocprofv3_pmc_counters_c4.md`); per-workgroup timeline of the miner: `{rnd}_miner_timeline.txt`;\n"
          f"`tools/kprof.py` output: `{rnd}_kprof.txt`; what was tried and what it bought: `{rnd}_experiments.md`.\n")
 open(os.path.join(dst, f"{rnd}_summary.md"), "w").write("\n".join(L))

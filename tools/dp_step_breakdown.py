@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Where the data-parallel step form spends its time WITHOUT communication: a one-rank RCCL group on one GPU runs
+phase-1 step -> reduce-scatter -> sharded apply -> all-gather -> transpose rebuild, each piece bracketed by events.
+usage: python tools/dp_step_breakdown.py [--grad-dtype fp32|bf16]"""
+import argparse, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch, torch.distributed as dist
+from dae_rnn_news_recommendation_amd import _lib as L, dp
+from dae_rnn_news_recommendation_amd.engine import Engine
+from dae_rnn_news_recommendation_amd.synthetic import synthetic_csr, synthetic_labels, xavier_uniform
+ap = argparse.ArgumentParser(); ap.add_argument("--grad-dtype", default="fp32"); a = ap.parse_args()
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29534")
+torch.cuda.set_device(0); dist.init_process_group("nccl", rank=0, world_size=1); dp.quiet_first_collective()
+F, H, B = 10000, 500, 800
+m = synthetic_csr(1600, F, seed=1); lab = synthetic_labels(1600, seed=1).astype(np.int32)
+eng = Engine(F, H, B, dtype="bf16", triplet="batch_all", learning_rate=0.1, dp_world=1)
+eng.upload_csr(m); eng.set_params(xavier_uniform(F, H))
+ex = dp.ShardedExchange(eng, grad_dtype=a.grad_dtype)
+idx = torch.arange(B, dtype=torch.int32, device="cuda"); labs = torch.from_numpy(lab[:B]).cuda(); stats = torch.zeros(8, device="cuda")
+kw = dict(corr_mode=L.CORR_PHILOX_MASK, seed=1, rng_stream=0, corr_frac=0.3)
+def timed(fn, n=50):
+    for _ in range(5): fn()
+    torch.cuda.synchronize(); e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    import time; t0 = time.perf_counter(); e0.record()
+    for _ in range(n): fn()
+    e1.record(); host = (time.perf_counter() - t0) / n * 1e6; torch.cuda.synchronize()
+    return 1e3 * e0.elapsed_time(e1) / n, host
+Hp, c = eng.Hp, eng.chunk_rows
+gw = eng.grad[:ex.n_w]; bias = eng.grad[eng.Fp * Hp:eng.Fp * Hp + Hp + eng.Fp]
+rows = [("fused single-GPU step (phase 3)", lambda: eng.train_step(idx, labs, stats, phase=3, **kw)),
+        ("phase-1 step (gradient to memory)", lambda: eng.train_step(idx, labs, stats, phase=1, **kw)),
+        ("reduce_scatter (1 rank)", lambda: dist.reduce_scatter_tensor(ex.rs_out, gw if a.grad_dtype == "fp32" else gw.to(torch.bfloat16))),
+        ("all_reduce bias (1 rank)", lambda: dist.all_reduce(bias)),
+        ("apply_rows (all rows at 1 rank)", lambda: eng.apply_rows(ex.rs_f32, ex.f0, ex.f1, grad_scale=1.0, update_bias=True)),
+        ("copy of my W_lo rows", lambda: ex.my_lo.copy_(eng.W_lo_full[:c])),
+        ("all_gather (1 rank)", lambda: dist.all_gather_into_tensor(eng.W_lo_full.view(-1), ex.my_lo.view(-1))),
+        ("refresh_wt (transpose rebuild)", lambda: eng.refresh_wt()),
+        ("whole exchange.step", lambda: ex.step(grad_scale=1.0)),
+        ("phase-1 step + exchange.step", lambda: (eng.train_step(idx, labs, stats, phase=1, **kw), ex.step(grad_scale=1.0)))]
+print(f"{'piece':40s} {'GPU us':>9s} {'host us/call':>13s}")
+for name, fn in rows:
+    g, h = timed(fn)
+    print(f"{name:40s} {g:9.1f} {h:13.1f}")
+dist.destroy_process_group()

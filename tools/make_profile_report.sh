@@ -27,6 +27,7 @@ python tools/pmc_summary.py $OUT/pmc_fetch4/f4_results.db $OUT/pmc_write4/w4_res
 rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/pmc_sq2 $OUT/pmc_fetch4 $OUT/pmc_write4
 $T python tools/kprof.py > $OUT/kprof.txt 2>/dev/null
 [ -f dae_rnn_news_recommendation_amd/libdae_mp4.so ] && $T python tools/miner_timeline.py --lib dae_rnn_news_recommendation_amd/libdae_mp4.so > $OUT/miner_timeline.txt 2>/dev/null
+$T python tools/dp_step_breakdown.py > $OUT/dp_step_breakdown.txt 2>/dev/null
 python -c "import bench; print(bench.source_hash())" > $OUT/source_hash.txt
 nproc > $OUT/host.txt; lscpu | grep "Model name" >> $OUT/host.txt; rocminfo | grep -E "gfx|Compute Unit" | head -4 >> $OUT/host.txt
 ls -la $OUT
