@@ -306,9 +306,13 @@ def committed_traffic(kernel, cfg_name):
     if t is None:
         return None, why
     sec = t.get(cfg_name)
+    src = t["_file"]
+    if (not sec or kernel not in sec) and cfg_name in ("c1", "c3") and kernel in ("dw_gemm", "decode_loss", "dh_gemm", "encode_gemm"):
+        sec = t.get("c2")           # c1 / c3 run the same kernels on the same shapes as c2 (only the miner differs)
+        src += " (c2 pass: same kernel, same shape)"
     if not sec or kernel not in sec:
         return None, "no PMC pass for %s / %s in %s" % (cfg_name, kernel, t["_file"])
-    return sec[kernel]["fetch_bytes"] + sec[kernel]["write_bytes"], t["_file"]
+    return sec[kernel]["fetch_bytes"] + sec[kernel]["write_bytes"], src
 
 
 def kernel_table(a, prof, nsteps):

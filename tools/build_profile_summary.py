@@ -3,10 +3,13 @@
 the bench JSON lines of the five configs, the rocprofv3 kernel-trace and PMC tables, the per-launch HBM traffic JSON bench.py
 reads back (stamped with the hash of the kernel sources it was measured on) and a summary.
 
-usage: python tools/build_profile_summary.py gpurun_out/r02 r02"""
+usage: python tools/build_profile_summary.py gpurun_out/r02 r02 [--traffic-only]
+(--traffic-only: just the PMC traffic JSON -- make_profile_report.sh calls it on the GPU box between the PMC passes and the bench
+runs, so that the bench lines of the same run can quote the traffic of the kernels they are timing)"""
 import json, os, shutil, sys
 
 src, rnd = sys.argv[1], sys.argv[2]
+TRAFFIC_ONLY = "--traffic-only" in sys.argv
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 dst = os.path.join(root, "profiles")
 # step slot (bench.py `kernels` key) -> kernel symbol prefix in the rocprofv3 tables
@@ -27,7 +30,7 @@ def copy(a, b):
         shutil.copy(os.path.join(src, a), os.path.join(dst, f"{rnd}_{b}"))
 
 
-for c in ("c1", "c2", "c3", "c4", "c5"):
+for c in (() if TRAFFIC_ONLY else ("c1", "c2", "c3", "c4", "c5")):
     copy(f"bench_{c}.json", f"bench_n1_{c}.json")
 copy("bench_under_rocprof.json", "bench_under_rocprof.json")
 copy("kernel_stats.md", "rocprofv3_kernel_stats.md"); copy("pmc_counters.md", "rocprofv3_pmc_counters.md")
@@ -91,6 +94,9 @@ if m and nv and "SQ_INSTS_VALU" in m:
     traffic["miner_valu"] = {"wave_insts_per_launch": m["SQ_INSTS_VALU"], "n_valid": nv, "insts_per_triplet_lane": m["SQ_INSTS_VALU"] * 64.0 / nv,
                              "active_quad_cycles": m.get("SQ_ACTIVE_INST_VALU")}
 json.dump(traffic, open(os.path.join(dst, f"{rnd}_pmc_traffic.json"), "w"), indent=1)
+if TRAFFIC_ONLY:
+    print("wrote", os.path.join(dst, f"{rnd}_pmc_traffic.json"))
+    sys.exit(0)
 
 b = load("bench_c2.json")
 host = open(os.path.join(src, "host.txt")).read().split("\n")

@@ -1,6 +1,7 @@
 #!/bin/bash
-# Run on the GPU box (via gpurun): bench JSON lines of the five named configs + rocprofv3 kernel trace + PMC passes + tool outputs
-# into gpurun_out/<tag>/;  tools/build_profile_summary.py turns that directory into the committed profiles/<round>_* set.
+# Run on the GPU box (via gpurun): PMC passes -> traffic JSON -> bench JSON lines of the five named configs -> rocprofv3 kernel
+# trace -> tool outputs, all into gpurun_out/<tag>/;  tools/build_profile_summary.py turns that directory into the committed
+# profiles/<round>_* set (run it again locally on the merged gpurun_out/<tag>/).
 # usage: bash tools/make_profile_report.sh r02
 set -u
 TAG=${1:-r02}
@@ -8,12 +9,7 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 T="timeout 400"
-$T python bench.py --config c2 --steps 300 --warmup 30 > $OUT/bench_c2.json 2> $OUT/bench.err
-$T python bench.py --config c1 --steps 300 --warmup 30 > $OUT/bench_c1.json 2>> $OUT/bench.err
-$T python bench.py --config c3 --steps 300 --warmup 30 --no-cpu-baseline > $OUT/bench_c3.json 2>> $OUT/bench.err
-$T python bench.py --config c5 --steps 200 --warmup 20 --no-cpu-baseline > $OUT/bench_c5.json 2>> $OUT/bench.err
-$T python bench.py --config c4 --steps 100 --warmup 10 --no-cpu-baseline > $OUT/bench_c4.json 2>> $OUT/bench.err
-$T rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-roofline --no-fit > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
+python -c "import bench; print(bench.source_hash())" > $OUT/source_hash.txt
 PMC="rocprofv3 --kernel-trace --pmc"
 $T $PMC FETCH_SIZE -d $OUT/pmc_fetch -o f -- python tools/run_steps.py 20 > $OUT/run_steps.txt 2> $OUT/pmc.err
 $T $PMC WRITE_SIZE -d $OUT/pmc_write -o w -- python tools/run_steps.py 20 > /dev/null 2>> $OUT/pmc.err
@@ -21,13 +17,21 @@ $T $PMC SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLE
 $T $PMC SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAVES TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc_sq2 -o s2 -- python tools/run_steps.py 20 > /dev/null 2>> $OUT/pmc.err
 $T $PMC FETCH_SIZE -d $OUT/pmc_fetch4 -o f4 -- python tools/run_steps.py 10 batch_all c4 > /dev/null 2>> $OUT/pmc.err
 $T $PMC WRITE_SIZE -d $OUT/pmc_write4 -o w4 -- python tools/run_steps.py 10 batch_all c4 > /dev/null 2>> $OUT/pmc.err
-python tools/rocprof_summary.py $OUT/trace/t_results.db > $OUT/kernel_stats.md
 python tools/pmc_summary.py $OUT/pmc_fetch/f_results.db $OUT/pmc_write/w_results.db $OUT/pmc_sq/s_results.db $OUT/pmc_sq2/s2_results.db > $OUT/pmc_counters.md
 python tools/pmc_summary.py $OUT/pmc_fetch4/f4_results.db $OUT/pmc_write4/w4_results.db > $OUT/pmc_counters_c4.md
-rm -rf $OUT/trace $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/pmc_sq2 $OUT/pmc_fetch4 $OUT/pmc_write4
+rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/pmc_sq2 $OUT/pmc_fetch4 $OUT/pmc_write4
+# the traffic file bench.py quotes (same kernels, same box, minutes apart)
+python tools/build_profile_summary.py $OUT $TAG --traffic-only > /dev/null
+$T python bench.py --config c2 --steps 300 --warmup 30 > $OUT/bench_c2.json 2> $OUT/bench.err
+$T python bench.py --config c1 --steps 300 --warmup 30 > $OUT/bench_c1.json 2>> $OUT/bench.err
+$T python bench.py --config c3 --steps 300 --warmup 30 --no-cpu-baseline > $OUT/bench_c3.json 2>> $OUT/bench.err
+$T python bench.py --config c5 --steps 200 --warmup 20 --no-cpu-baseline > $OUT/bench_c5.json 2>> $OUT/bench.err
+$T python bench.py --config c4 --steps 100 --warmup 10 --no-cpu-baseline > $OUT/bench_c4.json 2>> $OUT/bench.err
+$T rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-roofline --no-fit > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
+python tools/rocprof_summary.py $OUT/trace/t_results.db > $OUT/kernel_stats.md
+rm -rf $OUT/trace
 $T python tools/kprof.py > $OUT/kprof.txt 2>/dev/null
 [ -f dae_rnn_news_recommendation_amd/libdae_mp4.so ] && $T python tools/miner_timeline.py --lib dae_rnn_news_recommendation_amd/libdae_mp4.so > $OUT/miner_timeline.txt 2>/dev/null
 $T python tools/dp_step_breakdown.py > $OUT/dp_step_breakdown.txt 2>/dev/null
-python -c "import bench; print(bench.source_hash())" > $OUT/source_hash.txt
 nproc > $OUT/host.txt; lscpu | grep "Model name" >> $OUT/host.txt; rocminfo | grep -E "gfx|Compute Unit" | head -4 >> $OUT/host.txt
 ls -la $OUT
