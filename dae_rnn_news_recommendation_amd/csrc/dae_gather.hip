@@ -111,46 +111,82 @@ __global__ __launch_bounds__(GATHER_THREADS) void gather_csr_kernel(
     if (x_bits && tid < (ncol >> 5)) x_bits[(int64_t)i * ldw + (c0 >> 5) + tid] = lbits_x[tid];
 }
 
+// four / two consecutive elements as ONE store (the destinations are 8- resp. 16-byte aligned: padded leading dimensions,
+// column offsets that are multiples of 4 / 2)
+__device__ __forceinline__ void store4(bf16_t* dst, const float* v) {
+    uint2 u;
+    u.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+    u.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+    *reinterpret_cast<uint2*>(dst) = u;
+}
+__device__ __forceinline__ void store4(float* dst, const float* v) { *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ void store2(bf16_t* dst, float a, float b) {
+    *reinterpret_cast<uint32_t*>(dst) = (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
+}
+__device__ __forceinline__ void store2(float* dst, float a, float b) { *reinterpret_cast<float2*>(dst) = make_float2(a, b); }
+
 // Dense ndarray input (autoencoder.py:143 sparse_input False; dense masking utils.py:107-109).
-// 64x64 tiles: coalesced fp32 reads along f, LDS transpose for the x~^T operand.
-template <typename T>
+// 64 x 64 tiles.  A thread owns four neighbouring features of a row: one 16-byte read of the fp32 row, ONE Philox evaluation for
+// the four keep decisions (the per-element draw made this kernel VALU-bound: 10 rounds x 40 M elements at F = 50000), 8-byte
+// stores of the bf16 x / x~ rows; the x~^T operand goes through an LDS transpose and is written as packed pairs.
+// VEC = false is the same arithmetic element by element (unaligned rows, F not a multiple of 4).
+template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void gather_dense_kernel(
     const float* __restrict__ data, int64_t ld_data, const int32_t* __restrict__ row_idx, int B, int F,
     T* __restrict__ x, T* __restrict__ xc, int64_t ldx, T* __restrict__ xct, int64_t ldt, float* __restrict__ rowsq_part,
     int corr_mode, const uint32_t* __restrict__ keep_bits, uint64_t seed, uint32_t stream, float corr_frac, float scale) {
     __shared__ float tile[64][65];
-    __shared__ float sq[4][64];
+    __shared__ float sq[64];
     const int i0 = blockIdx.x * 64, f0 = blockIdx.y * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // ty in 0..3
-#pragma unroll 4
-    for (int r = ty; r < 64; r += 4) {
-        const int i = i0 + r, f = f0 + tx;
-        float v = 0.f, vc = 0.f;
+    const int c4 = threadIdx.x & 15, rr = threadIdx.x >> 4;          // 16 threads x 4 features per row, 16 rows per pass
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = rr + 16 * k, i = i0 + r, f = f0 + 4 * c4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f}, vc[4] = {0.f, 0.f, 0.f, 0.f};
         if (i < B && f < F) {
             const int64_t row = row_idx[i];
-            v = data[row * ld_data + f];
-            const uint64_t eidx = (uint64_t)row * (uint64_t)F + (uint64_t)f;
-            const bool keep = keep_entry(corr_mode, keep_bits, eidx, seed, stream, corr_frac);
-            vc = keep ? v * scale : 0.f;
+            if (VEC) {
+                const float4 q = *reinterpret_cast<const float4*>(data + row * ld_data + f);
+                v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = (f + j < F) ? data[row * ld_data + f + j] : 0.f;
+            }
+            bool keep[4] = {true, true, true, true};
+            if (corr_mode == DAE_CORR_KEEPBITS) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint64_t e = (uint64_t)row * (uint64_t)F + (uint64_t)(f + j);      // C order of the ndarray (utils.py:108)
+                    keep[j] = (f + j < F) && ((keep_bits[e >> 5] >> (e & 31)) & 1u);
+                }
+            } else if (corr_mode == DAE_CORR_PHILOX_MASK) {
+                const uint4 o = philox_dense4((uint32_t)row, (uint32_t)(f >> 2), seed, stream);
+                keep[0] = philox_word_uniform(o.x) >= corr_frac; keep[1] = philox_word_uniform(o.y) >= corr_frac;
+                keep[2] = philox_word_uniform(o.z) >= corr_frac; keep[3] = philox_word_uniform(o.w) >= corr_frac;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) vc[j] = keep[j] ? v[j] * scale : 0.f;
         }
-        if (x) x[(int64_t)i * ldx + f] = Elem<T>::from(v);
-        if (xc) xc[(int64_t)i * ldx + f] = Elem<T>::from(vc);
-        tile[r][tx] = vc;
+        if (x) store4(x + (int64_t)i * ldx + f, v);
+        if (xc) store4(xc + (int64_t)i * ldx + f, vc);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tile[r][4 * c4 + j] = vc[j];
         if (rowsq_part) {
-            float s = wave_sum(v * v);
-            if (tx == 0) sq[ty][r] = s;   // each r is handled by exactly one ty
+            float s2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+            s2 = row16_sum(s2);                                                            // the 16 lanes of a row sit in one DPP row
+            if (c4 == 0) sq[r] = s2;
         }
     }
     __syncthreads();
     if (xct) {
-#pragma unroll 4
-        for (int r = ty; r < 64; r += 4)   // r indexes f within the tile, tx indexes i
-            xct[(int64_t)(f0 + r) * ldt + i0 + tx] = Elem<T>::from(tile[tx][r]);
+        const int l2 = threadIdx.x & 31, fr0 = threadIdx.x >> 5;     // a half wave writes 64 consecutive i (packed pairs) of one feature row
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int fr = fr0 + 8 * p;
+            store2(xct + (int64_t)(f0 + fr) * ldt + i0 + 2 * l2, tile[2 * l2][fr], tile[2 * l2 + 1][fr]);
+        }
     }
-    if (rowsq_part && threadIdx.x < 64) {
-        const int r = threadIdx.x;
-        rowsq_part[(int64_t)blockIdx.y * gridDim.x * 64 + i0 + r] = sq[r & 3][r];
-    }
+    if (rowsq_part && threadIdx.x < 64) rowsq_part[(int64_t)blockIdx.y * gridDim.x * 64 + i0 + threadIdx.x] = sq[threadIdx.x];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -578,12 +614,13 @@ extern "C" int dae_gather_dense(const float* data, int64_t ld_data, const int32_
     dim3 grid(Bp / 64, (unsigned)(ldx / 64)), block(256);
     hipStream_t st = (hipStream_t)stream;
     float* part = rowsq ? rowsq_scratch : nullptr;
-    if (dtype == DAE_BF16)
-        hipLaunchKernelGGL((gather_dense_kernel<bf16_t>), grid, block, 0, st, data, ld_data, row_idx, B, F, (bf16_t*)x,
-                           (bf16_t*)xc, ldx, (bf16_t*)xct, ldt, part, corr_mode, keep_bits, seed, rng_stream, corr_frac, scale);
-    else
-        hipLaunchKernelGGL((gather_dense_kernel<float>), grid, block, 0, st, data, ld_data, row_idx, B, F, (float*)x,
-                           (float*)xc, ldx, (float*)xct, ldt, part, corr_mode, keep_bits, seed, rng_stream, corr_frac, scale);
+    // 16-byte row reads need F % 4 == 0 and 16-byte aligned rows
+    const bool vec = (F % 4 == 0) && (ld_data % 4 == 0) && ((reinterpret_cast<uintptr_t>(data) & 15) == 0);
+#define DAE_GD(TT, VV) hipLaunchKernelGGL((gather_dense_kernel<TT, VV>), grid, block, 0, st, data, ld_data, row_idx, B, F, (TT*)x, (TT*)xc, ldx, \
+                                          (TT*)xct, ldt, part, corr_mode, keep_bits, seed, rng_stream, corr_frac, scale)
+    if (dtype == DAE_BF16) { if (vec) DAE_GD(bf16_t, true); else DAE_GD(bf16_t, false); }
+    else { if (vec) DAE_GD(float, true); else DAE_GD(float, false); }
+#undef DAE_GD
     DAE_CHECK_LAUNCH();
     if (rowsq) {
         hipLaunchKernelGGL(rowsq_reduce_kernel, dim3((Bp + 255) / 256), dim3(256), 0, st, part, (int)(ldx / 64), Bp, rowsq);

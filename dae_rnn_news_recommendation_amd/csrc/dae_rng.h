@@ -30,4 +30,11 @@ __device__ __forceinline__ float philox_uniform(uint64_t idx, uint64_t seed, uin
     return (float)(o.x >> 8) * 5.9604644775390625e-8f;   // 2^-24
 }
 
+// Dense-ndarray masking: ONE Philox evaluation serves four neighbouring elements.  Element (row, f) of the train set takes
+// word f & 3 of the draw at counter (f >> 2, row, stream, 2), key = seed  (oracle.philox_uniform_dense restates it).
+__device__ __forceinline__ uint4 philox_dense4(uint32_t row, uint32_t f_quad, uint64_t seed, uint32_t stream) {
+    return philox4x32_10(make_uint4(f_quad, row, stream, 2u), make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+}
+__device__ __forceinline__ float philox_word_uniform(uint32_t w) { return (float)(w >> 8) * 5.9604644775390625e-8f; }
+
 }  // namespace dae

@@ -128,7 +128,10 @@ int dae_salt_pepper_batch(const int64_t* indptr, const int32_t* indices, const f
 int dae_host_mt19937_keep_bits(uint32_t* key, int32_t* pos, int64_t n, double corr_frac, uint32_t* bits_out);
 
 /* Dense-ndarray input (autoencoder.py:143 sparse_input=False; utils.py:107-109 dense masking):
- * gathers fp32 rows data[row_idx[i], :] into x / xc / xct with optional Philox masking. */
+ * gathers fp32 rows data[row_idx[i], :] into x / xc / xct (ldx, ldt multiples of 128; x / xc / xct 16-byte aligned) with the
+ * keep decision from keep_bits (DAE_CORR_KEEPBITS) or from Philox (DAE_CORR_PHILOX_MASK): element (row, f) is kept iff word
+ * f & 3 of Philox4x32-10 at counter (f >> 2, row, rng_stream, 2), key = seed, scaled to [0, 1) by (w >> 8) * 2^-24, is
+ * >= corr_frac -- one draw per four neighbouring features (restated by oracle.philox_uniform_dense). */
 int dae_gather_dense(const float* data, int64_t ld_data, const int32_t* row_idx, int32_t B, int32_t F,
                      int32_t dtype, void* x, void* xc, int64_t ldx, void* xct, int64_t ldt, float* rowsq,
                      float* rowsq_scratch /* [(Fp/64) x Bp], needed iff rowsq */,

@@ -25,7 +25,7 @@ __all__ = [
     "OptState", "opt_apply",
     "masking_noise", "salt_and_pepper_noise", "decay_noise", "gen_batches_index",
     "get_sparse_ind_val_shape", "xavier_bound", "epoch_plan", "fit_reference",
-    "philox4x32", "philox_uniform", "salt_and_pepper_philox", "pairwise_similarity", "pair_stats",
+    "philox4x32", "philox_uniform", "philox_uniform_dense", "salt_and_pepper_philox", "pairwise_similarity", "pair_stats",
 ]
 
 EPS = 1e-16
@@ -615,6 +615,19 @@ def philox_uniform(idx, seed, stream):
     x0, _, _, _ = philox4x32(lo, hi, np.full(lo.shape, np.uint32(stream)), np.zeros(lo.shape, np.uint32),
                              np.uint32(seed & 0xFFFFFFFF), np.uint32((seed >> 32) & 0xFFFFFFFF))
     return (x0 >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)
+
+
+def philox_uniform_dense(rows, F, seed, stream):
+    """Uniforms of the dense-ndarray masking (csrc/dae_rng.h::philox_dense4): element (row, f) takes word f & 3 of the draw at
+    counter (f >> 2, row, stream, 2), key = (seed_lo, seed_hi).  Returns float32 [len(rows) x F]."""
+    rows = np.asarray(rows, np.uint32)
+    nq = (F + 3) // 4
+    c0 = np.broadcast_to(np.arange(nq, dtype=np.uint32)[None, :], (len(rows), nq)).ravel()
+    c1 = np.broadcast_to(rows[:, None], (len(rows), nq)).ravel()
+    out = philox4x32(c0, c1, np.full(c0.shape, np.uint32(stream)), np.full(c0.shape, np.uint32(2)),
+                     np.uint32(seed & 0xFFFFFFFF), np.uint32((seed >> 32) & 0xFFFFFFFF))
+    w = np.stack(out, axis=1).reshape(len(rows), nq * 4)[:, :F]
+    return (w >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)
 
 
 def salt_and_pepper_philox(X, rows, v, seed, stream, lo=None, hi=None):

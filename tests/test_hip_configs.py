@@ -55,8 +55,7 @@ def test_config4_dense_tfidf_50000_features():
     seed, stream = 77, 1
     eng.train_step(torch.from_numpy(idx.astype(np.int32)).cuda(), torch.from_numpy(lab[idx].astype(np.int32)).cuda(), stats,
                    corr_mode=L.CORR_PHILOX_MASK, seed=seed, rng_stream=stream, corr_frac=0.3, phase=1)
-    ii = idx.astype(np.uint64)[:, None] * np.uint64(F) + np.arange(F, dtype=np.uint64)[None, :]
-    keep = O.philox_uniform(ii, seed, stream) >= np.float32(0.3)
+    keep = O.philox_uniform_dense(idx, F, seed, stream) >= np.float32(0.3)
     xb = X[idx]
     r = O.forward_backward(W0, np.zeros(H, np.float32), np.zeros(F, np.float32), xb, xb * keep, lab[idx],
                            loss_func="cross_entropy", triplet_strategy="batch_all", alpha=1.0, dt=np.float32)

@@ -204,18 +204,18 @@ def test_gather_csr_philox_matches_oracle(ops, L):
     assert abs(keep.mean() - 0.7) < 0.02
 
 
+@pytest.mark.parametrize("F", [300, 301])          # 301: rows not 16-byte aligned -> the element-wise variant of the kernel
 @pytest.mark.parametrize("dtype", ["bf16", "f32"])
-def test_gather_dense(ops, L, dtype):
+def test_gather_dense(ops, L, dtype, F):
     rng = np.random.default_rng(5)
-    N, F, B = 150, 300, 70
+    N, B = 150, 70
     data = (rng.random((N, F)) * (rng.random((N, F)) < 0.3)).astype(np.float32)
     rows = rng.permutation(N)[:B].astype(np.int32)
     seed, stream, frac = 99, 3, 0.25
     dt = L.BF16 if dtype == "bf16" else L.F32
     x, xc, xct, rowsq = ops.gather_dense(dev(data), dev(rows), B, F, dt, want_rowsq=True, corr_mode=L.CORR_PHILOX_MASK,
                                          seed=seed, rng_stream=stream, corr_frac=frac, scale=1.0)
-    idx = rows.astype(np.uint64)[:, None] * np.uint64(F) + np.arange(F, dtype=np.uint64)[None, :]
-    keep = O.philox_uniform(idx, seed, stream) >= np.float32(frac)
+    keep = O.philox_uniform_dense(rows, F, seed, stream) >= np.float32(frac)
     want_x = np.zeros((L.pad(B), L.pad(F)), np.float32); want_x[:B, :F] = data[rows]
     want_xc = np.zeros_like(want_x); want_xc[:B, :F] = data[rows] * keep
     if dtype == "bf16":
