@@ -91,6 +91,7 @@ struct dae_plan {
     hipStream_t side;
     hipEvent_t ev_fork, ev_join;
     bool overlap_ok;
+    bool sym_ride_ok;                 // Gs = a/Nv (G + G^T) computed by rider workgroups of the decode launch instead of its own launch
     bool miner_order_ok;              // dispatch the batch_all workgroups by descending sweep cost (LabelJob::order)
     int32_t* miner_order;
     double prof_ms[PS_COUNT];
@@ -217,7 +218,7 @@ extern "C" int dae_plan_create(const dae_config* cfg, dae_plan** out) {
     // binary CSR + bf16: x~ goes to the encode GEMM as a bit image whenever the 8-wave bit kernel can run the shape
     p->bits_ok = cfg->dtype == DAE_BF16 && encode_bits_fits(p->Bpm, p->Hp, p->Fp, p->s_enc);
     p->sparse_ok = true;
-    p->miner_order_ok = true;
+    p->miner_order_ok = true; p->sym_ride_ok = true;
     p->overlap_ok = false;                              // measured: running the miner chain beside decode is SLOWER (0.410 vs 0.351 ms/step)
     *out = p;
     return 0;
@@ -247,6 +248,7 @@ extern "C" int dae_plan_set_option(dae_plan* p, const char* name, int32_t value)
     else if (!strcmp(name, "ce_literal")) p->ce_literal = on;
     else if (!strcmp(name, "overlap")) p->overlap_ok = on;
     else if (!strcmp(name, "miner_order")) p->miner_order_ok = on;
+    else if (!strcmp(name, "sym_in_decode")) p->sym_ride_ok = on;
     else if (!strcmp(name, "gram_fp32")) {
         DAE_CHECK_ARG(!p->bound, "plan_set_option: gram_fp32 changes the workspace layout, set it before dae_plan_bind");
         p->gram_split = !on && p->cfg.dtype == DAE_BF16 && (p->cfg.triplet == DAE_TRIPLET_BATCH_ALL || p->cfg.triplet == DAE_TRIPLET_BATCH_HARD);
@@ -474,7 +476,7 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     } else if (!labels_done) {
         PROF(PS_LABEL, dae_label_stats(s->labels, B, Bp, c.triplet, p->n_same, p->acc, p->nvalid, p->dw_i64, p->cw, c.alpha, p->tri_scalars, stream));
     }
-    bool forked = false;
+    bool forked = false, sym_ride = false;
     const bool fold_finalize = (c.triplet == DAE_TRIPLET_BATCH_ALL && !c.pos_triplets_only) && !ext_mine;
     if (!ext_mine && (c.triplet == DAE_TRIPLET_BATCH_ALL || c.triplet == DAE_TRIPLET_BATCH_HARD)) {
         const int64_t dslab = (int64_t)Bp * Bp;
@@ -514,7 +516,8 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
             if (!fold_finalize)   // batch_all over all valid triplets: scale comes from label_stats, sums from step_stats
                 PROF(PS_TRI_FIN, dae_triplet_finalize(c.triplet, c.pos_triplets_only, B, Bp, c.alpha, p->loss_part, p->cnt_part, p->nvalid,
                                         p->dw_i32, p->role_cnt, p->dw_f32, p->cw, p->tri_scalars, stream));
-            if (backward) PROF(PS_SYM, dae_sym_scale(p->G, B, Bp, p->tri_scalars, dt, p->Gs, stream));
+            sym_ride = backward && p->sym_ride_ok;        // the decode launch below carries it
+            if (backward && !sym_ride) PROF(PS_SYM, dae_sym_scale(p->G, B, Bp, p->tri_scalars, dt, p->Gs, stream));
         }
     }
     // 7. decode + reconstruction loss + d cost/d z2   (K3/K4)
@@ -527,10 +530,12 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     e.dbv_part = backward ? p->dbv_part : nullptr; e.cos_part = p->cos_part;
     e.delta2 = backward ? p->delta2 : nullptr; e.ldd = Fp; e.delta2_t = backward ? p->delta2_t : nullptr; e.lddt = ldB;
     e.B = B; e.F = F; e.Bp = Bp; e.Fp = Fp; e.dec_act = c.dec_act; e.loss_func = c.loss_func; e.ce_literal = p->ce_literal ? 1 : 0;
+    if (sym_ride) { e.sym_G = p->G; e.sym_scalars = p->tri_scalars; e.sym_Gs = p->Gs; e.sym_B = B; e.sym_Bp = Bp; }
     if (is_cos) {
         e.cos_pass = 1;
         PROF(PS_DECODE, launch_decode_loss(dt, Bp, Fp, Hp, p->h_lo, Hp, p->b.W_lo, Hp, e, st));
         PROF(PS_COS_REDUCE, dae_cos_reduce(p->cos_part, ncw, B, Bp, p->cos_stats, p->rowloss_part, stream));
+        e.sym_G = nullptr;                                 // the first pass carried the rider
         if (backward) { e.cos_pass = 2; PROF(PS_DECODE, launch_decode_loss(dt, Bp, Fp, Hp, p->h_lo, Hp, p->b.W_lo, Hp, e, st)); }
     } else {
         e.cos_pass = 0;

@@ -2,6 +2,7 @@
 // split-K reductions fused with the non-linear epilogues, label statistics, bias gradients,
 // optimizer update (with low-precision shadow refresh) and the per-step statistics.
 // All of them are stream-ordered, deterministic (fixed reduction order; only integer atomics).
+#include "dae_sym.h"
 #include "dae_common.h"
 #include "dae_kernels.h"
 #include "dae_label.h"
@@ -138,30 +139,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void sym_scale_kernel(const float* __restrict__ G, int B, int Bp,
                                                         const float* __restrict__ tri_scalars, T* __restrict__ Gs) {
     __shared__ float tile[64][65];
-    const int j0 = blockIdx.x * 64, i0 = blockIdx.y * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    // all 32 loads of a thread are issued before the first use (the kernel is pure latency: 196 blocks, 3 MB)
-    float gt[16], gd[16];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int r = ty + 4 * k;
-        const int a = j0 + r, b = i0 + tx;             // tile of G^T: element (j0+r, i0+tx)
-        gt[k] = (a < B && b < B) ? G[(int64_t)a * Bp + b] : 0.f;
-        const int i = i0 + r, j = j0 + tx;
-        gd[k] = (i < B && j < B) ? G[(int64_t)i * Bp + j] : 0.f;
-    }
-    const float sc = tri_scalars[0];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) tile[ty + 4 * k][tx] = gt[k];
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int r = ty + 4 * k;
-        const int i = i0 + r, j = j0 + tx;
-        float v = 0.f;
-        if (i < B && j < B) v = sc * (gd[k] + tile[tx][r]);
-        Gs[(int64_t)i * Bp + j] = Elem<T>::from(v);
-    }
+    sym_scale_tile<T>(G, B, Bp, tri_scalars, Gs, blockIdx.x, blockIdx.y, tile);
 }
 
 // ------------------------------------------------------------------------------------------------

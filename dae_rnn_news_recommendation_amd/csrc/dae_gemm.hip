@@ -23,6 +23,7 @@
 // Staging: GLDS=true uses global_load_lds_dwordx4 (LDS image is lane-linear, so the swizzle is applied
 // to the per-lane SOURCE address); GLDS=false stages through registers (global_load_dwordx4 ->
 // ds_write_b128) with the loads issued before the MFMA block and the LDS write after it.
+#include "dae_sym.h"
 #include "dae_kernels.h"
 #include "dae_label.h"
 
@@ -1156,6 +1157,12 @@ __global__ __launch_bounds__(GEMM_THREADS, DecGeo<BN_T>::WG_PER_CU) void gemm_de
     static_assert(!XBITS || STAGED, "the bit image of x is a bf16-mode operand");
     static_assert(BN_T == 128 || STAGED, "the 64-column tile is a bf16-mode kernel");
     constexpr bool IS_COS = (LOSS == DAE_LOSS_COSINE);
+    if (e.sym_G && (int)blockIdx.x >= e.sym_first) {   // rider workgroups: the symmetrised triplet gradient (see DecodeEpi)
+        const int t = (int)blockIdx.x - e.sym_first, nt = e.sym_Bp / 64;
+        sym_scale_tile<T>(e.sym_G, e.sym_B, e.sym_Bp, e.sym_scalars, reinterpret_cast<T*>(e.sym_Gs), t % nt, t / nt,
+                          reinterpret_cast<float(*)[65]>(lds));
+        return;
+    }
     int tm, tn, split, kt0, kt1;
     if (!block_to_tile(p, tm, tn, split, kt0, kt1)) return;
     const int tid = threadIdx.x;
@@ -1622,7 +1629,8 @@ int launch_dw_opt(int M, int N, const void* A0, int64_t lda0, const void* Bt0, i
 }
 
 int launch_decode_loss(int dtype, int Bp, int Fp, int Hp, const void* h_lo, int64_t ldh, const void* W_lo, int64_t ldw,
-                       const DecodeEpi& e, hipStream_t st) {
+                       const DecodeEpi& e_in, hipStream_t st) {
+    DecodeEpi e = e_in;
     GemmParams p;
     const int bn = decode_tile_n(dtype);
     if (int rc = fill_params(p, dtype, Bp, Fp, h_lo, ldh, W_lo, ldw, Hp, nullptr, 0, nullptr, 0, 0, 1, bn)) return rc;
@@ -1635,7 +1643,14 @@ int launch_decode_loss(int dtype, int Bp, int Fp, int Hp, const void* h_lo, int6
         DAE_CHECK_ARG(dtype == DAE_BF16 && e.ldxb >= Fp / 32 && ((uintptr_t)e.x_bits % 4) == 0, "decode_loss: bad x bit image");
         k = decode_kernel_xbits(e.loss_func, e.dec_act);
     }
-    dim3 grid(grid_blocks(p)), block(GEMM_THREADS);
+    int nblocks = grid_blocks(p);
+    if (e.sym_G) {
+        DAE_CHECK_ARG(e.sym_scalars && e.sym_Gs && e.sym_Bp % 64 == 0 && e.sym_B <= e.sym_Bp, "decode_loss: bad sym_scale rider");
+        e.sym_first = nblocks;
+        nblocks += (e.sym_Bp / 64) * (e.sym_Bp / 64);
+    }
+    dim3 grid(nblocks), block(GEMM_THREADS);
+    static_assert(DecGeo<DECODE_BN_BF16>::LDS_BYTES >= 64 * 65 * 4 && DecGeo<BN>::LDS_BYTES >= 64 * 65 * 4, "rider tile must fit the decode LDS");
     hipLaunchKernelGGL(k, grid, block, dtype == DAE_BF16 ? DecGeo<DECODE_BN_BF16>::LDS_BYTES : DecGeo<BN>::LDS_BYTES, st, p, e);
     DAE_CHECK_LAUNCH();
     return 0;

@@ -22,7 +22,10 @@ struct DecodeEpi {
     int B, F, Bp, Fp;
     int dec_act, loss_func;
     int cos_pass;             // 0: not cosine, 1: statistics pass, 2: final pass
-    int ce_literal;           // 1: always evaluate cross_entropy with the reference-literal formula (DAE_CE_LITERAL=1; A/B and tests)
+    int ce_literal;           // 1: always evaluate cross_entropy with the reference-literal formula (option ce_literal; A/B and tests)
+    // optional rider: (sym_Bp/64)^2 extra workgroups at the end of the grid compute Gs = scalars[0] * (G + G^T) for the dh GEMM
+    // (the stand-alone sym_scale launch sits between the miner and this kernel and neither depends on the other)
+    const float* sym_G; const float* sym_scalars; void* sym_Gs; int sym_B, sym_Bp, sym_first;
 };
 
 struct LabelJob;

@@ -204,6 +204,20 @@ def test_miner_dispatch_order_changes_nothing(dtype, B):
         assert np.array_equal(np.asarray(u), np.asarray(v))
 
 
+@pytest.mark.parametrize("strategy,loss", [("batch_all", "cross_entropy"), ("batch_hard", "cross_entropy"), ("batch_all", "cosine_proximity")])
+def test_sym_scale_rider_equals_own_launch(strategy, loss):
+    """Gs = a/Nv (G + G^T) is computed by extra workgroups of the decode launch (option sym_in_decode, default on) instead of a
+    launch of its own: same tile code, so everything downstream must be bit-identical."""
+    acts = ("sigmoid", "sigmoid") if loss == "cross_entropy" else ("tanh", "none")
+    a, _, pa = _run_case("bf16", strategy, loss, acts, "gradient_descent", steps=2, seed=51)
+    b, _, pb = _run_case("bf16", strategy, loss, acts, "gradient_descent", steps=2, seed=51, options={"sym_in_decode": 0})
+    for (_, sa, dWa, dbha, dbva), (_, sb, dWb, dbhb, dbvb) in zip(a, b):
+        assert np.array_equal(sa[:6], sb[:6])
+        assert np.array_equal(dWa, dWb) and np.array_equal(dbha, dbhb) and np.array_equal(dbva, dbvb)
+    for u, v in zip(pa, pb):
+        assert np.array_equal(np.asarray(u), np.asarray(v))
+
+
 def test_phase3_updates_like_phase0():
     """phase 3 (no W-gradient image) must leave the same parameters as phase 0."""
     from dae_rnn_news_recommendation_amd import _lib as L
