@@ -179,15 +179,15 @@ class Runner:
             d["bits"] = utils.masking_keep_bits(n, v).view(np.int32)
         order = utils.epoch_permutation(self.N)
         # staged like DenoisingAutoencoder._stage_epoch: pinned tensors, uploaded asynchronously by the stepping thread
-        t = self.torch
+        from dae_rnn_news_recommendation_amd.autoencoder.autoencoder import pinned_copy
         if "bits" in d:
-            d["bits"] = t.from_numpy(d["bits"]).pin_memory()
+            d["bits"] = pinned_copy(d["bits"])
         o = order.astype(np.int32)
         if self.explicit:
-            d["order"] = t.from_numpy(np.stack([o, o + self.N, o + 2 * self.N])).pin_memory()
+            d["order"] = pinned_copy(np.stack([o, o + self.N, o + 2 * self.N]))
         else:
-            d["order"] = t.from_numpy(o).pin_memory()
-            d["labels"] = t.from_numpy(np.ascontiguousarray(self.labels[order])).pin_memory()
+            d["order"] = pinned_copy(o)
+            d["labels"] = pinned_copy(self.labels[order])
         return d
 
     def _prep_epoch(self):
@@ -225,15 +225,16 @@ class Runner:
         self.feeder.close()
 
 
-def fit_leg(a, rng):
-    """The same workload through the drop-in estimator: samples/s = N * timed epochs / wall, first epoch excluded."""
+def fit_leg(a, rng, epochs):
+    """The same workload through the drop-in estimator: samples/s = N * timed epochs / wall, first epoch excluded.
+    `epochs`: at least --fit-epochs, and enough of them that the timed window is ~0.1 s (an epoch of c1 is 1 ms)."""
     import tempfile
     from dae_rnn_news_recommendation_amd.autoencoder import DenoisingAutoencoder, DenoisingAutoencoderTriplet
     from dae_rnn_news_recommendation_amd.synthetic import xavier_uniform
     c = a.cfg
     data, labels = make_data(c, 0)
     F, H = c["features"], c["features"] // c["cf"]
-    kw = dict(compress_factor=c["cf"], enc_act_func="sigmoid", dec_act_func="sigmoid", loss_func=c["loss"], num_epochs=a.fit_epochs,
+    kw = dict(compress_factor=c["cf"], enc_act_func="sigmoid", dec_act_func="sigmoid", loss_func=c["loss"], num_epochs=epochs,
               batch_size=c["batch"], opt="gradient_descent", learning_rate=0.1, corr_type="masking", corr_frac=0.3, verbose=0,
               verbose_step=1 << 20, seed=0, alpha=1, precision=a.precision, rng=rng, init_weights=xavier_uniform(F, H, seed=42))
     with tempfile.TemporaryDirectory() as tmp:
@@ -243,9 +244,22 @@ def fit_leg(a, rng):
         else:
             m = DenoisingAutoencoder(model_name="b", main_dir="b", triplet_strategy=c["strategy"], results_root=tmp + "/", **kw)
             m.fit(data, train_set_label=labels if c["strategy"] != "none" else None)
-        st = m.epoch_stats(a.fit_epochs)
-    return {"samples_per_s": m.samples_per_sec, "epochs_timed": a.fit_epochs - 1, "final_cost": st["cost"], "final_ae": st["ae"],
+        st = m.epoch_stats(epochs)
+    return {"samples_per_s": m.samples_per_sec, "epochs_timed": epochs - 1, "final_cost": st["cost"], "final_ae": st["ae"],
             "final_triplet": st["triplet"]}
+
+
+def _cpu_budget():
+    """CPUs this process may actually use: the affinity mask, capped by the container's cgroup quota (cpu.max) -- threads beyond
+    the quota only get the whole process throttled."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:        # noqa: BLE001
+        pass
+    return n
 
 
 def cpu_baseline(a):
@@ -260,7 +274,7 @@ def cpu_baseline(a):
     full, full_labels = make_data(c, 0)                      # the bench's own matrix: the sample is its first 2*B rows
     data, labels = full[:2 * c["batch"]], full_labels[:2 * c["batch"]]
     F, H, B = c["features"], c["features"] // c["cf"], c["batch"]
-    threads = min(os.cpu_count() or 1, 64)                    # beyond ~64 threads the many small torch-CPU ops only pay for synchronisation
+    threads = min(_cpu_budget(), 64)                          # beyond ~64 threads the many small torch-CPU ops only pay for synchronisation
     lit = 2 if c["strategy"] == "batch_all" else 0
     t = TB.time_baseline(data, labels, xavier_uniform(F, H, seed=42), batch=B, strategy=c["strategy"], literal_steps=lit,
                          chunked_steps=10 if F <= 10000 else 4, threads=threads)
@@ -462,11 +476,13 @@ def main():
     run.close()
     _log("profile pass done")
     if rank == 0 and world == 1 and not a.no_fit:
-        out["fit"] = {a.rng: fit_leg(a, a.rng)}
+        epoch_s = (dt / a.steps) * run.nb
+        epochs = max(a.fit_epochs, min(200, int(0.1 / max(epoch_s, 1e-6)) + 2))
+        out["fit"] = {a.rng: fit_leg(a, a.rng, epochs)}
         _log("fit leg done")
         other = "numpy" if a.rng == "philox" else "philox"
         if not (other == "numpy" and c["kind"] == "dense_tfidf"):      # the legacy dense draw is 4*10^8 host choices per epoch
-            out["fit"][other] = fit_leg(a, other)
+            out["fit"][other] = fit_leg(a, other, epochs)
         out["fit"]["note"] = ("DenoisingAutoencoder.fit() on the same workload: N * timed epochs / wall, first epoch excluded; rng=numpy is the "
                               "reference-exact legacy stream (keep decisions drawn one epoch ahead on a feeder thread)")
     _log("fit legs done")
