@@ -364,6 +364,17 @@ def kernel_table(a, prof, nsteps):
     return kern, 1e3 * tot / nsteps, (mfma, hbm)
 
 
+def _prewarm_clocks(torch, device, seconds=0.25):
+    """Untimed, outside the model: keep the GPU busy for a moment so that the W warm-up steps and the timed steps run at
+    steady clocks (a fresh process starts from the idle power state; a 5 ms warm-up does not leave it)."""
+    x = torch.randn(4096, 4096, device=device, dtype=torch.bfloat16)
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(10):
+            x = (x @ x).clamp_(-1, 1)
+        torch.cuda.synchronize()
+
+
 def main():
     a = parse()
     import torch
@@ -386,6 +397,7 @@ def main():
     assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     c = a.cfg
     run = Runner(a, rank, world)
+    _prewarm_clocks(torch, run.eng.device)
     _log("runner ready")
 
     for _ in range(a.warmup):
