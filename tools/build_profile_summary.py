@@ -149,6 +149,14 @@ if "miner_valu" in traffic:
 if os.path.exists(os.path.join(src, "dp_step_breakdown.txt")):
     L.append("## Data-parallel step form without communication (one-rank RCCL group, `tools/dp_step_breakdown.py`)\n\n```\n"
              + "".join(l for l in open(os.path.join(src, "dp_step_breakdown.txt")) if "us" in l or "step" in l or "rank" in l) + "```\n")
+fb = os.path.join(dst, f"{rnd}_bench_n1_c2_fastbox.json")
+if os.path.exists(fb):
+    x = json.loads(open(fb).read().strip().splitlines()[-1])
+    L.append(f"## Box variance\n\nThe same kernels (source hash above) on one of the fast boxes of the pool, 20 minutes earlier: **{x['value']:,.0f} samples/s** "
+             f"({1e3 * x['ms_per_step']:.1f} us/step), `{rnd}_bench_n1_c2_fastbox.json` / `{rnd}_kprof_fastbox.txt`.  That line was produced by the bench.py revision before "
+             "the per-epoch staging fix: its `fit.numpy` figure (0.71 M) shows the bug fixed afterwards -- torch's parallel pinned copy woke 128 OpenMP workers per "
+             "epoch and the container's 16-CPU cgroup quota throttled the whole process; with the single-threaded staging the reference-exact RNG mode "
+             "runs at the Philox rate (table above).\n")
 L.append(f"PMC detail: `{rnd}_rocprofv3_pmc_counters.md` (c4: `{rnd}_rocprofv3_pmc_counters_c4.md`); per-workgroup timeline of the miner: `{rnd}_miner_timeline.txt`;\n"
          f"`tools/kprof.py` output: `{rnd}_kprof.txt`; what was tried and what it bought: `{rnd}_experiments.md`.\n")
 open(os.path.join(dst, f"{rnd}_summary.md"), "w").write("\n".join(L))
