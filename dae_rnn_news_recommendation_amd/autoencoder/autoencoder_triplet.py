@@ -74,24 +74,55 @@ class DenoisingAutoencoderTriplet(DenoisingAutoencoder):
         eng = self.engine
         n_batches = -(-N // batch)
         self._stats = torch.zeros((max(self.num_epochs, 1), n_batches, L.STATS_STRIDE), dtype=torch.float32, device=eng.device)
+        from .autoencoder import _EpochFeeder, pinned_copy
+
+        def draw_epoch(e):
+            # feeder thread, one epoch ahead: ONE corruption draw over the stacked set (org, pos, neg in order), then ONE shuffle
+            # shared by the three blocks (utils.py:87-91); the batch row lists [idx | N + idx | 2N + idx] staged as one pinned array
+            d = self._draw_epoch(stacked, e, n_shuffle=N)
+            o = d['order'].astype(np.int32)
+            rows = [np.concatenate([o[s:s + batch], N + o[s:s + batch], 2 * N + o[s:s + batch]]) for s in range(0, N, batch)]
+            d['row_offsets'] = np.cumsum([0] + [len(r) for r in rows])
+            d['rows_t'] = pinned_copy(np.concatenate(rows))
+            if 'bits' in d:
+                d['bits_t'] = pinned_copy(d['bits'])
+            return d
+
+        feeder = _EpochFeeder(draw_epoch, self.num_epochs)
         t_fit = time.time()
-        for i in range(self.num_epochs):
-            t0 = time.time()
-            draw = self._draw_epoch(stacked, i, n_shuffle=N)  # one corruption draw over the stacked set (org, pos, neg in order),
-            plan = self._corruption_plan(draw, i)            # then ONE shuffle shared by the three blocks (utils.py:87-91)
-            order = draw['order']
-            for b, start in enumerate(range(0, N, batch)):
-                idx = order[start:start + batch]
-                rows = np.concatenate([idx, N + idx, 2 * N + idx]).astype(np.int32)
-                eng.train_step(torch.from_numpy(rows).to(eng.device), None, self._stats[i, b], phase=0, **plan)
-            if (i + 1) % self.verbose_step == 0 or i + 1 == self.num_epochs:
-                torch.cuda.synchronize()
-                self.train_time = time.time() - t0
-                self._run_validation_error_and_summaries(i + 1, validation_set, None)
+        t_first = None
+        try:
+            for i in range(self.num_epochs):
+                t0 = time.time()
+                draw = feeder.get()
+                plan = self._corruption_plan(draw, i)
+                sp = plan.pop('_sp', None)                   # device salt-and-pepper (rng='philox'): flipped per batch
+                if sp is not None and not hasattr(self, '_sp_range'):
+                    d = stacked.data if stacked.nnz else np.zeros(1)
+                    full = stacked.nnz == stacked.shape[0] * stacked.shape[1]
+                    self._sp_range = (float(d.min() if full else min(d.min(), 0.0)), float(d.max() if full else max(d.max(), 0.0)))
+                rows_dev = draw['rows_t'].to(eng.device, non_blocking=True)
+                off = draw['row_offsets']
+                for b in range(n_batches):
+                    rows = rows_dev[off[b]:off[b + 1]]
+                    if sp is not None:
+                        plan['corrupted_csr'] = eng.salt_pepper_batch(rows, sp[0], self._sp_range[0], self._sp_range[1], sp[1], sp[2])
+                    eng.train_step(rows, None, self._stats[i, b], phase=0, **plan)
+                if (i + 1) % self.verbose_step == 0 or i + 1 == self.num_epochs:
+                    torch.cuda.synchronize()
+                    self.train_time = time.time() - t0
+                    self._run_validation_error_and_summaries(i + 1, validation_set, None)
+                if i == 0:
+                    torch.cuda.synchronize()
+                    t_first = time.time()
+        finally:
+            feeder.close()
         torch.cuda.synchronize()
-        wall = time.time() - t_fit
-        if self.num_epochs > 0 and wall > 0:
-            self.samples_per_sec = 3 * N * self.num_epochs / wall
+        t_end = time.time()
+        if self.num_epochs > 1 and t_end > t_first:          # rows x timed epochs / wall, first epoch excluded as warm-up
+            self.samples_per_sec = 3 * N * (self.num_epochs - 1) / (t_end - t_first)
+        elif self.num_epochs > 0 and t_end > t_fit:
+            self.samples_per_sec = 3 * N * self.num_epochs / (t_end - t_fit)
 
     def _validation_forward_triplet(self, validation_set):
         """Forward pass of the whole validation dict as ONE stacked batch, uncorrupted (reference :160-199)."""

@@ -112,6 +112,66 @@ def test_explicit_triplet_estimator_matches_oracle(tmp_path):
     assert np.abs(model.engine.get_params()[0] - W).max() <= 2e-5 * np.abs(W).max()
 
 
+def test_explicit_triplet_masking_noise_feeder_matches_oracle(tmp_path):
+    """Explicit-triplet fit with the reference-exact masking stream: per epoch ONE rand() draw over the stacked (org, pos, neg) set,
+    then ONE shuffle shared by the three blocks -- drawn one epoch ahead by the feeder thread."""
+    from dae_rnn_news_recommendation_amd.autoencoder.autoencoder_triplet import DenoisingAutoencoderTriplet
+    rng = np.random.default_rng(1)
+    N, F = 90, 300
+    H = F // 10
+
+    def mk(seed):
+        m = sparse.random(N, F, density=0.06, random_state=np.random.RandomState(seed), format="csr", dtype=np.float32)
+        m.data = (m.data * 0.9 + 0.1).astype(np.float32); m.sort_indices()
+        return m
+    data = {"org": mk(4), "pos": mk(5), "neg": mk(6)}
+    W0 = rng.uniform(-0.2, 0.2, (F, H)).astype(np.float32)
+    model = DenoisingAutoencoderTriplet(model_name="t4", main_dir="t4", compress_factor=10, enc_act_func="sigmoid",
+                                        dec_act_func="sigmoid", loss_func="mean_squared", num_epochs=3, batch_size=30,
+                                        learning_rate=0.05, corr_type="masking", corr_frac=0.3, verbose=False, verbose_step=1, seed=8,
+                                        alpha=1, precision="fp32", rng="numpy", init_weights=W0, results_root=str(tmp_path) + "/")
+    model.fit(data)
+    stacked = sparse.vstack([data[k] for k in ("org", "pos", "neg")]).tocsr()
+    np.random.seed(8)
+    W = W0.astype(np.float64); bh = np.zeros(H); bv = np.zeros(F)
+    st = O.OptState("gradient_descent", [W.shape, bh.shape, bv.shape], np.float64)
+    for e in range(3):
+        keep = np.random.rand(stacked.nnz) >= 0.3                       # utils.masking_noise over the stacked set (storage order)
+        sc = stacked.copy(); sc.data = sc.data * keep
+        order = O.gen_batches_index(N, 30)
+        costs = []
+        for idx in order:
+            xs = [stacked[k * N + np.asarray(idx)].toarray() for k in range(3)]
+            xcs = [sc[k * N + np.asarray(idx)].toarray() for k in range(3)]
+            r = O.explicit_triplet_forward_backward(W, bh, bv, xs, xcs, loss_func="mean_squared", alpha=1.0, dt=np.float64)
+            O.opt_apply(st, [W, bh, bv], [r["dW"], r["dbh"], r["dbv"]], 0.05, 0.5, np.float64)
+            costs.append(float(r["cost"]))
+        got = model.epoch_stats(e + 1)["cost"]
+        assert abs(got - np.mean(costs)) <= 1e-4 * abs(np.mean(costs)), (e, got, np.mean(costs))
+    assert model.samples_per_sec > 0
+
+
+def test_explicit_triplet_device_salt_and_pepper_runs(tmp_path):
+    """corr_type='salt_and_pepper' with rng='philox' on the explicit-triplet estimator: flips drawn per batch on the device."""
+    from dae_rnn_news_recommendation_amd.autoencoder.autoencoder_triplet import DenoisingAutoencoderTriplet
+    N, F = 60, 300
+
+    def mk(seed):
+        m = sparse.random(N, F, density=0.06, random_state=np.random.RandomState(seed), format="csr", dtype=np.float32)
+        m.data[:] = 1.0; m.sort_indices()
+        return m
+    data = {"org": mk(7), "pos": mk(8), "neg": mk(9)}
+    costs = []
+    for _ in range(2):
+        model = DenoisingAutoencoderTriplet(model_name="t5", main_dir="t5", compress_factor=10, enc_act_func="sigmoid",
+                                            dec_act_func="sigmoid", loss_func="cross_entropy", num_epochs=2, batch_size=20,
+                                            learning_rate=0.05, corr_type="salt_and_pepper", corr_frac=0.05, verbose=False, verbose_step=1,
+                                            seed=3, alpha=1, precision="fp32", rng="philox", results_root=str(tmp_path) + "/")
+        model.fit(data)
+        costs.append([model.epoch_stats(e + 1)["cost"] for e in range(2)])
+    assert np.isfinite(costs).all() and costs[0] == costs[1]           # counter RNG: the same seed gives the same run
+
+
 def test_bench_two_ranks_on_one_gpu(tmp_path):
     """The N > 1 path of bench.py (phase-1 step -> all-reduce of the flat gradient -> dae_plan_apply) with two processes
     sharing this box's single GPU (gloo collectives; RCCL needs one GPU per rank): launch line exactly as the driver's,
