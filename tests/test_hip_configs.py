@@ -10,6 +10,11 @@ import oracle as O
 pytestmark = pytest.mark.gpu
 
 
+# bf16 MFMA operands, fp32 accumulation: max-abs error of a gradient image relative to its largest entry.  Measured 1.7e-3 (c1, c4)
+# to 2.2e-3 (c5) at these shapes; the gate sits at ~2x that.
+GATE_BF16_GRAD = 5e-3
+
+
 def _rel(a, b):
     return float(np.max(np.abs(np.asarray(a, np.float64) - b)) / (np.max(np.abs(b)) + 1e-30))
 
@@ -35,7 +40,9 @@ def test_config1_plain_dae_strategy_none():
                            triplet_strategy="none", dt=np.float32)
     st = stats.cpu().numpy()
     assert abs(st[0] - r["cost"]) <= 1e-4 * abs(r["cost"])
-    assert _rel(eng.grads()[0], r["dW"]) < 3e-2
+    e = _rel(eng.grads()[0], r["dW"])
+    print("bf16 dW rel err", e)
+    assert e < GATE_BF16_GRAD, e
 
 
 def test_config4_dense_tfidf_50000_features():
@@ -43,7 +50,7 @@ def test_config4_dense_tfidf_50000_features():
     from dae_rnn_news_recommendation_amd import _lib as L
     from dae_rnn_news_recommendation_amd.engine import Engine
     from dae_rnn_news_recommendation_amd.synthetic import synthetic_csr, synthetic_labels, xavier_uniform
-    N, F, H, B = 320, 50000, 1000, 256
+    N, F, H, B = 900, 50000, 1000, 800
     X = synthetic_csr(N, F, nnz_per_row=300, seed=5, tfidf=True).toarray().astype(np.float32)
     lab = synthetic_labels(N, seed=5)
     W0 = xavier_uniform(F, H)
@@ -63,7 +70,9 @@ def test_config4_dense_tfidf_50000_features():
     assert abs(st[1] - r["ae_loss"]) <= 1e-4 * abs(r["ae_loss"]), (st, r["ae_loss"])
     assert abs(st[2] - r["triplet_loss"]) <= 1e-4 * abs(r["triplet_loss"]) + 1e-9
     dW, dbh, dbv = eng.grads()
-    assert _rel(dW, r["dW"]) < 3e-2 and _rel(dbv, r["dbv"]) < 3e-2
+    e = (_rel(dW, r["dW"]), _rel(dbv, r["dbv"]))
+    print("bf16 grad rel err", e)
+    assert max(e) < GATE_BF16_GRAD, e
 
 
 def test_config3_batch_hard_category_labels_dp_shard():
@@ -88,13 +97,24 @@ def test_config3_batch_hard_category_labels_dp_shard():
     assert abs(st[2] - tl) <= 2e-5 * abs(tl) and st[4] == num and abs(st[3] - fr) < 1e-6
     dwf = eng.buffer("dw_f32", (896,), torch.float32).cpu().numpy()[:B]
     assert np.array_equal(dwf, dw)                                   # bit-exact data_weight
+    # autoencoder leg weighted by those data weights, and the step's gradients (fp32 step vs the float64 oracle; the oracle
+    # mines on its own float64 Gram matrix, measured 2e-6 / 2e-7 / 2e-5 on dW / dbv / dbh)
+    r = O.forward_backward(W0, np.zeros(H), np.zeros(F), xb, xb, lab[idx], triplet_strategy="batch_hard", alpha=1.0, dt=np.float64)
+    y = O.decode(h, W0, np.zeros(F), "sigmoid", np.float64)
+    ae = O.weighted_loss(xb, y, "cross_entropy", dw, np.float64)
+    assert abs(st[1] - ae) <= 2e-5 * abs(ae), (st[1], ae)
+    assert abs(st[0] - (ae + tl)) <= 2e-5 * abs(ae + tl)
+    dW, dbh, dbv = eng.grads()
+    e = (_rel(dW, r["dW"]), _rel(dbv, r["dbv"]), _rel(dbh, r["dbh"]))
+    print("c3 fp32 grad rel err", e)
+    assert max(e) < 1e-4, e
 
 
 def test_config5_explicit_triplets_cosine():
     """configs[4]: explicit (anchor,pos,neg) batches through the same W, cosine_proximity, B=800 per block."""
     from dae_rnn_news_recommendation_amd.engine import Engine
     from dae_rnn_news_recommendation_amd.synthetic import synthetic_csr, xavier_uniform
-    N, F, H, Bt = 400, 10000, 500, 320
+    N, F, H, Bt = 1000, 10000, 500, 800
     ms = [synthetic_csr(N, F, seed=20 + k, tfidf=True) for k in range(3)]
     W0 = xavier_uniform(F, H)
     eng = Engine(F, H, 3 * Bt, dtype="bf16", loss_func="cosine_proximity", triplet="explicit", alpha=1.0, learning_rate=0.1)
@@ -108,4 +128,6 @@ def test_config5_explicit_triplets_cosine():
                                             alpha=1.0, dt=np.float32)
     st = stats.cpu().numpy()
     assert abs(st[0] - r["cost"]) <= 2e-4 * abs(r["cost"]), (st, r["cost"], r["ae_loss"], r["triplet_loss"])
-    assert _rel(eng.grads()[0], r["dW"]) < 3e-2
+    e = _rel(eng.grads()[0], r["dW"])
+    print("bf16 dW rel err", e)
+    assert e < GATE_BF16_GRAD, e

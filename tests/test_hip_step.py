@@ -360,5 +360,6 @@ def test_full_size_step_config2(dtype, strategy):
         assert st[5] == np.float32(nv)                                   # N_valid: exact integer
         assert abs(st[4] - r["num"]) <= (1e-5 if dtype == "fp32" else 2e-3) * r["num"] + 64
     dW, dbh, dbv = eng.grads()
-    gt = 5e-4 if dtype == "fp32" else 3e-2          # the oracle leg is fp32 NumPy here: its own rounding is ~1e-4
-    assert _rel(dW, r["dW"]) < gt and _rel(dbh, r["dbh"]) < gt and _rel(dbv, r["dbv"]) < gt
+    gt = 5e-4 if dtype == "fp32" else 6e-3          # the oracle leg is fp32 NumPy here: its own rounding is ~1e-4; bf16 operands: ~2e-3 measured
+    e = (_rel(dW, r["dW"]), _rel(dbh, r["dbh"]), _rel(dbv, r["dbv"]))
+    assert max(e) < gt, e
