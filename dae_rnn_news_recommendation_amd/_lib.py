@@ -39,7 +39,7 @@ class dae_buffers(C.Structure):
     _fields_ = [("indptr", vp), ("indices", vp), ("values", vp), ("dense", vp), ("ld_dense", i64),
                 ("n_rows", i64), ("nnz", i64),
                 ("W", vp), ("bh", vp), ("bv", vp), ("grad", vp), ("opt_s1", vp), ("opt_s2", vp),
-                ("W_lo", vp), ("Wt_lo", vp), ("workspace", vp), ("workspace_bytes", u64)]
+                ("W_lo", vp), ("Wt_lo", vp), ("workspace", vp), ("workspace_bytes", u64), ("grad_lo", vp)]
 
 
 class dae_step(C.Structure):
@@ -131,7 +131,7 @@ def load():
         fn = getattr(lib, name)      # AttributeError here == stale library
         fn.restype = res
         fn.argtypes = args
-    if lib.dae_abi_version() != 2:
+    if lib.dae_abi_version() != 3:
         raise RuntimeError("libdae_hip.so ABI version mismatch")
     _lib = lib
     return lib

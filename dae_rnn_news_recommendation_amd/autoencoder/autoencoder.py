@@ -58,8 +58,8 @@ class _EpochFeeder(object):
 
         def run():
             try:
-                import torch
-                torch.set_num_threads(1)          # per-thread OpenMP setting: nothing this thread does may wake the intra-op pool
+                # (no torch CPU op runs on this thread: pinned_copy fills its buffers through NumPy, so the intra-op OpenMP pool is
+                # never woken from here and the process-wide torch thread count is left alone)
                 for e in range(n_epochs):
                     if self._stop:
                         return
@@ -189,7 +189,8 @@ class DenoisingAutoencoder(object):
                              dtype=self.precision, enc_act=act(self.enc_act_func), dec_act=act(self.dec_act_func),
                              loss_func=self.loss_func, opt=self.opt, learning_rate=self.learning_rate,
                              momentum=self.momentum, alpha=float(self.alpha), triplet=self._strategy_key(),
-                             device=self.device, dp_world=dp_world)
+                             device=self.device, dp_world=dp_world,
+                             grad_lo=(dp_world > 1 and self.dp_grad_dtype == 'bf16'))
         return self.engine
 
     def _initial_parameters(self, n_features):
@@ -217,6 +218,8 @@ class DenoisingAutoencoder(object):
             assert validation_set.shape[0] == len(validation_set_label)
 
         n_features = train_set.shape[1]
+        if hasattr(self, '_sp_range'):
+            del self._sp_range             # salt-and-pepper min / max belong to the previous fit's data
         self.sparse_input = not isinstance(train_set, np.ndarray)
         self.n_components = int(np.floor(n_features / self.compress_factor))
         batch = self._resolve_batch(train_set.shape[0])
@@ -263,6 +266,7 @@ class DenoisingAutoencoder(object):
         self._train_model(train_set, validation_set, train_set_label, validation_set_label)
         if world > 1:
             self._exchange.gather_master()  # the fp32 masters are sharded over the ranks during training
+            self._exchange.gather_slots()   # ... and so are the optimizer slots of W (the checkpoint below saves them)
         if rank == 0:                      # one writer: every rank holds identical parameters
             self._save(self.model_path)
         if world > 1:

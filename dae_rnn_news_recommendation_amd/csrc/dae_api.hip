@@ -104,7 +104,12 @@ struct dae_plan {
     int s_enc, s_dh, s_gram;
     uint64_t ws_bytes;
     // carved pointers
-    char *x, *xc, *xct, *h_lo, *h_t, *Gs, *delta2, *delta2_t, *delta1_t, *hcat_a, *hcat_b;
+    char *x, *xc, *xct, *h_lo, *h_t, *Gs, *delta2, *delta2_t, *delta1_t, *delta1_lo, *hcat_a, *hcat_b;
+    uint32_t* xtb;                   // x~^T as a bit image [Fp x Bpm/32] (binary CSR + bf16: operand of the sparse half of the dW kernel)
+    bool xtb_clean;                  // the bit image holds only zeros (every step clears what it set; see step_tail_kernel)
+    bool dw_sparse_ok;               // option "dw_sparse" = 0: dense x~^T image and a K = 2 Bp dW GEMM (A/B, equivalence tests)
+    bool enc_w32_ok;                 // option "encode_w32": bf16 mode encodes from the fp32 MASTER weights (h fp32-accurate); 0 = from W_lo
+    int w32_cols;                    // option "encode_w32_cols": 64 (default) or 128 H columns per workgroup of that kernel
     bool gram_split;                 // Gram matrix as a 3-term split-bf16 MFMA GEMM (bf16 mode) instead of exact-fp32 MFMA
     float *slabs, *h_f32, *D_slabs, *G, *rowloss_part, *dbv_part, *colsum_part, *cos_part, *cos_stats, *cw, *loss_part,
         *dw_f32, *tri_scalars, *dh_extra, *rowsq_scratch, *tile_part;
@@ -153,6 +158,8 @@ static uint64_t carve(dae_plan* p, char* base) {
     p->h_lo = take(Bp * Hp * es);
     p->h_t = take(Hp * Bp * es);
     p->delta1_t = take(Hp * Bp * es);
+    p->delta1_lo = take(Bp * Hp * es);
+    p->xtb = (uint32_t*)take(Fp * (Bp / 32) * 4);
     p->dh_extra = (float*)take(Bp * Hp * 4);
     p->hcat_a = take(p->gram_split ? Bp * 3 * Hp * 2 : 256);
     p->hcat_b = take(p->gram_split ? Bp * 3 * Hp * 2 : 256);
@@ -214,7 +221,10 @@ extern "C" int dae_plan_create(const dae_config* cfg, dae_plan** out) {
     p->label_enc_ok = true;
     p->ce_literal = false;
     p->xbits_ok = cfg->dtype == DAE_BF16;
-    p->xct_clean = false;
+    p->xct_clean = false; p->xtb_clean = false;
+    p->dw_sparse_ok = true;
+    p->enc_w32_ok = cfg->dtype == DAE_BF16;
+    p->w32_cols = 64;
     // binary CSR + bf16: x~ goes to the encode GEMM as a bit image whenever the 8-wave bit kernel can run the shape
     p->bits_ok = cfg->dtype == DAE_BF16 && encode_bits_fits(p->Bpm, p->Hp, p->Fp, p->s_enc);
     p->sparse_ok = true;
@@ -243,6 +253,9 @@ extern "C" int dae_plan_set_option(dae_plan* p, const char* name, int32_t value)
     else if (!strcmp(name, "encode_bits")) p->bits_ok = on && p->cfg.dtype == DAE_BF16 && encode_bits_fits(p->Bpm, p->Hp, p->Fp, p->s_enc);
     else if (!strcmp(name, "x_bits")) p->xbits_ok = on && p->cfg.dtype == DAE_BF16;
     else if (!strcmp(name, "fused_opt")) p->fuse_opt_ok = on;
+    else if (!strcmp(name, "dw_sparse")) p->dw_sparse_ok = on;
+    else if (!strcmp(name, "encode_w32")) p->enc_w32_ok = on && p->cfg.dtype == DAE_BF16;
+    else if (!strcmp(name, "encode_w32_cols")) { DAE_CHECK_ARG(value == 64 || value == 128, "plan_set_option: encode_w32_cols is 64 or 128"); p->w32_cols = value; }
     else if (!strcmp(name, "tail")) p->tail_ok = on;
     else if (!strcmp(name, "label_with_encode")) p->label_enc_ok = on;
     else if (!strcmp(name, "ce_literal")) p->ce_literal = on;
@@ -295,6 +308,7 @@ extern "C" int dae_plan_bind(dae_plan* p, const dae_buffers* bufs) {
     carve(p, (char*)bufs->workspace);
     p->bound = true;
     p->xct_clean = false;            // a (re)bound workspace has not been cleared: the next backward step memsets x~^T once
+    p->xtb_clean = false;
     return 0;
 }
 
@@ -308,6 +322,7 @@ extern "C" void* dae_plan_buffer(dae_plan* p, const char* name) {
     if (!p || !p->bound || !name) return nullptr;
 #define DAE_BUF(n) if (!strcmp(name, #n)) return (void*)p->n;
     DAE_BUF(hcat_a) DAE_BUF(hcat_b) DAE_BUF(x) DAE_BUF(xc) DAE_BUF(xct) DAE_BUF(h_lo) DAE_BUF(h_t) DAE_BUF(Gs) DAE_BUF(delta2) DAE_BUF(delta2_t) DAE_BUF(delta1_t)
+    DAE_BUF(delta1_lo) DAE_BUF(xtb)
     DAE_BUF(slabs) DAE_BUF(h_f32) DAE_BUF(D_slabs) DAE_BUF(G) DAE_BUF(rowloss_part) DAE_BUF(dbv_part) DAE_BUF(colsum_part)
     DAE_BUF(cos_part) DAE_BUF(cos_stats) DAE_BUF(cw) DAE_BUF(loss_part) DAE_BUF(dw_f32) DAE_BUF(tri_scalars) DAE_BUF(dh_extra)
     DAE_BUF(tile_part) DAE_BUF(cnt_part) DAE_BUF(role_cnt) DAE_BUF(dw_i32) DAE_BUF(n_same) DAE_BUF(nvalid) DAE_BUF(dw_i64)
@@ -402,13 +417,26 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     const bool label_with_encode = p->tail_ok && !explicit3 && !ext_mine && Bp <= 1024 && p->label_enc_ok;
     const bool label_in_gather = p->tail_ok && !label_with_encode && !explicit3 && !ext_mine && !s->c_indptr && p->b.indptr && Bp <= 1024;
     const bool tail = p->tail_ok;
-    if (!resume && backward && csr_in && !(tail && p->xct_clean)) PROF(PS_MEMSET, memset_async(p->xct, (size_t)Fp * ldB * p->es, st));
-    if (backward) p->xct_clean = false;
     float* rowsq = is_cos ? p->cos_stats : nullptr;
     bool use_bits = false;
     // binary CSR train set in bf16 mode: the clean rows reach the decode epilogue as a bit image (1.1 MB, not 18 MB)
     const bool use_xbits = p->xbits_ok && p->b.indptr && !p->b.values;
     const bool use_sparse = p->sparse_ok && csr_in;
+    // phase 0 / 3 in bf16 mode: the optimizer runs in the dW GEMM's epilogue (phase 3 does not materialise the W gradient);
+    // phase 1 / 5 (data parallel) in bf16 mode: the same kernel in its gradient-only form when the shape fits it
+    const bool apply_now = (s->phase == 0 || s->phase == 3);
+    const bool fuse_opt = backward && apply_now && dt == DAE_BF16 && p->fuse_opt_ok;
+    // binary CSR + bf16 + the fused sparse encode: x~^T is a BIT image and the x~^T.delta1 half of dW is summed from the kept entries
+    // by the dW kernel (autoencoder.py:377,452); otherwise the dense x~^T image feeds a K = 2 Bp GEMM
+    const bool src_binary = s->c_indptr ? !s->c_values : (p->b.indptr && !p->b.values);
+    const bool dw_pc_grad = backward && !apply_now && dt == DAE_BF16 && p->fuse_opt_ok && dw_sparse_fits(Fp, Hp, Bp);
+    const bool dw_sparse = p->dw_sparse_ok && use_sparse && src_binary && backward && dt == DAE_BF16 && (fuse_opt || dw_pc_grad) &&
+                           dw_sparse_fits(Fp, Hp, Bp);
+    if (!resume && backward && csr_in) {
+        if (dw_sparse) { if (!(tail && p->xtb_clean)) PROF(PS_MEMSET, memset_async(p->xtb, (size_t)Fp * (ldB / 32) * 4, st)); }
+        else if (!(tail && p->xct_clean)) PROF(PS_MEMSET, memset_async(p->xct, (size_t)Fp * ldB * p->es, st));
+    }
+    if (backward) { if (dw_sparse) p->xtb_clean = false; else p->xct_clean = false; }
     const int64_t slab = (int64_t)Bp * Hp;
     int enc_label_done = 0;
     bool labels_done = ext_mine;               // label statistics already produced by a workgroup of an earlier launch (or by the caller)
@@ -418,7 +446,9 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
         // CSR input: corrupt + gather + encode in one launch on the stored entries (tf.sparse.matmul, autoencoder.py:377,389);
         // the dense x~ image is never formed.  The clean rows reach the decode epilogue as a bit image written by the same
         // launch (binary data) or as a dense tile from the gather kernel (valued data / explicitly corrupted copy).
-        const bool own_clean = !s->c_indptr && use_xbits;            // the encode launch also emits the clean-row images
+        const bool w32 = p->enc_w32_ok && dt == DAE_BF16;   // (a sharded-optimizer exchange turns the option off: only W_lo is current on every rank)
+        // the encode launch also emits the clean-row images, unless their LDS rows do not fit (e.g. 50000 features)
+        const bool own_clean = !s->c_indptr && use_xbits && encode_csr_lds_bytes(dt, w32, p->w32_cols, Fp / 32) <= 64 * 1024;
         if (!own_clean)
             PROF(PS_GATHER, gather_batch(p, p->b.indptr, p->b.indices, p->b.values, p->b.dense, p->b.ld_dense, s->row_idx, B,
                             use_xbits ? nullptr : p->x, nullptr, nullptr, rowsq, DAE_CORR_NONE, nullptr, 0, 0, 0.f, 1.f, stream, nullptr, nullptr,
@@ -427,12 +457,13 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
         memset(&q, 0, sizeof(q));
         q.indptr = s->c_indptr ? s->c_indptr : p->b.indptr; q.indices = s->c_indptr ? s->c_indices : p->b.indices;
         q.values = s->c_indptr ? s->c_values : p->b.values; q.row_idx = (s->c_indptr && s->c_row_idx) ? s->c_row_idx : s->row_idx; q.B = B; q.F = F; q.H = H; q.dtype = dt;
-        q.W = p->b.W_lo; q.ldw = Hp; q.bh = p->b.bh; q.enc_act = c.enc_act;
+        q.W = w32 ? (const void*)p->b.W : (const void*)p->b.W_lo; q.w_f32 = w32 ? 1 : 0; q.w32_cols = p->w32_cols; q.ldw = Hp; q.bh = p->b.bh; q.enc_act = c.enc_act;
         q.corr_mode = s->c_indptr ? DAE_CORR_NONE : s->corr_mode; q.keep_bits = s->keep_bits; q.seed = s->seed; q.rng_stream = s->rng_stream;
         q.corr_frac = s->corr_frac; q.scale = s->scale;
         q.h_f32 = p->h_f32; q.h_lo = p->h_lo; q.ldh = Hp; q.h_t = p->h_t; q.ldht = ldB;
         q.hcat_a = p->gram_split ? p->hcat_a : nullptr; q.hcat_b = p->gram_split ? p->hcat_b : nullptr;
-        q.x_bits = own_clean ? p->x_bits : nullptr; q.ldxb = Fp / 32; q.xct = backward ? p->xct : nullptr; q.ldt = ldB;
+        q.x_bits = own_clean ? p->x_bits : nullptr; q.ldxb = Fp / 32; q.xct = (backward && !dw_sparse) ? p->xct : nullptr; q.ldt = ldB;
+        q.xtb = (backward && dw_sparse) ? p->xtb : nullptr; q.ldxt = ldB / 32;
         q.rowsq = own_clean ? rowsq : nullptr;
         q.label_job = label_with_encode ? &lj : nullptr;
         PROF(PS_ENC_GEMM, launch_encode_csr(q, st));
@@ -556,20 +587,31 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     const bool mined = !ext_mine && (c.triplet == DAE_TRIPLET_BATCH_ALL || c.triplet == DAE_TRIPLET_BATCH_HARD);
     PROF(PS_DH_GEMM, launch_gemm_f32out(dt, Bp, Hp, p->delta2, Fp, p->b.Wt_lo, Fp, Fp, mined ? p->Gs : nullptr, Bp, mined ? p->h_t : nullptr, ldB,
                           mined ? Bp : 0, p->slabs, Hp, p->s_dh, slab, st, GEMM_ROLE_DH));
-    PROF(PS_DH_FIN, dae_dh_finish(p->slabs, p->s_dh, slab, Hp, (explicit3 || ext_mine) ? p->dh_extra : nullptr, p->h_f32, Hp, p->b.bh, B, H, c.enc_act, dt,
-                     p->delta1_t, ldB, p->colsum_part, nullptr, stream));
+    PROF(PS_DH_FIN, launch_dh_finish(p->slabs, p->s_dh, slab, Hp, (explicit3 || ext_mine) ? p->dh_extra : nullptr, p->h_f32, Hp, p->b.bh, B, H, c.enc_act, dt,
+                     dw_sparse ? nullptr : p->delta1_t, ldB, p->colsum_part, nullptr, dw_sparse ? p->delta1_lo : nullptr, st));
     // 11. dW = x~^T delta1 + delta2^T h                                      (K8, tied weights)
-    // phase 0 / 3 in bf16 mode: the optimizer runs in the dW GEMM's epilogue (phase 3 does not materialise the W gradient)
-    const bool apply_now = (s->phase == 0 || s->phase == 3);
-    const bool fuse_opt = apply_now && dt == DAE_BF16 && p->fuse_opt_ok;
-    if (fuse_opt) {
+    if (fuse_opt || dw_pc_grad) {
         OptEpi oe;
-        oe.W = p->b.W; oe.grad = s->phase == 3 ? nullptr : p->b.grad; oe.s1 = p->b.opt_s1; oe.s2 = p->b.opt_s2;
-        oe.W_lo = p->b.W_lo; oe.Wt_lo = p->b.Wt_lo; oe.ldw = Hp; oe.ldwt = Fp; oe.opt = c.opt; oe.lr = plan_lr(p, s->adam_t);
-        oe.mom = c.momentum; oe.gscale = s->grad_scale;
-        PROF(PS_DW_GEMM, launch_dw_opt(Fp, Hp, p->xct, ldB, p->delta1_t, ldB, Bp, p->delta2_t, ldB, p->h_t, ldB, Bp, oe, st));
+        memset(&oe, 0, sizeof(oe));
+        oe.ldw = Hp; oe.ldwt = Fp;
+        if (fuse_opt) {
+            oe.W = p->b.W; oe.grad = s->phase == 3 ? nullptr : p->b.grad; oe.s1 = p->b.opt_s1; oe.s2 = p->b.opt_s2;
+            oe.W_lo = p->b.W_lo; oe.Wt_lo = p->b.Wt_lo; oe.opt = c.opt; oe.lr = plan_lr(p, s->adam_t);
+            oe.mom = c.momentum; oe.gscale = s->grad_scale;
+        } else {                                     // data parallel: gradient to memory (fp32 flat buffer, or the bf16 exchange image)
+            oe.opt = DW_OPT_GRAD_ONLY; oe.grad = p->b.grad_lo ? nullptr : p->b.grad; oe.grad_lo = p->b.grad_lo;
+            oe.ldw = Hp;
+        }
+        if (dw_sparse) {
+            DwSparseArgs sa{p->xtb, ldB / 32, p->delta1_lo, Hp, s->scale};
+            PROF(PS_DW_GEMM, launch_dw_opt(Fp, Hp, p->delta2_t, ldB, p->h_t, ldB, Bp, nullptr, 0, nullptr, 0, 0, oe, st, &sa));
+        } else {
+            PROF(PS_DW_GEMM, launch_dw_opt(Fp, Hp, p->xct, ldB, p->delta1_t, ldB, Bp, p->delta2_t, ldB, p->h_t, ldB, Bp, oe, st));
+        }
     } else {
         PROF(PS_DW_GEMM, launch_gemm_f32out(dt, Fp, Hp, p->xct, ldB, p->delta1_t, ldB, Bp, p->delta2_t, ldB, p->h_t, ldB, Bp, p->b.grad, Hp, 1, 0, st, GEMM_ROLE_DW));
+        // data parallel with a bf16 exchange image: the shape did not fit the kernel that writes it directly
+        if (!apply_now && dt == DAE_BF16 && p->b.grad_lo) RC(launch_cast_bf16(p->b.grad, p->b.grad_lo, (int64_t)Fp * Hp, st));
     }
     // 12. bias gradients
     float* g_bh = p->b.grad + (int64_t)Fp * Hp;
@@ -580,9 +622,10 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
                     fuse_bias ? 1 : 0, c.opt, plan_lr(p, s->adam_t), c.momentum, s->grad_scale, p->b.bv,
                     p->b.opt_s1 ? p->b.opt_s1 + boff : nullptr, p->b.opt_s2 ? p->b.opt_s2 + boff : nullptr};
         ClearArgs ca{s->c_indptr ? s->c_indptr : p->b.indptr, s->c_indptr ? s->c_indices : p->b.indices,
-                     (s->c_indptr && s->c_row_idx) ? s->c_row_idx : s->row_idx, B, F, p->xct, ldB, p->es};
+                     (s->c_indptr && s->c_row_idx) ? s->c_row_idx : s->row_idx, B, F, dw_sparse ? nullptr : p->xct, ldB, p->es,
+                     dw_sparse ? p->xtb : nullptr, ldB / 32};
         PROF(PS_BIAS, launch_step_tail(ba, &sa, csr_in ? &ca : nullptr, st));
-        if (csr_in) p->xct_clean = true;
+        if (csr_in) { if (dw_sparse) p->xtb_clean = true; else p->xct_clean = true; }
     } else {
         PROF(PS_BIAS, dae_bias_grads(p->dbv_part, 2 * Bp / 128, p->colsum_part, Bp / 32, p->b.bh, H, Hp, F, Fp, c.enc_act, g_bh, g_bh + Hp,
                                      fuse_bias ? 1 : 0, c.opt, plan_lr(p, s->adam_t), c.momentum, s->grad_scale, p->b.bv,
@@ -639,7 +682,9 @@ extern "C" int dae_encode_rows(dae_plan* p, const int32_t* row_idx, int32_t B, f
         EncCsrLaunch q;
         memset(&q, 0, sizeof(q));
         q.indptr = indptr; q.indices = indices; q.values = values; q.row_idx = row_idx; q.B = B; q.F = p->F; q.H = p->H; q.dtype = dt;
-        q.W = p->b.W_lo; q.ldw = Hp; q.bh = p->b.bh; q.enc_act = p->cfg.enc_act; q.corr_mode = DAE_CORR_NONE; q.scale = scale;
+        const bool w32 = p->enc_w32_ok && dt == DAE_BF16;
+        q.W = w32 ? (const void*)p->b.W : (const void*)p->b.W_lo; q.w_f32 = w32 ? 1 : 0; q.w32_cols = p->w32_cols;
+        q.ldw = Hp; q.bh = p->b.bh; q.enc_act = p->cfg.enc_act; q.corr_mode = DAE_CORR_NONE; q.scale = scale;
         q.h_f32 = p->h_f32; q.ldh = Hp;
         RC(launch_encode_csr(q, st));
         DAE_CHECK_HIP(hipMemcpy2DAsync(out, (size_t)ld_out * 4, p->h_f32, (size_t)Hp * 4, (size_t)p->H * 4, B, hipMemcpyDeviceToDevice, st));

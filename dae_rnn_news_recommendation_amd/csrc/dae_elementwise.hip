@@ -73,62 +73,72 @@ __global__ __launch_bounds__(256) void encode_finish_kernel(const float* __restr
 // K8 (middle): dh = sum_s slab_s (+ dh_extra); delta1 = dh * act'(z1); delta1^T; column partial sums
 // for db_h = sum_i delta1 - act'(bh) * sum_i dh    (the -act(bh) term of autoencoder.py:389)
 // ------------------------------------------------------------------------------------------------
+// 512 threads = 64 columns x 8 row groups; a thread owns rows ty + 8k (k < 4) of a 32-row block.  The kernel is pure latency
+// (224 blocks, < 20 MB): every load of a thread -- h, dh_extra and up to 8 slabs x 4 rows -- is issued before the first use,
+// so the block pays one memory round trip instead of one per slab group.
+constexpr int DHF_THREADS = 512;
 template <typename T>
-__global__ __launch_bounds__(256) void dh_finish_kernel(const float* __restrict__ slabs, int splits, int64_t slab_stride,
-                                                        int64_t ld_slab, const float* __restrict__ dh_extra,
-                                                        const float* __restrict__ h_f32, int64_t ldh,
-                                                        const float* __restrict__ bh, int B, int H, int enc_act,
-                                                        T* __restrict__ delta1_t, int64_t ldt, float* __restrict__ colsum_part,
-                                                        int Hp, float* __restrict__ delta1_f32) {
+__global__ __launch_bounds__(DHF_THREADS) void dh_finish_kernel(const float* __restrict__ slabs, int splits, int64_t slab_stride,
+                                                                int64_t ld_slab, const float* __restrict__ dh_extra,
+                                                                const float* __restrict__ h_f32, int64_t ldh,
+                                                                const float* __restrict__ bh, int B, int H, int enc_act,
+                                                                T* __restrict__ delta1_t, int64_t ldt, float* __restrict__ colsum_part,
+                                                                int Hp, float* __restrict__ delta1_f32, T* __restrict__ delta1_lo) {
     __shared__ float tile[32][65];
-    __shared__ float cs[2][4][64];
+    __shared__ float cs[2][8][64];
     const int j0 = blockIdx.x * 64, i0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int j = j0 + tx;
+    float hv[4], ex[4], dhv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = i0 + ty + 8 * k;
+        hv[k] = h_f32[(int64_t)i * ldh + j];
+        ex[k] = dh_extra ? dh_extra[(int64_t)i * ldh + j] : 0.f;
+        dhv[k] = 0.f;
+    }
     const float ab = act_apply(enc_act, bh[j]);
-    float dhv[8];
+    for (int s0 = 0; s0 < splits; s0 += 8) {            // 8 slabs x 4 rows = 32 loads in flight; slab order of the sum unchanged
+        float t[8][4];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) dhv[k] = 0.f;
-    for (int s0 = 0; s0 < splits; s0 += 4) {            // 4 slabs = 32 loads in flight (see encode_finish_kernel)
-        float t[4][8];
+        for (int u = 0; u < 8; ++u) {
+            const float* sl = slabs + (int64_t)min(s0 + u, splits - 1) * slab_stride + (int64_t)i0 * ld_slab + j;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float* sl = slabs + (int64_t)(s0 + u) * slab_stride + (int64_t)i0 * ld_slab + j;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) t[u][k] = (s0 + u < splits) ? sl[(int64_t)(ty + 4 * k) * ld_slab] : 0.f;
+            for (int k = 0; k < 4; ++k) t[u][k] = sl[(int64_t)(ty + 8 * k) * ld_slab];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < 8; ++u)
 #pragma unroll
-            for (int k = 0; k < 8; ++k) dhv[k] += t[u][k];
+            for (int k = 0; k < 4; ++k) dhv[k] += (s0 + u < splits) ? t[u][k] : 0.f;
     }
     float s_d1 = 0.f, s_dh = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int r = ty + 4 * k, i = i0 + r;
-        float dh = dhv[k];
-        if (dh_extra) dh += dh_extra[(int64_t)i * ldh + j];
+    for (int k = 0; k < 4; ++k) {
+        const int r = ty + 8 * k, i = i0 + r;
+        float dh = dhv[k] + ex[k];
         const bool ok = (i < B && j < H);
         dh = ok ? dh : 0.f;
-        const float a1 = h_f32[(int64_t)i * ldh + j] + ab;          // act(z1)
+        const float a1 = hv[k] + ab;                                // act(z1)
         const float d1 = ok ? dh * act_grad(enc_act, a1) : 0.f;
         s_d1 += d1; s_dh += dh;
         tile[r][tx] = d1;
         if (delta1_f32) delta1_f32[(int64_t)i * ldh + j] = d1;
+        if (delta1_lo) delta1_lo[(int64_t)i * ldh + j] = Elem<T>::from(d1);
     }
     cs[0][ty][tx] = s_d1; cs[1][ty][tx] = s_dh;
     __syncthreads();
     if (delta1_t) {
-        const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+        const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5;      // 16 feature rows per pass, 32 batch columns each
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int r = r0 + 8 * k;
+        for (int k = 0; k < 4; ++k) {
+            const int r = r0 + 16 * k;
             delta1_t[(int64_t)(j0 + r) * ldt + i0 + c] = Elem<T>::from(tile[c][r]);
         }
     }
     if (threadIdx.x < 128) {
         const int which = threadIdx.x >> 6, c = threadIdx.x & 63;
-        const float v = cs[which][0][c] + cs[which][1][c] + cs[which][2][c] + cs[which][3][c];
+        const float v = ((cs[which][0][c] + cs[which][1][c]) + (cs[which][2][c] + cs[which][3][c])) +
+                        ((cs[which][4][c] + cs[which][5][c]) + (cs[which][6][c] + cs[which][7][c]));
         // layout [2][n_row_blocks][Hp], n_row_blocks = Bp / 32
         colsum_part[((int64_t)which * gridDim.y + blockIdx.y) * Hp + j0 + c] = v;
     }
@@ -453,7 +463,8 @@ __global__ __launch_bounds__(256) void step_tail_kernel(BiasArgs ba, StatsArgs s
     for (int64_t k = s0 + lane; k < e0; k += 64) {
         const int col = ca.indices[k];
         if (col < ca.F) {
-            if (ca.es == 2) reinterpret_cast<bf16_t*>(ca.xct)[(int64_t)col * ca.ldt + i] = 0;
+            if (ca.xtb) ca.xtb[(int64_t)col * ca.ldxt + (i >> 5)] = 0u;        // every lane that touches the word writes the same zero
+            else if (ca.es == 2) reinterpret_cast<bf16_t*>(ca.xct)[(int64_t)col * ca.ldt + i] = 0;
             else reinterpret_cast<float*>(ca.xct)[(int64_t)col * ca.ldt + i] = 0.f;
         }
     }
@@ -519,21 +530,28 @@ extern "C" int dae_encode_finish(const float* slabs, int32_t splits, int64_t sla
     return 0;
 }
 
+int dae::launch_dh_finish(const float* slabs, int splits, int64_t slab_stride, int64_t ld_slab, const float* dh_extra, const float* h_f32,
+                          int64_t ldh, const float* bh, int B, int H, int enc_act, int dtype, void* delta1_t, int64_t ldt, float* colsum_part,
+                          float* delta1_f32, void* delta1_lo, hipStream_t st) {
+    DAE_CHECK_ARG(slabs && h_f32 && bh && colsum_part, "dh_finish: null input");
+    DAE_CHECK_ARG(B > 0 && H > 0 && ldh >= dae_pad(H) && splits >= 1, "dh_finish: bad shape");
+    const int Bp = (int)dae_pad(B), Hp = (int)dae_pad(H);
+    dim3 grid(Hp / 64, Bp / 32), block(DHF_THREADS);
+    if (dtype == DAE_BF16)
+        hipLaunchKernelGGL((dh_finish_kernel<bf16_t>), grid, block, 0, st, slabs, splits, slab_stride, ld_slab, dh_extra,
+                           h_f32, ldh, bh, B, H, enc_act, (bf16_t*)delta1_t, ldt, colsum_part, Hp, delta1_f32, (bf16_t*)delta1_lo);
+    else
+        hipLaunchKernelGGL((dh_finish_kernel<float>), grid, block, 0, st, slabs, splits, slab_stride, ld_slab, dh_extra,
+                           h_f32, ldh, bh, B, H, enc_act, (float*)delta1_t, ldt, colsum_part, Hp, delta1_f32, (float*)delta1_lo);
+    DAE_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int dae_dh_finish(const float* slabs, int32_t splits, int64_t slab_stride, int64_t ld_slab, const float* dh_extra,
                              const float* h_f32, int64_t ldh, const float* bh, int32_t B, int32_t H, int32_t enc_act,
                              int32_t dtype, void* delta1_t, int64_t ldt, float* colsum_part, float* delta1_f32, void* stream) {
-    DAE_CHECK_ARG(slabs && h_f32 && bh && colsum_part, "dh_finish: null input");
-    DAE_CHECK_ARG(B > 0 && H > 0 && ldh >= dae_pad(H), "dh_finish: bad shape");
-    const int Bp = (int)dae_pad(B), Hp = (int)dae_pad(H);
-    dim3 grid(Hp / 64, Bp / 32), block(256);
-    if (dtype == DAE_BF16)
-        hipLaunchKernelGGL((dh_finish_kernel<bf16_t>), grid, block, 0, ST(stream), slabs, splits, slab_stride, ld_slab, dh_extra,
-                           h_f32, ldh, bh, B, H, enc_act, (bf16_t*)delta1_t, ldt, colsum_part, Hp, delta1_f32);
-    else
-        hipLaunchKernelGGL((dh_finish_kernel<float>), grid, block, 0, ST(stream), slabs, splits, slab_stride, ld_slab, dh_extra,
-                           h_f32, ldh, bh, B, H, enc_act, (float*)delta1_t, ldt, colsum_part, Hp, delta1_f32);
-    DAE_CHECK_LAUNCH();
-    return 0;
+    return launch_dh_finish(slabs, splits, slab_stride, ld_slab, dh_extra, h_f32, ldh, bh, B, H, enc_act, dtype, delta1_t, ldt, colsum_part,
+                            delta1_f32, nullptr, ST(stream));
 }
 
 extern "C" int dae_sym_scale(const float* G, int32_t B, int32_t Bp, const float* tri_scalars, int32_t dtype, void* Gs,
@@ -690,6 +708,23 @@ extern "C" int dae_step_stats(const float* rowloss_part, int32_t n_col_waves, co
     DAE_CHECK_ARG(!loss_part || (cnt_part && nvalid && triplet == DAE_TRIPLET_BATCH_ALL), "step_stats: miner partials need cnt_part + nvalid");
     StatsArgs sa{rowloss_part, n_col_waves, tile_part, n_tiles, cw, B, Bp, triplet, alpha, tri_scalars, nvalid, stats, loss_part, cnt_part};
     hipLaunchKernelGGL(step_stats_kernel, dim3(1), dim3(1024), 0, ST(stream), sa);
+    DAE_CHECK_LAUNCH();
+    return 0;
+}
+
+namespace dae {
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t n4) {
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n4; k += (int64_t)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(src)[k];
+        uint2 o;
+        o.x = f2bf_pack_hw(v.x, v.y); o.y = f2bf_pack_hw(v.z, v.w);
+        reinterpret_cast<uint2*>(dst)[k] = o;
+    }
+}
+}  // namespace dae
+int dae::launch_cast_bf16(const float* src, void* dst_bf16, int64_t n, hipStream_t st) {
+    DAE_CHECK_ARG(src && dst_bf16 && n % 4 == 0, "cast_bf16: bad args");
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(2048), dim3(256), 0, st, src, (bf16_t*)dst_bf16, n / 4);
     DAE_CHECK_LAUNCH();
     return 0;
 }

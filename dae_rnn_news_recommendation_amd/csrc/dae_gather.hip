@@ -278,6 +278,7 @@ struct EncCsrArgs {
     float* h_f32; void* h_lo; int64_t ldh; void* h_t; int64_t ldht; bf16_t* hcat_a; bf16_t* hcat_b;
     uint32_t* x_bits; int64_t ldxb;             // clean bit image [Bp x ldxb] (binary data) or NULL
     void* xct; int64_t ldt;                     // x~^T [Fp x ldt] scatter target (pre-zeroed) or NULL
+    uint32_t* xtb; int64_t ldxt;                // x~^T as a BIT image [Fp x ldxt words] (pre-zeroed; bit i of row f <=> entry (i, f) kept) or NULL
     float* rowsq;                               // [Bp] or NULL
     int n_slices;
     LabelJob job; int label_block;
@@ -285,14 +286,17 @@ struct EncCsrArgs {
 
 constexpr int ENC_ROWS = 8;                     // batch rows per workgroup: one per wave (8 waves = 512 threads)
 constexpr int ENC_THREADS = 64 * ENC_ROWS;
-constexpr int ENC_COLS = 128;                   // H columns per workgroup ("slice": 256 B of a bf16 W row, two cache lines)
 
-template <typename WT> struct WRow;
-template <> struct WRow<bf16_t> {               // 128 columns = 256 B: lane part (0..15) reads 16 B = 8 bf16
+// One W-row slice of COLS columns is read by the 16 lanes of an entry group, CPL = COLS / 16 columns per lane.
+//   bf16 shadow, 128 columns (256 B): 16 B per lane      fp32 master, 128 columns (512 B): 32 B per lane
+//   fp32 master,  64 columns (256 B): 16 B per lane  -- 8 slices of 2.6 MB at 10000 x 500, one per XCD L2, where the 128-column
+//   fp32 slice (5.2 MB) would not fit a 4 MiB L2
+template <typename WT, int CPL> struct WRow;
+template <> struct WRow<bf16_t, 8> {
     typedef i32x4 Raw;
     static constexpr int BATCH = 18;              // W-row loads in flight per lane (4 VGPRs each)
     static __device__ __forceinline__ Raw load(const char* p) { return *reinterpret_cast<const i32x4*>(p); }
-    static __device__ __forceinline__ void fma8(const Raw& v, float w, float (&acc)[8]) {
+    static __device__ __forceinline__ void fma(const Raw& v, float w, float (&acc)[8]) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             acc[2 * q] = fmaf(w, __uint_as_float(((uint32_t)v[q]) << 16), acc[2 * q]);
@@ -300,45 +304,63 @@ template <> struct WRow<bf16_t> {               // 128 columns = 256 B: lane par
         }
     }
 };
-template <> struct WRow<float> {                // 128 columns = 512 B: lane part reads 32 B = 8 fp32
+template <> struct WRow<float, 8> {
     struct Raw { f32x4 a, b; };
     static constexpr int BATCH = 9;               // 8 VGPRs each
     static __device__ __forceinline__ Raw load(const char* p) {
         Raw r; r.a = *reinterpret_cast<const f32x4*>(p); r.b = *reinterpret_cast<const f32x4*>(p + 16); return r;
     }
-    static __device__ __forceinline__ void fma8(const Raw& v, float w, float (&acc)[8]) {
+    static __device__ __forceinline__ void fma(const Raw& v, float w, float (&acc)[8]) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) { acc[q] = fmaf(w, v.a[q], acc[q]); acc[4 + q] = fmaf(w, v.b[q], acc[4 + q]); }
     }
 };
+template <> struct WRow<float, 4> {
+    typedef f32x4 Raw;
+    static constexpr int BATCH = 18;
+    static __device__ __forceinline__ Raw load(const char* p) { return *reinterpret_cast<const f32x4*>(p); }
+    static __device__ __forceinline__ void fma(const Raw& v, float w, float (&acc)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = fmaf(w, v[q], acc[q]);
+    }
+};
 
-template <typename WT, typename T>
+// LDS carve of the kernel (bytes): pre-activation tile, transposed low-precision tile, per-wave kept-entry lists, clean bit rows
+__host__ __device__ constexpr size_t enc_lds_fixed(int cols, int tsize) {
+    return (size_t)ENC_ROWS * cols * 4 + (size_t)cols * ENC_ROWS * tsize + (size_t)ENC_ROWS * 256 * 8;
+}
+
+// WT: element type of the weight image that is read (bf16 shadow, or the fp32 master);  T: element type of the activation
+// images that are written (h_lo, h^T, x~^T);  COLS: H columns per workgroup ("slice")
+template <typename WT, typename T, int COLS>
 __global__ __launch_bounds__(ENC_THREADS, 4) void encode_csr_kernel(EncCsrArgs a) {
+    constexpr int CPL = COLS / 16;                 // columns per lane of an entry group
+    constexpr int EPL = COLS / 64;                 // columns per lane of the epilogue (thread = row x EPL columns)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if ((int)blockIdx.x == a.label_block) { label_stats_block<ENC_THREADS>(a.job, smem); return; }
-    float* zt = reinterpret_cast<float*>(smem);                                           // [ENC_ROWS][128] pre-activations of this slice
-    T* ht = reinterpret_cast<T*>(smem + ENC_ROWS * ENC_COLS * 4);                         // [128][ENC_ROWS] transposed low-precision h
-    int2* const lists = reinterpret_cast<int2*>(smem + 2 * ENC_ROWS * ENC_COLS * 4);      // [ENC_ROWS][256] kept (column, value) of a pass
-    uint32_t* xb = reinterpret_cast<uint32_t*>(smem + 2 * ENC_ROWS * ENC_COLS * 4 + ENC_ROWS * 256 * 8);   // [ENC_ROWS][ldxb] clean bit rows
+    float* zt = reinterpret_cast<float*>(smem);                                           // [ENC_ROWS][COLS] pre-activations of this slice
+    T* ht = reinterpret_cast<T*>(smem + ENC_ROWS * COLS * 4);                             // [COLS][ENC_ROWS] transposed low-precision h
+    int2* const lists = reinterpret_cast<int2*>(smem + ENC_ROWS * COLS * 4 + COLS * ENC_ROWS * sizeof(T));   // [ENC_ROWS][256] kept (column, value)
+    uint32_t* xb = reinterpret_cast<uint32_t*>(smem + enc_lds_fixed(COLS, (int)sizeof(T)));                  // [ENC_ROWS][ldxb] clean bit rows
     const int slice = blockIdx.x % a.n_slices, i0 = (blockIdx.x / a.n_slices) * ENC_ROWS;
     const int tid = threadIdx.x, lane = tid & 63;
     const int r = __builtin_amdgcn_readfirstlane(tid >> 6), i = i0 + r;  // this wave's batch row
-    const int sub = lane >> 4, part = lane & 15;                         // 4 entries per load instruction, 16 x 16 B per W-row slice
+    const int sub = lane >> 4, part = lane & 15;                         // 4 entries per load instruction, 16 lanes per W-row slice
     // side images: task t is produced by the workgroups of slice t % n_slices
     const bool do_xbits = a.x_bits && slice == 0;
-    const bool do_xct = a.xct && slice == 1 % a.n_slices;
+    const bool do_xct = (a.xct || a.xtb) && slice == 1 % a.n_slices;
     const bool do_rowsq = a.rowsq && slice == 2 % a.n_slices;
     if (do_xbits) {
         for (int k = tid; k < ENC_ROWS * (int)a.ldxb; k += ENC_THREADS) xb[k] = 0u;
         __syncthreads();
     }
-    const char* Wb = reinterpret_cast<const char*>(a.W) + (int64_t)slice * ENC_COLS * sizeof(WT) + part * (8 * sizeof(WT));
-    const uint32_t ldw_b = (uint32_t)(a.ldw * (int64_t)sizeof(WT));
+    const char* Wb = reinterpret_cast<const char*>(a.W) + (int64_t)slice * COLS * sizeof(WT) + part * (CPL * sizeof(WT));
+    const uint64_t ldw_b = (uint64_t)(a.ldw * (int64_t)sizeof(WT));
     T* xct = reinterpret_cast<T*>(a.xct);
     int2* const mylist = lists + r * 256;
-    float acc[8];
+    float acc[CPL];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+    for (int q = 0; q < CPL; ++q) acc[q] = 0.f;
     float sq = 0.f;
 #ifdef DAE_ENC_PROBE
     const bool probe_skip_rows = (DAE_ENC_PROBE & 2) != 0;              // probe: no entry phase at all
@@ -352,7 +374,7 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void encode_csr_kernel(EncCsrArgs a
             // a lane owns 4 stored entries of the pass.  All reads (ids, values, keep words) are issued UNCONDITIONALLY on clamped
             // addresses, group by group, so that they are in flight together: a per-entry branch around a load makes hipcc wait
             // vmcnt(0) per entry, i.e. four dependent L2 round trips instead of one.
-            int col[4]; float vc[4], vv[4];
+            int col[4]; float vv[4];
             int64_t kc[4];
             uint32_t kw[4];
 #pragma unroll
@@ -384,7 +406,11 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void encode_csr_kernel(EncCsrArgs a
                 const float v = valid ? vv[u] : 0.f;
                 const float w = keep ? v * a.scale : 0.f;
                 if (do_xbits && valid) atomicOr(&xb[r * a.ldxb + (col[u] >> 5)], 1u << (col[u] & 31));
-                if (do_xct && keep) xct[(int64_t)col[u] * a.ldt + i] = Elem<T>::from(w);
+                if (do_xct && keep) {
+                    // x~^T for the dW GEMM: a bit per kept entry (binary data; integer OR -> order-independent), or the dense scatter
+                    if (a.xtb) atomicOr(&a.xtb[(int64_t)col[u] * a.ldxt + (i >> 5)], 1u << (i & 31));
+                    else xct[(int64_t)col[u] * a.ldt + i] = Elem<T>::from(w);
+                }
                 if (do_rowsq) sq += v * v;
                 const bool kp = w != 0.f;
                 const unsigned long long m = __ballot(kp);
@@ -394,11 +420,11 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void encode_csr_kernel(EncCsrArgs a
 #ifdef DAE_ENC_PROBE
             if (DAE_ENC_PROBE & 1) nkept = 0;                            // probe: no W-row reads
 #endif
-            // walk the list 4 entries at a time (one per 16-lane group): lane (sub, part) reads 16 bytes (part) of the W-row slice
-            // of entry `sub`; BATCH loads (1 KiB each per wave) are issued back to back before the first use
-            constexpr int NB = WRow<WT>::BATCH;
+            // walk the list 4 entries at a time (one per 16-lane group): lane (sub, part) reads its CPL columns of the W-row slice
+            // of entry `sub`; BATCH loads are issued back to back before the first use
+            constexpr int NB = WRow<WT, CPL>::BATCH;
             for (int t0 = 0; t0 * 4 < nkept; t0 += NB) {
-                typename WRow<WT>::Raw wr[NB];
+                typename WRow<WT, CPL>::Raw wr[NB];
                 float wj[NB];
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
@@ -406,16 +432,16 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void encode_csr_kernel(EncCsrArgs a
                     const int2 cw = mylist[min(e, 255)];
                     const bool on = e < nkept;
                     wj[j] = on ? __int_as_float(cw.y) : 0.f;
-                    wr[j] = WRow<WT>::load(Wb + (uint64_t)((uint32_t)(on ? cw.x : 0) * ldw_b));
+                    wr[j] = WRow<WT, CPL>::load(Wb + (uint64_t)(uint32_t)(on ? cw.x : 0) * ldw_b);
                 }
 #pragma unroll
-                for (int j = 0; j < NB; ++j) WRow<WT>::fma8(wr[j], wj[j], acc);
+                for (int j = 0; j < NB; ++j) WRow<WT, CPL>::fma(wr[j], wj[j], acc);
             }
         }
     }
     // butterfly over the 4 entry groups (lane bits 4, 5); lanes 0..15 (sub == 0) end up with the row's sums
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < CPL; ++q) {
         float t = acc[q];
         t += __shfl_xor(t, 16, 64);
         t += __shfl_xor(t, 32, 64);
@@ -423,47 +449,62 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void encode_csr_kernel(EncCsrArgs a
     }
     if (sub == 0) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) zt[r * ENC_COLS + part * 8 + q] = acc[q];
+        for (int q = 0; q < CPL; ++q) zt[r * COLS + part * CPL + q] = acc[q];
     }
     if (do_rowsq) {
         sq = wave_sum(sq);
         if (lane == 0) a.rowsq[i] = (i < a.B) ? sq : 0.f;
     }
     __syncthreads();
-    // ---- epilogue on the [8 rows x 128 columns] tile: thread = (row, column pair) ----
+    // ---- epilogue on the [8 rows x COLS columns] tile: thread = (row, EPL neighbouring columns) ----
 #ifdef DAE_ENC_PROBE
     if (DAE_ENC_PROBE & 4) return;                                       // probe: no epilogue
 #endif
     {
-        float hv[2];
-        const int col0 = slice * ENC_COLS + lane * 2;
+        float hv[EPL];
+        const int col0 = slice * COLS + lane * EPL;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int cl = lane * 2 + u, col = col0 + u;
+        for (int u = 0; u < EPL; ++u) {
+            const int cl = lane * EPL + u, col = col0 + u;
             const float b = a.bh[col];
-            const float z = zt[r * ENC_COLS + cl] + b;
+            const float z = zt[r * COLS + cl] + b;
             hv[u] = (i < a.B && col < a.H) ? act_apply(a.enc_act, z) - act_apply(a.enc_act, b) : 0.f;
             ht[cl * ENC_ROWS + r] = Elem<T>::from(hv[u]);
         }
-        if (a.h_f32) *reinterpret_cast<float2*>(a.h_f32 + (int64_t)i * a.ldh + col0) = make_float2(hv[0], hv[1]);
+        if (a.h_f32) {
+            float* hp = a.h_f32 + (int64_t)i * a.ldh + col0;
+            if constexpr (EPL == 2) *reinterpret_cast<float2*>(hp) = make_float2(hv[0], hv[1]);
+            else hp[0] = hv[0];
+        }
         if (a.h_lo) {
             T* hl = reinterpret_cast<T*>(a.h_lo) + (int64_t)i * a.ldh + col0;
-            if constexpr (sizeof(T) == 2) *reinterpret_cast<uint32_t*>(hl) = (uint32_t)f2bf(hv[0]) | ((uint32_t)f2bf(hv[1]) << 16);
-            else { hl[0] = Elem<T>::from(hv[0]); hl[1] = Elem<T>::from(hv[1]); }
+            if constexpr (sizeof(T) == 2 && EPL == 2) *reinterpret_cast<uint32_t*>(hl) = (uint32_t)f2bf(hv[0]) | ((uint32_t)f2bf(hv[1]) << 16);
+            else {
+#pragma unroll
+                for (int u = 0; u < EPL; ++u) hl[u] = Elem<T>::from(hv[u]);
+            }
         }
         if (a.hcat_a) {   // split-bf16 operands of the Gram matrix: h = hi + lo, D ~= hi.hi + hi.lo + lo.hi
-            const bf16_t hi0 = f2bf(hv[0]), hi1 = f2bf(hv[1]);
-            const bf16_t lo0 = f2bf(hv[0] - bf2f(hi0)), lo1 = f2bf(hv[1] - bf2f(hi1));
-            const uint32_t hi = (uint32_t)hi0 | ((uint32_t)hi1 << 16), lo = (uint32_t)lo0 | ((uint32_t)lo1 << 16);
-            uint32_t* pa = reinterpret_cast<uint32_t*>(a.hcat_a + (int64_t)i * (3 * a.Hp) + col0);
-            uint32_t* pb = reinterpret_cast<uint32_t*>(a.hcat_b + (int64_t)i * (3 * a.Hp) + col0);
-            pa[0] = hi; pa[a.Hp / 2] = hi; pa[a.Hp] = lo;
-            pb[0] = hi; pb[a.Hp / 2] = lo; pb[a.Hp] = hi;
+            bf16_t* pa = a.hcat_a + (int64_t)i * (3 * a.Hp) + col0;
+            bf16_t* pb = a.hcat_b + (int64_t)i * (3 * a.Hp) + col0;
+            if constexpr (EPL == 2) {
+                const bf16_t hi0 = f2bf(hv[0]), hi1 = f2bf(hv[1]);
+                const bf16_t lo0 = f2bf(hv[0] - bf2f(hi0)), lo1 = f2bf(hv[1] - bf2f(hi1));
+                const uint32_t hi = (uint32_t)hi0 | ((uint32_t)hi1 << 16), lo = (uint32_t)lo0 | ((uint32_t)lo1 << 16);
+                uint32_t* qa = reinterpret_cast<uint32_t*>(pa);
+                uint32_t* qb = reinterpret_cast<uint32_t*>(pb);
+                qa[0] = hi; qa[a.Hp / 2] = hi; qa[a.Hp] = lo;
+                qb[0] = hi; qb[a.Hp / 2] = lo; qb[a.Hp] = hi;
+            } else {
+                const bf16_t hi = f2bf(hv[0]), lo = f2bf(hv[0] - bf2f(hi));
+                pa[0] = hi; pa[a.Hp] = hi; pa[2 * a.Hp] = lo;
+                pb[0] = hi; pb[a.Hp] = lo; pb[2 * a.Hp] = hi;
+            }
         }
     }
     __syncthreads();
-    if (a.h_t && tid < ENC_COLS) {                   // h^T: 8 batch columns of one feature row = one 16-byte (bf16) / 32-byte store
-        T* dst = reinterpret_cast<T*>(a.h_t) + (int64_t)(slice * ENC_COLS + tid) * a.ldht + i0;
+    if (a.h_t && tid < COLS) {                       // h^T: 8 batch columns of one feature row = one 16-byte (bf16) / 32-byte store
+        T* dst = reinterpret_cast<T*>(a.h_t) + (int64_t)(slice * COLS + tid) * a.ldht + i0;
         const T* src = ht + tid * ENC_ROWS;
         *reinterpret_cast<i32x4*>(dst) = *reinterpret_cast<const i32x4*>(src);
         if constexpr (sizeof(T) == 4) *reinterpret_cast<i32x4*>(dst + 4) = *reinterpret_cast<const i32x4*>(src + 4);
@@ -520,6 +561,15 @@ int dae::launch_gather_csr(const int64_t* indptr, const int32_t* indices, const 
     return 0;
 }
 
+// dynamic LDS of the launch for `dtype` activations, weights read as fp32 (w_f32) or as the low-precision shadow, and
+// ldxb words per clean bit row (0 = no bit rows); the step driver asks this before it lets the launch emit the clean bit image
+static int enc_cols(int dtype, int w_f32, int w32_cols) { return (dtype == DAE_BF16 && w_f32 && w32_cols == 64) ? 64 : 128; }
+size_t dae::encode_csr_lds_bytes(int dtype, int w_f32, int w32_cols, int64_t ldxb) {
+    const int cols = enc_cols(dtype, w_f32, w32_cols);
+    size_t lds = enc_lds_fixed(cols, dtype == DAE_BF16 ? 2 : 4) + (size_t)ENC_ROWS * (size_t)ldxb * 4;
+    return lds;
+}
+
 int dae::launch_encode_csr(const EncCsrLaunch& q, hipStream_t st) {
     DAE_CHECK_ARG(q.indptr && q.indices && q.row_idx && q.W && q.bh, "encode_csr: null input");
     DAE_CHECK_ARG(q.B > 0 && q.F > 0 && q.H > 0, "encode_csr: bad shape");
@@ -529,6 +579,7 @@ int dae::launch_encode_csr(const EncCsrLaunch& q, hipStream_t st) {
     DAE_CHECK_ARG(q.ldw >= Hp && q.ldh >= Hp && (!q.h_t || q.ldht >= Bp), "encode_csr: leading dimensions too small");
     DAE_CHECK_ARG(!q.x_bits || (!q.values && q.ldxb >= dae_pad(q.F) / 32), "encode_csr: the bit image of x needs binary data and ldxb >= Fp/32");
     DAE_CHECK_ARG(!q.xct || q.ldt >= Bp, "encode_csr: ldt too small");
+    DAE_CHECK_ARG(!q.xtb || (!q.values && q.ldxt >= Bp / 32 && !q.xct), "encode_csr: the bit image of x~^T needs binary data, ldxt >= Bp/32 and no dense x~^T");
     DAE_CHECK_ARG(!q.label_job || q.label_job->Bp <= 1024, "encode_csr: in-kernel label statistics need a padded batch <= 1024");
     DAE_CHECK_ARG((q.hcat_a == nullptr) == (q.hcat_b == nullptr), "encode_csr: hcat_a/hcat_b must be given together");
     EncCsrArgs a;
@@ -538,17 +589,24 @@ int dae::launch_encode_csr(const EncCsrLaunch& q, hipStream_t st) {
     a.corr_mode = q.corr_mode; a.keep_bits = q.keep_bits; a.seed = q.seed; a.stream = q.rng_stream; a.corr_frac = q.corr_frac; a.scale = q.scale;
     a.enc_act = q.enc_act; a.h_f32 = q.h_f32; a.h_lo = q.h_lo; a.ldh = q.ldh; a.h_t = q.h_t; a.ldht = q.ldht;
     a.hcat_a = (bf16_t*)q.hcat_a; a.hcat_b = (bf16_t*)q.hcat_b; a.x_bits = q.x_bits; a.ldxb = q.ldxb; a.xct = q.xct; a.ldt = q.ldt;
-    a.rowsq = q.rowsq; a.n_slices = Hp / ENC_COLS;
+    a.xtb = q.xtb; a.ldxt = q.ldxt;
+    const int cols = enc_cols(q.dtype, q.w_f32, q.w32_cols);
+    a.rowsq = q.rowsq; a.n_slices = Hp / cols;
     const int nblk = a.n_slices * (Bp / ENC_ROWS);
     a.label_block = q.label_job ? nblk : -1;
     if (q.label_job) a.job = *q.label_job;
-    size_t lds = 2 * ENC_ROWS * ENC_COLS * 4 + ENC_ROWS * 256 * 8 + (q.x_bits ? (size_t)ENC_ROWS * q.ldxb * 4 : 0);
+    size_t lds = encode_csr_lds_bytes(q.dtype, q.w_f32, q.w32_cols, q.x_bits ? q.ldxb : 0);
     if (q.label_job && lds < (size_t)LABEL_SMEM_BYTES) lds = LABEL_SMEM_BYTES;
-    DAE_CHECK_ARG(lds <= 64 * 1024, "encode_csr: %zu B of LDS for the bit rows of %d features", lds, q.F);
+    DAE_CHECK_ARG(lds <= 64 * 1024, "encode_csr: %zu B of LDS for the bit rows of %d features (route the clean rows through dae_gather_csr)", lds, q.F);
     dim3 grid(nblk + (q.label_job ? 1 : 0)), block(ENC_THREADS);
-    // element type of the weight image follows the activation type: bf16 shadow W_lo, or the fp32 image in parity mode
-    if (q.dtype == DAE_BF16) hipLaunchKernelGGL((encode_csr_kernel<bf16_t, bf16_t>), grid, block, lds, st, a);
-    else hipLaunchKernelGGL((encode_csr_kernel<float, float>), grid, block, lds, st, a);
+    // weight image: the low-precision shadow W_lo of the activation type, or -- w_f32, bf16 activations -- the fp32 master
+    if (q.dtype == DAE_BF16) {
+        if (!q.w_f32) hipLaunchKernelGGL((encode_csr_kernel<bf16_t, bf16_t, 128>), grid, block, lds, st, a);
+        else if (cols == 64) hipLaunchKernelGGL((encode_csr_kernel<float, bf16_t, 64>), grid, block, lds, st, a);
+        else hipLaunchKernelGGL((encode_csr_kernel<float, bf16_t, 128>), grid, block, lds, st, a);
+    } else {
+        hipLaunchKernelGGL((encode_csr_kernel<float, float, 128>), grid, block, lds, st, a);
+    }
     DAE_CHECK_LAUNCH();
     return 0;
 }

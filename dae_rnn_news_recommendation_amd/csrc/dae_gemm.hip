@@ -712,6 +712,16 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_nt_pc(GemmParams p, float*
 // [32 w, +32): 5 accumulators, per 16-deep k step 5 A fragments + 1 B fragment for 5 MFMAs; fragments are double buffered
 // one k step ahead (48 VGPRs) so that the master weights of the tile can stay prefetched in registers (80 VGPRs, SGD).
 // The last row tile is partial (10112 = 63 x 160 + 32): its out-of-range rows load row Fp-1 and are never stored.
+//
+// SPARSE (binary CSR input): only  delta2^T . h  runs on MFMA (K = Bp).  The other half of the tied-weight gradient,
+//     x~^T . delta1        (autoencoder.py:377,452: the autodiff of tf.sparse.matmul(x~, W) is itself a sparse product)
+// is summed from the KEPT ENTRIES: x~^T arrives as a bit image (bit i of row f <=> entry (i, f) kept, written by the encode
+// launch: 1.1 MB instead of an 18 MB image that is 98.6 % zeros), and after the K loop -- the LDS ring is dead by then -- all
+// 8 waves turn the tile's 160 bit rows into index lists and add up the matching rows of delta1 [Bp x Hp] (row-major, from
+// dh_finish): a 16-lane group owns one feature row, lane `part` its 8 columns, 8 independent 16-byte loads in flight; the
+// sums land in an fp32 LDS tile that the consumer waves add to their MFMA accumulators.  Entries are walked in batch-row
+// order -> deterministic.  ~11 entries per feature: 0.11 GFLOP instead of the 8 GFLOP of zeros the dense form multiplies.
+// OPT == DW_GRAD_ONLY: no optimizer, the gradient tile goes to memory (fp32 `grad` and / or bf16 `grad_lo`): the data-parallel step.
 // ------------------------------------------------------------------------------------------------
 constexpr int DW_BM = 160, DW_MB = DW_BM / 32;                         // rows per tile, MFMA row blocks per consumer wave
 constexpr int DW_A_BYTES = DW_BM * BKB;                                // 20 KiB
@@ -719,10 +729,36 @@ constexpr int DW_STAGE = DW_A_BYTES + TILE_BYTES;                      // + 16 K
 constexpr int DW_NST = 4;
 constexpr int DW_P0 = 128 * 2 + 16;                                    // staged W_lo row [160][128 bf16 + pad]
 constexpr int DW_P1 = DW_BM * 2 + 16;                                  // staged Wt_lo row [128][160 bf16 + pad]
-constexpr int DW_LDS = DW_NST * DW_STAGE;                              // 144 KiB (the epilogue tiles, 86 KiB, reuse it)
+constexpr int DW_RING = DW_NST * DW_STAGE;                             // 144 KiB (the epilogue tiles, 86 KiB, reuse it)
+constexpr int DW_GRAD_ONLY = DW_OPT_GRAD_ONLY;                                       // OPT value: gradient to memory, no update
+constexpr int DWS_PITCH = 132;                                         // floats per row of the sparse-sum tile [160][128 + 4]
+constexpr int DWS_TILE = DW_BM * DWS_PITCH * 4;                        // 84,480 B
+constexpr int DWS_CAP = 1024;                                          // list entries per 16-lane group (Bp <= 1024)
+constexpr int DWS_GROUPS = PC_THREADS / 16;                            // 32
+constexpr int DWS_LDS = DWS_TILE + DWS_GROUPS * DWS_CAP * 2;           // 150,016 B
+constexpr int DW_LDS = DW_RING;
+constexpr int DW_LDS_SPARSE = DWS_LDS > DW_RING ? DWS_LDS : DW_RING;
 
-template <int OPT>
-__global__ __launch_bounds__(PC_THREADS, 1) void gemm_dw_pc(GemmParams p, OptEpi e, int Mrows) {
+struct DwSparse {
+    const uint32_t* xtb; int64_t ldxt;       // x~^T bit image [Mrows x ldxt words]
+    const bf16_t* d1; int64_t ldd1;          // delta1 [Bp x ldd1] bf16, row-major
+    int nwords;                              // Bp / 32 (<= 32)
+    float scale;                             // value of every kept entry (the corruption's scale factor; 1 for masking noise)
+};
+
+__device__ __forceinline__ int group16_excl_scan(int v, int part, int& total) {
+    int x = v;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+        const int y = __shfl_up(x, d, 16);
+        if (part >= d) x += y;
+    }
+    total = __shfl(x, 15, 16);
+    return x - v;
+}
+
+template <int OPT, bool SPARSE>
+__global__ __launch_bounds__(PC_THREADS, 1) void gemm_dw_pc(GemmParams p, OptEpi e, int Mrows, DwSparse sp) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     // XCD-banded tile map: XCD x = b % 8 owns 8 consecutive row tiles (all column tiles), so a band's A panel is read from
     // HBM by one XCD and re-used from its L2 by the 4 column tiles
@@ -738,6 +774,28 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_dw_pc(GemmParams p, OptEpi
     const int nk = p.ktiles_total;
 #endif
     const int row0_m = tm * DW_BM, row0_n = tn * BN;
+    constexpr bool UPDATE = OPT != DW_GRAD_ONLY;
+#ifdef DAE_DW_PROBE
+    constexpr bool PREFETCH_W = (OPT == DAE_OPT_SGD) && !(DAE_DW_PROBE & 8);   // probe: no master-weight read
+#else
+    constexpr bool PREFETCH_W = (OPT == DAE_OPT_SGD);
+#endif
+    // ---- SPARSE: this 16-lane group's bit rows (5 feature rows x 2 words per lane), requested before the K loop ----
+    const int gq = tid >> 4, part = lane & 15;                              // group 0..31 owns tile rows gq, gq + 32, ...
+    uint32_t bw[DW_MB][2];
+    if constexpr (SPARSE) {
+#pragma unroll
+        for (int s2 = 0; s2 < DW_MB; ++s2) {
+            const int grow = row0_m + s2 * 32 + gq;
+            const uint32_t* rowp = sp.xtb + (int64_t)min(grow, Mrows - 1) * sp.ldxt;
+            bw[s2][0] = rowp[min(part, sp.nwords - 1)];                     // raw words; masked where they are used, after the
+            bw[s2][1] = rowp[min(part + 16, sp.nwords - 1)];                // K loop, so that nothing waits for them before it
+        }
+    }
+    const int g = lane >> 5, c = lane & 31;
+    float* __restrict__ Wp = e.W;
+    float wv[DW_MB][16] = {};
+    f32x16 acc[DW_MB];
 
     if (wave8 >= 4) {
         // ================= producer: 5 A pieces + 4 B pieces per K tile =================
@@ -774,13 +832,13 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_dw_pc(GemmParams p, OptEpi
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gB + voB[i]),
                                                  (__attribute__((address_space(3))) void*)(slot + DW_A_BYTES + (i * 4 + wave) * 1024), 16, 0, 0);
             ++kt_dma;
-            if (kt_dma == p.seg[0].ktiles) seg_setup(kt_dma);
+            if (kt_dma == p.seg[0].ktiles) { if (kt_dma < p.ktiles_total) seg_setup(kt_dma); }
             else { gA += BKB; gB += BKB; }
         };
 #pragma unroll
         for (int st = 0; st < DW_NST; ++st)
             if (st < nk) dma_stage(lds + st * DW_STAGE);
-        if (nk >= DW_NST) wait_vm<(DW_NST - 1) * 9>(); else wait_vm<0>();   // stage 0 landed
+        if (nk >= DW_NST) wait_vm<(DW_NST - 1) * 9>(); else wait_vm<0>();   // stage 0 landed (older plain loads return first)
         __builtin_amdgcn_s_barrier();
         int cur = 0;
         for (int i = 0; i < nk; ++i) {
@@ -796,15 +854,7 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_dw_pc(GemmParams p, OptEpi
     } else {
         // ================= consumer =================
         const int wave = wave8;                                             // column block
-        const int g = lane >> 5, c = lane & 31;
-        float* __restrict__ Wp = e.W;
         // master weights of this lane's 80 elements, requested before the K loop (plain SGD; see gemm_dw_opt)
-#ifdef DAE_DW_PROBE
-        constexpr bool PREFETCH_W = (OPT == DAE_OPT_SGD) && !(DAE_DW_PROBE & 8);   // probe: no master-weight read
-#else
-        constexpr bool PREFETCH_W = (OPT == DAE_OPT_SGD);
-#endif
-        float wv[DW_MB][16] = {};
         if constexpr (PREFETCH_W) {
 #pragma unroll
             for (int m = 0; m < DW_MB; ++m)
@@ -814,7 +864,6 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_dw_pc(GemmParams p, OptEpi
                     wv[m][r] = Wp[(int64_t)grow * e.ldw + row0_n + wave * 32 + c];
                 }
         }
-        f32x16 acc[DW_MB];
 #pragma unroll
         for (int m = 0; m < DW_MB; ++m)
 #pragma unroll
@@ -875,10 +924,73 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_dw_pc(GemmParams p, OptEpi
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #undef DAE_DW_READ
 #undef DAE_DW_MMA
-        // ---- optimizer on the gradient tile in registers; both bf16 shadows staged in LDS (the ring is dead for this wave's
-        //      columns only after the barrier below, which all 8 waves reach) ----
-        __builtin_amdgcn_s_barrier();                                       // B1: every consumer is out of the K loop
-        char* R0 = lds;                                                     // W_lo tile   [160][DW_P0]
+    }
+    __builtin_amdgcn_s_barrier();                                           // B1: every wave is out of the K loop; the ring is dead
+    asm volatile("" ::: "memory");
+
+    if constexpr (SPARSE) {
+        // ================= x~^T . delta1 from the kept entries (all 8 waves; one feature row per 16-lane group) =================
+        float* S = reinterpret_cast<float*>(lds);                                                  // [160][DWS_PITCH]
+        unsigned short* list = reinterpret_cast<unsigned short*>(lds + DWS_TILE) + gq * DWS_CAP;   // this group's batch-row list
+        const char* d1b = reinterpret_cast<const char*>(sp.d1) + (int64_t)(row0_n + part * 8) * 2;
+        const int64_t ldd1_b = sp.ldd1 * 2;
+#pragma unroll 1
+        for (int s2 = 0; s2 < DW_MB; ++s2) {
+            const int lrow = s2 * 32 + gq;
+            // bit words -> ascending list of batch rows (word `part` before word `part + 16`, ranks by prefix over the group)
+            const bool rok = row0_m + lrow < Mrows;
+            uint32_t w0 = (rok && part < sp.nwords) ? bw[s2][0] : 0u, w1 = (rok && part + 16 < sp.nwords) ? bw[s2][1] : 0u;
+            int tot0, tot1;
+            int o0 = group16_excl_scan(__builtin_popcount(w0), part, tot0);
+            int o1 = tot0 + group16_excl_scan(__builtin_popcount(w1), part, tot1);
+            const int cnt = tot0 + tot1;
+            while (w0) { const int bb = __builtin_ctz(w0); w0 &= w0 - 1; list[o0++] = (unsigned short)(part * 32 + bb); }
+            while (w1) { const int bb = __builtin_ctz(w1); w1 &= w1 - 1; list[o1++] = (unsigned short)((part + 16) * 32 + bb); }
+            // (LDS operations of one wave complete in order: the reads below see the list)
+            float sa[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) sa[q] = 0.f;
+            for (int k0 = 0; k0 < cnt; k0 += 8) {
+                i32x4 v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int i = list[min(k0 + j, cnt - 1)];
+                    v[j] = *reinterpret_cast<const i32x4*>(d1b + (int64_t)i * ldd1_b);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float on = (k0 + j < cnt) ? 1.0f : 0.0f;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        sa[2 * q] = fmaf(on, __uint_as_float(((uint32_t)v[j][q]) << 16), sa[2 * q]);
+                        sa[2 * q + 1] = fmaf(on, __uint_as_float(((uint32_t)v[j][q]) & 0xffff0000u), sa[2 * q + 1]);
+                    }
+                }
+            }
+            f32x4 lo4 = {sa[0] * sp.scale, sa[1] * sp.scale, sa[2] * sp.scale, sa[3] * sp.scale};
+            f32x4 hi4 = {sa[4] * sp.scale, sa[5] * sp.scale, sa[6] * sp.scale, sa[7] * sp.scale};
+            *reinterpret_cast<f32x4*>(S + lrow * DWS_PITCH + part * 8) = lo4;
+            *reinterpret_cast<f32x4*>(S + lrow * DWS_PITCH + part * 8 + 4) = hi4;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                       // B2: the sparse-sum tile is complete
+        asm volatile("" ::: "memory");
+        if (wave8 < 4) {
+            const float* Sl = S + (4 * g) * DWS_PITCH + wave8 * 32 + c;
+#pragma unroll
+            for (int m = 0; m < DW_MB; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][r] += Sl[(m * 32 + (r & 3) + 8 * (r >> 2)) * DWS_PITCH];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                       // B3: the tile is consumed; the LDS is free for the staging
+        asm volatile("" ::: "memory");
+    }
+
+    if (wave8 < 4) {
+        // ---- optimizer on the gradient tile in registers; both bf16 shadows staged in LDS ----
+        const int wave = wave8;
+        char* R0 = lds;                                                     // W_lo tile   [160][DW_P0]   (GRAD_ONLY: the bf16 gradient tile)
         char* R1 = lds + DW_BM * DW_P0;                                     // Wt_lo tile  [128][DW_P1]
         float* __restrict__ gradp = e.grad;
         float* __restrict__ s1p = e.s1;
@@ -888,7 +1000,7 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_dw_pc(GemmParams p, OptEpi
         auto block = [&](auto MB) {
             constexpr int m = decltype(MB)::value;
             float a1[16], a2[16];
-            if constexpr (OPT != DAE_OPT_SGD) {
+            if constexpr (UPDATE && OPT != DAE_OPT_SGD) {
 #pragma unroll
                 for (int r2 = 0; r2 < 16; ++r2) {
                     const int grow = min(row0_m + m * 32 + (r2 & 3) + 8 * (r2 >> 2) + 4 * g, Mrows - 1);
@@ -909,6 +1021,11 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_dw_pc(GemmParams p, OptEpi
                     const bool ok = row0_m + lrow < Mrows;
                     const int64_t k = (int64_t)(row0_m + lrow) * e.ldw + row0_n + lcol;
                     const float gr = acc[m][r2];
+                    if constexpr (!UPDATE) {
+                        if (ok && gradp) gradp[k] = gr;
+                        if (e.grad_lo) *reinterpret_cast<bf16_t*>(R0 + lrow * DW_P0 + lcol * 2) = f2bf_hw(gr);
+                        continue;
+                    }
                     const float gg = gr * gscale, p0 = wv[m][r2];
                     float pn;
                     if constexpr (OPT == DAE_OPT_SGD) pn = p0 - lr * gg;
@@ -927,10 +1044,12 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_dw_pc(GemmParams p, OptEpi
                     pv[q] = pn;
                     *reinterpret_cast<bf16_t*>(R0 + lrow * DW_P0 + lcol * 2) = f2bf_hw(pn);
                 }
-                uint2 v;
-                v.x = f2bf_pack_hw(pv[0], pv[1]);
-                v.y = f2bf_pack_hw(pv[2], pv[3]);
-                *reinterpret_cast<uint2*>(R1 + lcol * DW_P1 + (m * 32 + 8 * r4 + 4 * g) * 2) = v;
+                if constexpr (UPDATE) {
+                    uint2 v;
+                    v.x = f2bf_pack_hw(pv[0], pv[1]);
+                    v.y = f2bf_pack_hw(pv[2], pv[3]);
+                    *reinterpret_cast<uint2*>(R1 + lcol * DW_P1 + (m * 32 + 8 * r4 + 4 * g) * 2) = v;
+                }
             }
         };
         block(std::integral_constant<int, 0>{});
@@ -939,30 +1058,33 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_dw_pc(GemmParams p, OptEpi
         block(std::integral_constant<int, 3>{});
         block(std::integral_constant<int, 4>{});
     }
-    if (wave8 >= 4) __builtin_amdgcn_s_barrier();                           // B1 (producers): the consumers have left the K loop
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                                           // B2: both staged tiles are complete
+    __builtin_amdgcn_s_barrier();                                           // B4: the staged tiles are complete
     asm volatile("" ::: "memory");
-    // ---- all 8 waves: coalesced 16-byte stores of the two shadow tiles ----
+    // ---- all 8 waves: coalesced 16-byte stores of the staged tiles ----
 #ifdef DAE_DW_PROBE
     if (DAE_DW_PROBE & 4) return;                                           // probe: no shadow stores
 #endif
     {
         const char* R0 = lds;
         const char* R1 = lds + DW_BM * DW_P0;
-        bf16_t* Wlo = reinterpret_cast<bf16_t*>(e.W_lo);
+        bf16_t* Wlo = reinterpret_cast<bf16_t*>(UPDATE ? e.W_lo : e.grad_lo);
         bf16_t* Wtlo = reinterpret_cast<bf16_t*>(e.Wt_lo);
-        for (int ch = tid; ch < DW_BM * 16; ch += PC_THREADS) {              // W_lo: 160 rows x 16 chunks
-            const int row = ch >> 4, c16 = ch & 15;
-            if (row0_m + row < Mrows)
-                *reinterpret_cast<i32x4*>(Wlo + (int64_t)(row0_m + row) * e.ldw + row0_n + c16 * 8) =
-                    *reinterpret_cast<const i32x4*>(R0 + row * DW_P0 + c16 * 16);
+        if (Wlo) {
+            for (int ch = tid; ch < DW_BM * 16; ch += PC_THREADS) {          // W_lo (or the bf16 gradient): 160 rows x 16 chunks
+                const int row = ch >> 4, c16 = ch & 15;
+                if (row0_m + row < Mrows)
+                    *reinterpret_cast<i32x4*>(Wlo + (int64_t)(row0_m + row) * e.ldw + row0_n + c16 * 8) =
+                        *reinterpret_cast<const i32x4*>(R0 + row * DW_P0 + c16 * 16);
+            }
         }
-        for (int ch = tid; ch < 128 * 20; ch += PC_THREADS) {                // Wt_lo: 128 rows x 20 chunks of 8 features
-            const int row = ch / 20, c16 = ch % 20;
-            if (row0_m + c16 * 8 < Mrows)
-                *reinterpret_cast<i32x4*>(Wtlo + (int64_t)(row0_n + row) * e.ldwt + row0_m + c16 * 8) =
-                    *reinterpret_cast<const i32x4*>(R1 + row * DW_P1 + c16 * 16);
+        if constexpr (UPDATE) {
+            for (int ch = tid; ch < 128 * 20; ch += PC_THREADS) {            // Wt_lo: 128 rows x 20 chunks of 8 features
+                const int row = ch / 20, c16 = ch % 20;
+                if (row0_m + c16 * 8 < Mrows)
+                    *reinterpret_cast<i32x4*>(Wtlo + (int64_t)(row0_n + row) * e.ldwt + row0_m + c16 * 8) =
+                        *reinterpret_cast<const i32x4*>(R1 + row * DW_P1 + c16 * 16);
+            }
         }
     }
 }
@@ -1586,29 +1708,54 @@ int launch_gemm_f32out(int dtype, int M, int N, const void* A0, int64_t lda0, co
     return 0;
 }
 
+// can the 160 x 128 producer/consumer kernel with the sparse x~^T.delta1 phase run this shape?  (one round of the chip, list
+// capacity of a bit row, whole 64-deep K tiles)
+bool dw_sparse_fits(int M, int N, int Bp) {
+    if (gemm_init()) return false;
+    const int tiles_m = (M + DW_BM - 1) / DW_BM, tiles_n = N / BN, per = (tiles_m + 7) / 8;
+    return N % BN == 0 && Bp % 64 == 0 && Bp <= DWS_CAP && 8 * per * tiles_n <= g_cus && g_dw_pc != 0;
+}
+
 int launch_dw_opt(int M, int N, const void* A0, int64_t lda0, const void* Bt0, int64_t ldb0, int K0, const void* A1, int64_t lda1,
-                  const void* Bt1, int64_t ldb1, int K1, const OptEpi& e, hipStream_t st) {
+                  const void* Bt1, int64_t ldb1, int K1, const OptEpi& e, hipStream_t st, const DwSparseArgs* sa) {
     GemmParams p;
     if (int rc = fill_params(p, DAE_BF16, M, N, A0, lda0, Bt0, ldb0, K0, A1, lda1, Bt1, ldb1, K1, 1)) return rc;
     if (int rc = gemm_init()) return rc;
-    DAE_CHECK_ARG(e.W && e.W_lo && e.Wt_lo && e.ldw >= N && e.ldwt >= M && e.ldw % 8 == 0 && e.ldwt % 8 == 0, "dw_opt: bad parameter images");
-    DAE_CHECK_ARG(e.opt >= DAE_OPT_SGD && e.opt <= DAE_OPT_ADAM && (e.opt == DAE_OPT_SGD || e.s1) && (e.opt != DAE_OPT_ADAM || e.s2),
-                  "dw_opt: optimizer slots missing");
+    const bool grad_only = e.opt == DW_GRAD_ONLY;
+    if (grad_only) {
+        DAE_CHECK_ARG((e.grad || e.grad_lo) && e.ldw >= N && e.ldw % 8 == 0, "dw: gradient-only form needs grad or grad_lo");
+    } else {
+        DAE_CHECK_ARG(e.W && e.W_lo && e.Wt_lo && e.ldw >= N && e.ldwt >= M && e.ldw % 8 == 0 && e.ldwt % 8 == 0, "dw_opt: bad parameter images");
+        DAE_CHECK_ARG(e.opt >= DAE_OPT_SGD && e.opt <= DAE_OPT_ADAM && (e.opt == DAE_OPT_SGD || e.s1) && (e.opt != DAE_OPT_ADAM || e.s2),
+                      "dw_opt: optimizer slots missing");
+    }
     {   // 160 x 128 tiles, 8-wave producer/consumer: one workgroup per CU in a single round when the tile count fits the chip
         const int tiles_m = (M + DW_BM - 1) / DW_BM, tiles_n = N / BN;
         const int per = (tiles_m + 7) / 8;
-        if (g_dw_pc && K0 % 64 == 0 && K1 % 64 == 0 && 8 * per * tiles_n <= g_cus && (g_dw_pc == 2 || 8 * per * tiles_n > (3 * g_cus) / 4)) {
-            typedef void (*dwpc_fn)(GemmParams, OptEpi, int);
-            static const dwpc_fn pcs[4] = {gemm_dw_pc<DAE_OPT_SGD>, gemm_dw_pc<DAE_OPT_ADAGRAD>, gemm_dw_pc<DAE_OPT_MOMENTUM>, gemm_dw_pc<DAE_OPT_ADAM>};
+        const bool fits = g_dw_pc && K0 % 64 == 0 && K1 % 64 == 0 && 8 * per * tiles_n <= g_cus;
+        DAE_CHECK_ARG(!sa || (fits && K1 == 0 && K0 <= DWS_CAP && sa->xtb && sa->d1 && sa->ldxt >= K0 / 32 && sa->ldd1 >= N),
+                      "dw: the sparse x~^T.delta1 form does not fit this shape (M=%d N=%d Bp=%d)", M, N, K0);
+        DAE_CHECK_ARG(!grad_only || fits, "dw: the gradient-only form runs on the 160 x 128 kernel only (M=%d N=%d)", M, N);
+        if (fits && (sa || grad_only || g_dw_pc == 2 || 8 * per * tiles_n > (3 * g_cus) / 4)) {
+            typedef void (*dwpc_fn)(GemmParams, OptEpi, int, DwSparse);
+            static const dwpc_fn pcs[2][5] = {
+                {gemm_dw_pc<DAE_OPT_SGD, false>, gemm_dw_pc<DAE_OPT_ADAGRAD, false>, gemm_dw_pc<DAE_OPT_MOMENTUM, false>, gemm_dw_pc<DAE_OPT_ADAM, false>,
+                 gemm_dw_pc<DW_GRAD_ONLY, false>},
+                {gemm_dw_pc<DAE_OPT_SGD, true>, gemm_dw_pc<DAE_OPT_ADAGRAD, true>, gemm_dw_pc<DAE_OPT_MOMENTUM, true>, gemm_dw_pc<DAE_OPT_ADAM, true>,
+                 gemm_dw_pc<DW_GRAD_ONLY, true>}};
             static int pc_rc = [] {
                 int rc = 0;
-                for (dwpc_fn f : pcs) rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS);
+                for (int v = 0; v < 2; ++v)
+                    for (dwpc_fn f : pcs[v])
+                        rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 return rc;
             }();
             DAE_CHECK_ARG(pc_rc == 0, "dw_pc: hipFuncSetAttribute failed");
             GemmParams q = p;
             q.tiles_m = tiles_m; q.tiles_n = tiles_n;
-            hipLaunchKernelGGL(pcs[e.opt], dim3(8 * per * tiles_n), dim3(PC_THREADS), DW_LDS, st, q, e, M);
+            DwSparse sp; memset(&sp, 0, sizeof(sp));
+            if (sa) { sp.xtb = sa->xtb; sp.ldxt = sa->ldxt; sp.d1 = (const bf16_t*)sa->d1; sp.ldd1 = sa->ldd1; sp.nwords = K0 / 32; sp.scale = sa->scale; }
+            hipLaunchKernelGGL(pcs[sa ? 1 : 0][e.opt], dim3(8 * per * tiles_n), dim3(PC_THREADS), sa ? DW_LDS_SPARSE : DW_LDS, st, q, e, M, sp);
             DAE_CHECK_LAUNCH();
             return 0;
         }

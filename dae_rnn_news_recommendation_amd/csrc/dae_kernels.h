@@ -61,8 +61,12 @@ struct EncCsrLaunch {
     float* h_f32; void* h_lo; int64_t ldh; void* h_t; int64_t ldht; void* hcat_a; void* hcat_b;
     uint32_t* x_bits; int64_t ldxb; void* xct; int64_t ldt; float* rowsq;
     const LabelJob* label_job;
+    uint32_t* xtb; int64_t ldxt;   // x~^T as a bit image [Fp x ldxt words] (binary data; pre-zeroed) instead of the dense xct
+    int w_f32;                     // bf16 activations only: W points at the fp32 MASTER weights [Fp x ldw] (h is then fp32-accurate)
+    int w32_cols;                  // w_f32: 64 (default: one 2.6 MB slice per XCD L2) or 128 columns per workgroup
 };
 int launch_encode_csr(const EncCsrLaunch& q, hipStream_t st);
+size_t encode_csr_lds_bytes(int dtype, int w_f32, int w32_cols, int64_t ldxb);
 
 // ---- argument packs of the step-tail kernel (bias gradients + statistics + x~^T un-scatter in one launch) ----
 struct BiasArgs {
@@ -76,7 +80,13 @@ struct StatsArgs {
 };
 struct ClearArgs {            // CSR rows whose entries were scattered into x~^T [Fp x ldt] this step
     const int64_t* indptr; const int32_t* indices; const int32_t* row_idx; int B, F; void* xct; int64_t ldt; int es;
+    uint32_t* xtb; int64_t ldxt;   // the bit image of x~^T instead of the dense one (xct == NULL): clears the word holding bit (i, col)
 };
+// K8 (middle), see dae_dh_finish; delta1_lo: optional ROW-MAJOR delta1 [Bp x ldh] in `dtype` (operand of the sparse x~^T.delta1)
+int launch_dh_finish(const float* slabs, int splits, int64_t slab_stride, int64_t ld_slab, const float* dh_extra, const float* h_f32,
+                     int64_t ldh, const float* bh, int B, int H, int enc_act, int dtype, void* delta1_t, int64_t ldt, float* colsum_part,
+                     float* delta1_f32, void* delta1_lo, hipStream_t st);
+int launch_cast_bf16(const float* src, void* dst_bf16, int64_t n, hipStream_t st);
 int launch_step_tail(const BiasArgs& ba, const StatsArgs* sa, const ClearArgs* ca, hipStream_t st);
 // batch_all miner with an optional dispatch order of the anchors (dae_triplet.hip)
 int launch_batch_all(const float* D_slabs, int d_splits, int64_t slab_stride, int64_t ldd, const int32_t* labels, int B, int Bp, int a0,
@@ -90,11 +100,21 @@ struct OptEpi {
     float *s1, *s2;           // optimizer slots (same layout as W), NULL when unused by `opt`
     void *W_lo, *Wt_lo;       // bf16 shadows [Fp x ldw] and [Hp x ldwt]
     int64_t ldw, ldwt;
-    int opt;
+    int opt;                  // DAE_OPT_* or DW_OPT_GRAD_ONLY (gradient to memory, no update: `grad` fp32 and / or `grad_lo` bf16)
     float lr, mom, gscale;
+    void* grad_lo;            // DW_OPT_GRAD_ONLY: bf16 gradient image [Fp x ldw] (the reduce-scatter operand of data parallel) or NULL
 };
+enum { DW_OPT_GRAD_ONLY = 4 };
+// sparse half of the tied-weight gradient, x~^T.delta1 summed from the kept entries (binary CSR input; see gemm_dw_pc)
+struct DwSparseArgs {
+    const uint32_t* xtb; int64_t ldxt;   // x~^T bit image [Fp x ldxt words]: bit i of row f <=> entry (i, f) of the batch kept
+    const void* d1; int64_t ldd1;        // delta1 [Bp x ldd1] bf16, row-major
+    float scale;                         // value of a kept entry
+};
+bool dw_sparse_fits(int M, int N, int Bp);
+// sa != NULL: A0/Bt0 = delta2^T / h^T only (K1 = 0), the x~^T.delta1 half comes from `sa`
 int launch_dw_opt(int M, int N, const void* A0, int64_t lda0, const void* Bt0, int64_t ldb0, int K0, const void* A1, int64_t lda1,
-                  const void* Bt1, int64_t ldb1, int K1, const OptEpi& e, hipStream_t st);
+                  const void* Bt1, int64_t ldb1, int K1, const OptEpi& e, hipStream_t st, const DwSparseArgs* sa = nullptr);
 void set_use_glds(int nst);
 int launch_gemm_trace(int dtype, int M, int N, const void* A0, int64_t lda0, const void* Bt0, int64_t ldb0, int K0, const void* A1,
                       int64_t lda1, const void* Bt1, int64_t ldb1, int K1, float* C, int64_t ldc, int splits, int64_t slab_stride,

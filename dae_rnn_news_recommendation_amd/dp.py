@@ -133,6 +133,9 @@ class ShardedExchange:
         assert eng.dp_world == self.world, "create the Engine with dp_world = world size (%d != %d)" % (eng.dp_world, self.world)
         assert grad_dtype in ("fp32", "bf16")
         self.grad_dtype = grad_dtype
+        # only the bf16 shadow W_lo is all-gathered: the fp32 masters of the rows another rank owns are stale here, so the sparse
+        # encode must read W_lo (single-GPU bf16 steps read the fp32 master, option encode_w32)
+        eng.set_option("encode_w32", 0)
         c, Hp = eng.chunk_rows, eng.Hp
         self.f0 = min(eng.Fp, self.rank * c)
         self.f1 = min(eng.Fp, (self.rank + 1) * c)
@@ -161,7 +164,9 @@ class ShardedExchange:
         if self.grad_dtype == "fp32":
             dist.reduce_scatter_tensor(self.rs_out, gw, op=dist.ReduceOp.SUM)
         else:
-            dist.reduce_scatter_tensor(self.rs_out, gw.to(torch.bfloat16), op=dist.ReduceOp.SUM)
+            # bf16 exchange: the dW kernel's epilogue wrote the gradient as bf16 (Engine(grad_lo=True)); otherwise cast here
+            src = eng.grad_lo.view(-1) if getattr(eng, "grad_lo", None) is not None else gw.to(torch.bfloat16)
+            dist.reduce_scatter_tensor(self.rs_out, src, op=dist.ReduceOp.SUM)
             self.rs_f32.copy_(self.rs_out)
         dist.all_reduce(bias, op=dist.ReduceOp.SUM)
         if self._ev:
@@ -197,6 +202,23 @@ class ShardedExchange:
         dist.all_gather_into_tensor(full.view(-1), mine.view(-1))
         eng.W.copy_(full[:eng.Fp])
 
+    def gather_slots(self):
+        """Full optimizer slots on every rank.  The sharded optimizer updates the W rows of s1 / s2 (momentum, Adagrad, Adam
+        state) only where the row chunk is owned, so a checkpoint written from one rank's buffers would pair current weights with
+        initial slots for (world-1)/world of W.  The bias slots are updated identically on every rank."""
+        torch, dist, eng = self.torch, self.dist, self.eng
+        c, Hp, n = eng.chunk_rows, eng.Hp, eng.Fp * eng.Hp
+        for t in (eng.s1, eng.s2):
+            if t is None:
+                continue
+            part = t[:n].view(eng.Fp, Hp)
+            mine = torch.zeros((c, Hp), dtype=torch.float32, device=eng.device)
+            if self.f1 > self.f0:
+                mine[:self.f1 - self.f0] = part[self.f0:self.f1]
+            full = torch.empty((eng.rows_alloc, Hp), dtype=torch.float32, device=eng.device)
+            dist.all_gather_into_tensor(full.view(-1), mine.view(-1))
+            part.copy_(full[:eng.Fp])
+
 
 class GlobalMiner:
     """Global-batch triplet mining under data parallel (SURVEY 8e mode i): the reference objective at the GLOBAL batch size.
@@ -225,6 +247,12 @@ class GlobalMiner:
         self.per_max = -(-int(max_global_batch) // self.world)
         self.Mp = L.pad(self.per_max)
         self.Gp = L.pad(self.per_max * self.world)
+        # the miners hold one D row of the GLOBAL batch per workgroup in LDS: dae_triplet_batch_all_rows up to 4096 padded columns,
+        # dae_triplet_batch_hard_rows up to 16384 -- fail here, not at the first step of the fit
+        limit = 4096 if strategy == "batch_all" else 16384
+        if self.Gp > limit:
+            raise ValueError("dp_mining='global' with %s supports a padded global batch of at most %d rows (got %d = %d ranks x %d); "
+                             "use dp_mining='local' or a smaller batch" % (strategy, limit, self.Gp, self.world, self.per_max))
         dev, Hp = eng.device, eng.Hp
         z = lambda *shape, dtype=torch.float32: torch.zeros(shape, dtype=dtype, device=dev)
         self.h_blocks = z(self.world * self.per_max, Hp)

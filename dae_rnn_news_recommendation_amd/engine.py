@@ -20,7 +20,8 @@ from . import _lib as L
 class Engine:
     def __init__(self, n_features, n_components, max_batch, *, dtype="bf16", enc_act="sigmoid", dec_act="sigmoid",
                  loss_func="cross_entropy", opt="gradient_descent", learning_rate=0.1, momentum=0.5, alpha=1.0,
-                 triplet="none", pos_triplets_only=False, device=None, encode_splits=0, dh_splits=0, gram_splits=0, dp_world=1):
+                 triplet="none", pos_triplets_only=False, device=None, encode_splits=0, dh_splits=0, gram_splits=0, dp_world=1,
+                 grad_lo=False):
         if not torch.cuda.is_available():
             raise RuntimeError("dae_rnn_news_recommendation_amd.Engine needs a ROCm GPU (MI355X): no CPU fallback exists")
         self.lib = L.load()
@@ -40,7 +41,9 @@ class Engine:
         dev = self.device
         n_flat = self.Fp * self.Hp + self.Hp + self.Fp
         # data parallel with a sharded optimizer (dp.ShardedExchange): W is cut into `dp_world` equal chunks of whole 64-row
-        # blocks; the gradient buffer and W_lo are over-allocated so that every chunk exists (rows >= Fp stay zero)
+        # blocks; the gradient buffer and W_lo are over-allocated so that every chunk exists.  NOTE: the flat gradient is
+        # [dW (Fp*Hp) | dbh | dbv], so "rows" >= Fp of that over-allocated view alias the bias gradients: the exchange may sum them
+        # as if they were W rows, and dae_plan_apply_rows clamps its update to rows < Fp
         self.dp_world = int(dp_world)
         self.chunk_rows = -(-self.Fp // (64 * self.dp_world)) * 64
         self.rows_alloc = self.chunk_rows * self.dp_world
@@ -49,6 +52,11 @@ class Engine:
         self.bh = torch.zeros(self.Hp, dtype=torch.float32, device=dev)
         self.bv = torch.zeros(self.Fp, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(max(n_flat, self.rows_alloc * self.Hp), dtype=torch.float32, device=dev)
+        # data parallel with a bf16 exchange (dp_grad_dtype='bf16'): the dW kernel writes the W gradient as bf16 straight into
+        # this image (dae_buffers.grad_lo) in phase 1 / 5 steps; the bias gradients stay in `grad`
+        self.grad_lo = None
+        if grad_lo and self.dtype == L.BF16:
+            self.grad_lo = torch.zeros((self.rows_alloc, self.Hp), dtype=torch.bfloat16, device=dev)
         self.s1 = self.s2 = None
         if opt == "ada_grad":
             self.s1 = torch.full((n_flat,), 0.1, dtype=torch.float32, device=dev)   # TF initial_accumulator_value
@@ -118,6 +126,7 @@ class Engine:
         b.opt_s2 = None if self.s2 is None else self.s2.data_ptr()
         b.W_lo = self.W_lo.data_ptr(); b.Wt_lo = self.Wt_lo.data_ptr()
         b.workspace = self.workspace.data_ptr(); b.workspace_bytes = self.workspace.numel()
+        b.grad_lo = None if self.grad_lo is None else self.grad_lo.data_ptr()
         L.check(self.lib.dae_plan_bind(self.plan, C.byref(b)), "dae_plan_bind")
         self._bound = True
 
@@ -138,14 +147,20 @@ class Engine:
         return (self.W[:self.F, :self.H].cpu().numpy(), self.bh[:self.H].cpu().numpy(), self.bv[:self.F].cpu().numpy())
 
     def grads(self):
-        """(dW, dbh, dbv) views of the flat gradient buffer, unpadded copies on the host."""
+        """(dW, dbh, dbv) views of the flat gradient buffer, unpadded copies on the host (the W part from the bf16 exchange
+        image when the engine was created with grad_lo=True: phase 1 / 5 steps write it there)."""
         n = self.Fp * self.Hp
-        dW = self.grad[:n].view(self.Fp, self.Hp)[:self.F, :self.H].cpu().numpy()
+        if self.grad_lo is not None:
+            dW = self.grad_lo[:self.F, :self.H].float().cpu().numpy()
+        else:
+            dW = self.grad[:n].view(self.Fp, self.Hp)[:self.F, :self.H].cpu().numpy()
         dbh = self.grad[n:n + self.Hp][:self.H].cpu().numpy()
         dbv = self.grad[n + self.Hp:n + self.Hp + self.Fp][:self.F].cpu().numpy()
         return dW, dbh, dbv
 
     def optimizer_state(self):
+        """Optimizer slots in the flat layout [W | bh | bv].  Under dp.ShardedExchange only the W rows this rank owns are current:
+        call ShardedExchange.gather_slots() first (fit() does, before it saves)."""
         return {"s1": self.s1, "s2": self.s2, "adam_t": self.adam_t}
 
     # ------------------------------------------------------------------ steps

@@ -29,7 +29,7 @@ extern "C" {
 #endif
 
 #define DAE_PAD 128
-#define DAE_ABI_VERSION 2   /* 2: dae_step.c_row_idx, plan options replace environment switches, phases 4/5, sharded apply */
+#define DAE_ABI_VERSION 3   /* 3: dae_buffers.grad_lo, options dw_sparse / encode_w32; 2: dae_step.c_row_idx, plan options, phases 4/5, sharded apply */
 
 enum { DAE_BF16 = 0, DAE_F32 = 1 };
 enum { DAE_ACT_NONE = 0, DAE_ACT_SIGMOID = 1, DAE_ACT_TANH = 2 };
@@ -242,7 +242,8 @@ int dae_triplet_batch_hard(const float* D_slabs, int32_t d_splits, int64_t slab_
                            const int32_t* labels, int32_t B, int32_t Bp,
                            float* loss_part, uint32_t* cnt_part, int32_t* dw, float* G, void* stream);
 
-/* batch_hard for the anchors [a0, a0 + n_anchors) only (see dae_triplet_batch_all_rows); dw[B] accumulates over all launches. */
+/* batch_hard for the anchors [a0, a0 + n_anchors) only (see dae_triplet_batch_all_rows).  dw[B] is zeroed by EVERY call and then
+ * receives the contributions of this call's anchors: callers that split a batch over several calls / ranks sum the dw vectors. */
 int dae_triplet_batch_hard_rows(const float* D_slabs, int32_t d_splits, int64_t slab_stride, int64_t ldd,
                                 const int32_t* labels, int32_t B, int32_t Bp, int32_t a0, int32_t n_anchors,
                                 float* loss_part, uint32_t* cnt_part, int32_t* dw, float* G, void* stream);
@@ -348,6 +349,10 @@ typedef struct {
     /* low-precision shadows W_lo [Fp x Hp], Wt_lo [Hp x Fp] in cfg.dtype */
     void* W_lo; void* Wt_lo;
     void* workspace; uint64_t workspace_bytes;
+    /* optional (may be NULL): bf16 image [Fp x Hp] of the W gradient.  When set, phase 1 / 5 steps in bf16 mode write the W part of the
+     * gradient THERE instead of into `grad` (the bias parts stay in `grad`): the operand of a bf16 reduce-scatter, produced by the dW
+     * kernel's epilogue instead of a separate cast pass. */
+    void* grad_lo;
 } dae_buffers;
 
 typedef struct {
@@ -413,7 +418,11 @@ int      dae_plan_sync_shadows(dae_plan* p, void* stream);
  * GEMM; on by default for binary CSR + bf16), "x_bits" (clean rows as a bit image into the decode epilogue), "fused_opt" (optimizer in the
  * dW GEMM's epilogue), "tail" (bias gradients + statistics + x~^T un-scatter in one launch), "label_with_encode", "ce_literal"
  * (cross_entropy always by the reference-literal formula), "overlap" (miner chain on a side stream), "gram_fp32" (exact-fp32 Gram
- * matrix in bf16 mode; before dae_plan_bind only).  Unknown names are an error. */
+ * matrix in bf16 mode; before dae_plan_bind only), "dw_sparse" (binary CSR + bf16: x~^T as a bit image and the x~^T.delta1 half of dW
+ * summed from the kept entries inside the dW kernel -- default on; 0 = dense x~^T image, K = 2 Bp GEMM), "encode_w32" (bf16 mode: the
+ * sparse encode reads the fp32 master weights, so h -- and with the split-bf16 Gram matrix the triplet leg -- is fp32-accurate; default
+ * on; a sharded-optimizer exchange must turn it off because only W_lo is current on every rank), "encode_w32_cols" (64 | 128 columns
+ * per workgroup of that kernel).  Unknown names are an error. */
 int      dae_plan_set_option(dae_plan* p, const char* name, int32_t value);
 int      dae_train_step(dae_plan* p, const dae_step* step, void* stream);
 int      dae_plan_apply(dae_plan* p, int32_t adam_t, float grad_scale, void* stream);

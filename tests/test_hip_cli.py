@@ -173,7 +173,8 @@ def test_explicit_triplet_device_salt_and_pepper_runs(tmp_path):
 
 
 def test_bench_two_ranks_on_one_gpu(tmp_path):
-    """The N > 1 path of bench.py (phase-1 step -> all-reduce of the flat gradient -> dae_plan_apply) with two processes
+    """The N > 1 path of bench.py (phase-1 step -> reduce-scatter of the W gradient -> sharded optimizer -> all-gather of the
+    low-precision shadow, dp.ShardedExchange) with two processes
     sharing this box's single GPU (gloo collectives; RCCL needs one GPU per rank): launch line exactly as the driver's,
     one JSON line from rank 0, n_gpus = 2, a finite loss that went down."""
     import json

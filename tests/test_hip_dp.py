@@ -44,6 +44,39 @@ def _fit(tmp, strategy, opt, dp_flag, grad_dtype="fp32", seed=11, mining="local"
     return stats, model.engine.get_params()
 
 
+def _fit_save_restore(tmp, opt, dp_flag, precision="fp32"):
+    """fit 2 epochs (checkpoint written by rank 0) -> a NEW estimator restores it and trains 2 more epochs.  Returns the checkpoint's
+    optimizer slots and the final parameters."""
+    from dae_rnn_news_recommendation_amd.autoencoder import DenoisingAutoencoder
+    m, lab, W0 = _data()
+    kw = dict(model_name="ck", main_dir="ck", compress_factor=10, enc_act_func="sigmoid", dec_act_func="sigmoid", loss_func="cross_entropy",
+              num_epochs=2, batch_size=37, opt=opt, learning_rate=0.05, momentum=0.5, corr_type="masking", corr_frac=0.3, verbose=0,
+              verbose_step=1, seed=11, alpha=1, triplet_strategy="none", precision=precision, rng="numpy", data_parallel=dp_flag,
+              results_root=tmp + "/")
+    a = DenoisingAutoencoder(init_weights=W0, **kw)
+    a.fit(m)
+    if dp_flag:
+        from dae_rnn_news_recommendation_amd import dp
+        dp.barrier()
+    z = np.load(a.model_path + ".npz")
+    slots = {k: z[k].copy() for k in z.files if k.startswith("opt-")}
+    b = DenoisingAutoencoder(init_weights=W0, **kw)
+    b.fit(m, restore_previous_model=True)
+    return slots, b.engine.get_params()
+
+
+def _worker_ck(rank, world, port, tmp, opt, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK="0")
+    import torch
+    from dae_rnn_news_recommendation_amd import dp
+    torch.cuda.set_device(0)
+    dp.init_from_env("gloo")
+    out[rank] = _fit_save_restore(tmp, opt, True)
+    dp.barrier()
+    torch.distributed.destroy_process_group()
+
+
 def _worker(rank, world, port, tmp, strategy, opt, grad_dtype, seed, mining, out):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK="0")
@@ -131,3 +164,32 @@ def test_fit_two_ranks_global_mining_equals_one_rank(tmp_path, strategy):
         for a, b in zip(p, ref_p):
             assert _rel(a, b) < 5e-5
     assert np.array_equal(out[0][1][0], out[1][1][0])
+
+
+@pytest.mark.parametrize("opt", ["adam", "momentum"])
+def test_dp_checkpoint_carries_every_ranks_optimizer_slots(tmp_path, opt):
+    """the sharded optimizer updates the slots of W only on the owner of a row chunk; fit() gathers them before rank 0
+    saves, so save -> restore -> continue under data parallel equals the same sequence on one rank (slots and parameters)."""
+    import torch.multiprocessing as mp
+    one = str(tmp_path / "one"); two = str(tmp_path / "two")
+    os.makedirs(one); os.makedirs(two)
+    ref_slots, ref_p = _fit_save_restore(one, opt, False)
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager(); out = mgr.dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_ck, args=(r, 2, port, two, opt, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0, "rank exited with %r" % (p.exitcode,)
+    slots, params = out[0]
+    assert set(slots) == set(ref_slots) and len(slots) >= 1
+    tol = 5e-3 if opt == "adam" else 2e-5
+    for k in slots:
+        n = ref_slots[k].size
+        assert _rel(slots[k], ref_slots[k]) < tol, (k, _rel(slots[k], ref_slots[k]))
+        # the rows of the OTHER rank's chunk are not the initial value any more
+        assert np.count_nonzero(slots[k]) > 0.5 * np.count_nonzero(ref_slots[k])
+    for a, b in zip(params, ref_p):
+        assert _rel(a, b) < tol
