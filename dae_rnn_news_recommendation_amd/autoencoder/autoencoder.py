@@ -14,8 +14,9 @@ New (keyword-only, all optional):
               'philox' -- counter-based masking generated on the device (statistically equivalent,
                           no host RNG in the epoch loop)
   init_weights  (W0[, bh0, bv0]) injected instead of the Xavier draw (tf.random_uniform is not reproducible)
-  data_parallel  True -> shard every mini-batch over torch.distributed ranks (RCCL all-reduce of the flat
-                 gradient), see dae_rnn_news_recommendation_amd/dp.py
+  data_parallel  True -> shard every mini-batch over torch.distributed ranks (reduce-scatter of the W gradient, sharded
+                 optimizer, all-gather of the low-precision shadow), see dae_rnn_news_recommendation_amd/dp.py
+  plan_options   {name: value} handed to dae_plan_set_option (implementation choices of the same arithmetic; A/B runs)
 """
 from __future__ import annotations
 
@@ -96,7 +97,7 @@ class DenoisingAutoencoder(object):
                  xavier_init=1, opt='gradient_descent', learning_rate=0.01, momentum=0.5, corr_type='none',
                  corr_frac=0., verbose=True, verbose_step=5, seed=-1, alpha=1, triplet_strategy='batch_all',
                  *, precision='bf16', rng='numpy', init_weights=None, device=None, data_parallel=False,
-                 dp_grad_dtype='fp32', dp_mining='local', results_root='results/'):
+                 dp_grad_dtype='fp32', dp_mining='local', results_root='results/', plan_options=None):
         self.algo_name = algo_name
         self.model_name = model_name
         self.compress_factor = compress_factor
@@ -126,6 +127,7 @@ class DenoisingAutoencoder(object):
         self.dp_mining = dp_mining               # data parallel + triplet strategy: 'local' (each rank mines its shard) | 'global'
         assert self.dp_mining in ('local', 'global')
         self.results_root = results_root
+        self.plan_options = dict(plan_options or {})   # code-path choices of the step plan (dae_plan_set_option): A/B runs, tests
 
         assert type(self.verbose_step) == int                      # reference :68
         assert self.verbose >= 0
@@ -191,6 +193,8 @@ class DenoisingAutoencoder(object):
                              momentum=self.momentum, alpha=float(self.alpha), triplet=self._strategy_key(),
                              device=self.device, dp_world=dp_world,
                              grad_lo=(dp_world > 1 and self.dp_grad_dtype == 'bf16'))
+        for name, value in self.plan_options.items():
+            self.engine.set_option(name, value)
         return self.engine
 
     def _initial_parameters(self, n_features):

@@ -107,7 +107,7 @@ struct dae_plan {
     char *x, *xc, *xct, *h_lo, *h_t, *Gs, *delta2, *delta2_t, *delta1_t, *delta1_lo, *hcat_a, *hcat_b;
     uint32_t* xtb;                   // x~^T as a bit image [Fp x Bpm/32] (binary CSR + bf16: operand of the sparse half of the dW kernel)
     bool xtb_clean;                  // the bit image holds only zeros (every step clears what it set; see step_tail_kernel)
-    bool dw_sparse_ok;               // option "dw_sparse" = 0: dense x~^T image and a K = 2 Bp dW GEMM (A/B, equivalence tests)
+    bool dw_bits_ok;               // option "dw_bits" = 0: dense x~^T image and a K = 2 Bp dW GEMM (A/B, equivalence tests)
     bool enc_w32_ok;                 // option "encode_w32": bf16 mode encodes from the fp32 MASTER weights (h fp32-accurate); 0 = from W_lo
     int w32_cols;                    // option "encode_w32_cols": 64 (default) or 128 H columns per workgroup of that kernel
     bool gram_split;                 // Gram matrix as a 3-term split-bf16 MFMA GEMM (bf16 mode) instead of exact-fp32 MFMA
@@ -222,7 +222,7 @@ extern "C" int dae_plan_create(const dae_config* cfg, dae_plan** out) {
     p->ce_literal = false;
     p->xbits_ok = cfg->dtype == DAE_BF16;
     p->xct_clean = false; p->xtb_clean = false;
-    p->dw_sparse_ok = true;
+    p->dw_bits_ok = true;
     p->enc_w32_ok = cfg->dtype == DAE_BF16;
     p->w32_cols = 64;
     // binary CSR + bf16: x~ goes to the encode GEMM as a bit image whenever the 8-wave bit kernel can run the shape
@@ -253,7 +253,7 @@ extern "C" int dae_plan_set_option(dae_plan* p, const char* name, int32_t value)
     else if (!strcmp(name, "encode_bits")) p->bits_ok = on && p->cfg.dtype == DAE_BF16 && encode_bits_fits(p->Bpm, p->Hp, p->Fp, p->s_enc);
     else if (!strcmp(name, "x_bits")) p->xbits_ok = on && p->cfg.dtype == DAE_BF16;
     else if (!strcmp(name, "fused_opt")) p->fuse_opt_ok = on;
-    else if (!strcmp(name, "dw_sparse")) p->dw_sparse_ok = on;
+    else if (!strcmp(name, "dw_bits")) p->dw_bits_ok = on;
     else if (!strcmp(name, "encode_w32")) p->enc_w32_ok = on && p->cfg.dtype == DAE_BF16;
     else if (!strcmp(name, "encode_w32_cols")) { DAE_CHECK_ARG(value == 64 || value == 128, "plan_set_option: encode_w32_cols is 64 or 128"); p->w32_cols = value; }
     else if (!strcmp(name, "tail")) p->tail_ok = on;
@@ -426,17 +426,17 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     // phase 1 / 5 (data parallel) in bf16 mode: the same kernel in its gradient-only form when the shape fits it
     const bool apply_now = (s->phase == 0 || s->phase == 3);
     const bool fuse_opt = backward && apply_now && dt == DAE_BF16 && p->fuse_opt_ok;
-    // binary CSR + bf16 + the fused sparse encode: x~^T is a BIT image and the x~^T.delta1 half of dW is summed from the kept entries
-    // by the dW kernel (autoencoder.py:377,452); otherwise the dense x~^T image feeds a K = 2 Bp GEMM
+    // binary CSR + bf16 + the fused sparse encode: x~^T is a BIT image (1.1 MB) from which the dW kernel's producer waves build the
+    // A tiles of its x~^T.delta1 segment in LDS; otherwise the dense x~^T image (18 MB, scattered / un-scattered every step) is streamed
     const bool src_binary = s->c_indptr ? !s->c_values : (p->b.indptr && !p->b.values);
-    const bool dw_pc_grad = backward && !apply_now && dt == DAE_BF16 && p->fuse_opt_ok && dw_sparse_fits(Fp, Hp, Bp);
-    const bool dw_sparse = p->dw_sparse_ok && use_sparse && src_binary && backward && dt == DAE_BF16 && (fuse_opt || dw_pc_grad) &&
-                           dw_sparse_fits(Fp, Hp, Bp);
+    const bool dw_pc_grad = backward && !apply_now && dt == DAE_BF16 && p->fuse_opt_ok && dw_bits_fits(Fp, Hp, Bp);
+    const bool dw_bits = p->dw_bits_ok && use_sparse && src_binary && backward && dt == DAE_BF16 && (fuse_opt || dw_pc_grad) &&
+                           dw_bits_fits(Fp, Hp, Bp);
     if (!resume && backward && csr_in) {
-        if (dw_sparse) { if (!(tail && p->xtb_clean)) PROF(PS_MEMSET, memset_async(p->xtb, (size_t)Fp * (ldB / 32) * 4, st)); }
+        if (dw_bits) { if (!(tail && p->xtb_clean)) PROF(PS_MEMSET, memset_async(p->xtb, (size_t)Fp * (ldB / 32) * 4, st)); }
         else if (!(tail && p->xct_clean)) PROF(PS_MEMSET, memset_async(p->xct, (size_t)Fp * ldB * p->es, st));
     }
-    if (backward) { if (dw_sparse) p->xtb_clean = false; else p->xct_clean = false; }
+    if (backward) { if (dw_bits) p->xtb_clean = false; else p->xct_clean = false; }
     const int64_t slab = (int64_t)Bp * Hp;
     int enc_label_done = 0;
     bool labels_done = ext_mine;               // label statistics already produced by a workgroup of an earlier launch (or by the caller)
@@ -462,8 +462,8 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
         q.corr_frac = s->corr_frac; q.scale = s->scale;
         q.h_f32 = p->h_f32; q.h_lo = p->h_lo; q.ldh = Hp; q.h_t = p->h_t; q.ldht = ldB;
         q.hcat_a = p->gram_split ? p->hcat_a : nullptr; q.hcat_b = p->gram_split ? p->hcat_b : nullptr;
-        q.x_bits = own_clean ? p->x_bits : nullptr; q.ldxb = Fp / 32; q.xct = (backward && !dw_sparse) ? p->xct : nullptr; q.ldt = ldB;
-        q.xtb = (backward && dw_sparse) ? p->xtb : nullptr; q.ldxt = ldB / 32;
+        q.x_bits = own_clean ? p->x_bits : nullptr; q.ldxb = Fp / 32; q.xct = (backward && !dw_bits) ? p->xct : nullptr; q.ldt = ldB;
+        q.xtb = (backward && dw_bits) ? p->xtb : nullptr; q.ldxt = ldB / 32;
         q.rowsq = own_clean ? rowsq : nullptr;
         q.label_job = label_with_encode ? &lj : nullptr;
         PROF(PS_ENC_GEMM, launch_encode_csr(q, st));
@@ -588,7 +588,7 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     PROF(PS_DH_GEMM, launch_gemm_f32out(dt, Bp, Hp, p->delta2, Fp, p->b.Wt_lo, Fp, Fp, mined ? p->Gs : nullptr, Bp, mined ? p->h_t : nullptr, ldB,
                           mined ? Bp : 0, p->slabs, Hp, p->s_dh, slab, st, GEMM_ROLE_DH));
     PROF(PS_DH_FIN, launch_dh_finish(p->slabs, p->s_dh, slab, Hp, (explicit3 || ext_mine) ? p->dh_extra : nullptr, p->h_f32, Hp, p->b.bh, B, H, c.enc_act, dt,
-                     dw_sparse ? nullptr : p->delta1_t, ldB, p->colsum_part, nullptr, dw_sparse ? p->delta1_lo : nullptr, st));
+                     p->delta1_t, ldB, p->colsum_part, nullptr, nullptr, st));
     // 11. dW = x~^T delta1 + delta2^T h                                      (K8, tied weights)
     if (fuse_opt || dw_pc_grad) {
         OptEpi oe;
@@ -602,9 +602,9 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
             oe.opt = DW_OPT_GRAD_ONLY; oe.grad = p->b.grad_lo ? nullptr : p->b.grad; oe.grad_lo = p->b.grad_lo;
             oe.ldw = Hp;
         }
-        if (dw_sparse) {
-            DwSparseArgs sa{p->xtb, ldB / 32, p->delta1_lo, Hp, s->scale};
-            PROF(PS_DW_GEMM, launch_dw_opt(Fp, Hp, p->delta2_t, ldB, p->h_t, ldB, Bp, nullptr, 0, nullptr, 0, 0, oe, st, &sa));
+        if (dw_bits) {
+            DwBitsArgs xa{p->xtb, ldB / 32, s->scale};
+            PROF(PS_DW_GEMM, launch_dw_opt(Fp, Hp, nullptr, ldB, p->delta1_t, ldB, Bp, p->delta2_t, ldB, p->h_t, ldB, Bp, oe, st, &xa));
         } else {
             PROF(PS_DW_GEMM, launch_dw_opt(Fp, Hp, p->xct, ldB, p->delta1_t, ldB, Bp, p->delta2_t, ldB, p->h_t, ldB, Bp, oe, st));
         }
@@ -622,10 +622,10 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
                     fuse_bias ? 1 : 0, c.opt, plan_lr(p, s->adam_t), c.momentum, s->grad_scale, p->b.bv,
                     p->b.opt_s1 ? p->b.opt_s1 + boff : nullptr, p->b.opt_s2 ? p->b.opt_s2 + boff : nullptr};
         ClearArgs ca{s->c_indptr ? s->c_indptr : p->b.indptr, s->c_indptr ? s->c_indices : p->b.indices,
-                     (s->c_indptr && s->c_row_idx) ? s->c_row_idx : s->row_idx, B, F, dw_sparse ? nullptr : p->xct, ldB, p->es,
-                     dw_sparse ? p->xtb : nullptr, ldB / 32};
+                     (s->c_indptr && s->c_row_idx) ? s->c_row_idx : s->row_idx, B, F, dw_bits ? nullptr : p->xct, ldB, p->es,
+                     dw_bits ? p->xtb : nullptr, ldB / 32};
         PROF(PS_BIAS, launch_step_tail(ba, &sa, csr_in ? &ca : nullptr, st));
-        if (csr_in) { if (dw_sparse) p->xtb_clean = true; else p->xct_clean = true; }
+        if (csr_in) { if (dw_bits) p->xtb_clean = true; else p->xct_clean = true; }
     } else {
         PROF(PS_BIAS, dae_bias_grads(p->dbv_part, 2 * Bp / 128, p->colsum_part, Bp / 32, p->b.bh, H, Hp, F, Fp, c.enc_act, g_bh, g_bh + Hp,
                                      fuse_bias ? 1 : 0, c.opt, plan_lr(p, s->adam_t), c.momentum, s->grad_scale, p->b.bv,

@@ -279,6 +279,7 @@ struct EncCsrArgs {
     uint32_t* x_bits; int64_t ldxb;             // clean bit image [Bp x ldxb] (binary data) or NULL
     void* xct; int64_t ldt;                     // x~^T [Fp x ldt] scatter target (pre-zeroed) or NULL
     uint32_t* xtb; int64_t ldxt;                // x~^T as a BIT image [Fp x ldxt words] (pre-zeroed; bit i of row f <=> entry (i, f) kept) or NULL
+    int xtl_off, Fp;                            // xtl_off > 0: LDS byte image [Fp] of the workgroup's 8 batch rows at that offset (else global atomics)
     float* rowsq;                               // [Bp] or NULL
     int n_slices;
     LabelJob job; int label_block;
@@ -350,10 +351,13 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void encode_csr_kernel(EncCsrArgs a
     const bool do_xbits = a.x_bits && slice == 0;
     const bool do_xct = (a.xct || a.xtb) && slice == 1 % a.n_slices;
     const bool do_rowsq = a.rowsq && slice == 2 % a.n_slices;
-    if (do_xbits) {
-        for (int k = tid; k < ENC_ROWS * (int)a.ldxb; k += ENC_THREADS) xb[k] = 0u;
-        __syncthreads();
-    }
+    // x~^T bits of this workgroup's 8 batch rows (i0 is a multiple of 8): ONE byte per feature, assembled in LDS (bit r of byte f =
+    // row i0 + r keeps feature f) and stored as bytes -- the workgroup owns byte i0 / 8 of every feature row, so no global atomics
+    uint32_t* xtl = reinterpret_cast<uint32_t*>(smem + a.xtl_off);
+    const bool xt_lds = do_xct && a.xtb && a.xtl_off > 0;
+    if (do_xbits) for (int k = tid; k < ENC_ROWS * (int)a.ldxb; k += ENC_THREADS) xb[k] = 0u;
+    if (xt_lds) for (int k = tid; k < a.Fp / 4; k += ENC_THREADS) xtl[k] = 0u;
+    if (do_xbits || xt_lds) __syncthreads();
     const char* Wb = reinterpret_cast<const char*>(a.W) + (int64_t)slice * COLS * sizeof(WT) + part * (CPL * sizeof(WT));
     const uint64_t ldw_b = (uint64_t)(a.ldw * (int64_t)sizeof(WT));
     T* xct = reinterpret_cast<T*>(a.xct);
@@ -408,7 +412,8 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void encode_csr_kernel(EncCsrArgs a
                 if (do_xbits && valid) atomicOr(&xb[r * a.ldxb + (col[u] >> 5)], 1u << (col[u] & 31));
                 if (do_xct && keep) {
                     // x~^T for the dW GEMM: a bit per kept entry (binary data; integer OR -> order-independent), or the dense scatter
-                    if (a.xtb) atomicOr(&a.xtb[(int64_t)col[u] * a.ldxt + (i >> 5)], 1u << (i & 31));
+                    if (xt_lds) atomicOr(&xtl[col[u] >> 2], 1u << (8 * (col[u] & 3) + r));
+                    else if (a.xtb) atomicOr(&a.xtb[(int64_t)col[u] * a.ldxt + (i >> 5)], 1u << (i & 31));
                     else xct[(int64_t)col[u] * a.ldt + i] = Elem<T>::from(w);
                 }
                 if (do_rowsq) sq += v * v;
@@ -515,6 +520,18 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void encode_csr_kernel(EncCsrArgs a
             a.x_bits[(int64_t)(i0 + rr) * a.ldxb + w] = xb[k];
         }
     }
+    if (xt_lds) {                                    // (the barriers above ordered every LDS atomic before these reads)
+        uint8_t* xt8 = reinterpret_cast<uint8_t*>(a.xtb) + (i0 >> 3);
+        const int64_t ld8 = a.ldxt * 4;
+        for (int k = tid; k < a.Fp / 4; k += ENC_THREADS) {
+            uint32_t w = xtl[k];
+            while (w) {
+                const int q = __builtin_ctz(w) >> 3;
+                xt8[(int64_t)(4 * k + q) * ld8] = (uint8_t)(w >> (8 * q));
+                w &= ~(0xffu << (8 * q));
+            }
+        }
+    }
 }
 
 __global__ void rowsq_reduce_kernel(const float* __restrict__ part, int nparts, int Bp, float* __restrict__ rowsq) {
@@ -596,6 +613,8 @@ int dae::launch_encode_csr(const EncCsrLaunch& q, hipStream_t st) {
     a.label_block = q.label_job ? nblk : -1;
     if (q.label_job) a.job = *q.label_job;
     size_t lds = encode_csr_lds_bytes(q.dtype, q.w_f32, q.w32_cols, q.x_bits ? q.ldxb : 0);
+    a.Fp = (int)dae_pad(q.F);
+    if (q.xtb && lds + (size_t)a.Fp <= 64 * 1024) { a.xtl_off = (int)lds; lds += (size_t)a.Fp; }     // else: global atomics
     if (q.label_job && lds < (size_t)LABEL_SMEM_BYTES) lds = LABEL_SMEM_BYTES;
     DAE_CHECK_ARG(lds <= 64 * 1024, "encode_csr: %zu B of LDS for the bit rows of %d features (route the clean rows through dae_gather_csr)", lds, q.F);
     dim3 grid(nblk + (q.label_job ? 1 : 0)), block(ENC_THREADS);

@@ -713,14 +713,15 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_nt_pc(GemmParams p, float*
 // one k step ahead (48 VGPRs) so that the master weights of the tile can stay prefetched in registers (80 VGPRs, SGD).
 // The last row tile is partial (10112 = 63 x 160 + 32): its out-of-range rows load row Fp-1 and are never stored.
 //
-// SPARSE (binary CSR input): only  delta2^T . h  runs on MFMA (K = Bp).  The other half of the tied-weight gradient,
-//     x~^T . delta1        (autoencoder.py:377,452: the autodiff of tf.sparse.matmul(x~, W) is itself a sparse product)
-// is summed from the KEPT ENTRIES: x~^T arrives as a bit image (bit i of row f <=> entry (i, f) kept, written by the encode
-// launch: 1.1 MB instead of an 18 MB image that is 98.6 % zeros), and after the K loop -- the LDS ring is dead by then -- all
-// 8 waves turn the tile's 160 bit rows into index lists and add up the matching rows of delta1 [Bp x Hp] (row-major, from
-// dh_finish): a 16-lane group owns one feature row, lane `part` its 8 columns, 8 independent 16-byte loads in flight; the
-// sums land in an fp32 LDS tile that the consumer waves add to their MFMA accumulators.  Entries are walked in batch-row
-// order -> deterministic.  ~11 entries per feature: 0.11 GFLOP instead of the 8 GFLOP of zeros the dense form multiplies.
+// XBITS (binary CSR input): x~^T never exists as an 18 MB image that is mostly zeros.  It arrives as a BIT image (bit i of row f
+// <=> entry (i, f) of the batch was kept; written by the encode launch, 1.1 MB) and the A tiles of the x~^T . delta1 segment
+// are BUILT in LDS by the producer waves (zero fill + one 2-byte store per set bit, or an arithmetic expansion when a word is
+// dense -- the popular features of a Zipf vocabulary are kept in most rows, so their rows are NOT sparse), exactly as
+// gemm_encode_bits_pc builds x~.  Only delta1^T is streamed for that segment: 187 MB through the LDS-DMA path per launch instead
+// of 258 MB, and an XCD's share of the operands (3.2 MB) fits its 4 MiB L2.  Same MFMA products and accumulation order as the
+// dense image -> bit-identical gradients.  (A sum over the kept entries instead -- "sparse x~^T.delta1" -- was built and
+// measured first: 0.11 GFLOP, but half of the entries sit in 3 % of the feature rows and one tile took 120 us;
+// profiles/r03_experiments.md.)
 // OPT == DW_GRAD_ONLY: no optimizer, the gradient tile goes to memory (fp32 `grad` and / or bf16 `grad_lo`): the data-parallel step.
 // ------------------------------------------------------------------------------------------------
 constexpr int DW_BM = 160, DW_MB = DW_BM / 32;                         // rows per tile, MFMA row blocks per consumer wave
@@ -730,35 +731,33 @@ constexpr int DW_NST = 4;
 constexpr int DW_P0 = 128 * 2 + 16;                                    // staged W_lo row [160][128 bf16 + pad]
 constexpr int DW_P1 = DW_BM * 2 + 16;                                  // staged Wt_lo row [128][160 bf16 + pad]
 constexpr int DW_RING = DW_NST * DW_STAGE;                             // 144 KiB (the epilogue tiles, 86 KiB, reuse it)
-constexpr int DW_GRAD_ONLY = DW_OPT_GRAD_ONLY;                                       // OPT value: gradient to memory, no update
-constexpr int DWS_PITCH = 132;                                         // floats per row of the sparse-sum tile [160][128 + 4]
-constexpr int DWS_TILE = DW_BM * DWS_PITCH * 4;                        // 84,480 B
-constexpr int DWS_CAP = 1024;                                          // list entries per 16-lane group (Bp <= 1024)
-constexpr int DWS_GROUPS = PC_THREADS / 16;                            // 32
-constexpr int DWS_LDS = DWS_TILE + DWS_GROUPS * DWS_CAP * 2;           // 150,016 B
+constexpr int DW_GRAD_ONLY = DW_OPT_GRAD_ONLY;                         // OPT value: gradient to memory, no update
 constexpr int DW_LDS = DW_RING;
-constexpr int DW_LDS_SPARSE = DWS_LDS > DW_RING ? DWS_LDS : DW_RING;
+constexpr int DWB_MAXKT = 16;                                          // XBITS: K tiles of the x~^T segment (Bp <= 1024)
 
-struct DwSparse {
+struct DwBits {
     const uint32_t* xtb; int64_t ldxt;       // x~^T bit image [Mrows x ldxt words]
-    const bf16_t* d1; int64_t ldd1;          // delta1 [Bp x ldd1] bf16, row-major
-    int nwords;                              // Bp / 32 (<= 32)
-    float scale;                             // value of every kept entry (the corruption's scale factor; 1 for masking noise)
+    int nwords;                              // Bp / 32
+    uint32_t one;                            // bf16 bits of the value of a kept entry (the corruption's scale factor; 1.0 for masking noise)
 };
 
-__device__ __forceinline__ int group16_excl_scan(int v, int part, int& total) {
-    int x = v;
-#pragma unroll
-    for (int d = 1; d < 16; d <<= 1) {
-        const int y = __shfl_up(x, d, 16);
-        if (part >= d) x += y;
+__device__ __forceinline__ void wait_vm_n(int n) {   // counted vmcnt wait for the op counts a mixed (4 / 9 pieces per stage) ring can leave in flight
+    switch (n) {
+        case 0: wait_vm<0>(); break;
+        case 4: wait_vm<4>(); break;
+        case 8: wait_vm<8>(); break;
+        case 9: wait_vm<9>(); break;
+        case 12: wait_vm<12>(); break;
+        case 13: wait_vm<13>(); break;
+        case 17: wait_vm<17>(); break;
+        case 18: wait_vm<18>(); break;
+        case 22: wait_vm<22>(); break;
+        default: wait_vm<27>(); break;
     }
-    total = __shfl(x, 15, 16);
-    return x - v;
 }
 
-template <int OPT, bool SPARSE>
-__global__ __launch_bounds__(PC_THREADS, 1) void gemm_dw_pc(GemmParams p, OptEpi e, int Mrows, DwSparse sp) {
+template <int OPT, bool XBITS>
+__global__ __launch_bounds__(PC_THREADS, 1) void gemm_dw_pc(GemmParams p, OptEpi e, int Mrows, DwBits xb) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     // XCD-banded tile map: XCD x = b % 8 owns 8 consecutive row tiles (all column tiles), so a band's A panel is read from
     // HBM by one XCD and re-used from its L2 by the 4 column tiles
@@ -773,6 +772,7 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_dw_pc(GemmParams p, OptEpi
 #else
     const int nk = p.ktiles_total;
 #endif
+    const int nk0 = p.seg[0].ktiles;                                        // XBITS: K tiles whose A operand is built from the bit image
     const int row0_m = tm * DW_BM, row0_n = tn * BN;
     constexpr bool UPDATE = OPT != DW_GRAD_ONLY;
 #ifdef DAE_DW_PROBE
@@ -780,26 +780,37 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_dw_pc(GemmParams p, OptEpi
 #else
     constexpr bool PREFETCH_W = (OPT == DAE_OPT_SGD);
 #endif
-    // ---- SPARSE: this 16-lane group's bit rows (5 feature rows x 2 words per lane), requested before the K loop ----
-    const int gq = tid >> 4, part = lane & 15;                              // group 0..31 owns tile rows gq, gq + 32, ...
-    uint32_t bw[DW_MB][2];
-    if constexpr (SPARSE) {
-#pragma unroll
-        for (int s2 = 0; s2 < DW_MB; ++s2) {
-            const int grow = row0_m + s2 * 32 + gq;
-            const uint32_t* rowp = sp.xtb + (int64_t)min(grow, Mrows - 1) * sp.ldxt;
-            bw[s2][0] = rowp[min(part, sp.nwords - 1)];                     // raw words; masked where they are used, after the
-            bw[s2][1] = rowp[min(part + 16, sp.nwords - 1)];                // K loop, so that nothing waits for them before it
-        }
-    }
     const int g = lane >> 5, c = lane & 31;
     float* __restrict__ Wp = e.W;
     float wv[DW_MB][16] = {};
     f32x16 acc[DW_MB];
 
     if (wave8 >= 4) {
-        // ================= producer: 5 A pieces + 4 B pieces per K tile =================
+        // ================= producer: per K tile 5 A pieces (DMA, or built from bits) + 4 B pieces =================
         const int wave = wave8 - 4;
+        // XBITS: this wave builds tile rows [40 wave, +40): item 0 of a lane = (row 40 wave + (lane >> 1), 32-column half lane & 1),
+        // item 1 (lanes 0..15) = (row 40 wave + 32 + (lane >> 1), half).  The lane's bit words of EVERY K tile of the segment are
+        // loaded here, once, into registers that rotate by one per built stage (no run-time register index, and no ordinary
+        // load inside the LDS-DMA loop -- hipcc would drain the DMA queue at its use)
+        uint32_t bw0[DWB_MAXKT], bw1[DWB_MAXKT];
+        const int half = lane & 1;
+        const int lrow_a = wave * 40 + (lane >> 1), lrow_b = wave * 40 + 32 + (lane >> 1);
+        if constexpr (XBITS) {
+            const bool ok_a = row0_m + lrow_a < Mrows, ok_b = lane < 16 && row0_m + lrow_b < Mrows;
+            const uint32_t* pa = xb.xtb + (int64_t)min(row0_m + lrow_a, Mrows - 1) * xb.ldxt;
+            const uint32_t* pb = xb.xtb + (int64_t)min(row0_m + lrow_b, Mrows - 1) * xb.ldxt;
+#pragma unroll
+            for (int t = 0; t < DWB_MAXKT; ++t) {
+                const int wi = min(2 * t + half, xb.nwords - 1);
+                bw0[t] = pa[wi]; bw1[t] = pb[wi];
+            }
+#pragma unroll
+            for (int t = 0; t < DWB_MAXKT; ++t) {
+                const bool in = 2 * t + half < xb.nwords;
+                bw0[t] = (in && ok_a) ? bw0[t] : 0u;
+                bw1[t] = (in && ok_b) ? bw1[t] : 0u;
+            }
+        }
         uint32_t voA[5], voB[4];
         const char *gA = nullptr, *gB = nullptr;
         int kt_dma = 0;
@@ -822,30 +833,70 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_dw_pc(GemmParams p, OptEpi
             gB = p.seg[sg].Bt + (int64_t)k * BKB;
         };
         seg_setup(0);
-        auto dma_stage = [&](char* slot) {
+        // one (row, half) item of the A tile of the stage in `slot`: 32 consecutive k of tile row `lrow` from one bit word
+        auto build_item = [&](char* slot, int lrow, uint32_t word, bool dense) {
+            const uint32_t swz = (uint32_t)((lrow >> 1) & 7);
+            if (dense) {                                   // arithmetic expansion: 8 bits -> 8 bf16 (0 / one) per 16-byte slot
 #pragma unroll
-            for (int i = 0; i < 5; ++i)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gA + voA[i]),
-                                                 (__attribute__((address_space(3))) void*)(slot + (i * 4 + wave) * 1024), 16, 0, 0);
+                for (int j = 0; j < 4; ++j) {
+                    i32x4 v;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const uint32_t b2 = (word >> (8 * j + 2 * q)) & 3u;
+                        v[q] = (int)(((b2 & 1u) * xb.one) | ((b2 >> 1) * (xb.one << 16)));
+                    }
+                    *reinterpret_cast<i32x4*>(slot + lrow * BKB + (((uint32_t)(half * 4 + j) ^ swz) << 4)) = v;
+                }
+            } else {
+                while (word) {                             // one 2-byte store per set bit (in-order LDS: lands after the zero fill)
+                    const int bb = __builtin_ctz(word);
+                    word &= word - 1;
+                    const uint32_t k = (uint32_t)(half * 32 + bb);
+                    *reinterpret_cast<bf16_t*>(slot + lrow * BKB + (((k >> 3) ^ swz) << 4) + (k & 7) * 2) = (bf16_t)xb.one;
+                }
+            }
+        };
+        auto build_a = [&](char* slot) {                   // consumes bw0[0] / bw1[0] and rotates the registers
+            const uint32_t w0 = bw0[0], w1 = bw1[0];
+#pragma unroll
+            for (int t = 0; t + 1 < DWB_MAXKT; ++t) { bw0[t] = bw0[t + 1]; bw1[t] = bw1[t + 1]; }
+            const bool dense = __builtin_amdgcn_ballot_w64(__builtin_popcount(w0) > 6 || __builtin_popcount(w1) > 6) != 0ull;
+            if (!dense) {                                  // zero this wave's 40 rows (5 KiB): 5 x ds_write_b128 per lane
+                const i32x4 z = {0, 0, 0, 0};
+#pragma unroll
+                for (int i = 0; i < 5; ++i) *reinterpret_cast<i32x4*>(slot + wave * 40 * BKB + i * 1024 + lane * 16) = z;
+            }
+            build_item(slot, lrow_a, w0, dense);
+            if (lane < 16) build_item(slot, lrow_b, w1, dense);
+        };
+        auto dma_stage = [&](char* slot) {                 // returns nothing; issues 9 (dense A) or 4 (built A) pieces
+            const bool built = XBITS && kt_dma < nk0;
+            if (!built) {
+#pragma unroll
+                for (int i = 0; i < 5; ++i)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gA + voA[i]),
+                                                     (__attribute__((address_space(3))) void*)(slot + (i * 4 + wave) * 1024), 16, 0, 0);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gB + voB[i]),
                                                  (__attribute__((address_space(3))) void*)(slot + DW_A_BYTES + (i * 4 + wave) * 1024), 16, 0, 0);
+            if (built) build_a(slot);
             ++kt_dma;
             if (kt_dma == p.seg[0].ktiles) { if (kt_dma < p.ktiles_total) seg_setup(kt_dma); }
             else { gA += BKB; gB += BKB; }
         };
+        auto ops = [&](int st) { return st >= nk ? 0 : ((XBITS && st < nk0) ? 4 : 9); };   // LDS-DMA pieces of stage st (per wave)
 #pragma unroll
         for (int st = 0; st < DW_NST; ++st)
             if (st < nk) dma_stage(lds + st * DW_STAGE);
-        if (nk >= DW_NST) wait_vm<(DW_NST - 1) * 9>(); else wait_vm<0>();   // stage 0 landed (older plain loads return first)
+        wait_vm_n(ops(1) + ops(2) + ops(3));                                // stage 0 landed (older plain loads return first)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // ... and every A tile built so far is written
         __builtin_amdgcn_s_barrier();
         int cur = 0;
         for (int i = 0; i < nk; ++i) {
-            const int ahead = min(DW_NST - 2, nk - 2 - i);                  // stages younger than i+1 already requested
-            if (ahead >= 2) wait_vm<18>();
-            else if (ahead == 1) wait_vm<9>();
-            else wait_vm<0>();
+            wait_vm_n(ops(i + 2) + ops(i + 3));                             // stage i+1 landed; younger stages stay in flight
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if (i + DW_NST < nk) dma_stage(lds + cur * DW_STAGE);
@@ -927,65 +978,6 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_dw_pc(GemmParams p, OptEpi
     }
     __builtin_amdgcn_s_barrier();                                           // B1: every wave is out of the K loop; the ring is dead
     asm volatile("" ::: "memory");
-
-    if constexpr (SPARSE) {
-        // ================= x~^T . delta1 from the kept entries (all 8 waves; one feature row per 16-lane group) =================
-        float* S = reinterpret_cast<float*>(lds);                                                  // [160][DWS_PITCH]
-        unsigned short* list = reinterpret_cast<unsigned short*>(lds + DWS_TILE) + gq * DWS_CAP;   // this group's batch-row list
-        const char* d1b = reinterpret_cast<const char*>(sp.d1) + (int64_t)(row0_n + part * 8) * 2;
-        const int64_t ldd1_b = sp.ldd1 * 2;
-#pragma unroll 1
-        for (int s2 = 0; s2 < DW_MB; ++s2) {
-            const int lrow = s2 * 32 + gq;
-            // bit words -> ascending list of batch rows (word `part` before word `part + 16`, ranks by prefix over the group)
-            const bool rok = row0_m + lrow < Mrows;
-            uint32_t w0 = (rok && part < sp.nwords) ? bw[s2][0] : 0u, w1 = (rok && part + 16 < sp.nwords) ? bw[s2][1] : 0u;
-            int tot0, tot1;
-            int o0 = group16_excl_scan(__builtin_popcount(w0), part, tot0);
-            int o1 = tot0 + group16_excl_scan(__builtin_popcount(w1), part, tot1);
-            const int cnt = tot0 + tot1;
-            while (w0) { const int bb = __builtin_ctz(w0); w0 &= w0 - 1; list[o0++] = (unsigned short)(part * 32 + bb); }
-            while (w1) { const int bb = __builtin_ctz(w1); w1 &= w1 - 1; list[o1++] = (unsigned short)((part + 16) * 32 + bb); }
-            // (LDS operations of one wave complete in order: the reads below see the list)
-            float sa[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) sa[q] = 0.f;
-            for (int k0 = 0; k0 < cnt; k0 += 8) {
-                i32x4 v[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int i = list[min(k0 + j, cnt - 1)];
-                    v[j] = *reinterpret_cast<const i32x4*>(d1b + (int64_t)i * ldd1_b);
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float on = (k0 + j < cnt) ? 1.0f : 0.0f;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        sa[2 * q] = fmaf(on, __uint_as_float(((uint32_t)v[j][q]) << 16), sa[2 * q]);
-                        sa[2 * q + 1] = fmaf(on, __uint_as_float(((uint32_t)v[j][q]) & 0xffff0000u), sa[2 * q + 1]);
-                    }
-                }
-            }
-            f32x4 lo4 = {sa[0] * sp.scale, sa[1] * sp.scale, sa[2] * sp.scale, sa[3] * sp.scale};
-            f32x4 hi4 = {sa[4] * sp.scale, sa[5] * sp.scale, sa[6] * sp.scale, sa[7] * sp.scale};
-            *reinterpret_cast<f32x4*>(S + lrow * DWS_PITCH + part * 8) = lo4;
-            *reinterpret_cast<f32x4*>(S + lrow * DWS_PITCH + part * 8 + 4) = hi4;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                                       // B2: the sparse-sum tile is complete
-        asm volatile("" ::: "memory");
-        if (wave8 < 4) {
-            const float* Sl = S + (4 * g) * DWS_PITCH + wave8 * 32 + c;
-#pragma unroll
-            for (int m = 0; m < DW_MB; ++m)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[m][r] += Sl[(m * 32 + (r & 3) + 8 * (r >> 2)) * DWS_PITCH];
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                                       // B3: the tile is consumed; the LDS is free for the staging
-        asm volatile("" ::: "memory");
-    }
 
     if (wave8 < 4) {
         // ---- optimizer on the gradient tile in registers; both bf16 shadows staged in LDS ----
@@ -1708,18 +1700,19 @@ int launch_gemm_f32out(int dtype, int M, int N, const void* A0, int64_t lda0, co
     return 0;
 }
 
-// can the 160 x 128 producer/consumer kernel with the sparse x~^T.delta1 phase run this shape?  (one round of the chip, list
-// capacity of a bit row, whole 64-deep K tiles)
-bool dw_sparse_fits(int M, int N, int Bp) {
+// can the 160 x 128 producer/consumer kernel run this shape with x~^T as a bit image?  (one round of the chip, the bit words of
+// the segment fit the producers' registers, whole 64-deep K tiles)
+bool dw_bits_fits(int M, int N, int Bp) {
     if (gemm_init()) return false;
     const int tiles_m = (M + DW_BM - 1) / DW_BM, tiles_n = N / BN, per = (tiles_m + 7) / 8;
-    return N % BN == 0 && Bp % 64 == 0 && Bp <= DWS_CAP && 8 * per * tiles_n <= g_cus && g_dw_pc != 0;
+    return N % BN == 0 && Bp % 64 == 0 && Bp / 64 <= DWB_MAXKT && 8 * per * tiles_n <= g_cus && g_dw_pc != 0;
 }
 
 int launch_dw_opt(int M, int N, const void* A0, int64_t lda0, const void* Bt0, int64_t ldb0, int K0, const void* A1, int64_t lda1,
-                  const void* Bt1, int64_t ldb1, int K1, const OptEpi& e, hipStream_t st, const DwSparseArgs* sa) {
+                  const void* Bt1, int64_t ldb1, int K1, const OptEpi& e, hipStream_t st, const DwBitsArgs* xa) {
     GemmParams p;
-    if (int rc = fill_params(p, DAE_BF16, M, N, A0, lda0, Bt0, ldb0, K0, A1, lda1, Bt1, ldb1, K1, 1)) return rc;
+    // xa: segment 0's A operand is the bit image (A0 == NULL); fill_params only needs a non-null, aligned placeholder
+    if (int rc = fill_params(p, DAE_BF16, M, N, xa ? Bt0 : A0, xa ? ldb0 : lda0, Bt0, ldb0, K0, A1, lda1, Bt1, ldb1, K1, 1)) return rc;
     if (int rc = gemm_init()) return rc;
     const bool grad_only = e.opt == DW_GRAD_ONLY;
     if (grad_only) {
@@ -1733,11 +1726,11 @@ int launch_dw_opt(int M, int N, const void* A0, int64_t lda0, const void* Bt0, i
         const int tiles_m = (M + DW_BM - 1) / DW_BM, tiles_n = N / BN;
         const int per = (tiles_m + 7) / 8;
         const bool fits = g_dw_pc && K0 % 64 == 0 && K1 % 64 == 0 && 8 * per * tiles_n <= g_cus;
-        DAE_CHECK_ARG(!sa || (fits && K1 == 0 && K0 <= DWS_CAP && sa->xtb && sa->d1 && sa->ldxt >= K0 / 32 && sa->ldd1 >= N),
-                      "dw: the sparse x~^T.delta1 form does not fit this shape (M=%d N=%d Bp=%d)", M, N, K0);
+        DAE_CHECK_ARG(!xa || (fits && K0 / 64 <= DWB_MAXKT && xa->xtb && xa->ldxt >= K0 / 32),
+                      "dw: the bit-image form of x~^T does not fit this shape (M=%d N=%d Bp=%d)", M, N, K0);
         DAE_CHECK_ARG(!grad_only || fits, "dw: the gradient-only form runs on the 160 x 128 kernel only (M=%d N=%d)", M, N);
-        if (fits && (sa || grad_only || g_dw_pc == 2 || 8 * per * tiles_n > (3 * g_cus) / 4)) {
-            typedef void (*dwpc_fn)(GemmParams, OptEpi, int, DwSparse);
+        if (fits && (xa || grad_only || g_dw_pc == 2 || 8 * per * tiles_n > (3 * g_cus) / 4)) {
+            typedef void (*dwpc_fn)(GemmParams, OptEpi, int, DwBits);
             static const dwpc_fn pcs[2][5] = {
                 {gemm_dw_pc<DAE_OPT_SGD, false>, gemm_dw_pc<DAE_OPT_ADAGRAD, false>, gemm_dw_pc<DAE_OPT_MOMENTUM, false>, gemm_dw_pc<DAE_OPT_ADAM, false>,
                  gemm_dw_pc<DW_GRAD_ONLY, false>},
@@ -1747,15 +1740,21 @@ int launch_dw_opt(int M, int N, const void* A0, int64_t lda0, const void* Bt0, i
                 int rc = 0;
                 for (int v = 0; v < 2; ++v)
                     for (dwpc_fn f : pcs[v])
-                        rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                        rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS);
                 return rc;
             }();
             DAE_CHECK_ARG(pc_rc == 0, "dw_pc: hipFuncSetAttribute failed");
             GemmParams q = p;
             q.tiles_m = tiles_m; q.tiles_n = tiles_n;
-            DwSparse sp; memset(&sp, 0, sizeof(sp));
-            if (sa) { sp.xtb = sa->xtb; sp.ldxt = sa->ldxt; sp.d1 = (const bf16_t*)sa->d1; sp.ldd1 = sa->ldd1; sp.nwords = K0 / 32; sp.scale = sa->scale; }
-            hipLaunchKernelGGL(pcs[sa ? 1 : 0][e.opt], dim3(8 * per * tiles_n), dim3(PC_THREADS), sa ? DW_LDS_SPARSE : DW_LDS, st, q, e, M, sp);
+            DwBits xb; memset(&xb, 0, sizeof(xb));
+            if (xa) {
+                xb.xtb = xa->xtb; xb.ldxt = xa->ldxt; xb.nwords = K0 / 32;
+                uint32_t u; memcpy(&u, &xa->scale, 4);
+                u += 0x7fffu + ((u >> 16) & 1u);               // bf16(scale), round to nearest even (a finite positive factor)
+                xb.one = u >> 16;
+                q.seg[0].A = nullptr;
+            }
+            hipLaunchKernelGGL(pcs[xa ? 1 : 0][e.opt], dim3(8 * per * tiles_n), dim3(PC_THREADS), DW_LDS, st, q, e, M, xb);
             DAE_CHECK_LAUNCH();
             return 0;
         }
@@ -1770,6 +1769,7 @@ int launch_dw_opt(int M, int N, const void* A0, int64_t lda0, const void* Bt0, i
     }();
     DAE_CHECK_ARG(attr_rc == 0, "dw_opt: hipFuncSetAttribute failed");
     static_assert(DAE_OPT_SGD == 0 && DAE_OPT_ADAGRAD == 1 && DAE_OPT_MOMENTUM == 2 && DAE_OPT_ADAM == 3, "optimizer enum order");
+    DAE_CHECK_ARG(!xa && !grad_only, "dw: this shape needs the dense x~^T image and the fused-optimizer form");
     hipLaunchKernelGGL(fns[e.opt], dim3(grid_blocks(p)), dim3(GEMM_THREADS), ldsb, st, p, e);
     DAE_CHECK_LAUNCH();
     return 0;

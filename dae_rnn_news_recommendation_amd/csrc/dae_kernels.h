@@ -105,16 +105,15 @@ struct OptEpi {
     void* grad_lo;            // DW_OPT_GRAD_ONLY: bf16 gradient image [Fp x ldw] (the reduce-scatter operand of data parallel) or NULL
 };
 enum { DW_OPT_GRAD_ONLY = 4 };
-// sparse half of the tied-weight gradient, x~^T.delta1 summed from the kept entries (binary CSR input; see gemm_dw_pc)
-struct DwSparseArgs {
-    const uint32_t* xtb; int64_t ldxt;   // x~^T bit image [Fp x ldxt words]: bit i of row f <=> entry (i, f) of the batch kept
-    const void* d1; int64_t ldd1;        // delta1 [Bp x ldd1] bf16, row-major
+// x~^T handed to the dW kernel as a BIT image (binary CSR input): the A tiles of the x~^T.delta1 segment are built in LDS
+struct DwBitsArgs {
+    const uint32_t* xtb; int64_t ldxt;   // [Fp x ldxt words]: bit i of row f <=> entry (i, f) of the batch kept
     float scale;                         // value of a kept entry
 };
-bool dw_sparse_fits(int M, int N, int Bp);
-// sa != NULL: A0/Bt0 = delta2^T / h^T only (K1 = 0), the x~^T.delta1 half comes from `sa`
+bool dw_bits_fits(int M, int N, int Bp);
+// xa != NULL: segment 0 is x~^T (bit image, A0 ignored) . Bt0 = delta1^T; segment 1 = delta2^T . h^T as usual
 int launch_dw_opt(int M, int N, const void* A0, int64_t lda0, const void* Bt0, int64_t ldb0, int K0, const void* A1, int64_t lda1,
-                  const void* Bt1, int64_t ldb1, int K1, const OptEpi& e, hipStream_t st, const DwSparseArgs* sa = nullptr);
+                  const void* Bt1, int64_t ldb1, int K1, const OptEpi& e, hipStream_t st, const DwBitsArgs* xa = nullptr);
 void set_use_glds(int nst);
 int launch_gemm_trace(int dtype, int M, int N, const void* A0, int64_t lda0, const void* Bt0, int64_t ldb0, int K0, const void* A1,
                       int64_t lda1, const void* Bt1, int64_t ldb1, int K1, float* C, int64_t ldc, int splits, int64_t slab_stride,

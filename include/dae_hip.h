@@ -29,7 +29,7 @@ extern "C" {
 #endif
 
 #define DAE_PAD 128
-#define DAE_ABI_VERSION 3   /* 3: dae_buffers.grad_lo, options dw_sparse / encode_w32; 2: dae_step.c_row_idx, plan options, phases 4/5, sharded apply */
+#define DAE_ABI_VERSION 3   /* 3: dae_buffers.grad_lo, options dw_bits / encode_w32; 2: dae_step.c_row_idx, plan options, phases 4/5, sharded apply */
 
 enum { DAE_BF16 = 0, DAE_F32 = 1 };
 enum { DAE_ACT_NONE = 0, DAE_ACT_SIGMOID = 1, DAE_ACT_TANH = 2 };
@@ -418,8 +418,8 @@ int      dae_plan_sync_shadows(dae_plan* p, void* stream);
  * GEMM; on by default for binary CSR + bf16), "x_bits" (clean rows as a bit image into the decode epilogue), "fused_opt" (optimizer in the
  * dW GEMM's epilogue), "tail" (bias gradients + statistics + x~^T un-scatter in one launch), "label_with_encode", "ce_literal"
  * (cross_entropy always by the reference-literal formula), "overlap" (miner chain on a side stream), "gram_fp32" (exact-fp32 Gram
- * matrix in bf16 mode; before dae_plan_bind only), "dw_sparse" (binary CSR + bf16: x~^T as a bit image and the x~^T.delta1 half of dW
- * summed from the kept entries inside the dW kernel -- default on; 0 = dense x~^T image, K = 2 Bp GEMM), "encode_w32" (bf16 mode: the
+ * matrix in bf16 mode; before dae_plan_bind only), "dw_bits" (binary CSR + bf16: x~^T reaches the dW kernel as a bit image and the A tiles of
+ * its x~^T.delta1 segment are built in LDS -- default on; 0 = dense x~^T image, scattered and un-scattered every step), "encode_w32" (bf16 mode: the
  * sparse encode reads the fp32 master weights, so h -- and with the split-bf16 Gram matrix the triplet leg -- is fp32-accurate; default
  * on; a sharded-optimizer exchange must turn it off because only W_lo is current on every rank), "encode_w32_cols" (64 | 128 columns
  * per workgroup of that kernel).  Unknown names are an error. */
