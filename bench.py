@@ -179,6 +179,8 @@ class Runner:
             v = 0.3 if not isinstance(self.m, np.ndarray) else utils.dense_masking_threshold(0.3)
             d["bits"] = utils.masking_keep_bits(n, v).view(np.int32)
         order = utils.epoch_permutation(self.N)
+        if self.world == 1 and not self.explicit and self.c["strategy"] != "none":
+            order = utils.class_sort_batches(order, self.labels, self.B)       # as DenoisingAutoencoder.fit() stages its epochs
         # staged like DenoisingAutoencoder._stage_epoch: pinned tensors, uploaded asynchronously by the stepping thread
         from dae_rnn_news_recommendation_amd.autoencoder.autoencoder import pinned_copy
         if "bits" in d:

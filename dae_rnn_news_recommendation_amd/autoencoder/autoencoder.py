@@ -300,7 +300,10 @@ class DenoisingAutoencoder(object):
         self._stats = torch.zeros((max(self.num_epochs, 1), n_batches, L.STATS_STRIDE), dtype=torch.float32,
                                   device=eng.device)
         self._epoch_seconds = []
-        feeder = _EpochFeeder(lambda e: self._stage_epoch(self._draw_epoch(train_set, e), label_ids), self.num_epochs)
+        # single GPU + a mining strategy: every mini-batch is handed over class-sorted (utils.class_sort_batches); under data
+        # parallel the ranks take contiguous shards of a batch, which must stay a random sample of it
+        sort_batch = batch if (world == 1 and label_ids is not None and self.triplet_strategy != 'none') else None
+        feeder = _EpochFeeder(lambda e: self._stage_epoch(self._draw_epoch(train_set, e), label_ids, sort_batch), self.num_epochs)
         t_fit = time.time()
         t_first = None
         i = -1
@@ -356,9 +359,11 @@ class DenoisingAutoencoder(object):
         return draw
 
     @staticmethod
-    def _stage_epoch(draw, label_ids):
+    def _stage_epoch(draw, label_ids, sort_batch=None):
         """Feeder thread: the epoch's host arrays as PINNED tensors (row order, labels in that order, keep bits), so the training
         thread's uploads are asynchronous copies instead of staged pageable ones."""
+        if sort_batch and label_ids is not None:
+            draw['order'] = utils.class_sort_batches(draw['order'], label_ids, sort_batch)
         order = draw['order']
         draw['order_t'] = pinned_copy(order.astype(np.int32))
         if label_ids is not None:

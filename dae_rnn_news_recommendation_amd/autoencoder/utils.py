@@ -193,3 +193,15 @@ def pack_keep_bits(keep):
     if pad:
         bits = np.concatenate([bits, np.zeros(pad, np.uint8)])
     return bits.view(np.uint32)
+
+
+def class_sort_batches(order, labels, batch):
+    """Reorder an epoch's row permutation so that every mini-batch (consecutive `batch` rows) is sorted by label (stable).
+    A mini-batch is a SET for the reference's objective -- every per-batch quantity it computes (weighted reconstruction loss,
+    batch_all / batch_hard mining, their gradients) is a sum or mean over the batch -- so the batches keep exactly the rows the
+    reference's shuffle gave them (utils.py:57-60) and only the position inside a batch changes.  The batch_all miner then finds
+    an anchor's positives and negatives as index ranges instead of compacting them.  Returns the new permutation."""
+    order = np.asarray(order)
+    lab = np.asarray(labels)[order].astype(np.int64)
+    key = (np.arange(order.size, dtype=np.int64) // int(batch)) * (int(lab.max()) + 1 if lab.size else 1) + lab
+    return order[np.argsort(key, kind='stable')]

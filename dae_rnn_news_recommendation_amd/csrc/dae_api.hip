@@ -94,6 +94,8 @@ struct dae_plan {
     bool sym_ride_ok;                 // Gs = a/Nv (G + G^T) computed by rider workgroups of the decode launch instead of its own launch
     bool miner_order_ok;              // dispatch the batch_all workgroups by descending sweep cost (LabelJob::order)
     int32_t* miner_order;
+    int32_t* cls_range;               // [1 + 2 Bpm]: sortedness flag + class range of every row (LabelJob::cls), the miner's range fast path
+    bool miner_ranges_ok;             // option "miner_ranges" = 0: always compact positives / negatives by ballots
     double prof_ms[PS_COUNT];
     int prof_n[PS_COUNT];
     dae_config cfg;
@@ -109,7 +111,7 @@ struct dae_plan {
     bool xtb_clean;                  // the bit image holds only zeros (every step clears what it set; see step_tail_kernel)
     bool dw_bits_ok;               // option "dw_bits" = 0: dense x~^T image and a K = 2 Bp dW GEMM (A/B, equivalence tests)
     bool enc_w32_ok;                 // option "encode_w32": bf16 mode encodes from the fp32 MASTER weights (h fp32-accurate); 0 = from W_lo
-    int w32_cols;                    // option "encode_w32_cols": 64 (default) or 128 H columns per workgroup of that kernel
+    int w32_cols;                    // option "encode_w32_cols": 128 (default) or 64 H columns per workgroup of that kernel
     bool gram_split;                 // Gram matrix as a 3-term split-bf16 MFMA GEMM (bf16 mode) instead of exact-fp32 MFMA
     float *slabs, *h_f32, *D_slabs, *G, *rowloss_part, *dbv_part, *colsum_part, *cos_part, *cos_stats, *cw, *loss_part,
         *dw_f32, *tri_scalars, *dh_extra, *rowsq_scratch, *tile_part;
@@ -186,6 +188,7 @@ static uint64_t carve(dae_plan* p, char* base) {
     p->acc = (uint64_t*)take(256);
     p->tri_scalars = (float*)take(256);
     p->miner_order = (int32_t*)take(Bp * 4);
+    p->cls_range = (int32_t*)take((1 + 2 * Bp) * 4);
     return off;
 }
 
@@ -222,13 +225,13 @@ extern "C" int dae_plan_create(const dae_config* cfg, dae_plan** out) {
     p->ce_literal = false;
     p->xbits_ok = cfg->dtype == DAE_BF16;
     p->xct_clean = false; p->xtb_clean = false;
-    p->dw_bits_ok = true;
+    p->dw_bits_ok = false;                             // measured slower than streaming the dense image (profiles/r03_experiments.md)
     p->enc_w32_ok = cfg->dtype == DAE_BF16;
-    p->w32_cols = 64;
+    p->w32_cols = 128;                                 // measured: 128-column fp32 slices (5.2 MB, served by the MALL) beat 64-column ones
     // binary CSR + bf16: x~ goes to the encode GEMM as a bit image whenever the 8-wave bit kernel can run the shape
     p->bits_ok = cfg->dtype == DAE_BF16 && encode_bits_fits(p->Bpm, p->Hp, p->Fp, p->s_enc);
     p->sparse_ok = true;
-    p->miner_order_ok = true; p->sym_ride_ok = true;
+    p->miner_order_ok = true; p->sym_ride_ok = true; p->miner_ranges_ok = true;
     p->overlap_ok = false;                              // measured: running the miner chain beside decode is SLOWER (0.410 vs 0.351 ms/step)
     *out = p;
     return 0;
@@ -261,6 +264,8 @@ extern "C" int dae_plan_set_option(dae_plan* p, const char* name, int32_t value)
     else if (!strcmp(name, "ce_literal")) p->ce_literal = on;
     else if (!strcmp(name, "overlap")) p->overlap_ok = on;
     else if (!strcmp(name, "miner_order")) p->miner_order_ok = on;
+    else if (!strcmp(name, "miner_ranges")) p->miner_ranges_ok = on;
+    else if (!strcmp(name, "miner_pack")) set_miner_pack(on);        // process-wide (the launcher's choice), like dae_set_glds
     else if (!strcmp(name, "sym_in_decode")) p->sym_ride_ok = on;
     else if (!strcmp(name, "gram_fp32")) {
         DAE_CHECK_ARG(!p->bound, "plan_set_option: gram_fp32 changes the workspace layout, set it before dae_plan_bind");
@@ -412,7 +417,8 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     // overwrites whole tiles and never needs it.
     const bool csr_in = s->c_indptr || p->b.indptr;
     // label statistics (cw, N_valid, data weights) depend on the labels alone: they ride on the CSR gather launch
-    LabelJob lj{s->labels, B, Bp, c.triplet, p->nvalid, p->dw_i64, p->cw, c.alpha, p->tri_scalars, p->miner_order_ok ? p->miner_order : nullptr};
+    LabelJob lj{s->labels, B, Bp, c.triplet, p->nvalid, p->dw_i64, p->cw, c.alpha, p->tri_scalars, p->miner_order_ok ? p->miner_order : nullptr,
+                p->miner_ranges_ok ? p->cls_range : nullptr};
     // ... on the encode GEMM's launch when that grid leaves a CU free (else on the CSR gather's, else their own)
     const bool label_with_encode = p->tail_ok && !explicit3 && !ext_mine && Bp <= 1024 && p->label_enc_ok;
     const bool label_in_gather = p->tail_ok && !label_with_encode && !explicit3 && !ext_mine && !s->c_indptr && p->b.indptr && Bp <= 1024;
@@ -513,6 +519,7 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
         const int64_t dslab = (int64_t)Bp * Bp;
         // the label block of this step's encode launch also ranked the anchors by sweep cost (only then is the buffer current)
         const int32_t* order = (labels_done && !ext_mine && p->miner_order_ok && c.triplet == DAE_TRIPLET_BATCH_ALL) ? p->miner_order : nullptr;
+        const int32_t* cls = (labels_done && !ext_mine && p->miner_ranges_ok && c.triplet == DAE_TRIPLET_BATCH_ALL) ? p->cls_range : nullptr;
         // batch_all (all valid triplets): cw comes from the labels alone -> the miner chain and the decode kernel are
         // independent until dL/dh; fork the chain onto the side stream (never while profiling: events are per stream)
         const bool overlap = p->overlap_ok && !p->prof && c.triplet == DAE_TRIPLET_BATCH_ALL && !c.pos_triplets_only;
@@ -532,7 +539,7 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
         if (forked) {
             RC(launch_gram(p, Bp, Hp, dslab, ms));
             RC(launch_batch_all(p->D_slabs, p->s_gram, dslab, Bp, s->labels, B, Bp, 0, B, dt == DAE_BF16 ? DAE_MINER_FAST : 0, p->loss_part, p->cnt_part, p->G,
-                                p->role_cnt, order, ms));
+                                p->role_cnt, order, ms, cls));
             if (backward) RC(dae_sym_scale(p->G, B, Bp, p->tri_scalars, dt, p->Gs, mstream));
             DAE_CHECK_HIP(hipEventRecord(p->ev_join, ms));
         } else {
@@ -540,7 +547,7 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
             if (c.triplet == DAE_TRIPLET_BATCH_ALL)
                 PROF(PS_MINER, launch_batch_all(p->D_slabs, p->s_gram, dslab, Bp, s->labels, B, Bp, 0, B,
                                          (c.pos_triplets_only ? DAE_MINER_POS_ONLY : 0) | (dt == DAE_BF16 ? DAE_MINER_FAST : 0), p->loss_part,
-                                         p->cnt_part, p->G, p->role_cnt, order, st));
+                                         p->cnt_part, p->G, p->role_cnt, order, st, cls));
             else
                 PROF(PS_MINER, dae_triplet_batch_hard(p->D_slabs, p->s_gram, dslab, Bp, s->labels, B, Bp, p->loss_part, p->cnt_part, p->dw_i32, p->G,
                                           stream));

@@ -46,6 +46,8 @@ struct LabelJob {
     const int32_t* labels; int B, Bp, triplet; int64_t* nvalid; int64_t* dw; float* cw; float alpha; float* tri_scalars;
     int32_t* order;           // [B] or NULL: the batch rows by DESCENDING batch_all sweep cost (n-1)(B-n), ties by index -- the
                               // dispatch order of the miner's workgroups (longest anchors first, the short ones fill the tail)
+    int32_t* cls;             // [1 + 2 B] or NULL: cls[0] = 1 iff the labels are non-decreasing (a class-sorted batch); then
+                              // cls[1 + 2i], cls[2 + 2i] = first index and end of row i's class (the miner's range fast path)
 };
 int launch_gather_csr(const int64_t* indptr, const int32_t* indices, const float* values, const int32_t* row_idx, int B, int F, int dtype,
                       void* x, void* xc, int64_t ldx, void* xct, int64_t ldt, float* rowsq, int corr_mode, const uint32_t* keep_bits,
@@ -91,7 +93,9 @@ int launch_step_tail(const BiasArgs& ba, const StatsArgs* sa, const ClearArgs* c
 // batch_all miner with an optional dispatch order of the anchors (dae_triplet.hip)
 int launch_batch_all(const float* D_slabs, int d_splits, int64_t slab_stride, int64_t ldd, const int32_t* labels, int B, int Bp, int a0,
                      int n_anchors, int mode, float* loss_part, uint32_t* npos_part, float* G, uint32_t* role_cnt, const int32_t* order,
-                     hipStream_t st);
+                     hipStream_t st, const int32_t* cls = nullptr);
+
+void set_miner_pack(int on);
 
 // epilogue of the fused dW + optimizer GEMM (gemm_dw_opt): parameters updated in place from the gradient tile
 struct OptEpi {

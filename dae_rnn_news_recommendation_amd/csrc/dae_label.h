@@ -6,7 +6,7 @@
 
 namespace dae {
 
-constexpr int LABEL_SMEM_BYTES = 4096 + 4096 * 4 + 32;
+constexpr int LABEL_SMEM_BYTES = 4096 + 4096 * 4 + 64;
 
 // single-launch variant for B <= 1024 (the usual mini-batch): ONE block of NT threads, 1024 / NT labels per thread.  Label
 // multiplicities come from an LDS histogram when every id lies in [0, 4096) (the Python layer always passes dense
@@ -105,6 +105,36 @@ __device__ __forceinline__ void label_stats_block(const LabelJob& j, char* smem)
         for (int e = 0; e < E; ++e) {
             const int i = t + e * NT;
             if (i < B) j.order[(key[e] > 0 ? cntK[key[e] - 1] : 0) + slot[e]] = i;
+        }
+    }
+    if (j.cls && triplet == DAE_TRIPLET_BATCH_ALL) {
+        // class ranges of a label-sorted batch: sortedness by neighbour comparison (block-wide AND through the LDS flag that is
+        // free again), the class of row i = [lower_bound, upper_bound) of its label in the sorted LDS copy
+        int* flag = out_of_range + 1;
+        if (t == 0) *flag = 1;
+        __syncthreads();
+        bool ok = true;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int i = t + e * NT;
+            if (i + 1 < B && lab[i] > lab[i + 1]) ok = false;
+        }
+        if (!ok) *flag = 0;
+        __syncthreads();
+        const int sorted = *flag;
+        if (t == 0) j.cls[0] = sorted;
+        if (sorted) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int i = t + e * NT;
+                if (i < B) {
+                    const int32_t v = li[e];
+                    int a0 = 0, a1 = i;                 // first index with lab >= v lies in [0, i]
+                    while (a0 < a1) { const int m = (a0 + a1) >> 1; if (lab[m] < v) a0 = m + 1; else a1 = m; }
+                    j.cls[1 + 2 * i] = a0;
+                    j.cls[2 + 2 * i] = a0 + (int)n[e];
+                }
+            }
         }
     }
     const long long S = (long long)acc[0], NV = (long long)acc[1];

@@ -250,14 +250,13 @@ __device__ __forceinline__ void sweep_pairs2(const float* __restrict__ pu, const
 #else
 #define MINER_STAMP(i) do { } while (0)
 #endif
-template <bool POS_ONLY, int OCC>
-__global__ __launch_bounds__(TRIP_THREADS, OCC) void batch_all_kernel(const float* __restrict__ D_slabs, int d_splits,
-                                                                 int64_t slab_stride, int64_t ldd,
-                                                                 const int32_t* __restrict__ labels, int B, int Bp,
-                                                                 float* __restrict__ loss_part, uint32_t* __restrict__ npos_part,
-                                                                 float* __restrict__ G, uint32_t* __restrict__ role_cnt, int fast, int a0,
-                                                                 const int32_t* __restrict__ order) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+// One anchor: everything the workgroup does for row `ar` of D / G (batch element a0 + ar).
+template <bool POS_ONLY>
+__device__ __forceinline__ void batch_all_anchor(char* smem, const int ar, const float* __restrict__ D_slabs, int d_splits,
+                                                 int64_t slab_stride, int64_t ldd, const int32_t* __restrict__ labels, int B, int Bp,
+                                                 float* __restrict__ loss_part, uint32_t* __restrict__ npos_part,
+                                                 float* __restrict__ G, uint32_t* __restrict__ role_cnt, int fast, int a0,
+                                                 const int32_t* __restrict__ cls) {
     // positives are compacted from the front of val[]/idx[], negatives from the back (nP + nN <= B)
     float* val = reinterpret_cast<float*>(smem);             // [Bp]
     int* idx = reinterpret_cast<int*>(val + Bp);              // [Bp]
@@ -272,9 +271,7 @@ __global__ __launch_bounds__(TRIP_THREADS, OCC) void batch_all_kernel(const floa
 
     // anchors [a0, a0 + gridDim.x) of the batch: row `ar` of D / G / the partial arrays belongs to batch element a = a0 + ar
     // (a0 = 0 and a square D for a whole batch; a0 > 0 when a rank mines ITS anchors against an all-gathered batch)
-    // `order` (whole-batch launches of the training step): workgroup b takes the b-th most expensive anchor, so the 3.1
-    // workgroups per CU start with the long sweeps and the ones that only get a slot late are the short ones
-    const int ar = order ? order[blockIdx.x] : blockIdx.x, a = a0 + ar;
+    const int a = a0 + ar;
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     MINER_STAMP(0);
@@ -301,7 +298,49 @@ __global__ __launch_bounds__(TRIP_THREADS, OCC) void batch_all_kernel(const floa
     float *nv;                            // negatives: val[Bp-nN .. Bp)
     int *pidx = idx, *nidx;
     constexpr int KU = 4;
-    if (K <= KU) {
+    // CLASS-SORTED batch (the training loops sort every mini-batch by label; the label block verifies it and publishes each
+    // row's class range in `cls`): positives are the index range [cs, ce) minus the anchor, negatives the rest -- destinations
+    // are index arithmetic, so there are no ballots, no count arrays and no barrier before the scatter; the row's min / max
+    // ride along.  Same slots as the compaction below (index order), so everything downstream is identical.
+    const bool ranged = cls != nullptr && K <= KU && cls[0] != 0;
+    float lo = INFINITY, hi = -INFINITY;
+    if (ranged) {
+        const int cs = cls[1 + 2 * a], ce = cls[2 + 2 * a];
+        nP = ce - cs - 1; nN = B - (ce - cs);
+        nv = val + (Bp - nN);
+        nidx = idx + (Bp - nN);
+        float dj[KU];
+#pragma unroll
+        for (int k = 0; k < KU; ++k) dj[k] = 0.f;
+        for (int s0 = 0; s0 < d_splits; s0 += 4) {          // 4 K-slices of the Gram matrix at a time: 16 loads in flight
+            float dd[4][KU];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float* Drow = D_slabs + (int64_t)min(s0 + u, d_splits - 1) * slab_stride + (int64_t)ar * ldd;
+#pragma unroll
+                for (int k = 0; k < KU; ++k) {
+                    const int j = k * TRIP_THREADS + tid;
+                    dd[u][k] = Drow[min(j, B - 1)];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < KU; ++k) dj[k] += (s0 + u < d_splits) ? dd[u][k] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < KU; ++k) {
+            const int j = k * TRIP_THREADS + tid;
+            if (j < B && j != a) {
+                const float d = dj[k];
+                if (j >= cs && j < ce) { const int o = j - cs - (j > a ? 1 : 0); pu[o] = d; pidx[o] = j; }
+                else { const int o = j < cs ? j : j - (ce - cs); nv[o] = d; nidx[o] = j; }
+                lo = fminf(lo, d); hi = fmaxf(hi, d);
+            }
+        }
+        lo = wave_min(lo); hi = wave_max(hi);
+        if (lane == 0) { red[wave] = lo; reinterpret_cast<float*>(redu)[wave] = hi; }
+    } else if (K <= KU) {
         // usual mini-batch (B <= 1024): every global load of the prologue is issued up front -- labels and the D row
         // (d_splits slabs) of all K strips -- so the block pays ONE memory latency instead of 2K dependent ones
         int32_t lj[KU];
@@ -401,11 +440,17 @@ __global__ __launch_bounds__(TRIP_THREADS, OCC) void batch_all_kernel(const floa
     __syncthreads();
     MINER_STAMP(1);
     // range of the anchor's D row over its positives and negatives -> factorised or direct sweep (uniform choice)
-    float lo = INFINITY, hi = -INFINITY;
-    for (int k = tid; k < nP; k += TRIP_THREADS) { lo = fminf(lo, pu[k]); hi = fmaxf(hi, pu[k]); }
-    for (int k = tid; k < nN; k += TRIP_THREADS) { lo = fminf(lo, nv[k]); hi = fmaxf(hi, nv[k]); }
-    lo = block_min_f(lo, red);
-    hi = block_max_f(hi, red);
+    if (ranged) {
+        const float* rh = reinterpret_cast<const float*>(redu);
+        lo = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
+        hi = fmaxf(fmaxf(rh[0], rh[1]), fmaxf(rh[2], rh[3]));
+        __syncthreads();                                     // red / redu are reused by the block sums at the end
+    } else {
+        for (int k = tid; k < nP; k += TRIP_THREADS) { lo = fminf(lo, pu[k]); hi = fmaxf(hi, pu[k]); }
+        for (int k = tid; k < nN; k += TRIP_THREADS) { lo = fminf(lo, nv[k]); hi = fmaxf(hi, nv[k]); }
+        lo = block_min_f(lo, red);
+        hi = block_max_f(hi, red);
+    }
     const bool fact = (hi - lo) <= 80.0f;                    // also false for NaN/inf rows
     const bool fact2 = !POS_ONLY && (hi - lo) <= 40.0f;      // pair-packed sweep: products of two (1 + exp(t)) stay finite
     const float mid = 0.5f * (hi + lo);
@@ -507,6 +552,36 @@ __global__ __launch_bounds__(TRIP_THREADS, OCC) void batch_all_kernel(const floa
 #endif
 }
 
+// Workgroup -> anchors.  The launch has min(n_anchors, nslots) workgroups, nslots = what the chip holds at once (3 per CU):
+// with 800 anchors on 768 slots the 32 workgroups of a second round used to start when the first ones ended and finished at
+// 1.6 x the median (profiles/r02_miner_timeline.txt).  Now every workgroup is resident from the start and walks the anchor list in
+// SNAKE order -- b, 2 nslots - 1 - b, 2 nslots + b, ... -- so with `order` (anchors by descending sweep cost, from the label
+// block) the workgroups that take a second anchor are the ones whose first was the cheapest, and the second is the cheapest
+// of all: classic longest-processing-time packing.  Every anchor is still computed by one workgroup, alone, in the same way.
+template <bool POS_ONLY, int OCC>
+__global__ __launch_bounds__(TRIP_THREADS, OCC) void batch_all_kernel(const float* __restrict__ D_slabs, int d_splits,
+                                                                 int64_t slab_stride, int64_t ldd,
+                                                                 const int32_t* __restrict__ labels, int B, int Bp,
+                                                                 float* __restrict__ loss_part, uint32_t* __restrict__ npos_part,
+                                                                 float* __restrict__ G, uint32_t* __restrict__ role_cnt, int fast, int a0,
+                                                                 const int32_t* __restrict__ order, int n_anchors,
+                                                                 const int32_t* __restrict__ cls) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nslots = gridDim.x, b = blockIdx.x;
+    bool first = true;
+    for (int r = 0; r * nslots < n_anchors; ++r) {     // round r hands out the anchors [r nslots, (r + 1) nslots), odd rounds from the far end
+        const int k = (r & 1) ? (r + 1) * nslots - 1 - b : r * nslots + b;
+        if (k >= n_anchors) continue;
+        const int ar = order ? order[k] : k;
+        if (!first) __syncthreads();                   // the previous anchor's LDS image is dead
+        first = false;
+        batch_all_anchor<POS_ONLY>(smem, ar, D_slabs, d_splits, slab_stride, ldd, labels, B, Bp, loss_part, npos_part, G, role_cnt, fast, a0, cls);
+    }
+}
+
+}  // namespace dae
+namespace dae {
+
 // ------------------------------------------------------------------------------------------------
 // batch_hard
 // ------------------------------------------------------------------------------------------------
@@ -603,11 +678,15 @@ extern "C" int dae_triplet_batch_all_rows(const float* D_slabs, int32_t d_splits
                             (hipStream_t)stream);
 }
 
+static int g_miner_pack = 1;       // 0: one workgroup per anchor (A/B; plan option "miner_pack")
+void dae::set_miner_pack(int on) { g_miner_pack = on ? 1 : 0; }
+
 // order: optional dispatch order of the anchors (LabelJob::order; whole-batch launches only)
 int dae::launch_batch_all(const float* D_slabs, int d_splits, int64_t slab_stride, int64_t ldd, const int32_t* labels, int B, int Bp, int a0,
                           int n_anchors, int mode, float* loss_part, uint32_t* npos_part, float* G, uint32_t* role_cnt, const int32_t* order,
-                          hipStream_t st) {
+                          hipStream_t st, const int32_t* cls) {
     DAE_CHECK_ARG(!order || (a0 == 0 && n_anchors == B), "batch_all: a dispatch order needs the whole batch");
+    DAE_CHECK_ARG(!cls || (a0 == 0 && n_anchors == B), "batch_all: class ranges need the whole batch");
     DAE_CHECK_ARG(a0 >= 0 && n_anchors > 0 && a0 + n_anchors <= B, "batch_all: anchors [%d, %d) outside the batch of %d", a0, a0 + n_anchors, B);
     const int pos_only = mode & DAE_MINER_POS_ONLY, fast = (mode & DAE_MINER_FAST) ? 1 : 0;
     DAE_CHECK_ARG(D_slabs && labels && loss_part && npos_part && G, "batch_all: null input");
@@ -616,7 +695,7 @@ int dae::launch_batch_all(const float* D_slabs, int d_splits, int64_t slab_strid
     // val + idx + 4 per-wave gradient rows (+ 4 count rows when pos_only) + scans + reductions
     const size_t lds = (size_t)Bp * (pos_only ? 52 : 32) + 2 * (TRIP_THREADS + 1) * sizeof(int) + 8 * sizeof(float);
     DAE_CHECK_ARG(lds <= 160 * 1024, "batch_all: batch %d needs %zu B of LDS (> 160 KiB)", B, lds);
-    typedef void (*ba_fn)(const float*, int, int64_t, int64_t, const int32_t*, int, int, float*, uint32_t*, float*, uint32_t*, int, int, const int32_t*);
+    typedef void (*ba_fn)(const float*, int, int64_t, int64_t, const int32_t*, int, int, float*, uint32_t*, float*, uint32_t*, int, int, const int32_t*, int, const int32_t*);
     ba_fn k = pos_only ? batch_all_kernel<true, 3> : batch_all_kernel<false, 3>;      // 3 workgroups per CU (168 VGPRs)
     static bool attr_done = false;
     if (!attr_done) {
@@ -625,8 +704,18 @@ int dae::launch_batch_all(const float* D_slabs, int d_splits, int64_t slab_strid
             DAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
-    hipLaunchKernelGGL(k, dim3(n_anchors), dim3(TRIP_THREADS), lds, st, D_slabs, d_splits, slab_stride, ldd, labels, B, Bp, loss_part, npos_part, G,
-                       role_cnt, fast, a0, order);
+    // at most one resident round: 3 workgroups per CU (168 VGPRs); the workgroups walk the anchor list in snake order (see the kernel)
+    static int slots = 0;
+    if (!slots) {
+        int dev = 0, cus = 0;
+        DAE_CHECK_HIP(hipGetDevice(&dev));
+        DAE_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        const int per_cu = (int)((160 * 1024) / lds) < 3 ? (int)((160 * 1024) / lds) : 3;
+        slots = cus * (per_cu < 1 ? 1 : per_cu);
+    }
+    const int nwg = (g_miner_pack && n_anchors > slots) ? slots : n_anchors;
+    hipLaunchKernelGGL(k, dim3(nwg), dim3(TRIP_THREADS), lds, st, D_slabs, d_splits, slab_stride, ldd, labels, B, Bp, loss_part, npos_part, G,
+                       role_cnt, fast, a0, order, n_anchors, cls);
     DAE_CHECK_LAUNCH();
     return 0;
 }

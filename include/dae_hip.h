@@ -419,9 +419,10 @@ int      dae_plan_sync_shadows(dae_plan* p, void* stream);
  * dW GEMM's epilogue), "tail" (bias gradients + statistics + x~^T un-scatter in one launch), "label_with_encode", "ce_literal"
  * (cross_entropy always by the reference-literal formula), "overlap" (miner chain on a side stream), "gram_fp32" (exact-fp32 Gram
  * matrix in bf16 mode; before dae_plan_bind only), "dw_bits" (binary CSR + bf16: x~^T reaches the dW kernel as a bit image and the A tiles of
- * its x~^T.delta1 segment are built in LDS -- default on; 0 = dense x~^T image, scattered and un-scattered every step), "encode_w32" (bf16 mode: the
+ * its x~^T.delta1 segment are built in LDS instead of streamed -- off by default: measured slower than the dense image), "miner_pack"
+ * (batch_all workgroups = one resident round, each walking the anchor list in snake order; 0 = one workgroup per anchor), "encode_w32" (bf16 mode: the
  * sparse encode reads the fp32 master weights, so h -- and with the split-bf16 Gram matrix the triplet leg -- is fp32-accurate; default
- * on; a sharded-optimizer exchange must turn it off because only W_lo is current on every rank), "encode_w32_cols" (64 | 128 columns
+ * on; a sharded-optimizer exchange must turn it off because only W_lo is current on every rank), "encode_w32_cols" (128 | 64 columns
  * per workgroup of that kernel).  Unknown names are an error. */
 int      dae_plan_set_option(dae_plan* p, const char* name, int32_t value);
 int      dae_train_step(dae_plan* p, const dae_step* step, void* stream);

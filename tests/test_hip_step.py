@@ -26,7 +26,7 @@ def _keep_bits(keep):
 
 
 def _run_case(dtype, strategy, loss_func, acts, opt, *, N=400, F=700, H=90, B=150, steps=2, seed=0, dense=False,
-              alpha=0.7, tol=None, options=None, scale=1.0, phase=0, engine_kw=None):
+              alpha=0.7, tol=None, options=None, scale=1.0, phase=0, engine_kw=None, sort_by_label=False):
     from dae_rnn_news_recommendation_amd import _lib as L
     from dae_rnn_news_recommendation_amd.engine import Engine
     rng = np.random.default_rng(seed)
@@ -52,6 +52,8 @@ def _run_case(dtype, strategy, loss_func, acts, opt, *, N=400, F=700, H=90, B=15
     out = []
     for s in range(steps):
         idx = rng.permutation(N)[:B]
+        if sort_by_label:                                   # a class-sorted mini-batch (what fit() hands over: utils.class_sort_batches)
+            idx = idx[np.argsort(lab[idx], kind="stable")]
         if dense:
             keep_d = rng.random((N, F)) >= 0.3
             xc_all = m.toarray() * keep_d
@@ -196,14 +198,14 @@ def test_dw_producer_consumer_kernel_equals_four_wave_kernel(opt):
 @pytest.mark.parametrize("opt", ["gradient_descent", "adam"])
 @pytest.mark.parametrize("strategy", ["none", "batch_all"])
 def test_dw_bit_image_of_xt_equals_dense_xt_image(opt, strategy):
-    """Binary CSR + bf16: x~^T reaches the dW kernel as a BIT image and the producer waves build the A tiles of the x~^T.delta1
-    segment in LDS (default); option dw_bits = 0 streams the dense bf16 x~^T image.  Same MFMA operands in the same order:
+    """Binary CSR + bf16, option dw_bits = 1: x~^T reaches the dW kernel as a BIT image and the producer waves build the A tiles of
+    the x~^T.delta1 segment in LDS; the default (0) streams the dense bf16 x~^T image.  Same MFMA operands in the same order:
     statistics, gradients and parameters are bit-identical -- and the bit image is clean again after every step."""
     from dae_rnn_news_recommendation_amd import _lib as L
     lib = L.load()
     try:
         lib.dae_set_glds(-5)
-        a, _, pa = _run_case("bf16", strategy, "cross_entropy", ("sigmoid", "sigmoid"), opt, steps=3, seed=61)
+        a, _, pa = _run_case("bf16", strategy, "cross_entropy", ("sigmoid", "sigmoid"), opt, steps=3, seed=61, options={"dw_bits": 1})
         b, _, pb = _run_case("bf16", strategy, "cross_entropy", ("sigmoid", "sigmoid"), opt, steps=3, seed=61, options={"dw_bits": 0})
     finally:
         lib.dae_set_glds(-4)
@@ -227,6 +229,7 @@ def test_dw_bit_image_dense_rows_and_global_atomics_fallback():
         lab = rng.integers(0, 3, N).astype(np.int32)
         W0 = torch.as_tensor(rng.uniform(-0.05, 0.05, (F, H)).astype(np.float32)).to(torch.bfloat16).float().numpy()
         eng = Engine(F, H, B, dtype="bf16", triplet="batch_all", learning_rate=0.05)
+        eng.set_option("dw_bits", 1)
         L.load().dae_set_glds(-5)
         try:
             eng.upload_csr(m); eng.set_params(W0)
@@ -245,7 +248,8 @@ def test_dw_bit_image_dense_rows_and_global_atomics_fallback():
 
 def test_dw_bit_image_with_decay_scale_matches_oracle():
     """corr_type 'decay' (scale 0.7 on every stored entry, utils.py:147-159): the built A tiles carry bf16(scale) per set bit."""
-    out, ref, got = _run_case("bf16", "batch_all", "cross_entropy", ("sigmoid", "sigmoid"), "gradient_descent", steps=2, seed=62, scale=0.7)
+    out, ref, got = _run_case("bf16", "batch_all", "cross_entropy", ("sigmoid", "sigmoid"), "gradient_descent", steps=2, seed=62, scale=0.7,
+                              options={"dw_bits": 1})
     for r, st, dW, dbh, dbv in out:
         assert abs(st[0] - r["cost"]) <= 3e-4 * abs(r["cost"])
         assert _rel(dW, r["dW"]) < 2e-2 and _rel(dbh, r["dbh"]) < 2e-2
@@ -328,6 +332,42 @@ def test_miner_dispatch_order_changes_nothing(dtype, B):
     kw = dict(steps=2, seed=41, B=B, N=max(400, 2 * B), F=700, H=90)
     a, _, pa = _run_case(dtype, "batch_all", "cross_entropy", ("sigmoid", "sigmoid"), "gradient_descent", **kw)
     b, _, pb = _run_case(dtype, "batch_all", "cross_entropy", ("sigmoid", "sigmoid"), "gradient_descent", options={"miner_order": 0}, **kw)
+    for (_, sa, dWa, dbha, dbva), (_, sb, dWb, dbhb, dbvb) in zip(a, b):
+        assert np.array_equal(sa[:6], sb[:6])
+        assert np.array_equal(dWa, dWb) and np.array_equal(dbha, dbhb) and np.array_equal(dbva, dbvb)
+    for u, v in zip(pa, pb):
+        assert np.array_equal(np.asarray(u), np.asarray(v))
+
+
+@pytest.mark.parametrize("dtype,B", [("bf16", 150), ("fp32", 333), ("bf16", 800)])
+def test_miner_class_range_path_equals_compaction(dtype, B):
+    """A class-sorted mini-batch (fit() sorts every batch by label) lets the batch_all miner take an anchor's positives and
+    negatives as index RANGES published by the label block (option miner_ranges, default on) instead of compacting them with
+    ballots.  Same slots, same sweep: bit-identical statistics, gradients and parameters -- and an unsorted batch silently
+    takes the compaction path (the other tests of this file)."""
+    kw = dict(steps=2, seed=43, B=B, N=max(400, 2 * B), F=700, H=90, sort_by_label=True)
+    a, _, pa = _run_case(dtype, "batch_all", "cross_entropy", ("sigmoid", "sigmoid"), "gradient_descent", **kw)
+    b, _, pb = _run_case(dtype, "batch_all", "cross_entropy", ("sigmoid", "sigmoid"), "gradient_descent", options={"miner_ranges": 0}, **kw)
+    for (ra, sa, dWa, dbha, dbva), (_, sb, dWb, dbhb, dbvb) in zip(a, b):
+        assert np.array_equal(sa[:6], sb[:6])
+        assert np.array_equal(dWa, dWb) and np.array_equal(dbha, dbhb) and np.array_equal(dbva, dbvb)
+        assert abs(sa[2] - ra["triplet_loss"]) <= (2e-5 if dtype == "fp32" else 2e-4) * abs(ra["triplet_loss"])      # and it is right
+    for u, v in zip(pa, pb):
+        assert np.array_equal(np.asarray(u), np.asarray(v))
+
+
+def test_miner_snake_packing_equals_one_workgroup_per_anchor():
+    """800 anchors on the chip's 768 resident slots: the launch has 768 workgroups and 32 of them take a second anchor (snake
+    order over the cost-sorted list; option miner_pack, default on).  Every anchor is still swept by one workgroup alone:
+    bit-identical to one workgroup per anchor."""
+    from dae_rnn_news_recommendation_amd import _lib as L
+    kw = dict(steps=2, seed=44, B=800, N=1600, F=700, H=90)
+    try:
+        a, _, pa = _run_case("bf16", "batch_all", "cross_entropy", ("sigmoid", "sigmoid"), "gradient_descent", options={"miner_pack": 1}, **kw)
+        b, _, pb = _run_case("bf16", "batch_all", "cross_entropy", ("sigmoid", "sigmoid"), "gradient_descent", options={"miner_pack": 0}, **kw)
+    finally:
+        from dae_rnn_news_recommendation_amd.engine import Engine
+        Engine(64, 8, 16).set_option("miner_pack", 1)                      # the switch is process-wide: leave it on
     for (_, sa, dWa, dbha, dbva), (_, sb, dWb, dbhb, dbvb) in zip(a, b):
         assert np.array_equal(sa[:6], sb[:6])
         assert np.array_equal(dWa, dWb) and np.array_equal(dbha, dbhb) and np.array_equal(dbva, dbvb)

@@ -189,3 +189,18 @@ def test_save_file_read_file_round_trips(tmp_path):
         H.save_file(m, d + "m.npy")                                   # scipy matrices only go to .npz
     with pytest.raises(AssertionError):
         H.read_file(d + "missing.npy")
+
+
+def test_class_sort_batches_keeps_every_batch_as_a_set():
+    """fit() hands every mini-batch over sorted by label: the rows of a batch are exactly those of the reference's shuffle."""
+    from dae_rnn_news_recommendation_amd.autoencoder import utils
+    rng = np.random.default_rng(0)
+    order = rng.permutation(1003); lab = rng.integers(0, 5, 1003)
+    out = utils.class_sort_batches(order, lab, 250)
+    assert sorted(out) == sorted(order)
+    for s in range(0, 1003, 250):
+        assert sorted(out[s:s + 250]) == sorted(order[s:s + 250])
+        assert (np.diff(lab[out[s:s + 250]]) >= 0).all()
+    # stable: rows of one class keep their shuffled order
+    first = out[:250]; want = [r for c in range(5) for r in order[:250] if lab[r] == c]
+    assert list(first) == want

@@ -17,6 +17,7 @@ ap.add_argument("--enc-splits", type=int, default=0); ap.add_argument("--tag", d
 ap.add_argument("--nst", type=int, default=-1); ap.add_argument("--phase", type=int, default=3); ap.add_argument("--gram-splits", type=int, default=0)
 ap.add_argument("--corr", default="philox", choices=["philox", "bits", "none"])
 ap.add_argument("--opt", action="append", default=[], help="plan option name=value (dae_plan_set_option), repeatable")
+ap.add_argument("--unsorted", action="store_true", help="batches in row order instead of class-sorted")
 ap.add_argument("--lib", default="", help="alternative libdae_hip build (probe variants; tools only)")
 a = ap.parse_args()
 if a.lib:
@@ -31,8 +32,11 @@ for o in a.opt:
 eng.upload_csr(m); eng.set_params(xavier_uniform(a.features, a.hidden))
 # the steps cycle through the rows // batch different batches of the set (fresh rows every step, as in training)
 nb = max(1, a.rows // a.batch)
-idxs = [torch.arange(b * a.batch, (b + 1) * a.batch, dtype=torch.int32, device="cuda") for b in range(nb)]
-labss = [torch.from_numpy(lab[b * a.batch:(b + 1) * a.batch]).cuda() for b in range(nb)]
+rows_b = [np.arange(b * a.batch, (b + 1) * a.batch) for b in range(nb)]
+if not a.unsorted:        # class-sorted batches, as fit() stages them (utils.class_sort_batches)
+    rows_b = [r[np.argsort(lab[r], kind="stable")] for r in rows_b]
+idxs = [torch.from_numpy(r.astype(np.int32)).cuda() for r in rows_b]
+labss = [torch.from_numpy(lab[r]).cuda() for r in rows_b]
 stats = torch.zeros(8, device="cuda")
 _step = [0]
 def one_step():

@@ -1,0 +1,18 @@
+#!/bin/bash
+set -u
+O=gpurun_out/r3c
+mkdir -p $O
+export TMPDIR=/tmp
+timeout 600 python -m pytest tests/test_hip_step.py tests/test_hip_fit.py tests/test_hip_kernels.py -q --maxfail=25 > $O/tests.log 2>&1
+tail -30 $O/tests.log | cut -c1-300
+for o in "" "--opt miner_pack=0" "--opt miner_ranges=0" "--opt miner_pack=0 --opt miner_ranges=0" "--unsorted" "--opt dw_bits=1"; do
+  timeout 200 python tools/kprof.py $o >> $O/kprof.txt 2>&1
+done
+timeout 300 python bench.py --steps 200 --warmup 20 --no-cpu-baseline > $O/bench.json 2> $O/bench.err
+tail -3 $O/bench.err
+cat $O/kprof.txt | grep -v amdgpu.ids
+python - <<'PY'
+import json
+d=json.load(open('gpurun_out/r3c/bench.json'))
+print('value', d['value'], 'ms/step', d['ms_per_step'], 'fit', {k:v.get('samples_per_s') for k,v in d['fit'].items() if isinstance(v,dict)}, 'fp32', d['fp32']['value'])
+PY
