@@ -266,6 +266,7 @@ extern "C" int dae_plan_set_option(dae_plan* p, const char* name, int32_t value)
     else if (!strcmp(name, "miner_order")) p->miner_order_ok = on;
     else if (!strcmp(name, "miner_ranges")) p->miner_ranges_ok = on;
     else if (!strcmp(name, "miner_pack")) set_miner_pack(on);        // process-wide (the launcher's choice), like dae_set_glds
+    else if (!strcmp(name, "miner_tile")) set_miner_tile(on);        // process-wide: 0 = the former wave-per-positive batch_all kernel
     else if (!strcmp(name, "sym_in_decode")) p->sym_ride_ok = on;
     else if (!strcmp(name, "gram_fp32")) {
         DAE_CHECK_ARG(!p->bound, "plan_set_option: gram_fp32 changes the workspace layout, set it before dae_plan_bind");

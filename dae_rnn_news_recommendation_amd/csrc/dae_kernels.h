@@ -96,6 +96,7 @@ int launch_batch_all(const float* D_slabs, int d_splits, int64_t slab_stride, in
                      hipStream_t st, const int32_t* cls = nullptr);
 
 void set_miner_pack(int on);
+void set_miner_tile(int on);
 
 // epilogue of the fused dW + optimizer GEMM (gemm_dw_opt): parameters updated in place from the gradient tile
 struct OptEpi {

@@ -15,6 +15,7 @@
 
 #include "dae_common.h"
 #include "dae_kernels.h"
+#include "dae_miner_tile.h"
 
 namespace dae {
 
@@ -262,8 +263,8 @@ __device__ __forceinline__ void batch_all_anchor(char* smem, const int ar, const
     int* idx = reinterpret_cast<int*>(val + Bp);              // [Bp]
     float* gpos = reinterpret_cast<float*>(idx + Bp);         // [Bp]    positive-role gradient sums (one owner wave each)
     float* pf = gpos + Bp;                                    // [Bp]    F_p = exp(mid - u_p) of the factorised sweep
-    float* gneg = pf + Bp;                                    // [4][Bp] per-wave negative-role partial sums
-    int* scan = reinterpret_cast<int*>(gneg + 4 * Bp);        // [2][TRIP_THREADS + 1]
+    float* gneg = pf + Bp;                                    // [4][Bp] per-wave negative-role partial sums (>= 1024 floats: the count's sorted runs)
+    int* scan = reinterpret_cast<int*>(gneg + (4 * Bp > 1024 ? 4 * Bp : 1024));        // [2][TRIP_THREADS + 1]
     float* red = reinterpret_cast<float*>(scan + 2 * (TRIP_THREADS + 1));   // [4]
     unsigned* redu = reinterpret_cast<unsigned*>(red + 4);    // [4]
     unsigned* cpos = POS_ONLY ? redu + 4 : nullptr;           // [Bp]    (pos_only role counts)
@@ -579,6 +580,273 @@ __global__ __launch_bounds__(TRIP_THREADS, OCC) void batch_all_kernel(const floa
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// batch_all, lane-grid form (dae_miner_tile.h): the kernel of the usual mini-batch (B <= 1024, all valid triplets).
+// One workgroup per anchor, ALL anchors resident at once (<= 128 VGPRs: 4 workgroups per CU = 1024 slots), so there is no
+// second round of workgroups and no packing.  Per anchor: D row -> positives / negatives (class ranges of a label-sorted batch,
+// else ballot compaction), exact count of the positive triplets from sorted runs, sweep variant by the row's range:
+//   range <= 40: pair-shared reciprocal, LOGW = 8 / 4 / 2 factors per logarithm (range <= 10 / 20 / 40); FAST (bf16 steps) or exact
+//   range <= 80: one reciprocal and one logarithm per cell (exp(t) = E_n F_p still finite)
+//   otherwise (and NaN / inf rows): exp(-|t|) per cell, the reference-literal stable form
+// ------------------------------------------------------------------------------------------------
+#if defined(DAE_MINER_PROBE) && (DAE_MINER_PROBE & 4)
+#define TILE_STAMP(i) do { if (threadIdx.x == 0) reinterpret_cast<unsigned long long*>(role_cnt)[(size_t)blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define TILE_STAMP(i) do { } while (0)
+#endif
+enum { MT_FAST = 0, MT_EXACT = 1, MT_CELL = 2, MT_DIRECT = 3 };
+
+// Sweep variants without the pair trick, same lane grid and the same outputs as tile_sweep.
+//   DIRECT = false: w = 1 + E_n F_p per cell, one v_rcp_f32 and one v_log_f32 per cell (row range <= 80)
+//   DIRECT = true : t = v_n - u_p, en = exp(-|t|), softplus = max(t, 0) + log1p(en), sigmoid = t >= 0 ? 1/(1+en) : en/(1+en)
+template <int Q2, bool DIRECT>
+__device__ __forceinline__ void tile_sweep_cells(const float* __restrict__ pu, const float* __restrict__ pf, const float* __restrict__ nv, float mid,
+                                                 int nP, int nN, int k0, bool first, float* __restrict__ gpos, float* __restrict__ gneg_w,
+                                                 float& loss) {
+    const int tid = threadIdx.x, lane = tid & 63, b = tid & 15, a = tid >> 4;
+    float x[2 * Q2], gs[2 * Q2];                                            // E_n (or v_n when DIRECT) and the column sums
+#pragma unroll
+    for (int m = 0; m < 2 * Q2; ++m) {
+        const int k = k0 + 16 * m + b;
+        const float v = (k < nN) ? nv[k] : -INFINITY;
+        x[m] = DIRECT ? v : __builtin_amdgcn_exp2f((v - mid) * kMtLog2e);
+        gs[m] = 0.f;
+    }
+    const int T = (nP + 15) >> 4;
+    for (int t = 0; t < T; ++t) {
+        const int j = a + 16 * t;
+        const float f = (j < nP) ? (DIRECT ? pu[j] : pf[j]) : (DIRECT ? INFINITY : 0.f);   // u = +inf -> t = -inf -> contributes nothing
+        float rs = 0.f;
+#pragma unroll
+        for (int m = 0; m < 2 * Q2; ++m) {
+            float sp, sg;
+            if constexpr (DIRECT) {
+                const float tt = x[m] - f;
+                const float en = __builtin_amdgcn_exp2f(-fabsf(tt) * kMtLog2e);
+                const float w = 1.0f + en;
+                const float r = __builtin_amdgcn_rcpf(w);
+                const float lg = 0.6931471805599453f * __builtin_amdgcn_logf(w);
+                const float l = en < 1e-4f ? en * (1.0f - 0.5f * en) : lg;
+                sp = fmaxf(tt, 0.f) + l;
+                sg = tt >= 0.f ? r : en * r;
+                if (!(tt == tt)) { sp = tt; sg = tt; }                      // NaN rows stay NaN
+                if (tt == -INFINITY) { sp = 0.f; sg = 0.f; }
+            } else {
+                const float e = x[m] * f;
+                const float w = 1.0f + e;
+                const float r = __builtin_amdgcn_rcpf(w);
+                const float lg = 0.6931471805599453f * __builtin_amdgcn_logf(w);
+                sp = e < 1e-4f ? e * (1.0f - 0.5f * e) : lg;
+                sg = e * r;
+            }
+            loss += sp; gs[m] += sg; rs += sg;
+        }
+        rs = row16_sum(rs);
+        if (b == 0 && j < nP) { if (first) gpos[j] = rs; else gpos[j] += rs; }
+    }
+#pragma unroll
+    for (int m = 0; m < 2 * Q2; ++m) {
+        const float c = mt_cross_row_sum(gs[m]);
+        const int k = k0 + 16 * m + b;
+        if (lane < 16 && k < nN) gneg_w[k] = c;
+    }
+}
+
+template <int OCC>
+__global__ __launch_bounds__(TRIP_THREADS, OCC) void batch_all_tile_kernel(const float* __restrict__ D_slabs, int d_splits, int64_t slab_stride,
+                                                                           int64_t ldd, const int32_t* __restrict__ labels, int B, int Bp,
+                                                                           float* __restrict__ loss_part, uint32_t* __restrict__ npos_part,
+                                                                           float* __restrict__ G, uint32_t* __restrict__ role_cnt, int fast, int a0,
+                                                                           const int32_t* __restrict__ order, const int32_t* __restrict__ cls) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* val = reinterpret_cast<float*>(smem);             // [Bp]  positives from the front, negatives from the back
+    int* idx = reinterpret_cast<int*>(val + Bp);              // [Bp]
+    float* gpos = reinterpret_cast<float*>(idx + Bp);         // [Bp]
+    float* pf = gpos + Bp;                                    // [Bp]  F_p = exp(mid - u_p)
+    float* gneg = pf + Bp;                                    // [4][Bp] per-wave negative-role partial sums; before the sweeps: the count's sorted runs (1024)
+    int* scan = reinterpret_cast<int*>(gneg + (4 * Bp > 1024 ? 4 * Bp : 1024));   // [2][16]
+    float* red = reinterpret_cast<float*>(scan + 32);         // [8]
+    unsigned* redu = reinterpret_cast<unsigned*>(red + 8);    // [4]
+
+    const int ar = order ? order[blockIdx.x] : (int)blockIdx.x;
+    const int a = a0 + ar;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    TILE_STAMP(0);
+    float* Grow = G + (int64_t)ar * Bp;
+    for (int j = tid; j < Bp; j += TRIP_THREADS) {
+        if (j >= B || j == a) Grow[j] = 0.f;
+        gpos[j] = 0.f;
+    }
+    constexpr int KU = 4;                                     // B <= 1024: element j = k * 256 + tid
+    int nP = 0, nN = 0;
+    float* pu = val;
+    float* nv;
+    int *pidx = idx, *nidx;
+    float lo = INFINITY, hi = -INFINITY;
+    float dj[KU];
+#pragma unroll
+    for (int k = 0; k < KU; ++k) dj[k] = 0.f;
+    const bool ranged = cls != nullptr && cls[0] != 0;
+    int32_t lj[KU];
+    const int32_t la = ranged ? 0 : labels[a];
+    if (!ranged) {
+#pragma unroll
+        for (int k = 0; k < KU; ++k) { const int j = k * TRIP_THREADS + tid; lj[k] = (j < B) ? labels[j] : la; }
+    }
+    for (int s0 = 0; s0 < d_splits; s0 += 4) {                // 4 K-slices of the Gram matrix at a time: 16 loads in flight
+        float dd[4][KU];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float* Drow = D_slabs + (int64_t)min(s0 + u, d_splits - 1) * slab_stride + (int64_t)ar * ldd;
+#pragma unroll
+            for (int k = 0; k < KU; ++k) dd[u][k] = Drow[min(k * TRIP_THREADS + tid, B - 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < KU; ++k) dj[k] += (s0 + u < d_splits) ? dd[u][k] : 0.f;
+    }
+    if (ranged) {
+        // class-sorted batch: positives are the index range [cs, ce) minus the anchor, negatives the rest (index arithmetic only)
+        const int cs = cls[1 + 2 * a], ce = cls[2 + 2 * a];
+        nP = ce - cs - 1; nN = B - (ce - cs);
+        nv = val + (Bp - nN); nidx = idx + (Bp - nN);
+#pragma unroll
+        for (int k = 0; k < KU; ++k) {
+            const int j = k * TRIP_THREADS + tid;
+            if (j < B && j != a) {
+                const float d = dj[k];
+                if (j >= cs && j < ce) { const int o = j - cs - (j > a ? 1 : 0); pu[o] = d; pidx[o] = j; }
+                else { const int o = j < cs ? j : j - (ce - cs); nv[o] = d; nidx[o] = j; }
+                lo = fminf(lo, d); hi = fmaxf(hi, d);
+            }
+        }
+    } else {
+        // deterministic compaction in index order (ballot ranks)
+        int* cntP = scan; int* cntN = scan + 16;
+        unsigned long long bp[KU], bn[KU];
+#pragma unroll
+        for (int k = 0; k < KU; ++k) {
+            const int j = k * TRIP_THREADS + tid;
+            const bool isP = (j < B) && (lj[k] == la) && (j != a);
+            const bool isN = (j < B) && (lj[k] != la);
+            bp[k] = __ballot(isP); bn[k] = __ballot(isN);
+            if (lane == 0) { cntP[k * 4 + wave] = __popcll(bp[k]); cntN[k * 4 + wave] = __popcll(bn[k]); }
+        }
+        __syncthreads();
+        int beforeP[KU], beforeN[KU];
+        int offP = 0, offN = 0;
+#pragma unroll
+        for (int k = 0; k < KU; ++k) {
+            beforeP[k] = offP; beforeN[k] = offN;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const int cp = cntP[k * 4 + w], cn = cntN[k * 4 + w];
+                if (w < wave) { beforeP[k] += cp; beforeN[k] += cn; }
+                offP += cp; offN += cn;
+            }
+        }
+        nP = offP; nN = offN;
+        nv = val + (Bp - nN); nidx = idx + (Bp - nN);
+        const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+        for (int k = 0; k < KU; ++k) {
+            const int j = k * TRIP_THREADS + tid;
+            const bool isP = (bp[k] >> lane) & 1ull, isN = (bn[k] >> lane) & 1ull;
+            if (isP) { const int o = beforeP[k] + __popcll(bp[k] & lt); pu[o] = dj[k]; pidx[o] = j; }
+            if (isN) { const int o = beforeN[k] + __popcll(bn[k] & lt); nv[o] = dj[k]; nidx[o] = j; }
+            if (isP || isN) { lo = fminf(lo, dj[k]); hi = fmaxf(hi, dj[k]); }
+        }
+    }
+    lo = wave_min(lo); hi = wave_max(hi);
+    if (lane == 0) { red[wave] = lo; red[4 + wave] = hi; }
+    __syncthreads();
+    lo = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
+    hi = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+    const float range = hi - lo;                              // NaN for NaN rows, inf for inf rows: every comparison below is then false
+    const float mid = 0.5f * (hi + lo);
+    const int kind = range <= 40.0f ? (fast ? MT_FAST : MT_EXACT) : (range <= 80.0f ? MT_CELL : MT_DIRECT);
+    if (kind != MT_DIRECT)
+        for (int k = tid; k < nP; k += TRIP_THREADS) pf[k] = __builtin_amdgcn_exp2f((mid - pu[k]) * kMtLog2e);
+    TILE_STAMP(1);
+    // exact count of the positive triplets (its sorted runs live in the gneg region, which the sweeps write only at a chunk's end)
+    unsigned cnt = count_positive_triplets(pu, nP, nv, nN, gneg);
+    __syncthreads();
+    TILE_STAMP(2);
+#if defined(DAE_MINER_PROBE) && (DAE_MINER_PROBE & 4)
+    const long long sweep_c0 = clock64();
+#endif
+
+    float loss = 0.f;
+    float* gneg_w = gneg + wave * Bp;
+    const int need2 = (nN + 31) / 32;                         // register pairs per lane that cover the negatives (16 columns x 2)
+    const int nch = (need2 + 11) / 12;
+    int q2 = nch > 0 ? (need2 + nch - 1) / nch : 4;
+    q2 = (q2 + 1) & ~1;
+    if (q2 < 4) q2 = 4;
+    auto pair_sweeps = [&](auto FASTV, auto LOGWV) {
+        constexpr bool FAST = decltype(FASTV)::value;
+        constexpr int LOGW = decltype(LOGWV)::value;
+        float loss_log2 = 0.f, loss_corr = 0.f;
+        for (int k0 = 0; k0 < nN; k0 += 32 * q2) {
+            const bool first = (k0 == 0);
+            switch (q2) {
+                case 12: tile_sweep<12, FAST, LOGW>(pf, nv, mid, nP, nN, k0, first, gpos, gneg_w, loss_log2, loss_corr); break;
+                case 10: tile_sweep<10, FAST, LOGW>(pf, nv, mid, nP, nN, k0, first, gpos, gneg_w, loss_log2, loss_corr); break;
+                case 8: tile_sweep<8, FAST, LOGW>(pf, nv, mid, nP, nN, k0, first, gpos, gneg_w, loss_log2, loss_corr); break;
+                case 6: tile_sweep<6, FAST, LOGW>(pf, nv, mid, nP, nN, k0, first, gpos, gneg_w, loss_log2, loss_corr); break;
+                default: tile_sweep<4, FAST, LOGW>(pf, nv, mid, nP, nN, k0, first, gpos, gneg_w, loss_log2, loss_corr); break;
+            }
+        }
+        loss = kLn2 * loss_log2 + loss_corr;
+    };
+    // LOGW factors (1 + exp(t)) <= 1 + e^range are multiplied before one v_log_f32: their product must stay finite
+    auto by_range = [&](auto FASTV) {
+        if (range <= 10.0f) pair_sweeps(FASTV, std::integral_constant<int, 8>{});
+        else if (range <= 20.0f) pair_sweeps(FASTV, std::integral_constant<int, 4>{});
+        else pair_sweeps(FASTV, std::integral_constant<int, 2>{});
+    };
+    auto cell_sweeps = [&](auto DIRECTV) {
+        constexpr bool DIRECT = decltype(DIRECTV)::value;
+        for (int k0 = 0; k0 < nN; k0 += 128) tile_sweep_cells<4, DIRECT>(pu, pf, nv, mid, nP, nN, k0, k0 == 0, gpos, gneg_w, loss);
+    };
+    if (kind == MT_FAST) {
+        by_range(std::true_type{});
+        // FAST drops the first-order log1p correction: |log(fl(1+e)) - log1p(e)| <= 2^-24 per triplet.  Accept when that is below
+        // 2e-6 of the anchor's sum (mean term >= 0.03 = softplus(-3.5)); otherwise every triplet is far on the satisfied side: exact form
+        const float lsum = block_sum_f(loss, red);
+        if (!(lsum >= 0.03f * (float)nP * (float)nN)) { __syncthreads(); by_range(std::false_type{}); }
+    } else if (kind == MT_EXACT) {
+        by_range(std::false_type{});
+    } else if (kind == MT_CELL) {
+        cell_sweeps(std::false_type{});
+    } else {
+        cell_sweeps(std::true_type{});
+    }
+    __syncthreads();
+    TILE_STAMP(3);
+#if defined(DAE_MINER_PROBE) && (DAE_MINER_PROBE & 4)
+    const unsigned long long sweep_cycles = (unsigned long long)(clock64() - sweep_c0);
+#endif
+    for (int k = tid; k < nP; k += TRIP_THREADS) Grow[pidx[k]] = -gpos[k];
+    for (int k = tid; k < nN; k += TRIP_THREADS) Grow[nidx[k]] = (gneg[k] + gneg[Bp + k]) + (gneg[2 * Bp + k] + gneg[3 * Bp + k]);
+    const float ltot = block_sum_f(loss, red);
+    const unsigned ctot = block_sum_u(cnt, redu);
+    if (tid == 0) { loss_part[ar] = ltot; npos_part[ar] = ctot; }
+    TILE_STAMP(4);
+#if defined(DAE_MINER_PROBE) && (DAE_MINER_PROBE & 4)
+    if (tid == 0) {
+        unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        const unsigned long long kd = kind <= MT_EXACT ? (range <= 10.f ? 8 : range <= 20.f ? 4 : 2) : (kind == MT_CELL ? 1 : 15);
+        reinterpret_cast<unsigned long long*>(role_cnt)[(size_t)blockIdx.x * 8 + 5] = (kd << 40) | ((unsigned long long)xcc << 32) | hw;
+        reinterpret_cast<unsigned long long*>(role_cnt)[(size_t)blockIdx.x * 8 + 6] = ((unsigned long long)nP << 32) | (unsigned)nN;
+        reinterpret_cast<unsigned long long*>(role_cnt)[(size_t)blockIdx.x * 8 + 7] = (sweep_cycles << 32) | (unsigned long long)__float_as_uint(range);
+    }
+#endif
+}
+
 }  // namespace dae
 namespace dae {
 
@@ -680,6 +948,8 @@ extern "C" int dae_triplet_batch_all_rows(const float* D_slabs, int32_t d_splits
 
 static int g_miner_pack = 1;       // 0: one workgroup per anchor (A/B; plan option "miner_pack")
 void dae::set_miner_pack(int on) { g_miner_pack = on ? 1 : 0; }
+static int g_miner_tile = 1;       // 0: the former wave-per-positive kernel also for B <= 1024 (A/B and equivalence tests; plan option "miner_tile")
+void dae::set_miner_tile(int on) { g_miner_tile = on ? 1 : 0; }
 
 // order: optional dispatch order of the anchors (LabelJob::order; whole-batch launches only)
 int dae::launch_batch_all(const float* D_slabs, int d_splits, int64_t slab_stride, int64_t ldd, const int32_t* labels, int B, int Bp, int a0,
@@ -693,8 +963,22 @@ int dae::launch_batch_all(const float* D_slabs, int d_splits, int64_t slab_strid
     DAE_CHECK_ARG(B > 0 && B <= Bp && Bp <= TRIP_MAX_B, "batch_all: batch %d (padded %d) exceeds the supported %d", B, Bp, TRIP_MAX_B);
     DAE_CHECK_ARG(!pos_only || role_cnt, "batch_all: role_cnt required with pos_triplets_only");
     // val + idx + 4 per-wave gradient rows (+ 4 count rows when pos_only) + scans + reductions
-    const size_t lds = (size_t)Bp * (pos_only ? 52 : 32) + 2 * (TRIP_THREADS + 1) * sizeof(int) + 8 * sizeof(float);
+    const size_t lds = (size_t)Bp * (pos_only ? 52 : 32) + (4 * Bp < 1024 ? (size_t)(1024 - 4 * Bp) * 4 : 0) + 2 * (TRIP_THREADS + 1) * sizeof(int) +
+                       8 * sizeof(float);
     DAE_CHECK_ARG(lds <= 160 * 1024, "batch_all: batch %d needs %zu B of LDS (> 160 KiB)", B, lds);
+    if (!pos_only && Bp <= 1024 && g_miner_tile) {
+        // the lane-grid kernel: one workgroup per anchor, all of them resident (4 per CU)
+        const size_t tl = (size_t)Bp * 16 + (size_t)(4 * Bp > 1024 ? 4 * Bp : 1024) * 4 + 32 * sizeof(int) + 12 * sizeof(float);
+        static bool tile_attr_done = false;
+        if (!tile_attr_done) {
+            DAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(batch_all_tile_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            tile_attr_done = true;
+        }
+        hipLaunchKernelGGL(batch_all_tile_kernel<4>, dim3(n_anchors), dim3(TRIP_THREADS), tl, st, D_slabs, d_splits, slab_stride, ldd, labels, B, Bp,
+                           loss_part, npos_part, G, role_cnt, fast, a0, order, cls);
+        DAE_CHECK_LAUNCH();
+        return 0;
+    }
     typedef void (*ba_fn)(const float*, int, int64_t, int64_t, const int32_t*, int, int, float*, uint32_t*, float*, uint32_t*, int, int, const int32_t*, int, const int32_t*);
     ba_fn k = pos_only ? batch_all_kernel<true, 3> : batch_all_kernel<false, 3>;      // 3 workgroups per CU (168 VGPRs)
     static bool attr_done = false;

@@ -1,0 +1,207 @@
+// miner_probe.hip -- stand-alone check + timing of the lane-grid batch_all sweep (csrc/dae_miner_tile.h) on a synthetic
+// mini-batch of the c2 shape (B = 800, four classes .27/.26/.36/.11): one workgroup per anchor, as in batch_all_kernel.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I dae_rnn_news_recommendation_amd/csrc tools/miner_probe.hip -o tools/miner_probe
+// Prints, per variant (FAST / exact, LOGW = 2 / 4 / 8): max relative error of loss / positive-role / negative-role sums against a
+// float64 CPU evaluation of sampled anchors, exact-count agreement, median cycles per anchor for the count and the sweep, and
+// the kernel's wall time (HIP events, 20 launches).  Tool only -- nothing here is linked into libdae_hip.so.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <algorithm>
+#include <vector>
+
+namespace dae { void set_error(const char*, ...) {} }
+#include "dae_miner_tile.h"
+
+using namespace dae;
+
+struct Anchor { int nP, nN, offP, offN; };
+
+__device__ __forceinline__ float blk_sum(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+template <bool FAST, int LOGW, int OCC>
+__global__ __launch_bounds__(256, OCC) void probe_kernel(const Anchor* __restrict__ anchors, const float* __restrict__ U,
+                                                         const float* __restrict__ V, int Bp, float* __restrict__ gpos_out,
+                                                         float* __restrict__ gneg_out, float* __restrict__ loss_out,
+                                                         unsigned* __restrict__ cnt_out, long long* __restrict__ stamps, int do_count) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* pu = reinterpret_cast<float*>(smem);          // [Bp]
+    float* nv = pu + Bp;                                  // [Bp]
+    float* gpos = nv + Bp;                                // [Bp]
+    float* pf = gpos + Bp;                                // [Bp]
+    float* gneg = pf + Bp;                                // [4][Bp]  (>= 1024 floats: the sort's scratch before the sweeps)
+    float* red = gneg + (4 * Bp > 1024 ? 4 * Bp : 1024);  // [8]
+    const Anchor A = anchors[blockIdx.x];
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const long long w0 = wall_clock64(), c0 = clock64();
+    const int nP = A.nP, nN = A.nN;
+    float lo = INFINITY, hi = -INFINITY;
+    for (int i = tid; i < nP; i += 256) { const float u = U[A.offP + i]; pu[i] = u; lo = fminf(lo, u); hi = fmaxf(hi, u); }
+    for (int i = tid; i < nN; i += 256) { const float v = V[A.offN + i]; nv[i] = v; lo = fminf(lo, v); hi = fmaxf(hi, v); }
+    lo = wave_min(lo); hi = wave_max(hi);
+    if ((tid & 63) == 0) { red[wave] = lo; red[4 + wave] = hi; }
+    __syncthreads();
+    lo = fminf(fminf(red[0], red[1]), fminf(red[2], red[3]));
+    hi = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+    const float mid = 0.5f * (lo + hi);
+    for (int i = tid; i < nP; i += 256) pf[i] = __builtin_amdgcn_exp2f((mid - pu[i]) * kMtLog2e);
+    __syncthreads();
+    const long long t0 = clock64(), w1 = wall_clock64();
+    unsigned cnt = 0u;
+    if (do_count) cnt = count_positive_triplets(pu, nP, nv, nN, gneg);
+    __syncthreads();
+    const long long t1 = clock64(), w2 = wall_clock64();
+    float loss_log2 = 0.f, loss_corr = 0.f;
+    const int need2 = (nN + 31) / 32;
+    const int nch = (need2 + 11) / 12;
+    int q2 = nch > 0 ? (need2 + nch - 1) / nch : 2;
+    q2 = (q2 + 1) & ~1;
+    if (q2 < 2) q2 = 2;
+    float* gneg_w = gneg + wave * Bp;
+    for (int k0 = 0; k0 < nN; k0 += 32 * q2) {
+        const bool first = k0 == 0;
+        switch (q2) {
+            case 12: tile_sweep<12, FAST, LOGW>(pf, nv, mid, nP, nN, k0, first, gpos, gneg_w, loss_log2, loss_corr); break;
+            case 10: tile_sweep<10, FAST, LOGW>(pf, nv, mid, nP, nN, k0, first, gpos, gneg_w, loss_log2, loss_corr); break;
+            case 8: tile_sweep<8, FAST, LOGW>(pf, nv, mid, nP, nN, k0, first, gpos, gneg_w, loss_log2, loss_corr); break;
+            case 6: tile_sweep<6, FAST, LOGW>(pf, nv, mid, nP, nN, k0, first, gpos, gneg_w, loss_log2, loss_corr); break;
+            case 4: tile_sweep<4, FAST, LOGW>(pf, nv, mid, nP, nN, k0, first, gpos, gneg_w, loss_log2, loss_corr); break;
+            default: tile_sweep<2, FAST, LOGW>(pf, nv, mid, nP, nN, k0, first, gpos, gneg_w, loss_log2, loss_corr); break;
+        }
+    }
+    __syncthreads();
+    const long long t2 = clock64(), w3 = wall_clock64();
+    for (int i = tid; i < nP; i += 256) gpos_out[A.offP + i] = gpos[i];
+    for (int i = tid; i < nN; i += 256) gneg_out[A.offN + i] = (gneg[i] + gneg[Bp + i]) + (gneg[2 * Bp + i] + gneg[3 * Bp + i]);
+    const float loss = blk_sum(0.6931471805599453f * loss_log2 + loss_corr, red);
+    cnt = wave_sum_u32(cnt);
+    __syncthreads();
+    if ((tid & 63) == 0) reinterpret_cast<unsigned*>(red)[wave] = cnt;
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned* ru = reinterpret_cast<const unsigned*>(red);
+        loss_out[blockIdx.x] = loss;
+        cnt_out[blockIdx.x] = ru[0] + ru[1] + ru[2] + ru[3];
+        stamps[blockIdx.x * 8] = t1 - t0;
+        stamps[blockIdx.x * 8 + 1] = t2 - t1;
+        stamps[blockIdx.x * 8 + 2] = w0; stamps[blockIdx.x * 8 + 3] = w1; stamps[blockIdx.x * 8 + 4] = w2; stamps[blockIdx.x * 8 + 5] = w3;
+        stamps[blockIdx.x * 8 + 6] = wall_clock64(); stamps[blockIdx.x * 8 + 7] = clock64() - c0;
+    }
+}
+
+typedef void (*pk_fn)(const Anchor*, const float*, const float*, int, float*, float*, float*, unsigned*, long long*, int);
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
+
+int main(int argc, char** argv) {
+    const int B = 800, Bp = 896;
+    const float spread = argc > 1 ? atof(argv[1]) : 0.3f;       // std of the D row entries (row range ~ 6-7 spreads)
+    const int sizes[4] = {216, 208, 288, 88};
+    std::vector<int> cls(B);
+    { int i = 0; for (int c = 0; c < 4; ++c) for (int k = 0; k < sizes[c]; ++k) cls[i++] = c; }
+    std::vector<Anchor> anchors(B);
+    std::vector<float> U, V;
+    srand(1234);
+    auto rnd = [&]() { float s = 0.f; for (int i = 0; i < 6; ++i) s += (float)rand() / RAND_MAX; return (s - 3.0f) * 1.4142f; };
+    for (int a = 0; a < B; ++a) {
+        const int n = sizes[cls[a]];
+        anchors[a] = Anchor{n - 1, B - n, (int)U.size(), (int)V.size()};
+        for (int i = 0; i < n - 1; ++i) U.push_back(0.1f + spread * rnd());
+        for (int i = 0; i < B - n; ++i) V.push_back(0.05f + spread * rnd());
+        // a few exact ties and near-ties to exercise the literal predicate of the count
+        if (n > 4) { V[anchors[a].offN + 1] = U[anchors[a].offP + 2]; V[anchors[a].offN + 3] = nextafterf(U[anchors[a].offP + 1], 10.f); }
+    }
+    // longest anchors first, as the label block orders them
+    std::vector<int> order(B);
+    for (int i = 0; i < B; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return (long)anchors[x].nP * anchors[x].nN > (long)anchors[y].nP * anchors[y].nN; });
+    std::vector<Anchor> sorted_anchors(B);
+    for (int i = 0; i < B; ++i) sorted_anchors[i] = anchors[order[i]];
+    Anchor* dA; float *dU, *dV, *dGp, *dGn, *dL; unsigned* dC; long long* dS;
+    CK(hipMalloc(&dA, B * sizeof(Anchor))); CK(hipMalloc(&dU, U.size() * 4)); CK(hipMalloc(&dV, V.size() * 4));
+    CK(hipMalloc(&dGp, U.size() * 4)); CK(hipMalloc(&dGn, V.size() * 4)); CK(hipMalloc(&dL, B * 4)); CK(hipMalloc(&dC, B * 4));
+    CK(hipMalloc(&dS, B * 8 * sizeof(long long)));
+    CK(hipMemcpy(dA, sorted_anchors.data(), B * sizeof(Anchor), hipMemcpyHostToDevice));
+    CK(hipMemcpy(dU, U.data(), U.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dV, V.data(), V.size() * 4, hipMemcpyHostToDevice));
+    const size_t lds = (size_t)(4 * Bp + (4 * Bp > 1024 ? 4 * Bp : 1024) + 8) * 4;
+    struct Var { const char* name; pk_fn f; bool fast; };
+    Var vars[] = {
+        {"FAST  LOGW=2 occ4", probe_kernel<true, 2, 4>, true}, {"FAST  LOGW=4 occ4", probe_kernel<true, 4, 4>, true},
+        {"FAST  LOGW=8 occ3", probe_kernel<true, 8, 3>, true}, {"FAST  LOGW=8 occ4", probe_kernel<true, 8, 4>, true},
+        {"FAST  LOGW=8 occ5", probe_kernel<true, 8, 5>, true}, {"FAST  LOGW=8 occ6", probe_kernel<true, 8, 6>, true},
+        {"exact LOGW=2 occ4", probe_kernel<false, 2, 4>, false}, {"exact LOGW=8 occ4", probe_kernel<false, 8, 4>, false},
+        {"exact LOGW=8 occ5", probe_kernel<false, 8, 5>, false},
+    };
+    // float64 reference of sampled anchors
+    const int NS = 12;
+    std::vector<int> sample;
+    for (int s = 0; s < NS; ++s) sample.push_back((s * 67 + 5) % B);
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (const Var& v : vars) {
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(v.f), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        for (int dc = 1; dc >= 0; --dc) {
+            hipLaunchKernelGGL(v.f, dim3(B), dim3(256), lds, 0, dA, dU, dV, Bp, dGp, dGn, dL, dC, dS, dc);
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0, 0));
+            for (int r = 0; r < 20; ++r) hipLaunchKernelGGL(v.f, dim3(B), dim3(256), lds, 0, dA, dU, dV, Bp, dGp, dGn, dL, dC, dS, dc);
+            CK(hipEventRecord(e1, 0));
+            CK(hipEventSynchronize(e1));
+            float ms = 0.f; CK(hipEventElapsedTime(&ms, e0, e1));
+            if (dc == 0) { printf("      without the count: kernel %.1f us\n", 1e3 * ms / 20); continue; }
+            std::vector<float> gp(U.size()), gn(V.size()), L(B); std::vector<unsigned> C(B); std::vector<long long> S(8 * B);
+            CK(hipMemcpy(gp.data(), dGp, gp.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(gn.data(), dGn, gn.size() * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(L.data(), dL, B * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(C.data(), dC, B * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(S.data(), dS, 8 * B * 8, hipMemcpyDeviceToHost));
+            double eL = 0, eP = 0, eN = 0; long cnt_bad = 0;
+            for (int si : sample) {
+                const Anchor& A = sorted_anchors[si];
+                double loss = 0; std::vector<double> rp(A.nP, 0.0), rn(A.nN, 0.0); unsigned long cnt = 0;
+                for (int p = 0; p < A.nP; ++p)
+                    for (int n = 0; n < A.nN; ++n) {
+                        const float u = U[A.offP + p], vv = V[A.offN + n];
+                        const double t = (double)vv - (double)u;
+                        loss += t > 0 ? t + log1p(exp(-t)) : log1p(exp(t));
+                        const double sg = 1.0 / (1.0 + exp(-t));
+                        rp[p] += sg; rn[n] += sg;
+                        const float tf = vv - u;
+                        cnt += tf > 1e-16f ? 1 : 0;
+                    }
+                eL = std::max(eL, fabs(L[si] - loss) / fabs(loss));
+                double mp = 0, mn = 0;
+                for (int p = 0; p < A.nP; ++p) mp = std::max(mp, fabs(rp[p]));
+                for (int n = 0; n < A.nN; ++n) mn = std::max(mn, fabs(rn[n]));
+                for (int p = 0; p < A.nP; ++p) eP = std::max(eP, fabs(gp[A.offP + p] - rp[p]) / mp);
+                for (int n = 0; n < A.nN; ++n) eN = std::max(eN, fabs(gn[A.offN + n] - rn[n]) / mn);
+                if (cnt != C[si]) ++cnt_bad;
+            }
+            std::vector<long long> c0, c1;
+            for (int i = 0; i < B; ++i) { c0.push_back(S[8 * i]); c1.push_back(S[8 * i + 1]); }
+            std::sort(c0.begin(), c0.end()); std::sort(c1.begin(), c1.end());
+            printf("%-20s kernel %6.1f us | count %6lld cyc  sweep %7lld cyc (median per anchor; max %lld) | err loss %.1e pos %.1e neg %.1e  count mismatches %ld/%d\n",
+                   v.name, 1e3 * ms / 20, c0[B / 2], c1[B / 2], c1[B - 1], eL, eP, eN, cnt_bad, NS);
+            {   // timeline of the last launch (100 MHz wall clock), relative to the first workgroup's start
+                long long first = S[2];
+                for (int i = 0; i < B; ++i) first = std::min(first, S[8 * i + 2]);
+                auto pct = [&](int col, int rel) {
+                    std::vector<double> x;
+                    for (int i = 0; i < B; ++i) x.push_back(0.01 * (double)(S[8 * i + col] - (rel ? S[8 * i + rel] : first)));
+                    std::sort(x.begin(), x.end());
+                    printf(" %6.2f %6.2f %6.2f %6.2f", x[0], x[B / 2], x[(9 * B) / 10], x[B - 1]);
+                };
+                printf("      timeline us (min med p90 max): start"); pct(2, 0); printf(" | prologue"); pct(3, 2); printf(" | count"); pct(4, 3);
+                printf(" | sweep"); pct(5, 4); printf(" | end"); pct(6, 0);
+                double ghz = 0; for (int i = 0; i < B; ++i) ghz += (double)S[8 * i + 7] / (10.0 * (double)(S[8 * i + 6] - S[8 * i + 2])); 
+                printf(" | clock %.2f GHz\n", ghz / B);
+            }
+        }
+    }
+    return 0;
+}

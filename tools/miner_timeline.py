@@ -9,6 +9,7 @@ import numpy as np, torch
 from dae_rnn_news_recommendation_amd import _lib as L
 ap = argparse.ArgumentParser()
 ap.add_argument("--lib", required=True); ap.add_argument("--batch", type=int, default=800)
+ap.add_argument("--unsorted", action="store_true", help="rows in set order instead of class-sorted (fit() sorts every batch by label)")
 a = ap.parse_args()
 L.LIB_PATH = os.path.abspath(a.lib)
 from dae_rnn_news_recommendation_amd.engine import Engine
@@ -17,7 +18,8 @@ F, H, B = 10000, 500, a.batch
 m = synthetic_csr(2 * B, F, seed=1); lab = synthetic_labels(2 * B, seed=1).astype(np.int32)
 eng = Engine(F, H, B, dtype="bf16", triplet="batch_all", loss_func="cross_entropy", learning_rate=0.1)
 eng.upload_csr(m); eng.set_params(xavier_uniform(F, H))
-idx = torch.arange(B, dtype=torch.int32, device="cuda"); labs = torch.from_numpy(lab[:B]).cuda(); stats = torch.zeros(8, device="cuda")
+rows = np.arange(B) if a.unsorted else np.argsort(lab[:B], kind="stable")
+idx = torch.from_numpy(rows.astype(np.int32)).cuda(); labs = torch.from_numpy(lab[rows]).cuda(); stats = torch.zeros(8, device="cuda")
 for _ in range(4):
     eng.train_step(idx, labs, stats, phase=3, corr_mode=L.CORR_PHILOX_MASK, seed=1, rng_stream=0, corr_frac=0.3)
 torch.cuda.synchronize()
@@ -27,7 +29,7 @@ t = eng.buffer("role_cnt", (Bp * Bp // 2,), torch.int64)[: nb * 8].cpu().numpy()
 st = t[:, :5].astype(np.float64) * 0.01          # us
 t0 = st[:, 0].min()
 print(f"workgroups {nb}; kernel span {st[:, 4].max() - t0:.1f} us (first start -> last end)")
-names = ["start (rel.)", "prologue: loads+compaction", "range + exp(pf)", "sweeps", "epilogue"]
+names = ["start (rel.)", "prologue: loads+lists+exp", "count: sort + search", "sweeps", "epilogue"]
 d = np.stack([st[:, 0] - t0, st[:, 1] - st[:, 0], st[:, 2] - st[:, 1], st[:, 3] - st[:, 2], st[:, 4] - st[:, 3]], 1)
 for i, n in enumerate(names):
     q = np.percentile(d[:, i], [0, 10, 50, 90, 100])
@@ -37,6 +39,12 @@ print("  end time percentiles:", np.round(np.percentile(end, [10, 50, 90, 99, 10
 late = np.argsort(st[:, 0])[-40:]
 print("  40 latest starters: start", np.round(d[late, 0].min(), 1), "-", np.round(d[late, 0].max(), 1), "us; their sweeps med", np.round(np.median(d[late, 3]), 1))
 xcc = (t[:, 5] >> 32) & 0xF; hw = t[:, 5] & 0xFFFFFFFF
+kind = (t[:, 5] >> 40) & 0xF
+print("  sweep kind per workgroup (8/4/2 = pair sweep with that many factors per log, 1 = per-cell, 15 = direct):", {int(k): int(v) for k, v in zip(*np.unique(kind, return_counts=True))})
+rng = (t[:, 7] & 0xFFFFFFFF).astype(np.uint32).view(np.float32)
+cyc = (t[:, 7] >> 32).astype(np.float64)
+print("  shader clock during the sweeps (s_memtime cycles / wall): med %.2f GHz" % np.median(cyc / np.maximum(d[:, 3], 1e-3) / 1e3))
+print("  D-row range (max - min over the anchor's positives and negatives): min %.2f  p10 %.2f  med %.2f  p90 %.2f  max %.2f" % tuple(np.percentile(rng, [0, 10, 50, 90, 100])))
 cu = (hw >> 8) & 0xF; se = (hw >> 13) & 0x7
 key = xcc * 1000 + se * 16 + cu
 u, c = np.unique(key, return_counts=True)

@@ -1,0 +1,14 @@
+#!/bin/bash
+# round-3 GPU pass 5: lean lane-grid miner kernel -- parity tests, timeline, A/B against the former kernel
+set -u
+O=gpurun_out/r3h
+mkdir -p $O
+export TMPDIR=/tmp
+timeout 300 python -m pytest tests/test_hip_kernels.py -q -x -k "miners" > $O/tests_miner.log 2>&1
+tail -5 $O/tests_miner.log | cut -c1-300
+timeout 200 python tools/miner_timeline.py --lib dae_rnn_news_recommendation_amd/libdae_mp4.so > $O/timeline.txt 2>&1
+cat $O/timeline.txt | grep -v amdgpu.ids
+for o in "" "--opt miner_tile=0" "--unsorted"; do
+  timeout 200 python tools/kprof.py $o >> $O/kprof.txt 2>&1
+done
+grep -v amdgpu.ids $O/kprof.txt
