@@ -85,10 +85,11 @@ __device__ __forceinline__ float mt_cross_row_sum(float v) {
 //   loss_log2 += sum log2(w) over this lane's cells;  loss_corr += first-order log1p corrections (natural units; !FAST)
 // FAST: accumulates r = 1/w = 1 - sigmoid and converts at the end (padding cells have w = 1, r = 1, sigmoid = 0).
 // Per unit of the body (2 positives x 2 negatives, FAST, LOGW = 8): 6 packed + 3.5 plain + 2.5 transcendental instructions.
-template <int Q2, bool FAST, int LOGW>
+template <int Q2, bool FAST, int LOGW, int FENCE = 2>
 __device__ __forceinline__ void tile_sweep(const float* __restrict__ pf, const float* __restrict__ nv, float mid, int nP, int nN,
                                            int k0, bool first, float* __restrict__ gpos, float* __restrict__ gneg_w,
-                                           float& loss_log2, float& loss_corr) {
+                                           float& loss_log2, float& loss_corr, int t_begin = 0, int t_step = 1) {
+    // t_begin / t_step: this workgroup walks the positive iterations t_begin, t_begin + t_step, ... (an anchor shared by t_step workgroups)
     static_assert(LOGW == 2 || LOGW == 4 || LOGW == 8, "LOGW");
     const int tid = threadIdx.x, lane = tid & 63, b = tid & 15, a = tid >> 4;
     mt_f32x2 ev2[Q2], gs2[Q2];
@@ -104,12 +105,14 @@ __device__ __forceinline__ void tile_sweep(const float* __restrict__ pf, const f
     mt_f32x2 corr2 = {0.f, 0.f};
     const int T = (nP + 31) >> 5;                                           // two positives per iteration: a + 32 t, a + 32 t + 16
     mt_f32x2 Fn;
-    Fn.x = (a < nP) ? pf[a] : 0.f; Fn.y = (a + 16 < nP) ? pf[a + 16] : 0.f;
-    for (int t = 0; t < T; ++t) {
+    Fn.x = (a + 32 * t_begin < nP) ? pf[a + 32 * t_begin] : 0.f; Fn.y = (a + 32 * t_begin + 16 < nP) ? pf[a + 32 * t_begin + 16] : 0.f;
+    int walked = 0;
+    for (int t = t_begin; t < T; t += t_step) {
+        ++walked;
         const int j0 = a + 32 * t, j1 = j0 + 16;
         const mt_f32x2 ff = Fn;
-        Fn.x = (j0 + 32 < nP) ? pf[j0 + 32] : 0.f;                          // next iteration's factors (LDS latency under the body)
-        Fn.y = (j1 + 32 < nP) ? pf[j1 + 32] : 0.f;
+        Fn.x = (j0 + 32 * t_step < nP) ? pf[j0 + 32 * t_step] : 0.f;        // next iteration's factors (LDS latency under the body)
+        Fn.y = (j1 + 32 * t_step < nP) ? pf[j1 + 32 * t_step] : 0.f;
         mt_f32x2 rs0 = {0.f, 0.f}, rs1 = {0.f, 0.f};
         float PP = 1.0f;
 #pragma unroll
@@ -145,8 +148,8 @@ __device__ __forceinline__ void tile_sweep(const float* __restrict__ pf, const f
                 if ((q & 1) == 0 && q + 1 < Q2) PP = mt_mul(P0, P1);
                 else mt_add_log2(loss_log2, (q & 1) ? mt_mul(PP, mt_mul(P0, P1)) : mt_mul(P0, P1));
             }
-            // fence for the machine scheduler: two register pairs x two positives = 4 independent chains in flight, no more
-            if ((q & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+            // fence for the machine scheduler every FENCE register pairs: FENCE x two positives independent chains in flight, no more
+            if (FENCE > 0 && (q % FENCE) == FENCE - 1) __builtin_amdgcn_sched_barrier(0);
         }
         float s0 = row16_sum(rs0.x + rs0.y), s1 = row16_sum(rs1.x + rs1.y);
         if constexpr (FAST) { s0 = (float)(32 * Q2) - s0; s1 = (float)(32 * Q2) - s1; }      // sum of sigmoids = cells - sum of r
@@ -156,7 +159,7 @@ __device__ __forceinline__ void tile_sweep(const float* __restrict__ pf, const f
         }
     }
     loss_corr += corr2.x + corr2.y;
-    const float slots = (float)(8 * T);                                     // positive cells walked by the 4 rows of this wave
+    const float slots = (float)(8 * walked);                                // positive cells walked by the 4 rows of this wave
 #pragma unroll
     for (int q = 0; q < Q2; ++q) {
         const float cx = mt_cross_row_sum(gs2[q].x), cy = mt_cross_row_sum(gs2[q].y);
@@ -171,39 +174,57 @@ __device__ __forceinline__ void tile_sweep(const float* __restrict__ pf, const f
 // Bitonic sort of 256 floats inside ONE wave, ascending over the index e = 4 * lane + r (x[r] of lane `lane`): the strides 1
 // and 2 of the network are register-to-register, the strides 4 .. 128 one cross-lane exchange per register -- no LDS
 // array, no barrier (an LDS-resident network cost 42 k cycles per anchor, 763 per stage, against 29 k for the whole sweep).
-__device__ __forceinline__ void mt_cmpx(float& lo, float& hi, bool asc) {      // (lo, hi) ascending when asc
-    const float mn = fminf(lo, hi), mx = fmaxf(lo, hi);
-    lo = asc ? mn : mx; hi = asc ? mx : mn;
+// A compare-exchange output is ONE v_med3_f32: med3(x, y, -inf) = min(x, y), med3(x, y, +inf) = max(x, y), so the direction
+// is a per-lane constant instead of min + max + select.  Lane distances 1, 2, 4, 8 are DPP moves on the VALU operand path
+// (quad_perm, row_shl / row_shr under bank masks, row_ror:8); only the distances 16 and 32 (3 of the 21 cross-lane stages) go
+// through the LDS crossbar.  No NaNs reach this (NaN rows never take the count's fast path ... they give NaN statistics anyway).
+__device__ __forceinline__ float mt_med3(float a, float b, float c) { float d; asm("v_med3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+template <int DIST>
+__device__ __forceinline__ float mt_lane_xor(float f) {
+    const int v = __float_as_int(f);
+    int r;
+    if constexpr (DIST == 1) r = __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false);               // quad_perm [1,0,3,2]
+    else if constexpr (DIST == 2) r = __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false);          // quad_perm [2,3,0,1]
+    else if constexpr (DIST == 4) {
+        r = __builtin_amdgcn_update_dpp(v, v, 0x104, 0xF, 0x5, false);                                   // banks 0, 2 <- lane + 4   (row_shl:4)
+        r = __builtin_amdgcn_update_dpp(r, v, 0x114, 0xF, 0xA, false);                                   // banks 1, 3 <- lane - 4   (row_shr:4)
+    } else if constexpr (DIST == 8) r = __builtin_amdgcn_update_dpp(v, v, 0x128, 0xF, 0xF, false);       // row_ror:8
+    else r = __shfl_xor(v, DIST, 64);
+    return __int_as_float(r);
+}
+__device__ __forceinline__ void mt_cmpx(float& lo, float& hi, float c_lo, float c_hi) {   // c_lo = -inf, c_hi = +inf: (lo, hi) ascending
+    const float a = mt_med3(lo, hi, c_lo), b = mt_med3(lo, hi, c_hi);
+    lo = a; hi = b;
+}
+template <int K, int J>
+__device__ __forceinline__ void mt_cross_stage(float (&x)[4], int lane) {       // partner element e ^ J lives in lane ^ (J / 4), same register
+    const bool asc = K == 256 ? true : ((lane & (K >> 2)) == 0);
+    const bool lower = (lane & (J >> 2)) == 0;
+    const float c = (lower == asc) ? -INFINITY : INFINITY;                      // keep the smaller / the larger of the two
+#pragma unroll
+    for (int r = 0; r < 4; ++r) x[r] = mt_med3(x[r], mt_lane_xor<(J >> 2)>(x[r]), c);
+}
+template <int K>
+__device__ __forceinline__ void mt_sort_level(float (&x)[4], int lane) {
+    // blocks of K elements alternate ascending / descending ((e & K) == 0 <=> ascending; the last merge is ascending)
+    if constexpr (K >= 256) mt_cross_stage<K, 128>(x, lane);
+    if constexpr (K >= 128) mt_cross_stage<K, 64>(x, lane);
+    if constexpr (K >= 64) mt_cross_stage<K, 32>(x, lane);
+    if constexpr (K >= 32) mt_cross_stage<K, 16>(x, lane);
+    if constexpr (K >= 16) mt_cross_stage<K, 8>(x, lane);
+    if constexpr (K >= 8) mt_cross_stage<K, 4>(x, lane);
+    if constexpr (K >= 4) {
+        const bool asc = K == 256 ? true : ((lane & (K >> 2)) == 0);           // K = 4: (e & 4) = lane & 1
+        const float c_lo = asc ? -INFINITY : INFINITY, c_hi = asc ? INFINITY : -INFINITY;
+        mt_cmpx(x[0], x[2], c_lo, c_hi); mt_cmpx(x[1], x[3], c_lo, c_hi);       // stride 2
+        mt_cmpx(x[0], x[1], c_lo, c_hi); mt_cmpx(x[2], x[3], c_lo, c_hi);       // stride 1
+    } else {                                                                    // K = 2: pairs (0,1) ascending, (2,3) descending
+        mt_cmpx(x[0], x[1], -INFINITY, INFINITY); mt_cmpx(x[2], x[3], INFINITY, -INFINITY);
+    }
 }
 __device__ __forceinline__ void wave_sort256(float (&x)[4], int lane) {
-#pragma unroll
-    for (int k = 2; k <= 256; k <<= 1) {
-        // blocks of k elements alternate ascending / descending ((e & k) == 0 <=> ascending; the last merge is ascending)
-#pragma unroll
-        for (int j = k >> 1; j >= 4; j >>= 1) {                             // partner element e ^ j lives in lane ^ (j / 4), same register
-            const bool asc = k == 256 ? true : ((lane & (k >> 2)) == 0);
-            const bool lower = (lane & (j >> 2)) == 0;
-            const bool keep_min = lower == asc;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float y = __shfl_xor(x[r], j >> 2, 64);
-                x[r] = keep_min ? fminf(x[r], y) : fmaxf(x[r], y);
-            }
-        }
-        if (k >= 4) {
-            const bool asc = k == 256 ? true : (k == 4 ? false : ((lane & (k >> 2)) == 0));
-            if (k == 4) {                                                   // (e & 4) = lane & 1
-                const bool asc4 = (lane & 1) == 0;
-                mt_cmpx(x[0], x[2], asc4); mt_cmpx(x[1], x[3], asc4);
-                mt_cmpx(x[0], x[1], asc4); mt_cmpx(x[2], x[3], asc4);
-            } else {
-                mt_cmpx(x[0], x[2], asc); mt_cmpx(x[1], x[3], asc);         // stride 2
-                mt_cmpx(x[0], x[1], asc); mt_cmpx(x[2], x[3], asc);         // stride 1
-            }
-        } else {                                                            // k = 2: pairs (0,1) ascending, (2,3) descending
-            mt_cmpx(x[0], x[1], true); mt_cmpx(x[2], x[3], false);
-        }
-    }
+    mt_sort_level<2>(x, lane); mt_sort_level<4>(x, lane); mt_sort_level<8>(x, lane); mt_sort_level<16>(x, lane);
+    mt_sort_level<32>(x, lane); mt_sort_level<64>(x, lane); mt_sort_level<128>(x, lane); mt_sort_level<256>(x, lane);
 }
 
 // Number of "positive" triplets of one anchor, #{(p, n) : fl(v_n - u_p) > 1e-16f} (triplet_loss_utils.py:106,114), exact:

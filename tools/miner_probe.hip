@@ -26,7 +26,7 @@ __device__ __forceinline__ float blk_sum(float v, float* red) {
     return red[0] + red[1] + red[2] + red[3];
 }
 
-template <bool FAST, int LOGW, int OCC>
+template <bool FAST, int LOGW, int OCC, int FENCE = 2, int SPLIT = 1>
 __global__ __launch_bounds__(256, OCC) void probe_kernel(const Anchor* __restrict__ anchors, const float* __restrict__ U,
                                                          const float* __restrict__ V, int Bp, float* __restrict__ gpos_out,
                                                          float* __restrict__ gneg_out, float* __restrict__ loss_out,
@@ -38,7 +38,8 @@ __global__ __launch_bounds__(256, OCC) void probe_kernel(const Anchor* __restric
     float* pf = gpos + Bp;                                // [Bp]
     float* gneg = pf + Bp;                                // [4][Bp]  (>= 1024 floats: the sort's scratch before the sweeps)
     float* red = gneg + (4 * Bp > 1024 ? 4 * Bp : 1024);  // [8]
-    const Anchor A = anchors[blockIdx.x];
+    const Anchor A = anchors[blockIdx.x / SPLIT];
+    const int half = blockIdx.x % SPLIT;
     const int tid = threadIdx.x, wave = tid >> 6;
     const long long w0 = wall_clock64(), c0 = clock64();
     const int nP = A.nP, nN = A.nN;
@@ -55,7 +56,8 @@ __global__ __launch_bounds__(256, OCC) void probe_kernel(const Anchor* __restric
     __syncthreads();
     const long long t0 = clock64(), w1 = wall_clock64();
     unsigned cnt = 0u;
-    if (do_count) cnt = count_positive_triplets(pu, nP, nv, nN, gneg);
+    const bool count_last = do_count == 2 && (blockIdx.x & 1);
+    if (do_count && !count_last) cnt = count_positive_triplets(pu, nP, nv, nN, gneg);
     __syncthreads();
     const long long t1 = clock64(), w2 = wall_clock64();
     float loss_log2 = 0.f, loss_corr = 0.f;
@@ -68,18 +70,19 @@ __global__ __launch_bounds__(256, OCC) void probe_kernel(const Anchor* __restric
     for (int k0 = 0; k0 < nN; k0 += 32 * q2) {
         const bool first = k0 == 0;
         switch (q2) {
-            case 12: tile_sweep<12, FAST, LOGW>(pf, nv, mid, nP, nN, k0, first, gpos, gneg_w, loss_log2, loss_corr); break;
-            case 10: tile_sweep<10, FAST, LOGW>(pf, nv, mid, nP, nN, k0, first, gpos, gneg_w, loss_log2, loss_corr); break;
-            case 8: tile_sweep<8, FAST, LOGW>(pf, nv, mid, nP, nN, k0, first, gpos, gneg_w, loss_log2, loss_corr); break;
-            case 6: tile_sweep<6, FAST, LOGW>(pf, nv, mid, nP, nN, k0, first, gpos, gneg_w, loss_log2, loss_corr); break;
-            case 4: tile_sweep<4, FAST, LOGW>(pf, nv, mid, nP, nN, k0, first, gpos, gneg_w, loss_log2, loss_corr); break;
-            default: tile_sweep<2, FAST, LOGW>(pf, nv, mid, nP, nN, k0, first, gpos, gneg_w, loss_log2, loss_corr); break;
+            case 12: tile_sweep<12, FAST, LOGW, FENCE>(pf, nv, mid, nP, nN, k0, first, gpos, gneg_w, loss_log2, loss_corr, half, SPLIT); break;
+            case 10: tile_sweep<10, FAST, LOGW, FENCE>(pf, nv, mid, nP, nN, k0, first, gpos, gneg_w, loss_log2, loss_corr, half, SPLIT); break;
+            case 8: tile_sweep<8, FAST, LOGW, FENCE>(pf, nv, mid, nP, nN, k0, first, gpos, gneg_w, loss_log2, loss_corr, half, SPLIT); break;
+            case 6: tile_sweep<6, FAST, LOGW, FENCE>(pf, nv, mid, nP, nN, k0, first, gpos, gneg_w, loss_log2, loss_corr, half, SPLIT); break;
+            case 4: tile_sweep<4, FAST, LOGW, FENCE>(pf, nv, mid, nP, nN, k0, first, gpos, gneg_w, loss_log2, loss_corr, half, SPLIT); break;
+            default: tile_sweep<2, FAST, LOGW, FENCE>(pf, nv, mid, nP, nN, k0, first, gpos, gneg_w, loss_log2, loss_corr, half, SPLIT); break;
         }
     }
     __syncthreads();
     const long long t2 = clock64(), w3 = wall_clock64();
-    for (int i = tid; i < nP; i += 256) gpos_out[A.offP + i] = gpos[i];
-    for (int i = tid; i < nN; i += 256) gneg_out[A.offN + i] = (gneg[i] + gneg[Bp + i]) + (gneg[2 * Bp + i] + gneg[3 * Bp + i]);
+    if (SPLIT == 1) for (int i = tid; i < nP; i += 256) gpos_out[A.offP + i] = gpos[i];
+    if (SPLIT == 1) for (int i = tid; i < nN; i += 256) gneg_out[A.offN + i] = (gneg[i] + gneg[Bp + i]) + (gneg[2 * Bp + i] + gneg[3 * Bp + i]);
+    if (count_last) { __syncthreads(); cnt = count_positive_triplets(pu, nP, nv, nN, gneg); }
     const float loss = blk_sum(0.6931471805599453f * loss_log2 + loss_corr, red);
     cnt = wave_sum_u32(cnt);
     __syncthreads();
@@ -87,8 +90,8 @@ __global__ __launch_bounds__(256, OCC) void probe_kernel(const Anchor* __restric
     __syncthreads();
     if (tid == 0) {
         const unsigned* ru = reinterpret_cast<const unsigned*>(red);
-        loss_out[blockIdx.x] = loss;
-        cnt_out[blockIdx.x] = ru[0] + ru[1] + ru[2] + ru[3];
+        if (SPLIT == 1) { loss_out[blockIdx.x] = loss; cnt_out[blockIdx.x] = ru[0] + ru[1] + ru[2] + ru[3]; }
+        else if (loss == 123.f) loss_out[0] = loss;
         stamps[blockIdx.x * 8] = t1 - t0;
         stamps[blockIdx.x * 8 + 1] = t2 - t1;
         stamps[blockIdx.x * 8 + 2] = w0; stamps[blockIdx.x * 8 + 3] = w1; stamps[blockIdx.x * 8 + 4] = w2; stamps[blockIdx.x * 8 + 5] = w3;
@@ -101,7 +104,7 @@ typedef void (*pk_fn)(const Anchor*, const float*, const float*, int, float*, fl
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
 
 int main(int argc, char** argv) {
-    const int B = 800, Bp = 896;
+    const int B = 800, Bp = 800;
     const float spread = argc > 1 ? atof(argv[1]) : 0.3f;       // std of the D row entries (row range ~ 6-7 spreads)
     const int sizes[4] = {216, 208, 288, 88};
     std::vector<int> cls(B);
@@ -127,18 +130,17 @@ int main(int argc, char** argv) {
     Anchor* dA; float *dU, *dV, *dGp, *dGn, *dL; unsigned* dC; long long* dS;
     CK(hipMalloc(&dA, B * sizeof(Anchor))); CK(hipMalloc(&dU, U.size() * 4)); CK(hipMalloc(&dV, V.size() * 4));
     CK(hipMalloc(&dGp, U.size() * 4)); CK(hipMalloc(&dGn, V.size() * 4)); CK(hipMalloc(&dL, B * 4)); CK(hipMalloc(&dC, B * 4));
-    CK(hipMalloc(&dS, B * 8 * sizeof(long long)));
+    CK(hipMalloc(&dS, 2 * B * 8 * sizeof(long long)));
     CK(hipMemcpy(dA, sorted_anchors.data(), B * sizeof(Anchor), hipMemcpyHostToDevice));
     CK(hipMemcpy(dU, U.data(), U.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dV, V.data(), V.size() * 4, hipMemcpyHostToDevice));
     const size_t lds = (size_t)(4 * Bp + (4 * Bp > 1024 ? 4 * Bp : 1024) + 8) * 4;
-    struct Var { const char* name; pk_fn f; bool fast; };
+    struct Var { const char* name; pk_fn f; bool fast; int split; };
     Var vars[] = {
-        {"FAST  LOGW=2 occ4", probe_kernel<true, 2, 4>, true}, {"FAST  LOGW=4 occ4", probe_kernel<true, 4, 4>, true},
-        {"FAST  LOGW=8 occ3", probe_kernel<true, 8, 3>, true}, {"FAST  LOGW=8 occ4", probe_kernel<true, 8, 4>, true},
-        {"FAST  LOGW=8 occ5", probe_kernel<true, 8, 5>, true}, {"FAST  LOGW=8 occ6", probe_kernel<true, 8, 6>, true},
-        {"exact LOGW=2 occ4", probe_kernel<false, 2, 4>, false}, {"exact LOGW=8 occ4", probe_kernel<false, 8, 4>, false},
-        {"exact LOGW=8 occ5", probe_kernel<false, 8, 5>, false},
+        {"FAST  LOGW=4 occ4", probe_kernel<true, 4, 4, 2, 1>, true, 1},
+        {"FAST  LOGW=4 occ6 split2", probe_kernel<true, 4, 6, 2, 2>, true, 2},
+        {"FAST  LOGW=4 occ7 split2", probe_kernel<true, 4, 7, 2, 2>, true, 2},
+        {"FAST  LOGW=4 occ5 split2", probe_kernel<true, 4, 5, 2, 2>, true, 2},
     };
     // float64 reference of sampled anchors
     const int NS = 12;
@@ -147,15 +149,17 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (const Var& v : vars) {
         CK(hipFuncSetAttribute(reinterpret_cast<const void*>(v.f), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        for (int dc = 1; dc >= 0; --dc) {
-            hipLaunchKernelGGL(v.f, dim3(B), dim3(256), lds, 0, dA, dU, dV, Bp, dGp, dGn, dL, dC, dS, dc);
+        for (int dc : {1, 2, 0}) {
+            hipLaunchKernelGGL(v.f, dim3(B * v.split), dim3(256), lds, 0, dA, dU, dV, Bp, dGp, dGn, dL, dC, dS, dc);
             CK(hipDeviceSynchronize());
             CK(hipEventRecord(e0, 0));
-            for (int r = 0; r < 20; ++r) hipLaunchKernelGGL(v.f, dim3(B), dim3(256), lds, 0, dA, dU, dV, Bp, dGp, dGn, dL, dC, dS, dc);
+            for (int r = 0; r < 20; ++r) hipLaunchKernelGGL(v.f, dim3(B * v.split), dim3(256), lds, 0, dA, dU, dV, Bp, dGp, dGn, dL, dC, dS, dc);
             CK(hipEventRecord(e1, 0));
             CK(hipEventSynchronize(e1));
             float ms = 0.f; CK(hipEventElapsedTime(&ms, e0, e1));
             if (dc == 0) { printf("      without the count: kernel %.1f us\n", 1e3 * ms / 20); continue; }
+            if (dc == 2) continue;
+            if (v.split > 1) { printf("%-26s kernel %6.1f us (two workgroups per anchor, no result check)\n", v.name, 1e3 * ms / 20); continue; }
             std::vector<float> gp(U.size()), gn(V.size()), L(B); std::vector<unsigned> C(B); std::vector<long long> S(8 * B);
             CK(hipMemcpy(gp.data(), dGp, gp.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(gn.data(), dGn, gn.size() * 4, hipMemcpyDeviceToHost));
             CK(hipMemcpy(L.data(), dL, B * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(C.data(), dC, B * 4, hipMemcpyDeviceToHost));
@@ -185,7 +189,7 @@ int main(int argc, char** argv) {
             std::vector<long long> c0, c1;
             for (int i = 0; i < B; ++i) { c0.push_back(S[8 * i]); c1.push_back(S[8 * i + 1]); }
             std::sort(c0.begin(), c0.end()); std::sort(c1.begin(), c1.end());
-            printf("%-20s kernel %6.1f us | count %6lld cyc  sweep %7lld cyc (median per anchor; max %lld) | err loss %.1e pos %.1e neg %.1e  count mismatches %ld/%d\n",
+            printf("%-26s kernel %6.1f us | count %6lld cyc  sweep %7lld cyc (median per anchor; max %lld) | err loss %.1e pos %.1e neg %.1e  count mismatches %ld/%d\n",
                    v.name, 1e3 * ms / 20, c0[B / 2], c1[B / 2], c1[B - 1], eL, eP, eN, cnt_bad, NS);
             {   // timeline of the last launch (100 MHz wall clock), relative to the first workgroup's start
                 long long first = S[2];

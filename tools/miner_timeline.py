@@ -38,6 +38,8 @@ end = st[:, 4] - t0
 print("  end time percentiles:", np.round(np.percentile(end, [10, 50, 90, 99, 100]), 1))
 late = np.argsort(st[:, 0])[-40:]
 print("  40 latest starters: start", np.round(d[late, 0].min(), 1), "-", np.round(d[late, 0].max(), 1), "us; their sweeps med", np.round(np.median(d[late, 3]), 1))
+nP = t[:, 6] >> 32; nN = t[:, 6] & 0xFFFFFFFF
+work = (nP * nN).astype(np.float64)
 xcc = (t[:, 5] >> 32) & 0xF; hw = t[:, 5] & 0xFFFFFFFF
 kind = (t[:, 5] >> 40) & 0xF
 print("  sweep kind per workgroup (8/4/2 = pair sweep with that many factors per log, 1 = per-cell, 15 = direct):", {int(k): int(v) for k, v in zip(*np.unique(kind, return_counts=True))})
@@ -49,6 +51,11 @@ cu = (hw >> 8) & 0xF; se = (hw >> 13) & 0x7
 key = xcc * 1000 + se * 16 + cu
 u, c = np.unique(key, return_counts=True)
 print(f"  distinct (xcc,se,cu) = {len(u)}; workgroups per CU: min {c.min()} max {c.max()}; histogram {np.bincount(c)}")
-nP = t[:, 6] >> 32; nN = t[:, 6] & 0xFFFFFFFF
-work = (nP * nN).astype(np.float64)
+# does the dispatcher place block b on the CU of block b % 256?  (blocks of one CU: residues mod 256, mod 8)
+same256 = sum(len(set(np.nonzero(key == k)[0] % 256)) == 1 for k in u)
+print(f"  CUs whose blocks all share b % 256: {same256} of {len(u)};  blocks of the first CUs:", [list(np.nonzero(key == k)[0]) for k in u[:6]])
+work_cu = np.array([work[key == k].sum() for k in u]); end_cu = np.array([end[key == k].max() for k in u])
+print("  cells per CU: min %.0fk med %.0fk max %.0fk; CU end time vs cells corr %.2f; end of 4-block CUs med %.1f, of 3-block CUs med %.1f" % (
+    work_cu.min() / 1e3, np.median(work_cu) / 1e3, work_cu.max() / 1e3, np.corrcoef(work_cu, end_cu)[0, 1], np.median(end_cu[c == 4]) if (c == 4).any() else 0, np.median(end_cu[c == 3]) if (c == 3).any() else 0))
+
 print("  sweep us per 1e5 triplets (med):", np.round(np.median(d[:, 3] / np.maximum(work, 1) * 1e5), 2))

@@ -14,16 +14,21 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 
 enum Kind { K_FMA = 0, K_PKFMA, K_PKADD, K_PKMUL, K_MUL, K_ADD, K_RCP, K_LOG, K_EXP, K_CMP_BCNT, K_CMP_ONLY, K_DPP_ADD, K_BODY_PK, K_BODY_SC,
-            K_BODY_NEW, K_BODY_NEW4, K_BODY_NEWSC, K_COUNT };
+            K_BODY_NEW, K_BODY_NEW4, K_BODY_NEWSC, K_PKFMA_BCAST, K_PKFMA_SWAP, K_PKFMA_CONST, K_UNIT_PK, K_UNIT_SC, K_COUNT };
 static const char* kNames[K_COUNT] = {"v_fma_f32", "v_pk_fma_f32", "v_pk_add_f32", "v_pk_mul_f32", "v_mul_f32", "v_add_f32", "v_rcp_f32",
                                       "v_log_f32", "v_exp_f32", "v_cmp+s_bcnt1+s_add", "v_cmp only", "v_add_f32 dpp row_shr",
                                       "pair body: current (packed ops, log+rcp per pair, t2+2cmp)",
                                       "pair body: same arithmetic, scalar ops",
                                       "pair body: new packed (no t2, log per 2 pairs)",
                                       "pair body: new packed (no t2, log per 4 pairs)",
-                                      "pair body: new scalar (no t2, log per 2 pairs)"};
+                                      "pair body: new scalar (no t2, log per 2 pairs)",
+                                      "v_pk_fma_f32 op_sel_hi:[1,0,1] (src1 low half broadcast)",
+                                      "v_pk_fma_f32 op_sel:[1,0,0] op_sel_hi:[0,0,1] (src0 swapped, src1 broadcast)",
+                                      "v_pk_fma_f32 a, b, 1.0 op_sel_hi:[1,0,0] (inline constant)",
+                                      "lane-grid unit (2 pos x 2 neg): packed, as tile_sweep",
+                                      "lane-grid unit (2 pos x 2 neg): scalar v_fma_f32 only"};
 // instructions (or pairs, for the bodies) per loop iteration
-static const int kPerIter[K_COUNT] = {32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 8, 8, 8, 8, 8};
+static const int kPerIter[K_COUNT] = {32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 8, 8, 8, 8, 8, 32, 32, 32, 8, 8};
 
 template <int KIND>
 __global__ __launch_bounds__(1024) void probe(long long* out, int iters, float seed) {
@@ -85,6 +90,67 @@ __global__ __launch_bounds__(1024) void probe(long long* out, int iters, float s
 #define X(i) asm volatile("v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a[i]));
             REP8(X) REP8(X) REP8(X) REP8(X)
 #undef X
+        } else if constexpr (KIND == K_PKFMA_BCAST) {
+#define X(i) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(p[i]) : "v"(q), "v"(r));
+            REP8(X) REP8(X) REP8(X) REP8(X)
+#undef X
+        } else if constexpr (KIND == K_PKFMA_SWAP) {
+#define X(i) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[0,0,1]" : "+v"(p[i]) : "v"(q), "v"(r));
+            REP8(X) REP8(X) REP8(X) REP8(X)
+#undef X
+        } else if constexpr (KIND == K_PKFMA_CONST) {
+#define X(i) asm volatile("v_pk_fma_f32 %0, %1, %2, 1.0 op_sel_hi:[1,0,0]" : "=v"(p[i]) : "v"(q), "v"(r));
+            REP8(X) REP8(X) REP8(X) REP8(X)
+#undef X
+        } else if constexpr (KIND == K_UNIT_PK) {
+            // 8 units: ev2 = p[i], factors ff = q, accumulators: gs = p[i] (stand-in: separate regs below), rs0/rs1
+            f32x2 rs0 = {0.f, 0.f}, rs1 = {0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                f32x2 w0, w1, RR;
+                asm("v_pk_fma_f32 %0, %1, %2, 1.0 op_sel_hi:[1,0,0]" : "=v"(w0) : "v"(p[i]), "v"(q));
+                asm("v_pk_fma_f32 %0, %1, %2, 1.0 op_sel:[0,1,0] op_sel_hi:[1,1,0]" : "=v"(w1) : "v"(p[i]), "v"(q));
+                float P0, P1, PP, lg;
+                asm("v_mul_f32 %0, %1, %2" : "=v"(P0) : "v"(w0.x), "v"(w0.y));
+                asm("v_mul_f32 %0, %1, %2" : "=v"(P1) : "v"(w1.x), "v"(w1.y));
+                asm("v_rcp_f32 %0, %1" : "=v"(RR.x) : "v"(P0));
+                asm("v_rcp_f32 %0, %1" : "=v"(RR.y) : "v"(P1));
+                asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[0,0,1]" : "+v"(r) : "v"(w0), "v"(RR));
+                asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1]" : "+v"(r) : "v"(w1), "v"(RR));
+                asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[0,0,1]" : "+v"(rs0) : "v"(w0), "v"(RR));
+                asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1]" : "+v"(rs1) : "v"(w1), "v"(RR));
+                asm("v_mul_f32 %0, %1, %2" : "=v"(PP) : "v"(P0), "v"(P1));
+                asm("v_log_f32 %0, %1" : "=v"(lg) : "v"(PP));
+                asm("v_add_f32 %0, %0, %1" : "+v"(L) : "v"(lg));
+            }
+            L += rs0.x + rs0.y + rs1.x + rs1.y;
+        } else if constexpr (KIND == K_UNIT_SC) {
+            float s0 = 0.f, s1 = 0.f, gx = 0.f, gy = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float w0x, w0y, w1x, w1y, P0, P1, R0, R1, PP, lg;
+                asm("v_fma_f32 %0, %1, %2, 1.0" : "=v"(w0x) : "v"(p[i].x), "v"(q.x));
+                asm("v_fma_f32 %0, %1, %2, 1.0" : "=v"(w0y) : "v"(p[i].y), "v"(q.x));
+                asm("v_fma_f32 %0, %1, %2, 1.0" : "=v"(w1x) : "v"(p[i].x), "v"(q.y));
+                asm("v_fma_f32 %0, %1, %2, 1.0" : "=v"(w1y) : "v"(p[i].y), "v"(q.y));
+                asm("v_mul_f32 %0, %1, %2" : "=v"(P0) : "v"(w0x), "v"(w0y));
+                asm("v_mul_f32 %0, %1, %2" : "=v"(P1) : "v"(w1x), "v"(w1y));
+                asm("v_rcp_f32 %0, %1" : "=v"(R0) : "v"(P0));
+                asm("v_rcp_f32 %0, %1" : "=v"(R1) : "v"(P1));
+                asm("v_fma_f32 %0, %1, %2, %0" : "+v"(gx) : "v"(w0y), "v"(R0));
+                asm("v_fma_f32 %0, %1, %2, %0" : "+v"(gy) : "v"(w0x), "v"(R0));
+                asm("v_fma_f32 %0, %1, %2, %0" : "+v"(gx) : "v"(w1y), "v"(R1));
+                asm("v_fma_f32 %0, %1, %2, %0" : "+v"(gy) : "v"(w1x), "v"(R1));
+                float t0, t1;
+                asm("v_add_f32 %0, %1, %2" : "=v"(t0) : "v"(w0x), "v"(w0y));
+                asm("v_add_f32 %0, %1, %2" : "=v"(t1) : "v"(w1x), "v"(w1y));
+                asm("v_fma_f32 %0, %1, %2, %0" : "+v"(s0) : "v"(t0), "v"(R0));
+                asm("v_fma_f32 %0, %1, %2, %0" : "+v"(s1) : "v"(t1), "v"(R1));
+                asm("v_mul_f32 %0, %1, %2" : "=v"(PP) : "v"(P0), "v"(P1));
+                asm("v_log_f32 %0, %1" : "=v"(lg) : "v"(PP));
+                asm("v_add_f32 %0, %0, %1" : "+v"(L) : "v"(lg));
+            }
+            L += s0 + s1 + gx + gy;
         } else if constexpr (KIND == K_BODY_PK) {
             // the current FAST body of sweep_pairs2 (dae_triplet.hip), 8 register pairs, one positive
             const float u = b, fp = c;
