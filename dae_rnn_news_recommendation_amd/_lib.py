@@ -57,6 +57,7 @@ SIGNATURES = {
     "dae_last_error": (C.c_char_p, []),
     "dae_pad": (i64, [i64]),
     "dae_set_glds": (None, [i32]),
+    "dae_gemm_w8_splits": (i32, [i32, i32, i32, i32]),
     "dae_gather_csr": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp, i64, vp, i64, vp, i32, vp, u64, u32, f32, f32, vp]),
     "dae_gather_csr_bits": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp, i64, vp, i64, vp, i32, vp, u64, u32, f32, f32, vp,
                                   i64, vp]),

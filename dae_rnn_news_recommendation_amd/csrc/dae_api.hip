@@ -24,6 +24,7 @@ extern "C" int dae_abi_version(void) { return DAE_ABI_VERSION; }
 extern "C" const char* dae_last_error(void) { return g_err; }
 extern "C" int64_t dae_pad(int64_t n) { return pad128(n); }
 extern "C" void dae_set_glds(int32_t nst) { set_use_glds(nst); }
+extern "C" int32_t dae_gemm_w8_splits(int32_t dtype, int32_t M, int32_t N, int32_t K) { return gemm_w8_splits(dtype, M, N, K * (dtype == DAE_BF16 ? 2 : 4) / 128); }
 extern "C" int32_t dae_decode_tile_n(int32_t dtype) { return decode_tile_n(dtype); }
 
 extern "C" int dae_gemm_nt(int32_t dtype, int32_t M, int32_t N, const void* A0, int64_t lda0, const void* Bt0, int64_t ldb0,
@@ -213,6 +214,9 @@ extern "C" int dae_plan_create(const dae_config* cfg, dae_plan** out) {
     p->s_dh = cfg->dh_splits > 0 ? cfg->dh_splits : auto_splits(tiles_bh, kt_f);
     const int tiles_bb = (p->Bpm / 128) * (p->Bpm / 128);
     p->s_gram = cfg->gram_splits > 0 ? cfg->gram_splits : auto_splits(tiles_bb, p->Hp * 4 / 128);
+    // large dense-input shapes: the 256 x 256 kernel picks its own slice count (one workgroup per CU)
+    if (cfg->encode_splits <= 0) if (const int w = gemm_w8_splits(cfg->dtype, p->Bpm, p->Hp, kt_f)) p->s_enc = w;
+    if (cfg->dh_splits <= 0) if (const int w = gemm_w8_splits(cfg->dtype, p->Bpm, p->Hp, kt_f + p->Bpm * p->es / 128)) p->s_dh = w;
     if (p->s_enc > kt_f) p->s_enc = kt_f;
     if (p->s_dh > kt_f) p->s_dh = kt_f;
     if (p->s_gram > p->Hp * 4 / 128) p->s_gram = p->Hp * 4 / 128;

@@ -401,6 +401,10 @@ static int grid_blocks(const GemmParams& p) {
     return 8 * ((big + 7) / 8) * small;
 }
 
+}  // namespace dae
+#include "dae_gemm_w8.h"      // 256 x 256 tiles, 8 MFMA waves: the large split-K contractions (uses GemmSeg / Mma / wait_vm above)
+namespace dae {
+
 // ------------------------------------------------------------------------------------------------
 // plain fp32-output kernel (split-K slabs or final C)
 // ------------------------------------------------------------------------------------------------
@@ -1673,6 +1677,33 @@ static int gemm_init() {
     return rc;
 }
 
+static int g_w8 = 1;         // 256 x 256 / 8-MFMA-wave kernel for the large split-K contractions (dae_set_glds(-6) disables, -7 enables)
+typedef void (*w8_fn)(W8Params, float*, int64_t, int64_t);
+static w8_fn w8_kernel(int role) {
+    switch (role) {
+        case ROLE_ENCODE: return gemm_nt_w8<ROLE_ENCODE>;
+        case ROLE_DH: return gemm_nt_w8<ROLE_DH>;
+        case ROLE_DW: return gemm_nt_w8<ROLE_DW>;
+        case ROLE_GRAM: return gemm_nt_w8<ROLE_GRAM>;
+        default: return gemm_nt_w8<ROLE_GENERIC>;
+    }
+}
+// Does the 256 x 256 kernel pay for this shape, and with how many K slices?  bf16, at most one workgroup per CU and at least 60 % of
+// the CUs busy, >= 16 K tiles per workgroup (its 2-tile prologue and the 256 KiB slab it writes must be amortised); slices in
+// multiples of 8 so that one slice maps to one XCD.  0 = the shape stays on the 128 x 128 kernels.  The plan sizes its slab
+// workspace with this number, and launch_gemm_f32out takes the 256 x 256 path exactly when it is handed the same number.
+int gemm_w8_splits(int dtype, int M, int N, int ktiles) {
+    if (gemm_init()) return 0;
+    if (!g_w8 || dtype != DAE_BF16 || g_cus <= 0) return 0;
+    const int tiles = ((M + W8_BM - 1) / W8_BM) * ((N + W8_BN - 1) / W8_BN);
+    if (M < 512 || N < 512 || tiles > g_cus) return 0;
+    int s = g_cus / tiles;
+    if (s >= 8) s = (s / 8) * 8;
+    if (s > 16) s = 16;
+    while (s > 1 && ktiles / s < 16) s = s > 8 ? s - 8 : s / 2;
+    if (s < 1 || ktiles / s < 16 || 10 * tiles * s < 6 * g_cus) return 0;
+    return s;
+}
 int launch_gemm_f32out(int dtype, int M, int N, const void* A0, int64_t lda0, const void* Bt0, int64_t ldb0, int K0,
                        const void* A1, int64_t lda1, const void* Bt1, int64_t ldb1, int K1, float* C, int64_t ldc,
                        int splits, int64_t slab_stride, hipStream_t st, int role, const LabelJob* label_job, int* label_done) {
@@ -1681,6 +1712,21 @@ int launch_gemm_f32out(int dtype, int M, int N, const void* A0, int64_t lda0, co
     if (int rc = fill_params(p, dtype, M, N, A0, lda0, Bt0, ldb0, K0, A1, lda1, Bt1, ldb1, K1, splits)) return rc;
     DAE_CHECK_ARG(C != nullptr, "gemm: C is null");
     if (int rc = gemm_init()) return rc;
+    if (p.splits == gemm_w8_splits(dtype, M, N, p.ktiles_total)) {
+        W8Params q;
+        q.seg[0] = p.seg[0]; q.seg[1] = p.seg[1]; q.ktiles_total = p.ktiles_total; q.M = M; q.N = N;
+        q.tiles_m = (M + W8_BM - 1) / W8_BM; q.tiles_n = (N + W8_BN - 1) / W8_BN; q.splits = p.splits;
+        const int ws = p.splits;
+        static bool attr = false;
+        if (!attr) {
+            for (int r = 0; r <= ROLE_GRAM; ++r)
+                DAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(w8_kernel(r)), hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS));
+            attr = true;
+        }
+        hipLaunchKernelGGL(w8_kernel(role), dim3(q.tiles_m * q.tiles_n * ws), dim3(W8_THREADS), W8_LDS, st, q, C, ldc, slab_stride);
+        DAE_CHECK_LAUNCH();
+        return 0;
+    }
     dim3 grid(grid_blocks(p)), block(GEMM_THREADS);
     const int nst = g_nst;
     if (nst == DEFAULT_NST && (int)grid.x <= g_cus && g_use_pc) {      // at most one workgroup per CU: producer/consumer waves
@@ -2053,6 +2099,8 @@ void set_use_glds(int nst) {
     if (nst == -3) { g_dw_pc = 0; return; }          // A/B: dW on the 4-wave 128 x 128 kernel
     if (nst == -4) { g_dw_pc = 1; return; }
     if (nst == -5) { g_dw_pc = 2; return; }          // tests: the 160 x 128 kernel for every grid that fits one round
+    if (nst == -6) { g_w8 = 0; return; }             // A/B: never the 256 x 256 / 8-MFMA-wave kernel
+    if (nst == -7) { g_w8 = 1; return; }
     g_nst = nst;
 }
 

@@ -35,6 +35,8 @@ int launch_gemm_f32out(int dtype, int M, int N, const void* A0, int64_t lda0, co
                        const void* A1, int64_t lda1, const void* Bt1, int64_t ldb1, int K1, float* C, int64_t ldc, int splits,
                        int64_t slab_stride, hipStream_t st, int role = 0, const struct LabelJob* label_job = nullptr,
                        int* label_done = nullptr);
+// K slices the 256 x 256 / 8-MFMA-wave kernel wants for this shape (0: the shape stays on the 128 x 128 kernels); see dae_gemm.hip
+int gemm_w8_splits(int dtype, int M, int N, int ktiles);
 enum { GEMM_ROLE_GENERIC = 0, GEMM_ROLE_ENCODE = 1, GEMM_ROLE_DH = 2, GEMM_ROLE_DW = 3, GEMM_ROLE_GRAM = 4 };
 int launch_decode_loss(int dtype, int Bp, int Fp, int Hp, const void* h_lo, int64_t ldh, const void* W_lo, int64_t ldw,
                        const DecodeEpi& e, hipStream_t st);

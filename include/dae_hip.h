@@ -324,6 +324,11 @@ int dae_weighted_loss_rows(const float* x, int64_t ldx, const float* y, int64_t 
  * 128 x 128 kernel / on the 8-wave 160 x 128 kernel when its grid fills one round of the chip (default) / whenever it fits. */
 void dae_set_glds(int32_t nst);
 
+/* K slices with which dae_gemm_nt runs a bf16 shape on the 256 x 256-tile kernel (8 MFMA waves, one workgroup per CU; the large
+ * split-K contractions of the dense-input configs: x~[B x F].W and delta2.W with F = 50 000) -- calling dae_gemm_nt with exactly this
+ * `splits` selects it; 0 = the shape stays on the 128 x 128 kernels.  dae_set_glds(-6) / (-7) turn the kernel off / on (A/B). */
+int32_t dae_gemm_w8_splits(int32_t dtype, int32_t M, int32_t N, int32_t K);
+
 /* ---------------------------------------------------------------------------------------------
  * Whole-step driver: what DenoisingAutoencoder._run_train_step (autoencoder.py:206-246) does per
  * mini-batch, as one host call that enqueues every kernel above on `stream`.

@@ -82,6 +82,44 @@ def test_gemm_nt(ops, L, glds, dtype, shape):
         L.load().dae_set_glds(1)
 
 
+@pytest.mark.parametrize("shape", [(896, 1024, 16384, 0), (1024, 512, 8192 + 4096, 0), (896, 1024, 12288, 896), (800, 768, 16384, 0)])
+def test_gemm_nt_256_tile_kernel(ops, L, shape):
+    """The 256 x 256 / 8-MFMA-wave kernel (dense-input encode / dh shapes): selected by its own split count, checked against
+    float64 and against the 128 x 128 kernels on the same operands (partial last row tile: M = 896, 800)."""
+    M, N, K0, K1 = shape
+    lib = L.load()
+    s = lib.dae_gemm_w8_splits(L.BF16, M, N, K0 + K1)
+    assert s in (8, 16), s
+    rng = np.random.default_rng(M + N + K0)
+    A0 = torch.as_tensor(rng.standard_normal((M, K0)).astype(np.float32)).to(torch.bfloat16).cuda()
+    B0 = torch.as_tensor(rng.standard_normal((N, K0)).astype(np.float32)).to(torch.bfloat16).cuda()
+    A1 = B1 = None
+    ref = A0.double().cpu() @ B0.double().cpu().T
+    if K1:
+        A1 = torch.as_tensor(rng.standard_normal((M, K1)).astype(np.float32)).to(torch.bfloat16).cuda()
+        B1 = torch.as_tensor(rng.standard_normal((N, K1)).astype(np.float32)).to(torch.bfloat16).cuda()
+        ref = ref + A1.double().cpu() @ B1.double().cpu().T
+    for rep in range(3):                                 # repeated launches: a DMA / barrier race shows as a run-to-run difference
+        C = ops.gemm_nt(A0, B0, A1, B1, splits=s)
+        torch.cuda.synchronize()
+        got = C.sum(0).double().cpu()
+        err = (got - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 2e-6, (shape, s, rep, err)
+        if rep == 0:
+            first = C.clone()
+        else:
+            assert torch.equal(C, first)
+    if M % 128 == 0 and N % 128 == 0:
+        lib.dae_set_glds(-6)
+        try:
+            C2 = ops.gemm_nt(A0, B0, A1, B1, splits=s)
+            torch.cuda.synchronize()
+        finally:
+            lib.dae_set_glds(-7)
+        e2 = (C2.sum(0) - first.sum(0)).abs().max().item() / ref.abs().max().item()
+        assert e2 < 2e-6, e2
+
+
 def test_gemm_identity_transpose_detecting(ops):
     """A = I picks out rows of Bt: catches a swapped C layout (guide 5.4 rule 16)."""
     M = N = K = 128
