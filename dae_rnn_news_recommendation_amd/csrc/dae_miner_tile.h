@@ -38,6 +38,13 @@ __device__ __forceinline__ mt_f32x2 mt_w_lo(mt_f32x2 a, mt_f32x2 b) {
 __device__ __forceinline__ mt_f32x2 mt_w_hi(mt_f32x2 a, mt_f32x2 b) {
     mt_f32x2 d; asm("v_pk_fma_f32 %0, %1, %2, 1.0 op_sel:[0,1,0] op_sel_hi:[1,1,0]" : "=v"(d) : "v"(a), "v"(b)); return d;
 }
+// d = a * bcast(b.x) + bcast(c.x)   /  d = a * bcast(b.y) + bcast(c.x)      (scaled form: the addend is e^-c instead of 1)
+__device__ __forceinline__ mt_f32x2 mt_ws_lo(mt_f32x2 a, mt_f32x2 b, mt_f32x2 c) {
+    mt_f32x2 d; asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d;
+}
+__device__ __forceinline__ mt_f32x2 mt_ws_hi(mt_f32x2 a, mt_f32x2 b, mt_f32x2 c) {
+    mt_f32x2 d; asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d;
+}
 // d = a * bcast(b.x)            /  d = a * bcast(b.y)
 __device__ __forceinline__ mt_f32x2 mt_mul_lo(mt_f32x2 a, mt_f32x2 b) {
     mt_f32x2 d; asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(d) : "v"(a), "v"(b)); return d;
@@ -69,6 +76,11 @@ __device__ __forceinline__ mt_f32x2 mt_pk_sub(mt_f32x2 a, mt_f32x2 b) { mt_f32x2
 __device__ __forceinline__ float mt_mul(float a, float b) { float d; asm("v_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 __device__ __forceinline__ float mt_rcp(float a) { float d; asm("v_rcp_f32 %0, %1" : "=v"(d) : "v"(a)); return d; }
 __device__ __forceinline__ void mt_add_log2(float& acc, float a) { float l; asm("v_log_f32 %0, %1" : "=v"(l) : "v"(a)); asm("v_add_f32 %0, %0, %1" : "+v"(acc) : "v"(l)); }
+// acc += log2(a) + k   (scaled form: k = 2c log2(e) restores log2(w_a w_b) >= 0 BEFORE it is accumulated -- summing the raw
+// log2(w^_a w^_b) ~ -115 and adding 2c * pairs at the end would cancel five digits)
+__device__ __forceinline__ void mt_add_log2k(float& acc, float a, float k) {
+    float l; asm("v_log_f32 %0, %1" : "=v"(l) : "v"(a)); asm("v_add_f32 %0, %0, %1" : "+v"(l) : "v"(k)); asm("v_add_f32 %0, %0, %1" : "+v"(acc) : "v"(l));
+}
 
 // Sum over the 4 DPP rows of a wave for every column b = lane & 15 (lanes l, l^16, l^32, l^48); every lane receives it.
 __device__ __forceinline__ float mt_cross_row_sum(float v) {
@@ -85,10 +97,15 @@ __device__ __forceinline__ float mt_cross_row_sum(float v) {
 //   loss_log2 += sum log2(w) over this lane's cells;  loss_corr += first-order log1p corrections (natural units; !FAST)
 // FAST: accumulates r = 1/w = 1 - sigmoid and converts at the end (padding cells have w = 1, r = 1, sigmoid = 0).
 // Per unit of the body (2 positives x 2 negatives, FAST, LOGW = 8): 6 packed + 3.5 plain + 2.5 transcendental instructions.
-template <int Q2, bool FAST, int LOGW, int FENCE = 2>
+// SCALED (row range in (40, 80], FAST, LOGW = 2): with c = range / 2 every factor is carried as w^ = e^-c (1 + exp(t)) in
+// [e^-c, ~e^c], so that the product of a pair stays finite (e^80) where (1 + e^range)^2 would overflow:
+//   1/w_a = e^-c w^_b / (w^_a w^_b),   log w_a + log w_b = log(w^_a w^_b) + 2c
+// -- one extra v_mul_f32 (R e^-c) and one extra v_add_f32 (+ 2c) per pair.  `escale` = e^-c (1 when !SCALED).
+template <int Q2, bool FAST, int LOGW, int FENCE = 2, bool SCALED = false>
 __device__ __forceinline__ void tile_sweep(const float* __restrict__ pf, const float* __restrict__ nv, float mid, int nP, int nN,
                                            int k0, bool first, float* __restrict__ gpos, float* __restrict__ gneg_w,
-                                           float& loss_log2, float& loss_corr, int t_begin = 0, int t_step = 1) {
+                                           float& loss_log2, float& loss_corr, int t_begin = 0, int t_step = 1, float escale = 1.0f) {
+    static_assert(!SCALED || (FAST && LOGW == 2), "the scaled form exists for the FAST pair sweep with one logarithm per pair");
     // t_begin / t_step: this workgroup walks the positive iterations t_begin, t_begin + t_step, ... (an anchor shared by t_step workgroups)
     static_assert(LOGW == 2 || LOGW == 4 || LOGW == 8, "LOGW");
     const int tid = threadIdx.x, lane = tid & 63, b = tid & 15, a = tid >> 4;
@@ -103,6 +120,9 @@ __device__ __forceinline__ void tile_sweep(const float* __restrict__ pf, const f
         gs2[q] = mt_f32x2{0.f, 0.f};
     }
     mt_f32x2 corr2 = {0.f, 0.f};
+    const mt_f32x2 esc2 = {escale, escale};
+    const float klog = SCALED ? -2.0f * __builtin_amdgcn_logf(escale) : 0.f;       // 2c log2(e) = -2 log2(e^-c)
+    (void)esc2; (void)klog;
     const int T = (nP + 31) >> 5;                                           // two positives per iteration: a + 32 t, a + 32 t + 16
     mt_f32x2 Fn;
     Fn.x = (a + 32 * t_begin < nP) ? pf[a + 32 * t_begin] : 0.f; Fn.y = (a + 32 * t_begin + 16 < nP) ? pf[a + 32 * t_begin + 16] : 0.f;
@@ -110,7 +130,8 @@ __device__ __forceinline__ void tile_sweep(const float* __restrict__ pf, const f
     for (int t = t_begin; t < T; t += t_step) {
         ++walked;
         const int j0 = a + 32 * t, j1 = j0 + 16;
-        const mt_f32x2 ff = Fn;
+        mt_f32x2 ff = Fn;
+        if constexpr (SCALED) { ff.x *= escale; ff.y *= escale; }
         Fn.x = (j0 + 32 * t_step < nP) ? pf[j0 + 32 * t_step] : 0.f;        // next iteration's factors (LDS latency under the body)
         Fn.y = (j1 + 32 * t_step < nP) ? pf[j1 + 32 * t_step] : 0.f;
         mt_f32x2 rs0 = {0.f, 0.f}, rs1 = {0.f, 0.f};
@@ -120,9 +141,12 @@ __device__ __forceinline__ void tile_sweep(const float* __restrict__ pf, const f
             float P0, P1;
             mt_f32x2 RR;
             if constexpr (FAST) {
-                const mt_f32x2 w0 = mt_w_lo(ev2[q], ff), w1 = mt_w_hi(ev2[q], ff);         // 1 + exp(t)
+                mt_f32x2 w0, w1;
+                if constexpr (SCALED) { w0 = mt_ws_lo(ev2[q], ff, esc2); w1 = mt_ws_hi(ev2[q], ff, esc2); }   // e^-c (1 + exp(t)); ff carries e^-c too
+                else { w0 = mt_w_lo(ev2[q], ff); w1 = mt_w_hi(ev2[q], ff); }                                   // 1 + exp(t)
                 P0 = mt_mul(w0.x, w0.y); P1 = mt_mul(w1.x, w1.y);
                 RR.x = mt_rcp(P0); RR.y = mt_rcp(P1);
+                if constexpr (SCALED) { RR.x = mt_mul(RR.x, escale); RR.y = mt_mul(RR.y, escale); }
                 mt_acc_swap_lo(gs2[q], w0, RR); mt_acc_swap_hi(gs2[q], w1, RR);           // += 1/w = 1 - sigmoid(t)
                 mt_acc_swap_lo(rs0, w0, RR); mt_acc_swap_hi(rs1, w1, RR);
             } else {
@@ -140,8 +164,8 @@ __device__ __forceinline__ void tile_sweep(const float* __restrict__ pf, const f
             }
             // sum of logs = log of the product: LOGW factors w per v_log_f32
             if constexpr (LOGW == 2) {
-                mt_add_log2(loss_log2, P0);
-                mt_add_log2(loss_log2, P1);
+                if constexpr (SCALED) { mt_add_log2k(loss_log2, P0, klog); mt_add_log2k(loss_log2, P1, klog); }
+                else { mt_add_log2(loss_log2, P0); mt_add_log2(loss_log2, P1); }
             } else if constexpr (LOGW == 4) {
                 mt_add_log2(loss_log2, mt_mul(P0, P1));
             } else {

@@ -595,7 +595,7 @@ __global__ __launch_bounds__(TRIP_THREADS, OCC) void batch_all_kernel(const floa
 #else
 #define TILE_STAMP(i) do { } while (0)
 #endif
-enum { MT_FAST = 0, MT_EXACT = 1, MT_CELL = 2, MT_DIRECT = 3 };
+enum { MT_FAST = 0, MT_EXACT = 1, MT_CELL = 2, MT_DIRECT = 3, MT_FAST_SCALED = 4 };
 
 // Sweep variants without the pair trick, same lane grid and the same outputs as tile_sweep.
 //   DIRECT = false: w = 1 + E_n F_p per cell, one v_rcp_f32 and one v_log_f32 per cell (row range <= 80)
@@ -655,17 +655,19 @@ __device__ __forceinline__ void tile_sweep_cells(const float* __restrict__ pu, c
 
 // all chunks of the anchor's negatives through tile_sweep (plain functions, pointers by value: closures that capture the LDS
 // pointers by reference end up in scratch as GENERIC pointers and every LDS access of the sweep becomes a flat_load / flat_store)
-template <bool FAST, int LOGW>
-__device__ __forceinline__ float tile_pair_sweeps(const float* pf, const float* nv, float mid, int nP, int nN, int q2, float* gpos, float* gneg_w) {
+template <bool FAST, int LOGW, bool SCALED = false>
+__device__ __forceinline__ float tile_pair_sweeps(const float* pf, const float* nv, float mid, int nP, int nN, int q2, float* gpos, float* gneg_w,
+                                                  float half_range = 0.f) {
     float loss_log2 = 0.f, loss_corr = 0.f;
+    const float esc = SCALED ? __builtin_amdgcn_exp2f(-half_range * kMtLog2e) : 1.0f;
     for (int k0 = 0; k0 < nN; k0 += 32 * q2) {
         const bool first = (k0 == 0);
         switch (q2) {
-            case 12: tile_sweep<12, FAST, LOGW>(pf, nv, mid, nP, nN, k0, first, gpos, gneg_w, loss_log2, loss_corr); break;
-            case 10: tile_sweep<10, FAST, LOGW>(pf, nv, mid, nP, nN, k0, first, gpos, gneg_w, loss_log2, loss_corr); break;
-            case 8: tile_sweep<8, FAST, LOGW>(pf, nv, mid, nP, nN, k0, first, gpos, gneg_w, loss_log2, loss_corr); break;
-            case 6: tile_sweep<6, FAST, LOGW>(pf, nv, mid, nP, nN, k0, first, gpos, gneg_w, loss_log2, loss_corr); break;
-            default: tile_sweep<4, FAST, LOGW>(pf, nv, mid, nP, nN, k0, first, gpos, gneg_w, loss_log2, loss_corr); break;
+            case 12: tile_sweep<12, FAST, LOGW, 2, SCALED>(pf, nv, mid, nP, nN, k0, first, gpos, gneg_w, loss_log2, loss_corr, 0, 1, esc); break;
+            case 10: tile_sweep<10, FAST, LOGW, 2, SCALED>(pf, nv, mid, nP, nN, k0, first, gpos, gneg_w, loss_log2, loss_corr, 0, 1, esc); break;
+            case 8: tile_sweep<8, FAST, LOGW, 2, SCALED>(pf, nv, mid, nP, nN, k0, first, gpos, gneg_w, loss_log2, loss_corr, 0, 1, esc); break;
+            case 6: tile_sweep<6, FAST, LOGW, 2, SCALED>(pf, nv, mid, nP, nN, k0, first, gpos, gneg_w, loss_log2, loss_corr, 0, 1, esc); break;
+            default: tile_sweep<4, FAST, LOGW, 2, SCALED>(pf, nv, mid, nP, nN, k0, first, gpos, gneg_w, loss_log2, loss_corr, 0, 1, esc); break;
         }
     }
     return kLn2 * loss_log2 + loss_corr;
@@ -799,7 +801,8 @@ __global__ __launch_bounds__(TRIP_THREADS, OCC) void batch_all_tile_kernel(const
     hi = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
     const float range = hi - lo;                              // NaN for NaN rows, inf for inf rows: every comparison below is then false
     const float mid = 0.5f * (hi + lo);
-    const int kind = range <= 40.0f ? (fast ? MT_FAST : MT_EXACT) : (range <= 80.0f ? MT_CELL : MT_DIRECT);
+    // (40, 80]: bf16 steps take the SCALED pair sweep (factors carried as e^-c (1 + exp(t)), c = range / 2), exact mode one reciprocal per cell
+    const int kind = range <= 40.0f ? (fast ? MT_FAST : MT_EXACT) : (range <= 80.0f ? (fast ? MT_FAST_SCALED : MT_CELL) : MT_DIRECT);
     if (kind != MT_DIRECT)
         for (int k = tid; k < nP; k += TRIP_THREADS) pf[k] = __builtin_amdgcn_exp2f((mid - pu[k]) * kMtLog2e);
     TILE_STAMP(1);
@@ -824,6 +827,10 @@ __global__ __launch_bounds__(TRIP_THREADS, OCC) void batch_all_tile_kernel(const
         // 2e-6 of the anchor's sum (mean term >= 0.03 = softplus(-3.5)); otherwise every triplet is far on the satisfied side: exact form
         const float lsum = block_sum_f(loss, red);
         if (!(lsum >= 0.03f * (float)nP * (float)nN)) { __syncthreads(); loss = tile_pair_sweeps_by_range<false>(range, pf, nv, mid, nP, nN, q2, gpos, gneg_w); }
+    } else if (kind == MT_FAST_SCALED) {
+        loss = tile_pair_sweeps<true, 2, true>(pf, nv, mid, nP, nN, q2, gpos, gneg_w, 0.5f * range);
+        const float lsum = block_sum_f(loss, red);            // same acceptance test as above; the fallback is the per-cell sweep
+        if (!(lsum >= 0.03f * (float)nP * (float)nN)) { __syncthreads(); loss = tile_cell_sweeps<false>(pu, pf, nv, mid, nP, nN, gpos, gneg_w); }
     } else if (kind == MT_EXACT) {
         loss = tile_pair_sweeps_by_range<false>(range, pf, nv, mid, nP, nN, q2, gpos, gneg_w);
     } else if (kind == MT_CELL) {
@@ -846,7 +853,7 @@ __global__ __launch_bounds__(TRIP_THREADS, OCC) void batch_all_tile_kernel(const
     if (tid == 0) {
         unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        const unsigned long long kd = kind <= MT_EXACT ? (range <= 10.f ? 8 : range <= 20.f ? 4 : 2) : (kind == MT_CELL ? 1 : 15);
+        const unsigned long long kd = kind <= MT_EXACT ? (range <= 10.f ? 8 : range <= 20.f ? 4 : 2) : (kind == MT_CELL ? 1 : kind == MT_FAST_SCALED ? 3 : 15);
         reinterpret_cast<unsigned long long*>(role_cnt)[(size_t)blockIdx.x * 8 + 5] = (kd << 40) | ((unsigned long long)xcc << 32) | hw;
         reinterpret_cast<unsigned long long*>(role_cnt)[(size_t)blockIdx.x * 8 + 6] = ((unsigned long long)nP << 32) | (unsigned)nN;
         reinterpret_cast<unsigned long long*>(role_cnt)[(size_t)blockIdx.x * 8 + 7] = (sweep_cycles << 32) | (unsigned long long)__float_as_uint(range);

@@ -150,14 +150,14 @@ def label_stats(labels, B, triplet):
     return nvalid, dw, cw
 
 
-def triplet_batch_all(D_slabs, labels, B, pos_only=False):
+def triplet_batch_all(D_slabs, labels, B, pos_only=False, fast=False):
     S, Bp, _ = D_slabs.shape
     dev = D_slabs.device
     loss_part = torch.zeros(Bp, dtype=torch.float32, device=dev)
     npos = torch.zeros(Bp, dtype=torch.int32, device=dev)
     G = torch.zeros((Bp, Bp), dtype=torch.float32, device=dev)
     role = torch.zeros((Bp, Bp), dtype=torch.int32, device=dev) if pos_only else None
-    L.call("dae_triplet_batch_all", L.ptr(D_slabs), S, Bp * Bp, Bp, L.ptr(labels), B, Bp, int(pos_only),
+    L.call("dae_triplet_batch_all", L.ptr(D_slabs), S, Bp * Bp, Bp, L.ptr(labels), B, Bp, int(pos_only) | (2 if fast else 0),
            L.ptr(loss_part), L.ptr(npos), L.ptr(G), L.ptr(role), L.current_stream())
     return loss_part, npos, G, role
 

@@ -82,7 +82,7 @@ def test_gemm_nt(ops, L, glds, dtype, shape):
         L.load().dae_set_glds(1)
 
 
-@pytest.mark.parametrize("shape", [(896, 1024, 16384, 0), (1024, 512, 8192 + 4096, 0), (896, 1024, 12288, 896), (800, 768, 16384, 0)])
+@pytest.mark.parametrize("shape", [(896, 1024, 16384, 0), (1024, 1024, 16384, 0), (896, 1024, 16384, 896), (896, 768, 16384, 0)])
 def test_gemm_nt_256_tile_kernel(ops, L, shape):
     """The 256 x 256 / 8-MFMA-wave kernel (dense-input encode / dh shapes): selected by its own split count, checked against
     float64 and against the 128 x 128 kernels on the same operands (partial last row tile: M = 896, 800)."""
@@ -417,6 +417,9 @@ def test_miners_vs_reference_golden(ops, L, case):
 
 @pytest.mark.parametrize("B,classes,signed,scale", [(200, 4, True, 2.0), (333, 7, True, 2.0), (128, 1, False, 0.3), (257, 50, True, 2.0),
                                                      (300, 3, True, 12.0),      # D row range > 80: the direct (non-factorised) sweep
+                                                     (300, 3, True, 1.5), (300, 3, True, 2.8),   # row ranges ~7 / ~25: 8 / 2 factors per logarithm
+                                                     (300, 3, True, 4.0),       # row range in (40, 80]: per-cell sweep (exact), scaled pairs (fast)
+                                                     (800, 4, True, 2.2),       # the c2 batch size: two chunks of negatives
                                                      (1100, 5, True, 1.0)])     # B > 1024: two-kernel label statistics
 def test_miners_gradients(ops, L, B, classes, signed, scale):
     rng = np.random.default_rng(B)
@@ -443,6 +446,13 @@ def test_miners_gradients(ops, L, B, classes, signed, scale):
     want = 0.5 * (Go + Go.T)
     assert rel_err(Gs[:B, :B], want) < 5e-5 if nv else (Gs == 0).all()
     assert (Gs[B:] == 0).all() and (Gs[:, B:] == 0).all()
+    # the bf16 steps' FAST mode (sums of 1/w, no first-order log1p correction, exact re-run of anchors it cannot bound)
+    lpf, nposf, Gf, _ = ops.triplet_batch_all(D, labels, B, False, fast=True)
+    trif, _ = ops.triplet_finalize(L.TRIPLET["batch_all"], False, B, 0.5, lpf, nposf, nvalid, None, None, cw)
+    trif = trif.cpu().numpy()
+    assert np.allclose(trif[1], lo, rtol=2e-5, atol=1e-7) and trif[3] == num32
+    Gsf = ops.sym_scale(Gf, B, dev(trif), L.F32).cpu().numpy()
+    assert rel_err(Gsf[:B, :B], want) < 1e-4 if nv else (Gsf == 0).all()
     # batch_hard
     lp, cnt, dwi, Gm = ops.triplet_batch_hard(D, labels, B)
     cwh = torch.zeros_like(cw)
