@@ -42,6 +42,11 @@ PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, MI355X_MICROARCH.md
 PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
 PEAK_VALU_TLANEOPS = 39.3      # 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz: one wave64 VALU instruction per SIMD per 4 clocks
+# batch_all sweep, lane-grid kernel (csrc/dae_miner_tile.h): issue cycles per (positive, negative) cell on one SIMD at saturating
+# occupancy, measured on the box by tools/valu_ubench.hip ("lane-grid unit": 49 cycles per 4 cells = 6 packed + 3 plain + 3
+# transcendental instructions); the chip then evaluates 256 CUs x 4 SIMDs x 64 lanes x 2.4 GHz / 12.25 cells per second
+MINER_CYCLES_PER_CELL = 12.25
+PEAK_MINER_TCELLS = 256 * 4 * 64 * 2.4e9 / MINER_CYCLES_PER_CELL / 1e12
                                # (packed-fp32 instructions count once; they issue at this rate too on this part)
 
 CONFIGS = {
@@ -479,14 +484,13 @@ def main():
         kern, step_us, (mfma, hbm) = kernel_table(a, prof, a.profile_steps)
         if "miner" in kern and kern["miner"].get("bound") == "valu":
             nv = float(np.mean(run.stats.cpu().numpy()[:, 5]))        # N_valid of the last epoch's batches
-            pmc, _ = _committed_pmc()
-            mv = (pmc or {}).get("miner_valu")
-            ops = mv["insts_per_triplet_lane"] if mv else 10.8        # VALU instructions per triplet-lane: SQ_INSTS_VALU x 64 / N_valid
             e = kern["miner"]
-            e.update(achieved=nv * ops / (e["avg_us"] * 1e-6) / 1e12, peak=PEAK_VALU_TLANEOPS, unit="T lane-ops/s",
-                     kind="VALU issue utilisation, self-counted (instructions the kernel itself executes, not an algorithmic roofline)",
-                     note=f"N_valid = {nv:.3g} triplets x {ops:.1f} VALU instructions per triplet-lane "
-                          + (f"(SQ_INSTS_VALU, {pmc['_file']})" if mv else "(round-2 PMC value; no PMC file for these sources)"))
+            e.update(achieved=nv / (e["avg_us"] * 1e-6) / 1e12, peak=PEAK_MINER_TCELLS, unit="T triplets/s",
+                     kind="VALU issue roofline of the sweep's own instruction mix (not a hardware counter)",
+                     note=f"N_valid = {nv:.3g} triplets per launch; peak = 256 CUs x 4 SIMDs x 64 lanes x 2.4 GHz / {MINER_CYCLES_PER_CELL} issue "
+                          "cycles per cell (6 packed + 3 plain + 3 transcendental VALU instructions per 2 positives x 2 negatives, priced by "
+                          "tools/valu_ubench.hip on the box: 49 cycles per 4 cells at 3-4 waves per SIMD); the launch also holds the D-row "
+                          "prologue, the count's sort and the 16 % lane padding of the c2 class sizes")
             e["frac"] = e["achieved"] / e["peak"]
         out["kernels"] = kern
         out["profiled_step_us"] = step_us

@@ -13,13 +13,13 @@ TRAFFIC_ONLY = "--traffic-only" in sys.argv
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 dst = os.path.join(root, "profiles")
 # step slot (bench.py `kernels` key) -> kernel symbol prefix in the rocprofv3 tables
-SLOT_KERNEL = [("encode_gemm", "encode_csr_kernel"), ("gram", "gemm_nt_pc<unsigned short, 4, 4>"), ("miner", "batch_all_kernel"),
+SLOT_KERNEL = [("encode_gemm", "encode_csr_kernel"), ("gram", "gemm_nt_pc<unsigned short, 4, 4>"), ("miner", "batch_all_tile_kernel"),
                ("sym_scale", "sym_scale_kernel"), ("decode_loss", "gemm_decode_loss"), ("dh_gemm", "gemm_nt_pc<unsigned short, 4, 2>"),
                ("dh_finish", "dh_finish_kernel"), ("dw_gemm", "gemm_dw_pc"), ("bias_grads", "step_tail_kernel")]
-SLOT_KERNEL_C4 = [("gather", "gather_dense_kernel"), ("encode_gemm", "gemm_nt_pc<unsigned short, 4, 1>"), ("encode_finish", "encode_finish_kernel"),
-                  ("decode_loss", "gemm_decode_loss"), ("dh_gemm", "gemm_nt_pc<unsigned short, 4, 2>"), ("dw_gemm", "gemm_dw")]
-NOTE = {"encode_gemm": "corrupt + gather + sparse x~.W + bias + act, all images of h, x bit image, x~^T scatter, label statistics",
-        "gram": "split-bf16 (3 products), split-K 4", "miner": "batch_all, pair-packed FAST sweep", "sym_scale": "Gs = a/Nv (G + G^T) -> bf16",
+SLOT_KERNEL_C4 = [("gather", "gather_dense_kernel"), ("encode_gemm", "gemm_nt_w8<1>"), ("encode_finish", "encode_finish_kernel"),
+                  ("decode_loss", "gemm_decode_loss"), ("dh_gemm", "gemm_nt_w8<2>"), ("dw_gemm", "gemm_dw")]
+NOTE = {"encode_gemm": "corrupt + gather + sparse x~.W (fp32 master W) + bias + act, all images of h, x bit image, x~^T scatter, label statistics",
+        "gram": "split-bf16 (3 products), split-K 4", "miner": "batch_all on a 16 x 16 lane grid (FAST pair sweep), positive-triplet count from sorted runs", "sym_scale": "Gs = a/Nv (G + G^T) -> bf16",
         "decode_loss": "128 x 64 tiles: GEMM + loss + delta2 (two layouts), x from bits", "dh_gemm": "delta2.W + Gs.h, split-K 8",
         "dh_finish": "slab reduction, act', delta1^T, column sums", "dw_gemm": "160 x 128 tiles: dW GEMM + SGD update of W and both bf16 shadows",
         "bias_grads": "step tail: bias grads + update, statistics, x~^T un-scatter"}
@@ -85,7 +85,7 @@ for cfg, slots, tab in (("c2", SLOT_KERNEL, pmc), ("c4", SLOT_KERNEL_C4, pmc4)):
         if c and "FETCH_SIZE" in c:
             traffic[cfg][slot] = {"fetch_bytes": int(c["FETCH_SIZE"] * 1024 * 2), "write_bytes": int(c.get("WRITE_SIZE", 0) * 1024)}
 # miner: VALU instructions per triplet-lane (SQ_INSTS_VALU counts wave instructions)
-m = find(pmc, "batch_all_kernel")
+m = find(pmc, "batch_all_tile_kernel")
 try:
     nv = float(open(os.path.join(src, "run_steps.txt")).read().split("mean_n_valid")[1].split()[0])
 except Exception:       # noqa: BLE001
