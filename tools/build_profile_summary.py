@@ -14,8 +14,8 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 dst = os.path.join(root, "profiles")
 # step slot (bench.py `kernels` key) -> kernel symbol prefix in the rocprofv3 tables
 SLOT_KERNEL = [("encode_gemm", "encode_csr_kernel"), ("gram", "gemm_nt_pc<unsigned short, 4, 4>"), ("miner", "batch_all_tile_kernel"),
-               ("sym_scale", "sym_scale_kernel"), ("decode_loss", "gemm_decode_loss"), ("dh_gemm", "gemm_nt_pc<unsigned short, 4, 2>"),
-               ("dh_finish", "dh_finish_kernel"), ("dw_gemm", "gemm_dw_pc"), ("bias_grads", "step_tail_kernel")]
+               ("sym_scale", "sym_scale_kernel"), ("decode_loss", "gemm_decode_loss<unsigned short"), ("dh_gemm", "gemm_nt_pc<unsigned short, 4, 2>"),
+               ("dh_finish", "dh_finish_kernel<unsigned short"), ("dw_gemm", "gemm_dw_pc"), ("bias_grads", "step_tail_kernel")]
 SLOT_KERNEL_C4 = [("gather", "gather_dense_kernel"), ("encode_gemm", "gemm_nt_w8<1>"), ("encode_finish", "encode_finish_kernel"),
                   ("decode_loss", "gemm_decode_loss"), ("dh_gemm", "gemm_nt_w8<2>"), ("dw_gemm", "gemm_dw")]
 NOTE = {"encode_gemm": "corrupt + gather + sparse x~.W (fp32 master W) + bias + act, all images of h, x bit image, x~^T scatter, label statistics",

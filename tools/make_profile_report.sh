@@ -27,7 +27,7 @@ $T python bench.py --config c1 --steps 300 --warmup 30 > $OUT/bench_c1.json 2>> 
 $T python bench.py --config c3 --steps 300 --warmup 30 --no-cpu-baseline > $OUT/bench_c3.json 2>> $OUT/bench.err
 $T python bench.py --config c5 --steps 200 --warmup 20 --no-cpu-baseline > $OUT/bench_c5.json 2>> $OUT/bench.err
 $T python bench.py --config c4 --steps 100 --warmup 10 --no-cpu-baseline > $OUT/bench_c4.json 2>> $OUT/bench.err
-$T rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-roofline --no-fit > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
+$T rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-roofline --no-fit --no-fp32 > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
 python tools/rocprof_summary.py $OUT/trace/t_results.db > $OUT/kernel_stats.md
 rm -rf $OUT/trace
 $T python tools/kprof.py > $OUT/kprof.txt 2>/dev/null
