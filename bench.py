@@ -224,7 +224,7 @@ class Runner:
         rows, labs = self.batch(b)
         if self.exchange is not None:
             self.eng.train_step(rows, labs, self.stats[b], phase=1, **self.plan)
-            self.exchange.step(grad_scale=1.0 / self.world)
+            self.exchange.step(grad_scale=1.0 / self.world, grad_ready_after_dw=True)
         else:
             self.eng.train_step(rows, labs, self.stats[b], phase=3, **self.plan)
         self.step_i += 1
@@ -441,8 +441,9 @@ def main():
                                + f", strategy {c['strategy']}, masking 0.3, {c['loss']}, SGD lr 0.1, {a.precision} MFMA operands + fp32 "
                                "accumulate / master weights",
                    "global_batch": c["batch"] * world, "parallelism": f"dp{world}", "rng": a.rng,
-                   "collective": None if world == 1 else f"per step: reduce-scatter of the W gradient ({a.grad_dtype}) + all-reduce of the "
-                                                         "bias gradients, sharded optimizer, all-gather of the low-precision W shadow (RCCL)"},
+                   "collective": None if world == 1 else f"per step: reduce-scatter of the W gradient ({a.grad_dtype}; issued behind the dW GEMM on a side "
+                                                         "stream, beside the step tail), sharded optimizer writing into the all-gather send buffer, "
+                                                         "all-gather of the low-precision W rows + every rank's bias gradients, one unpack kernel (RCCL)"},
         "final_losses": {"cost": float(last[:, 0].mean()), "autoencoder": float(last[:, 1].mean()),
                          "triplet": float(last[:, 2].mean()), "fraction": float(last[:, 3].mean()),
                          "note": "means over the last epoch's batches, as the reference prints them (autoencoder.py:283-294)"},
@@ -454,7 +455,7 @@ def main():
             run.step(); run.exchange.collect_time()
         out["collective_us"] = 1e3 * run.exchange.collective_ms / max(1, min(20, a.steps))
         # exposed = what the exchange adds to a step on the critical path: the step with it minus the same local step without it
-        # (phase-1 step alone, timed back to back below); nothing of the exchange overlaps compute yet, so exposed ~ its full cost
+        # (phase-1 step alone, timed back to back below); only the reduce-scatter overlaps compute (the step's tail kernel)
         torch.cuda.synchronize(); dp.barrier()
         t1 = time.perf_counter()
         for s_ in range(min(20, a.steps)):

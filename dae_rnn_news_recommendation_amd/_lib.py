@@ -102,6 +102,10 @@ SIGNATURES = {
     "dae_plan_apply": (i32, [vp, i32, f32, vp]),
     "dae_plan_apply_rows": (i32, [vp, i32, f32, vp, i32, i32, i32, vp]),
     "dae_plan_refresh_wt": (i32, [vp, vp]),
+    "dae_plan_stream_wait_dw": (i32, [vp, vp]),
+    "dae_plan_apply_rows_packed": (i32, [vp, i32, f32, vp, i32, i32, vp, i64, vp]),
+    "dae_plan_dp_unpack": (i32, [vp, vp, i32, i32, i64, i64, i32, f32, vp]),
+    "dae_dp_unpack": (i32, [vp, i32, i32, i64, i64, i32, i32, i32, vp, vp, i32, f32, f32, f32, vp, vp, vp, vp, vp, vp]),
     "dae_opt_step_rows": (i32, [i32, f32, f32, f32, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
     "dae_opt_bias": (i32, [i32, f32, f32, f32, vp, vp, vp, vp, vp, i32, i32, vp]),
     "dae_transpose_shadow": (i32, [vp, i32, i32, i32, vp, vp]),

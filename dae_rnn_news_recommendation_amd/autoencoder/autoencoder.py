@@ -435,20 +435,28 @@ class DenoisingAutoencoder(object):
                     eng.grad.zero_()
                     stats[b].zero_()
                 stats[b, L.STAT_TRIPLET] = tl; stats[b, L.STAT_FRACTION] = fr; stats[b, L.STAT_NUM] = num
-                self._exchange.step(grad_scale=1.0)
+                self._exchange.step(grad_scale=1.0, grad_ready_after_dw=hi > lo)
             elif world > 1:
                 # the global-batch mean is sum_r (rows_r / rows) * mean_r: every rank's gradient (and statistics) is weighted
                 # by its share of the rows, so ragged tails (37 rows on 4 ranks = 10/10/10/7) and empty shards stay exact
                 w = (hi - lo) / float(stop - start)
                 shard_w.append(w)
+                untouched = False                             # the W gradient is exactly what the step's dW kernel wrote
                 if hi > lo:
                     eng.train_step(rows, labs, stats[b], phase=1, **plan)
                     if abs(w * world - 1.0) > 1e-12:
                         eng.grad.mul_(w * world)
+                        if getattr(eng, "grad_lo", None) is not None:
+                            eng.grad_lo.mul_(w * world)
+                    else:
+                        untouched = True
                 else:
                     eng.grad.zero_()
+                    if getattr(eng, "grad_lo", None) is not None:
+                        eng.grad_lo.zero_()
                     stats[b].zero_()
-                self._exchange.step(grad_scale=1.0 / world)   # reduce-scatter -> sharded optimizer -> all-gather of W_lo
+                # reduce-scatter (beside the step tail when the gradient is untouched) -> sharded optimizer -> all-gather -> unpack
+                self._exchange.step(grad_scale=1.0 / world, grad_ready_after_dw=untouched)
             else:
                 eng.train_step(rows, labs, stats[b], phase=3, **plan)
         if world > 1 and getattr(self, '_miner', None) is not None:      # AE legs add up (cw is globally normalised); triplet stats are global

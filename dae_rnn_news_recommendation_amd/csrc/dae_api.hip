@@ -91,6 +91,8 @@ struct dae_plan {
     // depend on the labels only, so the chain is independent of the decode GEMM and runs beside it
     hipStream_t side;
     hipEvent_t ev_fork, ev_join;
+    hipEvent_t ev_dw;                 // recorded right behind the kernel that completes the W gradient (dae_plan_dw_event): a data-parallel
+                                      // caller starts its reduce-scatter from here, beside the step's tail kernel
     bool overlap_ok;
     bool sym_ride_ok;                 // Gs = a/Nv (G + G^T) computed by rider workgroups of the decode launch instead of its own launch
     bool miner_order_ok;              // dispatch the batch_all workgroups by descending sweep cost (LabelJob::order)
@@ -247,6 +249,7 @@ extern "C" void dae_plan_destroy(dae_plan* p) {
     if (p->ev1) (void)hipEventDestroy(p->ev1);
     if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
     if (p->ev_join) (void)hipEventDestroy(p->ev_join);
+    if (p->ev_dw) (void)hipEventDestroy(p->ev_dw);
     if (p->side) (void)hipStreamDestroy(p->side);
     delete p;
 }
@@ -625,6 +628,7 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
         // data parallel with a bf16 exchange image: the shape did not fit the kernel that writes it directly
         if (!apply_now && dt == DAE_BF16 && p->b.grad_lo) RC(launch_cast_bf16(p->b.grad, p->b.grad_lo, (int64_t)Fp * Hp, st));
     }
+    if (p->ev_dw) DAE_CHECK_HIP(hipEventRecord(p->ev_dw, st));      // the W gradient (grad / grad_lo) is complete from here on
     // 12. bias gradients
     float* g_bh = p->b.grad + (int64_t)Fp * Hp;
     const int64_t boff = (int64_t)Fp * Hp;
@@ -675,6 +679,45 @@ extern "C" int dae_plan_apply_rows(dae_plan* p, int32_t adam_t, float grad_scale
                         p->b.opt_s2 ? p->b.opt_s2 + off : nullptr, p->Hp, p->Fp, stream));
     }
     return 0;
+}
+
+// Data parallel: make `stream` wait until the W gradient of the LAST enqueued dae_train_step is complete (the event sits between the dW
+// GEMM and the step's tail kernel).  The first call creates the event; steps enqueued before it are not covered (returns 1 then).
+extern "C" int dae_plan_stream_wait_dw(dae_plan* p, void* stream) {
+    DAE_CHECK_ARG(p && p->bound, "plan_stream_wait_dw: plan not bound");
+    if (!p->ev_dw) {
+        DAE_CHECK_HIP(hipEventCreateWithFlags(&p->ev_dw, hipEventDisableTiming));
+        set_error("plan_stream_wait_dw: event created; it covers the steps enqueued from now on");
+        return 1;
+    }
+    DAE_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, p->ev_dw, 0));
+    return 0;
+}
+
+// Packed form of the sharded second half (dp.ShardedExchange): the low-precision rows of [f0, f1) go straight into the all-gather SEND
+// buffer (row f at send + (f - f0) * Hp * es) and this rank's bias gradients are copied behind them (bias_off_bytes) -- the biases ride on
+// the all-gather instead of their own all-reduce, and no copy of the updated rows is needed.  Biases are NOT updated here.
+extern "C" int dae_plan_apply_rows_packed(dae_plan* p, int32_t adam_t, float grad_scale, const float* grad_rows, int32_t f0, int32_t f1,
+                                          void* send, int64_t bias_off_bytes, void* stream) {
+    DAE_CHECK_ARG(p && p->bound && grad_rows && send, "plan_apply_rows_packed: plan not bound / null buffer");
+    DAE_CHECK_ARG(f0 >= 0 && f0 <= f1 && f1 <= p->Fp && f0 % 64 == 0 && f1 % 64 == 0, "plan_apply_rows_packed: rows [%d, %d) outside [0, %d] or not multiples of 64", f0, f1, p->Fp);
+    const float lr = plan_lr(p, adam_t);
+    char* lo_base = (char*)send - (int64_t)f0 * p->Hp * p->es;                 // dae_opt_step_rows writes row f at base + f * Hp * es
+    RC(dae_opt_step_rows(p->cfg.opt, lr, p->cfg.momentum, grad_scale, p->b.W, grad_rows, p->b.opt_s1, p->b.opt_s2, p->Hp, f0, f1, p->cfg.dtype,
+                         lo_base, stream));
+    DAE_CHECK_HIP(hipMemcpyAsync((char*)send + bias_off_bytes, p->b.grad + (int64_t)p->Fp * p->Hp, (size_t)(p->Hp + p->Fp) * sizeof(float),
+                                 hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+
+// After the all-gather of the packed chunks: W_lo, Wt_lo and the biases of this rank (see dp_unpack_kernel).
+extern "C" int dae_plan_dp_unpack(dae_plan* p, const void* recv, int32_t world, int32_t chunk_rows, int64_t chunk_stride_bytes,
+                                  int64_t bias_off_bytes, int32_t adam_t, float grad_scale, void* stream) {
+    DAE_CHECK_ARG(p && p->bound && recv, "plan_dp_unpack: plan not bound / null buffer");
+    const int64_t off = (int64_t)p->Fp * p->Hp;
+    return dae_dp_unpack(recv, world, chunk_rows, chunk_stride_bytes, bias_off_bytes, p->Fp, p->Hp, p->cfg.dtype, p->b.W_lo, p->b.Wt_lo, p->cfg.opt,
+                         plan_lr(p, adam_t), p->cfg.momentum, grad_scale, p->b.bh, p->b.bv, p->b.opt_s1 ? p->b.opt_s1 + off : nullptr,
+                         p->b.opt_s2 ? p->b.opt_s2 + off : nullptr, p->b.grad + off, stream);
 }
 
 extern "C" int dae_plan_refresh_wt(dae_plan* p, void* stream) {

@@ -389,6 +389,42 @@ __global__ __launch_bounds__(256) void transpose_lo_kernel(const T* __restrict__
     for (int r = ty; r < 64; r += 4) Wt_lo[(int64_t)(j0 + r) * Fp + f0 + tx] = tile[tx][r];
 }
 
+// Data-parallel step, after the all-gather: `recv` holds one chunk per rank, each = [chunk_rows x Hp low-precision rows of W owned by
+// that rank | ... | that rank's LOCAL bias gradients (Hp + Fp floats) at bias_off].  Blocks (x, y < Fp / 64) copy a 64 x 64 tile of rows
+// into the contiguous shadow W_lo AND write its transpose into Wt_lo (the rebuild that used to be its own launch after a separate copy);
+// blocks y >= Fp / 64 sum the ranks' bias gradients in rank order (identical on every rank) and apply the optimizer to bh / bv.
+template <typename T>
+__global__ __launch_bounds__(256) void dp_unpack_kernel(const char* __restrict__ recv, int world, int chunk_rows, int64_t chunk_stride,
+                                                        int64_t bias_off, int Fp, int Hp, T* __restrict__ W_lo, T* __restrict__ Wt_lo,
+                                                        int opt, float lr, float mom, float gscale, float* __restrict__ bh, float* __restrict__ bv,
+                                                        float* __restrict__ s1b, float* __restrict__ s2b, float* __restrict__ grad_b) {
+    __shared__ T tile[64][66];
+    const int ty_tiles = Fp / 64;
+    if ((int)blockIdx.y >= ty_tiles) {
+        const int k = (((int)blockIdx.y - ty_tiles) * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+        if (k >= Hp + Fp) return;
+        float g = 0.f;
+        for (int r = 0; r < world; ++r) g += reinterpret_cast<const float*>(recv + (int64_t)r * chunk_stride + bias_off)[k];
+        grad_b[k] = g;                                        // the rank-summed bias gradient stays readable (Engine.grads)
+        float* q = (k < Hp) ? &bh[k] : &bv[k - Hp];
+        *q = opt_update(opt, lr, mom, *q, g * gscale, s1b, s2b, k);
+        return;
+    }
+    const int j0 = blockIdx.x * 64, f0 = blockIdx.y * 64;
+    const int r = f0 / chunk_rows;                            // chunk_rows % 64 == 0: a tile never straddles two ranks' chunks
+    const T* src = reinterpret_cast<const T*>(recv + (int64_t)r * chunk_stride) + (int64_t)(f0 - r * chunk_rows) * Hp;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll 4
+    for (int i = ty; i < 64; i += 4) {
+        const T v = src[(int64_t)i * Hp + j0 + tx];
+        tile[i][tx] = v;
+        W_lo[(int64_t)(f0 + i) * Hp + j0 + tx] = v;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int i = ty; i < 64; i += 4) Wt_lo[(int64_t)(j0 + i) * Fp + f0 + tx] = tile[tx][i];
+}
+
 __global__ void opt_bias_kernel(int opt, float lr, float mom, float gscale, float* __restrict__ bh, float* __restrict__ bv,
                                 const float* __restrict__ grad_b, float* __restrict__ s1b, float* __restrict__ s2b, int Hp,
                                 int Fp) {
@@ -686,6 +722,25 @@ extern "C" int dae_opt_step_rows(int32_t opt, float lr, float momentum, float gr
     else
         hipLaunchKernelGGL((opt_w_kernel<float>), grid, block, 0, ST(stream), opt, lr, momentum, grad_scale, W + off, grad_rows, s1 ? s1 + off : nullptr,
                            s2 ? s2 + off : nullptr, 0, Hp, (float*)((char*)W_lo + off * es), (float*)nullptr, 1);
+    DAE_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int dae_dp_unpack(const void* recv, int32_t world, int32_t chunk_rows, int64_t chunk_stride_bytes, int64_t bias_off_bytes,
+                             int32_t Fp, int32_t Hp, int32_t dtype, void* W_lo, void* Wt_lo, int32_t opt, float lr, float momentum,
+                             float grad_scale, float* bh, float* bv, float* s1b, float* s2b, float* grad_b, void* stream) {
+    DAE_CHECK_ARG(recv && W_lo && Wt_lo && bh && bv && grad_b && world >= 1 && Fp % 64 == 0 && Hp % 64 == 0 && chunk_rows % 64 == 0 && chunk_rows > 0,
+                  "dp_unpack: bad args");
+    DAE_CHECK_ARG((int64_t)world * chunk_rows >= Fp && bias_off_bytes % 4 == 0 && chunk_stride_bytes % 16 == 0, "dp_unpack: chunks do not cover W");
+    DAE_CHECK_ARG(opt >= DAE_OPT_SGD && opt <= DAE_OPT_ADAM && (opt == DAE_OPT_SGD || s1b) && (opt != DAE_OPT_ADAM || s2b), "dp_unpack: optimizer slots");
+    const int gx = Hp / 64, nb = (Hp + Fp + 255) / 256;
+    dim3 grid(gx, Fp / 64 + (nb + gx - 1) / gx), block(256);
+    if (dtype == DAE_BF16)
+        hipLaunchKernelGGL((dp_unpack_kernel<bf16_t>), grid, block, 0, ST(stream), (const char*)recv, world, chunk_rows, chunk_stride_bytes, bias_off_bytes,
+                           Fp, Hp, (bf16_t*)W_lo, (bf16_t*)Wt_lo, opt, lr, momentum, grad_scale, bh, bv, s1b, s2b, grad_b);
+    else
+        hipLaunchKernelGGL((dp_unpack_kernel<float>), grid, block, 0, ST(stream), (const char*)recv, world, chunk_rows, chunk_stride_bytes, bias_off_bytes,
+                           Fp, Hp, (float*)W_lo, (float*)Wt_lo, opt, lr, momentum, grad_scale, bh, bv, s1b, s2b, grad_b);
     DAE_CHECK_LAUNCH();
     return 0;
 }

@@ -114,17 +114,21 @@ class ShardedExchange:
 
         reduce-scattered by row chunks   -> rank r receives the rank-summed gradient of ITS rows      ((R-1)/R * 20.7 MB fp32,
                                                                                                          or 10.4 MB as bf16)
-        updated by the optimizer there   -> sharded master weights / optimizer slots (dae_plan_apply_rows)
-        all-gathered as the bf16 shadow  -> every rank receives W_lo                                  ((R-1)/R * 10.4 MB)
+        updated by the optimizer there   -> sharded master weights / optimizer slots; the low-precision rows are written
+                                            straight into the all-gather send buffer (dae_plan_apply_rows_packed)
+        all-gathered as the bf16 shadow  -> every rank receives all chunks                             ((R-1)/R * 10.4 MB)
+        unpacked                         -> W_lo, Wt_lo and the biases in one kernel (dae_plan_dp_unpack)
 
-    and Wt_lo is rebuilt locally (dae_plan_refresh_wt).  The bias part (10.6 K floats) is all-reduced and applied on every
-    rank.  Per step and rank that is 3/4 (fp32 gradients) or 1/2 (bf16 gradients) of the all-reduce's traffic, in two collectives
-    that RCCL runs as direct exchanges over all 7 links.  Only the owner of a row block holds its current fp32 master;
-    ``gather_master`` rebuilds the full W where it is needed (get_params / checkpoint).
+    TWO collectives per step: the bias gradients (10.6 K floats per rank) do not get an all-reduce of their own -- every rank
+    appends its LOCAL bias gradients to its all-gather chunk and all ranks sum the gathered pieces in rank order (identical
+    result everywhere).  The reduce-scatter is issued on a side stream right behind the dW GEMM, so it runs beside the step's tail
+    kernel (bias gradients, statistics, x~^T un-scatter) instead of after it.  Only the owner of a row block holds its current fp32
+    master; ``gather_master`` / ``gather_slots`` rebuild the full state where it is needed (get_params / checkpoint).
+    ``packed=False`` keeps the former three-collective form (A/B in tools/dp_step_breakdown.py).
 
-    ``collective_ms`` accumulates the time of the collectives (events on the current stream when it is a CUDA stream)."""
+    ``collective_ms`` accumulates the time of the collectives (events on the streams they run on, CUDA only)."""
 
-    def __init__(self, eng, grad_dtype="fp32"):
+    def __init__(self, eng, grad_dtype="fp32", packed=True, overlap=True):
         import torch
         import torch.distributed as dist
         assert is_initialized(), "torch.distributed is not initialised"
@@ -133,6 +137,7 @@ class ShardedExchange:
         assert eng.dp_world == self.world, "create the Engine with dp_world = world size (%d != %d)" % (eng.dp_world, self.world)
         assert grad_dtype in ("fp32", "bf16")
         self.grad_dtype = grad_dtype
+        self.packed = bool(packed)
         # only the bf16 shadow W_lo is all-gathered: the fp32 masters of the rows another rank owns are stale here, so the sparse
         # encode must read W_lo (single-GPU bf16 steps read the fp32 master, option encode_w32)
         eng.set_option("encode_w32", 0)
@@ -144,23 +149,25 @@ class ShardedExchange:
         self.rs_out = torch.zeros(c * Hp, dtype=gdt, device=eng.device)
         self.rs_f32 = self.rs_out if grad_dtype == "fp32" else torch.zeros(c * Hp, dtype=torch.float32, device=eng.device)
         self.my_lo = torch.zeros((c, Hp), dtype=eng.td, device=eng.device)
+        # packed chunk: [c x Hp low-precision rows | pad to 16 B | Hp + Fp fp32 bias gradients | pad to 16 B]
+        es = 2 if eng.td == torch.bfloat16 else 4
+        self.bias_off = -(-(c * Hp * es) // 16) * 16
+        self.chunk_stride = self.bias_off + -(-((Hp + eng.Fp) * 4) // 16) * 16
+        self.send = torch.zeros(self.chunk_stride, dtype=torch.uint8, device=eng.device)
+        self.recv = torch.zeros(self.world * self.chunk_stride, dtype=torch.uint8, device=eng.device)
         self.collective_ms = 0.0
         self.steps = 0
         self._ev = None
+        self._side = None
         if eng.device.type == "cuda":
-            self._ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True),
-                        torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self._ev = tuple(torch.cuda.Event(enable_timing=True) for _ in range(4))
+            if overlap and self.packed:
+                self._side = torch.cuda.Stream(device=eng.device)
+                self._ev_dw = torch.cuda.Event(); self._ev_rs = torch.cuda.Event()
         self._pending = None
 
-    def step(self, grad_scale):
-        """Call after eng.train_step(phase=1): exchange + sharded update + shadow rebuild.  grad_scale multiplies the rank-SUMMED
-        gradient (1/world for equal shards)."""
+    def _reduce_scatter(self, gw):
         torch, dist, eng = self.torch, self.dist, self.eng
-        Hp, c = eng.Hp, eng.chunk_rows
-        gw = eng.grad[:self.n_w]
-        bias = eng.grad[eng.Fp * Hp:eng.Fp * Hp + Hp + eng.Fp]
-        if self._ev:
-            self._ev[0].record()
         if self.grad_dtype == "fp32":
             dist.reduce_scatter_tensor(self.rs_out, gw, op=dist.ReduceOp.SUM)
         else:
@@ -168,6 +175,55 @@ class ShardedExchange:
             src = eng.grad_lo.view(-1) if getattr(eng, "grad_lo", None) is not None else gw.to(torch.bfloat16)
             dist.reduce_scatter_tensor(self.rs_out, src, op=dist.ReduceOp.SUM)
             self.rs_f32.copy_(self.rs_out)
+
+    def step(self, grad_scale, grad_ready_after_dw=False):
+        """Call after eng.train_step(phase=1): exchange + sharded update + shadow rebuild.  grad_scale multiplies the rank-SUMMED
+        gradient (1/world for equal shards).  grad_ready_after_dw=True: the W gradient is exactly what the step's dW kernel wrote
+        (nothing was enqueued behind train_step that touches it), so the reduce-scatter may start behind that kernel, beside the
+        step's tail; otherwise it starts behind everything enqueued so far."""
+        torch, dist, eng = self.torch, self.dist, self.eng
+        Hp, c = eng.Hp, eng.chunk_rows
+        gw = eng.grad[:self.n_w]
+        if not self.packed:
+            return self._step_three_collectives(grad_scale)
+        if self._side is not None:
+            # reduce-scatter on the side stream: it waits for the W gradient only (the last mark, else everything enqueued so far)
+            cur = torch.cuda.current_stream()
+            if not (grad_ready_after_dw and eng.stream_wait_dw(self._side)):
+                self._ev_dw.record(cur)
+                self._side.wait_event(self._ev_dw)
+            with torch.cuda.stream(self._side):
+                self._ev[0].record()
+                self._reduce_scatter(gw)
+                self._ev[1].record()
+                self._ev_rs.record()
+            cur.wait_event(self._ev_rs)
+        else:
+            if self._ev:
+                self._ev[0].record()
+            self._reduce_scatter(gw)
+            if self._ev:
+                self._ev[1].record()
+        eng.adam_t += 1 if eng.opt == "adam" else 0
+        eng.apply_rows_packed(self.rs_f32, self.f0, self.f1, self.send, self.bias_off, grad_scale=grad_scale)
+        if self._ev:
+            self._ev[2].record()
+        dist.all_gather_into_tensor(self.recv, self.send)
+        if self._ev:
+            self._ev[3].record()
+        eng.dp_unpack(self.recv, self.world, self.chunk_stride, self.bias_off, grad_scale=grad_scale)
+        self.steps += 1
+        if self._ev:
+            self._pending = True
+
+    def _step_three_collectives(self, grad_scale):
+        torch, dist, eng = self.torch, self.dist, self.eng
+        Hp, c = eng.Hp, eng.chunk_rows
+        gw = eng.grad[:self.n_w]
+        bias = eng.grad[eng.Fp * Hp:eng.Fp * Hp + Hp + eng.Fp]
+        if self._ev:
+            self._ev[0].record()
+        self._reduce_scatter(gw)
         dist.all_reduce(bias, op=dist.ReduceOp.SUM)
         if self._ev:
             self._ev[1].record()

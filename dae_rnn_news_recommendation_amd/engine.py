@@ -209,6 +209,22 @@ class Engine:
         L.check(self.lib.dae_plan_apply_rows(self.plan, self.adam_t, float(grad_scale), L.ptr(grad_rows), int(f0), int(f1),
                                              int(bool(update_bias)), L.current_stream()), "dae_plan_apply_rows")
 
+    def stream_wait_dw(self, stream):
+        """Make the torch stream `stream` wait for the W gradient of the last enqueued step (event between the dW GEMM and the step tail).
+        Returns False when the event did not exist yet (first call): the caller then waits for the whole step."""
+        return self.lib.dae_plan_stream_wait_dw(self.plan, C.c_void_p(stream.cuda_stream)) == 0
+
+    def apply_rows_packed(self, grad_rows, f0, f1, send, bias_off, grad_scale=1.0):
+        """Sharded-optimizer step on the rows [f0, f1); their low-precision image goes straight into the all-gather send buffer
+        `send` (uint8 tensor) and this rank's bias gradients are copied to send[bias_off:] (dp.ShardedExchange, packed form)."""
+        L.check(self.lib.dae_plan_apply_rows_packed(self.plan, self.adam_t, float(grad_scale), L.ptr(grad_rows), int(f0), int(f1),
+                                                    L.ptr(send), int(bias_off), L.current_stream()), "dae_plan_apply_rows_packed")
+
+    def dp_unpack(self, recv, world, chunk_stride, bias_off, grad_scale=1.0):
+        """After the all-gather of the packed chunks: W_lo, Wt_lo and the biases (rank-ordered sum of the gathered bias gradients)."""
+        L.check(self.lib.dae_plan_dp_unpack(self.plan, L.ptr(recv), int(world), int(self.chunk_rows), int(chunk_stride), int(bias_off),
+                                            self.adam_t, float(grad_scale), L.current_stream()), "dae_plan_dp_unpack")
+
     def refresh_wt(self):
         L.check(self.lib.dae_plan_refresh_wt(self.plan, L.current_stream()), "dae_plan_refresh_wt")
 

@@ -439,6 +439,25 @@ int      dae_plan_apply(dae_plan* p, int32_t adam_t, float grad_scale, void* str
 int      dae_plan_apply_rows(dae_plan* p, int32_t adam_t, float grad_scale, const float* grad_rows, int32_t f0, int32_t f1,
                              int32_t update_bias, void* stream);
 int      dae_plan_refresh_wt(dae_plan* p, void* stream);
+
+/* Packed exchange of the data-parallel step (two collectives per step instead of three, no copy, one rebuild kernel):
+ *   dae_plan_apply_rows_packed: the sharded optimizer step of dae_plan_apply_rows, but the low-precision rows of [f0, f1) are written
+ *     into the all-gather SEND buffer (row f at send + (f - f0) * Hp * elem) and this rank's LOCAL bias gradients (Hp + Fp floats) are
+ *     copied to send + bias_off_bytes; the biases are not updated.
+ *   dae_plan_dp_unpack: after all-gathering the send buffers into recv (world chunks of chunk_stride_bytes): W_lo <- the rows,
+ *     Wt_lo <- their transpose, and the biases are updated from the rank-ordered sum of the gathered bias gradients (every rank
+ *     computes the same sum).  dae_dp_unpack is the plan-free form. */
+/* Data parallel: `stream` waits until the W gradient of the last enqueued dae_train_step is complete (an event between the dW GEMM and
+ * the step's tail kernel), so that a reduce-scatter issued on `stream` runs beside the tail.  The first call only creates the event and
+ * returns 1 (steps enqueued earlier are not covered: wait for the step's stream instead). */
+int dae_plan_stream_wait_dw(dae_plan* plan, void* stream);
+int dae_plan_apply_rows_packed(dae_plan* plan, int32_t adam_t, float grad_scale, const float* grad_rows, int32_t f0, int32_t f1,
+                               void* send, int64_t bias_off_bytes, void* stream);
+int dae_plan_dp_unpack(dae_plan* plan, const void* recv, int32_t world, int32_t chunk_rows, int64_t chunk_stride_bytes,
+                       int64_t bias_off_bytes, int32_t adam_t, float grad_scale, void* stream);
+int dae_dp_unpack(const void* recv, int32_t world, int32_t chunk_rows, int64_t chunk_stride_bytes, int64_t bias_off_bytes,
+                  int32_t Fp, int32_t Hp, int32_t dtype, void* W_lo, void* Wt_lo, int32_t opt, float lr, float momentum,
+                  float grad_scale, float* bh, float* bv, float* s1b, float* s2b, float* grad_b, void* stream);
 /* transform(): out[B x H] fp32 (ld_out) = encode of rows row_idx (autoencoder.py:479-505) */
 int      dae_encode_rows(dae_plan* p, const int32_t* row_idx, int32_t B, float scale,
                          const int64_t* indptr, const int32_t* indices, const float* values,

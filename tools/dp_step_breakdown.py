@@ -27,16 +27,24 @@ def timed(fn, n=50):
     return 1e3 * e0.elapsed_time(e1) / n, host
 Hp, c = eng.Hp, eng.chunk_rows
 gw = eng.grad[:ex.n_w]; bias = eng.grad[eng.Fp * Hp:eng.Fp * Hp + Hp + eng.Fp]
+ex3 = dp.ShardedExchange(eng, grad_dtype=a.grad_dtype, packed=False)
+def step_and(exch, after_dw):
+    eng.train_step(idx, labs, stats, phase=1, **kw); exch.step(grad_scale=1.0, grad_ready_after_dw=after_dw)
 rows = [("fused single-GPU step (phase 3)", lambda: eng.train_step(idx, labs, stats, phase=3, **kw)),
         ("phase-1 step (gradient to memory)", lambda: eng.train_step(idx, labs, stats, phase=1, **kw)),
         ("reduce_scatter (1 rank)", lambda: dist.reduce_scatter_tensor(ex.rs_out, gw if a.grad_dtype == "fp32" else gw.to(torch.bfloat16))),
-        ("all_reduce bias (1 rank)", lambda: dist.all_reduce(bias)),
-        ("apply_rows (all rows at 1 rank)", lambda: eng.apply_rows(ex.rs_f32, ex.f0, ex.f1, grad_scale=1.0, update_bias=True)),
-        ("copy of my W_lo rows", lambda: ex.my_lo.copy_(eng.W_lo_full[:c])),
-        ("all_gather (1 rank)", lambda: dist.all_gather_into_tensor(eng.W_lo_full.view(-1), ex.my_lo.view(-1))),
-        ("refresh_wt (transpose rebuild)", lambda: eng.refresh_wt()),
-        ("whole exchange.step", lambda: ex.step(grad_scale=1.0)),
-        ("phase-1 step + exchange.step", lambda: (eng.train_step(idx, labs, stats, phase=1, **kw), ex.step(grad_scale=1.0)))]
+        ("apply_rows_packed (all rows at 1 rank)", lambda: eng.apply_rows_packed(ex.rs_f32, ex.f0, ex.f1, ex.send, ex.bias_off, grad_scale=1.0)),
+        ("all_gather of the packed chunk (1 rank)", lambda: dist.all_gather_into_tensor(ex.recv, ex.send)),
+        ("dp_unpack (W_lo + Wt_lo + biases)", lambda: eng.dp_unpack(ex.recv, 1, ex.chunk_stride, ex.bias_off, grad_scale=1.0)),
+        ("whole exchange.step, packed", lambda: ex.step(grad_scale=1.0)),
+        ("phase-1 step + packed exchange", lambda: step_and(ex, False)),
+        ("  ... reduce-scatter beside the tail", lambda: step_and(ex, True)),
+        ("former form: all_reduce bias (1 rank)", lambda: dist.all_reduce(bias)),
+        ("former form: apply_rows", lambda: eng.apply_rows(ex3.rs_f32, ex3.f0, ex3.f1, grad_scale=1.0, update_bias=True)),
+        ("former form: copy of my W_lo rows", lambda: ex3.my_lo.copy_(eng.W_lo_full[:c])),
+        ("former form: refresh_wt", lambda: eng.refresh_wt()),
+        ("former form: whole exchange.step", lambda: ex3.step(grad_scale=1.0)),
+        ("former form: phase-1 step + exchange", lambda: step_and(ex3, False))]
 print(f"{'piece':40s} {'GPU us':>9s} {'host us/call':>13s}")
 for name, fn in rows:
     g, h = timed(fn)
