@@ -121,14 +121,15 @@ class ShardedExchange:
 
     TWO collectives per step: the bias gradients (10.6 K floats per rank) do not get an all-reduce of their own -- every rank
     appends its LOCAL bias gradients to its all-gather chunk and all ranks sum the gathered pieces in rank order (identical
-    result everywhere).  The reduce-scatter is issued on a side stream right behind the dW GEMM, so it runs beside the step's tail
-    kernel (bias gradients, statistics, x~^T un-scatter) instead of after it.  Only the owner of a row block holds its current fp32
-    master; ``gather_master`` / ``gather_slots`` rebuild the full state where it is needed (get_params / checkpoint).
-    ``packed=False`` keeps the former three-collective form (A/B in tools/dp_step_breakdown.py).
+    result everywhere).  Only the owner of a row block holds its current fp32 master; ``gather_master`` / ``gather_slots`` rebuild
+    the full state where it is needed (get_params / checkpoint).  ``packed=False`` keeps the former three-collective form and
+    ``overlap=True`` issues the reduce-scatter on a side stream right behind the dW GEMM, beside the step's tail kernel -- measured
+    SLOWER with torch.distributed's RCCL process group (every collective already hops to the group's own stream and back; a second
+    hop costs more than the 10 us of tail it hides: profiles/r03_dp_step_breakdown.txt), so it is off by default.
 
     ``collective_ms`` accumulates the time of the collectives (events on the streams they run on, CUDA only)."""
 
-    def __init__(self, eng, grad_dtype="fp32", packed=True, overlap=True):
+    def __init__(self, eng, grad_dtype="fp32", packed=True, overlap=False):
         import torch
         import torch.distributed as dist
         assert is_initialized(), "torch.distributed is not initialised"

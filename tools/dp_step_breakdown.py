@@ -28,6 +28,7 @@ def timed(fn, n=50):
 Hp, c = eng.Hp, eng.chunk_rows
 gw = eng.grad[:ex.n_w]; bias = eng.grad[eng.Fp * Hp:eng.Fp * Hp + Hp + eng.Fp]
 ex3 = dp.ShardedExchange(eng, grad_dtype=a.grad_dtype, packed=False)
+exn = dp.ShardedExchange(eng, grad_dtype=a.grad_dtype, packed=True, overlap=False)
 def step_and(exch, after_dw):
     eng.train_step(idx, labs, stats, phase=1, **kw); exch.step(grad_scale=1.0, grad_ready_after_dw=after_dw)
 rows = [("fused single-GPU step (phase 3)", lambda: eng.train_step(idx, labs, stats, phase=3, **kw)),
@@ -39,6 +40,8 @@ rows = [("fused single-GPU step (phase 3)", lambda: eng.train_step(idx, labs, st
         ("whole exchange.step, packed", lambda: ex.step(grad_scale=1.0)),
         ("phase-1 step + packed exchange", lambda: step_and(ex, False)),
         ("  ... reduce-scatter beside the tail", lambda: step_and(ex, True)),
+        ("packed, everything on the step's stream", lambda: exn.step(grad_scale=1.0)),
+        ("phase-1 step + that", lambda: step_and(exn, False)),
         ("former form: all_reduce bias (1 rank)", lambda: dist.all_reduce(bias)),
         ("former form: apply_rows", lambda: eng.apply_rows(ex3.rs_f32, ex3.f0, ex3.f1, grad_scale=1.0, update_bias=True)),
         ("former form: copy of my W_lo rows", lambda: ex3.my_lo.copy_(eng.W_lo_full[:c])),
