@@ -6,8 +6,11 @@ With the CLI's lr 0.1 the decoder saturates from the 5th step on: logits beyond 
 literal cross entropy then charges log(1e-16) = -36.8 for such a unit instead of ~-z, and its autodiff gives it a zero gradient.
 The fp32 step reproduces that to 1e-5 over all 20 steps.  With bf16 MFMA operands a logit carries ~4e-3 relative error, so units
 within ~0.07 of the rounding threshold land on the other side of a 20-unit jump of the loss: steps in the saturated regime are
-held to 1e-3, the steps before it to the 1e-4 gate.  The triplet leg (1-3 units of a cost of 3500-7600) is checked on its own at
-1e-2 in bf16: at this learning rate the embeddings move by O(1) per step and bf16 W rounding shows in h.h differences."""
+held to 6e-4 (measured: <= 2.8e-4 at steps 4-7, <= 6e-6 from step 10 on; profiles/r03_bf16_curve.txt), the steps before it to the
+1e-4 gate.  The triplet leg (0.7 of a cost of 3500-7600) is checked on its own: <= 1e-4 for steps 0-2 (measured 2.6e-5), 5e-4 at
+step 3, 1e-2 afterwards (measured: growing to 6.8e-3 at step 19) -- the encode reads the fp32 master weights, so h is exact GIVEN W;
+what drifts is W itself (bf16 delta2 / h / W operands in the three gradient GEMMs, accumulated over the steps), and the triplet
+loss ~ 0.69 + mean(T)/2 turns a 1e-2 shift of the mean distance gap into 7e-3.  precision='fp32' holds 2e-5 throughout."""
 import os
 import sys
 
@@ -21,7 +24,7 @@ PATH = os.path.join(HERE, "golden", "full_curve_c2.npz")
 
 
 @pytest.mark.skipif(not os.path.exists(PATH), reason="tests/golden/full_curve_c2.npz not generated")
-@pytest.mark.parametrize("precision,tol,tol_saturated", [("fp32", 2e-5, 2e-5), ("bf16", 1e-4, 1e-3)])
+@pytest.mark.parametrize("precision,tol,tol_saturated", [("fp32", 2e-5, 2e-5), ("bf16", 1e-4, 6e-4)])
 def test_full_shape_loss_curve(tmp_path, precision, tol, tol_saturated):
     sys.path.insert(0, os.path.join(HERE, "golden"))
     import make_full_curve as M
@@ -42,7 +45,8 @@ def test_full_shape_loss_curve(tmp_path, precision, tol, tol_saturated):
             rel = np.abs(pb[:, col] - G[key][e]) / np.abs(G[key][e])
             gate = np.where(np.arange(pb.shape[0]) + e * pb.shape[0] < 4, tol, tol_saturated)     # steps 0-3: no saturated logit yet
             if key == "triplet" and precision == "bf16":
-                gate = np.maximum(gate, 1e-2)
+                step = np.arange(pb.shape[0]) + e * pb.shape[0]
+                gate = np.where(step < 3, 1e-4, np.where(step == 3, 5e-4, 1e-2))
             assert (rel <= gate).all(), (precision, e, key, rel)
         if precision == "fp32":
             assert np.abs(pb[:, 4] - G["num"][e]).max() <= 200        # of ~5*10^7 positive triplets: near-ties of the fp32 Gram matrix

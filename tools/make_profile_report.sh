@@ -24,9 +24,9 @@ rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/pmc_sq2 $OUT/pmc_fetch4 $O
 python tools/build_profile_summary.py $OUT $TAG --traffic-only > /dev/null
 $T python bench.py --config c2 --steps 300 --warmup 30 > $OUT/bench_c2.json 2> $OUT/bench.err
 $T python bench.py --config c1 --steps 300 --warmup 30 > $OUT/bench_c1.json 2>> $OUT/bench.err
-$T python bench.py --config c3 --steps 300 --warmup 30 --no-cpu-baseline > $OUT/bench_c3.json 2>> $OUT/bench.err
+$T python bench.py --config c3 --steps 300 --warmup 30 > $OUT/bench_c3.json 2>> $OUT/bench.err
 $T python bench.py --config c5 --steps 200 --warmup 20 --no-cpu-baseline > $OUT/bench_c5.json 2>> $OUT/bench.err
-$T python bench.py --config c4 --steps 100 --warmup 10 --no-cpu-baseline > $OUT/bench_c4.json 2>> $OUT/bench.err
+$T python bench.py --config c4 --steps 100 --warmup 10 > $OUT/bench_c4.json 2>> $OUT/bench.err
 $T rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-roofline --no-fit --no-fp32 > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
 python tools/rocprof_summary.py $OUT/trace/t_results.db > $OUT/kernel_stats.md
 rm -rf $OUT/trace
