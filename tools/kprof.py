@@ -19,11 +19,14 @@ ap.add_argument("--corr", default="philox", choices=["philox", "bits", "none"])
 ap.add_argument("--opt", action="append", default=[], help="plan option name=value (dae_plan_set_option), repeatable")
 ap.add_argument("--unsorted", action="store_true", help="batches in row order instead of class-sorted")
 ap.add_argument("--lib", default="", help="alternative libdae_hip build (probe variants; tools only)")
+ap.add_argument("--glds", type=int, action="append", default=[], help="dae_set_glds code(s), e.g. -8 = dW on the producer/consumer kernel")
 a = ap.parse_args()
 if a.lib:
     L.LIB_PATH = os.path.abspath(a.lib)
 if a.nst >= 0:
     L.load().dae_set_glds(a.nst)
+for code in a.glds:
+    L.load().dae_set_glds(code)
 m = synthetic_csr(a.rows, a.features, seed=1); lab = synthetic_labels(a.rows, seed=1).astype(np.int32)
 eng = Engine(a.features, a.hidden, a.batch, dtype=a.precision, triplet=a.strategy, loss_func=a.loss, learning_rate=0.1,
              encode_splits=a.enc_splits, dh_splits=a.enc_splits, gram_splits=a.gram_splits)
@@ -66,6 +69,6 @@ for _ in range(200):
 e1.record(); torch.cuda.synchronize()
 free_us = 1e3 * e0.elapsed_time(e1) / 200
 tot = sum(ms for ms, n in prof.values())
-print(f"== corr={a.corr} {a.tag} {a.opt} {a.strategy} {a.precision} total {1e3*tot/a.steps:.1f} us/step (bracketed kernels), {free_us:.1f} us/step un-profiled  info={eng.info()}")
+print(f"== corr={a.corr} {a.tag} glds={a.glds} {a.opt} {a.strategy} {a.precision} total {1e3*tot/a.steps:.1f} us/step (bracketed kernels), {free_us:.1f} us/step un-profiled  info={eng.info()}")
 for k, (ms, n) in prof.items():
     if n: print(f"   {k:18s} {1e3*ms/n:9.1f} us  x{n/a.steps:.0f}")
