@@ -42,69 +42,63 @@ __device__ __forceinline__ void w8_block_to_tile(const W8Params& p, int& tm, int
     kt1 = (int)(((int64_t)p.ktiles_total * (split + 1)) / p.splits);
 }
 
-template <int ROLE>
-__global__ __launch_bounds__(W8_THREADS, 1) void gemm_nt_w8(W8Params p, float* __restrict__ C, int64_t ldc, int64_t slab_stride) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    int tm, tn, split, kt0, kt1;
-    w8_block_to_tile(p, tm, tn, split, kt0, kt1);
+// K loop of one 256 x 256 tile: rows [row0_m, +256) of A (clamped to p.M), rows [row0_n, +256) of Bt (clamped to p.N), K tiles [kt0, kt1).
+// acc[mt][nt]: the wave's 128 x 64 block (wm = wave >> 2, wn = wave & 3), 32 x 32 accumulators in the MFMA register layout.
+__device__ __forceinline__ void w8_mainloop(const W8Params& p, int row0_m, int row0_n, int kt0, int kt1, char* lds, f32x16 (&acc)[4][2]) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;                 // 2 x 4 waves: rows [128 wm, +128), columns [64 wn, +64)
     const int nk = kt1 - kt0;
-    const int row0_m = tm * W8_BM, row0_n = tn * W8_BN;
-
-    f32x16 acc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    if (nk <= 0) return;
+    // ---- LDS-DMA addressing: 4 pieces (8 rows x 128 B) per operand per wave and stage ----
+    uint32_t voA[4], voB[4];
+    const char *gA = nullptr, *gB = nullptr;
+    int kt_dma = kt0;
+    auto seg_setup = [&](int kt) {
+        const int sg = kt >= p.seg[0].ktiles ? 1 : 0;
+        const int k = kt - (sg ? p.seg[0].ktiles : 0);
+        const uint32_t lda = (uint32_t)p.seg[sg].lda_b, ldb = (uint32_t)p.seg[sg].ldb_b;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (i * 8 + wave) * 8 + (lane >> 3);
+            const uint32_t ss = (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) << 4);
+            voA[i] = (uint32_t)min(row0_m + row, p.M - 1) * lda + ss;
+            voB[i] = (uint32_t)min(row0_n + row, p.N - 1) * ldb + ss;
+        }
+        gA = p.seg[sg].A + (int64_t)k * BKB;
+        gB = p.seg[sg].Bt + (int64_t)k * BKB;
+    };
+    seg_setup(kt0);
+    auto dma_stage = [&](char* slot) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int piece = i * 8 + wave;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gA + voA[i]),
+                                             (__attribute__((address_space(3))) void*)(slot + piece * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gB + voB[i]),
+                                             (__attribute__((address_space(3))) void*)(slot + W8_TILE_BYTES + piece * 1024), 16, 0, 0);
+        }
+        ++kt_dma;
+        if (kt_dma == p.seg[0].ktiles) { if (kt_dma < p.ktiles_total) seg_setup(kt_dma); }
+        else { gA += BKB; gB += BKB; }
+    };
 
-    if (nk > 0) {
-        // ---- LDS-DMA addressing: 4 pieces (8 rows x 128 B) per operand per wave and stage ----
-        uint32_t voA[4], voB[4];
-        const char *gA = nullptr, *gB = nullptr;
-        int kt_dma = kt0;
-        auto seg_setup = [&](int kt) {
-            const int sg = kt >= p.seg[0].ktiles ? 1 : 0;
-            const int k = kt - (sg ? p.seg[0].ktiles : 0);
-            const uint32_t lda = (uint32_t)p.seg[sg].lda_b, ldb = (uint32_t)p.seg[sg].ldb_b;
+    // ---- fragment addressing ----
+    const int r = lane & 31, g = lane >> 5;
+    const int swz = (r >> 1) & 7;
+    const uint32_t lbase = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)lds;
+    const uint32_t offa = (wm * 128 + r) * BKB, offb = W8_TILE_BYTES + (wn * 64 + r) * BKB;
+    uint32_t so[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = (i * 8 + wave) * 8 + (lane >> 3);
-                const uint32_t ss = (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) << 4);
-                voA[i] = (uint32_t)min(row0_m + row, p.M - 1) * lda + ss;
-                voB[i] = (uint32_t)min(row0_n + row, p.N - 1) * ldb + ss;
-            }
-            gA = p.seg[sg].A + (int64_t)k * BKB;
-            gB = p.seg[sg].Bt + (int64_t)k * BKB;
-        };
-        seg_setup(kt0);
-        auto dma_stage = [&](char* slot) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int piece = i * 8 + wave;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gA + voA[i]),
-                                                 (__attribute__((address_space(3))) void*)(slot + piece * 1024), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gB + voB[i]),
-                                                 (__attribute__((address_space(3))) void*)(slot + W8_TILE_BYTES + piece * 1024), 16, 0, 0);
-            }
-            ++kt_dma;
-            if (kt_dma == p.seg[0].ktiles) seg_setup(kt_dma);
-            else { gA += BKB; gB += BKB; }
-        };
-
-        // ---- fragment addressing ----
-        const int r = lane & 31, g = lane >> 5;
-        const int swz = (r >> 1) & 7;
-        const uint32_t lbase = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)lds;
-        const uint32_t offa = (wm * 128 + r) * BKB, offb = W8_TILE_BYTES + (wn * 64 + r) * BKB;
-        uint32_t so[4];
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) so[kk] = (uint32_t)(((kk * 2 + g) ^ swz) << 4);
-        i32x4 fa[2][4], fb[2][2];
-        // one 16-deep chunk: A fragments of the 4 row blocks (32 rows = 4096 B apart), B fragments of the 2 column blocks
+    for (int kk = 0; kk < 4; ++kk) so[kk] = (uint32_t)(((kk * 2 + g) ^ swz) << 4);
+    i32x4 fa[2][4], fb[2][2];
+    // one 16-deep chunk: A fragments of the 4 row blocks (32 rows = 4096 B apart), B fragments of the 2 column blocks
 #define W8_READ(SET, KK, SLOTBASE)                                                         \
     asm volatile("ds_read_b128 %0, %1" : "=&v"(fa[SET][0]) : "v"((SLOTBASE) + offa + so[KK]));               \
     asm volatile("ds_read_b128 %0, %1 offset:4096" : "=&v"(fa[SET][1]) : "v"((SLOTBASE) + offa + so[KK]));   \
@@ -119,47 +113,59 @@ __global__ __launch_bounds__(W8_THREADS, 1) void gemm_nt_w8(W8Params p, float* _
     }                                                                                      \
     __builtin_amdgcn_sched_barrier(0);
 
-        // ---- prologue: tiles 0 and 1 requested, tile 0 landed, its first chunk read ----
-        dma_stage(lds);
-        if (nk > 1) dma_stage(lds + W8_STAGE);
-        if (nk > 1) wait_vm<8>(); else wait_vm<0>();
+    // ---- prologue: tiles 0 and 1 requested, tile 0 landed, its first chunk read ----
+    dma_stage(lds);
+    if (nk > 1) dma_stage(lds + W8_STAGE);
+    if (nk > 1) wait_vm<8>(); else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    W8_READ(0, 0, lbase)
+    __builtin_amdgcn_sched_barrier(0);
+    int cur = 0;
+    for (int i = 0; i < nk; ++i) {
+        const uint32_t cb = lbase + cur * W8_STAGE, nb = lbase + (cur ^ 1) * W8_STAGE;
+        // chunk 0 (set 0) | prefetch chunk 1 -> set 1
+        W8_READ(1, 1, cb)
+        asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        W8_MMA(0)
+        // chunk 1 (set 1) | prefetch chunk 2 -> set 0
+        W8_READ(0, 2, cb)
+        asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        W8_MMA(1)
+        // chunk 2 (set 0) | prefetch chunk 3 -> set 1
+        W8_READ(1, 3, cb)
+        asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        W8_MMA(0)
+        // every read of tile i has been issued; retire them and my DMA pieces of tile i+1, then the tile barrier
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        wait_vm<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        W8_READ(0, 0, lbase)
+        if (i + 2 < nk) dma_stage(lds + cur * W8_STAGE);      // tile i+2 into the slot tile i just left
+        W8_READ(0, 0, nb)                                      // first chunk of tile i+1 (stale and unused after the last tile)
         __builtin_amdgcn_sched_barrier(0);
-        int cur = 0;
-        for (int i = 0; i < nk; ++i) {
-            const uint32_t cb = lbase + cur * W8_STAGE, nb = lbase + (cur ^ 1) * W8_STAGE;
-            // chunk 0 (set 0) | prefetch chunk 1 -> set 1
-            W8_READ(1, 1, cb)
-            asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            W8_MMA(0)
-            // chunk 1 (set 1) | prefetch chunk 2 -> set 0
-            W8_READ(0, 2, cb)
-            asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            W8_MMA(1)
-            // chunk 2 (set 0) | prefetch chunk 3 -> set 1
-            W8_READ(1, 3, cb)
-            asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            W8_MMA(0)
-            // every read of tile i has been issued; retire them and my DMA pieces of tile i+1, then the tile barrier
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            wait_vm<0>();
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if (i + 2 < nk) dma_stage(lds + cur * W8_STAGE);      // tile i+2 into the slot tile i just left
-            W8_READ(0, 0, nb)                                      // first chunk of tile i+1 (stale and unused after the last tile)
-            __builtin_amdgcn_sched_barrier(0);
-            W8_MMA(1)                                              // chunk 3
-            cur ^= 1;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        W8_MMA(1)                                              // chunk 3
+        cur ^= 1;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #undef W8_READ
 #undef W8_MMA
-    }
+}
+
+template <int ROLE>
+__global__ __launch_bounds__(W8_THREADS, 1) void gemm_nt_w8(W8Params p, float* __restrict__ C, int64_t ldc, int64_t slab_stride) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    int tm, tn, split, kt0, kt1;
+    w8_block_to_tile(p, tm, tn, split, kt0, kt1);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int row0_m = tm * W8_BM, row0_n = tn * W8_BN;
+    f32x16 acc[4][2];
+    w8_mainloop(p, row0_m, row0_n, kt0, kt1, lds, acc);
     // ---- epilogue: the wave's 128 x 64 block of the slab ----
     const int g = lane >> 5, c = lane & 31;
     float* Cs = C + (int64_t)split * slab_stride;

@@ -433,6 +433,58 @@ def test_step_dense_input_matches_oracle():
         assert _rel(a, b) < 1e-5
 
 
+@pytest.mark.parametrize("opt", ["gradient_descent", "adam"])
+def test_large_dense_shape_256_tile_kernels_equal_128_tile_kernels(opt):
+    """Dense input, F = 25000, H = 1000, B = 896: the encode / dh GEMMs (16 K slices) run on the 256 x 256-tile / 8-MFMA-wave kernel
+    (gemm_nt_w8; the last row tile of W is partial: 25088 = 98 x 256).  dae_set_glds(-6) AFTER the plan is built routes the same
+    launches -- same K slices -- to the 128 x 128 kernels: every element is summed in the same order, so gradients and statistics are
+    bit-identical (a DMA / barrier race in the 8-wave kernel would show here and as a run-to-run difference).  With the switch thrown
+    BEFORE the plan is built the 128-tile kernels run with their own 6 K slices: same bf16 products, another fp32 summation order ->
+    a few bf16 roundings of h / delta fall on the other side, the max-norm difference stays at the size of one such flip."""
+    from dae_rnn_news_recommendation_amd import _lib as L
+    from dae_rnn_news_recommendation_amd.engine import Engine
+    lib = L.load()
+    rng = np.random.default_rng(5)
+    N, F, H, B = 1000, 25000, 1000, 896
+    x = (rng.random((N, F)) < 0.01).astype(np.float32) * rng.random((N, F)).astype(np.float32)
+    lab = rng.integers(0, 4, N).astype(np.int32)
+    W0 = rng.uniform(-0.02, 0.02, (F, H)).astype(np.float32)
+
+    def run(plan_mode, launch_mode):
+        lib.dae_set_glds(plan_mode)
+        eng = Engine(F, H, B, dtype="bf16", opt=opt, learning_rate=0.05, triplet="batch_all", loss_func="mean_squared", dec_act="none",
+                     enc_act="sigmoid")
+        eng.upload_dense(x); eng.set_params(W0)
+        lib.dae_set_glds(launch_mode)
+        stats = torch.zeros((2, 8), device="cuda")
+        g = []
+        for s_ in range(2):
+            idx = np.arange(s_ * 100, s_ * 100 + B) % N
+            eng.train_step(torch.from_numpy(idx.astype(np.int32)).cuda(), torch.from_numpy(lab[idx]).cuda(), stats[s_], phase=0,
+                           corr_mode=L.CORR_PHILOX_MASK, seed=3, rng_stream=s_, corr_frac=0.3)
+            g.append(np.array(eng.grads()[0], copy=True))
+        torch.cuda.synchronize()
+        return stats.cpu().numpy(), [np.asarray(v) for v in eng.get_params()], g, eng.info()
+
+    try:
+        sa, pa, ga, ia = run(-7, -7)
+        sa2, pa2, ga2, _ = run(-7, -7)
+        sc, pc, gc, ic = run(-7, -6)
+        sb, pb, gb, ib = run(-6, -6)
+    finally:
+        lib.dae_set_glds(-7)
+    assert ia["encode_splits"] == 16 and ic["encode_splits"] == 16 and ib["encode_splits"] != 16, (ia, ib)
+    assert np.array_equal(sa, sa2) and all(np.array_equal(u, v) for u, v in zip(pa, pa2))
+    assert all(np.array_equal(u, v) for u, v in zip(ga, ga2))
+    assert np.array_equal(sa, sc) and all(np.array_equal(u, v) for u, v in zip(ga, gc))          # same K slices: same sums
+    for u, v in zip(pa, pc):
+        assert _rel(u, np.asarray(v, np.float64)) < 1e-6
+    assert np.allclose(sa[:, :5], sb[:, :5], rtol=2e-5, atol=0), (sa, sb)
+    assert _rel(ga[0], gb[0].astype(np.float64)) < 5e-3 and _rel(ga[1], gb[1].astype(np.float64)) < 5e-3
+    for u, v in zip(pa, pb):
+        assert _rel(u, np.asarray(v, np.float64)) < (1e-4 if opt == "gradient_descent" else 2e-3)
+
+
 def test_step_short_last_batch_and_pad_invariants():
     """A short batch after a full one: stale rows of the workspace must not leak (padding stays zero)."""
     from dae_rnn_news_recommendation_amd import _lib as L
