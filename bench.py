@@ -88,6 +88,8 @@ def parse():
                          "gradient image the dW kernel's epilogue writes, fp32 steps the fp32 gradient)")
     ap.add_argument("--profile-steps", type=int, default=20)
     ap.add_argument("--fit-epochs", type=int, default=6)
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="code-path choice of the plan for A/B measurements (dae_plan_set_option), e.g. --option overlap=1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-fit", action="store_true")
@@ -157,6 +159,9 @@ class Runner:
         self.eng = Engine(F, H, self.B * (3 if self.explicit else 1), dtype=a.precision, enc_act="sigmoid", dec_act="sigmoid",
                           loss_func=c["loss"], opt="gradient_descent", learning_rate=0.1, alpha=1.0, triplet=c["strategy"],
                           dp_world=world, grad_lo=((world > 1 or a.force_exchange) and a.grad_dtype == "bf16"))
+        for kv in a.option:
+            name, _, value = kv.partition("=")
+            self.eng.set_option(name, int(value))
         if self.explicit:
             self.m = sparse.vstack(data).tocsr()
             self.eng.upload_csr(self.m)
@@ -445,13 +450,15 @@ def main():
                                + f", strategy {c['strategy']}, masking 0.3, {c['loss']}, SGD lr 0.1, {a.precision} MFMA operands + fp32 "
                                "accumulate / master weights",
                    "global_batch": c["batch"] * world, "parallelism": f"dp{world}", "rng": a.rng,
-                   "collective": None if world == 1 else f"per step: reduce-scatter of the W gradient ({a.grad_dtype}; issued behind the dW GEMM on a side "
-                                                         "stream, beside the step tail), sharded optimizer writing into the all-gather send buffer, "
+                   "collective": None if world == 1 else f"per step: reduce-scatter of the W gradient ({a.grad_dtype}, written by the dW GEMM's epilogue), "
+                                                         "sharded optimizer writing into the all-gather send buffer, "
                                                          "all-gather of the low-precision W rows + every rank's bias gradients, one unpack kernel (RCCL)"},
         "final_losses": {"cost": float(last[:, 0].mean()), "autoencoder": float(last[:, 1].mean()),
                          "triplet": float(last[:, 2].mean()), "fraction": float(last[:, 3].mean()),
                          "note": "means over the last epoch's batches, as the reference prints them (autoencoder.py:283-294)"},
     }
+    if a.option:
+        out["config"]["plan_options"] = list(a.option)
     if run.exchange:
         # the collectives of the LAST `steps` steps, timed by events on the step's stream (a second, short pass keeps the host
         # event synchronisation out of the timed region above)

@@ -523,71 +523,67 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     }
     bool forked = false, sym_ride = false;
     const bool fold_finalize = (c.triplet == DAE_TRIPLET_BATCH_ALL && !c.pos_triplets_only) && !ext_mine;
+    // 7. decode + reconstruction loss + d cost/d z2   (K3/K4) -- on stream `ds`; `ride`: the launch also scales G + G^T (sym_scale)
+    const int dbn = decode_tile_n(dt);
+    const int ncw = 2 * Fp / dbn;
+    auto decode_section = [&](hipStream_t ds, bool ride) -> int {
+        DecodeEpi e;
+        memset(&e, 0, sizeof(e));
+        e.bv = p->b.bv; e.x = p->x; e.ldx = Fp; e.x_bits = use_xbits ? p->x_bits : nullptr; e.ldxb = Fp / 32; e.cw = p->cw; e.cos_stats = is_cos ? p->cos_stats : nullptr;
+        e.rowloss_part = is_cos ? p->rowloss_part : nullptr; e.tile_part = is_cos ? nullptr : p->tile_part;
+        e.dbv_part = backward ? p->dbv_part : nullptr; e.cos_part = p->cos_part;
+        e.delta2 = backward ? p->delta2 : nullptr; e.ldd = Fp; e.delta2_t = backward ? p->delta2_t : nullptr; e.lddt = ldB;
+        e.B = B; e.F = F; e.Bp = Bp; e.Fp = Fp; e.dec_act = c.dec_act; e.loss_func = c.loss_func; e.ce_literal = p->ce_literal ? 1 : 0;
+        if (ride) { e.sym_G = p->G; e.sym_scalars = p->tri_scalars; e.sym_Gs = p->Gs; e.sym_B = B; e.sym_Bp = Bp; }
+        if (is_cos) {
+            e.cos_pass = 1;
+            PROF(PS_DECODE, launch_decode_loss(dt, Bp, Fp, Hp, p->h_lo, Hp, p->b.W_lo, Hp, e, ds));
+            PROF(PS_COS_REDUCE, dae_cos_reduce(p->cos_part, ncw, B, Bp, p->cos_stats, p->rowloss_part, (void*)ds));
+            e.sym_G = nullptr;                                 // the first pass carried the rider
+            if (backward) { e.cos_pass = 2; PROF(PS_DECODE, launch_decode_loss(dt, Bp, Fp, Hp, p->h_lo, Hp, p->b.W_lo, Hp, e, ds)); }
+        } else {
+            e.cos_pass = 0;
+            PROF(PS_DECODE, launch_decode_loss(dt, Bp, Fp, Hp, p->h_lo, Hp, p->b.W_lo, Hp, e, ds));
+        }
+        return 0;
+    };
     if (!ext_mine && (c.triplet == DAE_TRIPLET_BATCH_ALL || c.triplet == DAE_TRIPLET_BATCH_HARD)) {
         const int64_t dslab = (int64_t)Bp * Bp;
         // the label block of this step's encode launch also ranked the anchors by sweep cost (only then is the buffer current)
         const int32_t* order = (labels_done && !ext_mine && p->miner_order_ok && c.triplet == DAE_TRIPLET_BATCH_ALL) ? p->miner_order : nullptr;
         const int32_t* cls = (labels_done && !ext_mine && p->miner_ranges_ok && c.triplet == DAE_TRIPLET_BATCH_ALL) ? p->cls_range : nullptr;
-        // batch_all (all valid triplets): cw comes from the labels alone -> the miner chain and the decode kernel are
-        // independent until dL/dh; fork the chain onto the side stream (never while profiling: events are per stream)
+        // batch_all (all valid triplets): cw comes from the labels alone -> the Gram -> miner chain (VALU work, the longer of the two) and
+        // the decode kernel (MFMA + loss epilogue) are independent until dL/dh.  Option "overlap": the decode forks onto the side stream,
+        // the chain stays on the step's stream and joins before the dh GEMM (never while profiling: the slot events are per stream)
         const bool overlap = p->overlap_ok && !p->prof && c.triplet == DAE_TRIPLET_BATCH_ALL && !c.pos_triplets_only;
-        hipStream_t ms = st;
         if (overlap) {
             if (!p->side) {
                 DAE_CHECK_HIP(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
                 DAE_CHECK_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
                 DAE_CHECK_HIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
             }
-            ms = p->side;
             DAE_CHECK_HIP(hipEventRecord(p->ev_fork, st));
-            DAE_CHECK_HIP(hipStreamWaitEvent(ms, p->ev_fork, 0));
+            DAE_CHECK_HIP(hipStreamWaitEvent(p->side, p->ev_fork, 0));
+            RC(decode_section(p->side, false));
+            DAE_CHECK_HIP(hipEventRecord(p->ev_join, p->side));
             forked = true;
         }
-        void* mstream = (void*)ms;
-        if (forked) {
-            RC(launch_gram(p, Bp, Hp, dslab, ms));
-            RC(launch_batch_all(p->D_slabs, p->s_gram, dslab, Bp, s->labels, B, Bp, 0, B, dt == DAE_BF16 ? DAE_MINER_FAST : 0, p->loss_part, p->cnt_part, p->G,
-                                p->role_cnt, order, ms, cls));
-            if (backward) RC(dae_sym_scale(p->G, B, Bp, p->tri_scalars, dt, p->Gs, mstream));
-            DAE_CHECK_HIP(hipEventRecord(p->ev_join, ms));
-        } else {
-            PROF(PS_GRAM, launch_gram(p, Bp, Hp, dslab, st));
-            if (c.triplet == DAE_TRIPLET_BATCH_ALL)
-                PROF(PS_MINER, launch_batch_all(p->D_slabs, p->s_gram, dslab, Bp, s->labels, B, Bp, 0, B,
-                                         (c.pos_triplets_only ? DAE_MINER_POS_ONLY : 0) | (dt == DAE_BF16 ? DAE_MINER_FAST : 0), p->loss_part,
-                                         p->cnt_part, p->G, p->role_cnt, order, st, cls));
-            else
-                PROF(PS_MINER, dae_triplet_batch_hard(p->D_slabs, p->s_gram, dslab, Bp, s->labels, B, Bp, p->loss_part, p->cnt_part, p->dw_i32, p->G,
-                                          stream));
-            if (!fold_finalize)   // batch_all over all valid triplets: scale comes from label_stats, sums from step_stats
-                PROF(PS_TRI_FIN, dae_triplet_finalize(c.triplet, c.pos_triplets_only, B, Bp, c.alpha, p->loss_part, p->cnt_part, p->nvalid,
-                                        p->dw_i32, p->role_cnt, p->dw_f32, p->cw, p->tri_scalars, stream));
-            sym_ride = backward && p->sym_ride_ok;        // the decode launch below carries it
-            if (backward && !sym_ride) PROF(PS_SYM, dae_sym_scale(p->G, B, Bp, p->tri_scalars, dt, p->Gs, stream));
-        }
+        PROF(PS_GRAM, launch_gram(p, Bp, Hp, dslab, st));
+        if (c.triplet == DAE_TRIPLET_BATCH_ALL)
+            PROF(PS_MINER, launch_batch_all(p->D_slabs, p->s_gram, dslab, Bp, s->labels, B, Bp, 0, B,
+                                     (c.pos_triplets_only ? DAE_MINER_POS_ONLY : 0) | (dt == DAE_BF16 ? DAE_MINER_FAST : 0), p->loss_part,
+                                     p->cnt_part, p->G, p->role_cnt, order, st, cls));
+        else
+            PROF(PS_MINER, dae_triplet_batch_hard(p->D_slabs, p->s_gram, dslab, Bp, s->labels, B, Bp, p->loss_part, p->cnt_part, p->dw_i32, p->G,
+                                      stream));
+        if (!fold_finalize)   // batch_all over all valid triplets: scale comes from label_stats, sums from step_stats
+            PROF(PS_TRI_FIN, dae_triplet_finalize(c.triplet, c.pos_triplets_only, B, Bp, c.alpha, p->loss_part, p->cnt_part, p->nvalid,
+                                    p->dw_i32, p->role_cnt, p->dw_f32, p->cw, p->tri_scalars, stream));
+        sym_ride = backward && p->sym_ride_ok && !forked;        // the decode launch below carries it
+        if (backward && !sym_ride) PROF(PS_SYM, dae_sym_scale(p->G, B, Bp, p->tri_scalars, dt, p->Gs, stream));
     }
-    // 7. decode + reconstruction loss + d cost/d z2   (K3/K4)
-    const int dbn = decode_tile_n(dt);
-    const int ncw = 2 * Fp / dbn;
-    DecodeEpi e;
-    memset(&e, 0, sizeof(e));
-    e.bv = p->b.bv; e.x = p->x; e.ldx = Fp; e.x_bits = use_xbits ? p->x_bits : nullptr; e.ldxb = Fp / 32; e.cw = p->cw; e.cos_stats = is_cos ? p->cos_stats : nullptr;
-    e.rowloss_part = is_cos ? p->rowloss_part : nullptr; e.tile_part = is_cos ? nullptr : p->tile_part;
-    e.dbv_part = backward ? p->dbv_part : nullptr; e.cos_part = p->cos_part;
-    e.delta2 = backward ? p->delta2 : nullptr; e.ldd = Fp; e.delta2_t = backward ? p->delta2_t : nullptr; e.lddt = ldB;
-    e.B = B; e.F = F; e.Bp = Bp; e.Fp = Fp; e.dec_act = c.dec_act; e.loss_func = c.loss_func; e.ce_literal = p->ce_literal ? 1 : 0;
-    if (sym_ride) { e.sym_G = p->G; e.sym_scalars = p->tri_scalars; e.sym_Gs = p->Gs; e.sym_B = B; e.sym_Bp = Bp; }
-    if (is_cos) {
-        e.cos_pass = 1;
-        PROF(PS_DECODE, launch_decode_loss(dt, Bp, Fp, Hp, p->h_lo, Hp, p->b.W_lo, Hp, e, st));
-        PROF(PS_COS_REDUCE, dae_cos_reduce(p->cos_part, ncw, B, Bp, p->cos_stats, p->rowloss_part, stream));
-        e.sym_G = nullptr;                                 // the first pass carried the rider
-        if (backward) { e.cos_pass = 2; PROF(PS_DECODE, launch_decode_loss(dt, Bp, Fp, Hp, p->h_lo, Hp, p->b.W_lo, Hp, e, st)); }
-    } else {
-        e.cos_pass = 0;
-        PROF(PS_DECODE, launch_decode_loss(dt, Bp, Fp, Hp, p->h_lo, Hp, p->b.W_lo, Hp, e, st));
-    }
-    if (forked) DAE_CHECK_HIP(hipStreamWaitEvent(st, p->ev_join, 0));   // join: triplet scalars and Gs are ready
+    if (forked) DAE_CHECK_HIP(hipStreamWaitEvent(st, p->ev_join, 0));   // join: delta2 and the loss partials are ready
+    else RC(decode_section(st, sym_ride));
     // 8. statistics of this step (autoencoder.py:233 fetch list)
     StatsArgs sa{is_cos ? p->rowloss_part : nullptr, 1, is_cos ? nullptr : p->tile_part, (Bp / 128) * (Fp / dbn), p->cw, B, Bp,
                  c.triplet == 3 ? DAE_TRIPLET_BATCH_HARD : c.triplet, c.alpha, p->tri_scalars,

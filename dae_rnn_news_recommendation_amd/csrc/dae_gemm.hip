@@ -786,8 +786,26 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_dw_pc(GemmParams p, OptEpi
 #endif
     const int g = lane >> 5, c = lane & 31;
     float* __restrict__ Wp = e.W;
-    float wv[DW_MB][16] = {};
     f32x16 acc[DW_MB];
+    // Epilogue work items: the 160 x 128 tile as 40 x 32 blocks of 4 rows x 4 columns, block `tid + 512 i` to thread tid (i < 3; the last
+    // round is half full).  Every global access of the epilogue is a 16-byte piece of a 512-byte row run -- a store of one dword per lane
+    // straight from the accumulator layout (two 128-byte runs per wave-instruction) moved the 20 MB of master weights at 1 TB/s and cost
+    // 19 of the kernel's 51 us (probe builds, profiles/r03_experiments.md).
+    constexpr int DW_EB = 3;
+    // plain SGD: the master weights of this thread's blocks are requested BEFORE the K loop, by all 8 waves (in the producers the plain
+    // loads are older than every LDS-DMA piece, so the counted vmcnt waits of the ring still hold)
+    f32x4 wq[DW_EB][4];
+    if constexpr (PREFETCH_W) {
+#pragma unroll
+        for (int i = 0; i < DW_EB; ++i) {
+            const int blk = tid + PC_THREADS * i, rg = blk >> 5, c4 = blk & 31;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int grow = min(row0_m + rg * 4 + q, Mrows - 1);
+                if (blk < DW_BM * 8) wq[i][q] = *reinterpret_cast<const f32x4*>(Wp + (int64_t)grow * e.ldw + row0_n + c4 * 4);
+            }
+        }
+    }
 
     if (wave8 >= 4) {
         // ================= producer: per K tile 5 A pieces (DMA, or built from bits) + 4 B pieces =================
@@ -875,6 +893,9 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_dw_pc(GemmParams p, OptEpi
         };
         auto dma_stage = [&](char* slot) {                 // returns nothing; issues 9 (dense A) or 4 (built A) pieces
             const bool built = XBITS && kt_dma < nk0;
+#if defined(DAE_DW_PROBE) && (DAE_DW_PROBE & 16)
+            if (true) { ++kt_dma; return; }                // probe: no operand stream (the consumers multiply whatever the ring holds)
+#endif
             if (!built) {
 #pragma unroll
                 for (int i = 0; i < 5; ++i)
@@ -909,16 +930,6 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_dw_pc(GemmParams p, OptEpi
     } else {
         // ================= consumer =================
         const int wave = wave8;                                             // column block
-        // master weights of this lane's 80 elements, requested before the K loop (plain SGD; see gemm_dw_opt)
-        if constexpr (PREFETCH_W) {
-#pragma unroll
-            for (int m = 0; m < DW_MB; ++m)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int grow = min(row0_m + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * g, Mrows - 1);
-                    wv[m][r] = Wp[(int64_t)grow * e.ldw + row0_n + wave * 32 + c];
-                }
-        }
 #pragma unroll
         for (int m = 0; m < DW_MB; ++m)
 #pragma unroll
@@ -944,6 +955,18 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_dw_pc(GemmParams p, OptEpi
     Mma<bf16_t>::run(fa[S][2], fb[S], acc[2]);                                         \
     Mma<bf16_t>::run(fa[S][3], fb[S], acc[3]);                                         \
     Mma<bf16_t>::run(fa[S][4], fb[S], acc[4]);
+#if defined(DAE_DW_PROBE) && (DAE_DW_PROBE & 32)           // probe: the consumers only take part in the barriers
+#undef DAE_DW_READ
+#undef DAE_DW_MMA
+#define DAE_DW_READ(S, KK, SLOTBASE) fb[S] = i32x4{0, 0, 0, 0}; fa[S][0] = fa[S][1] = fa[S][2] = fa[S][3] = fa[S][4] = fb[S];
+#define DAE_DW_MMA(S)
+#elif defined(DAE_DW_PROBE) && (DAE_DW_PROBE & 64)          // probe: fragment reads but no MFMAs
+#undef DAE_DW_MMA
+#define DAE_DW_MMA(S) asm volatile("" :: "v"(fa[S][0]), "v"(fa[S][1]), "v"(fa[S][2]), "v"(fa[S][3]), "v"(fa[S][4]), "v"(fb[S]));
+#elif defined(DAE_DW_PROBE) && (DAE_DW_PROBE & 128)         // probe: MFMAs on whatever the registers hold, no fragment reads
+#undef DAE_DW_READ
+#define DAE_DW_READ(S, KK, SLOTBASE) asm volatile("" : "+v"(fa[S][0]), "+v"(fa[S][1]), "+v"(fa[S][2]), "+v"(fa[S][3]), "+v"(fa[S][4]), "+v"(fb[S]));
+#endif
         __builtin_amdgcn_s_barrier();                                       // stage 0 landed (producers waited for it)
         asm volatile("" ::: "memory");
         DAE_DW_READ(0, 0, lbase)
@@ -983,104 +1006,110 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_dw_pc(GemmParams p, OptEpi
     __builtin_amdgcn_s_barrier();                                           // B1: every wave is out of the K loop; the ring is dead
     asm volatile("" ::: "memory");
 
+    // ---- epilogue: the gradient tile is parked in LDS (fp32 [160][128], conflict-free from the accumulator layout), then all 8 waves
+    //      run the optimizer block-wise: W, optimizer slots and the optional gradient image as 16-byte pieces, W_lo as 8-byte pieces;
+    //      the transposed shadow is staged in a second LDS tile and leaves in 16-byte pieces ----
+    float* Gt = reinterpret_cast<float*>(lds);                              // [160][128] fp32 (80 KiB)
+    char* R1 = lds + DW_BM * 128 * 4;                                       // Wt_lo tile  [128][DW_P1] (42 KiB)
+    static_assert(DW_BM * 128 * 4 + 128 * DW_P1 <= DW_RING, "the epilogue tiles must fit the dead ring");
     if (wave8 < 4) {
-        // ---- optimizer on the gradient tile in registers; both bf16 shadows staged in LDS ----
-        const int wave = wave8;
-        char* R0 = lds;                                                     // W_lo tile   [160][DW_P0]   (GRAD_ONLY: the bf16 gradient tile)
-        char* R1 = lds + DW_BM * DW_P0;                                     // Wt_lo tile  [128][DW_P1]
+        const int lcol = wave8 * 32 + c;
+#pragma unroll
+        for (int m = 0; m < DW_MB; ++m)
+#pragma unroll
+            for (int r2 = 0; r2 < 16; ++r2) Gt[(m * 32 + (r2 & 3) + 8 * (r2 >> 2) + 4 * g) * 128 + lcol] = acc[m][r2];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                           // B2: the gradient tile is complete
+    asm volatile("" ::: "memory");
+    {
         float* __restrict__ gradp = e.grad;
         float* __restrict__ s1p = e.s1;
         float* __restrict__ s2p = e.s2;
+        bf16_t* __restrict__ Wlo = reinterpret_cast<bf16_t*>(UPDATE ? e.W_lo : e.grad_lo);
         const float lr = e.lr, mom = e.mom, gscale = e.gscale;
-        const int lcol = wave * 32 + c;
-        auto block = [&](auto MB) {
-            constexpr int m = decltype(MB)::value;
-            float a1[16], a2[16];
-            if constexpr (UPDATE && OPT != DAE_OPT_SGD) {
 #pragma unroll
-                for (int r2 = 0; r2 < 16; ++r2) {
-                    const int grow = min(row0_m + m * 32 + (r2 & 3) + 8 * (r2 >> 2) + 4 * g, Mrows - 1);
-                    const int64_t k = (int64_t)grow * e.ldw + row0_n + lcol;
-                    wv[m][r2] = Wp[k];
-                    a1[r2] = s1p[k];
-                    a2[r2] = (OPT == DAE_OPT_ADAM) ? s2p[k] : 0.f;
+        for (int i = 0; i < DW_EB; ++i) {
+            const int blk = tid + PC_THREADS * i, rg = blk >> 5, c4 = blk & 31;
+            if (blk >= DW_BM * 8) break;
+            float pv[4][4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int lrow = rg * 4 + q;
+                const bool ok = row0_m + lrow < Mrows;
+                const int64_t k = (int64_t)min(row0_m + lrow, Mrows - 1) * e.ldw + row0_n + c4 * 4;
+                const f32x4 gr = *reinterpret_cast<const f32x4*>(Gt + lrow * 128 + c4 * 4);
+                if constexpr (!UPDATE) {
+                    if (ok && gradp) *reinterpret_cast<f32x4*>(gradp + k) = gr;
+                    if (ok && Wlo) {
+                        uint2 lo;
+                        lo.x = f2bf_pack_hw(gr[0], gr[1]); lo.y = f2bf_pack_hw(gr[2], gr[3]);
+                        *reinterpret_cast<uint2*>(Wlo + k) = lo;
+                    }
+                    continue;
                 }
-                __builtin_amdgcn_sched_barrier(0);
-            }
+                f32x4 p0, a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f}, pn;
+                if constexpr (PREFETCH_W) p0 = wq[i][q];
+                else p0 = *reinterpret_cast<const f32x4*>(Wp + k);
+                if constexpr (OPT == DAE_OPT_ADAGRAD || OPT == DAE_OPT_MOMENTUM || OPT == DAE_OPT_ADAM) a1 = *reinterpret_cast<const f32x4*>(s1p + k);
+                if constexpr (OPT == DAE_OPT_ADAM) a2 = *reinterpret_cast<const f32x4*>(s2p + k);
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                float pv[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int r2 = r4 * 4 + q;
-                    const int lrow = m * 32 + 8 * r4 + q + 4 * g;
-                    const bool ok = row0_m + lrow < Mrows;
-                    const int64_t k = (int64_t)(row0_m + lrow) * e.ldw + row0_n + lcol;
-                    const float gr = acc[m][r2];
-                    if constexpr (!UPDATE) {
-                        if (ok && gradp) gradp[k] = gr;
-                        if (e.grad_lo) *reinterpret_cast<bf16_t*>(R0 + lrow * DW_P0 + lcol * 2) = f2bf_hw(gr);
-                        continue;
-                    }
-                    const float gg = gr * gscale, p0 = wv[m][r2];
-                    float pn;
-                    if constexpr (OPT == DAE_OPT_SGD) pn = p0 - lr * gg;
-                    else if constexpr (OPT == DAE_OPT_ADAGRAD) { const float a = a1[r2] + gg * gg; if (ok) s1p[k] = a; pn = p0 - lr * gg * rsqrtf(a); }
-                    else if constexpr (OPT == DAE_OPT_MOMENTUM) { const float a = mom * a1[r2] + gg; if (ok) s1p[k] = a; pn = p0 - lr * a; }
+                for (int j = 0; j < 4; ++j) {
+                    const float gg = gr[j] * gscale;
+                    if constexpr (OPT == DAE_OPT_SGD) pn[j] = p0[j] - lr * gg;
+                    else if constexpr (OPT == DAE_OPT_ADAGRAD) { const float a = a1[j] + gg * gg; a1[j] = a; pn[j] = p0[j] - lr * gg * rsqrtf(a); }
+                    else if constexpr (OPT == DAE_OPT_MOMENTUM) { const float a = mom * a1[j] + gg; a1[j] = a; pn[j] = p0[j] - lr * a; }
                     else {
-                        const float mm = 0.9f * a1[r2] + 0.1f * gg;
-                        const float vv = 0.999f * a2[r2] + 0.001f * gg * gg;
-                        if (ok) { s1p[k] = mm; s2p[k] = vv; }
-                        pn = p0 - lr * mm / (sqrtf(vv) + 1e-8f);
+                        const float mm = 0.9f * a1[j] + 0.1f * gg;
+                        const float vv = 0.999f * a2[j] + 0.001f * gg * gg;
+                        a1[j] = mm; a2[j] = vv;
+                        pn[j] = p0[j] - lr * mm / (sqrtf(vv) + 1e-8f);
                     }
+                    pv[q][j] = pn[j];
+                }
+                if (ok) {
 #ifdef DAE_DW_PROBE
                     if (!(DAE_DW_PROBE & 2))                                 // probe: no master-weight store
 #endif
-                    if (ok) { Wp[k] = pn; if (gradp) gradp[k] = gr; }
-                    pv[q] = pn;
-                    *reinterpret_cast<bf16_t*>(R0 + lrow * DW_P0 + lcol * 2) = f2bf_hw(pn);
-                }
-                if constexpr (UPDATE) {
-                    uint2 v;
-                    v.x = f2bf_pack_hw(pv[0], pv[1]);
-                    v.y = f2bf_pack_hw(pv[2], pv[3]);
-                    *reinterpret_cast<uint2*>(R1 + lcol * DW_P1 + (m * 32 + 8 * r4 + 4 * g) * 2) = v;
+                    *reinterpret_cast<f32x4*>(Wp + k) = pn;
+                    if (gradp) *reinterpret_cast<f32x4*>(gradp + k) = gr;
+                    if constexpr (OPT == DAE_OPT_ADAGRAD || OPT == DAE_OPT_MOMENTUM || OPT == DAE_OPT_ADAM) *reinterpret_cast<f32x4*>(s1p + k) = a1;
+                    if constexpr (OPT == DAE_OPT_ADAM) *reinterpret_cast<f32x4*>(s2p + k) = a2;
+#ifdef DAE_DW_PROBE
+                    if (!(DAE_DW_PROBE & 4))                                 // probe: no shadow stores
+#endif
+                    {
+                        uint2 lo;
+                        lo.x = f2bf_pack_hw(pn[0], pn[1]); lo.y = f2bf_pack_hw(pn[2], pn[3]);
+                        *reinterpret_cast<uint2*>(Wlo + k) = lo;
+                    }
                 }
             }
-        };
-        block(std::integral_constant<int, 0>{});
-        block(std::integral_constant<int, 1>{});
-        block(std::integral_constant<int, 2>{});
-        block(std::integral_constant<int, 3>{});
-        block(std::integral_constant<int, 4>{});
+            if constexpr (UPDATE) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {                               // 4 features of column c4 * 4 + j: one 8-byte piece of the transposed tile
+                    uint2 v;
+                    v.x = f2bf_pack_hw(pv[0][j], pv[1][j]);
+                    v.y = f2bf_pack_hw(pv[2][j], pv[3][j]);
+                    *reinterpret_cast<uint2*>(R1 + (c4 * 4 + j) * DW_P1 + rg * 8) = v;
+                }
+            }
+        }
     }
+    if constexpr (!UPDATE) return;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                                           // B4: the staged tiles are complete
+    __builtin_amdgcn_s_barrier();                                           // B3: the transposed tile is complete
     asm volatile("" ::: "memory");
-    // ---- all 8 waves: coalesced 16-byte stores of the staged tiles ----
 #ifdef DAE_DW_PROBE
     if (DAE_DW_PROBE & 4) return;                                           // probe: no shadow stores
 #endif
     {
-        const char* R0 = lds;
-        const char* R1 = lds + DW_BM * DW_P0;
-        bf16_t* Wlo = reinterpret_cast<bf16_t*>(UPDATE ? e.W_lo : e.grad_lo);
         bf16_t* Wtlo = reinterpret_cast<bf16_t*>(e.Wt_lo);
-        if (Wlo) {
-            for (int ch = tid; ch < DW_BM * 16; ch += PC_THREADS) {          // W_lo (or the bf16 gradient): 160 rows x 16 chunks
-                const int row = ch >> 4, c16 = ch & 15;
-                if (row0_m + row < Mrows)
-                    *reinterpret_cast<i32x4*>(Wlo + (int64_t)(row0_m + row) * e.ldw + row0_n + c16 * 8) =
-                        *reinterpret_cast<const i32x4*>(R0 + row * DW_P0 + c16 * 16);
-            }
-        }
-        if constexpr (UPDATE) {
-            for (int ch = tid; ch < 128 * 20; ch += PC_THREADS) {            // Wt_lo: 128 rows x 20 chunks of 8 features
-                const int row = ch / 20, c16 = ch % 20;
-                if (row0_m + c16 * 8 < Mrows)
-                    *reinterpret_cast<i32x4*>(Wtlo + (int64_t)(row0_n + row) * e.ldwt + row0_m + c16 * 8) =
-                        *reinterpret_cast<const i32x4*>(R1 + row * DW_P1 + c16 * 16);
-            }
+        for (int ch = tid; ch < 128 * 20; ch += PC_THREADS) {                // Wt_lo: 128 rows x 20 chunks of 8 features
+            const int row = ch / 20, c16 = ch % 20;
+            if (row0_m + c16 * 8 < Mrows)
+                *reinterpret_cast<i32x4*>(Wtlo + (int64_t)(row0_n + row) * e.ldwt + row0_m + c16 * 8) =
+                    *reinterpret_cast<const i32x4*>(R1 + row * DW_P1 + c16 * 16);
         }
     }
 }
