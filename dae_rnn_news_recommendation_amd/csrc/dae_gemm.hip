@@ -459,7 +459,13 @@ __device__ __forceinline__ float opt_apply_elem(int opt, float lr, float mom, fl
 
 constexpr int DWO_PITCH = 272;                        // staged bf16 row: 128 elements + 16 B pad
 constexpr int DWO_TILE_BYTES = 128 * DWO_PITCH;
+constexpr int DWO_G_BYTES = 64 * 128 * 4;             // half of the gradient tile, fp32 [64][128]
+constexpr int DWO_LDS = DWO_G_BYTES + DWO_TILE_BYTES; // 66 KiB (the two K-loop stages, 64 KiB, are dead by then)
 
+// Epilogue in two halves of 64 rows: the two waves that own the half park their accumulators in LDS (fp32, conflict-free from the
+// accumulator layout), then all 4 waves run the optimizer on blocks of 4 rows x 4 columns -- every global access is a 16-byte piece of a
+// 512-byte row run, a quarter of the instructions of the per-lane form (same scheme as gemm_dw_pc, where it was measured).  W_lo
+// leaves as 8-byte pieces; the transposed shadow is staged in LDS and leaves as 16-byte pieces at the end.
 template <int OPT>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_dw_opt(GemmParams p, OptEpi e) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -467,91 +473,97 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_dw_opt(GemmParams p, Opt
     if (!block_to_tile(p, tm, tn, split, kt0, kt1)) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, g = lane >> 5, c = lane & 31;
-    const int lrow0 = wm * 64 + 4 * g, lcol0 = wn * 64 + c;
     float* __restrict__ Wp = e.W;
     float* __restrict__ gradp = e.grad;
     float* __restrict__ s1p = e.s1;
     float* __restrict__ s2p = e.s2;
     const float lr = e.lr, mom = e.mom, gscale = e.gscale;
-    // this lane's 64 master weights are requested BEFORE the K loop: the epilogue is a load -> FMA -> store chain per
-    // element with only 8 waves per CU to hide HBM latency behind, so the loads ride under the 28 K tiles instead
-    // (plain SGD only: the stateful optimizers need the registers for their slots and load W with them, per quarter tile)
+    // block (half, i) of this thread: rows half * 64 + 4 * rg .. + 3, columns 4 * c4 .. + 3 of the tile
+    const int rg0 = tid >> 5, c4 = tid & 31;                                  // i-th block: row group rg0 + 8 i
+    // plain SGD: this thread's 16 master-weight pieces are requested BEFORE the K loop and ride under it (the stateful optimizers load W
+    // together with their slots, per block)
     constexpr bool PREFETCH_W = (OPT == DAE_OPT_SGD);
-    float wv[2][2][16];
+    f32x4 wq[2][2][4];
     if constexpr (PREFETCH_W) {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int lrow = lrow0 + mt * 32 + (r & 3) + 8 * (r >> 2), lcol = lcol0 + nt * 32;
-                    wv[mt][nt][r] = Wp[(int64_t)(tm * BM + lrow) * e.ldw + tn * BN + lcol];
-                }
+                for (int q = 0; q < 4; ++q)
+                    wq[h][i][q] = *reinterpret_cast<const f32x4*>(Wp + (int64_t)(tm * BM + h * 64 + (rg0 + 8 * i) * 4 + q) * e.ldw + tn * BN + c4 * 4);
     }
     f32x16 acc[2][2];
     gemm_mainloop<bf16_t, 2>(p, tm, tn, kt0, kt1, lds, acc);
-    __syncthreads();                                   // the K-loop stages are dead: reuse the LDS for the shadow tiles
-    char* R0 = lds;                                    // W_lo tile   [f_local][h_local]
-    char* R1 = lds + DWO_TILE_BYTES;                   // Wt_lo tile  [h_local][f_local]
-    auto quarter = [&](auto MT, auto NT) {
-        constexpr int mt = decltype(MT)::value, nt = decltype(NT)::value;
-        float a1[16], a2[16];
-        if constexpr (OPT != DAE_OPT_SGD) {            // optimizer slots of the quarter: all loads in flight together
+    float* Gt = reinterpret_cast<float*>(lds);          // gradient half [64][128]
+    char* R1 = lds + DWO_G_BYTES;                       // Wt_lo tile  [h_local][f_local]
+    bf16_t* __restrict__ Wlo = reinterpret_cast<bf16_t*>(e.W_lo);
+    auto half = [&](auto HV) {
+        constexpr int h = decltype(HV)::value;
+        __syncthreads();                                // the K-loop stages (h = 0) / the previous half's gradient reads are done
+        if (wm == h) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int lrow = lrow0 + mt * 32 + (r & 3) + 8 * (r >> 2), lcol = lcol0 + nt * 32;
-                const int64_t k = (int64_t)(tm * BM + lrow) * e.ldw + tn * BN + lcol;
-                wv[mt][nt][r] = Wp[k];
-                a1[r] = s1p[k];
-                a2[r] = (OPT == DAE_OPT_ADAM) ? s2p[k] : 0.f;
-            }
-            __builtin_amdgcn_sched_barrier(0);         // keep the next quarter's loads behind this quarter's stores
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        Gt[(mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g) * 128 + wn * 64 + nt * 32 + c] = acc[mt][nt][r];
         }
+        __syncthreads();
 #pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-            float pv[4];
+        for (int i = 0; i < 2; ++i) {
+            const int rg = rg0 + 8 * i;
+            float pv[4][4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int r = r4 * 4 + q;
-                const int lrow = lrow0 + mt * 32 + 8 * r4 + q, lcol = lcol0 + nt * 32;
-                const int64_t k = (int64_t)(tm * BM + lrow) * e.ldw + tn * BN + lcol;
-                const float gr = acc[mt][nt][r];
-                if (gradp) gradp[k] = gr;
-                const float gg = gr * gscale, p0 = wv[mt][nt][r];
-                float pn;
-                if constexpr (OPT == DAE_OPT_SGD) pn = p0 - lr * gg;
-                else if constexpr (OPT == DAE_OPT_ADAGRAD) { const float a = a1[r] + gg * gg; s1p[k] = a; pn = p0 - lr * gg * rsqrtf(a); }
-                else if constexpr (OPT == DAE_OPT_MOMENTUM) { const float a = mom * a1[r] + gg; s1p[k] = a; pn = p0 - lr * a; }
-                else {
-                    const float m = 0.9f * a1[r] + 0.1f * gg;
-                    const float v = 0.999f * a2[r] + 0.001f * gg * gg;
-                    s1p[k] = m; s2p[k] = v;
-                    pn = p0 - lr * m / (sqrtf(v) + 1e-8f);
+                const int lrow = rg * 4 + q;
+                const int64_t k = (int64_t)(tm * BM + h * 64 + lrow) * e.ldw + tn * BN + c4 * 4;
+                const f32x4 gr = *reinterpret_cast<const f32x4*>(Gt + lrow * 128 + c4 * 4);
+                f32x4 p0, a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f}, pn;
+                if constexpr (PREFETCH_W) p0 = wq[h][i][q];
+                else p0 = *reinterpret_cast<const f32x4*>(Wp + k);
+                if constexpr (OPT != DAE_OPT_SGD) a1 = *reinterpret_cast<const f32x4*>(s1p + k);
+                if constexpr (OPT == DAE_OPT_ADAM) a2 = *reinterpret_cast<const f32x4*>(s2p + k);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float gg = gr[j] * gscale;
+                    if constexpr (OPT == DAE_OPT_SGD) pn[j] = p0[j] - lr * gg;
+                    else if constexpr (OPT == DAE_OPT_ADAGRAD) { const float a = a1[j] + gg * gg; a1[j] = a; pn[j] = p0[j] - lr * gg * rsqrtf(a); }
+                    else if constexpr (OPT == DAE_OPT_MOMENTUM) { const float a = mom * a1[j] + gg; a1[j] = a; pn[j] = p0[j] - lr * a; }
+                    else {
+                        const float m = 0.9f * a1[j] + 0.1f * gg;
+                        const float v = 0.999f * a2[j] + 0.001f * gg * gg;
+                        a1[j] = m; a2[j] = v;
+                        pn[j] = p0[j] - lr * m / (sqrtf(v) + 1e-8f);
+                    }
+                    pv[q][j] = pn[j];
                 }
-                Wp[k] = pn;
-                pv[q] = pn;
-                *reinterpret_cast<bf16_t*>(R0 + lrow * DWO_PITCH + lcol * 2) = f2bf_hw(pn);
+                *reinterpret_cast<f32x4*>(Wp + k) = pn;
+                if (gradp) *reinterpret_cast<f32x4*>(gradp + k) = gr;
+                if constexpr (OPT != DAE_OPT_SGD) *reinterpret_cast<f32x4*>(s1p + k) = a1;
+                if constexpr (OPT == DAE_OPT_ADAM) *reinterpret_cast<f32x4*>(s2p + k) = a2;
+                uint2 lo;
+                lo.x = f2bf_pack_hw(pn[0], pn[1]); lo.y = f2bf_pack_hw(pn[2], pn[3]);
+                *reinterpret_cast<uint2*>(Wlo + k) = lo;
             }
-            uint2 v;
-            v.x = f2bf_pack_hw(pv[0], pv[1]);
-            v.y = f2bf_pack_hw(pv[2], pv[3]);
-            *reinterpret_cast<uint2*>(R1 + (lcol0 + nt * 32) * DWO_PITCH + (lrow0 + mt * 32 + 8 * r4) * 2) = v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                // 4 features of column 4 c4 + j: one 8-byte piece of the transposed tile
+                uint2 v;
+                v.x = f2bf_pack_hw(pv[0][j], pv[1][j]);
+                v.y = f2bf_pack_hw(pv[2][j], pv[3][j]);
+                *reinterpret_cast<uint2*>(R1 + (c4 * 4 + j) * DWO_PITCH + (h * 64 + rg * 4) * 2) = v;
+            }
         }
     };
-    quarter(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-    quarter(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
-    quarter(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
-    quarter(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+    half(std::integral_constant<int, 0>{});
+    half(std::integral_constant<int, 1>{});
     __syncthreads();
-    bf16_t* Wlo = reinterpret_cast<bf16_t*>(e.W_lo);
     bf16_t* Wtlo = reinterpret_cast<bf16_t*>(e.Wt_lo);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int ch = tid + GEMM_THREADS * i;
         const int row = ch >> 4, c16 = ch & 15;
-        *reinterpret_cast<i32x4*>(Wlo + (int64_t)(tm * BM + row) * e.ldw + tn * BN + c16 * 8) =
-            *reinterpret_cast<const i32x4*>(R0 + row * DWO_PITCH + c16 * 16);
         *reinterpret_cast<i32x4*>(Wtlo + (int64_t)(tn * BN + row) * e.ldwt + tm * BM + c16 * 8) =
             *reinterpret_cast<const i32x4*>(R1 + row * DWO_PITCH + c16 * 16);
     }
@@ -788,9 +800,10 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_dw_pc(GemmParams p, OptEpi
     float* __restrict__ Wp = e.W;
     f32x16 acc[DW_MB];
     // Epilogue work items: the 160 x 128 tile as 40 x 32 blocks of 4 rows x 4 columns, block `tid + 512 i` to thread tid (i < 3; the last
-    // round is half full).  Every global access of the epilogue is a 16-byte piece of a 512-byte row run -- a store of one dword per lane
-    // straight from the accumulator layout (two 128-byte runs per wave-instruction) moved the 20 MB of master weights at 1 TB/s and cost
-    // 19 of the kernel's 51 us (probe builds, profiles/r03_experiments.md).
+    // round is half full): ALL 8 waves run the optimizer, every global access is a 16-byte piece of a 512-byte row run.  (Before, the four
+    // MFMA waves alone updated W straight from the accumulator layout -- 80 dword loads + 80 dword stores + 100 LDS writes per lane, one
+    // wave per SIMD, the producers idle: the master-weight store alone cost 19 of the kernel's 51 us and the read 9, probe builds in
+    // profiles/r03_experiments.md; a store of that form streams as fast as any other when nothing else limits it, tools/lds_stream_ubench.)
     constexpr int DW_EB = 3;
     // plain SGD: the master weights of this thread's blocks are requested BEFORE the K loop, by all 8 waves (in the producers the plain
     // loads are older than every LDS-DMA piece, so the counted vmcnt waits of the ring still hold)
@@ -1836,7 +1849,7 @@ int launch_dw_opt(int M, int N, const void* A0, int64_t lda0, const void* Bt0, i
     }
     typedef void (*dwo_fn)(GemmParams, OptEpi);
     static const dwo_fn fns[4] = {gemm_dw_opt<DAE_OPT_SGD>, gemm_dw_opt<DAE_OPT_ADAGRAD>, gemm_dw_opt<DAE_OPT_MOMENTUM>, gemm_dw_opt<DAE_OPT_ADAM>};
-    constexpr int ldsb = 2 * DWO_TILE_BYTES > lds_bytes_for(2) ? 2 * DWO_TILE_BYTES : lds_bytes_for(2);
+    constexpr int ldsb = DWO_LDS > lds_bytes_for(2) ? DWO_LDS : lds_bytes_for(2);
     static int attr_rc = [] {
         int rc = 0;
         for (dwo_fn f : fns) rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);

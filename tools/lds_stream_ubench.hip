@@ -136,6 +136,51 @@ static void run(const char* src, long long window, bool shared, int waves, int c
            best * 1e6 / instr_cu, hipGetErrorString(hipGetLastError()));
 }
 
+// Stores, every byte written once (HBM-bound at best).  Form 0: 16 B per lane, the wave-instruction covers 1 KiB of one row; form 1: 4 B
+// per lane, 256 contiguous bytes; form 2: 4 B per lane in the MFMA accumulator layout -- lanes 0-31 write 128 B of row r, lanes 32-63
+// 128 B of row r + 4 (row stride S bytes), the next instruction moves one row down (what a GEMM epilogue does without staging).
+template <int FORM>
+__global__ __launch_bounds__(1024) void stream_store(char* __restrict__ dst, long long per_cu, long long S) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    char* base = dst + (long long)blockIdx.x * per_cu;
+    if constexpr (FORM == 0) {
+        const i32x4 v = {lane, wave, 1, 2};
+        for (long long off = (long long)wave * 1024; off + 1024 <= per_cu; off += (long long)nw * 1024)
+            *reinterpret_cast<i32x4*>(base + off + lane * 16) = v;
+    } else if constexpr (FORM == 1) {
+        for (long long off = (long long)wave * 256; off + 256 <= per_cu; off += (long long)nw * 256)
+            *reinterpret_cast<int*>(base + off + lane * 4) = lane;
+    } else {
+        // tiles of 32 rows x 128 B: a wave owns tile t = wave, wave + nw, ...; tile t sits at rows [32 (t / nt_row), +32), byte column 128 (t % nt_row)
+        const int nt_row = (int)(S / 128);
+        const long long ntiles = per_cu / (32 * 128);
+        for (long long t = wave; t < ntiles; t += nw) {
+            char* tb = base + (t / nt_row) * 32 * S + (t % nt_row) * 128;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                *reinterpret_cast<int*>(tb + (long long)((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * S + (lane & 31) * 4) = lane;
+        }
+    }
+}
+
+template <int FORM>
+static void run_store(char* dst, long long per_cu, long long S, int waves, int cus) {
+    static const char* names[3] = {"16 B / lane, 1 KiB runs", "4 B / lane, 256 B runs", "4 B / lane, accumulator layout (2 x 128 B runs, rows 4 apart)"};
+    printf("  store %-62s %2d waves/CU  row stride %5lld B: ", names[FORM], waves, S);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e30f;
+    for (int rep = 0; rep < 4; ++rep) {
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL((stream_store<FORM>), dim3(cus), dim3(64 * waves), 0, 0, dst, per_cu, S);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (rep && ms < best) best = ms;
+    }
+    printf("%7.1f GB/s per CU  %6.2f TB/s chip  (%s)\n", (double)per_cu / best * 1e-6, (double)per_cu * cus / best * 1e-9, hipGetErrorString(hipGetLastError()));
+}
+
 int main() {
     setvbuf(stdout, NULL, _IONBF, 0);
     hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);
@@ -166,6 +211,13 @@ int main() {
             run<M_DMA16, 15>(big, 1 << 20, false, waves, cus, sink, true);
             run<M_DMA16, 15>(big, 4 << 20, false, waves, cus, sink, true);
             run<M_REG16, 15>(big, 4 << 20, false, waves, cus, sink, true);
+        }
+        printf("stores, 4 MiB per CU written once (1 GiB):\n");
+        for (int waves : {4, 8, 16}) {
+            run_store<0>(big, 4 << 20, 2048, waves, cus);
+            run_store<1>(big, 4 << 20, 2048, waves, cus);
+            run_store<2>(big, 4 << 20, 2048, waves, cus);
+            run_store<2>(big, 4 << 20, 4096, waves, cus);
         }
         hipFree(big);
     }
