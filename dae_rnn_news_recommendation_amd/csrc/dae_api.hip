@@ -270,6 +270,7 @@ extern "C" int dae_plan_set_option(dae_plan* p, const char* name, int32_t value)
     else if (!strcmp(name, "label_with_encode")) p->label_enc_ok = on;
     else if (!strcmp(name, "ce_literal")) p->ce_literal = on;
     else if (!strcmp(name, "overlap")) p->overlap_ok = on;
+    else if (!strcmp(name, "gather_tile")) set_gather_tile(value);        // process-wide: tile shape of the dense gather (A/B measurements)
     else if (!strcmp(name, "miner_order")) p->miner_order_ok = on;
     else if (!strcmp(name, "miner_ranges")) p->miner_ranges_ok = on;
     else if (!strcmp(name, "miner_pack")) set_miner_pack(on);        // process-wide (the launcher's choice), like dae_set_glds

@@ -130,18 +130,22 @@ __device__ __forceinline__ void store2(float* dst, float a, float b) { *reinterp
 // the four keep decisions (the per-element draw made this kernel VALU-bound: 10 rounds x 40 M elements at F = 50000), 8-byte
 // stores of the bf16 x / x~ rows; the x~^T operand goes through an LDS transpose and is written as packed pairs.
 // VEC = false is the same arithmetic element by element (unaligned rows, F not a multiple of 4).
-template <typename T, bool VEC>
+template <typename T, bool VEC, int TR, int TC>
 __global__ __launch_bounds__(256) void gather_dense_kernel(
     const float* __restrict__ data, int64_t ld_data, const int32_t* __restrict__ row_idx, int B, int F,
     T* __restrict__ x, T* __restrict__ xc, int64_t ldx, T* __restrict__ xct, int64_t ldt, float* __restrict__ rowsq_part,
     int corr_mode, const uint32_t* __restrict__ keep_bits, uint64_t seed, uint32_t stream, float corr_frac, float scale) {
-    __shared__ float tile[64][65];
-    __shared__ float sq[64];
-    const int i0 = blockIdx.x * 64, f0 = blockIdx.y * 64;
-    const int c4 = threadIdx.x & 15, rr = threadIdx.x >> 4;          // 16 threads x 4 features per row, 16 rows per pass
+    // TR x TC tile: the fp32 rows are read in runs of 4 TC bytes, x~ leaves in runs of TC elements, x~^T in runs of TR elements
+    extern __shared__ __attribute__((aligned(16))) float gd_smem[];         // (dynamic: the 128 x 128 tile is 66 KiB)
+    float (*tile)[TC + 1] = reinterpret_cast<float (*)[TC + 1]>(gd_smem);
+    float* sq = gd_smem + TR * (TC + 1);
+    constexpr int TPR = TC / 4, RPP = 256 / TPR;                     // threads per row (4 features each), rows per pass
+    static_assert(TPR == 16 || TPR == 32 || TPR == 64, "a row's threads must sit in one wave");
+    const int i0 = blockIdx.x * TR, f0 = blockIdx.y * TC;
+    const int c4 = threadIdx.x % TPR, rr = threadIdx.x / TPR;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int r = rr + 16 * k, i = i0 + r, f = f0 + 4 * c4;
+    for (int k = 0; k < TR / RPP; ++k) {
+        const int r = rr + RPP * k, i = i0 + r, f = f0 + 4 * c4;
         float v[4] = {0.f, 0.f, 0.f, 0.f}, vc[4] = {0.f, 0.f, 0.f, 0.f};
         if (i < B && f < F) {
             const int64_t row = row_idx[i];
@@ -167,26 +171,31 @@ __global__ __launch_bounds__(256) void gather_dense_kernel(
 #pragma unroll
             for (int j = 0; j < 4; ++j) vc[j] = keep[j] ? v[j] * scale : 0.f;
         }
-        if (x) store4(x + (int64_t)i * ldx + f, v);
-        if (xc) store4(xc + (int64_t)i * ldx + f, vc);
+        if (f < ldx) {                                                  // (the last tile of a 128-padded row may hang over at TC = 256)
+            if (x) store4(x + (int64_t)i * ldx + f, v);
+            if (xc) store4(xc + (int64_t)i * ldx + f, vc);
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) tile[r][4 * c4 + j] = vc[j];
         if (rowsq_part) {
             float s2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-            s2 = row16_sum(s2);                                                            // the 16 lanes of a row sit in one DPP row
+            s2 = row16_sum(s2);                                                            // 16 lanes of a row sit in one DPP row
+            if (TPR >= 32) s2 += __shfl_xor(s2, 16);
+            if (TPR >= 64) s2 += __shfl_xor(s2, 32);
             if (c4 == 0) sq[r] = s2;
         }
     }
     __syncthreads();
     if (xct) {
-        const int l2 = threadIdx.x & 31, fr0 = threadIdx.x >> 5;     // a half wave writes 64 consecutive i (packed pairs) of one feature row
+        constexpr int LPF = TR / 2, FPP = 256 / LPF;                 // lanes per feature row (packed pairs of consecutive i), feature rows per pass
+        const int l2 = threadIdx.x % LPF, fr0 = threadIdx.x / LPF;
 #pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const int fr = fr0 + 8 * p;
-            store2(xct + (int64_t)(f0 + fr) * ldt + i0 + 2 * l2, tile[2 * l2][fr], tile[2 * l2 + 1][fr]);
+        for (int p = 0; p < TC / FPP; ++p) {
+            const int fr = fr0 + FPP * p;
+            if (f0 + fr < ldx) store2(xct + (int64_t)(f0 + fr) * ldt + i0 + 2 * l2, tile[2 * l2][fr], tile[2 * l2 + 1][fr]);
         }
     }
-    if (rowsq_part && threadIdx.x < 64) rowsq_part[(int64_t)blockIdx.y * gridDim.x * 64 + i0 + threadIdx.x] = sq[threadIdx.x];
+    if (rowsq_part && threadIdx.x < TR) rowsq_part[(int64_t)blockIdx.y * gridDim.x * TR + i0 + threadIdx.x] = sq[threadIdx.x];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -546,6 +555,9 @@ __global__ void rowsq_reduce_kernel(const float* __restrict__ part, int nparts, 
 
 using namespace dae;
 
+static int g_gather_tile = 0;      // dense gather tile shape (plan option "gather_tile", process-wide)
+void dae::set_gather_tile(int v) { g_gather_tile = v & 3; }
+
 int dae::launch_gather_csr(const int64_t* indptr, const int32_t* indices, const float* values, const int32_t* row_idx, int B, int F,
                            int dtype, void* x, void* xc, int64_t ldx, void* xct, int64_t ldt, float* rowsq, int corr_mode,
                            const uint32_t* keep_bits, uint64_t seed, uint32_t rng_stream, float corr_frac, float scale,
@@ -688,19 +700,30 @@ extern "C" int dae_gather_dense(const float* data, int64_t ld_data, const int32_
     DAE_CHECK_ARG(corr_mode != DAE_CORR_KEEPBITS || keep_bits, "gather_dense: keep_bits is null");
     DAE_CHECK_ARG(!rowsq || rowsq_scratch, "gather_dense: rowsq needs rowsq_scratch[(Fp/64) x Bp]");
     const int Bp = (int)dae_pad(B);
-    dim3 grid(Bp / 64, (unsigned)(ldx / 64)), block(256);
+    // tile shape: 64 x 64 (option gather_tile = 0), 64 x 128 (1), 128 x 64 (2), 128 x 128 (3) -- rows x features
+    const int tr = (g_gather_tile & 2) ? 128 : 64, tc = (g_gather_tile & 1) ? 128 : 64;
+    dim3 grid(Bp / tr, (unsigned)((ldx + tc - 1) / tc)), block(256);
     hipStream_t st = (hipStream_t)stream;
     float* part = rowsq ? rowsq_scratch : nullptr;
     // 16-byte row reads need F % 4 == 0 and 16-byte aligned rows
     const bool vec = (F % 4 == 0) && (ld_data % 4 == 0) && ((reinterpret_cast<uintptr_t>(data) & 15) == 0);
-#define DAE_GD(TT, VV) hipLaunchKernelGGL((gather_dense_kernel<TT, VV>), grid, block, 0, st, data, ld_data, row_idx, B, F, (TT*)x, (TT*)xc, ldx, \
-                                          (TT*)xct, ldt, part, corr_mode, keep_bits, seed, rng_stream, corr_frac, scale)
-    if (dtype == DAE_BF16) { if (vec) DAE_GD(bf16_t, true); else DAE_GD(bf16_t, false); }
-    else { if (vec) DAE_GD(float, true); else DAE_GD(float, false); }
+#define DAE_GD(TT, VV, TR_, TC_) do {                                                                                                            \
+        constexpr int ldsb = (TR_ * (TC_ + 1) + TR_) * 4;                                                                                         \
+        static int attr_rc = ldsb > 64 * 1024 ? (int)hipFuncSetAttribute(reinterpret_cast<const void*>(gather_dense_kernel<TT, VV, TR_, TC_>),    \
+                                                                         hipFuncAttributeMaxDynamicSharedMemorySize, ldsb) : 0;                   \
+        DAE_CHECK_ARG(attr_rc == 0, "gather_dense: hipFuncSetAttribute failed");                                                                   \
+        hipLaunchKernelGGL((gather_dense_kernel<TT, VV, TR_, TC_>), grid, block, ldsb, st, data, ld_data, row_idx, B, F, (TT*)x, (TT*)xc, ldx,    \
+                           (TT*)xct, ldt, part, corr_mode, keep_bits, seed, rng_stream, corr_frac, scale);                                        \
+    } while (0)
+#define DAE_GD_T(TT, VV) do { switch (g_gather_tile & 3) { case 0: DAE_GD(TT, VV, 64, 64); break; case 1: DAE_GD(TT, VV, 64, 128); break; \
+                                                           case 2: DAE_GD(TT, VV, 128, 64); break; default: DAE_GD(TT, VV, 128, 128); break; } } while (0)
+    if (dtype == DAE_BF16) { if (vec) DAE_GD_T(bf16_t, true); else DAE_GD_T(bf16_t, false); }
+    else { if (vec) DAE_GD_T(float, true); else DAE_GD_T(float, false); }
+#undef DAE_GD_T
 #undef DAE_GD
     DAE_CHECK_LAUNCH();
     if (rowsq) {
-        hipLaunchKernelGGL(rowsq_reduce_kernel, dim3((Bp + 255) / 256), dim3(256), 0, st, part, (int)(ldx / 64), Bp, rowsq);
+        hipLaunchKernelGGL(rowsq_reduce_kernel, dim3((Bp + 255) / 256), dim3(256), 0, st, part, (int)grid.y, Bp, rowsq);
         DAE_CHECK_LAUNCH();
     }
     return 0;

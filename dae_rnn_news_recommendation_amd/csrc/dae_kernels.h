@@ -122,6 +122,7 @@ bool dw_bits_fits(int M, int N, int Bp);
 int launch_dw_opt(int M, int N, const void* A0, int64_t lda0, const void* Bt0, int64_t ldb0, int K0, const void* A1, int64_t lda1,
                   const void* Bt1, int64_t ldb1, int K1, const OptEpi& e, hipStream_t st, const DwBitsArgs* xa = nullptr);
 void set_use_glds(int nst);
+void set_gather_tile(int v);          // dense gather tile: bit 0 = 128 features (else 64), bit 1 = 128 rows (else 64)
 int launch_gemm_trace(int dtype, int M, int N, const void* A0, int64_t lda0, const void* Bt0, int64_t ldb0, int K0, const void* A1,
                       int64_t lda1, const void* Bt1, int64_t ldb1, int K1, float* C, int64_t ldc, int splits, int64_t slab_stride,
                       int nst, unsigned long long* trace, hipStream_t st);

@@ -116,7 +116,9 @@ if cb and cb.get("value"):
 fl = b["final_losses"]
 L.append(f"| final losses (means over the last epoch's batches) | cost {fl['cost']:.2f}, AE {fl['autoencoder']:.2f}, triplet {fl['triplet']:.4f}, fraction {fl['fraction']:.4f} |")
 r = b.get("roofline")
-if r: L.append(f"| `roofline` ({r['kernel'].split(' (')[0]}) | {r['achieved']:.0f} {r['unit']} = **{100 * r['frac']:.1f} %** of {r['peak']:.0f}; traffic {r['traffic']} B ({r.get('traffic_source')}) |")
+if r:
+    both = f" (byte floor binds: {100 * r['hbm_frac']:.1f} % of HBM peak by minimum bytes, {100 * r['mfma_frac']:.1f} % of the MFMA peak by dense FLOPs)" if "mfma_frac" in r else ""
+    L.append(f"| `roofline` ({r['kernel'].split(' (')[0]}) | {r['achieved']:.0f} {r['unit']} = **{100 * r['frac']:.1f} %** of {r['peak']:.0f}{both}; traffic {r['traffic']} B ({r.get('traffic_source')}) |")
 sr = b.get("step_roofline")
 if sr: L.append(f"| whole step | {100 * sr['mfma_frac_dense_accounting']:.1f} % of bf16 MFMA peak by dense accounting (10.B.F.H), {100 * sr['hbm_frac_min_bytes']:.1f} % of HBM peak by minimum bytes |")
 L.append("\n## The other named configs (one JSON line each in this directory)\n\n| config | samples/s | us/step | fit() Philox | fit() numpy RNG | roofline |\n|---|---:|---:|---:|---:|---|")
@@ -137,6 +139,7 @@ for slot, kern in SLOT_KERNEL:
     rp = find(stats, kern) or float("nan"); t = traffic["c2"].get(slot)
     tot_ev += k["avg_us"]; tot_rp += rp
     roof = f"{k['bound']} {100 * k['frac']:.1f} %" if "frac" in k else ""
+    if "mfma_frac" in k and k["bound"] == "hbm": roof += f" (mfma {100 * k['mfma_frac']:.1f} %)"
     L.append(f"| {slot} | `{kern}` | {k['avg_us']:.1f} | {rp:.1f} | {roof} | "
              f"{(t['fetch_bytes'] / 1e6 if t else float('nan')):.1f} | {(t['write_bytes'] / 1e6 if t else float('nan')):.1f} | {NOTE[slot]} |")
 tb = sum(v["fetch_bytes"] + v["write_bytes"] for v in traffic["c2"].values())
