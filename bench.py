@@ -363,7 +363,6 @@ def kernel_table(a, prof, nsteps):
         hbm["encode_gemm"] = B * nnz_row * 8.0 + F * H * es + B * H * (4 + 3 * es)
     # the GEMM kernels that also stream whole operands / results once: their minimum HBM bytes per launch.  Whichever floor is the
     # longer one (bytes / 8 TB/s against FLOP / MFMA peak) is the roofline that binds the kernel; both fractions are reported
-    slabs = lambda n: n * B * H * 4.0
     hbm_alt = {"dw_gemm": 2.0 * F * B * es + 2.0 * H * B * es + 2 * F * H * 4.0 + 2.0 * F * H * es,   # x~^T, delta2^T, delta1^T, h^T; W read + write; shadows
                "decode_loss": B * H * es + F * H * es + 2.0 * B * F * es + (B * F / 8.0 if not dense_in else B * F * es),   # h, W_lo; delta2 twice; x
                "dh_gemm": B * F * es + F * H * es}                                                     # delta2, Wt_lo (+ the slabs, unknown split count)
@@ -538,6 +537,7 @@ def main():
                     "encode_gemm": "encode GEMM (gemm_nt_pc<ENCODE>: x~[BxF].W[FxH], split-K, 8-wave producer/consumer)",
                     "gather": "gather_dense_kernel (fp32 rows -> masked x~ / x~^T tiles): the HBM stream of the dense input"}[key]
             alg = (f"{mfma[key] / 1e9:.2f} GFLOP per launch (dense accounting)" if key in mfma else f"{hbm[key] / 1e6:.1f} MB per launch")
+            peak_mfma = PEAK_F32_MFMA_TFLOPS if a.precision == "fp32" else PEAK_BF16_TFLOPS
             if e["bound"] == "hbm" and "min_hbm_bytes" in e:
                 alg = (f"{e['min_hbm_bytes'] / 1e6:.1f} MB per launch (operands once, master weights read + written, both bf16 shadows written) = "
                        f"{e['min_hbm_bytes'] / PEAK_HBM_GBS / 1e3:.1f} us at 8 TB/s, against {mfma[key] / 1e9:.2f} GFLOP = "
@@ -547,8 +547,9 @@ def main():
                 # x~^T is ~1.4 % dense: the FLOPs that multiply non-zeros are delta2^T.h (2 B F H) + the kept entries (2 nnz_kept H)
                 useful = 2.0 * B * F * H + 2.0 * B * 200 * 0.7 * H
                 extra = {"useful_flop_per_launch": useful, "frac_useful": useful / (e["avg_us"] * 1e-6) / 1e12 / (PEAK_F32_MFMA_TFLOPS if a.precision == "fp32" else PEAK_BF16_TFLOPS),
-                         "note": "dense accounting counts the x~^T.delta1 segment at B*F*H although x~^T is ~1.4 % dense (its A tiles are "
-                                 "built in LDS from a bit image); frac_useful prices only delta2^T.h and the kept entries"}
+                         "note": "dense accounting counts the x~^T.delta1 segment at B*F*H although x~^T is ~1.4 % dense (it is streamed as a "
+                                 "dense bf16 image: the sparse and bit-image forms measured slower); frac_useful prices only delta2^T.h and "
+                                 "the kept entries"}
             if "mfma_frac" in e:
                 extra["mfma_frac"] = e["mfma_frac"]; extra["hbm_frac"] = e["hbm_frac"]
             out["roofline"] = {"kernel": what, "bound": e["bound"], "achieved": e["achieved"], "peak": e["peak"], "unit": e["unit"],

@@ -31,7 +31,7 @@ $T rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python bench.py --step
 python tools/rocprof_summary.py $OUT/trace/t_results.db > $OUT/kernel_stats.md
 rm -rf $OUT/trace
 $T python tools/kprof.py > $OUT/kprof.txt 2>/dev/null
-[ -f dae_rnn_news_recommendation_amd/libdae_mp4.so ] && $T python tools/miner_timeline.py --lib dae_rnn_news_recommendation_amd/libdae_mp4.so > $OUT/miner_timeline.txt 2>/dev/null
+[ -f dae_rnn_news_recommendation_amd/libdae_mp4.so ] && $T python tools/miner_timeline.py --lib dae_rnn_news_recommendation_amd/libdae_mp4.so > $OUT/miner_timeline.txt 2> $OUT/miner_timeline.err
 $T python tools/dp_step_breakdown.py > $OUT/dp_step_breakdown.txt 2>/dev/null
 nproc > $OUT/host.txt; lscpu | grep "Model name" >> $OUT/host.txt; rocminfo | grep -E "gfx|Compute Unit" | head -4 >> $OUT/host.txt
 ls -la $OUT
