@@ -442,21 +442,6 @@ __global__ __launch_bounds__(GEMM_THREADS, wg_per_cu_for(NST)) void gemm_nt_f32o
 // round trip through HBM and one kernel.  The shadows leave the CU as coalesced 16-byte rows staged through LDS
 // (same staging as the decode epilogue).  `grad` is still written when the caller wants to read it (NULL skips it).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float opt_apply_elem(int opt, float lr, float mom, float p, float g, float* __restrict__ s1,
-                                                float* __restrict__ s2, int64_t k) {
-    switch (opt) {
-        case DAE_OPT_SGD: return p - lr * g;
-        case DAE_OPT_ADAGRAD: { const float a = s1[k] + g * g; s1[k] = a; return p - lr * g * rsqrtf(a); }
-        case DAE_OPT_MOMENTUM: { const float a = mom * s1[k] + g; s1[k] = a; return p - lr * a; }
-        default: {   // Adam; lr already holds lr_t
-            const float m = 0.9f * s1[k] + 0.1f * g;
-            const float v = 0.999f * s2[k] + 0.001f * g * g;
-            s1[k] = m; s2[k] = v;
-            return p - lr * m / (sqrtf(v) + 1e-8f);
-        }
-    }
-}
-
 constexpr int DWO_PITCH = 272;                        // staged bf16 row: 128 elements + 16 B pad
 constexpr int DWO_TILE_BYTES = 128 * DWO_PITCH;
 constexpr int DWO_G_BYTES = 64 * 128 * 4;             // half of the gradient tile, fp32 [64][128]

@@ -422,7 +422,10 @@ int      dae_plan_sync_shadows(dae_plan* p, void* stream);
  * entries, dae_encode_csr -- default on; 0 = dense MFMA encode GEMM), "encode_bits" (dense path: x~ as a bit image into the encode
  * GEMM; on by default for binary CSR + bf16), "x_bits" (clean rows as a bit image into the decode epilogue), "fused_opt" (optimizer in the
  * dW GEMM's epilogue), "tail" (bias gradients + statistics + x~^T un-scatter in one launch), "label_with_encode", "ce_literal"
- * (cross_entropy always by the reference-literal formula), "overlap" (miner chain on a side stream), "gram_fp32" (exact-fp32 Gram
+ * (cross_entropy always by the reference-literal formula), "overlap" (batch_all: the decode kernel forks onto a side stream beside the Gram -> miner chain and joins before the dh
+ * GEMM; off: measured slower, two cross-stream waits per step), "gather_tile" (process-wide: tile of the dense-ndarray gather, bit 0 = 128
+ * features instead of 64, bit 1 = 128 rows instead of 64; 0 is the measured best), "miner_tile" (process-wide: 1 = lane-grid batch_all kernel,
+ * default), "miner_order" / "miner_ranges" / "sym_in_decode" (side jobs riding on other launches), "gram_fp32" (exact-fp32 Gram
  * matrix in bf16 mode; before dae_plan_bind only), "dw_bits" (binary CSR + bf16: x~^T reaches the dW kernel as a bit image and the A tiles of
  * its x~^T.delta1 segment are built in LDS instead of streamed -- off by default: measured slower than the dense image), "miner_pack"
  * (batch_all workgroups = one resident round, each walking the anchor list in snake order; 0 = one workgroup per anchor), "encode_w32" (bf16 mode: the
