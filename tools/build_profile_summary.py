@@ -152,6 +152,28 @@ if "miner_valu" in traffic:
 if os.path.exists(os.path.join(src, "dp_step_breakdown.txt")):
     L.append("## Data-parallel step form without communication (one-rank RCCL group, `tools/dp_step_breakdown.py`)\n\n```\n"
              + "".join(l for l in open(os.path.join(src, "dp_step_breakdown.txt")) if "us" in l or "step" in l or "rank" in l) + "```\n")
+# MFMA busy share of the dense-input GEMM kernels (c4): tools/pmc_c4_sq.sh, an own PMC pass
+if os.path.exists(os.path.join(src, "pmc_counters_c4_sq.md")):
+    copy("pmc_counters_c4_sq.md", "rocprofv3_pmc_counters_c4_sq.md")
+    sq4 = pmc_of("pmc_counters_c4_sq.md")
+    rows = []
+    for k, v in sq4.items():
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in v and v.get("GRBM_GUI_ACTIVE") and v["SQ_VALU_MFMA_BUSY_CYCLES"] > 0:
+            cyc = v["GRBM_GUI_ACTIVE"] / 8.0            # the counter is summed over the 8 XCDs
+            rows.append((v["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * cyc), k, cyc))
+    if rows:
+        L.append(f"## MFMA busy share of the dense-input kernels (c4; `{rnd}_rocprofv3_pmc_counters_c4_sq.md`, own PMC pass of `tools/pmc_c4_sq.sh`)\n\n"
+                 "`SQ_VALU_MFMA_BUSY_CYCLES` / (1024 SIMDs x kernel cycles), kernel cycles = `GRBM_GUI_ACTIVE` / 8 (summed over the XCDs); the 256-row tiles of "
+                 "`gemm_nt_w8` spend 12.5 % of their MFMA work on the 896 -> 1024 row padding:\n\n| kernel | MFMA busy | kernel cycles |\n|---|---:|---:|")
+        for share, k, cyc in sorted(rows, reverse=True):
+            L.append(f"| `{k}` | {100 * share:.1f} % | {cyc:,.0f} |")
+        L.append("")
+fb2 = os.path.join(dst, f"{rnd}_bench_n1_c2_fast_box.json")
+if os.path.exists(fb2):
+    x = json.loads(open(fb2).read().strip().splitlines()[-1])
+    L.append(f"## Box variance\n\nThe c2 step of the same kernels on a fast box of the pool, two hours earlier (`{rnd}_bench_n1_c2_fast_box.json`, `--no-fit --no-fp32`): "
+             f"**{x['value']:,.0f} samples/s** ({1e3 * x['ms_per_step']:.1f} us/step); per kernel (HIP events): "
+             + ", ".join(f"{k} {v['avg_us']:.1f}" for k, v in x.get("kernels", {}).items()) + ".\n")
 fb = os.path.join(dst, f"{rnd}_bench_n1_c2_fastbox.json")
 if os.path.exists(fb):
     x = json.loads(open(fb).read().strip().splitlines()[-1])
