@@ -29,6 +29,7 @@ $T python bench.py --config c5 --steps 200 --warmup 20 --no-cpu-baseline > $OUT/
 $T python bench.py --config c4 --steps 100 --warmup 10 > $OUT/bench_c4.json 2>> $OUT/bench.err
 $T rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-roofline --no-fit --no-fp32 > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
 python tools/rocprof_summary.py $OUT/trace/t_results.db > $OUT/kernel_stats.md
+python tools/trace_gaps.py $OUT/trace/t_results.db > $OUT/trace_gaps.txt 2>&1
 rm -rf $OUT/trace
 bash tools/pmc_c4_sq.sh $TAG > /dev/null 2>&1   # SQ counters of the c4 GEMM kernels (own PMC pass) -> $OUT/pmc_counters_c4_sq.md
 $T python tools/kprof.py > $OUT/kprof.txt 2>/dev/null
