@@ -435,16 +435,25 @@ __global__ void opt_bias_kernel(int opt, float lr, float mom, float gscale, floa
 }
 
 // per-step statistics (autoencoder.py:233 fetch list); any block size (sm holds blockDim.x doubles)
+// three block sums at once: xor-butterfly inside each wave (fixed order), one LDS round over the waves (summed in wave order)
+__device__ __forceinline__ void block_sum_d3(double& x, double& y, double& z, double* sm) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { x += __shfl_xor(x, o); y += __shfl_xor(y, o); z += __shfl_xor(z, o); }
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) { sm[3 * w] = x; sm[3 * w + 1] = y; sm[3 * w + 2] = z; }
+    __syncthreads();
+    x = y = z = 0.0;
+    for (int i = 0; i < nw; ++i) { x += sm[3 * i]; y += sm[3 * i + 1]; z += sm[3 * i + 2]; }
+    __syncthreads();
+}
+
 __device__ __forceinline__ void step_stats_body(const StatsArgs& a, double* sm) {
-    // batch_all (all valid triplets): fold triplet_finalize in -- loss = sum/(N_valid+1e-16), num = sum of counts
-    double lsum = 0.0, csum = 0.0;
-    if (a.loss_part) {
-        double l = 0.0, c = 0.0;
-        for (int i = threadIdx.x; i < a.B; i += blockDim.x) { l += (double)a.loss_part[i]; c += (double)a.cnt_part[i]; }
-        lsum = block_sum_d(l, sm);
-        csum = block_sum_d(c, sm);
-    }
-    double s = 0.0;
+    // batch_all (all valid triplets): fold triplet_finalize in -- loss = sum/(N_valid+1e-16), num = sum of counts.
+    // One workgroup on the step's critical path: every load is issued before the (single) reduction round.
+    double lsum = 0.0, csum = 0.0, s = 0.0;
+    const float nvf = (a.loss_part && a.nvalid) ? (float)a.nvalid[0] : 0.f;
+    if (a.loss_part)
+        for (int i = threadIdx.x; i < a.B; i += blockDim.x) { lsum += (double)a.loss_part[i]; csum += (double)a.cnt_part[i]; }
     if (a.tile_part) {                                    // per-tile weighted sums from the fused decode epilogue
         for (int i = threadIdx.x; i < a.n_tiles; i += blockDim.x) s += (double)a.tile_part[i];
     } else {
@@ -454,13 +463,12 @@ __device__ __forceinline__ void step_stats_body(const StatsArgs& a, double* sm) 
             s += (double)(r * a.cw[i]);
         }
     }
-    const double ae = block_sum_d(s, sm);
+    block_sum_d3(lsum, csum, s, sm);
     if (threadIdx.x == 0) {
-        const float aef = (float)ae;
+        const float aef = (float)s;
         float tl = 0.f, fr = 0.f, nm = 0.f, nv = 0.f;
         if (a.triplet != DAE_TRIPLET_NONE) {
             if (a.loss_part) {
-                const float nvf = (float)a.nvalid[0];
                 tl = (float)lsum / (nvf + 1e-16f); nm = (float)csum; fr = nm / (nvf + 1e-16f);
                 if (a.tri_scalars) { a.tri_scalars[1] = tl; a.tri_scalars[2] = fr; a.tri_scalars[3] = nm; }
             } else {
@@ -496,12 +504,22 @@ __global__ __launch_bounds__(256) void step_tail_kernel(BiasArgs ba, StatsArgs s
     if (i >= ca.B) return;
     const int64_t row = ca.row_idx[i];
     const int64_t s0 = ca.indptr[row], e0 = ca.indptr[row + 1];
-    for (int64_t k = s0 + lane; k < e0; k += 64) {
-        const int col = ca.indices[k];
-        if (col < ca.F) {
-            if (ca.xtb) ca.xtb[(int64_t)col * ca.ldxt + (i >> 5)] = 0u;        // every lane that touches the word writes the same zero
-            else if (ca.es == 2) reinterpret_cast<bf16_t*>(ca.xct)[(int64_t)col * ca.ldt + i] = 0;
-            else reinterpret_cast<float*>(ca.xct)[(int64_t)col * ca.ldt + i] = 0.f;
+    // 256 entries per round: the four index loads of a lane are issued together, then the four stores (one load latency per round
+    // instead of four -- the stores may alias the index array as far as the compiler knows, so it would not hoist the loads itself)
+    for (int64_t k0 = s0; k0 < e0; k0 += 256) {
+        int col[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t k = k0 + lane + 64 * j;
+            col[j] = k < e0 ? ca.indices[k] : ca.F;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (col[j] < ca.F) {
+                if (ca.xtb) ca.xtb[(int64_t)col[j] * ca.ldxt + (i >> 5)] = 0u;        // every lane that touches the word writes the same zero
+                else if (ca.es == 2) reinterpret_cast<bf16_t*>(ca.xct)[(int64_t)col[j] * ca.ldt + i] = 0;
+                else reinterpret_cast<float*>(ca.xct)[(int64_t)col[j] * ca.ldt + i] = 0.f;
+            }
         }
     }
 }
