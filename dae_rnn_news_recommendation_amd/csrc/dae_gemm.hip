@@ -47,8 +47,10 @@ struct GemmSeg {
     int ktiles;             // K_seg * sizeof(T) / 128
 };
 
+constexpr int GEMM_MAX_SEG = 5;    // K segments of one contraction: split-bf16 operands need (hi,hi) (hi,lo) (lo,hi) per product
 struct GemmParams {
-    GemmSeg seg[2];
+    GemmSeg seg[GEMM_MAX_SEG];
+    int nseg;                  // non-empty segments, walked in order
     int ktiles_total;
     int tiles_m, tiles_n, splits;
     unsigned long long* trace;   // dae_gemm_trace only: [blocks][4 waves][8] shader-clock sums per K-loop phase
@@ -70,10 +72,19 @@ template <> struct Mma<float> {
     }
 };
 
+// segment of K tile kt: its index, the tile's position inside it and the first K tile AFTER it (where the stream switches operands)
+template <typename P>
+__device__ __forceinline__ int seg_locate(const P& p, int kt, int& k_in_seg, int& seg_end) {
+    int sg = 0, base = 0;
+    while (sg + 1 < p.nseg && kt >= base + p.seg[sg].ktiles) { base += p.seg[sg].ktiles; ++sg; }
+    k_in_seg = kt - base;
+    seg_end = base + p.seg[sg].ktiles;
+    return sg;
+}
 __device__ __forceinline__ void seg_of(const GemmParams& p, int kt, const char*& A, const char*& Bt,
                                        int64_t& lda, int64_t& ldb, int64_t& kbyte) {
-    int s = (kt >= p.seg[0].ktiles) ? 1 : 0;
-    int k = kt - (s ? p.seg[0].ktiles : 0);
+    int k, end;
+    const int s = seg_locate(p, kt, k, end);
     A = p.seg[s].A; Bt = p.seg[s].Bt; lda = p.seg[s].lda_b; ldb = p.seg[s].ldb_b;
     kbyte = (int64_t)k * BKB;
 }
@@ -214,10 +225,10 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, int tm, int t
         //      from a uniform (SGPR) panel pointer that advances by one K tile per stage ----
         uint32_t voA[4], voB[4];
         const char *gA = nullptr, *gB = nullptr;
-        int kt_dma = kt0;
+        int kt_dma = kt0, seg_end = 0;
         auto seg_setup = [&](int kt) {
-            const int sg = kt >= p.seg[0].ktiles ? 1 : 0;
-            const int k = kt - (sg ? p.seg[0].ktiles : 0);
+            int k;
+            const int sg = seg_locate(p, kt, k, seg_end);
             const uint32_t lda = (uint32_t)p.seg[sg].lda_b, ldb = (uint32_t)p.seg[sg].ldb_b;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -239,7 +250,7 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, int tm, int t
         };
         auto dma_advance = [&]() {
             ++kt_dma;
-            if (kt_dma == p.seg[0].ktiles) seg_setup(kt_dma);
+            if (kt_dma == seg_end && kt_dma < p.ktiles_total) seg_setup(kt_dma);
             else { gA += BKB; gB += BKB; }
         };
         // Stage s lives in slot s % NST.  Rolling schedule of iteration i (fragment registers R0 = kk 0,1 and R1 = kk 2,3):
@@ -585,10 +596,10 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_nt_pc(GemmParams p, float*
         const int wave = wave8 - 4;
         uint32_t voA[4], voB[4];
         const char *gA = nullptr, *gB = nullptr;
-        int kt_dma = kt0;
+        int kt_dma = kt0, seg_end = 0;
         auto seg_setup = [&](int kt) {
-            const int sg = kt >= p.seg[0].ktiles ? 1 : 0;
-            const int k = kt - (sg ? p.seg[0].ktiles : 0);
+            int k;
+            const int sg = seg_locate(p, kt, k, seg_end);
             const uint32_t lda = (uint32_t)p.seg[sg].lda_b, ldb = (uint32_t)p.seg[sg].ldb_b;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -611,7 +622,7 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_nt_pc(GemmParams p, float*
                                                  (__attribute__((address_space(3))) void*)(slot + TILE_BYTES + piece * 1024), 16, 0, 0);
             }
             ++kt_dma;
-            if (kt_dma == p.seg[0].ktiles) seg_setup(kt_dma);
+            if (kt_dma == seg_end && kt_dma < p.ktiles_total) seg_setup(kt_dma);
             else { gA += BKB; gB += BKB; }
         };
 #pragma unroll
@@ -833,10 +844,10 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_dw_pc(GemmParams p, OptEpi
         }
         uint32_t voA[5], voB[4];
         const char *gA = nullptr, *gB = nullptr;
-        int kt_dma = 0;
+        int kt_dma = 0, seg_end = 0;
         auto seg_setup = [&](int kt) {
-            const int sg = kt >= p.seg[0].ktiles ? 1 : 0;
-            const int k = kt - (sg ? p.seg[0].ktiles : 0);
+            int k;
+            const int sg = seg_locate(p, kt, k, seg_end);
             const uint32_t lda = (uint32_t)p.seg[sg].lda_b, ldb = (uint32_t)p.seg[sg].ldb_b;
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
@@ -906,7 +917,7 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_dw_pc(GemmParams p, OptEpi
                                                  (__attribute__((address_space(3))) void*)(slot + DW_A_BYTES + (i * 4 + wave) * 1024), 16, 0, 0);
             if (built) build_a(slot);
             ++kt_dma;
-            if (kt_dma == p.seg[0].ktiles) { if (kt_dma < p.ktiles_total) seg_setup(kt_dma); }
+            if (kt_dma == seg_end) { if (kt_dma < p.ktiles_total) seg_setup(kt_dma); }
             else { gA += BKB; gB += BKB; }
         };
         auto ops = [&](int st) { return st >= nk ? 0 : ((XBITS && st < nk0) ? 4 : 9); };   // LDS-DMA pieces of stage st (per wave)
@@ -1224,11 +1235,15 @@ __device__ __forceinline__ void mainloop_n64(const GemmParams& p, int tm, int tn
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
-    const int nk = p.seg[0].ktiles;                    // single segment, no split-K
+    const int nk = p.ktiles_total;                     // all K segments back to back, no split-K
     if (nk <= 0) return;
     uint32_t voA[4], voB[2];
-    {
-        const uint32_t lda = (uint32_t)p.seg[0].lda_b, ldb = (uint32_t)p.seg[0].ldb_b;
+    const char *gA = nullptr, *gB = nullptr;
+    int kt_dma = 0, seg_end = 0;
+    auto seg_setup = [&](int kt) {
+        int k;
+        const int sg = seg_locate(p, kt, k, seg_end);
+        const uint32_t lda = (uint32_t)p.seg[sg].lda_b, ldb = (uint32_t)p.seg[sg].ldb_b;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = (i * 4 + wave) * 8 + (lane >> 3);
@@ -1239,9 +1254,10 @@ __device__ __forceinline__ void mainloop_n64(const GemmParams& p, int tm, int tn
             const int row = (i * 4 + wave) * 8 + (lane >> 3);
             voB[i] = (uint32_t)(row0_n + row) * ldb + (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) << 4);
         }
-    }
-    const char* gA = p.seg[0].A;
-    const char* gB = p.seg[0].Bt;
+        gA = p.seg[sg].A + (int64_t)k * BKB;
+        gB = p.seg[sg].Bt + (int64_t)k * BKB;
+    };
+    seg_setup(0);
     auto dma_stage = [&](char* slot) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -1251,7 +1267,9 @@ __device__ __forceinline__ void mainloop_n64(const GemmParams& p, int tm, int tn
         for (int i = 0; i < 2; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gB + voB[i]),
                                              (__attribute__((address_space(3))) void*)(slot + TILE_BYTES + (i * 4 + wave) * 1024), 16, 0, 0);
-        gA += BKB; gB += BKB;
+        ++kt_dma;
+        if (kt_dma == seg_end) { if (kt_dma < nk) seg_setup(kt_dma); }
+        else { gA += BKB; gB += BKB; }
     };
     const int r = lane & 31, g = lane >> 5;
     const int swz = (r >> 1) & 7;
@@ -1594,30 +1612,39 @@ __global__ __launch_bounds__(GEMM_THREADS, DecGeo<BN_T>::WG_PER_CU) void gemm_de
 // ------------------------------------------------------------------------------------------------
 static int g_nst = 2;   // staging variant of the plain GEMM: 0 register-staged, 2/3/4 global_load_lds ring depth
 
-static int fill_params(GemmParams& p, int dtype, int M, int N, const void* A0, int64_t lda0, const void* Bt0,
-                       int64_t ldb0, int K0, const void* A1, int64_t lda1, const void* Bt1, int64_t ldb1, int K1,
-                       int splits, int bn = BN) {
+// one K segment of a contraction as the host hands it over: A_seg [M x K], Bt_seg [N x K], both K-contiguous, leading dimensions in elements
+static int fill_params_n(GemmParams& p, int dtype, int M, int N, const GemmSegDesc* segs, int nsegs, int splits, int bn = BN) {
     const int es = (dtype == DAE_BF16) ? 2 : 4;
     const int kel = BKB / es;
     DAE_CHECK_ARG(dtype == DAE_BF16 || dtype == DAE_F32, "gemm: bad dtype %d", dtype);
     DAE_CHECK_ARG(M > 0 && N > 0 && M % BM == 0 && N % bn == 0, "gemm: M=%d N=%d must be positive multiples of %d / %d", M, N, BM, bn);
-    DAE_CHECK_ARG(K0 > 0 && K0 % kel == 0 && K1 >= 0 && K1 % kel == 0, "gemm: K0=%d K1=%d must be multiples of %d", K0, K1, kel);
-    DAE_CHECK_ARG(A0 && Bt0 && (K1 == 0 || (A1 && Bt1)), "gemm: null operand");
-    DAE_CHECK_ARG((lda0 * es) % 16 == 0 && (ldb0 * es) % 16 == 0 && (lda1 * es) % 16 == 0 && (ldb1 * es) % 16 == 0,
-                  "gemm: leading dimensions must be 16-byte multiples");
-    DAE_CHECK_ARG(((uintptr_t)A0 % 16) == 0 && ((uintptr_t)Bt0 % 16) == 0 && ((uintptr_t)A1 % 16) == 0 && ((uintptr_t)Bt1 % 16) == 0,
-                  "gemm: operands must be 16-byte aligned");
-    DAE_CHECK_ARG((uint64_t)M * (uint64_t)((lda0 > lda1 ? lda0 : lda1) * es) < (1ull << 32) &&
-                  (uint64_t)N * (uint64_t)((ldb0 > ldb1 ? ldb0 : ldb1) * es) < (1ull << 32),
-                  "gemm: an operand panel (rows x leading dimension) must stay below 4 GiB (32-bit DMA offsets)");
-    p.seg[0] = {(const char*)A0, (const char*)Bt0, lda0 * es, ldb0 * es, K0 / kel};
-    p.seg[1] = {(const char*)A1, (const char*)Bt1, lda1 * es, ldb1 * es, K1 / kel};
-    p.ktiles_total = p.seg[0].ktiles + p.seg[1].ktiles;
+    DAE_CHECK_ARG(segs && nsegs >= 1 && nsegs <= GEMM_MAX_SEG, "gemm: %d K segments (1..%d)", nsegs, GEMM_MAX_SEG);
+    DAE_CHECK_ARG(segs[0].K > 0, "gemm: the first K segment is empty");
+    memset(p.seg, 0, sizeof(p.seg));
+    p.nseg = 0; p.ktiles_total = 0;
+    for (int i = 0; i < nsegs; ++i) {
+        const GemmSegDesc& d = segs[i];
+        DAE_CHECK_ARG(d.K >= 0 && d.K % kel == 0, "gemm: K of segment %d = %d must be a multiple of %d", i, d.K, kel);
+        if (d.K == 0) continue;                                   // empty segments are dropped (seg[] holds the non-empty ones in order)
+        DAE_CHECK_ARG(d.A && d.Bt, "gemm: null operand in segment %d", i);
+        DAE_CHECK_ARG((d.lda * es) % 16 == 0 && (d.ldb * es) % 16 == 0, "gemm: leading dimensions must be 16-byte multiples");
+        DAE_CHECK_ARG(((uintptr_t)d.A % 16) == 0 && ((uintptr_t)d.Bt % 16) == 0, "gemm: operands must be 16-byte aligned");
+        DAE_CHECK_ARG((uint64_t)M * (uint64_t)(d.lda * es) < (1ull << 32) && (uint64_t)N * (uint64_t)(d.ldb * es) < (1ull << 32),
+                      "gemm: an operand panel (rows x leading dimension) must stay below 4 GiB (32-bit DMA offsets)");
+        p.seg[p.nseg++] = {(const char*)d.A, (const char*)d.Bt, d.lda * es, d.ldb * es, d.K / kel};
+        p.ktiles_total += d.K / kel;
+    }
     p.tiles_m = M / BM; p.tiles_n = N / bn;
     p.splits = splits < 1 ? 1 : splits;
     p.trace = nullptr;
     DAE_CHECK_ARG(p.splits <= p.ktiles_total, "gemm: splits=%d exceeds k-tiles=%d", p.splits, p.ktiles_total);
     return 0;
+}
+static int fill_params(GemmParams& p, int dtype, int M, int N, const void* A0, int64_t lda0, const void* Bt0,
+                       int64_t ldb0, int K0, const void* A1, int64_t lda1, const void* Bt1, int64_t ldb1, int K1,
+                       int splits, int bn = BN) {
+    const GemmSegDesc segs[2] = {{A0, lda0, Bt0, ldb0, K0}, {A1, lda1, Bt1, ldb1, K1}};
+    return fill_params_n(p, dtype, M, N, segs, 2, splits, bn);
 }
 
 // bf16 decode runs on 128 x 64 tiles (three workgroups per CU), fp32 (parity mode) keeps the 128 x 128 tile
@@ -1741,7 +1768,8 @@ int launch_gemm_f32out(int dtype, int M, int N, const void* A0, int64_t lda0, co
     if (int rc = gemm_init()) return rc;
     if (p.splits == gemm_w8_splits(dtype, M, N, p.ktiles_total)) {
         W8Params q;
-        q.seg[0] = p.seg[0]; q.seg[1] = p.seg[1]; q.ktiles_total = p.ktiles_total; q.M = M; q.N = N;
+        for (int i = 0; i < GEMM_MAX_SEG; ++i) q.seg[i] = p.seg[i];
+        q.nseg = p.nseg; q.ktiles_total = p.ktiles_total; q.M = M; q.N = N;
         q.tiles_m = (M + W8_BM - 1) / W8_BM; q.tiles_n = (N + W8_BN - 1) / W8_BN; q.splits = p.splits;
         const int ws = p.splits;
         static bool attr = false;

@@ -25,7 +25,8 @@ constexpr int W8_STAGE = 2 * W8_TILE_BYTES;         // 64 KiB
 constexpr int W8_LDS = 2 * W8_STAGE;                // 128 KiB
 
 struct W8Params {
-    GemmSeg seg[2];
+    GemmSeg seg[GEMM_MAX_SEG];
+    int nseg;
     int ktiles_total;
     int M, N;                 // valid rows of A / of Bt (multiples of 32; tiles are clamped to them)
     int tiles_m, tiles_n, splits;
@@ -59,10 +60,10 @@ __device__ __forceinline__ void w8_mainloop(const W8Params& p, int row0_m, int r
     // ---- LDS-DMA addressing: 4 pieces (8 rows x 128 B) per operand per wave and stage ----
     uint32_t voA[4], voB[4];
     const char *gA = nullptr, *gB = nullptr;
-    int kt_dma = kt0;
+    int kt_dma = kt0, seg_end = 0;
     auto seg_setup = [&](int kt) {
-        const int sg = kt >= p.seg[0].ktiles ? 1 : 0;
-        const int k = kt - (sg ? p.seg[0].ktiles : 0);
+        int k;
+        const int sg = seg_locate(p, kt, k, seg_end);
         const uint32_t lda = (uint32_t)p.seg[sg].lda_b, ldb = (uint32_t)p.seg[sg].ldb_b;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -85,7 +86,7 @@ __device__ __forceinline__ void w8_mainloop(const W8Params& p, int row0_m, int r
                                              (__attribute__((address_space(3))) void*)(slot + W8_TILE_BYTES + piece * 1024), 16, 0, 0);
         }
         ++kt_dma;
-        if (kt_dma == p.seg[0].ktiles) { if (kt_dma < p.ktiles_total) seg_setup(kt_dma); }
+        if (kt_dma == seg_end) { if (kt_dma < p.ktiles_total) seg_setup(kt_dma); }
         else { gA += BKB; gB += BKB; }
     };
 

@@ -101,6 +101,8 @@ void set_miner_pack(int on);
 void set_miner_tile(int on);
 
 // epilogue of the fused dW + optimizer GEMM (gemm_dw_opt): parameters updated in place from the gradient tile
+// one K segment of a contraction: A_seg [M x K] and Bt_seg [N x K], both K-contiguous (leading dimensions in ELEMENTS); K = 0 segments are skipped
+struct GemmSegDesc { const void* A; int64_t lda; const void* Bt; int64_t ldb; int K; };
 struct OptEpi {
     float* W;                 // [Fp x ldw] fp32 master weights
     float* grad;              // [Fp x ldw] gradient image, or NULL when nobody reads it
