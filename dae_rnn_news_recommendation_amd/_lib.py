@@ -27,6 +27,11 @@ PAD = 128
 i32, i64, u32, u64, f32, vp = C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float, C.c_void_p
 
 
+class dae_gemm_seg(C.Structure):
+    """One K segment of dae_gemm_nt_n (include/dae_hip.h)."""
+    _fields_ = [("A", C.c_void_p), ("lda", C.c_int64), ("Bt", C.c_void_p), ("ldb", C.c_int64), ("K", C.c_int32)]
+
+
 class dae_config(C.Structure):
     _fields_ = [("n_features", i32), ("n_components", i32), ("max_batch", i32),
                 ("dtype", i32), ("enc_act", i32), ("dec_act", i32), ("loss_func", i32), ("opt", i32),
@@ -68,6 +73,7 @@ SIGNATURES = {
     "dae_encode_bits": (i32, [vp, i64, vp, i64, i32, i32, i32, vp, i64, i32, i64, vp]),
     "dae_gather_dense": (i32, [vp, i64, vp, i32, i32, i32, vp, vp, i64, vp, i64, vp, vp, i32, vp, u64, u32, f32, f32, vp]),
     "dae_gemm_nt": (i32, [i32, i32, i32, vp, i64, vp, i64, i32, vp, i64, vp, i64, i32, vp, i64, i32, i64, vp]),
+    "dae_gemm_nt_n": (i32, [i32, i32, i32, vp, i32, vp, i64, i32, i64, vp]),
     "dae_pairwise_similarity_workspace": (u64, [i32, i32]),
     "dae_pairwise_similarity": (i32, [vp, i64, i32, i32, i32, i32, i32, vp, i64, vp, u64, vp]),
     "dae_pair_stats_workspace": (u64, [i32]),

@@ -34,6 +34,14 @@ extern "C" int dae_gemm_nt(int32_t dtype, int32_t M, int32_t N, const void* A0, 
                               (hipStream_t)stream);
 }
 
+extern "C" int dae_gemm_nt_n(int32_t dtype, int32_t M, int32_t N, const dae_gemm_seg* segs, int32_t nsegs, float* C, int64_t ldc,
+                             int32_t splits, int64_t slab_stride, void* stream) {
+    DAE_CHECK_ARG(segs && nsegs >= 1 && nsegs <= 5, "gemm_nt_n: 1..5 K segments");
+    GemmSegDesc d[5];
+    for (int i = 0; i < nsegs; ++i) d[i] = {segs[i].A, segs[i].lda, segs[i].Bt, segs[i].ldb, segs[i].K};
+    return launch_gemm_f32out_n(dtype, M, N, d, nsegs, C, ldc, splits, slab_stride, (hipStream_t)stream);
+}
+
 extern "C" int dae_gemm_trace(int32_t dtype, int32_t M, int32_t N, const void* A0, int64_t lda0, const void* Bt0, int64_t ldb0,
                               int32_t K0, const void* A1, int64_t lda1, const void* Bt1, int64_t ldb1, int32_t K1, float* C,
                               int64_t ldc, int32_t splits, int64_t slab_stride, int32_t nst, uint64_t* trace, void* stream) {

@@ -1761,9 +1761,15 @@ int gemm_w8_splits(int dtype, int M, int N, int ktiles) {
 int launch_gemm_f32out(int dtype, int M, int N, const void* A0, int64_t lda0, const void* Bt0, int64_t ldb0, int K0,
                        const void* A1, int64_t lda1, const void* Bt1, int64_t ldb1, int K1, float* C, int64_t ldc,
                        int splits, int64_t slab_stride, hipStream_t st, int role, const LabelJob* label_job, int* label_done) {
+    const GemmSegDesc segs[2] = {{A0, lda0, Bt0, ldb0, K0}, {A1, lda1, Bt1, ldb1, K1}};
+    return launch_gemm_f32out_n(dtype, M, N, segs, 2, C, ldc, splits, slab_stride, st, role, label_job, label_done);
+}
+
+int launch_gemm_f32out_n(int dtype, int M, int N, const GemmSegDesc* segs, int nsegs, float* C, int64_t ldc, int splits, int64_t slab_stride,
+                         hipStream_t st, int role, const LabelJob* label_job, int* label_done) {
     if (label_done) *label_done = 0;
     GemmParams p;
-    if (int rc = fill_params(p, dtype, M, N, A0, lda0, Bt0, ldb0, K0, A1, lda1, Bt1, ldb1, K1, splits)) return rc;
+    if (int rc = fill_params_n(p, dtype, M, N, segs, nsegs, splits)) return rc;
     DAE_CHECK_ARG(C != nullptr, "gemm: C is null");
     if (int rc = gemm_init()) return rc;
     if (p.splits == gemm_w8_splits(dtype, M, N, p.ktiles_total)) {

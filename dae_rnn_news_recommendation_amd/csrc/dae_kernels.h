@@ -29,12 +29,17 @@ struct DecodeEpi {
 };
 
 struct LabelJob;
+// one K segment of a contraction: A_seg [M x K] and Bt_seg [N x K], both K-contiguous (leading dimensions in ELEMENTS); K = 0 segments are skipped
+struct GemmSegDesc { const void* A; int64_t lda; const void* Bt; int64_t ldb; int K; };
 // label_job: when the launch uses the 8-wave kernel and leaves a CU free, one extra workgroup computes the label statistics
 // (*label_done = 1); otherwise the caller launches them itself
 int launch_gemm_f32out(int dtype, int M, int N, const void* A0, int64_t lda0, const void* Bt0, int64_t ldb0, int K0,
                        const void* A1, int64_t lda1, const void* Bt1, int64_t ldb1, int K1, float* C, int64_t ldc, int splits,
                        int64_t slab_stride, hipStream_t st, int role = 0, const struct LabelJob* label_job = nullptr,
                        int* label_done = nullptr);
+// the same contraction over up to 5 K segments (split-bf16 operands: (hi,hi) (hi,lo) (lo,hi) per product)
+int launch_gemm_f32out_n(int dtype, int M, int N, const GemmSegDesc* segs, int nsegs, float* C, int64_t ldc, int splits, int64_t slab_stride,
+                         hipStream_t st, int role = 0, const LabelJob* label_job = nullptr, int* label_done = nullptr);
 // K slices the 256 x 256 / 8-MFMA-wave kernel wants for this shape (0: the shape stays on the 128 x 128 kernels); see dae_gemm.hip
 int gemm_w8_splits(int dtype, int M, int N, int ktiles);
 enum { GEMM_ROLE_GENERIC = 0, GEMM_ROLE_ENCODE = 1, GEMM_ROLE_DH = 2, GEMM_ROLE_DW = 3, GEMM_ROLE_GRAM = 4 };
@@ -101,8 +106,6 @@ void set_miner_pack(int on);
 void set_miner_tile(int on);
 
 // epilogue of the fused dW + optimizer GEMM (gemm_dw_opt): parameters updated in place from the gradient tile
-// one K segment of a contraction: A_seg [M x K] and Bt_seg [N x K], both K-contiguous (leading dimensions in ELEMENTS); K = 0 segments are skipped
-struct GemmSegDesc { const void* A; int64_t lda; const void* Bt; int64_t ldb; int K; };
 struct OptEpi {
     float* W;                 // [Fp x ldw] fp32 master weights
     float* grad;              // [Fp x ldw] gradient image, or NULL when nobody reads it

@@ -35,6 +35,21 @@ def gemm_nt(A0, Bt0, A1=None, Bt1=None, splits=1, K0=None, K1=None, M=None, N=No
     return C
 
 
+def gemm_nt_n(segs, splits=1):
+    """C = sum_s A_s @ Bt_s.T over 1..5 K segments [(A, Bt), ...]; operands [rows x K_s] row-major (all bf16 or all fp32)."""
+    A0, Bt0 = segs[0]
+    _dev(A0)
+    dtype = L.BF16 if A0.dtype == torch.bfloat16 else L.F32
+    M, N = A0.shape[0], Bt0.shape[0]
+    arr = (L.dae_gemm_seg * len(segs))()
+    for i, (a, b) in enumerate(segs):
+        assert a.shape[0] == M and b.shape[0] == N and a.shape[1] == b.shape[1] and a.dtype == A0.dtype and b.dtype == A0.dtype
+        arr[i].A, arr[i].lda, arr[i].Bt, arr[i].ldb, arr[i].K = a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), a.shape[1]
+    C = torch.empty((splits, M, N), dtype=torch.float32, device=A0.device)
+    L.call("dae_gemm_nt_n", dtype, M, N, arr, len(segs), L.ptr(C), N, splits, M * N, L.current_stream())
+    return C
+
+
 def gather_csr(indptr, indices, values, row_idx, B, F, dtype, *, want_x=True, want_xc=True, want_xct=True,
                want_rowsq=False, corr_mode=L.CORR_NONE, keep_bits=None, seed=0, rng_stream=0, corr_frac=0.0,
                scale=1.0):

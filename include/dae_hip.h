@@ -151,6 +151,13 @@ int dae_gemm_nt(int32_t dtype, int32_t M, int32_t N,
                 const void* A1, int64_t lda1, const void* Bt1, int64_t ldb1, int32_t K1,
                 float* C, int64_t ldc, int32_t splits, int64_t slab_stride, void* stream);
 
+/* The same contraction over 1..5 K segments: C = sum_s A_s[M x K_s] . Bt_s[N x K_s]^T.  Split-bf16 operands (x = hi + lo, both bf16)
+ * multiply as (hi,hi) + (hi,lo) + (lo,hi): three segments per product, the lo.lo term (2^-16 of a 2^-8 term) is dropped.  Segments with
+ * K = 0 are skipped.  Same tiles, split-K slabs and kernels as dae_gemm_nt. */
+typedef struct dae_gemm_seg { const void* A; int64_t lda; const void* Bt; int64_t ldb; int32_t K; } dae_gemm_seg;
+int dae_gemm_nt_n(int32_t dtype, int32_t M, int32_t N, const dae_gemm_seg* segs, int32_t nsegs, float* C, int64_t ldc,
+                  int32_t splits, int64_t slab_stride, void* stream);
+
 /* Diagnostic twin of dae_gemm_nt (bf16, LDS-DMA ring depth nst = 2 or 3): same arithmetic, and every wave also writes
  * shader-clock sums of its K-loop phases to trace[(block*4 + wave)*8 + k]:
  *   k=0 first MFMA half (+DMA issue)  1 waits (vmcnt/lgkmcnt)  2 barrier  3 reads + second MFMA half + DMA issue  4 K iterations

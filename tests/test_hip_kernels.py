@@ -84,6 +84,48 @@ def test_gemm_nt(ops, L, glds, dtype, shape):
         L.load().dae_set_glds(1)
 
 
+@pytest.mark.parametrize("glds", [1, 0, -1])                       # LDS-DMA ring (8-wave where the grid fits), register staging, 4-wave DMA
+@pytest.mark.parametrize("shape", [(256, 256, (128, 192, 64), 1), (896, 512, (512, 512, 512), 4), (896, 512, (10112, 10112, 10112, 896, 896), 8),
+                                   (2048, 1536, (64, 128, 64, 128, 64), 1), (128, 128, (64, 0, 128), 2)])
+def test_gemm_nt_segments(ops, L, glds, shape):
+    """dae_gemm_nt_n: one contraction over 3..5 K segments with their own operands and leading dimensions (split-bf16 products);
+    segment boundaries fall inside split-K slices, an empty segment is skipped."""
+    M, N, Ks, splits = shape
+    L.load().dae_set_glds(glds)
+    try:
+        rng = np.random.default_rng(M + N + sum(Ks))
+        segs, ref = [], 0.0
+        for i, K in enumerate(Ks):
+            pad = 64 * (i % 3)                                                # different leading dimensions per segment
+            a = torch.as_tensor(rng.standard_normal((M, K + pad)).astype(np.float32)).to(torch.bfloat16).cuda()[:, :K]
+            b = torch.as_tensor(rng.standard_normal((N, K + 2 * pad)).astype(np.float32)).to(torch.bfloat16).cuda()[:, :K]
+            segs.append((a, b))
+            ref = ref + a.double().cpu() @ b.double().cpu().T
+        C = ops.gemm_nt_n(segs, splits=splits)
+        torch.cuda.synchronize()
+        err = (C.sum(0).double().cpu() - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 2e-6, (shape, glds, err)
+    finally:
+        L.load().dae_set_glds(1)
+
+
+def test_gemm_nt_split_bf16_products(ops, L):
+    """x = hi + lo (both bf16): (hi,hi) + (hi,lo) + (lo,hi) in one contraction is a 2^-16-accurate product of the fp32 operands
+    (plain bf16: 2^-8) -- the arithmetic of the Gram GEMM, here through the segment interface."""
+    rng = np.random.default_rng(11)
+    M, N, K = 256, 384, 1024
+    a = torch.as_tensor(rng.standard_normal((M, K)).astype(np.float32)).cuda()
+    b = torch.as_tensor(rng.standard_normal((N, K)).astype(np.float32)).cuda()
+    ah, bh = a.to(torch.bfloat16), b.to(torch.bfloat16)
+    al, bl = (a - ah.float()).to(torch.bfloat16), (b - bh.float()).to(torch.bfloat16)
+    ref = a.double().cpu() @ b.double().cpu().T
+    scale = ref.abs().max().item()
+    C3 = ops.gemm_nt_n([(ah, bh), (ah, bl), (al, bh)]).sum(0).double().cpu()
+    C1 = ops.gemm_nt_n([(ah, bh)]).sum(0).double().cpu()
+    e3, e1 = (C3 - ref).abs().max().item() / scale, (C1 - ref).abs().max().item() / scale
+    assert e3 < 3e-5 and e1 > 20 * e3, (e1, e3)
+
+
 @pytest.mark.parametrize("shape", [(896, 1024, 16384, 0), (1024, 1024, 16384, 0), (896, 1024, 16384, 896), (896, 768, 16384, 0)])
 def test_gemm_nt_256_tile_kernel(ops, L, shape):
     """The 256 x 256 / 8-MFMA-wave kernel (dense-input encode / dh shapes): selected by its own split count, checked against
