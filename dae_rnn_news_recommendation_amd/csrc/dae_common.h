@@ -60,6 +60,13 @@ template <> struct Elem<bf16_t> {
     static __device__ __forceinline__ float to(bf16_t v) { return bf2f(v); }
 };
 
+// split-bf16 operands (precision mode bf16x3): x = hi + lo with hi = bf16(x) and lo = bf16(x - hi); products multiply (hi,hi) + (hi,lo) + (lo,hi)
+template <typename T> __device__ __forceinline__ T elem_residual(float v) { return Elem<T>::from(v - Elem<T>::to(Elem<T>::from(v))); }
+__device__ __forceinline__ bf16_t bf_residual_hw(float v) { return f2bf_hw(v - bf2f(f2bf_hw(v))); }
+__device__ __forceinline__ uint32_t bf_residual_pack_hw(float a, float b) {
+    return f2bf_pack_hw(a - bf2f(f2bf_hw(a)), b - bf2f(f2bf_hw(b)));
+}
+
 // ---- activations (autoencoder.py:380-389, 398-411) ----
 __device__ __forceinline__ float sigmoidf_(float z) {
     // stable logistic; __expf error ~2 ulp, far inside the 1e-4 loss gate

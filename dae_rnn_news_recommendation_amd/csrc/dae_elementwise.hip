@@ -83,7 +83,8 @@ __global__ __launch_bounds__(DHF_THREADS) void dh_finish_kernel(const float* __r
                                                                 const float* __restrict__ h_f32, int64_t ldh,
                                                                 const float* __restrict__ bh, int B, int H, int enc_act,
                                                                 T* __restrict__ delta1_t, int64_t ldt, float* __restrict__ colsum_part,
-                                                                int Hp, float* __restrict__ delta1_f32, T* __restrict__ delta1_lo) {
+                                                                int Hp, float* __restrict__ delta1_f32, T* __restrict__ delta1_lo,
+                                                                T* __restrict__ delta1_t2) {
     __shared__ float tile[32][65];
     __shared__ float cs[2][8][64];
     const int j0 = blockIdx.x * 64, i0 = blockIdx.y * 32;
@@ -133,6 +134,7 @@ __global__ __launch_bounds__(DHF_THREADS) void dh_finish_kernel(const float* __r
         for (int k = 0; k < 4; ++k) {
             const int r = r0 + 16 * k;
             delta1_t[(int64_t)(j0 + r) * ldt + i0 + c] = Elem<T>::from(tile[c][r]);
+            if (delta1_t2) delta1_t2[(int64_t)(j0 + r) * ldt + i0 + c] = elem_residual<T>(tile[c][r]);      // split-bf16: the lo image
         }
     }
     if (threadIdx.x < 128) {
@@ -353,7 +355,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void opt_w_kernel(int opt, float lr, float mom, float gscale, float* __restrict__ W,
                                                     const float* __restrict__ grad, float* __restrict__ s1,
                                                     float* __restrict__ s2, int Fp, int Hp, T* __restrict__ W_lo,
-                                                    T* __restrict__ Wt_lo, int apply) {
+                                                    T* __restrict__ Wt_lo, int apply, T* __restrict__ W_lo2, T* __restrict__ Wt_lo2) {
+    // W_lo2 / Wt_lo2 (split-bf16 mode): the lo images, bf16(W - bf16(W)) in both layouts
     __shared__ float tile[64][65];
     const int j0 = blockIdx.x * 64, f0 = blockIdx.y * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -366,12 +369,16 @@ __global__ __launch_bounds__(256) void opt_w_kernel(int opt, float lr, float mom
             W[k] = p;
         }
         if (W_lo) W_lo[k] = Elem<T>::from(p);
+        if (W_lo2) W_lo2[k] = elem_residual<T>(p);
         tile[r][tx] = p;
     }
     __syncthreads();
     if (Wt_lo) {
 #pragma unroll 4
-        for (int r = ty; r < 64; r += 4) Wt_lo[(int64_t)(j0 + r) * Fp + f0 + tx] = Elem<T>::from(tile[tx][r]);
+        for (int r = ty; r < 64; r += 4) {
+            Wt_lo[(int64_t)(j0 + r) * Fp + f0 + tx] = Elem<T>::from(tile[tx][r]);
+            if (Wt_lo2) Wt_lo2[(int64_t)(j0 + r) * Fp + f0 + tx] = elem_residual<T>(tile[tx][r]);
+        }
     }
 }
 
@@ -586,17 +593,17 @@ extern "C" int dae_encode_finish(const float* slabs, int32_t splits, int64_t sla
 
 int dae::launch_dh_finish(const float* slabs, int splits, int64_t slab_stride, int64_t ld_slab, const float* dh_extra, const float* h_f32,
                           int64_t ldh, const float* bh, int B, int H, int enc_act, int dtype, void* delta1_t, int64_t ldt, float* colsum_part,
-                          float* delta1_f32, void* delta1_lo, hipStream_t st) {
+                          float* delta1_f32, void* delta1_lo, hipStream_t st, void* delta1_t2) {
     DAE_CHECK_ARG(slabs && h_f32 && bh && colsum_part, "dh_finish: null input");
     DAE_CHECK_ARG(B > 0 && H > 0 && ldh >= dae_pad(H) && splits >= 1, "dh_finish: bad shape");
     const int Bp = (int)dae_pad(B), Hp = (int)dae_pad(H);
     dim3 grid(Hp / 64, Bp / 32), block(DHF_THREADS);
     if (dtype == DAE_BF16)
         hipLaunchKernelGGL((dh_finish_kernel<bf16_t>), grid, block, 0, st, slabs, splits, slab_stride, ld_slab, dh_extra,
-                           h_f32, ldh, bh, B, H, enc_act, (bf16_t*)delta1_t, ldt, colsum_part, Hp, delta1_f32, (bf16_t*)delta1_lo);
+                           h_f32, ldh, bh, B, H, enc_act, (bf16_t*)delta1_t, ldt, colsum_part, Hp, delta1_f32, (bf16_t*)delta1_lo, (bf16_t*)delta1_t2);
     else
         hipLaunchKernelGGL((dh_finish_kernel<float>), grid, block, 0, st, slabs, splits, slab_stride, ld_slab, dh_extra,
-                           h_f32, ldh, bh, B, H, enc_act, (float*)delta1_t, ldt, colsum_part, Hp, delta1_f32, (float*)delta1_lo);
+                           h_f32, ldh, bh, B, H, enc_act, (float*)delta1_t, ldt, colsum_part, Hp, delta1_f32, (float*)delta1_lo, (float*)nullptr);
     DAE_CHECK_LAUNCH();
     return 0;
 }
@@ -686,9 +693,8 @@ extern "C" int dae_bias_grads(const float* dbv_part, int32_t n_row_waves, const 
 }
 
 // flat layout of grad / s1 / s2: [W (Fp*Hp) | bh (Hp) | bv (Fp)]
-extern "C" int dae_opt_step(int32_t opt, float lr, float momentum, float grad_scale, float* W, float* bh, float* bv,
-                            const float* grad, float* s1, float* s2, int32_t Fp, int32_t Hp, int32_t dtype, void* W_lo,
-                            void* Wt_lo, int32_t apply, void* stream) {
+int dae::launch_opt_step(int opt, float lr, float momentum, float grad_scale, float* W, float* bh, float* bv, const float* grad, float* s1,
+                         float* s2, int Fp, int Hp, int dtype, void* W_lo, void* Wt_lo, void* W_lo2, void* Wt_lo2, int apply, void* stream) {
     const bool skip_bias = (apply == 2);     // apply: 0 refresh shadows only, 1 update W and biases, 2 update W only
     if (apply == 2) apply = 1;
     DAE_CHECK_ARG(W && Fp % DAE_PAD == 0 && Hp % DAE_PAD == 0, "opt_step: bad args");
@@ -701,10 +707,10 @@ extern "C" int dae_opt_step(int32_t opt, float lr, float momentum, float grad_sc
     dim3 grid(Hp / 64, Fp / 64), block(256);
     if (dtype == DAE_BF16)
         hipLaunchKernelGGL((opt_w_kernel<bf16_t>), grid, block, 0, ST(stream), opt, lr, momentum, grad_scale, W, grad, s1, s2, Fp, Hp,
-                           (bf16_t*)W_lo, (bf16_t*)Wt_lo, apply);
+                           (bf16_t*)W_lo, (bf16_t*)Wt_lo, apply, (bf16_t*)W_lo2, (bf16_t*)Wt_lo2);
     else
         hipLaunchKernelGGL((opt_w_kernel<float>), grid, block, 0, ST(stream), opt, lr, momentum, grad_scale, W, grad, s1, s2, Fp, Hp,
-                           (float*)W_lo, (float*)Wt_lo, apply);
+                           (float*)W_lo, (float*)Wt_lo, apply, (float*)nullptr, (float*)nullptr);
     DAE_CHECK_LAUNCH();
     if (apply && !skip_bias) {
         const int64_t off = (int64_t)Fp * Hp;
@@ -713,6 +719,12 @@ extern "C" int dae_opt_step(int32_t opt, float lr, float momentum, float grad_sc
         DAE_CHECK_LAUNCH();
     }
     return 0;
+}
+
+extern "C" int dae_opt_step(int32_t opt, float lr, float momentum, float grad_scale, float* W, float* bh, float* bv,
+                            const float* grad, float* s1, float* s2, int32_t Fp, int32_t Hp, int32_t dtype, void* W_lo,
+                            void* Wt_lo, int32_t apply, void* stream) {
+    return launch_opt_step(opt, lr, momentum, grad_scale, W, bh, bv, grad, s1, s2, Fp, Hp, dtype, W_lo, Wt_lo, nullptr, nullptr, apply, stream);
 }
 
 extern "C" int dae_opt_bias(int32_t opt, float lr, float momentum, float grad_scale, float* bh, float* bv, const float* grad_b, float* s1b,
@@ -736,10 +748,10 @@ extern "C" int dae_opt_step_rows(int32_t opt, float lr, float momentum, float gr
     dim3 grid(Hp / 64, (f1 - f0) / 64), block(256);
     if (dtype == DAE_BF16)
         hipLaunchKernelGGL((opt_w_kernel<bf16_t>), grid, block, 0, ST(stream), opt, lr, momentum, grad_scale, W + off, grad_rows, s1 ? s1 + off : nullptr,
-                           s2 ? s2 + off : nullptr, 0, Hp, (bf16_t*)((char*)W_lo + off * es), (bf16_t*)nullptr, 1);
+                           s2 ? s2 + off : nullptr, 0, Hp, (bf16_t*)((char*)W_lo + off * es), (bf16_t*)nullptr, 1, (bf16_t*)nullptr, (bf16_t*)nullptr);
     else
         hipLaunchKernelGGL((opt_w_kernel<float>), grid, block, 0, ST(stream), opt, lr, momentum, grad_scale, W + off, grad_rows, s1 ? s1 + off : nullptr,
-                           s2 ? s2 + off : nullptr, 0, Hp, (float*)((char*)W_lo + off * es), (float*)nullptr, 1);
+                           s2 ? s2 + off : nullptr, 0, Hp, (float*)((char*)W_lo + off * es), (float*)nullptr, 1, (float*)nullptr, (float*)nullptr);
     DAE_CHECK_LAUNCH();
     return 0;
 }

@@ -92,9 +92,12 @@ struct ClearArgs {            // CSR rows whose entries were scattered into x~^T
     uint32_t* xtb; int64_t ldxt;   // the bit image of x~^T instead of the dense one (xct == NULL): clears the word holding bit (i, col)
 };
 // K8 (middle), see dae_dh_finish; delta1_lo: optional ROW-MAJOR delta1 [Bp x ldh] in `dtype` (operand of the sparse x~^T.delta1)
+// K9 on the whole of W (+ biases): dae_opt_step with the lo images of the split-bf16 shadows (NULL outside that mode)
+int launch_opt_step(int opt, float lr, float momentum, float grad_scale, float* W, float* bh, float* bv, const float* grad, float* s1, float* s2,
+                    int Fp, int Hp, int dtype, void* W_lo, void* Wt_lo, void* W_lo2, void* Wt_lo2, int apply, void* stream);
 int launch_dh_finish(const float* slabs, int splits, int64_t slab_stride, int64_t ld_slab, const float* dh_extra, const float* h_f32,
                      int64_t ldh, const float* bh, int B, int H, int enc_act, int dtype, void* delta1_t, int64_t ldt, float* colsum_part,
-                     float* delta1_f32, void* delta1_lo, hipStream_t st);
+                     float* delta1_f32, void* delta1_lo, hipStream_t st, void* delta1_t2 = nullptr);   // delta1_t2: lo image of delta1^T (split-bf16)
 int launch_cast_bf16(const float* src, void* dst_bf16, int64_t n, hipStream_t st);
 int launch_step_tail(const BiasArgs& ba, const StatsArgs* sa, const ClearArgs* ca, hipStream_t st);
 // batch_all miner with an optional dispatch order of the anchors (dae_triplet.hip)
