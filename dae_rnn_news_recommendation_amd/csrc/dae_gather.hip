@@ -285,6 +285,7 @@ struct EncCsrArgs {
     int corr_mode; const uint32_t* keep_bits; uint64_t seed; uint32_t stream; float corr_frac, scale;
     int enc_act;
     float* h_f32; void* h_lo; int64_t ldh; void* h_t; int64_t ldht; bf16_t* hcat_a; bf16_t* hcat_b;
+    void* h_t2;                                 // lo image of h^T (split-bf16 mode: h = hi + lo, h_t holds hi) or NULL
     uint32_t* x_bits; int64_t ldxb;             // clean bit image [Bp x ldxb] (binary data) or NULL
     void* xct; int64_t ldt;                     // x~^T [Fp x ldt] scatter target (pre-zeroed) or NULL
     uint32_t* xtb; int64_t ldxt;                // x~^T as a BIT image [Fp x ldxt words] (pre-zeroed; bit i of row f <=> entry (i, f) kept) or NULL
@@ -474,8 +475,8 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void encode_csr_kernel(EncCsrArgs a
 #ifdef DAE_ENC_PROBE
     if (DAE_ENC_PROBE & 4) return;                                       // probe: no epilogue
 #endif
+    float hv[EPL];
     {
-        float hv[EPL];
         const int col0 = slice * COLS + lane * EPL;
 #pragma unroll
         for (int u = 0; u < EPL; ++u) {
@@ -522,6 +523,17 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void encode_csr_kernel(EncCsrArgs a
         const T* src = ht + tid * ENC_ROWS;
         *reinterpret_cast<i32x4*>(dst) = *reinterpret_cast<const i32x4*>(src);
         if constexpr (sizeof(T) == 4) *reinterpret_cast<i32x4*>(dst + 4) = *reinterpret_cast<const i32x4*>(src + 4);
+    }
+    if constexpr (sizeof(T) == 2) {
+        if (a.h_t2) {                                // split-bf16: the lo image of h^T through the same transposing tile
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < EPL; ++u) ht[(lane * EPL + u) * ENC_ROWS + r] = elem_residual<T>(hv[u]);
+            __syncthreads();
+            if (tid < COLS)
+                *reinterpret_cast<i32x4*>(reinterpret_cast<T*>(a.h_t2) + (int64_t)(slice * COLS + tid) * a.ldht + i0) =
+                    *reinterpret_cast<const i32x4*>(ht + tid * ENC_ROWS);
+        }
     }
     if (do_xbits) {
         for (int k = tid; k < ENC_ROWS * (int)a.ldxb; k += ENC_THREADS) {
@@ -616,7 +628,7 @@ int dae::launch_encode_csr(const EncCsrLaunch& q, hipStream_t st) {
     a.indptr = q.indptr; a.indices = q.indices; a.values = q.values; a.row_idx = q.row_idx;
     a.B = q.B; a.Bp = Bp; a.F = q.F; a.H = q.H; a.Hp = Hp; a.W = q.W; a.ldw = q.ldw; a.bh = q.bh;
     a.corr_mode = q.corr_mode; a.keep_bits = q.keep_bits; a.seed = q.seed; a.stream = q.rng_stream; a.corr_frac = q.corr_frac; a.scale = q.scale;
-    a.enc_act = q.enc_act; a.h_f32 = q.h_f32; a.h_lo = q.h_lo; a.ldh = q.ldh; a.h_t = q.h_t; a.ldht = q.ldht;
+    a.enc_act = q.enc_act; a.h_f32 = q.h_f32; a.h_lo = q.h_lo; a.ldh = q.ldh; a.h_t = q.h_t; a.ldht = q.ldht; a.h_t2 = q.h_t2;
     a.hcat_a = (bf16_t*)q.hcat_a; a.hcat_b = (bf16_t*)q.hcat_b; a.x_bits = q.x_bits; a.ldxb = q.ldxb; a.xct = q.xct; a.ldt = q.ldt;
     a.xtb = q.xtb; a.ldxt = q.ldxt;
     const int cols = enc_cols(q.dtype, q.w_f32, q.w32_cols);

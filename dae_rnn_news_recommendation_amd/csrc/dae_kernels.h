@@ -73,6 +73,7 @@ struct EncCsrLaunch {
     uint32_t* xtb; int64_t ldxt;   // x~^T as a bit image [Fp x ldxt words] (binary data; pre-zeroed) instead of the dense xct
     int w_f32;                     // bf16 activations only: W points at the fp32 MASTER weights [Fp x ldw] (h is then fp32-accurate)
     int w32_cols;                  // w_f32: 64 (default: one 2.6 MB slice per XCD L2) or 128 columns per workgroup
+    void* h_t2;                    // split-bf16 mode: lo image of h^T [Hp x ldht] (h_t holds hi); NULL otherwise
 };
 int launch_encode_csr(const EncCsrLaunch& q, hipStream_t st);
 size_t encode_csr_lds_bytes(int dtype, int w_f32, int w32_cols, int64_t ldxb);
