@@ -768,7 +768,7 @@ __device__ __forceinline__ void wait_vm_n(int n) {   // counted vmcnt wait for t
     }
 }
 
-template <int OPT, bool XBITS>
+template <int OPT, bool XBITS, bool X3 = false>      // X3 (split-bf16 mode): the lo images of both shadows are written too (e.W_lo2 / e.Wt_lo2)
 __global__ __launch_bounds__(PC_THREADS, 1) void gemm_dw_pc(GemmParams p, OptEpi e, int Mrows, DwBits xb) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     // XCD-banded tile map: XCD x = b % 8 owns 8 consecutive row tiles (all column tiles), so a band's A panel is read from
@@ -1031,17 +1031,19 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_dw_pc(GemmParams p, OptEpi
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                           // B2: the gradient tile is complete
     asm volatile("" ::: "memory");
+    float pvk[X3 ? DW_EB : 1][4][4];                                        // X3: the updated weights stay in registers for the lo round below
     {
         float* __restrict__ gradp = e.grad;
         float* __restrict__ s1p = e.s1;
         float* __restrict__ s2p = e.s2;
         bf16_t* __restrict__ Wlo = reinterpret_cast<bf16_t*>(UPDATE ? e.W_lo : e.grad_lo);
+        bf16_t* __restrict__ Wlo2 = reinterpret_cast<bf16_t*>(e.W_lo2);
         const float lr = e.lr, mom = e.mom, gscale = e.gscale;
 #pragma unroll
         for (int i = 0; i < DW_EB; ++i) {
             const int blk = tid + PC_THREADS * i, rg = blk >> 5, c4 = blk & 31;
             if (blk >= DW_BM * 8) break;
-            float pv[4][4];
+            float (&pv)[4][4] = pvk[X3 ? i : 0];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int lrow = rg * 4 + q;
@@ -1091,6 +1093,11 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_dw_pc(GemmParams p, OptEpi
                         uint2 lo;
                         lo.x = f2bf_pack_hw(pn[0], pn[1]); lo.y = f2bf_pack_hw(pn[2], pn[3]);
                         *reinterpret_cast<uint2*>(Wlo + k) = lo;
+                        if constexpr (X3) {
+                            uint2 l2;
+                            l2.x = bf_residual_pack_hw(pn[0], pn[1]); l2.y = bf_residual_pack_hw(pn[2], pn[3]);
+                            *reinterpret_cast<uint2*>(Wlo2 + k) = l2;
+                        }
                     }
                 }
             }
@@ -1118,6 +1125,33 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_dw_pc(GemmParams p, OptEpi
             const int row = ch / 20, c16 = ch % 20;
             if (row0_m + c16 * 8 < Mrows)
                 *reinterpret_cast<i32x4*>(Wtlo + (int64_t)(row0_n + row) * e.ldwt + row0_m + c16 * 8) =
+                    *reinterpret_cast<const i32x4*>(R1 + row * DW_P1 + c16 * 16);
+        }
+    }
+    if constexpr (X3) {                                                     // second round through the same staging tile: Wt_lo2 = bf16(W - bf16(W))^T
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                       // every piece of the hi tile has been read
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < DW_EB; ++i) {
+            const int blk = tid + PC_THREADS * i, rg = blk >> 5, c4 = blk & 31;
+            if (blk >= DW_BM * 8) break;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint2 v;
+                v.x = bf_residual_pack_hw(pvk[i][0][j], pvk[i][1][j]);
+                v.y = bf_residual_pack_hw(pvk[i][2][j], pvk[i][3][j]);
+                *reinterpret_cast<uint2*>(R1 + (c4 * 4 + j) * DW_P1 + rg * 8) = v;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        bf16_t* Wtlo2 = reinterpret_cast<bf16_t*>(e.Wt_lo2);
+        for (int ch = tid; ch < 128 * 20; ch += PC_THREADS) {
+            const int row = ch / 20, c16 = ch % 20;
+            if (row0_m + c16 * 8 < Mrows)
+                *reinterpret_cast<i32x4*>(Wtlo2 + (int64_t)(row0_n + row) * e.ldwt + row0_m + c16 * 8) =
                     *reinterpret_cast<const i32x4*>(R1 + row * DW_P1 + c16 * 16);
         }
     }
@@ -1878,6 +1912,39 @@ int launch_dw_opt(int M, int N, const void* A0, int64_t lda0, const void* Bt0, i
     static_assert(DAE_OPT_SGD == 0 && DAE_OPT_ADAGRAD == 1 && DAE_OPT_MOMENTUM == 2 && DAE_OPT_ADAM == 3, "optimizer enum order");
     DAE_CHECK_ARG(!xa && !grad_only, "dw: this shape needs the dense x~^T image and the fused-optimizer form");
     hipLaunchKernelGGL(fns[e.opt], dim3(grid_blocks(p)), dim3(GEMM_THREADS), ldsb, st, p, e);
+    DAE_CHECK_LAUNCH();
+    return 0;
+}
+
+// dW GEMM + optimizer in split-bf16 mode: the contraction runs over up to 5 K segments (x~^T.delta1_hi, x~^T.delta1_lo, delta2^T_hi.h^T_hi,
+// delta2^T_hi.h^T_lo, delta2^T_lo.h^T_hi) and the epilogue also writes the lo images of both shadows (e.W_lo2, e.Wt_lo2).  One-round
+// 160 x 128 kernel only (the shapes whose tiles fill the chip once); other shapes are refused for now.
+int launch_dw_opt_n(int M, int N, const GemmSegDesc* segs, int nsegs, const OptEpi& e, hipStream_t st) {
+    GemmParams p;
+    if (int rc = fill_params_n(p, DAE_BF16, M, N, segs, nsegs, 1)) return rc;
+    if (int rc = gemm_init()) return rc;
+    DAE_CHECK_ARG(e.W && e.W_lo && e.Wt_lo && e.W_lo2 && e.Wt_lo2 && e.ldw >= N && e.ldwt >= M && e.ldw % 8 == 0 && e.ldwt % 8 == 0,
+                  "dw_opt_n: bad parameter images (split-bf16 mode needs W_lo2 / Wt_lo2)");
+    DAE_CHECK_ARG(e.opt >= DAE_OPT_SGD && e.opt <= DAE_OPT_ADAM && (e.opt == DAE_OPT_SGD || e.s1) && (e.opt != DAE_OPT_ADAM || e.s2),
+                  "dw_opt_n: optimizer slots missing");
+    const int tiles_m = (M + DW_BM - 1) / DW_BM, tiles_n = N / BN, per = (tiles_m + 7) / 8;
+    bool k64 = true;
+    for (int i = 0; i < nsegs; ++i) k64 = k64 && segs[i].K % 64 == 0;
+    DAE_CHECK_ARG(g_dw_pc && k64 && 8 * per * tiles_n <= g_cus,
+                  "dw_opt_n: the split-bf16 dW kernel runs shapes of at most one 160 x 128 tile per CU (M=%d N=%d)", M, N);
+    typedef void (*dwpc_fn)(GemmParams, OptEpi, int, DwBits);
+    static const dwpc_fn x3s[4] = {gemm_dw_pc<DAE_OPT_SGD, false, true>, gemm_dw_pc<DAE_OPT_ADAGRAD, false, true>,
+                                   gemm_dw_pc<DAE_OPT_MOMENTUM, false, true>, gemm_dw_pc<DAE_OPT_ADAM, false, true>};
+    static int rc3 = [] {
+        int rc = 0;
+        for (dwpc_fn f : x3s) rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS);
+        return rc;
+    }();
+    DAE_CHECK_ARG(rc3 == 0, "dw_opt_n: hipFuncSetAttribute failed");
+    GemmParams q = p;
+    q.tiles_m = tiles_m; q.tiles_n = tiles_n;
+    DwBits xb; memset(&xb, 0, sizeof(xb));
+    hipLaunchKernelGGL(x3s[e.opt], dim3(8 * per * tiles_n), dim3(PC_THREADS), DW_LDS, st, q, e, M, xb);
     DAE_CHECK_LAUNCH();
     return 0;
 }

@@ -115,6 +115,7 @@ struct OptEpi {
     float* grad;              // [Fp x ldw] gradient image, or NULL when nobody reads it
     float *s1, *s2;           // optimizer slots (same layout as W), NULL when unused by `opt`
     void *W_lo, *Wt_lo;       // bf16 shadows [Fp x ldw] and [Hp x ldwt]
+    void *W_lo2, *Wt_lo2;     // split-bf16 mode: their lo images, bf16(W - bf16(W)) (NULL otherwise)
     int64_t ldw, ldwt;
     int opt;                  // DAE_OPT_* or DW_OPT_GRAD_ONLY (gradient to memory, no update: `grad` fp32 and / or `grad_lo` bf16)
     float lr, mom, gscale;
@@ -130,6 +131,7 @@ bool dw_bits_fits(int M, int N, int Bp);
 // xa != NULL: segment 0 is x~^T (bit image, A0 ignored) . Bt0 = delta1^T; segment 1 = delta2^T . h^T as usual
 int launch_dw_opt(int M, int N, const void* A0, int64_t lda0, const void* Bt0, int64_t ldb0, int K0, const void* A1, int64_t lda1,
                   const void* Bt1, int64_t ldb1, int K1, const OptEpi& e, hipStream_t st, const DwBitsArgs* xa = nullptr);
+int launch_dw_opt_n(int M, int N, const GemmSegDesc* segs, int nsegs, const OptEpi& e, hipStream_t st);   // split-bf16 mode (e.W_lo2 / e.Wt_lo2 set)
 void set_use_glds(int nst);
 void set_gather_tile(int v);          // dense gather tile: bit 0 = 128 features (else 64), bit 1 = 128 rows (else 64)
 int launch_gemm_trace(int dtype, int M, int N, const void* A0, int64_t lda0, const void* Bt0, int64_t ldb0, int K0, const void* A1,
