@@ -1344,7 +1344,7 @@ __device__ __forceinline__ void mainloop_n64(const GemmParams& p, int tm, int tn
 
 constexpr float CE_FAST_ZMAX = 14.0f;               // sigmoid(14) = 1 - 8.3e-7: five fp32 ulps from saturation
 constexpr int DECODE_NST = 2;
-template <typename T, int LOSS, int ACT, bool XBITS = false, int BN_T = 128>
+template <typename T, int LOSS, int ACT, bool XBITS = false, int BN_T = 128, bool RES = false>   // RES (split-bf16 mode): also the lo images of delta2 / delta2^T
 __global__ __launch_bounds__(GEMM_THREADS, DecGeo<BN_T>::WG_PER_CU) void gemm_decode_loss(GemmParams p, DecodeEpi e) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     using Geo = DecGeo<BN_T>;
@@ -1353,6 +1353,7 @@ __global__ __launch_bounds__(GEMM_THREADS, DecGeo<BN_T>::WG_PER_CU) void gemm_de
     constexpr bool STAGED = (sizeof(T) == 2);
     static_assert(!XBITS || STAGED, "the bit image of x is a bf16-mode operand");
     static_assert(BN_T == 128 || STAGED, "the 64-column tile is a bf16-mode kernel");
+    static_assert(!RES || STAGED, "lo images exist for bf16 operands only");
     constexpr bool IS_COS = (LOSS == DAE_LOSS_COSINE);
     if (e.sym_G && (int)blockIdx.x >= e.sym_first) {   // rider workgroups: the symmetrised triplet gradient (see DecodeEpi)
         const int t = (int)blockIdx.x - e.sym_first, nt = e.sym_Bp / 64;
@@ -1457,6 +1458,7 @@ __global__ __launch_bounds__(GEMM_THREADS, DecGeo<BN_T>::WG_PER_CU) void gemm_de
     // the reference-literal path, which reproduces TF's fp32 behaviour there (y rounds to 1, log(1e-16) = -36.84).
     const bool want_rows = e.rowloss_part != nullptr;
     float wl_acc = 0.f;                                // this lane's share of sum_i cw_i * loss_if
+    uint32_t resv[RES ? 8 : 1][NTB][2];                // RES: packed bf16(d2 - bf16(d2)) of this lane's elements, block (mt, r4) at index mt * 4 + r4
     auto epi_block = [&](auto MT, auto R4, auto FASTV) {
         constexpr int mt = decltype(MT)::value, r4 = decltype(R4)::value;
         constexpr bool FAST = decltype(FASTV)::value;
@@ -1555,6 +1557,10 @@ __global__ __launch_bounds__(GEMM_THREADS, DecGeo<BN_T>::WG_PER_CU) void gemm_de
                 v.x = f2bf_pack_hw(d2v[nt][0], d2v[nt][1]);
                 v.y = f2bf_pack_hw(d2v[nt][2], d2v[nt][3]);
                 *reinterpret_cast<uint2*>(r1_lane + nt * 32 * P1 + rloc * 2) = v;
+                if constexpr (RES) {
+                    resv[mt * 4 + r4][nt][0] = bf_residual_pack_hw(d2v[nt][0], d2v[nt][1]);
+                    resv[mt * 4 + r4][nt][1] = bf_residual_pack_hw(d2v[nt][2], d2v[nt][3]);
+                }
             } else {
                 if (d2t_lane && !pass1)
                     store4<T>(d2t_lane + (int64_t)nt * 32 * e.lddt + rloc, d2v[nt][0], d2v[nt][1], d2v[nt][2], d2v[nt][3]);
@@ -1611,6 +1617,40 @@ __global__ __launch_bounds__(GEMM_THREADS, DecGeo<BN_T>::WG_PER_CU) void gemm_de
                     const int row = ch >> 4, c16 = ch & 15;
                     *reinterpret_cast<i32x4*>(D2T + (int64_t)(tn * BN_T + row) * e.lddt + tm * BM + c16 * 8) =
                         *reinterpret_cast<const i32x4*>(R1 + row * P1 + c16 * 16);
+                }
+            }
+            if constexpr (RES) {                        // second round through the same two staging tiles: the lo images
+                __syncthreads();                        // every piece of the hi tiles has been read
+#pragma unroll
+                for (int blk = 0; blk < 8; ++blk) {
+                    const int rloc = (blk >> 2) * 32 + 8 * (blk & 3);
+#pragma unroll
+                    for (int nt = 0; nt < NTB; ++nt) {
+                        const uint32_t a = resv[blk][nt][0], b = resv[blk][nt][1];
+                        *reinterpret_cast<bf16_t*>(r0_lane + (rloc + 0) * P0 + nt * 64) = (bf16_t)(a & 0xffffu);
+                        *reinterpret_cast<bf16_t*>(r0_lane + (rloc + 1) * P0 + nt * 64) = (bf16_t)(a >> 16);
+                        *reinterpret_cast<bf16_t*>(r0_lane + (rloc + 2) * P0 + nt * 64) = (bf16_t)(b & 0xffffu);
+                        *reinterpret_cast<bf16_t*>(r0_lane + (rloc + 3) * P0 + nt * 64) = (bf16_t)(b >> 16);
+                        uint2 v; v.x = a; v.y = b;
+                        *reinterpret_cast<uint2*>(r1_lane + nt * 32 * P1 + rloc * 2) = v;
+                    }
+                }
+                __syncthreads();
+                T* D2b = reinterpret_cast<T*>(e.delta2_2);
+                T* D2Tb = reinterpret_cast<T*>(e.delta2_t2);
+#pragma unroll
+                for (int i = 0; i < XCH; ++i) {
+                    const int ch = tid + GEMM_THREADS * i;
+                    if (D2b) {
+                        const int row = ch / (BN_T / 8), c16 = ch % (BN_T / 8);
+                        *reinterpret_cast<i32x4*>(D2b + (int64_t)(tm * BM + row) * e.ldd + tn * BN_T + c16 * 8) =
+                            *reinterpret_cast<const i32x4*>(R0 + row * P0 + c16 * 16);
+                    }
+                    if (D2Tb) {
+                        const int row = ch >> 4, c16 = ch & 15;
+                        *reinterpret_cast<i32x4*>(D2Tb + (int64_t)(tn * BN_T + row) * e.lddt + tm * BM + c16 * 8) =
+                            *reinterpret_cast<const i32x4*>(R1 + row * P1 + c16 * 16);
+                    }
                 }
             }
         }
@@ -1722,6 +1762,15 @@ static decode_fn decode_kernel_xbits(int loss, int act) {
 #define DAE_DKX(LV, AV) if (loss == LV && act == AV) return gemm_decode_loss<bf16_t, LV, AV, true, DECODE_BN_BF16>;
     DAE_DKX(0, 0) DAE_DKX(0, 1) DAE_DKX(0, 2) DAE_DKX(1, 0) DAE_DKX(1, 1) DAE_DKX(1, 2) DAE_DKX(2, 0) DAE_DKX(2, 1) DAE_DKX(2, 2)
 #undef DAE_DKX
+    return nullptr;
+}
+// split-bf16 mode: the same kernels with the lo images of delta2 / delta2^T as extra outputs (bf16, 64-column tiles)
+static decode_fn decode_kernel_res(int loss, int act, bool xbits) {
+#define DAE_DKR(LV, AV)                                                                                       \
+    if (loss == LV && act == AV)                                                                              \
+        return xbits ? gemm_decode_loss<bf16_t, LV, AV, true, DECODE_BN_BF16, true> : gemm_decode_loss<bf16_t, LV, AV, false, DECODE_BN_BF16, true>;
+    DAE_DKR(0, 0) DAE_DKR(0, 1) DAE_DKR(0, 2) DAE_DKR(1, 0) DAE_DKR(1, 1) DAE_DKR(1, 2) DAE_DKR(2, 0) DAE_DKR(2, 1) DAE_DKR(2, 2)
+#undef DAE_DKR
     return nullptr;
 }
 template <typename T> static decode_fn decode_kernel(int loss, int act) {
@@ -1951,10 +2000,17 @@ int launch_dw_opt_n(int M, int N, const GemmSegDesc* segs, int nsegs, const OptE
 
 int launch_decode_loss(int dtype, int Bp, int Fp, int Hp, const void* h_lo, int64_t ldh, const void* W_lo, int64_t ldw,
                        const DecodeEpi& e_in, hipStream_t st) {
+    const GemmSegDesc seg{h_lo, ldh, W_lo, ldw, Hp};
+    return launch_decode_loss_n(dtype, Bp, Fp, &seg, 1, e_in, st);
+}
+
+// z2 = sum_s h_s . W_s^T over 1..5 K segments (split-bf16 mode: (h_hi,W_hi) (h_hi,W_lo) (h_lo,W_hi)); with e.delta2_2 / e.delta2_t2 set the
+// epilogue also writes the lo images of delta2 / delta2^T
+int launch_decode_loss_n(int dtype, int Bp, int Fp, const GemmSegDesc* segs, int nsegs, const DecodeEpi& e_in, hipStream_t st) {
     DecodeEpi e = e_in;
     GemmParams p;
     const int bn = decode_tile_n(dtype);
-    if (int rc = fill_params(p, dtype, Bp, Fp, h_lo, ldh, W_lo, ldw, Hp, nullptr, 0, nullptr, 0, 0, 1, bn)) return rc;
+    if (int rc = fill_params_n(p, dtype, Bp, Fp, segs, nsegs, 1, bn)) return rc;
     if (int rc = gemm_init()) return rc;
     DAE_CHECK_ARG(e.dec_act >= 0 && e.dec_act <= 2 && e.loss_func >= 0 && e.loss_func <= 2, "decode_loss: bad act/loss");
     DAE_CHECK_ARG(e.ldx % 8 == 0 && (!e.delta2 || e.ldd % 8 == 0) && (!e.delta2_t || e.lddt % 8 == 0),
@@ -1963,6 +2019,20 @@ int launch_decode_loss(int dtype, int Bp, int Fp, int Hp, const void* h_lo, int6
     if (e.x_bits) {
         DAE_CHECK_ARG(dtype == DAE_BF16 && e.ldxb >= Fp / 32 && ((uintptr_t)e.x_bits % 4) == 0, "decode_loss: bad x bit image");
         k = decode_kernel_xbits(e.loss_func, e.dec_act);
+    }
+    if (e.delta2_2 || e.delta2_t2) {
+        DAE_CHECK_ARG(dtype == DAE_BF16, "decode_loss: lo images of delta2 exist in bf16 (split) mode only");
+        k = decode_kernel_res(e.loss_func, e.dec_act, e.x_bits != nullptr);
+        static int res_rc = [] {
+            int rc = 0;
+            for (int l = 0; l < 3; ++l)
+                for (int a = 0; a < 3; ++a)
+                    for (int x = 0; x < 2; ++x)
+                        rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(decode_kernel_res(l, a, x != 0)),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, DecGeo<DECODE_BN_BF16>::LDS_BYTES);
+            return rc;
+        }();
+        DAE_CHECK_ARG(res_rc == 0, "decode_loss: hipFuncSetAttribute failed");
     }
     int nblocks = grid_blocks(p);
     if (e.sym_G) {

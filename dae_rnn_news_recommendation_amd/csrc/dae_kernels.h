@@ -19,6 +19,7 @@ struct DecodeEpi {
     float* cos_part;          // cosine first pass: [2 x 2*tiles_n x Bp] partial {sum y^2, sum xhat*y}
     void* delta2; int64_t ldd;
     void* delta2_t; int64_t lddt;
+    void* delta2_2; void* delta2_t2;   // split-bf16 mode: lo images of delta2 / delta2^T, bf16(d - bf16(d)), same leading dimensions (NULL otherwise)
     int B, F, Bp, Fp;
     int dec_act, loss_func;
     int cos_pass;             // 0: not cosine, 1: statistics pass, 2: final pass
@@ -45,6 +46,7 @@ int gemm_w8_splits(int dtype, int M, int N, int ktiles);
 enum { GEMM_ROLE_GENERIC = 0, GEMM_ROLE_ENCODE = 1, GEMM_ROLE_DH = 2, GEMM_ROLE_DW = 3, GEMM_ROLE_GRAM = 4 };
 int launch_decode_loss(int dtype, int Bp, int Fp, int Hp, const void* h_lo, int64_t ldh, const void* W_lo, int64_t ldw,
                        const DecodeEpi& e, hipStream_t st);
+int launch_decode_loss_n(int dtype, int Bp, int Fp, const GemmSegDesc* segs, int nsegs, const DecodeEpi& e, hipStream_t st);
 // tile width (columns of y per workgroup) of the decode kernel for `dtype`: the partial-sum arrays it writes
 // (rowloss_part / cos_part: 2 * Fp / width rows; tile_part: (Bp/128) * (Fp/width) entries) are laid out by it
 int decode_tile_n(int dtype);
