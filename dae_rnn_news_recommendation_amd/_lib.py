@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libdae_hip.so")
 
 # enums (mirror include/dae_hip.h)
 BF16, F32 = 0, 1
+BF16X3 = 2      # dae_config.dtype only: split-bf16 mode (bf16 storage; operands of the gradient GEMMs kept as hi + lo)
 ACT = {"none": 0, "sigmoid": 1, "tanh": 2}
 LOSS = {"cross_entropy": 0, "mean_squared": 1, "cosine_proximity": 2}
 OPT = {"gradient_descent": 0, "ada_grad": 1, "momentum": 2, "adam": 3}

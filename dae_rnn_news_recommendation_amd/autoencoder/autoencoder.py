@@ -8,7 +8,8 @@ line (:283-294), the per-epoch order of host RNG draws (corrupt the whole set, t
 and variable names of the checkpoint (``enc-w``, ``hidden-bias``, ``visible-bias``; :365-367).
 
 New (keyword-only, all optional):
-  precision   'bf16' (MFMA bf16 operands, fp32 accumulate/master weights) or 'fp32' (exact-fp32 MFMA)
+  precision   'bf16' (MFMA bf16 operands, fp32 accumulate/master weights), 'fp32' (exact-fp32 MFMA) or 'bf16x3' (split-bf16:
+              every stored operand of the gradient GEMMs as hi + lo bf16, three products each; CSR input, single GPU)
   rng         'numpy'  -- reference-exact legacy-RandomState stream: keep decisions are drawn on the host
                           and shipped as one bit per stored entry per epoch;
               'philox' -- counter-based masking generated on the device (statistically equivalent,
@@ -132,7 +133,7 @@ class DenoisingAutoencoder(object):
         assert type(self.verbose_step) == int                      # reference :68
         assert self.verbose >= 0
         assert self.triplet_strategy in self._STRATEGIES           # reference :70
-        assert self.precision in ('bf16', 'fp32')
+        assert self.precision in ('bf16', 'fp32', 'bf16x3')
         assert self.rng in ('numpy', 'philox')
 
         if self.seed >= 0:

@@ -118,6 +118,9 @@ struct dae_plan {
     uint64_t ws_bytes;
     // carved pointers
     char *x, *xc, *xct, *h_lo, *h_t, *Gs, *delta2, *delta2_t, *delta1_t, *delta1_lo, *hcat_a, *hcat_b;
+    // split-bf16 mode (dae_config.dtype = DAE_BF16X3): every stored operand x of the gradient GEMMs is hi + lo, both bf16; the *_2 images are the lo parts
+    bool x3;
+    char *W_lo2, *Wt_lo2, *h_t2, *delta2_2, *delta2_t2, *delta1_t2;
     uint32_t* xtb;                   // x~^T as a bit image [Fp x Bpm/32] (binary CSR + bf16: operand of the sparse half of the dW kernel)
     bool xtb_clean;                  // the bit image holds only zeros (every step clears what it set; see step_tail_kernel)
     bool dw_bits_ok;               // option "dw_bits" = 0: dense x~^T image and a K = 2 Bp dW GEMM (A/B, equivalence tests)
@@ -174,6 +177,12 @@ static uint64_t carve(dae_plan* p, char* base) {
     p->delta1_lo = take(Bp * Hp * es);
     p->xtb = (uint32_t*)take(Fp * (Bp / 32) * 4);
     p->dh_extra = (float*)take(Bp * Hp * 4);
+    p->W_lo2 = take(p->x3 ? Fp * Hp * 2 : 256);
+    p->Wt_lo2 = take(p->x3 ? Hp * Fp * 2 : 256);
+    p->h_t2 = take(p->x3 ? Hp * Bp * 2 : 256);
+    p->delta2_2 = take(p->x3 ? Bp * Fp * 2 : 256);
+    p->delta2_t2 = take(p->x3 ? Fp * Bp * 2 : 256);
+    p->delta1_t2 = take(p->x3 ? Hp * Bp * 2 : 256);
     p->hcat_a = take(p->gram_split ? Bp * 3 * Hp * 2 : 256);
     p->hcat_b = take(p->gram_split ? Bp * 3 * Hp * 2 : 256);
     p->D_slabs = (float*)take((uint64_t)p->s_gram * Bp * Bp * 4);
@@ -206,7 +215,7 @@ static uint64_t carve(dae_plan* p, char* base) {
 extern "C" int dae_plan_create(const dae_config* cfg, dae_plan** out) {
     DAE_CHECK_ARG(cfg && out, "plan_create: null argument");
     DAE_CHECK_ARG(cfg->n_features > 0 && cfg->n_components > 0 && cfg->max_batch > 0, "plan_create: bad sizes");
-    DAE_CHECK_ARG(cfg->dtype == DAE_BF16 || cfg->dtype == DAE_F32, "plan_create: bad dtype");
+    DAE_CHECK_ARG(cfg->dtype == DAE_BF16 || cfg->dtype == DAE_F32 || cfg->dtype == DAE_BF16X3, "plan_create: bad dtype");
     DAE_CHECK_ARG(cfg->enc_act >= 0 && cfg->enc_act <= 2 && cfg->dec_act >= 0 && cfg->dec_act <= 2, "plan_create: bad activation");
     DAE_CHECK_ARG(cfg->loss_func >= 0 && cfg->loss_func <= 2, "plan_create: bad loss_func");
     DAE_CHECK_ARG(cfg->opt >= 0 && cfg->opt <= 3, "plan_create: bad optimizer");
@@ -215,6 +224,11 @@ extern "C" int dae_plan_create(const dae_config* cfg, dae_plan** out) {
     DAE_CHECK_ARG(p, "plan_create: out of memory");
     memset(p, 0, sizeof(*p));
     p->cfg = *cfg;
+    // split-bf16 mode: bf16 element type and kernels everywhere (cfg.dtype reads DAE_BF16 from here on); x3 adds the lo images, the
+    // extra K segments of the three gradient GEMMs and the epilogues that write both parts
+    p->x3 = cfg->dtype == DAE_BF16X3;
+    if (p->x3) p->cfg.dtype = DAE_BF16;
+    cfg = &p->cfg;
     p->F = cfg->n_features; p->H = cfg->n_components; p->Bmax = cfg->max_batch;
     p->Fp = (int)pad128(p->F); p->Hp = (int)pad128(p->H); p->Bpm = (int)pad128(p->Bmax);
     p->es = cfg->dtype == DAE_BF16 ? 2 : 4;
@@ -230,7 +244,7 @@ extern "C" int dae_plan_create(const dae_config* cfg, dae_plan** out) {
     if (p->s_enc > kt_f) p->s_enc = kt_f;
     if (p->s_dh > kt_f) p->s_dh = kt_f;
     if (p->s_gram > p->Hp * 4 / 128) p->s_gram = p->Hp * 4 / 128;
-    p->gram_split = (cfg->dtype == DAE_BF16) && (cfg->triplet == DAE_TRIPLET_BATCH_ALL || cfg->triplet == DAE_TRIPLET_BATCH_HARD);
+    p->gram_split = (cfg->dtype == DAE_BF16) && (p->x3 || cfg->triplet == DAE_TRIPLET_BATCH_ALL || cfg->triplet == DAE_TRIPLET_BATCH_HARD);   // x3: hcat_a also holds the row-major h_lo
     p->ws_bytes = carve(p, nullptr);
     // code-path choices below are plan state (dae_plan_set_option), never read from the environment
     p->fuse_opt_ok = true;
@@ -286,6 +300,7 @@ extern "C" int dae_plan_set_option(dae_plan* p, const char* name, int32_t value)
     else if (!strcmp(name, "sym_in_decode")) p->sym_ride_ok = on;
     else if (!strcmp(name, "gram_fp32")) {
         DAE_CHECK_ARG(!p->bound, "plan_set_option: gram_fp32 changes the workspace layout, set it before dae_plan_bind");
+        DAE_CHECK_ARG(!p->x3, "plan_set_option: gram_fp32 is not available in split-bf16 mode (its Gram operands double as the row-major h images)");
         p->gram_split = !on && p->cfg.dtype == DAE_BF16 && (p->cfg.triplet == DAE_TRIPLET_BATCH_ALL || p->cfg.triplet == DAE_TRIPLET_BATCH_HARD);
         p->ws_bytes = carve(p, nullptr);
     } else {
@@ -336,15 +351,15 @@ extern "C" int dae_plan_bind(dae_plan* p, const dae_buffers* bufs) {
 
 extern "C" int dae_plan_sync_shadows(dae_plan* p, void* stream) {
     DAE_CHECK_ARG(p && p->bound, "plan_sync_shadows: plan not bound");
-    return dae_opt_step(p->cfg.opt, 0.f, 0.f, 1.f, p->b.W, p->b.bh, p->b.bv, p->b.grad, p->b.opt_s1, p->b.opt_s2, p->Fp, p->Hp,
-                        p->cfg.dtype, p->b.W_lo, p->b.Wt_lo, /*apply=*/0, stream);
+    return launch_opt_step(p->cfg.opt, 0.f, 0.f, 1.f, p->b.W, p->b.bh, p->b.bv, p->b.grad, p->b.opt_s1, p->b.opt_s2, p->Fp, p->Hp,
+                           p->cfg.dtype, p->b.W_lo, p->b.Wt_lo, p->x3 ? p->W_lo2 : nullptr, p->x3 ? p->Wt_lo2 : nullptr, /*apply=*/0, stream);
 }
 
 extern "C" void* dae_plan_buffer(dae_plan* p, const char* name) {
     if (!p || !p->bound || !name) return nullptr;
 #define DAE_BUF(n) if (!strcmp(name, #n)) return (void*)p->n;
     DAE_BUF(hcat_a) DAE_BUF(hcat_b) DAE_BUF(x) DAE_BUF(xc) DAE_BUF(xct) DAE_BUF(h_lo) DAE_BUF(h_t) DAE_BUF(Gs) DAE_BUF(delta2) DAE_BUF(delta2_t) DAE_BUF(delta1_t)
-    DAE_BUF(delta1_lo) DAE_BUF(xtb)
+    DAE_BUF(delta1_lo) DAE_BUF(xtb) DAE_BUF(W_lo2) DAE_BUF(Wt_lo2) DAE_BUF(h_t2) DAE_BUF(delta2_2) DAE_BUF(delta2_t2) DAE_BUF(delta1_t2)
     DAE_BUF(slabs) DAE_BUF(h_f32) DAE_BUF(D_slabs) DAE_BUF(G) DAE_BUF(rowloss_part) DAE_BUF(dbv_part) DAE_BUF(colsum_part)
     DAE_BUF(cos_part) DAE_BUF(cos_stats) DAE_BUF(cw) DAE_BUF(loss_part) DAE_BUF(dw_f32) DAE_BUF(tri_scalars) DAE_BUF(dh_extra)
     DAE_BUF(tile_part) DAE_BUF(cnt_part) DAE_BUF(role_cnt) DAE_BUF(dw_i32) DAE_BUF(n_same) DAE_BUF(nvalid) DAE_BUF(dw_i64)
@@ -355,7 +370,7 @@ extern "C" void* dae_plan_buffer(dae_plan* p, const char* name) {
 extern "C" int dae_plan_info(const dae_plan* p, int32_t* out8) {
     DAE_CHECK_ARG(p && out8, "plan_info: null");
     out8[0] = p->Fp; out8[1] = p->Hp; out8[2] = p->Bpm; out8[3] = p->s_enc; out8[4] = p->s_dh; out8[5] = p->s_gram;
-    out8[6] = p->es; out8[7] = 0;
+    out8[6] = p->es; out8[7] = p->x3 ? 1 : 0;
     return 0;
 }
 
@@ -455,6 +470,14 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     const bool dw_pc_grad = backward && !apply_now && dt == DAE_BF16 && p->fuse_opt_ok && dw_bits_fits(Fp, Hp, Bp);
     const bool dw_bits = p->dw_bits_ok && use_sparse && src_binary && backward && dt == DAE_BF16 && (fuse_opt || dw_pc_grad) &&
                            dw_bits_fits(Fp, Hp, Bp);
+    const bool x3 = p->x3;
+    if (x3) {
+        // split-bf16 mode, first cut: CSR input encoded from the fp32 master weights (h is fp32-accurate and its hi / lo images come from
+        // the same launch), single-GPU phases; x~ must be exact in bf16 (binary data, or values with <= 8 significant bits)
+        DAE_CHECK_ARG(use_sparse && p->enc_w32_ok, "train_step: split-bf16 mode needs CSR input and the fp32-master sparse encode");
+        DAE_CHECK_ARG(!ext_mine && (s->phase == 0 || s->phase == 2 || s->phase == 3), "train_step: split-bf16 mode supports phases 0, 2, 3 (no data-parallel split yet)");
+        DAE_CHECK_ARG(!dw_bits, "train_step: split-bf16 mode streams the dense x~^T image (option dw_bits off)");
+    }
     if (!resume && backward && csr_in) {
         if (dw_bits) { if (!(tail && p->xtb_clean)) PROF(PS_MEMSET, memset_async(p->xtb, (size_t)Fp * (ldB / 32) * 4, st)); }
         else if (!(tail && p->xct_clean)) PROF(PS_MEMSET, memset_async(p->xct, (size_t)Fp * ldB * p->es, st));
@@ -488,6 +511,7 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
         q.x_bits = own_clean ? p->x_bits : nullptr; q.ldxb = Fp / 32; q.xct = (backward && !dw_bits) ? p->xct : nullptr; q.ldt = ldB;
         q.xtb = (backward && dw_bits) ? p->xtb : nullptr; q.ldxt = ldB / 32;
         q.rowsq = own_clean ? rowsq : nullptr;
+        q.h_t2 = x3 ? p->h_t2 : nullptr;
         q.label_job = label_with_encode ? &lj : nullptr;
         PROF(PS_ENC_GEMM, launch_encode_csr(q, st));
         labels_done = label_with_encode;
@@ -544,15 +568,26 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
         e.delta2 = backward ? p->delta2 : nullptr; e.ldd = Fp; e.delta2_t = backward ? p->delta2_t : nullptr; e.lddt = ldB;
         e.B = B; e.F = F; e.Bp = Bp; e.Fp = Fp; e.dec_act = c.dec_act; e.loss_func = c.loss_func; e.ce_literal = p->ce_literal ? 1 : 0;
         if (ride) { e.sym_G = p->G; e.sym_scalars = p->tri_scalars; e.sym_Gs = p->Gs; e.sym_B = B; e.sym_Bp = Bp; }
+        // z2 = h W^T: one K segment, or -- split-bf16 -- (h_hi, W_hi) (h_hi, W_lo) (h_lo, W_hi); the row-major h_hi / h_lo are the first and
+        // third block of the Gram operand hcat_a = [hi | hi | lo] (leading dimension 3 Hp)
+        GemmSegDesc dsegs[3] = {{p->h_lo, Hp, p->b.W_lo, Hp, Hp}, {nullptr, 0, nullptr, 0, 0}, {nullptr, 0, nullptr, 0, 0}};
+        int ndseg = 1;
+        if (x3) {
+            dsegs[0] = {p->hcat_a, 3 * (int64_t)Hp, p->b.W_lo, Hp, Hp};
+            dsegs[1] = {p->hcat_a, 3 * (int64_t)Hp, p->W_lo2, Hp, Hp};
+            dsegs[2] = {p->hcat_a + (size_t)2 * Hp * 2, 3 * (int64_t)Hp, p->b.W_lo, Hp, Hp};
+            ndseg = 3;
+            if (backward) { e.delta2_2 = p->delta2_2; e.delta2_t2 = p->delta2_t2; }
+        }
         if (is_cos) {
             e.cos_pass = 1;
-            PROF(PS_DECODE, launch_decode_loss(dt, Bp, Fp, Hp, p->h_lo, Hp, p->b.W_lo, Hp, e, ds));
+            PROF(PS_DECODE, launch_decode_loss_n(dt, Bp, Fp, dsegs, ndseg, e, ds));
             PROF(PS_COS_REDUCE, dae_cos_reduce(p->cos_part, ncw, B, Bp, p->cos_stats, p->rowloss_part, (void*)ds));
             e.sym_G = nullptr;                                 // the first pass carried the rider
-            if (backward) { e.cos_pass = 2; PROF(PS_DECODE, launch_decode_loss(dt, Bp, Fp, Hp, p->h_lo, Hp, p->b.W_lo, Hp, e, ds)); }
+            if (backward) { e.cos_pass = 2; PROF(PS_DECODE, launch_decode_loss_n(dt, Bp, Fp, dsegs, ndseg, e, ds)); }
         } else {
             e.cos_pass = 0;
-            PROF(PS_DECODE, launch_decode_loss(dt, Bp, Fp, Hp, p->h_lo, Hp, p->b.W_lo, Hp, e, ds));
+            PROF(PS_DECODE, launch_decode_loss_n(dt, Bp, Fp, dsegs, ndseg, e, ds));
         }
         return 0;
     };
@@ -605,10 +640,16 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     if (!backward) return 0;
     // 9-10. dL/dh = delta2 W + alpha (G+G^T) h ; delta1                     (K8)
     const bool mined = !ext_mine && (c.triplet == DAE_TRIPLET_BATCH_ALL || c.triplet == DAE_TRIPLET_BATCH_HARD);
-    PROF(PS_DH_GEMM, launch_gemm_f32out(dt, Bp, Hp, p->delta2, Fp, p->b.Wt_lo, Fp, Fp, mined ? p->Gs : nullptr, Bp, mined ? p->h_t : nullptr, ldB,
-                          mined ? Bp : 0, p->slabs, Hp, p->s_dh, slab, st, GEMM_ROLE_DH));
+    if (x3) {       // (d2_hi, Wt_hi) (d2_hi, Wt_lo) (d2_lo, Wt_hi) + Gs.(h_hi + h_lo): Gs itself stays bf16 (tools/precision_study.py)
+        const GemmSegDesc hs[5] = {{p->delta2, Fp, p->b.Wt_lo, Fp, Fp}, {p->delta2, Fp, p->Wt_lo2, Fp, Fp}, {p->delta2_2, Fp, p->b.Wt_lo, Fp, Fp},
+                                   {p->Gs, Bp, p->h_t, ldB, mined ? Bp : 0}, {p->Gs, Bp, p->h_t2, ldB, mined ? Bp : 0}};
+        PROF(PS_DH_GEMM, launch_gemm_f32out_n(dt, Bp, Hp, hs, 5, p->slabs, Hp, p->s_dh, slab, st, GEMM_ROLE_DH));
+    } else {
+        PROF(PS_DH_GEMM, launch_gemm_f32out(dt, Bp, Hp, p->delta2, Fp, p->b.Wt_lo, Fp, Fp, mined ? p->Gs : nullptr, Bp, mined ? p->h_t : nullptr, ldB,
+                              mined ? Bp : 0, p->slabs, Hp, p->s_dh, slab, st, GEMM_ROLE_DH));
+    }
     PROF(PS_DH_FIN, launch_dh_finish(p->slabs, p->s_dh, slab, Hp, (explicit3 || ext_mine) ? p->dh_extra : nullptr, p->h_f32, Hp, p->b.bh, B, H, c.enc_act, dt,
-                     p->delta1_t, ldB, p->colsum_part, nullptr, nullptr, st));
+                     p->delta1_t, ldB, p->colsum_part, nullptr, nullptr, st, x3 ? p->delta1_t2 : nullptr));
     // 11. dW = x~^T delta1 + delta2^T h                                      (K8, tied weights)
     if (fuse_opt || dw_pc_grad) {
         OptEpi oe;
@@ -622,12 +663,21 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
             oe.opt = DW_OPT_GRAD_ONLY; oe.grad = p->b.grad_lo ? nullptr : p->b.grad; oe.grad_lo = p->b.grad_lo;
             oe.ldw = Hp;
         }
-        if (dw_bits) {
+        if (x3) {   // x~^T.(d1_hi + d1_lo) + (d2^T_hi, h^T_hi) (d2^T_hi, h^T_lo) (d2^T_lo, h^T_hi); the epilogue writes both parts of both shadows
+            const GemmSegDesc ws[5] = {{p->xct, ldB, p->delta1_t, ldB, Bp}, {p->xct, ldB, p->delta1_t2, ldB, Bp}, {p->delta2_t, ldB, p->h_t, ldB, Bp},
+                                       {p->delta2_t, ldB, p->h_t2, ldB, Bp}, {p->delta2_t2, ldB, p->h_t, ldB, Bp}};
+            oe.W_lo2 = p->W_lo2; oe.Wt_lo2 = p->Wt_lo2;
+            PROF(PS_DW_GEMM, launch_dw_opt_n(Fp, Hp, ws, 5, oe, st));
+        } else if (dw_bits) {
             DwBitsArgs xa{p->xtb, ldB / 32, s->scale};
             PROF(PS_DW_GEMM, launch_dw_opt(Fp, Hp, nullptr, ldB, p->delta1_t, ldB, Bp, p->delta2_t, ldB, p->h_t, ldB, Bp, oe, st, &xa));
         } else {
             PROF(PS_DW_GEMM, launch_dw_opt(Fp, Hp, p->xct, ldB, p->delta1_t, ldB, Bp, p->delta2_t, ldB, p->h_t, ldB, Bp, oe, st));
         }
+    } else if (x3) {
+        const GemmSegDesc ws[5] = {{p->xct, ldB, p->delta1_t, ldB, Bp}, {p->xct, ldB, p->delta1_t2, ldB, Bp}, {p->delta2_t, ldB, p->h_t, ldB, Bp},
+                                   {p->delta2_t, ldB, p->h_t2, ldB, Bp}, {p->delta2_t2, ldB, p->h_t, ldB, Bp}};
+        PROF(PS_DW_GEMM, launch_gemm_f32out_n(dt, Fp, Hp, ws, 5, p->b.grad, Hp, 1, 0, st, GEMM_ROLE_DW));
     } else {
         PROF(PS_DW_GEMM, launch_gemm_f32out(dt, Fp, Hp, p->xct, ldB, p->delta1_t, ldB, Bp, p->delta2_t, ldB, p->h_t, ldB, Bp, p->b.grad, Hp, 1, 0, st, GEMM_ROLE_DW));
         // data parallel with a bf16 exchange image: the shape did not fit the kernel that writes it directly
@@ -654,13 +704,14 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     }
     if (s->phase == 1 || s->phase == 5 || fuse_opt) return 0;
     // 13. optimizer (K9): W (+ shadows); biases were updated above
-    PROF(PS_OPT, dae_opt_step(c.opt, plan_lr(p, s->adam_t), c.momentum, s->grad_scale, p->b.W, p->b.bh, p->b.bv, p->b.grad, p->b.opt_s1,
-                              p->b.opt_s2, Fp, Hp, dt, p->b.W_lo, p->b.Wt_lo, /*apply=*/2, stream));
+    PROF(PS_OPT, launch_opt_step(c.opt, plan_lr(p, s->adam_t), c.momentum, s->grad_scale, p->b.W, p->b.bh, p->b.bv, p->b.grad, p->b.opt_s1,
+                                 p->b.opt_s2, Fp, Hp, dt, p->b.W_lo, p->b.Wt_lo, x3 ? p->W_lo2 : nullptr, x3 ? p->Wt_lo2 : nullptr, /*apply=*/2, stream));
     return 0;
 }
 
 extern "C" int dae_plan_apply(dae_plan* p, int32_t adam_t, float grad_scale, void* stream) {
     DAE_CHECK_ARG(p && p->bound, "plan_apply: plan not bound");
+    DAE_CHECK_ARG(!p->x3, "plan_apply: split-bf16 mode has no data-parallel path yet");
     const float lr = plan_lr(p, adam_t);
     return dae_opt_step(p->cfg.opt, lr, p->cfg.momentum, grad_scale, p->b.W, p->b.bh, p->b.bv, p->b.grad, p->b.opt_s1, p->b.opt_s2,
                         p->Fp, p->Hp, p->cfg.dtype, p->b.W_lo, p->b.Wt_lo, /*apply=*/1, stream);
@@ -672,6 +723,7 @@ extern "C" int dae_plan_apply(dae_plan* p, int32_t adam_t, float grad_scale, voi
 // call dae_plan_refresh_wt.
 extern "C" int dae_plan_apply_rows(dae_plan* p, int32_t adam_t, float grad_scale, const float* grad_rows, int32_t f0, int32_t f1,
                                    int32_t update_bias, void* stream) {
+    DAE_CHECK_ARG(!p || !p->x3, "plan_apply_rows: split-bf16 mode has no data-parallel path yet");
     DAE_CHECK_ARG(p && p->bound && grad_rows, "plan_apply_rows: plan not bound / null gradient");
     DAE_CHECK_ARG(f0 >= 0 && f0 <= f1 && f1 <= p->Fp && f0 % 64 == 0 && f1 % 64 == 0, "plan_apply_rows: rows [%d, %d) outside [0, %d] or not multiples of 64", f0, f1, p->Fp);
     const float lr = plan_lr(p, adam_t);
@@ -704,6 +756,7 @@ extern "C" int dae_plan_stream_wait_dw(dae_plan* p, void* stream) {
 // the all-gather instead of their own all-reduce, and no copy of the updated rows is needed.  Biases are NOT updated here.
 extern "C" int dae_plan_apply_rows_packed(dae_plan* p, int32_t adam_t, float grad_scale, const float* grad_rows, int32_t f0, int32_t f1,
                                           void* send, int64_t bias_off_bytes, void* stream) {
+    DAE_CHECK_ARG(!p || !p->x3, "plan_apply_rows_packed: split-bf16 mode has no data-parallel path yet");
     DAE_CHECK_ARG(p && p->bound && grad_rows && send, "plan_apply_rows_packed: plan not bound / null buffer");
     DAE_CHECK_ARG(f0 >= 0 && f0 <= f1 && f1 <= p->Fp && f0 % 64 == 0 && f1 % 64 == 0, "plan_apply_rows_packed: rows [%d, %d) outside [0, %d] or not multiples of 64", f0, f1, p->Fp);
     const float lr = plan_lr(p, adam_t);
@@ -718,6 +771,7 @@ extern "C" int dae_plan_apply_rows_packed(dae_plan* p, int32_t adam_t, float gra
 // After the all-gather of the packed chunks: W_lo, Wt_lo and the biases of this rank (see dp_unpack_kernel).
 extern "C" int dae_plan_dp_unpack(dae_plan* p, const void* recv, int32_t world, int32_t chunk_rows, int64_t chunk_stride_bytes,
                                   int64_t bias_off_bytes, int32_t adam_t, float grad_scale, void* stream) {
+    DAE_CHECK_ARG(!p || !p->x3, "plan_dp_unpack: split-bf16 mode has no data-parallel path yet");
     DAE_CHECK_ARG(p && p->bound && recv, "plan_dp_unpack: plan not bound / null buffer");
     const int64_t off = (int64_t)p->Fp * p->Hp;
     return dae_dp_unpack(recv, world, chunk_rows, chunk_stride_bytes, bias_off_bytes, p->Fp, p->Hp, p->cfg.dtype, p->b.W_lo, p->b.Wt_lo, p->cfg.opt,
@@ -726,6 +780,7 @@ extern "C" int dae_plan_dp_unpack(dae_plan* p, const void* recv, int32_t world, 
 }
 
 extern "C" int dae_plan_refresh_wt(dae_plan* p, void* stream) {
+    DAE_CHECK_ARG(!p || !p->x3, "plan_refresh_wt: split-bf16 mode has no data-parallel path yet");
     DAE_CHECK_ARG(p && p->bound, "plan_refresh_wt: plan not bound");
     return dae_transpose_shadow(p->b.W_lo, p->Fp, p->Hp, p->cfg.dtype, p->b.Wt_lo, stream);
 }

@@ -27,11 +27,14 @@ class Engine:
         self.lib = L.load()
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         self.F, self.H, self.Bmax = int(n_features), int(n_components), int(max_batch)
-        self.dtype = {"bf16": L.BF16, "bfloat16": L.BF16, "fp32": L.F32, "f32": L.F32, "float32": L.F32}.get(dtype, dtype)
-        assert self.dtype in (L.BF16, L.F32), dtype
+        cfg_dtype = {"bf16": L.BF16, "bfloat16": L.BF16, "fp32": L.F32, "f32": L.F32, "float32": L.F32, "bf16x3": L.BF16X3}.get(dtype, dtype)
+        assert cfg_dtype in (L.BF16, L.F32, L.BF16X3), dtype
+        # split-bf16 mode stores bf16 everywhere (self.dtype = the element type of the images); only the plan's config says x3
+        self.x3 = cfg_dtype == L.BF16X3
+        self.dtype = L.BF16 if self.x3 else cfg_dtype
         self.td = torch.bfloat16 if self.dtype == L.BF16 else torch.float32
         self.opt = opt
-        self.cfg = L.dae_config(self.F, self.H, self.Bmax, self.dtype, L.ACT[enc_act], L.ACT[dec_act], L.LOSS[loss_func],
+        self.cfg = L.dae_config(self.F, self.H, self.Bmax, cfg_dtype, L.ACT[enc_act], L.ACT[dec_act], L.LOSS[loss_func],
                                 L.OPT[opt], L.TRIPLET[triplet], int(pos_triplets_only), encode_splits, dh_splits,
                                 gram_splits, float(learning_rate), float(momentum), float(alpha))
         plan = C.c_void_p()

@@ -31,7 +31,10 @@ extern "C" {
 #define DAE_PAD 128
 #define DAE_ABI_VERSION 3   /* 3: dae_buffers.grad_lo, options dw_bits / encode_w32; 2: dae_step.c_row_idx, plan options, phases 4/5, sharded apply */
 
-enum { DAE_BF16 = 0, DAE_F32 = 1 };
+enum { DAE_BF16 = 0, DAE_F32 = 1,
+       DAE_BF16X3 = 2 /* dae_config.dtype only: bf16 storage and MFMA, but every stored operand of the three gradient GEMMs is kept as
+                         hi + lo (both bf16) and multiplied as (hi,hi) + (hi,lo) + (lo,hi) -- 2^-16 operands at ~3x the bf16 GEMM work;
+                         CSR input, single GPU (first cut) */ };
 enum { DAE_ACT_NONE = 0, DAE_ACT_SIGMOID = 1, DAE_ACT_TANH = 2 };
 enum { DAE_LOSS_CROSS_ENTROPY = 0, DAE_LOSS_MEAN_SQUARED = 1, DAE_LOSS_COSINE = 2 };
 enum { DAE_OPT_SGD = 0, DAE_OPT_ADAGRAD = 1, DAE_OPT_MOMENTUM = 2, DAE_OPT_ADAM = 3 };
