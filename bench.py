@@ -81,7 +81,7 @@ def parse():
     ap.add_argument("--compress-factor", type=int, default=0)
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--strategy", default="", choices=["", "batch_all", "batch_hard", "none"])
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3"])
     ap.add_argument("--rng", default="philox", choices=["philox", "numpy"])
     ap.add_argument("--grad-dtype", default=None, choices=["fp32", "bf16"],
                     help="N>1: element type of the reduce-scattered W gradient (default: the compute precision -- bf16 steps exchange the bf16 "

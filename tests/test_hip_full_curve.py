@@ -24,7 +24,7 @@ PATH = os.path.join(HERE, "golden", "full_curve_c2.npz")
 
 
 @pytest.mark.skipif(not os.path.exists(PATH), reason="tests/golden/full_curve_c2.npz not generated")
-@pytest.mark.parametrize("precision,tol,tol_saturated", [("fp32", 2e-5, 2e-5), ("bf16", 1e-4, 6e-4)])
+@pytest.mark.parametrize("precision,tol,tol_saturated", [("fp32", 2e-5, 2e-5), ("bf16", 1e-4, 6e-4), ("bf16x3", 1e-4, 1e-4)])
 def test_full_shape_loss_curve(tmp_path, precision, tol, tol_saturated):
     sys.path.insert(0, os.path.join(HERE, "golden"))
     import make_full_curve as M
@@ -47,9 +47,10 @@ def test_full_shape_loss_curve(tmp_path, precision, tol, tol_saturated):
             if key == "triplet" and precision == "bf16":
                 step = np.arange(pb.shape[0]) + e * pb.shape[0]
                 gate = np.where(step < 3, 1e-4, np.where(step == 3, 5e-4, 1e-2))
+            print(f"[curve] {precision} epoch {e} {key}: max rel {rel.max():.2e} at batch {int(rel.argmax())}")
             assert (rel <= gate).all(), (precision, e, key, rel)
         if precision == "fp32":
             assert np.abs(pb[:, 4] - G["num"][e]).max() <= 200        # of ~5*10^7 positive triplets: near-ties of the fp32 Gram matrix
     W = model.engine.get_params()[0].astype(np.float64)
     got = np.array([np.abs(W).sum(), (W ** 2).sum(), W[17, 3], W[9999, 499]])
-    assert np.abs(got - G["W_checksum"]).max() <= (1e-5 if precision == "fp32" else 5e-3) * np.abs(G["W_checksum"]).max()
+    assert np.abs(got - G["W_checksum"]).max() <= {"fp32": 1e-5, "bf16x3": 1e-4}.get(precision, 5e-3) * np.abs(G["W_checksum"]).max()

@@ -120,11 +120,12 @@ def test_step_bf16x3_matches_oracle(strategy, opt):
     """Split-bf16 mode (every stored operand of the gradient GEMMs as hi + lo bf16, three products each): statistics, gradients and
     updated parameters of three steps agree with the fp64 oracle two orders of magnitude closer than plain bf16 does (2e-2 there)."""
     out, ref, got = _run_case("bf16x3", strategy, "cross_entropy", ("sigmoid", "sigmoid"), opt, steps=3)
+    tol = 2e-5 if opt == "gradient_descent" else 1e-4       # (Adam turns a 1e-5 gradient difference near zero into a full-size weight step)
     for r, st, dW, dbh, dbv in out:
-        assert abs(st[1] - r["ae_loss"]) <= 2e-5 * abs(r["ae_loss"]), (st[1], r["ae_loss"])
-        assert abs(st[0] - r["cost"]) <= 2e-5 * abs(r["cost"])
+        assert abs(st[1] - r["ae_loss"]) <= tol * abs(r["ae_loss"]), (st[1], r["ae_loss"])
+        assert abs(st[0] - r["cost"]) <= tol * abs(r["cost"])
         if strategy == "batch_all":
-            assert abs(st[2] - r["triplet_loss"]) <= 2e-5 * abs(r["triplet_loss"])
+            assert abs(st[2] - r["triplet_loss"]) <= tol * abs(r["triplet_loss"])
     if opt == "gradient_descent":          # (Adam moves a weight by ~lr * sign(g): no max-norm bound through a near-zero gradient element)
         for a, b in zip(got, ref):
             assert _rel(a, b) < 2e-4, _rel(a, b)
