@@ -143,7 +143,7 @@ def load():
         fn = getattr(lib, name)      # AttributeError here == stale library
         fn.restype = res
         fn.argtypes = args
-    if lib.dae_abi_version() != 3:
+    if lib.dae_abi_version() != 4:
         raise RuntimeError("libdae_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -29,7 +29,7 @@ extern "C" {
 #endif
 
 #define DAE_PAD 128
-#define DAE_ABI_VERSION 3   /* 3: dae_buffers.grad_lo, options dw_bits / encode_w32; 2: dae_step.c_row_idx, plan options, phases 4/5, sharded apply */
+#define DAE_ABI_VERSION 4   /* 4: DAE_BF16X3 (split-bf16 mode), dae_gemm_nt_n; 3: dae_buffers.grad_lo, options dw_bits / encode_w32; 2: dae_step.c_row_idx, plan options, phases 4/5, sharded apply */
 
 enum { DAE_BF16 = 0, DAE_F32 = 1,
        DAE_BF16X3 = 2 /* dae_config.dtype only: bf16 storage and MFMA, but every stored operand of the three gradient GEMMs is kept as

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in dae_hip.h but not exported by libdae_hip.so"
     assert names == set(_lib.SIGNATURES), names ^ set(_lib.SIGNATURES)
-    assert lib.dae_abi_version() == 3
+    assert lib.dae_abi_version() == 4
     assert lib.dae_pad(800) == 896 and lib.dae_pad(10000) == 10112 and lib.dae_pad(128) == 128
 
 
