@@ -114,6 +114,8 @@ if cb and cb.get("value"):
     L.append(f"| CPU baseline: PyTorch-CPU fp32 restatement, literal B^3 batch_all, {cb['cores']} threads | {cb['value']:.1f} samples/s |")
     if cb.get("chunked"): L.append(f"| CPU baseline, chunked (memory-lean) form | {cb['chunked']['samples_per_s']:.1f} samples/s |")
 fl = b["final_losses"]
+if b.get("bf16x3") and b["bf16x3"].get("value"):
+    L.append(f"| `precision='bf16x3'` (split-bf16: holds the 1e-4 curve gate on all 20 steps), same K steps | {b['bf16x3']['value']:,.0f} ({1e3 * b['bf16x3']['ms_per_step']:.1f} us/step) |")
 L.append(f"| final losses (means over the last epoch's batches) | cost {fl['cost']:.2f}, AE {fl['autoencoder']:.2f}, triplet {fl['triplet']:.4f}, fraction {fl['fraction']:.4f} |")
 r = b.get("roofline")
 if r:
