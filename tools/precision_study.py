@@ -100,7 +100,7 @@ def run(mode, data, labels, W0, steps, B, lr=0.1, alpha=1.0, seed=7):
         dbh = d1.sum(0) - sb * (1.0 - sb) * dh.sum(0)
         dbv = d2.sum(0)
         W -= lr * dW; bh -= lr * dbh; bv -= lr * dbv
-        out.append((float(ae) + alpha * tl, float(ae), tl))
+        out.append((float(ae.detach()) + alpha * tl, float(ae.detach()), tl))
     return np.array(out)
 
 
