@@ -477,6 +477,10 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
         DAE_CHECK_ARG(use_sparse && p->enc_w32_ok, "train_step: split-bf16 mode needs CSR input and the fp32-master sparse encode");
         DAE_CHECK_ARG(!ext_mine && (s->phase == 0 || s->phase == 2 || s->phase == 3), "train_step: split-bf16 mode supports phases 0, 2, 3 (no data-parallel split yet)");
         DAE_CHECK_ARG(!dw_bits, "train_step: split-bf16 mode streams the dense x~^T image (option dw_bits off)");
+        {   // the corruption's scale factor multiplies every entry of x~^T: it must be exact in bf16 as well (1.0 for masking noise)
+            uint32_t u; memcpy(&u, &s->scale, 4);
+            DAE_CHECK_ARG((u & 0xffffu) == 0u, "train_step: split-bf16 mode needs a corruption scale that is exact in bf16 (got %g)", (double)s->scale);
+        }
     }
     if (!resume && backward && csr_in) {
         if (dw_bits) { if (!(tail && p->xtb_clean)) PROF(PS_MEMSET, memset_async(p->xtb, (size_t)Fp * (ldB / 32) * 4, st)); }

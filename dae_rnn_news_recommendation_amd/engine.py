@@ -88,6 +88,12 @@ class Engine:
         assert m.shape[1] == self.F, (m.shape, self.F)
         dev = self.device
         binary = bool(m.nnz == 0 or np.all(m.data == 1))
+        if self.x3 and not binary:
+            # split-bf16 mode keeps x~ / x~^T as ONE bf16 image (no lo part yet): the stored values must be exact in bf16
+            v = np.ascontiguousarray(m.data, dtype=np.float32)
+            if not np.array_equal(torch.from_numpy(v).to(torch.bfloat16).float().numpy(), v):
+                raise ValueError("precision='bf16x3' needs input values that are exact in bf16 (binary bag-of-words data); "
+                                 "use precision='fp32' for tf-idf-valued input")
         self.csr = dict(
             indptr=torch.from_numpy(m.indptr.astype(np.int64)).to(dev),
             indices=torch.from_numpy(m.indices.astype(np.int32)).to(dev),
@@ -100,6 +106,8 @@ class Engine:
         return self.csr
 
     def upload_dense(self, a):
+        if self.x3:
+            raise ValueError("precision='bf16x3' supports CSR input only (the dense-ndarray encode GEMM has no split operands yet)")
         a = np.ascontiguousarray(a, dtype=np.float32)
         assert a.shape[1] == self.F
         self.dense = torch.from_numpy(a).to(self.device)
