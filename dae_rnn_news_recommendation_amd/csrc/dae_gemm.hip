@@ -9,7 +9,10 @@
 //   decode   z2   = h       . W^T       A = h  [Bp x Hp]        Bt = W_lo  [Fp x Hp]    fused loss epilogue
 //   dh       dh   = delta2  . W  + Gs.h A = [delta2 | Gs]       Bt = [W^T_lo ; h^T]     split-K slabs
 //   dW       dW   = x~^T.delta1 + delta2^T.h   A = [x~^T | delta2^T]  Bt = [delta1^T ; h^T]
-//   gram     D    = h . h^T             exact fp32 MFMA
+//   gram     D    = h . h^T             exact fp32 MFMA, or split-bf16 (K = 3 Hp: [hi|hi|lo] . [hi|lo|hi]^T)
+// A contraction walks up to GEMM_MAX_SEG = 5 K segments, each with its own operand pair and leading dimensions (seg_locate).  The
+// split-bf16 precision mode (DAE_BF16X3) uses them for x = hi + lo operands: decode (h_hi,W_hi) (h_hi,W_lo) (h_lo,W_hi); dh and dW
+// likewise, 5 segments each -- the kernels are the bf16 ones, only the segment lists and the lo images of the epilogues differ.
 //
 // Tiling (wave64, CDNA4): 128x128 output tile per 256-thread workgroup (4 waves as 2x2, each wave a
 // 64x64 sub-tile = 2x2 MFMA 32x32 accumulators = 64 AGPR/VGPR), K-tile = 128 BYTES per row (64 bf16 /
