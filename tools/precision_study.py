@@ -70,7 +70,9 @@ def batch_all(lab, h, chunk=32):
 
 
 def run(mode, data, labels, W0, steps, B, lr=0.1, alpha=1.0, seed=7):
-    """mode: dict operand -> 'f32' | 'bf16' | 'split' for h, W, d2, d1, Gs."""
+    """mode: dict operand -> 'f32' | 'bf16' | 'split' for h, W, d2, d1, Gs; a key 'op@gemm' (gemm in dec, dh, dw) overrides 'op' in that GEMM."""
+    def M(op, gemm):
+        return mode.get(f"{op}@{gemm}", mode[op])
     rng = np.random.default_rng(seed)
     N, F = data.shape
     W = torch.from_numpy(W0.copy()); bh = torch.zeros(W.shape[1]); bv = torch.zeros(F)
@@ -88,15 +90,15 @@ def run(mode, data, labels, W0, steps, B, lr=0.1, alpha=1.0, seed=7):
         h = a1 - sb
         tl, G, dw, nv = batch_all(lab, h)
         # decode on stored operands; the loss and d cost / d z2 literally (autograd over the element-wise part only)
-        z2 = (mm(h, W.t(), mode["h"], mode["W"]) + bv).requires_grad_(True)
+        z2 = (mm(h, W.t(), M("h", "dec"), M("W", "dec")) + bv).requires_grad_(True)
         y = torch.sigmoid(z2)
         row = -(x * torch.log(y + 1e-16) + (1.0 - x) * torch.log(1.0 - y + 1e-16)).sum(1)
         ae = (row * dw).sum() / (dw.sum() + 1e-16)
         (d2,) = torch.autograd.grad(ae, [z2])
         Gs = alpha * (G + G.t())
-        dh = mm(d2, W, mode["d2"], mode["W"]) + mm(Gs, h, mode["Gs"], mode["h"])
+        dh = mm(d2, W, M("d2", "dh"), M("W", "dh")) + mm(Gs, h, M("Gs", "dh"), M("h", "dh"))
         d1 = dh * a1 * (1.0 - a1)
-        dW = mm(xc.t(), d1, "f32", mode["d1"]) + mm(d2.t(), h, mode["d2"], mode["h"])
+        dW = mm(xc.t(), d1, "f32", M("d1", "dw")) + mm(d2.t(), h, M("d2", "dw"), M("h", "dw"))
         dbh = d1.sum(0) - sb * (1.0 - sb) * dh.sum(0)
         dbv = d2.sum(0)
         W -= lr * dW; bh -= lr * dbh; bv -= lr * dbv
@@ -111,6 +113,7 @@ def main():
     ap.add_argument("--features", type=int, default=10000)
     ap.add_argument("--batch", type=int, default=800)
     ap.add_argument("--threads", type=int, default=16)
+    ap.add_argument("--per-gemm", action="store_true", help="second study: which of the three GEMMs (decode, dh, dW) need their operands split")
     a = ap.parse_args()
     torch.set_num_threads(a.threads)
     data = synthetic_csr(a.rows, a.features, seed=1234).tocsr()
@@ -128,6 +131,15 @@ def main():
         for o in pair:
             m[o] = "split"
         modes["bf16, " + " + ".join(pair) + " split"] = m
+    if a.per_gemm:
+        base = dict.fromkeys(ops, "f32")
+        modes = {"all f32 (reference arithmetic)": base}
+        for gemms in (("dec",), ("dh",), ("dw",), ("dec", "dh"), ("dec", "dw"), ("dh", "dw")):
+            m = dict.fromkeys(ops, "split"); m["Gs"] = "bf16"
+            for g in gemms:                                  # these GEMMs fall back to plain bf16 operands
+                for o in ops:
+                    m[f"{o}@{g}"] = "bf16"
+            modes["split everywhere but plain bf16 in " + " + ".join(gemms)] = m
     ref = None
     for name, m in modes.items():
         t0 = time.time()
