@@ -97,7 +97,7 @@ class DenoisingAutoencoder(object):
                  dec_act_func='none', loss_func='mean_squared', num_epochs=10, batch_size=10,
                  xavier_init=1, opt='gradient_descent', learning_rate=0.01, momentum=0.5, corr_type='none',
                  corr_frac=0., verbose=True, verbose_step=5, seed=-1, alpha=1, triplet_strategy='batch_all',
-                 *, precision='bf16', rng='numpy', init_weights=None, device=None, data_parallel=False,
+                 *, precision='auto', rng='numpy', init_weights=None, device=None, data_parallel=False,
                  dp_grad_dtype='fp32', dp_mining='local', results_root='results/', plan_options=None):
         self.algo_name = algo_name
         self.model_name = model_name
@@ -133,7 +133,8 @@ class DenoisingAutoencoder(object):
         assert type(self.verbose_step) == int                      # reference :68
         assert self.verbose >= 0
         assert self.triplet_strategy in self._STRATEGIES           # reference :70
-        assert self.precision in ('bf16', 'fp32', 'bf16x3')
+        assert self.precision in ('auto', 'bf16', 'fp32', 'bf16x3')
+        self.precision_used = None if self.precision == 'auto' else self.precision    # what 'auto' resolved to (set by fit / load_model)
         assert self.rng in ('numpy', 'philox')
 
         if self.seed >= 0:
@@ -170,7 +171,7 @@ class DenoisingAutoencoder(object):
             print('---------------------------------------', file=fh)
             for k in self._PARAM_KEYS:
                 print('{}={}'.format(k, getattr(self, k)), file=fh)
-            print('precision={}'.format(self.precision), file=fh)
+            print('precision={}'.format(self.precision_used or self.precision), file=fh)
             print('rng={}'.format(self.rng), file=fh)
 
     # ------------------------------------------------------------------ model construction
@@ -183,13 +184,25 @@ class DenoisingAutoencoder(object):
             bs = max(round(n_rows * bs), 1)                         # reference utils.py:47
         return int(bs)
 
-    def _build_engine(self, n_features, max_batch, dp_world=1):
+    def _resolve_precision(self, data):
+        """precision='auto' (the default): the fastest mode that holds the reference's loss curve within 1e-4 (north star) for THIS input --
+        'bf16x3' (split-bf16 MFMA operands) where the engine supports it (CSR input whose values and corruption scale are exact in bf16,
+        e.g. the binary bag-of-words matrices of main_autoencoder.py:235), else 'fp32' (exact-fp32 MFMA).  Plain 'bf16' is faster but
+        outside that gate and must be asked for."""
+        if self.precision != 'auto':
+            return self.precision
+        from ..engine import Engine
+        scale = 1.0 - float(self.corr_frac) if self.corr_type == 'decay' else 1.0
+        return 'bf16x3' if (data is not None and Engine.supports_x3(data, scale)) else 'fp32'
+
+    def _build_engine(self, n_features, max_batch, dp_world=1, data=None):
         from ..engine import Engine                                # raises loudly without a GPU / the library
+        self.precision_used = self._resolve_precision(data)
         if self.opt not in L.OPT:
             raise ValueError("unknown optimizer %r (reference :444-475 silently builds no train step)" % (self.opt,))
         act = lambda a: a if a in ('sigmoid', 'tanh') else 'none'
         self.engine = Engine(n_features, self.n_components, max_batch,
-                             dtype=self.precision, enc_act=act(self.enc_act_func), dec_act=act(self.dec_act_func),
+                             dtype=self.precision_used, enc_act=act(self.enc_act_func), dec_act=act(self.dec_act_func),
                              loss_func=self.loss_func, opt=self.opt, learning_rate=self.learning_rate,
                              momentum=self.momentum, alpha=float(self.alpha), triplet=self._strategy_key(),
                              device=self.device, dp_world=dp_world,
@@ -232,7 +245,7 @@ class DenoisingAutoencoder(object):
 
         world, rank = self._dist()
         local_batch = -(-batch // world)
-        eng = self._build_engine(n_features, local_batch, dp_world=world)
+        eng = self._build_engine(n_features, local_batch, dp_world=world, data=train_set)
         self._exchange = None
         if self.sparse_input:
             eng.upload_csr(train_set)
@@ -433,7 +446,7 @@ class DenoisingAutoencoder(object):
                 if hi > lo:
                     eng.train_step(rows, labs, stats[b], phase=5, **plan)
                 else:
-                    eng.grad.zero_()
+                    eng.zero_grads()
                     stats[b].zero_()
                 stats[b, L.STAT_TRIPLET] = tl; stats[b, L.STAT_FRACTION] = fr; stats[b, L.STAT_NUM] = num
                 self._exchange.step(grad_scale=1.0, grad_ready_after_dw=hi > lo)
@@ -452,9 +465,7 @@ class DenoisingAutoencoder(object):
                     else:
                         untouched = True
                 else:
-                    eng.grad.zero_()
-                    if getattr(eng, "grad_lo", None) is not None:
-                        eng.grad_lo.zero_()
+                    eng.zero_grads()
                     stats[b].zero_()
                 # reduce-scatter (beside the step tail when the gradient is untouched) -> sharded optimizer -> all-gather -> unpack
                 self._exchange.step(grad_scale=1.0 / world, grad_ready_after_dw=untouched)
@@ -512,6 +523,13 @@ class DenoisingAutoencoder(object):
             print()
         self.history.append(rec)
 
+    def _forward_precision(self, data):
+        """Precision of a forward-only engine over `data` (validation): the training precision where the engine supports it for this
+        input, else fp32."""
+        from ..engine import Engine
+        p = self.precision_used or self._resolve_precision(data)
+        return p if (p != 'bf16x3' or Engine.supports_x3(data)) else 'fp32'
+
     def _validation_forward(self, validation_set, validation_set_label):
         """Forward pass of the whole validation set as ONE batch, uncorrupted (reference :300-312)."""
         import torch
@@ -520,7 +538,7 @@ class DenoisingAutoencoder(object):
         nv, F = validation_set.shape
         if getattr(self, '_val_engine', None) is None or self._val_engine.Bmax < nv:
             act = lambda a: a if a in ('sigmoid', 'tanh') else 'none'
-            self._val_engine = Engine(F, self.n_components, nv, dtype=self.precision, enc_act=act(self.enc_act_func),
+            self._val_engine = Engine(F, self.n_components, nv, dtype=self._forward_precision(validation_set), enc_act=act(self.enc_act_func),
                                       dec_act=act(self.dec_act_func), loss_func=self.loss_func, opt='gradient_descent',
                                       alpha=float(self.alpha), triplet=self._strategy_key(), device=self.device)
             if isinstance(validation_set, np.ndarray):

@@ -55,7 +55,7 @@ class DenoisingAutoencoderTriplet(DenoisingAutoencoder):
         self.n_components = int(np.floor(n_features / self.compress_factor))
         batch = self._resolve_batch(N)
         stacked = self._stack(train_set)                    # rows [0,N) org, [N,2N) pos, [2N,3N) neg
-        eng = self._build_engine(n_features, 3 * batch)
+        eng = self._build_engine(n_features, 3 * batch, data=stacked)
         eng.upload_csr(stacked) if self.sparse_input else eng.upload_dense(stacked)
         eng.set_params(*self._initial_parameters(n_features))
         if restore_previous_model:
@@ -132,7 +132,7 @@ class DenoisingAutoencoderTriplet(DenoisingAutoencoder):
         nv = validation_set['org'].shape[0]
         if getattr(self, '_val_engine', None) is None:
             act = lambda a: a if a in ('sigmoid', 'tanh') else 'none'
-            self._val_engine = Engine(stacked.shape[1], self.n_components, 3 * nv, dtype=self.precision, enc_act=act(self.enc_act_func),
+            self._val_engine = Engine(stacked.shape[1], self.n_components, 3 * nv, dtype=self._forward_precision(stacked), enc_act=act(self.enc_act_func),
                                       dec_act=act(self.dec_act_func), loss_func=self.loss_func, opt='gradient_descent',
                                       alpha=float(self.alpha), triplet='explicit', device=self.device)
             self._val_engine.upload_dense(stacked) if isinstance(stacked, np.ndarray) else self._val_engine.upload_csr(stacked)

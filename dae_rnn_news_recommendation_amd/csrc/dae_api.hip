@@ -463,19 +463,23 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     // phase 0 / 3 in bf16 mode: the optimizer runs in the dW GEMM's epilogue (phase 3 does not materialise the W gradient);
     // phase 1 / 5 (data parallel) in bf16 mode: the same kernel in its gradient-only form when the shape fits it
     const bool apply_now = (s->phase == 0 || s->phase == 3);
-    const bool fuse_opt = backward && apply_now && dt == DAE_BF16 && p->fuse_opt_ok;
+    const bool fuse_opt0 = backward && apply_now && dt == DAE_BF16 && p->fuse_opt_ok;
     // binary CSR + bf16 + the fused sparse encode: x~^T is a BIT image (1.1 MB) from which the dW kernel's producer waves build the
     // A tiles of its x~^T.delta1 segment in LDS; otherwise the dense x~^T image (18 MB, scattered / un-scattered every step) is streamed
     const bool src_binary = s->c_indptr ? !s->c_values : (p->b.indptr && !p->b.values);
-    const bool dw_pc_grad = backward && !apply_now && dt == DAE_BF16 && p->fuse_opt_ok && dw_bits_fits(Fp, Hp, Bp);
+    const bool x3 = p->x3;
+    // split-bf16 mode: the fused dW + optimizer kernel exists for shapes of at most one 160 x 128 tile per CU; larger shapes (and the
+    // data-parallel gradient-only phases) take the N-segment dW GEMM to memory + the optimizer kernel that writes all four shadows
+    const bool fuse_opt = fuse_opt0 && (!x3 || dw_x3_fits(Fp, Hp, Bp));
+    const bool dw_pc_grad = backward && !apply_now && dt == DAE_BF16 && !x3 && p->fuse_opt_ok && dw_bits_fits(Fp, Hp, Bp);
     const bool dw_bits = p->dw_bits_ok && use_sparse && src_binary && backward && dt == DAE_BF16 && (fuse_opt || dw_pc_grad) &&
                            dw_bits_fits(Fp, Hp, Bp);
-    const bool x3 = p->x3;
     if (x3) {
-        // split-bf16 mode, first cut: CSR input encoded from the fp32 master weights (h is fp32-accurate and its hi / lo images come from
-        // the same launch), single-GPU phases; x~ must be exact in bf16 (binary data, or values with <= 8 significant bits)
+        // split-bf16 mode: CSR input encoded from the fp32 master weights (h is fp32-accurate and its hi / lo images come from the same
+        // launch); x~ must be exact in bf16 (binary data, or values with <= 8 significant bits).  Every phase: the data-parallel
+        // exchange of this mode moves fp32 gradients and fp32 master rows (dp.ShardedExchange), so the master is current on every rank
         DAE_CHECK_ARG(use_sparse && p->enc_w32_ok, "train_step: split-bf16 mode needs CSR input and the fp32-master sparse encode");
-        DAE_CHECK_ARG(!ext_mine && (s->phase == 0 || s->phase == 2 || s->phase == 3), "train_step: split-bf16 mode supports phases 0, 2, 3 (no data-parallel split yet)");
+        DAE_CHECK_ARG(!p->b.grad_lo, "train_step: split-bf16 mode exchanges fp32 gradients (no bf16 gradient image)");
         DAE_CHECK_ARG(!dw_bits, "train_step: split-bf16 mode streams the dense x~^T image (option dw_bits off)");
         {   // the corruption's scale factor multiplies every entry of x~^T: it must be exact in bf16 as well (1.0 for masking noise)
             uint32_t u; memcpy(&u, &s->scale, 4);
@@ -715,10 +719,9 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
 
 extern "C" int dae_plan_apply(dae_plan* p, int32_t adam_t, float grad_scale, void* stream) {
     DAE_CHECK_ARG(p && p->bound, "plan_apply: plan not bound");
-    DAE_CHECK_ARG(!p->x3, "plan_apply: split-bf16 mode has no data-parallel path yet");
     const float lr = plan_lr(p, adam_t);
-    return dae_opt_step(p->cfg.opt, lr, p->cfg.momentum, grad_scale, p->b.W, p->b.bh, p->b.bv, p->b.grad, p->b.opt_s1, p->b.opt_s2,
-                        p->Fp, p->Hp, p->cfg.dtype, p->b.W_lo, p->b.Wt_lo, /*apply=*/1, stream);
+    return launch_opt_step(p->cfg.opt, lr, p->cfg.momentum, grad_scale, p->b.W, p->b.bh, p->b.bv, p->b.grad, p->b.opt_s1, p->b.opt_s2,
+                           p->Fp, p->Hp, p->cfg.dtype, p->b.W_lo, p->b.Wt_lo, p->x3 ? p->W_lo2 : nullptr, p->x3 ? p->Wt_lo2 : nullptr, /*apply=*/1, stream);
 }
 
 // Data-parallel second half with a SHARDED optimizer: this rank owns rows [f0, f1) of W.  grad_rows holds the
@@ -727,7 +730,8 @@ extern "C" int dae_plan_apply(dae_plan* p, int32_t adam_t, float grad_scale, voi
 // call dae_plan_refresh_wt.
 extern "C" int dae_plan_apply_rows(dae_plan* p, int32_t adam_t, float grad_scale, const float* grad_rows, int32_t f0, int32_t f1,
                                    int32_t update_bias, void* stream) {
-    DAE_CHECK_ARG(!p || !p->x3, "plan_apply_rows: split-bf16 mode has no data-parallel path yet");
+    // split-bf16 mode: only the fp32 master rows (and their hi image) are current afterwards; the caller all-gathers the MASTER rows and
+    // rebuilds all four shadows with dae_plan_sync_shadows (dp.ShardedExchange)
     DAE_CHECK_ARG(p && p->bound && grad_rows, "plan_apply_rows: plan not bound / null gradient");
     DAE_CHECK_ARG(f0 >= 0 && f0 <= f1 && f1 <= p->Fp && f0 % 64 == 0 && f1 % 64 == 0, "plan_apply_rows: rows [%d, %d) outside [0, %d] or not multiples of 64", f0, f1, p->Fp);
     const float lr = plan_lr(p, adam_t);

@@ -1901,6 +1901,12 @@ bool dw_bits_fits(int M, int N, int Bp) {
     return N % BN == 0 && Bp % 64 == 0 && Bp / 64 <= DWB_MAXKT && 8 * per * tiles_n <= g_cus && g_dw_pc != 0;
 }
 
+bool dw_x3_fits(int M, int N, int Bp) {
+    if (gemm_init()) return false;
+    const int tiles_m = (M + DW_BM - 1) / DW_BM, tiles_n = N / BN, per = (tiles_m + 7) / 8;
+    return N % BN == 0 && Bp % 64 == 0 && 8 * per * tiles_n <= g_cus && g_dw_pc != 0;
+}
+
 int launch_dw_opt(int M, int N, const void* A0, int64_t lda0, const void* Bt0, int64_t ldb0, int K0, const void* A1, int64_t lda1,
                   const void* Bt1, int64_t ldb1, int K1, const OptEpi& e, hipStream_t st, const DwBitsArgs* xa) {
     GemmParams p;
@@ -2302,6 +2308,10 @@ void set_use_glds(int nst) {
     if (nst == -5) { g_dw_pc = 2; return; }          // tests: the 160 x 128 kernel for every grid that fits one round
     if (nst == -6) { g_w8 = 0; return; }             // A/B: never the 256 x 256 / 8-MFMA-wave kernel
     if (nst == -7) { g_w8 = 1; return; }
+    if (nst <= -1000) {                              // tests: pretend the device has (-nst - 1000) compute units, so that every CU-count-keyed
+        if (gemm_init() == 0) g_cus = -nst - 1000;   // dispatch (one-round kernels, label riders, 256 x 256 slices) is exercised on any box
+        return;
+    }
     g_nst = nst;
 }
 

@@ -130,6 +130,7 @@ struct DwBitsArgs {
     float scale;                         // value of a kept entry
 };
 bool dw_bits_fits(int M, int N, int Bp);
+bool dw_x3_fits(int M, int N, int Bp);       // split-bf16 mode: can launch_dw_opt_n (one 160 x 128 tile per CU, whole 64-deep K tiles) run the shape?
 // xa != NULL: segment 0 is x~^T (bit image, A0 ignored) . Bt0 = delta1^T; segment 1 = delta2^T . h^T as usual
 int launch_dw_opt(int M, int N, const void* A0, int64_t lda0, const void* Bt0, int64_t ldb0, int K0, const void* A1, int64_t lda1,
                   const void* Bt1, int64_t ldb1, int K1, const OptEpi& e, hipStream_t st, const DwBitsArgs* xa = nullptr);

@@ -137,11 +137,18 @@ class ShardedExchange:
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
         assert eng.dp_world == self.world, "create the Engine with dp_world = world size (%d != %d)" % (eng.dp_world, self.world)
         assert grad_dtype in ("fp32", "bf16")
+        # split-bf16 mode (precision='bf16x3'): the 1e-4 curve needs fp32 gradients in the exchange and fp32-accurate weights in the
+        # encode, so this mode reduce-scatters fp32, updates its rows of the fp32 master and all-gathers the MASTER rows (the same
+        # bytes as the hi + lo bf16 images would be); every rank then rebuilds its four low-precision images locally
+        self.x3 = bool(getattr(eng, "x3", False))
+        if self.x3:
+            grad_dtype, packed, overlap = "fp32", False, False
         self.grad_dtype = grad_dtype
         self.packed = bool(packed)
         # only the bf16 shadow W_lo is all-gathered: the fp32 masters of the rows another rank owns are stale here, so the sparse
         # encode must read W_lo (single-GPU bf16 steps read the fp32 master, option encode_w32)
-        eng.set_option("encode_w32", 0)
+        if not self.x3:
+            eng.set_option("encode_w32", 0)
         c, Hp = eng.chunk_rows, eng.Hp
         self.f0 = min(eng.Fp, self.rank * c)
         self.f1 = min(eng.Fp, (self.rank + 1) * c)
@@ -166,6 +173,7 @@ class ShardedExchange:
                 self._side = torch.cuda.Stream(device=eng.device)
                 self._ev_dw = torch.cuda.Event(); self._ev_rs = torch.cuda.Event()
         self._pending = None
+        self._my_w = None
 
     def _reduce_scatter(self, gw):
         torch, dist, eng = self.torch, self.dist, self.eng
@@ -230,13 +238,24 @@ class ShardedExchange:
             self._ev[1].record()
         eng.adam_t += 1 if eng.opt == "adam" else 0
         eng.apply_rows(self.rs_f32, self.f0, self.f1, grad_scale=grad_scale, update_bias=True)
-        self.my_lo.copy_(eng.W_lo_full[self.rank * c:(self.rank + 1) * c])
-        if self._ev:
-            self._ev[2].record()
-        dist.all_gather_into_tensor(eng.W_lo_full.view(-1), self.my_lo.view(-1))
-        if self._ev:
-            self._ev[3].record()
-        eng.refresh_wt()
+        if self.x3:
+            if self._my_w is None:
+                self._my_w = torch.zeros((c, Hp), dtype=torch.float32, device=eng.device)
+            self._my_w.copy_(eng.W_full[self.rank * c:(self.rank + 1) * c])
+            if self._ev:
+                self._ev[2].record()
+            dist.all_gather_into_tensor(eng.W_full.view(-1), self._my_w.view(-1))
+            if self._ev:
+                self._ev[3].record()
+            eng.sync_shadows()
+        else:
+            self.my_lo.copy_(eng.W_lo_full[self.rank * c:(self.rank + 1) * c])
+            if self._ev:
+                self._ev[2].record()
+            dist.all_gather_into_tensor(eng.W_lo_full.view(-1), self.my_lo.view(-1))
+            if self._ev:
+                self._ev[3].record()
+            eng.refresh_wt()
         self.steps += 1
         if self._ev:
             self._pending = True
@@ -251,6 +270,8 @@ class ShardedExchange:
     def gather_master(self):
         """Full fp32 W on every rank (each rank contributes the rows it owns)."""
         torch, dist, eng = self.torch, self.dist, self.eng
+        if self.x3:
+            return                      # every step all-gathers the master rows: W is already current everywhere
         c, Hp = eng.chunk_rows, eng.Hp
         mine = torch.zeros((c, Hp), dtype=torch.float32, device=eng.device)
         if self.f1 > self.f0:

@@ -51,14 +51,16 @@ class Engine:
         self.chunk_rows = -(-self.Fp // (64 * self.dp_world)) * 64
         self.rows_alloc = self.chunk_rows * self.dp_world
         self.n_flat = n_flat
-        self.W = torch.zeros((self.Fp, self.Hp), dtype=torch.float32, device=dev)
+        # (split-bf16 mode under data parallel all-gathers the fp32 MASTER rows: W is over-allocated to whole chunks like W_lo)
+        self.W_full = torch.zeros((self.rows_alloc if self.x3 else self.Fp, self.Hp), dtype=torch.float32, device=dev)
+        self.W = self.W_full[:self.Fp]
         self.bh = torch.zeros(self.Hp, dtype=torch.float32, device=dev)
         self.bv = torch.zeros(self.Fp, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(max(n_flat, self.rows_alloc * self.Hp), dtype=torch.float32, device=dev)
         # data parallel with a bf16 exchange (dp_grad_dtype='bf16'): the dW kernel writes the W gradient as bf16 straight into
         # this image (dae_buffers.grad_lo) in phase 1 / 5 steps; the bias gradients stay in `grad`
         self.grad_lo = None
-        if grad_lo and self.dtype == L.BF16:
+        if grad_lo and self.dtype == L.BF16 and not self.x3:       # split-bf16 mode exchanges fp32 gradients
             self.grad_lo = torch.zeros((self.rows_alloc, self.Hp), dtype=torch.bfloat16, device=dev)
         self.s1 = self.s2 = None
         if opt == "ada_grad":
@@ -104,6 +106,20 @@ class Engine:
         self.dense = None
         self._bind()
         return self.csr
+
+    @staticmethod
+    def supports_x3(data, scale=1.0):
+        """Can precision='bf16x3' run this train set?  CSR input whose stored values -- and the corruption's scale factor -- are exact
+        in bf16 (x~ / x~^T are single bf16 images in that mode)."""
+        if isinstance(data, np.ndarray) or data is None:
+            return False
+        def exact(v):
+            v = np.ascontiguousarray(v, dtype=np.float32)
+            return bool(np.all((v.view(np.uint32) & 0xffff) == 0))
+        vals = getattr(data, "data", None)
+        if vals is None:
+            return False
+        return exact(np.asarray([scale])) and (vals.size == 0 or exact(vals))
 
     def upload_dense(self, a):
         if self.x3:
@@ -235,6 +251,16 @@ class Engine:
         """After the all-gather of the packed chunks: W_lo, Wt_lo and the biases (rank-ordered sum of the gathered bias gradients)."""
         L.check(self.lib.dae_plan_dp_unpack(self.plan, L.ptr(recv), int(world), int(self.chunk_rows), int(chunk_stride), int(bias_off),
                                             self.adam_t, float(grad_scale), L.current_stream()), "dae_plan_dp_unpack")
+
+    def sync_shadows(self):
+        """Rebuild every low-precision image of W (W_lo, Wt_lo and, in split-bf16 mode, their lo parts) from the fp32 master."""
+        L.check(self.lib.dae_plan_sync_shadows(self.plan, L.current_stream()), "dae_plan_sync_shadows")
+
+    def zero_grads(self):
+        """An empty shard contributes nothing to the exchange: clear the flat gradient AND its bf16 exchange image."""
+        self.grad.zero_()
+        if self.grad_lo is not None:
+            self.grad_lo.zero_()
 
     def refresh_wt(self):
         L.check(self.lib.dae_plan_refresh_wt(self.plan, L.current_stream()), "dae_plan_refresh_wt")

@@ -28,3 +28,29 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+# ---- fault hunting (tools/r04_guard.sh): both knobs are test infrastructure, off unless the environment asks --------------------
+# DAE_GUARD_ALLOC=end|start : every torch device tensor gets its own mapping with unmapped address space on both sides
+#                             (tools/guard_alloc.cpp), so an out-of-bounds access of a kernel faults on every box
+# DAE_FORCE_CUS=n           : the GEMM dispatch believes the device has n compute units (dae_set_glds(-1000 - n))
+def _install_guard_allocator():
+    mode = os.environ.get("DAE_GUARD_ALLOC")
+    if not mode:
+        return
+    import torch
+    so = os.path.join(ROOT, "tools", "libguard_alloc.so")
+    alloc = torch.cuda.memory.CUDAPluggableAllocator(so, "guard_malloc", "guard_free")
+    torch.cuda.memory.change_current_allocator(alloc)
+
+
+_install_guard_allocator()
+
+
+@pytest.fixture(autouse=True, scope="session")
+def _force_cus():
+    n = os.environ.get("DAE_FORCE_CUS")
+    if n and _has_gpu():
+        from dae_rnn_news_recommendation_amd import _lib
+        _lib.load().dae_set_glds(-1000 - int(n))
+    yield
