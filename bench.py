@@ -81,7 +81,9 @@ def parse():
     ap.add_argument("--compress-factor", type=int, default=0)
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--strategy", default="", choices=["", "batch_all", "batch_hard", "none"])
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3"])
+    ap.add_argument("--precision", default="auto", choices=["auto", "bf16x3", "fp32", "bf16"],
+                    help="auto (default) = what DenoisingAutoencoder(precision='auto') resolves to for the config's input: the fastest mode that "
+                         "holds the reference's loss curve within 1e-4 (the split-bf16 mode bf16x3); bf16 is faster but outside that gate")
     ap.add_argument("--rng", default="philox", choices=["philox", "numpy"])
     ap.add_argument("--grad-dtype", default=None, choices=["fp32", "bf16"],
                     help="N>1: element type of the reduce-scattered W gradient (default: the compute precision -- bf16 steps exchange the bf16 "
@@ -108,6 +110,9 @@ def parse():
     if a.strategy:
         c["strategy"] = a.strategy
     a.cfg = c
+    a.precision_asked = a.precision
+    if a.precision == "auto":      # what DenoisingAutoencoder(precision='auto') resolves to (Engine.supports_x3: every input kind)
+        a.precision = "bf16x3"
     if a.grad_dtype is None:
         a.grad_dtype = "bf16" if a.precision == "bf16" else "fp32"
     return a
@@ -363,9 +368,16 @@ def kernel_table(a, prof, nsteps):
         hbm["encode_gemm"] = B * nnz_row * 8.0 + F * H * es + B * H * (4 + 3 * es)
     # the GEMM kernels that also stream whole operands / results once: their minimum HBM bytes per launch.  Whichever floor is the
     # longer one (bytes / 8 TB/s against FLOP / MFMA peak) is the roofline that binds the kernel; both fractions are reported
-    hbm_alt = {"dw_gemm": 2.0 * F * B * es + 2.0 * H * B * es + 2 * F * H * 4.0 + 2.0 * F * H * es,   # x~^T, delta2^T, delta1^T, h^T; W read + write; shadows
-               "decode_loss": B * H * es + F * H * es + 2.0 * B * F * es + (B * F / 8.0 if not dense_in else B * F * es),   # h, W_lo; delta2 twice; x
-               "dh_gemm": B * F * es + F * H * es}                                                     # delta2, Wt_lo (+ the slabs, unknown split count)
+    # split-bf16 mode: every stored operand of the three gradient GEMMs exists as a hi and a lo bf16 image (x~^T alone is exact) -> `im` images
+    im = 2.0 if a.precision == "bf16x3" else 1.0
+    hbm_alt = {"dw_gemm": F * B * es + im * F * B * es + im * 2.0 * H * B * es + 2 * F * H * 4.0 + im * 2.0 * F * H * es,   # x~^T; delta2^T; delta1^T, h^T; W read + write; shadows
+               "decode_loss": im * B * H * es + im * F * H * es + im * 2.0 * B * F * es + (B * F / 8.0 if not dense_in else B * F * es),   # h, W_lo; delta2 twice; x
+               "dh_gemm": im * B * F * es + im * F * H * es}                                            # delta2, Wt_lo (+ the slabs, unknown split count)
+    # SURVEY 8(d)'s own minimum ("y / delta2: 0 if fused", the CSR batch instead of a dense x~^T image): what an ideal fusion would move
+    x_bytes = B * F * 4.0 if dense_in else B * nnz_row * 8.0
+    strict = {"dw_gemm": 2 * F * H * 4.0 + im * 2.0 * F * H * es + x_bytes + 2.0 * B * H * 4.0,      # W read + write, shadows, x~ batch, h / delta1
+              "decode_loss": im * F * H * es + B * H * 4.0 + x_bytes,                                # W_lo, h, x
+              "dh_gemm": im * F * H * es + B * H * 4.0}                                              # W^T_lo, delta1 out
     peak_mfma = PEAK_F32_MFMA_TFLOPS if a.precision == "fp32" else PEAK_BF16_TFLOPS
     kern = {}
     tot = sum(ms for ms, n in prof.values())
@@ -387,6 +399,8 @@ def kernel_table(a, prof, nsteps):
             e["mfma_frac"] = e["frac"]
             e["hbm_frac"] = t_hbm / (us * 1e-6)
             e["min_hbm_bytes"] = hbm_alt[k]
+            e["strict_hbm_bytes"] = strict[k]
+            e["strict_hbm_frac"] = strict[k] / (PEAK_HBM_GBS * 1e9) / (us * 1e-6)
             if t_hbm > t_mfma:        # the byte floor is the longer one: price the kernel against HBM
                 e.update(bound="hbm", achieved=hbm_alt[k] / (us * 1e-6) / 1e9, peak=PEAK_HBM_GBS, unit="GB/s", frac=e["hbm_frac"])
         kern[k] = e
@@ -447,6 +461,13 @@ def main():
 
     dt = timed_steps(run, a.steps, a.warmup)
     last = run.stats.cpu().numpy()
+    # the driver's K can make a 3 ms timed region: repeat the same loop over >= 50 ms and report it beside `value`
+    long_run = None
+    k2 = int(np.ceil(0.06 / max(dt / a.steps, 1e-6)))
+    if k2 > a.steps:
+        dt2 = timed_steps(run, k2, 0)
+        long_run = {"steps": k2, "seconds": dt2, "value": k2 * c["batch"] * world / dt2, "ms_per_step": 1e3 * dt2 / k2,
+                    "note": "the same step loop timed over >= 50 ms (`value` is over exactly --steps steps, as the contract asks)"}
     value = a.steps * c["batch"] * world / dt
     H = c["features"] // c["cf"]
 
@@ -456,8 +477,10 @@ def main():
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
         "fit": None,          # filled below: the same workload through DenoisingAutoencoder.fit() (timed over ~0.1 s; the sturdier figure)
-        "fp32": None,         # filled below: the same K steps in the reference's own arithmetic (precision='fp32', exact-fp32 MFMA)
-        "bf16x3": None,       # filled below: the same K steps in split-bf16 mode (holds the 1e-4 curve gate at bf16 MFMA speed / 3)
+        "long_run": long_run,
+        "precision_note": ("`value`, `kernels`, `roofline` are measured in precision=%r -- %s; the other modes are the objects `bf16x3` / `fp32` / `bf16` "
+                           "below, `bf16` being faster but outside the 1e-4 gate" % (a.precision, "what precision='auto' (the product default) resolves to for "
+                           "this input: the fastest mode that holds the reference's loss curve within 1e-4" if a.precision_asked == "auto" else "as asked")),
         "config": {"workload": f"{a.config} = BASELINE.json {c['baseline']}; per GPU: synthetic {c['rows']}x{c['features']} {c['kind']}, "
                                f"compress_factor {c['cf']} (H={H}), B={c['batch']}" + (" triplets (3 row blocks)" if c["strategy"] == "explicit" else "")
                                + f", strategy {c['strategy']}, masking 0.3, {c['loss']}, SGD lr 0.1, {a.precision} MFMA operands + fp32 "
@@ -555,6 +578,15 @@ def main():
                 extra["mfma_frac"] = e["mfma_frac"]; extra["hbm_frac"] = e["hbm_frac"]
             out["roofline"] = {"kernel": what, "bound": e["bound"], "achieved": e["achieved"], "peak": e["peak"], "unit": e["unit"],
                                "frac": e["frac"], "traffic": traffic, "traffic_source": src, "algorithmic": alg, **extra}
+            if "strict_hbm_bytes" in e:
+                out["roofline_strict"] = {"kernel": key, "bound": "hbm", "bytes": e["strict_hbm_bytes"], "frac": e["strict_hbm_frac"], "peak": PEAK_HBM_GBS,
+                                          "unit": "GB/s", "achieved": e["strict_hbm_bytes"] / (e["avg_us"] * 1e-6) / 1e9,
+                                          "note": "SURVEY 8(d)'s own byte list for this kernel (master weights read + written, shadows written, the CSR batch "
+                                                  "and h / delta1; delta2 / delta2^T counted as 0 'if fused', no dense x~^T image): the distance to `roofline` is "
+                                                  "what the current data flow still moves through HBM"}
+        longest = max(kern.items(), key=lambda kv: kv[1]["avg_us"] * kv[1]["launches_per_step"])
+        out["longest_kernel"] = {"slot": longest[0], "avg_us": longest[1]["avg_us"], "time_share": longest[1]["time_share"],
+                                 "frac": longest[1].get("frac"), "bound": longest[1].get("bound")}
     run.close()
     _log("profile pass done")
     if rank == 0 and world == 1 and not a.no_fit:
@@ -568,37 +600,31 @@ def main():
         out["fit"]["note"] = ("DenoisingAutoencoder.fit() on the same workload: N * timed epochs / wall, first epoch excluded; rng=numpy is the "
                               "reference-exact legacy stream (keep decisions drawn one epoch ahead on a feeder thread)")
     _log("fit legs done")
-    if rank == 0 and world == 1 and a.precision == "bf16" and not a.no_fp32:
+    if rank == 0 and world == 1 and not a.no_fp32:
+        # the same K steps in the other precision modes (never allowed to take the bench line down with them)
         import copy
-        a32 = copy.copy(a); a32.precision = "fp32"
-        run32 = Runner(a32, rank, world)
-        dt32 = timed_steps(run32, a.steps, a.warmup)
-        l32 = run32.stats.cpu().numpy()
-        run32.close()
-        out["fp32"] = {"value": a.steps * c["batch"] / dt32, "unit": "samples/s", "ms_per_step": 1e3 * dt32 / a.steps, "steps": a.steps,
-                       "final_cost": float(l32[:, 0].mean()),
-                       "note": "precision='fp32': exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), the reference's arithmetic; holds the 1e-4 "
-                               "loss-curve gate on every config (tests/test_hip_full_curve.py); peak 157 TFLOP/s = 1/16 of bf16"}
-        del run32
-        _log("fp32 leg done")
-        # split-bf16 leg (precision='bf16x3'): bf16 MFMA at three products per operand pair -- the fast mode that HOLDS the 1e-4 curve gate.
-        # CSR configs with label-mined or no triplets (the validated paths); never allowed to take the bench line down with it
-        if c["kind"] != "dense_tfidf" and c["strategy"] in ("batch_all", "batch_hard", "none"):
+        notes = {
+            "fp32": "precision='fp32': exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), the reference's arithmetic; holds the 1e-4 loss-curve gate on "
+                    "every config (tests/test_hip_full_curve.py); peak 157 TFLOP/s = 1/16 of bf16",
+            "bf16x3": "precision='bf16x3': every stored operand of the decode / dh / dW GEMMs as hi + lo bf16, products (hi,hi) + (hi,lo) + (lo,hi); "
+                      "holds the 1e-4 loss-curve gate on all 20 steps of the full-shape curve (tests/test_hip_full_curve.py)",
+            "bf16": "precision='bf16': plain bf16 MFMA operands -- FASTER BUT OUTSIDE the north star's 1e-4 loss-curve gate (cost <= 2.8e-4, triplet <= "
+                    "6.8e-3 over the 20-step curve, profiles/r03_bf16_curve.txt); reported for reference, never the headline"}
+        for mode in ("bf16x3", "fp32", "bf16"):
+            if mode == a.precision:
+                continue
             try:
-                a3 = copy.copy(a); a3.precision = "bf16x3"
-                run3 = Runner(a3, rank, world)
-                dt3 = timed_steps(run3, a.steps, a.warmup)
-                l3 = run3.stats.cpu().numpy()
-                run3.close()
-                del run3
-                out["bf16x3"] = {"value": a.steps * c["batch"] / dt3, "unit": "samples/s", "ms_per_step": 1e3 * dt3 / a.steps, "steps": a.steps,
-                                 "final_cost": float(l3[:, 0].mean()),
-                                 "note": "precision='bf16x3': every stored operand of the decode / dh / dW GEMMs as hi + lo bf16, products (hi,hi) + "
-                                         "(hi,lo) + (lo,hi); holds the 1e-4 loss-curve gate on all 20 steps of the full-shape curve (cost 2.8e-7, "
-                                         "triplet 5.1e-6; tests/test_hip_full_curve.py) at ~2.8x the rate of the fp32 mode"}
+                am = copy.copy(a); am.precision = mode
+                runm = Runner(am, rank, world)
+                dtm = timed_steps(runm, a.steps, a.warmup)
+                lm = runm.stats.cpu().numpy()
+                runm.close()
+                del runm
+                out[mode] = {"value": a.steps * c["batch"] / dtm, "unit": "samples/s", "ms_per_step": 1e3 * dtm / a.steps, "steps": a.steps,
+                             "final_cost": float(lm[:, 0].mean()), "holds_1e-4_gate": mode != "bf16", "note": notes[mode]}
             except Exception as ex:      # noqa: BLE001
-                out["bf16x3"] = {"error": repr(ex)[:300]}
-            _log("bf16x3 leg done")
+                out[mode] = {"error": repr(ex)[:300]}
+            _log(mode + " leg done")
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a)
         _log("cpu baseline done")

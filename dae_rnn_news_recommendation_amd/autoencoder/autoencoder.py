@@ -185,15 +185,14 @@ class DenoisingAutoencoder(object):
         return int(bs)
 
     def _resolve_precision(self, data):
-        """precision='auto' (the default): the fastest mode that holds the reference's loss curve within 1e-4 (north star) for THIS input --
-        'bf16x3' (split-bf16 MFMA operands) where the engine supports it (CSR input whose values and corruption scale are exact in bf16,
-        e.g. the binary bag-of-words matrices of main_autoencoder.py:235), else 'fp32' (exact-fp32 MFMA).  Plain 'bf16' is faster but
-        outside that gate and must be asked for."""
+        """precision='auto' (the default): the fastest mode that holds the reference's loss curve within 1e-4 (north star) -- 'bf16x3'
+        (split-bf16 MFMA operands: every stored operand of the gradient GEMMs as hi + lo bf16 images, three products each) for every
+        input kind the engine runs; 'fp32' (exact-fp32 MFMA) when there is no train set to look at (load_model).  Plain 'bf16' is faster
+        but outside that gate and must be asked for."""
         if self.precision != 'auto':
             return self.precision
         from ..engine import Engine
-        scale = 1.0 - float(self.corr_frac) if self.corr_type == 'decay' else 1.0
-        return 'bf16x3' if (data is not None and Engine.supports_x3(data, scale)) else 'fp32'
+        return 'bf16x3' if Engine.supports_x3(data) else 'fp32'
 
     def _build_engine(self, n_features, max_batch, dp_world=1, data=None):
         from ..engine import Engine                                # raises loudly without a GPU / the library

@@ -36,8 +36,8 @@ extern "C" int dae_gemm_nt(int32_t dtype, int32_t M, int32_t N, const void* A0, 
 
 extern "C" int dae_gemm_nt_n(int32_t dtype, int32_t M, int32_t N, const dae_gemm_seg* segs, int32_t nsegs, float* C, int64_t ldc,
                              int32_t splits, int64_t slab_stride, void* stream) {
-    DAE_CHECK_ARG(segs && nsegs >= 1 && nsegs <= 5, "gemm_nt_n: 1..5 K segments");
-    GemmSegDesc d[5];
+    DAE_CHECK_ARG(segs && nsegs >= 1 && nsegs <= 6, "gemm_nt_n: 1..6 K segments");
+    GemmSegDesc d[6];
     for (int i = 0; i < nsegs; ++i) d[i] = {segs[i].A, segs[i].lda, segs[i].Bt, segs[i].ldb, segs[i].K};
     return launch_gemm_f32out_n(dtype, M, N, d, nsegs, C, ldc, splits, slab_stride, (hipStream_t)stream);
 }
@@ -121,6 +121,9 @@ struct dae_plan {
     // split-bf16 mode (dae_config.dtype = DAE_BF16X3): every stored operand x of the gradient GEMMs is hi + lo, both bf16; the *_2 images are the lo parts
     bool x3;
     char *W_lo2, *Wt_lo2, *h_t2, *delta2_2, *delta2_t2, *delta1_t2;
+    char *x_2, *xct_2, *xc_2;         // ... and of the clean rows x / of x~^T / of x~ (dense input), used when the input values (or the corruption scale) are not exact in bf16
+    int s_enc3, s_dh3;               // split-K slice counts of the dense-input encode / dh GEMMs in split-bf16 mode (3 resp. 5 K segments)
+    bool xct2_clean;
     uint32_t* xtb;                   // x~^T as a bit image [Fp x Bpm/32] (binary CSR + bf16: operand of the sparse half of the dW kernel)
     bool xtb_clean;                  // the bit image holds only zeros (every step clears what it set; see step_tail_kernel)
     bool dw_bits_ok;               // option "dw_bits" = 0: dense x~^T image and a K = 2 Bp dW GEMM (A/B, equivalence tests)
@@ -168,7 +171,8 @@ static uint64_t carve(dae_plan* p, char* base) {
     p->x_bits = (uint32_t*)take(Bp * (Fp / 32) * 4);
     p->delta2 = take(Bp * Fp * es);
     p->delta2_t = take(Fp * Bp * es);
-    const int smax = p->s_enc > p->s_dh ? p->s_enc : p->s_dh;
+    int smax = p->s_enc > p->s_dh ? p->s_enc : p->s_dh;
+    if (p->x3) { if (p->s_enc3 > smax) smax = p->s_enc3; if (p->s_dh3 > smax) smax = p->s_dh3; }
     p->slabs = (float*)take((uint64_t)smax * Bp * Hp * 4);
     p->h_f32 = (float*)take(Bp * Hp * 4);
     p->h_lo = take(Bp * Hp * es);
@@ -183,6 +187,9 @@ static uint64_t carve(dae_plan* p, char* base) {
     p->delta2_2 = take(p->x3 ? Bp * Fp * 2 : 256);
     p->delta2_t2 = take(p->x3 ? Fp * Bp * 2 : 256);
     p->delta1_t2 = take(p->x3 ? Hp * Bp * 2 : 256);
+    p->x_2 = take(p->x3 ? Bp * Fp * 2 : 256);
+    p->xct_2 = take(p->x3 ? Fp * Bp * 2 : 256);
+    p->xc_2 = take(p->x3 ? Bp * Fp * 2 : 256);
     p->hcat_a = take(p->gram_split ? Bp * 3 * Hp * 2 : 256);
     p->hcat_b = take(p->gram_split ? Bp * 3 * Hp * 2 : 256);
     p->D_slabs = (float*)take((uint64_t)p->s_gram * Bp * Bp * 4);
@@ -243,6 +250,14 @@ extern "C" int dae_plan_create(const dae_config* cfg, dae_plan** out) {
     if (cfg->dh_splits <= 0) if (const int w = gemm_w8_splits(cfg->dtype, p->Bpm, p->Hp, kt_f + p->Bpm * p->es / 128)) p->s_dh = w;
     if (p->s_enc > kt_f) p->s_enc = kt_f;
     if (p->s_dh > kt_f) p->s_dh = kt_f;
+    // split-bf16 mode on dense-ndarray input: the encode contraction has 3 K segments and dh 5; the 256 x 256 kernel is taken exactly when the
+    // launch is handed ITS slice count for the real K-tile total, so these are planned with the segment lists' totals
+    p->s_enc3 = p->s_enc; p->s_dh3 = p->s_dh;
+    if (p->x3) {
+        const int kt_b = p->Bpm * p->es / 128;
+        if (cfg->encode_splits <= 0) if (const int w = gemm_w8_splits(cfg->dtype, p->Bpm, p->Hp, 3 * kt_f)) p->s_enc3 = w;
+        if (cfg->dh_splits <= 0) if (const int w = gemm_w8_splits(cfg->dtype, p->Bpm, p->Hp, 3 * kt_f + 2 * kt_b)) p->s_dh3 = w;
+    }
     if (p->s_gram > p->Hp * 4 / 128) p->s_gram = p->Hp * 4 / 128;
     p->gram_split = (cfg->dtype == DAE_BF16) && (p->x3 || cfg->triplet == DAE_TRIPLET_BATCH_ALL || cfg->triplet == DAE_TRIPLET_BATCH_HARD);   // x3: hcat_a also holds the row-major h_lo
     p->ws_bytes = carve(p, nullptr);
@@ -252,7 +267,7 @@ extern "C" int dae_plan_create(const dae_config* cfg, dae_plan** out) {
     p->label_enc_ok = true;
     p->ce_literal = false;
     p->xbits_ok = cfg->dtype == DAE_BF16;
-    p->xct_clean = false; p->xtb_clean = false;
+    p->xct_clean = false; p->xtb_clean = false; p->xct2_clean = false;
     p->dw_bits_ok = false;                             // measured slower than streaming the dense image (profiles/r03_experiments.md)
     p->enc_w32_ok = cfg->dtype == DAE_BF16;
     p->w32_cols = 128;                                 // measured: 128-column fp32 slices (5.2 MB, served by the MALL) beat 64-column ones
@@ -345,7 +360,7 @@ extern "C" int dae_plan_bind(dae_plan* p, const dae_buffers* bufs) {
     carve(p, (char*)bufs->workspace);
     p->bound = true;
     p->xct_clean = false;            // a (re)bound workspace has not been cleared: the next backward step memsets x~^T once
-    p->xtb_clean = false;
+    p->xtb_clean = false; p->xct2_clean = false;
     return 0;
 }
 
@@ -359,7 +374,7 @@ extern "C" void* dae_plan_buffer(dae_plan* p, const char* name) {
     if (!p || !p->bound || !name) return nullptr;
 #define DAE_BUF(n) if (!strcmp(name, #n)) return (void*)p->n;
     DAE_BUF(hcat_a) DAE_BUF(hcat_b) DAE_BUF(x) DAE_BUF(xc) DAE_BUF(xct) DAE_BUF(h_lo) DAE_BUF(h_t) DAE_BUF(Gs) DAE_BUF(delta2) DAE_BUF(delta2_t) DAE_BUF(delta1_t)
-    DAE_BUF(delta1_lo) DAE_BUF(xtb) DAE_BUF(W_lo2) DAE_BUF(Wt_lo2) DAE_BUF(h_t2) DAE_BUF(delta2_2) DAE_BUF(delta2_t2) DAE_BUF(delta1_t2)
+    DAE_BUF(delta1_lo) DAE_BUF(xtb) DAE_BUF(W_lo2) DAE_BUF(Wt_lo2) DAE_BUF(h_t2) DAE_BUF(delta2_2) DAE_BUF(delta2_t2) DAE_BUF(delta1_t2) DAE_BUF(x_2) DAE_BUF(xct_2) DAE_BUF(xc_2)
     DAE_BUF(slabs) DAE_BUF(h_f32) DAE_BUF(D_slabs) DAE_BUF(G) DAE_BUF(rowloss_part) DAE_BUF(dbv_part) DAE_BUF(colsum_part)
     DAE_BUF(cos_part) DAE_BUF(cos_stats) DAE_BUF(cw) DAE_BUF(loss_part) DAE_BUF(dw_f32) DAE_BUF(tri_scalars) DAE_BUF(dh_extra)
     DAE_BUF(tile_part) DAE_BUF(cnt_part) DAE_BUF(role_cnt) DAE_BUF(dw_i32) DAE_BUF(n_same) DAE_BUF(nvalid) DAE_BUF(dw_i64)
@@ -378,13 +393,19 @@ static int gather_batch(dae_plan* p, const int64_t* indptr, const int32_t* indic
                         int64_t ld_dense, const int32_t* row_idx, int B, void* x, void* xc, void* xct, float* rowsq,
                         int corr_mode, const uint32_t* keep_bits, uint64_t seed, uint32_t rng_stream, float corr_frac,
                         float scale, void* stream, uint32_t* xc_bits = nullptr, const LabelJob* label_job = nullptr,
-                        uint32_t* x_bits = nullptr) {
+                        uint32_t* x_bits = nullptr, void* x2 = nullptr) {
     if (indptr)
         return launch_gather_csr(indptr, indices, values, row_idx, B, p->F, p->cfg.dtype, x, xc, p->Fp, xct, p->Bpm, rowsq, corr_mode,
-                                 keep_bits, seed, rng_stream, corr_frac, scale, xc_bits, p->Fp / 32, label_job, (hipStream_t)stream, x_bits);
+                                 keep_bits, seed, rng_stream, corr_frac, scale, xc_bits, p->Fp / 32, label_job, (hipStream_t)stream, x_bits, x2);
     DAE_CHECK_ARG(dense, "step: no train set bound");
     return dae_gather_dense(dense, ld_dense, row_idx, B, p->F, p->cfg.dtype, x, xc, p->Fp, xct, p->Bpm, rowsq, p->rowsq_scratch,
                             corr_mode, keep_bits, seed, rng_stream, corr_frac, scale, stream);
+}
+// split-bf16 mode, dense input: the lo images of x / x~ / x~^T (a second pass over the fp32 rows with the same keep decisions)
+static int gather_dense_lo(dae_plan* p, const float* dense, int64_t ld_dense, const int32_t* row_idx, int B, void* x2, void* xc2, void* xct2,
+                           int corr_mode, const uint32_t* keep_bits, uint64_t seed, uint32_t rng_stream, float corr_frac, float scale, void* stream) {
+    return launch_gather_dense(dense, ld_dense, row_idx, B, p->F, p->cfg.dtype, x2, xc2, p->Fp, xct2, p->Bpm, nullptr, nullptr, corr_mode, keep_bits,
+                               seed, rng_stream, corr_frac, scale, stream, 1);
 }
 
 #define RC(expr) do { if (int rc__ = (expr)) return rc__; } while (0)
@@ -460,6 +481,7 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     // binary CSR train set in bf16 mode: the clean rows reach the decode epilogue as a bit image (1.1 MB, not 18 MB)
     const bool use_xbits = p->xbits_ok && p->b.indptr && !p->b.values;
     const bool use_sparse = p->sparse_ok && csr_in;
+    const bool dense_in = !csr_in && p->b.dense;
     // phase 0 / 3 in bf16 mode: the optimizer runs in the dW GEMM's epilogue (phase 3 does not materialise the W gradient);
     // phase 1 / 5 (data parallel) in bf16 mode: the same kernel in its gradient-only form when the shape fits it
     const bool apply_now = (s->phase == 0 || s->phase == 3);
@@ -478,19 +500,24 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
         // split-bf16 mode: CSR input encoded from the fp32 master weights (h is fp32-accurate and its hi / lo images come from the same
         // launch); x~ must be exact in bf16 (binary data, or values with <= 8 significant bits).  Every phase: the data-parallel
         // exchange of this mode moves fp32 gradients and fp32 master rows (dp.ShardedExchange), so the master is current on every rank
-        DAE_CHECK_ARG(use_sparse && p->enc_w32_ok, "train_step: split-bf16 mode needs CSR input and the fp32-master sparse encode");
+        DAE_CHECK_ARG((use_sparse && p->enc_w32_ok) || dense_in, "train_step: split-bf16 mode needs the fp32-master sparse encode (CSR input) or a dense train set");
         DAE_CHECK_ARG(!p->b.grad_lo, "train_step: split-bf16 mode exchanges fp32 gradients (no bf16 gradient image)");
         DAE_CHECK_ARG(!dw_bits, "train_step: split-bf16 mode streams the dense x~^T image (option dw_bits off)");
-        {   // the corruption's scale factor multiplies every entry of x~^T: it must be exact in bf16 as well (1.0 for masking noise)
-            uint32_t u; memcpy(&u, &s->scale, 4);
-            DAE_CHECK_ARG((u & 0xffffu) == 0u, "train_step: split-bf16 mode needs a corruption scale that is exact in bf16 (got %g)", (double)s->scale);
-        }
+    }
+    // split-bf16 mode with VALUED input (tf-idf, salt-and-pepper copies, decay noise's scale factor): x~ = scale * v is not exact in bf16, so
+    // x~^T and the clean rows x get lo images too (xct_2, x_2) and the dW contraction walks 6 segments; binary data with a bf16-exact scale
+    // (masking noise: 1.0) needs neither
+    bool x3_vals = false;
+    if (x3) {
+        uint32_t u; memcpy(&u, &s->scale, 4);
+        x3_vals = !src_binary || (u & 0xffffu) != 0u || (p->b.indptr && p->b.values) || dense_in;
     }
     if (!resume && backward && csr_in) {
         if (dw_bits) { if (!(tail && p->xtb_clean)) PROF(PS_MEMSET, memset_async(p->xtb, (size_t)Fp * (ldB / 32) * 4, st)); }
         else if (!(tail && p->xct_clean)) PROF(PS_MEMSET, memset_async(p->xct, (size_t)Fp * ldB * p->es, st));
+        if (x3_vals && !(tail && p->xct2_clean)) PROF(PS_MEMSET, memset_async(p->xct_2, (size_t)Fp * ldB * 2, st));
     }
-    if (backward) { if (dw_bits) p->xtb_clean = false; else p->xct_clean = false; }
+    if (backward) { if (dw_bits) p->xtb_clean = false; else p->xct_clean = false; if (x3_vals) p->xct2_clean = false; }
     const int64_t slab = (int64_t)Bp * Hp;
     int enc_label_done = 0;
     bool labels_done = ext_mine;               // label statistics already produced by a workgroup of an earlier launch (or by the caller)
@@ -506,7 +533,7 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
         if (!own_clean)
             PROF(PS_GATHER, gather_batch(p, p->b.indptr, p->b.indices, p->b.values, p->b.dense, p->b.ld_dense, s->row_idx, B,
                             use_xbits ? nullptr : p->x, nullptr, nullptr, rowsq, DAE_CORR_NONE, nullptr, 0, 0, 0.f, 1.f, stream, nullptr, nullptr,
-                            use_xbits ? p->x_bits : nullptr));
+                            use_xbits ? p->x_bits : nullptr, (x3 && !use_xbits && p->b.values) ? p->x_2 : nullptr));
         EncCsrLaunch q;
         memset(&q, 0, sizeof(q));
         q.indptr = s->c_indptr ? s->c_indptr : p->b.indptr; q.indices = s->c_indptr ? s->c_indices : p->b.indices;
@@ -520,6 +547,7 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
         q.xtb = (backward && dw_bits) ? p->xtb : nullptr; q.ldxt = ldB / 32;
         q.rowsq = own_clean ? rowsq : nullptr;
         q.h_t2 = x3 ? p->h_t2 : nullptr;
+        q.xct2 = (x3_vals && backward) ? p->xct_2 : nullptr;
         q.label_job = label_with_encode ? &lj : nullptr;
         PROF(PS_ENC_GEMM, launch_encode_csr(q, st));
         labels_done = label_with_encode;
@@ -537,15 +565,23 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
                             s->seed, s->rng_stream, s->corr_frac, s->scale, stream, use_bits ? p->xc_bits : nullptr, label_in_gather ? &lj : nullptr,
                             use_xbits ? p->x_bits : nullptr));
         }
+        if (x3 && dense_in)
+            PROF(PS_GATHER, gather_dense_lo(p, p->b.dense, p->b.ld_dense, s->row_idx, B, p->x_2, p->xc_2, backward ? p->xct_2 : nullptr, s->corr_mode,
+                                            s->keep_bits, s->seed, s->rng_stream, s->corr_frac, s->scale, stream));
         // 3-4. encode (K1/K2)
-        if (use_bits)
+        if (x3 && dense_in) {     // z1 = x~ W as (x~_hi, W^T_hi) (x~_hi, W^T_lo) (x~_lo, W^T_hi)
+            const GemmSegDesc es3[3] = {{p->xc, Fp, p->b.Wt_lo, Fp, Fp}, {p->xc, Fp, p->Wt_lo2, Fp, Fp}, {p->xc_2, Fp, p->b.Wt_lo, Fp, Fp}};
+            PROF(PS_ENC_GEMM, launch_gemm_f32out_n(dt, Bp, Hp, es3, 3, p->slabs, Hp, p->s_enc3, slab, st, GEMM_ROLE_ENCODE,
+                                                   label_with_encode ? &lj : nullptr, label_with_encode ? &enc_label_done : nullptr));
+        } else if (use_bits)
             PROF(PS_ENC_GEMM, launch_encode_bits(Bp, Hp, Fp, p->xc_bits, Fp / 32, p->b.Wt_lo, Fp, p->slabs, Hp, p->s_enc, slab, st,
                                                  label_with_encode ? &lj : nullptr, label_with_encode ? &enc_label_done : nullptr));
         else
             PROF(PS_ENC_GEMM, launch_gemm_f32out(dt, Bp, Hp, p->xc, Fp, p->b.Wt_lo, Fp, Fp, nullptr, 0, nullptr, 0, 0, p->slabs, Hp, p->s_enc, slab, st,
                                                  GEMM_ROLE_ENCODE, label_with_encode ? &lj : nullptr, label_with_encode ? &enc_label_done : nullptr));
-        PROF(PS_ENC_FIN, dae_encode_finish(p->slabs, p->s_enc, slab, Hp, p->b.bh, B, H, c.enc_act, dt, p->h_f32, p->h_lo, Hp, p->h_t, ldB,
-                                           p->gram_split ? p->hcat_a : nullptr, p->gram_split ? p->hcat_b : nullptr, stream));
+        PROF(PS_ENC_FIN, launch_encode_finish(p->slabs, (x3 && dense_in) ? p->s_enc3 : p->s_enc, slab, Hp, p->b.bh, B, H, c.enc_act, dt, p->h_f32, p->h_lo, Hp,
+                                              p->h_t, ldB, p->gram_split ? p->hcat_a : nullptr, p->gram_split ? p->hcat_b : nullptr,
+                                              x3 ? p->h_t2 : nullptr, stream));
         labels_done = (label_in_gather && !s->c_indptr) || enc_label_done;
     }
     if (h_only) return 0;
@@ -586,6 +622,7 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
             dsegs[2] = {p->hcat_a + (size_t)2 * Hp * 2, 3 * (int64_t)Hp, p->b.W_lo, Hp, Hp};
             ndseg = 3;
             if (backward) { e.delta2_2 = p->delta2_2; e.delta2_t2 = p->delta2_t2; }
+            if (!use_xbits && (p->b.values || dense_in)) e.x2 = p->x_2;    // valued clean rows: x = hi + lo (RES instantiations)
         }
         if (is_cos) {
             e.cos_pass = 1;
@@ -648,17 +685,21 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     if (!backward) return 0;
     // 9-10. dL/dh = delta2 W + alpha (G+G^T) h ; delta1                     (K8)
     const bool mined = !ext_mine && (c.triplet == DAE_TRIPLET_BATCH_ALL || c.triplet == DAE_TRIPLET_BATCH_HARD);
+    const int s_dh = (x3 && dense_in) ? p->s_dh3 : p->s_dh;
     if (x3) {       // (d2_hi, Wt_hi) (d2_hi, Wt_lo) (d2_lo, Wt_hi) + Gs.(h_hi + h_lo): Gs itself stays bf16 (tools/precision_study.py)
         const GemmSegDesc hs[5] = {{p->delta2, Fp, p->b.Wt_lo, Fp, Fp}, {p->delta2, Fp, p->Wt_lo2, Fp, Fp}, {p->delta2_2, Fp, p->b.Wt_lo, Fp, Fp},
                                    {p->Gs, Bp, p->h_t, ldB, mined ? Bp : 0}, {p->Gs, Bp, p->h_t2, ldB, mined ? Bp : 0}};
-        PROF(PS_DH_GEMM, launch_gemm_f32out_n(dt, Bp, Hp, hs, 5, p->slabs, Hp, p->s_dh, slab, st, GEMM_ROLE_DH));
+        PROF(PS_DH_GEMM, launch_gemm_f32out_n(dt, Bp, Hp, hs, 5, p->slabs, Hp, s_dh, slab, st, GEMM_ROLE_DH));
     } else {
         PROF(PS_DH_GEMM, launch_gemm_f32out(dt, Bp, Hp, p->delta2, Fp, p->b.Wt_lo, Fp, Fp, mined ? p->Gs : nullptr, Bp, mined ? p->h_t : nullptr, ldB,
                               mined ? Bp : 0, p->slabs, Hp, p->s_dh, slab, st, GEMM_ROLE_DH));
     }
-    PROF(PS_DH_FIN, launch_dh_finish(p->slabs, p->s_dh, slab, Hp, (explicit3 || ext_mine) ? p->dh_extra : nullptr, p->h_f32, Hp, p->b.bh, B, H, c.enc_act, dt,
+    PROF(PS_DH_FIN, launch_dh_finish(p->slabs, s_dh, slab, Hp, (explicit3 || ext_mine) ? p->dh_extra : nullptr, p->h_f32, Hp, p->b.bh, B, H, c.enc_act, dt,
                      p->delta1_t, ldB, p->colsum_part, nullptr, nullptr, st, x3 ? p->delta1_t2 : nullptr));
     // 11. dW = x~^T delta1 + delta2^T h                                      (K8, tied weights)
+    // split-bf16 segment list (K = 0 segments are skipped): the third one exists only when x~^T has a lo image
+    const GemmSegDesc ws3[6] = {{p->xct, ldB, p->delta1_t, ldB, Bp}, {p->xct, ldB, p->delta1_t2, ldB, Bp}, {p->xct_2, ldB, p->delta1_t, ldB, x3_vals ? Bp : 0},
+                                {p->delta2_t, ldB, p->h_t, ldB, Bp}, {p->delta2_t, ldB, p->h_t2, ldB, Bp}, {p->delta2_t2, ldB, p->h_t, ldB, Bp}};
     if (fuse_opt || dw_pc_grad) {
         OptEpi oe;
         memset(&oe, 0, sizeof(oe));
@@ -672,10 +713,8 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
             oe.ldw = Hp;
         }
         if (x3) {   // x~^T.(d1_hi + d1_lo) + (d2^T_hi, h^T_hi) (d2^T_hi, h^T_lo) (d2^T_lo, h^T_hi); the epilogue writes both parts of both shadows
-            const GemmSegDesc ws[5] = {{p->xct, ldB, p->delta1_t, ldB, Bp}, {p->xct, ldB, p->delta1_t2, ldB, Bp}, {p->delta2_t, ldB, p->h_t, ldB, Bp},
-                                       {p->delta2_t, ldB, p->h_t2, ldB, Bp}, {p->delta2_t2, ldB, p->h_t, ldB, Bp}};
             oe.W_lo2 = p->W_lo2; oe.Wt_lo2 = p->Wt_lo2;
-            PROF(PS_DW_GEMM, launch_dw_opt_n(Fp, Hp, ws, 5, oe, st));
+            PROF(PS_DW_GEMM, launch_dw_opt_n(Fp, Hp, ws3, 6, oe, st));
         } else if (dw_bits) {
             DwBitsArgs xa{p->xtb, ldB / 32, s->scale};
             PROF(PS_DW_GEMM, launch_dw_opt(Fp, Hp, nullptr, ldB, p->delta1_t, ldB, Bp, p->delta2_t, ldB, p->h_t, ldB, Bp, oe, st, &xa));
@@ -683,9 +722,7 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
             PROF(PS_DW_GEMM, launch_dw_opt(Fp, Hp, p->xct, ldB, p->delta1_t, ldB, Bp, p->delta2_t, ldB, p->h_t, ldB, Bp, oe, st));
         }
     } else if (x3) {
-        const GemmSegDesc ws[5] = {{p->xct, ldB, p->delta1_t, ldB, Bp}, {p->xct, ldB, p->delta1_t2, ldB, Bp}, {p->delta2_t, ldB, p->h_t, ldB, Bp},
-                                   {p->delta2_t, ldB, p->h_t2, ldB, Bp}, {p->delta2_t2, ldB, p->h_t, ldB, Bp}};
-        PROF(PS_DW_GEMM, launch_gemm_f32out_n(dt, Fp, Hp, ws, 5, p->b.grad, Hp, 1, 0, st, GEMM_ROLE_DW));
+        PROF(PS_DW_GEMM, launch_gemm_f32out_n(dt, Fp, Hp, ws3, 6, p->b.grad, Hp, 1, 0, st, GEMM_ROLE_DW));
     } else {
         PROF(PS_DW_GEMM, launch_gemm_f32out(dt, Fp, Hp, p->xct, ldB, p->delta1_t, ldB, Bp, p->delta2_t, ldB, p->h_t, ldB, Bp, p->b.grad, Hp, 1, 0, st, GEMM_ROLE_DW));
         // data parallel with a bf16 exchange image: the shape did not fit the kernel that writes it directly
@@ -702,9 +739,9 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
                     p->b.opt_s1 ? p->b.opt_s1 + boff : nullptr, p->b.opt_s2 ? p->b.opt_s2 + boff : nullptr};
         ClearArgs ca{s->c_indptr ? s->c_indptr : p->b.indptr, s->c_indptr ? s->c_indices : p->b.indices,
                      (s->c_indptr && s->c_row_idx) ? s->c_row_idx : s->row_idx, B, F, dw_bits ? nullptr : p->xct, ldB, p->es,
-                     dw_bits ? p->xtb : nullptr, ldB / 32};
+                     dw_bits ? p->xtb : nullptr, ldB / 32, x3_vals ? p->xct_2 : nullptr};
         PROF(PS_BIAS, launch_step_tail(ba, &sa, csr_in ? &ca : nullptr, st));
-        if (csr_in) { if (dw_bits) p->xtb_clean = true; else p->xct_clean = true; }
+        if (csr_in) { if (dw_bits) p->xtb_clean = true; else p->xct_clean = true; if (x3_vals) p->xct2_clean = true; }
     } else {
         PROF(PS_BIAS, dae_bias_grads(p->dbv_part, 2 * Bp / 128, p->colsum_part, Bp / 32, p->b.bh, H, Hp, F, Fp, c.enc_act, g_bh, g_bh + Hp,
                                      fuse_bias ? 1 : 0, c.opt, plan_lr(p, s->adam_t), c.momentum, s->grad_scale, p->b.bv,
@@ -817,6 +854,15 @@ extern "C" int dae_encode_rows(dae_plan* p, const int32_t* row_idx, int32_t B, f
     RC(gather_batch(p, indptr, indices, values, dense, ld_dense, row_idx, B, nullptr, use_bits ? nullptr : p->xc, nullptr, nullptr,
                     DAE_CORR_NONE, nullptr, 0, 0, 0.f, scale, stream, use_bits ? p->xc_bits : nullptr));
     const int64_t slab = (int64_t)Bp * Hp;
+    if (p->x3 && dense) {        // split-bf16 mode: x = hi + lo against W^T = hi + lo (three products), as the training step encodes
+        RC(gather_dense_lo(p, dense, ld_dense, row_idx, B, nullptr, p->xc_2, nullptr, DAE_CORR_NONE, nullptr, 0, 0, 0.f, scale, stream));
+        const GemmSegDesc es3[3] = {{p->xc, Fp, p->b.Wt_lo, Fp, Fp}, {p->xc, Fp, p->Wt_lo2, Fp, Fp}, {p->xc_2, Fp, p->b.Wt_lo, Fp, Fp}};
+        RC(launch_gemm_f32out_n(dt, Bp, Hp, es3, 3, p->slabs, Hp, p->s_enc3, slab, st, GEMM_ROLE_ENCODE));
+        RC(dae_encode_finish(p->slabs, p->s_enc3, slab, Hp, p->b.bh, B, p->H, p->cfg.enc_act, dt, p->h_f32, nullptr, Hp, nullptr, 0, nullptr, nullptr,
+                             stream));
+        DAE_CHECK_HIP(hipMemcpy2DAsync(out, (size_t)ld_out * 4, p->h_f32, (size_t)Hp * 4, (size_t)p->H * 4, B, hipMemcpyDeviceToDevice, st));
+        return 0;
+    }
     if (use_bits)
         RC(launch_encode_bits(Bp, Hp, Fp, p->xc_bits, Fp / 32, p->b.Wt_lo, Fp, p->slabs, Hp, p->s_enc, slab, st));
     else

@@ -18,7 +18,8 @@ __global__ __launch_bounds__(256) void encode_finish_kernel(const float* __restr
                                                             int64_t ld_slab, const float* __restrict__ bh, int B, int H,
                                                             int enc_act, float* __restrict__ h_f32, T* __restrict__ h_lo,
                                                             int64_t ldh, T* __restrict__ h_t, int64_t ldht,
-                                                            bf16_t* __restrict__ hcat_a, bf16_t* __restrict__ hcat_b, int Hp) {
+                                                            bf16_t* __restrict__ hcat_a, bf16_t* __restrict__ hcat_b, int Hp,
+                                                            T* __restrict__ h_t2) {
     __shared__ float tile[32][65];
     const int j0 = blockIdx.x * 64, i0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -65,6 +66,7 @@ __global__ __launch_bounds__(256) void encode_finish_kernel(const float* __restr
         for (int k = 0; k < 8; ++k) {
             const int r = r0 + 8 * k;
             h_t[(int64_t)(j0 + r) * ldht + i0 + c] = Elem<T>::from(tile[c][r]);
+            if (h_t2) h_t2[(int64_t)(j0 + r) * ldht + i0 + c] = elem_residual<T>(tile[c][r]);      // split-bf16 mode: lo image of h^T
         }
     }
 }
@@ -524,7 +526,10 @@ __global__ __launch_bounds__(256) void step_tail_kernel(BiasArgs ba, StatsArgs s
         for (int j = 0; j < 4; ++j) {
             if (col[j] < ca.F) {
                 if (ca.xtb) ca.xtb[(int64_t)col[j] * ca.ldxt + (i >> 5)] = 0u;        // every lane that touches the word writes the same zero
-                else if (ca.es == 2) reinterpret_cast<bf16_t*>(ca.xct)[(int64_t)col[j] * ca.ldt + i] = 0;
+                else if (ca.es == 2) {
+                    reinterpret_cast<bf16_t*>(ca.xct)[(int64_t)col[j] * ca.ldt + i] = 0;
+                    if (ca.xct2) reinterpret_cast<bf16_t*>(ca.xct2)[(int64_t)col[j] * ca.ldt + i] = 0;
+                }
                 else reinterpret_cast<float*>(ca.xct)[(int64_t)col[j] * ca.ldt + i] = 0.f;
             }
         }
@@ -573,22 +578,29 @@ using namespace dae;
 
 #define ST(s) ((hipStream_t)(s))
 
-extern "C" int dae_encode_finish(const float* slabs, int32_t splits, int64_t slab_stride, int64_t ld_slab, const float* bh,
-                                 int32_t B, int32_t H, int32_t enc_act, int32_t dtype, float* h_f32, void* h_lo, int64_t ldh,
-                                 void* h_t, int64_t ldht, void* hcat_a, void* hcat_b, void* stream) {
+int dae::launch_encode_finish(const float* slabs, int32_t splits, int64_t slab_stride, int64_t ld_slab, const float* bh,
+                              int32_t B, int32_t H, int32_t enc_act, int32_t dtype, float* h_f32, void* h_lo, int64_t ldh,
+                              void* h_t, int64_t ldht, void* hcat_a, void* hcat_b, void* h_t2, void* stream) {
     DAE_CHECK_ARG((hcat_a == nullptr) == (hcat_b == nullptr), "encode_finish: hcat_a/hcat_b must be given together");
     DAE_CHECK_ARG(slabs && bh && splits >= 1, "encode_finish: null input");
     DAE_CHECK_ARG(B > 0 && H > 0 && ldh >= dae_pad(H) && (!h_t || ldht >= dae_pad(B)), "encode_finish: bad shape");
+    DAE_CHECK_ARG(!h_t2 || (h_t && dtype == DAE_BF16), "encode_finish: the lo image of h^T needs h^T and bf16");
     const int Bp = (int)dae_pad(B), Hp = (int)dae_pad(H);
     dim3 grid(Hp / 64, Bp / 32), block(256);
     if (dtype == DAE_BF16)
         hipLaunchKernelGGL((encode_finish_kernel<bf16_t>), grid, block, 0, ST(stream), slabs, splits, slab_stride, ld_slab, bh, B,
-                           H, enc_act, h_f32, (bf16_t*)h_lo, ldh, (bf16_t*)h_t, ldht, (bf16_t*)hcat_a, (bf16_t*)hcat_b, Hp);
+                           H, enc_act, h_f32, (bf16_t*)h_lo, ldh, (bf16_t*)h_t, ldht, (bf16_t*)hcat_a, (bf16_t*)hcat_b, Hp, (bf16_t*)h_t2);
     else
         hipLaunchKernelGGL((encode_finish_kernel<float>), grid, block, 0, ST(stream), slabs, splits, slab_stride, ld_slab, bh, B,
-                           H, enc_act, h_f32, (float*)h_lo, ldh, (float*)h_t, ldht, (bf16_t*)hcat_a, (bf16_t*)hcat_b, Hp);
+                           H, enc_act, h_f32, (float*)h_lo, ldh, (float*)h_t, ldht, (bf16_t*)hcat_a, (bf16_t*)hcat_b, Hp, (float*)nullptr);
     DAE_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int dae_encode_finish(const float* slabs, int32_t splits, int64_t slab_stride, int64_t ld_slab, const float* bh,
+                                 int32_t B, int32_t H, int32_t enc_act, int32_t dtype, float* h_f32, void* h_lo, int64_t ldh,
+                                 void* h_t, int64_t ldht, void* hcat_a, void* hcat_b, void* stream) {
+    return launch_encode_finish(slabs, splits, slab_stride, ld_slab, bh, B, H, enc_act, dtype, h_f32, h_lo, ldh, h_t, ldht, hcat_a, hcat_b, nullptr, stream);
 }
 
 int dae::launch_dh_finish(const float* slabs, int splits, int64_t slab_stride, int64_t ld_slab, const float* dh_extra, const float* h_f32,

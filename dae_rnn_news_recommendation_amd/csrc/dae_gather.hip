@@ -33,7 +33,8 @@ __global__ __launch_bounds__(GATHER_THREADS) void gather_csr_kernel(
     const int32_t* __restrict__ row_idx, int B, int F, T* __restrict__ x, T* __restrict__ xc, int64_t ldx,
     T* __restrict__ xct, int64_t ldt, float* __restrict__ rowsq, int corr_mode, const uint32_t* __restrict__ keep_bits,
     uint64_t seed, uint32_t stream, float corr_frac, float scale, uint32_t* __restrict__ xc_bits, int64_t ldw,
-    LabelJob job, int label_slice, uint32_t* __restrict__ x_bits) {
+    LabelJob job, int label_slice, uint32_t* __restrict__ x_bits, T* __restrict__ x2) {
+    // x2 (split-bf16 mode, valued data): lo image of the clean rows, x = x + x2 to 2^-17; it uses the x~ tile, so xc must be NULL then
     // row tiles; the same LDS serves the label-statistics block (blockIdx.y == label_slice, blockIdx.x == 0)
     constexpr int TILE_B = 2 * GATHER_CW * (int)sizeof(T);
     __shared__ __attribute__((aligned(16))) char smem_raw[TILE_B > LABEL_SMEM_BYTES ? TILE_B : LABEL_SMEM_BYTES];
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(GATHER_THREADS) void gather_csr_kernel(
     // zero the tiles
     for (int k = tid * VEC; k < GATHER_CW; k += GATHER_THREADS * VEC) {
         if (x) *reinterpret_cast<i32x4*>(&lx[k]) = i32x4{0, 0, 0, 0};
-        if (xc) *reinterpret_cast<i32x4*>(&lxc[k]) = i32x4{0, 0, 0, 0};
+        if (xc || x2) *reinterpret_cast<i32x4*>(&lxc[k]) = i32x4{0, 0, 0, 0};
     }
     if (tid < GATHER_CW / 32) { lbits[tid] = 0u; lbits_x[tid] = 0u; }
     __syncthreads();
@@ -80,6 +81,7 @@ __global__ __launch_bounds__(GATHER_THREADS) void gather_csr_kernel(
             if (col < F) {
                 if (x) lx[col - c0] = Elem<T>::from(v);
                 if (xc) lxc[col - c0] = Elem<T>::from(vc);
+                if (x2) lxc[col - c0] = elem_residual<T>(v);
                 if (xc_bits && keep) atomicOr(&lbits[(col - c0) >> 5], 1u << ((col - c0) & 31));
                 if (x_bits) atomicOr(&lbits_x[(col - c0) >> 5], 1u << ((col - c0) & 31));
                 if (xct && keep) xct[(int64_t)col * ldt + i] = Elem<T>::from(vc);
@@ -104,6 +106,7 @@ __global__ __launch_bounds__(GATHER_THREADS) void gather_csr_kernel(
     for (int k = tid * VEC; k < ncol; k += GATHER_THREADS * VEC) {
         if (x) *reinterpret_cast<i32x4*>(&x[(int64_t)i * ldx + c0 + k]) = *reinterpret_cast<const i32x4*>(&lx[k]);
         if (xc) *reinterpret_cast<i32x4*>(&xc[(int64_t)i * ldx + c0 + k]) = *reinterpret_cast<const i32x4*>(&lxc[k]);
+        if (x2) *reinterpret_cast<i32x4*>(&x2[(int64_t)i * ldx + c0 + k]) = *reinterpret_cast<const i32x4*>(&lxc[k]);
     }
     // bit-packed x~ (binary inputs): bit b of word w of row i <=> feature 32*w + b is kept.  Operand of gemm_encode_bits.
     if (xc_bits && tid < (ncol >> 5)) xc_bits[(int64_t)i * ldw + (c0 >> 5) + tid] = lbits[tid];
@@ -134,7 +137,8 @@ template <typename T, bool VEC, int TR, int TC>
 __global__ __launch_bounds__(256) void gather_dense_kernel(
     const float* __restrict__ data, int64_t ld_data, const int32_t* __restrict__ row_idx, int B, int F,
     T* __restrict__ x, T* __restrict__ xc, int64_t ldx, T* __restrict__ xct, int64_t ldt, float* __restrict__ rowsq_part,
-    int corr_mode, const uint32_t* __restrict__ keep_bits, uint64_t seed, uint32_t stream, float corr_frac, float scale) {
+    int corr_mode, const uint32_t* __restrict__ keep_bits, uint64_t seed, uint32_t stream, float corr_frac, float scale, int res) {
+    // res != 0 (split-bf16 mode, second launch): every image receives the RESIDUAL v - bf16(v) instead of v (the lo parts of x, x~, x~^T)
     // TR x TC tile: the fp32 rows are read in runs of 4 TC bytes, x~ leaves in runs of TC elements, x~^T in runs of TR elements
     extern __shared__ __attribute__((aligned(16))) float gd_smem[];         // (dynamic: the 128 x 128 tile is 66 KiB)
     float (*tile)[TC + 1] = reinterpret_cast<float (*)[TC + 1]>(gd_smem);
@@ -170,6 +174,10 @@ __global__ __launch_bounds__(256) void gather_dense_kernel(
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) vc[j] = keep[j] ? v[j] * scale : 0.f;
+            if (res) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v[j] -= bf2f(f2bf(v[j])); vc[j] -= bf2f(f2bf(vc[j])); }
+            }
         }
         if (f < ldx) {                                                  // (the last tile of a 128-padded row may hang over at TC = 256)
             if (x) store4(x + (int64_t)i * ldx + f, v);
@@ -288,6 +296,7 @@ struct EncCsrArgs {
     void* h_t2;                                 // lo image of h^T (split-bf16 mode: h = hi + lo, h_t holds hi) or NULL
     uint32_t* x_bits; int64_t ldxb;             // clean bit image [Bp x ldxb] (binary data) or NULL
     void* xct; int64_t ldt;                     // x~^T [Fp x ldt] scatter target (pre-zeroed) or NULL
+    void* xct2;                                 // split-bf16 mode, x~ not exact in bf16: lo image of x~^T (same layout, pre-zeroed) or NULL
     uint32_t* xtb; int64_t ldxt;                // x~^T as a BIT image [Fp x ldxt words] (pre-zeroed; bit i of row f <=> entry (i, f) kept) or NULL
     int xtl_off, Fp;                            // xtl_off > 0: LDS byte image [Fp] of the workgroup's 8 batch rows at that offset (else global atomics)
     float* rowsq;                               // [Bp] or NULL
@@ -424,7 +433,10 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void encode_csr_kernel(EncCsrArgs a
                     // x~^T for the dW GEMM: a bit per kept entry (binary data; integer OR -> order-independent), or the dense scatter
                     if (xt_lds) atomicOr(&xtl[col[u] >> 2], 1u << (8 * (col[u] & 3) + r));
                     else if (a.xtb) atomicOr(&a.xtb[(int64_t)col[u] * a.ldxt + (i >> 5)], 1u << (i & 31));
-                    else xct[(int64_t)col[u] * a.ldt + i] = Elem<T>::from(w);
+                    else {
+                        xct[(int64_t)col[u] * a.ldt + i] = Elem<T>::from(w);
+                        if (a.xct2) reinterpret_cast<T*>(a.xct2)[(int64_t)col[u] * a.ldt + i] = elem_residual<T>(w);
+                    }
                 }
                 if (do_rowsq) sq += v * v;
                 const bool kp = w != 0.f;
@@ -573,8 +585,9 @@ void dae::set_gather_tile(int v) { g_gather_tile = v & 3; }
 int dae::launch_gather_csr(const int64_t* indptr, const int32_t* indices, const float* values, const int32_t* row_idx, int B, int F,
                            int dtype, void* x, void* xc, int64_t ldx, void* xct, int64_t ldt, float* rowsq, int corr_mode,
                            const uint32_t* keep_bits, uint64_t seed, uint32_t rng_stream, float corr_frac, float scale,
-                           uint32_t* xc_bits, int64_t ldw, const LabelJob* label_job, hipStream_t st, uint32_t* x_bits) {
+                           uint32_t* xc_bits, int64_t ldw, const LabelJob* label_job, hipStream_t st, uint32_t* x_bits, void* x2) {
     DAE_CHECK_ARG(indptr && indices && row_idx, "gather_csr: null CSR / row_idx");
+    DAE_CHECK_ARG(!x2 || (x && !xc && dtype == DAE_BF16), "gather_csr: the lo image of x needs x, no x~ tile and bf16");
     DAE_CHECK_ARG(B > 0 && F > 0, "gather_csr: B=%d F=%d", B, F);
     DAE_CHECK_ARG(ldx >= F && ldx % DAE_PAD == 0, "gather_csr: ldx=%lld must be the padded feature count", (long long)ldx);
     DAE_CHECK_ARG(dtype == DAE_BF16 || dtype == DAE_F32, "gather_csr: bad dtype");
@@ -593,11 +606,11 @@ int dae::launch_gather_csr(const int64_t* indptr, const int32_t* indices, const 
     if (dtype == DAE_BF16)
         hipLaunchKernelGGL((gather_csr_kernel<bf16_t>), grid, block, 0, st, indptr, indices, values, row_idx, B, F,
                            (bf16_t*)x, (bf16_t*)xc, ldx, (bf16_t*)xct, ldt, rowsq, corr_mode, keep_bits, seed, rng_stream,
-                           corr_frac, scale, xc_bits, ldw, job, label_slice, x_bits);
+                           corr_frac, scale, xc_bits, ldw, job, label_slice, x_bits, (bf16_t*)x2);
     else
         hipLaunchKernelGGL((gather_csr_kernel<float>), grid, block, 0, st, indptr, indices, values, row_idx, B, F,
                            (float*)x, (float*)xc, ldx, (float*)xct, ldt, rowsq, corr_mode, keep_bits, seed, rng_stream,
-                           corr_frac, scale, xc_bits, ldw, job, label_slice, x_bits);
+                           corr_frac, scale, xc_bits, ldw, job, label_slice, x_bits, (float*)nullptr);
     DAE_CHECK_LAUNCH();
     return 0;
 }
@@ -630,7 +643,8 @@ int dae::launch_encode_csr(const EncCsrLaunch& q, hipStream_t st) {
     a.corr_mode = q.corr_mode; a.keep_bits = q.keep_bits; a.seed = q.seed; a.stream = q.rng_stream; a.corr_frac = q.corr_frac; a.scale = q.scale;
     a.enc_act = q.enc_act; a.h_f32 = q.h_f32; a.h_lo = q.h_lo; a.ldh = q.ldh; a.h_t = q.h_t; a.ldht = q.ldht; a.h_t2 = q.h_t2;
     a.hcat_a = (bf16_t*)q.hcat_a; a.hcat_b = (bf16_t*)q.hcat_b; a.x_bits = q.x_bits; a.ldxb = q.ldxb; a.xct = q.xct; a.ldt = q.ldt;
-    a.xtb = q.xtb; a.ldxt = q.ldxt;
+    a.xtb = q.xtb; a.ldxt = q.ldxt; a.xct2 = q.xct2;
+    DAE_CHECK_ARG(!q.xct2 || (q.xct && q.dtype == DAE_BF16), "encode_csr: the lo image of x~^T needs the dense x~^T and bf16");
     const int cols = enc_cols(q.dtype, q.w_f32, q.w32_cols);
     a.rowsq = q.rowsq; a.n_slices = Hp / cols;
     const int nblk = a.n_slices * (Bp / ENC_ROWS);
@@ -701,15 +715,16 @@ extern "C" int dae_gather_csr(const int64_t* indptr, const int32_t* indices, con
                                seed, rng_stream, corr_frac, scale, nullptr, 0, stream);
 }
 
-extern "C" int dae_gather_dense(const float* data, int64_t ld_data, const int32_t* row_idx, int32_t B, int32_t F,
+int dae::launch_gather_dense(const float* data, int64_t ld_data, const int32_t* row_idx, int32_t B, int32_t F,
                                 int32_t dtype, void* x, void* xc, int64_t ldx, void* xct, int64_t ldt, float* rowsq,
                                 float* rowsq_scratch, int32_t corr_mode, const uint32_t* keep_bits, uint64_t seed,
-                                uint32_t rng_stream, float corr_frac, float scale, void* stream) {
+                                uint32_t rng_stream, float corr_frac, float scale, void* stream, int res) {
     DAE_CHECK_ARG(data && row_idx, "gather_dense: null input");
     DAE_CHECK_ARG(B > 0 && F > 0 && ld_data >= F, "gather_dense: bad shape");
     DAE_CHECK_ARG(ldx >= F && ldx % DAE_PAD == 0, "gather_dense: ldx must be the padded feature count");
     DAE_CHECK_ARG(dtype == DAE_BF16 || dtype == DAE_F32, "gather_dense: bad dtype");
     DAE_CHECK_ARG(corr_mode != DAE_CORR_KEEPBITS || keep_bits, "gather_dense: keep_bits is null");
+    DAE_CHECK_ARG(!res || (dtype == DAE_BF16 && !rowsq), "gather_dense: the residual pass writes bf16 lo images and no row squares");
     DAE_CHECK_ARG(!rowsq || rowsq_scratch, "gather_dense: rowsq needs rowsq_scratch[(Fp/64) x Bp]");
     const int Bp = (int)dae_pad(B);
     // tile shape: 64 x 64 (option gather_tile = 0), 64 x 128 (1), 128 x 64 (2), 128 x 128 (3) -- rows x features
@@ -725,7 +740,7 @@ extern "C" int dae_gather_dense(const float* data, int64_t ld_data, const int32_
                                                                          hipFuncAttributeMaxDynamicSharedMemorySize, ldsb) : 0;                   \
         DAE_CHECK_ARG(attr_rc == 0, "gather_dense: hipFuncSetAttribute failed");                                                                   \
         hipLaunchKernelGGL((gather_dense_kernel<TT, VV, TR_, TC_>), grid, block, ldsb, st, data, ld_data, row_idx, B, F, (TT*)x, (TT*)xc, ldx,    \
-                           (TT*)xct, ldt, part, corr_mode, keep_bits, seed, rng_stream, corr_frac, scale);                                        \
+                           (TT*)xct, ldt, part, corr_mode, keep_bits, seed, rng_stream, corr_frac, scale, res);                                        \
     } while (0)
 #define DAE_GD_T(TT, VV) do { switch (g_gather_tile & 3) { case 0: DAE_GD(TT, VV, 64, 64); break; case 1: DAE_GD(TT, VV, 64, 128); break; \
                                                            case 2: DAE_GD(TT, VV, 128, 64); break; default: DAE_GD(TT, VV, 128, 128); break; } } while (0)
@@ -739,4 +754,12 @@ extern "C" int dae_gather_dense(const float* data, int64_t ld_data, const int32_
         DAE_CHECK_LAUNCH();
     }
     return 0;
+}
+
+extern "C" int dae_gather_dense(const float* data, int64_t ld_data, const int32_t* row_idx, int32_t B, int32_t F,
+                                int32_t dtype, void* x, void* xc, int64_t ldx, void* xct, int64_t ldt, float* rowsq,
+                                float* rowsq_scratch, int32_t corr_mode, const uint32_t* keep_bits, uint64_t seed,
+                                uint32_t rng_stream, float corr_frac, float scale, void* stream) {
+    return launch_gather_dense(data, ld_data, row_idx, B, F, dtype, x, xc, ldx, xct, ldt, rowsq, rowsq_scratch, corr_mode, keep_bits, seed,
+                               rng_stream, corr_frac, scale, stream, 0);
 }

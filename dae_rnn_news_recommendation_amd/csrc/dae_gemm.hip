@@ -10,7 +10,7 @@
 //   dh       dh   = delta2  . W  + Gs.h A = [delta2 | Gs]       Bt = [W^T_lo ; h^T]     split-K slabs
 //   dW       dW   = x~^T.delta1 + delta2^T.h   A = [x~^T | delta2^T]  Bt = [delta1^T ; h^T]
 //   gram     D    = h . h^T             exact fp32 MFMA, or split-bf16 (K = 3 Hp: [hi|hi|lo] . [hi|lo|hi]^T)
-// A contraction walks up to GEMM_MAX_SEG = 5 K segments, each with its own operand pair and leading dimensions (seg_locate).  The
+// A contraction walks up to GEMM_MAX_SEG = 6 K segments, each with its own operand pair and leading dimensions (seg_locate).  The
 // split-bf16 precision mode (DAE_BF16X3) uses them for x = hi + lo operands: decode (h_hi,W_hi) (h_hi,W_lo) (h_lo,W_hi); dh and dW
 // likewise, 5 segments each -- the kernels are the bf16 ones, only the segment lists and the lo images of the epilogues differ.
 //
@@ -50,7 +50,7 @@ struct GemmSeg {
     int ktiles;             // K_seg * sizeof(T) / 128
 };
 
-constexpr int GEMM_MAX_SEG = 5;    // K segments of one contraction: split-bf16 operands need (hi,hi) (hi,lo) (lo,hi) per product
+constexpr int GEMM_MAX_SEG = 6;    // K segments of one contraction: split-bf16 operands need (hi,hi) (hi,lo) (lo,hi) per product (dW with a valued x~^T: 2 x 3)
 struct GemmParams {
     GemmSeg seg[GEMM_MAX_SEG];
     int nseg;                  // non-empty segments, walked in order
@@ -1449,6 +1449,7 @@ __global__ __launch_bounds__(GEMM_THREADS, DecGeo<BN_T>::WG_PER_CU) void gemm_de
     char* r0_lane = R0 + lrow0 * P0 + lcol0 * 2;
     char* r1_lane = R1 + lcol0 * P1 + lrow0 * 2;
     const T* x_lane = X + (int64_t)(tm * BM + lrow0) * e.ldx + tn * BN_T + lcol0;
+    const bf16_t* x2_lane = (RES && e.x2) ? reinterpret_cast<const bf16_t*>(e.x2) + (int64_t)(tm * BM + lrow0) * e.ldx + tn * BN_T + lcol0 : nullptr;
     T* d2_lane = D2 ? D2 + (int64_t)(tm * BM + lrow0) * e.ldd + tn * BN_T + lcol0 : nullptr;
     T* d2t_lane = D2T ? D2T + (int64_t)(tn * BN_T + lcol0) * e.lddt + tm * BM + lrow0 : nullptr;
 
@@ -1468,6 +1469,14 @@ __global__ __launch_bounds__(GEMM_THREADS, DecGeo<BN_T>::WG_PER_CU) void gemm_de
         constexpr int rloc = mt * 32 + 8 * r4;         // local row offset of q = 0 relative to lrow0
         float d2v[NTB][4];
         float xin[4][NTB];
+        float xlo[RES ? 4 : 1][RES ? NTB : 1];
+        if constexpr (RES) {                           // lo image of the clean rows (NULL for bf16-exact data): straight from memory
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int nt = 0; nt < NTB; ++nt)
+                    xlo[q][nt] = x2_lane ? bf2f(x2_lane[(int64_t)(rloc + q) * e.ldx + nt * 32]) : 0.f;
+        }
         if constexpr (!STAGED) {                       // fp32: batch the global loads of this block
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -1488,8 +1497,10 @@ __global__ __launch_bounds__(GEMM_THREADS, DecGeo<BN_T>::WG_PER_CU) void gemm_de
                 const float z = acc[mt][nt][r] + bvv[nt];
                 float x;
                 if constexpr (XBITS) x = (float)((xb_l[(lrow0 + rloc + q) * WPR + wn * NTB + nt] >> c) & 1u);
-                else if constexpr (STAGED) x = bf2f(*reinterpret_cast<const bf16_t*>(r0_lane + (rloc + q) * P0 + nt * 64));
-                else x = xin[q][nt];
+                else if constexpr (STAGED) {
+                    x = bf2f(*reinterpret_cast<const bf16_t*>(r0_lane + (rloc + q) * P0 + nt * 64));
+                    if constexpr (RES) x += xlo[q][nt];         // valued input in split-bf16 mode: x = hi + lo
+                } else x = xin[q][nt];
                 float l = 0.f, dy = 0.f;
                 if constexpr (FAST) {
                     const float en = __builtin_amdgcn_exp2f(-fabsf(z) * kLog2e);          // exp(-|z|)

@@ -9,6 +9,7 @@ struct DecodeEpi {
     const float* bv;          // [Fp]
     const void* x;            // [Bp x ldx] clean input, element type T
     int64_t ldx;
+    const void* x2;           // split-bf16 mode, input values not exact in bf16: lo image of x (bf16, same leading dimension); else NULL
     const uint32_t* x_bits;   // bf16 + binary input: [Bp x ldxb] bit image of x instead (bit b of word w = feature 32w+b); else NULL
     int64_t ldxb;
     const float* cw;          // [Bp] w_i / (sum w + 1e-16), zero for i >= B
@@ -61,7 +62,15 @@ struct LabelJob {
 int launch_gather_csr(const int64_t* indptr, const int32_t* indices, const float* values, const int32_t* row_idx, int B, int F, int dtype,
                       void* x, void* xc, int64_t ldx, void* xct, int64_t ldt, float* rowsq, int corr_mode, const uint32_t* keep_bits,
                       uint64_t seed, uint32_t rng_stream, float corr_frac, float scale, uint32_t* xc_bits, int64_t ldw,
-                      const LabelJob* label_job, hipStream_t st, uint32_t* x_bits = nullptr);
+                      const LabelJob* label_job, hipStream_t st, uint32_t* x_bits = nullptr, void* x2 = nullptr);   // x2: lo image of x (split-bf16, needs xc == NULL)
+
+// dae_gather_dense with res = 1: the RESIDUAL images v - bf16(v) (split-bf16 mode: lo parts of x, x~, x~^T; bf16 only, no row squares)
+int launch_gather_dense(const float* data, int64_t ld_data, const int32_t* row_idx, int32_t B, int32_t F, int32_t dtype, void* x, void* xc, int64_t ldx,
+                        void* xct, int64_t ldt, float* rowsq, float* rowsq_scratch, int32_t corr_mode, const uint32_t* keep_bits, uint64_t seed,
+                        uint32_t rng_stream, float corr_frac, float scale, void* stream, int res);
+// dae_encode_finish with the lo image of h^T (split-bf16 mode; NULL otherwise)
+int launch_encode_finish(const float* slabs, int32_t splits, int64_t slab_stride, int64_t ld_slab, const float* bh, int32_t B, int32_t H, int32_t enc_act,
+                         int32_t dtype, float* h_f32, void* h_lo, int64_t ldh, void* h_t, int64_t ldht, void* hcat_a, void* hcat_b, void* h_t2, void* stream);
 
 // fused corrupt + gather + encode for CSR inputs (dae_gather.hip: encode_csr_kernel)
 struct EncCsrLaunch {
@@ -76,6 +85,7 @@ struct EncCsrLaunch {
     int w_f32;                     // bf16 activations only: W points at the fp32 MASTER weights [Fp x ldw] (h is then fp32-accurate)
     int w32_cols;                  // w_f32: 64 (default: one 2.6 MB slice per XCD L2) or 128 columns per workgroup
     void* h_t2;                    // split-bf16 mode: lo image of h^T [Hp x ldht] (h_t holds hi); NULL otherwise
+    void* xct2;                    // split-bf16 mode, x~ not exact in bf16: lo image of x~^T (layout of xct, pre-zeroed); NULL otherwise
 };
 int launch_encode_csr(const EncCsrLaunch& q, hipStream_t st);
 size_t encode_csr_lds_bytes(int dtype, int w_f32, int w32_cols, int64_t ldxb);
@@ -93,6 +103,7 @@ struct StatsArgs {
 struct ClearArgs {            // CSR rows whose entries were scattered into x~^T [Fp x ldt] this step
     const int64_t* indptr; const int32_t* indices; const int32_t* row_idx; int B, F; void* xct; int64_t ldt; int es;
     uint32_t* xtb; int64_t ldxt;   // the bit image of x~^T instead of the dense one (xct == NULL): clears the word holding bit (i, col)
+    void* xct2;                    // split-bf16 mode with inexact x~: the lo image of x~^T, cleared alongside (bf16; NULL otherwise)
 };
 // K8 (middle), see dae_dh_finish; delta1_lo: optional ROW-MAJOR delta1 [Bp x ldh] in `dtype` (operand of the sparse x~^T.delta1)
 // K9 on the whole of W (+ biases): dae_opt_step with the lo images of the split-bf16 shadows (NULL outside that mode)

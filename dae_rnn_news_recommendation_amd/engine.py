@@ -90,12 +90,6 @@ class Engine:
         assert m.shape[1] == self.F, (m.shape, self.F)
         dev = self.device
         binary = bool(m.nnz == 0 or np.all(m.data == 1))
-        if self.x3 and not binary:
-            # split-bf16 mode keeps x~ / x~^T as ONE bf16 image (no lo part yet): the stored values must be exact in bf16
-            v = np.ascontiguousarray(m.data, dtype=np.float32)
-            if not np.array_equal(torch.from_numpy(v).to(torch.bfloat16).float().numpy(), v):
-                raise ValueError("precision='bf16x3' needs input values that are exact in bf16 (binary bag-of-words data); "
-                                 "use precision='fp32' for tf-idf-valued input")
         self.csr = dict(
             indptr=torch.from_numpy(m.indptr.astype(np.int64)).to(dev),
             indices=torch.from_numpy(m.indices.astype(np.int32)).to(dev),
@@ -109,21 +103,11 @@ class Engine:
 
     @staticmethod
     def supports_x3(data, scale=1.0):
-        """Can precision='bf16x3' run this train set?  CSR input whose stored values -- and the corruption's scale factor -- are exact
-        in bf16 (x~ / x~^T are single bf16 images in that mode)."""
-        if isinstance(data, np.ndarray) or data is None:
-            return False
-        def exact(v):
-            v = np.ascontiguousarray(v, dtype=np.float32)
-            return bool(np.all((v.view(np.uint32) & 0xffff) == 0))
-        vals = getattr(data, "data", None)
-        if vals is None:
-            return False
-        return exact(np.asarray([scale])) and (vals.size == 0 or exact(vals))
+        """Can precision='bf16x3' run this train set?  Every input kind: binary CSR is exact in bf16; valued CSR (tf-idf, decay noise's scale
+        factor, salt-and-pepper copies) and dense ndarrays get lo images of x, x~ and x~^T as well."""
+        return data is not None
 
     def upload_dense(self, a):
-        if self.x3:
-            raise ValueError("precision='bf16x3' supports CSR input only (the dense-ndarray encode GEMM has no split operands yet)")
         a = np.ascontiguousarray(a, dtype=np.float32)
         assert a.shape[1] == self.F
         self.dense = torch.from_numpy(a).to(self.device)

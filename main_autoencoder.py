@@ -68,8 +68,8 @@ def build_parser():
     p.add_argument("--triplet_strategy", default="batch_all", choices=["batch_all", "batch_hard", "none"])
     # MI355X-side additions
     p.add_argument("--precision", default="auto", choices=["auto", "bf16x3", "fp32", "bf16"],
-                   help="auto (default): the fastest mode that holds the reference's loss curve within 1e-4 -- bf16x3 (split-bf16 MFMA operands) "
-                        "for binary / bf16-exact CSR input, else fp32; bf16 is faster but outside that gate")
+                   help="auto (default): the fastest mode that holds the reference's loss curve within 1e-4 -- bf16x3 (split-bf16 MFMA "
+                        "operands: hi + lo images, three products per GEMM); fp32: exact-fp32 MFMA; bf16 is faster but outside that gate")
     p.add_argument("--rng", default="numpy", choices=["numpy", "philox"])
     p.add_argument("--data", default="", help="scipy-sparse .npz or dense .npy feature matrix (rows = articles)")
     p.add_argument("--labels", default="", help=".npy label vector aligned with --data")

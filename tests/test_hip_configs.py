@@ -1,5 +1,7 @@
-"""BASELINE.json configs 3-5 as parity-test cases (one full-shape step each against the CPU oracle); config 2 is
-the bench workload (tests/test_hip_step.py::test_full_size_step_config2), config 1 is its strategy-none form."""
+"""BASELINE.json configs 1 and 3-5 as parity-test cases (one full-shape step each against the CPU oracle); config 2 is the bench
+workload (tests/test_hip_step.py::test_full_size_step_config2 and the 20-step curve of tests/test_hip_full_curve.py).  Every config runs
+in plain bf16 (gradient gate 5e-3) AND in its PARITY mode -- what precision='auto' resolves to, 'bf16x3' (c4, the dense-ndarray config, also in
+'fp32') -- where losses and gradients must sit within 1e-4 of the oracle."""
 import numpy as np
 import pytest
 import torch
@@ -13,13 +15,15 @@ pytestmark = pytest.mark.gpu
 # bf16 MFMA operands, fp32 accumulation: max-abs error of a gradient image relative to its largest entry.  Measured 1.7e-3 (c1, c4)
 # to 2.2e-3 (c5) at these shapes; the gate sits at ~2x that.
 GATE_BF16_GRAD = 5e-3
+GATE_PARITY = 1e-4            # the north star's gate, applied to losses and to every gradient image of the step
 
 
 def _rel(a, b):
     return float(np.max(np.abs(np.asarray(a, np.float64) - b)) / (np.max(np.abs(b)) + 1e-30))
 
 
-def test_config1_plain_dae_strategy_none():
+@pytest.mark.parametrize("dtype", ["bf16", "bf16x3"])
+def test_config1_plain_dae_strategy_none(dtype):
     """configs[0]: 8000x10000 binary CSR, plain DAE, batch 800 (the reference's CPU-runnable case)."""
     from dae_rnn_news_recommendation_amd import _lib as L
     from dae_rnn_news_recommendation_amd.engine import Engine
@@ -30,7 +34,7 @@ def test_config1_plain_dae_strategy_none():
     keep = rng.random(m.nnz) >= 0.3
     bits = np.packbits(keep, bitorder="little"); bits = np.concatenate([bits, np.zeros((-len(bits)) % 4, np.uint8)]).view(np.int32)
     idx = rng.permutation(N)[:B]
-    eng = Engine(F, H, B, dtype="bf16", triplet="none", learning_rate=0.1)
+    eng = Engine(F, H, B, dtype=dtype, triplet="none", learning_rate=0.1)
     eng.upload_csr(m); eng.set_params(W0)
     stats = torch.zeros(8, device="cuda")
     eng.train_step(torch.from_numpy(idx.astype(np.int32)).cuda(), None, stats, corr_mode=L.CORR_KEEPBITS,
@@ -41,11 +45,12 @@ def test_config1_plain_dae_strategy_none():
     st = stats.cpu().numpy()
     assert abs(st[0] - r["cost"]) <= 1e-4 * abs(r["cost"])
     e = _rel(eng.grads()[0], r["dW"])
-    print("bf16 dW rel err", e)
-    assert e < GATE_BF16_GRAD, e
+    print(dtype, "dW rel err", e)
+    assert e < (GATE_BF16_GRAD if dtype == "bf16" else GATE_PARITY), e
 
 
-def test_config4_dense_tfidf_50000_features():
+@pytest.mark.parametrize("dtype", ["bf16", "fp32", "bf16x3"])
+def test_config4_dense_tfidf_50000_features(dtype):
     """configs[3]: dense fp32 tf-idf ndarray, F=50000, compress_factor 50 (H=1000), cross_entropy, alpha=1, batch_all."""
     from dae_rnn_news_recommendation_amd import _lib as L
     from dae_rnn_news_recommendation_amd.engine import Engine
@@ -56,7 +61,7 @@ def test_config4_dense_tfidf_50000_features():
     W0 = xavier_uniform(F, H)
     rng = np.random.default_rng(2)
     idx = rng.permutation(N)[:B]
-    eng = Engine(F, H, B, dtype="bf16", triplet="batch_all", loss_func="cross_entropy", alpha=1.0, learning_rate=0.1)
+    eng = Engine(F, H, B, dtype=dtype, triplet="batch_all", loss_func="cross_entropy", alpha=1.0, learning_rate=0.1)
     eng.upload_dense(X); eng.set_params(W0)
     stats = torch.zeros(8, device="cuda")
     seed, stream = 77, 1
@@ -71,11 +76,12 @@ def test_config4_dense_tfidf_50000_features():
     assert abs(st[2] - r["triplet_loss"]) <= 1e-4 * abs(r["triplet_loss"]) + 1e-9
     dW, dbh, dbv = eng.grads()
     e = (_rel(dW, r["dW"]), _rel(dbv, r["dbv"]))
-    print("bf16 grad rel err", e)
-    assert max(e) < GATE_BF16_GRAD, e
+    print(dtype, "grad rel err", e)
+    assert max(e) < (GATE_BF16_GRAD if dtype == "bf16" else GATE_PARITY), e
 
 
-def test_config3_batch_hard_category_labels_dp_shard():
+@pytest.mark.parametrize("dtype", ["fp32", "bf16x3"])
+def test_config3_batch_hard_category_labels_dp_shard(dtype):
     """configs[2]: batch_hard + 4 category labels; one rank's 800-row local batch of the 64000x10000 set."""
     from dae_rnn_news_recommendation_amd import _lib as L
     from dae_rnn_news_recommendation_amd.engine import Engine
@@ -84,7 +90,7 @@ def test_config3_batch_hard_category_labels_dp_shard():
     m = synthetic_csr(N, F, seed=11); lab = synthetic_labels(N, seed=11); W0 = xavier_uniform(F, H)
     rng = np.random.default_rng(3)
     idx = rng.permutation(N)[:B]
-    eng = Engine(F, H, B, dtype="fp32", triplet="batch_hard", learning_rate=0.1)
+    eng = Engine(F, H, B, dtype=dtype, triplet="batch_hard", learning_rate=0.1)
     eng.upload_csr(m); eng.set_params(W0)
     stats = torch.zeros(8, device="cuda")
     eng.train_step(torch.from_numpy(idx.astype(np.int32)).cuda(), torch.from_numpy(lab[idx].astype(np.int32)).cuda(), stats, phase=1)
@@ -106,18 +112,19 @@ def test_config3_batch_hard_category_labels_dp_shard():
     assert abs(st[0] - (ae + tl)) <= 2e-5 * abs(ae + tl)
     dW, dbh, dbv = eng.grads()
     e = (_rel(dW, r["dW"]), _rel(dbv, r["dbv"]), _rel(dbh, r["dbh"]))
-    print("c3 fp32 grad rel err", e)
+    print("c3", dtype, "grad rel err", e)
     assert max(e) < 1e-4, e
 
 
-def test_config5_explicit_triplets_cosine():
+@pytest.mark.parametrize("dtype", ["bf16", "bf16x3"])
+def test_config5_explicit_triplets_cosine(dtype):
     """configs[4]: explicit (anchor,pos,neg) batches through the same W, cosine_proximity, B=800 per block."""
     from dae_rnn_news_recommendation_amd.engine import Engine
     from dae_rnn_news_recommendation_amd.synthetic import synthetic_csr, xavier_uniform
     N, F, H, Bt = 1000, 10000, 500, 800
     ms = [synthetic_csr(N, F, seed=20 + k, tfidf=True) for k in range(3)]
     W0 = xavier_uniform(F, H)
-    eng = Engine(F, H, 3 * Bt, dtype="bf16", loss_func="cosine_proximity", triplet="explicit", alpha=1.0, learning_rate=0.1)
+    eng = Engine(F, H, 3 * Bt, dtype=dtype, loss_func="cosine_proximity", triplet="explicit", alpha=1.0, learning_rate=0.1)
     eng.upload_csr(sparse.vstack(ms).tocsr()); eng.set_params(W0)
     idx = np.random.default_rng(4).permutation(N)[:Bt]
     rows = np.concatenate([idx, N + idx, 2 * N + idx]).astype(np.int32)
@@ -127,7 +134,7 @@ def test_config5_explicit_triplets_cosine():
     r = O.explicit_triplet_forward_backward(W0, np.zeros(H, np.float32), np.zeros(F, np.float32), xs, xs, loss_func="cosine_proximity",
                                             alpha=1.0, dt=np.float32)
     st = stats.cpu().numpy()
-    assert abs(st[0] - r["cost"]) <= 2e-4 * abs(r["cost"]), (st, r["cost"], r["ae_loss"], r["triplet_loss"])
+    assert abs(st[0] - r["cost"]) <= (2e-4 if dtype == "bf16" else GATE_PARITY) * abs(r["cost"]), (st, r["cost"], r["ae_loss"], r["triplet_loss"])
     e = _rel(eng.grads()[0], r["dW"])
-    print("bf16 dW rel err", e)
-    assert e < GATE_BF16_GRAD, e
+    print(dtype, "dW rel err", e)
+    assert e < (GATE_BF16_GRAD if dtype == "bf16" else GATE_PARITY), e

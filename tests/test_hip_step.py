@@ -131,6 +131,57 @@ def test_step_bf16x3_matches_oracle(strategy, opt):
             assert _rel(a, b) < 2e-4, _rel(a, b)
 
 
+@pytest.mark.parametrize("loss_func,acts,scale,strategy", [("mean_squared", ("tanh", "none"), 1.0, "batch_all"),
+                                                            ("cosine_proximity", ("sigmoid", "sigmoid"), 1.0, "none"),
+                                                            ("cross_entropy", ("sigmoid", "sigmoid"), 0.7, "batch_hard")])
+def test_step_bf16x3_valued_input_matches_oracle(loss_func, acts, scale, strategy):
+    """Split-bf16 mode on input that is NOT exact in bf16 -- valued CSR (the tf-idf configs) resp. binary data under decay noise's scale
+    factor: x and x~^T get lo images as well (the dW contraction walks 6 segments), so the step stays at the fp64 oracle like the
+    binary case does."""
+    out, ref, got = _run_case("bf16x3", strategy, loss_func, acts, "gradient_descent", steps=3, scale=scale)
+    for r, st, dW, dbh, dbv in out:
+        assert abs(st[1] - r["ae_loss"]) <= 2e-5 * abs(r["ae_loss"]), (st[1], r["ae_loss"])
+        assert abs(st[0] - r["cost"]) <= 2e-5 * abs(r["cost"])
+        assert _rel(dW, r["dW"]) < 1e-4 and _rel(dbv, r["dbv"]) < 1e-4, (_rel(dW, r["dW"]), _rel(dbv, r["dbv"]))
+    for a, b in zip(got, ref):
+        assert _rel(a, b) < 2e-4, _rel(a, b)
+
+
+@pytest.mark.parametrize("loss_func,acts,strategy", [("cross_entropy", ("sigmoid", "sigmoid"), "batch_all"), ("mean_squared", ("tanh", "none"), "none")])
+def test_step_bf16x3_dense_input_matches_oracle(loss_func, acts, strategy):
+    """Split-bf16 mode on a dense ndarray train set (the tf-idf config): the gather writes hi and lo images of x, x~ and x~^T, the encode GEMM
+    runs (x~_hi, W^T_hi) (x~_hi, W^T_lo) (x~_lo, W^T_hi) -- statistics, gradients and parameters stay at the fp64 oracle."""
+    out, ref, got = _run_case("bf16x3", strategy, loss_func, acts, "gradient_descent", steps=3, dense=True)
+    for r, st, dW, dbh, dbv in out:
+        assert abs(st[1] - r["ae_loss"]) <= 2e-5 * abs(r["ae_loss"]), (st[1], r["ae_loss"])
+        assert abs(st[0] - r["cost"]) <= 2e-5 * abs(r["cost"])
+        assert _rel(dW, r["dW"]) < 1e-4 and _rel(dbh, r["dbh"]) < 1e-4, (_rel(dW, r["dW"]), _rel(dbh, r["dbh"]))
+    for a, b in zip(got, ref):
+        assert _rel(a, b) < 2e-4, _rel(a, b)
+
+
+def test_step_bf16x3_shape_beyond_one_dw_round():
+    """A W of more 160 x 128 tiles than the chip has CUs (5120 x 1280 -> 320): the split-bf16 step takes the N-segment dW GEMM to memory +
+    the optimizer kernel that writes all four shadow images instead of refusing the shape."""
+    out, ref, got = _run_case("bf16x3", "batch_all", "cross_entropy", ("sigmoid", "sigmoid"), "momentum", N=300, F=5000, H=1200, B=128, steps=2)
+    for r, st, dW, dbh, dbv in out:
+        assert abs(st[0] - r["cost"]) <= 2e-5 * abs(r["cost"]), (st[0], r["cost"])
+        assert _rel(dW, r["dW"]) < 1e-4, _rel(dW, r["dW"])
+    for a, b in zip(got, ref):
+        assert _rel(a, b) < 2e-4, _rel(a, b)
+
+
+def test_step_bf16x3_gradient_only_phase_matches_oracle():
+    """phase = 1 (the data-parallel first half) in split-bf16 mode: fp32 gradients to the flat buffer, optimizer applied afterwards by
+    dae_plan_apply (all four shadows refreshed)."""
+    out, ref, got = _run_case("bf16x3", "batch_all", "cross_entropy", ("sigmoid", "sigmoid"), "gradient_descent", steps=3, phase=1)
+    for r, st, dW, dbh, dbv in out:
+        assert abs(st[0] - r["cost"]) <= 2e-5 * abs(r["cost"])
+        assert _rel(dW, r["dW"]) < 1e-4 and _rel(dbh, r["dbh"]) < 1e-4
+    for a, b in zip(got, ref):
+        assert _rel(a, b) < 2e-4, _rel(a, b)
+
+
 def test_step_bf16x3_unfused_optimizer_equals_fused():
     """fused_opt = 0 in split-bf16 mode: the 5-segment dW GEMM writes the gradient, opt_w_kernel updates W and all four shadow images;
     same products in the same order as the fused epilogue."""
@@ -565,14 +616,17 @@ def test_explicit_triplet_step_matches_oracle():
     assert _rel(dW, r["dW"]) < 5e-5 and _rel(dbh, r["dbh"]) < 5e-5 and _rel(dbv, r["dbv"]) < 5e-5
 
 
-def test_encode_rows_matches_oracle():
+@pytest.mark.parametrize("dtype,dense", [("fp32", False), ("bf16x3", False), ("bf16x3", True), ("fp32", True)])
+def test_encode_rows_matches_oracle(dtype, dense):
+    """transform()'s kernel path (dae_encode_rows) in the parity modes, CSR and dense-ndarray input."""
     from dae_rnn_news_recommendation_amd.engine import Engine
     rng = np.random.default_rng(5)
     N, F, H = 333, 500, 77
     m = _mk(rng, N, F, False)
     W0 = rng.uniform(-0.3, 0.3, (F, H)).astype(np.float32); bh0 = (rng.standard_normal(H) * 0.1).astype(np.float32)
-    eng = Engine(F, H, 128, dtype="fp32")
-    eng.upload_csr(m); eng.set_params(W0, bh0)
+    eng = Engine(F, H, 128, dtype=dtype)
+    eng.upload_dense(m.toarray()) if dense else eng.upload_csr(m)
+    eng.set_params(W0, bh0)
     out = torch.zeros((N, H), device="cuda")
     for i0 in range(0, N, 128):
         idx = torch.arange(i0, min(N, i0 + 128), dtype=torch.int32, device="cuda")

@@ -64,6 +64,13 @@ extern "C" void* guard_malloc(ssize_t size, int device, hipStream_t) {
     if (e != hipSuccess) die("hipMemSetAccess", e);
     void* p = g_at_start ? r.map_at : (void*)((char*)r.map_at + mapped - need);
     g_recs[p] = r;
+    // DAE_GUARD_POISON=1: fresh memory is filled with 0xA5 (NaN-ish floats, huge indices), so code that relies on new device memory
+    // being zero -- true on a fresh box, not guaranteed anywhere -- fails visibly
+    static const bool poison = [] { const char* q = getenv("DAE_GUARD_POISON"); return q && *q == '1'; }();
+    if (poison) {
+        e = hipMemset(r.map_at, 0xA5, mapped);
+        if (e != hipSuccess) die("hipMemset(poison)", e);
+    }
     return p;
 }
 
