@@ -114,6 +114,11 @@ def main():
     ap.add_argument("--batch", type=int, default=800)
     ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--per-gemm", action="store_true", help="second study: which of the three GEMMs (decode, dh, dW) need their operands split")
+    ap.add_argument("--per-term", action="store_true",
+                    help="third study: split everywhere (Gs bf16), then ONE operand use (operand@gemm) back to plain bf16 -- i.e. one lo.hi / hi.lo "
+                         "product term of one GEMM dropped -- and the combinations of the droppable ones (--drop)")
+    ap.add_argument("--drop", action="append", default=[], metavar="OP@GEMM[,OP@GEMM...]",
+                    help="with --per-term: evaluate exactly these combinations of dropped terms instead of the single-term sweep")
     a = ap.parse_args()
     torch.set_num_threads(a.threads)
     data = synthetic_csr(a.rows, a.features, seed=1234).tocsr()
@@ -140,6 +145,16 @@ def main():
                 for o in ops:
                     m[f"{o}@{g}"] = "bf16"
             modes["split everywhere but plain bf16 in " + " + ".join(gemms)] = m
+    if a.per_term:
+        uses = ("h@dec", "W@dec", "d2@dh", "W@dh", "h@dh", "d1@dw", "d2@dw", "h@dw")
+        modes = {"all f32 (reference arithmetic)": dict.fromkeys(ops, "f32")}
+        combos = [tuple(c.split(",")) for c in a.drop] if a.drop else [(u,) for u in uses]
+        for combo in combos:
+            m = dict.fromkeys(ops, "split"); m["Gs"] = "bf16"
+            for u in combo:
+                assert u in uses, u
+                m[u] = "bf16"
+            modes["split, lo term dropped: " + " + ".join(combo)] = m
     ref = None
     for name, m in modes.items():
         t0 = time.time()
