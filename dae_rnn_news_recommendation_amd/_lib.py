@@ -22,6 +22,7 @@ OPT = {"gradient_descent": 0, "ada_grad": 1, "momentum": 2, "adam": 3}
 TRIPLET = {"none": 0, "batch_all": 1, "batch_hard": 2, "explicit": 3}
 CORR_NONE, CORR_KEEPBITS, CORR_PHILOX_MASK = 0, 1, 2
 STATS_STRIDE = 8
+WAIT_DW_CREATED = 2     # dae_plan_stream_wait_dw: the event was created by this call (not an error)
 STAT_COST, STAT_AE, STAT_TRIPLET, STAT_FRACTION, STAT_NUM, STAT_NVALID = range(6)
 PAD = 128
 

@@ -122,7 +122,10 @@ struct dae_plan {
     bool x3;
     char *W_lo2, *Wt_lo2, *h_t2, *delta2_2, *delta2_t2, *delta1_t2;
     char *x_2, *xct_2, *xc_2;         // ... and of the clean rows x / of x~^T / of x~ (dense input), used when the input values (or the corruption scale) are not exact in bf16
-    int s_enc3, s_dh3;               // split-K slice counts of the dense-input encode / dh GEMMs in split-bf16 mode (3 resp. 5 K segments)
+    int s_enc3, s_dh3;               // split-K slice counts of the dense-input encode / dh GEMMs in split-bf16 mode (3 resp. 4-5 K segments)
+    // split-bf16 mode, product terms that the 20-step curve does not need (tools/precision_study.py --per-term, profiles/r04_precision_terms.txt):
+    bool x3_dec_wlo;                 // option "x3_dec_wlo": decode also multiplies (h_hi, W_lo)  [default off: z2 = h_hi.W_hi + h_lo.W_hi]
+    bool x3_dh_hlo;                  // option "x3_dh_hlo": dh also multiplies (Gs, h^T_lo)       [default off: Gs.h^T_hi only]
     bool xct2_clean;
     uint32_t* xtb;                   // x~^T as a bit image [Fp x Bpm/32] (binary CSR + bf16: operand of the sparse half of the dW kernel)
     bool xtb_clean;                  // the bit image holds only zeros (every step clears what it set; see step_tail_kernel)
@@ -154,6 +157,16 @@ static int auto_splits(int tiles, int ktiles) {
     if (s > cap) s = cap;
     if (s < 1) s = 1;
     return s;
+}
+
+// split-bf16 mode on dense-ndarray input: slice counts of the 3-segment encode and the 4-5-segment dh contraction (see dae_plan_create)
+static void plan_x3_splits(dae_plan* p) {
+    const dae_config& c = p->cfg;
+    const int kt_f = p->Fp * p->es / 128, kt_b = p->Bpm * p->es / 128;
+    p->s_enc3 = p->s_enc; p->s_dh3 = p->s_dh;
+    if (!p->x3) return;
+    if (c.encode_splits <= 0) if (const int w = gemm_w8_splits(c.dtype, p->Bpm, p->Hp, 3 * kt_f)) p->s_enc3 = w;
+    if (c.dh_splits <= 0) if (const int w = gemm_w8_splits(c.dtype, p->Bpm, p->Hp, 3 * kt_f + (p->x3_dh_hlo ? 2 : 1) * kt_b)) p->s_dh3 = w;
 }
 
 static uint64_t carve(dae_plan* p, char* base) {
@@ -252,12 +265,8 @@ extern "C" int dae_plan_create(const dae_config* cfg, dae_plan** out) {
     if (p->s_dh > kt_f) p->s_dh = kt_f;
     // split-bf16 mode on dense-ndarray input: the encode contraction has 3 K segments and dh 5; the 256 x 256 kernel is taken exactly when the
     // launch is handed ITS slice count for the real K-tile total, so these are planned with the segment lists' totals
-    p->s_enc3 = p->s_enc; p->s_dh3 = p->s_dh;
-    if (p->x3) {
-        const int kt_b = p->Bpm * p->es / 128;
-        if (cfg->encode_splits <= 0) if (const int w = gemm_w8_splits(cfg->dtype, p->Bpm, p->Hp, 3 * kt_f)) p->s_enc3 = w;
-        if (cfg->dh_splits <= 0) if (const int w = gemm_w8_splits(cfg->dtype, p->Bpm, p->Hp, 3 * kt_f + 2 * kt_b)) p->s_dh3 = w;
-    }
+    p->x3_dec_wlo = false; p->x3_dh_hlo = false;
+    plan_x3_splits(p);
     if (p->s_gram > p->Hp * 4 / 128) p->s_gram = p->Hp * 4 / 128;
     p->gram_split = (cfg->dtype == DAE_BF16) && (p->x3 || cfg->triplet == DAE_TRIPLET_BATCH_ALL || cfg->triplet == DAE_TRIPLET_BATCH_HARD);   // x3: hcat_a also holds the row-major h_lo
     p->ws_bytes = carve(p, nullptr);
@@ -313,6 +322,12 @@ extern "C" int dae_plan_set_option(dae_plan* p, const char* name, int32_t value)
     else if (!strcmp(name, "miner_pack")) set_miner_pack(on);        // process-wide (the launcher's choice), like dae_set_glds
     else if (!strcmp(name, "miner_tile")) set_miner_tile(on);        // process-wide: 0 = the former wave-per-positive batch_all kernel
     else if (!strcmp(name, "sym_in_decode")) p->sym_ride_ok = on;
+    else if (!strcmp(name, "x3_dec_wlo") || !strcmp(name, "x3_dh_hlo")) {
+        DAE_CHECK_ARG(!p->bound, "plan_set_option: %s changes the split-K plan (workspace layout), set it before dae_plan_bind", name);
+        if (name[4] == 'e') p->x3_dec_wlo = on; else p->x3_dh_hlo = on;
+        plan_x3_splits(p);
+        p->ws_bytes = carve(p, nullptr);
+    }
     else if (!strcmp(name, "gram_fp32")) {
         DAE_CHECK_ARG(!p->bound, "plan_set_option: gram_fp32 changes the workspace layout, set it before dae_plan_bind");
         DAE_CHECK_ARG(!p->x3, "plan_set_option: gram_fp32 is not available in split-bf16 mode (its Gram operands double as the row-major h images)");
@@ -618,7 +633,7 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
         int ndseg = 1;
         if (x3) {
             dsegs[0] = {p->hcat_a, 3 * (int64_t)Hp, p->b.W_lo, Hp, Hp};
-            dsegs[1] = {p->hcat_a, 3 * (int64_t)Hp, p->W_lo2, Hp, Hp};
+            dsegs[1] = {p->hcat_a, 3 * (int64_t)Hp, p->W_lo2, Hp, p->x3_dec_wlo ? Hp : 0};      // K = 0: the term is dropped
             dsegs[2] = {p->hcat_a + (size_t)2 * Hp * 2, 3 * (int64_t)Hp, p->b.W_lo, Hp, Hp};
             ndseg = 3;
             if (backward) { e.delta2_2 = p->delta2_2; e.delta2_t2 = p->delta2_t2; }
@@ -686,9 +701,9 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     // 9-10. dL/dh = delta2 W + alpha (G+G^T) h ; delta1                     (K8)
     const bool mined = !ext_mine && (c.triplet == DAE_TRIPLET_BATCH_ALL || c.triplet == DAE_TRIPLET_BATCH_HARD);
     const int s_dh = (x3 && dense_in) ? p->s_dh3 : p->s_dh;
-    if (x3) {       // (d2_hi, Wt_hi) (d2_hi, Wt_lo) (d2_lo, Wt_hi) + Gs.(h_hi + h_lo): Gs itself stays bf16 (tools/precision_study.py)
+    if (x3) {       // (d2_hi, Wt_hi) (d2_hi, Wt_lo) (d2_lo, Wt_hi) + Gs.h_hi (+ Gs.h_lo with option x3_dh_hlo): Gs itself stays bf16 (tools/precision_study.py)
         const GemmSegDesc hs[5] = {{p->delta2, Fp, p->b.Wt_lo, Fp, Fp}, {p->delta2, Fp, p->Wt_lo2, Fp, Fp}, {p->delta2_2, Fp, p->b.Wt_lo, Fp, Fp},
-                                   {p->Gs, Bp, p->h_t, ldB, mined ? Bp : 0}, {p->Gs, Bp, p->h_t2, ldB, mined ? Bp : 0}};
+                                   {p->Gs, Bp, p->h_t, ldB, mined ? Bp : 0}, {p->Gs, Bp, p->h_t2, ldB, (mined && p->x3_dh_hlo) ? Bp : 0}};
         PROF(PS_DH_GEMM, launch_gemm_f32out_n(dt, Bp, Hp, hs, 5, p->slabs, Hp, s_dh, slab, st, GEMM_ROLE_DH));
     } else {
         PROF(PS_DH_GEMM, launch_gemm_f32out(dt, Bp, Hp, p->delta2, Fp, p->b.Wt_lo, Fp, Fp, mined ? p->Gs : nullptr, Bp, mined ? p->h_t : nullptr, ldB,
@@ -713,7 +728,7 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
             oe.ldw = Hp;
         }
         if (x3) {   // x~^T.(d1_hi + d1_lo) + (d2^T_hi, h^T_hi) (d2^T_hi, h^T_lo) (d2^T_lo, h^T_hi); the epilogue writes both parts of both shadows
-            oe.W_lo2 = p->W_lo2; oe.Wt_lo2 = p->Wt_lo2;
+            oe.W_lo2 = p->x3_dec_wlo ? p->W_lo2 : nullptr; oe.Wt_lo2 = p->Wt_lo2;     // W_lo2 feeds the decode's (h_hi, W_lo) term only
             PROF(PS_DW_GEMM, launch_dw_opt_n(Fp, Hp, ws3, 6, oe, st));
         } else if (dw_bits) {
             DwBitsArgs xa{p->xtb, ldB / 32, s->scale};
@@ -784,13 +799,13 @@ extern "C" int dae_plan_apply_rows(dae_plan* p, int32_t adam_t, float grad_scale
 }
 
 // Data parallel: make `stream` wait until the W gradient of the LAST enqueued dae_train_step is complete (the event sits between the dW
-// GEMM and the step's tail kernel).  The first call creates the event; steps enqueued before it are not covered (returns 1 then).
+// GEMM and the step's tail kernel).  The first call creates the event; steps enqueued before it are not covered (returns DAE_WAIT_DW_CREATED then;
+// 0 = the wait was enqueued; any other value is an error, text in dae_last_error).
 extern "C" int dae_plan_stream_wait_dw(dae_plan* p, void* stream) {
     DAE_CHECK_ARG(p && p->bound, "plan_stream_wait_dw: plan not bound");
     if (!p->ev_dw) {
         DAE_CHECK_HIP(hipEventCreateWithFlags(&p->ev_dw, hipEventDisableTiming));
-        set_error("plan_stream_wait_dw: event created; it covers the steps enqueued from now on");
-        return 1;
+        return DAE_WAIT_DW_CREATED;      // not an error (dae_last_error untouched): the event covers the steps enqueued from now on
     }
     DAE_CHECK_HIP(hipStreamWaitEvent((hipStream_t)stream, p->ev_dw, 0));
     return 0;

@@ -1097,9 +1097,11 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_dw_pc(GemmParams p, OptEpi
                         lo.x = f2bf_pack_hw(pn[0], pn[1]); lo.y = f2bf_pack_hw(pn[2], pn[3]);
                         *reinterpret_cast<uint2*>(Wlo + k) = lo;
                         if constexpr (X3) {
-                            uint2 l2;
-                            l2.x = bf_residual_pack_hw(pn[0], pn[1]); l2.y = bf_residual_pack_hw(pn[2], pn[3]);
-                            *reinterpret_cast<uint2*>(Wlo2 + k) = l2;
+                            if (Wlo2) {                                      // NULL: nobody reads the lo image of the row-major shadow
+                                uint2 l2;
+                                l2.x = bf_residual_pack_hw(pn[0], pn[1]); l2.y = bf_residual_pack_hw(pn[2], pn[3]);
+                                *reinterpret_cast<uint2*>(Wlo2 + k) = l2;
+                            }
                         }
                     }
                 }
@@ -1875,12 +1877,13 @@ int launch_gemm_f32out_n(int dtype, int M, int N, const GemmSegDesc* segs, int n
         q.nseg = p.nseg; q.ktiles_total = p.ktiles_total; q.M = M; q.N = N;
         q.tiles_m = (M + W8_BM - 1) / W8_BM; q.tiles_n = (N + W8_BN - 1) / W8_BN; q.splits = p.splits;
         const int ws = p.splits;
-        static bool attr = false;
-        if (!attr) {
+        static const int w8_attr_rc = [] {
+            int rc = 0;
             for (int r = 0; r <= ROLE_GRAM; ++r)
-                DAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(w8_kernel(r)), hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS));
-            attr = true;
-        }
+                rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(w8_kernel(r)), hipFuncAttributeMaxDynamicSharedMemorySize, W8_LDS);
+            return rc;
+        }();
+        DAE_CHECK_ARG(w8_attr_rc == 0, "gemm: hipFuncSetAttribute failed for the 256 x 256 kernel (%d)", w8_attr_rc);
         hipLaunchKernelGGL(w8_kernel(role), dim3(q.tiles_m * q.tiles_n * ws), dim3(W8_THREADS), W8_LDS, st, q, C, ldc, slab_stride);
         DAE_CHECK_LAUNCH();
         return 0;
@@ -1992,8 +1995,8 @@ int launch_dw_opt_n(int M, int N, const GemmSegDesc* segs, int nsegs, const OptE
     GemmParams p;
     if (int rc = fill_params_n(p, DAE_BF16, M, N, segs, nsegs, 1)) return rc;
     if (int rc = gemm_init()) return rc;
-    DAE_CHECK_ARG(e.W && e.W_lo && e.Wt_lo && e.W_lo2 && e.Wt_lo2 && e.ldw >= N && e.ldwt >= M && e.ldw % 8 == 0 && e.ldwt % 8 == 0,
-                  "dw_opt_n: bad parameter images (split-bf16 mode needs W_lo2 / Wt_lo2)");
+    DAE_CHECK_ARG(e.W && e.W_lo && e.Wt_lo && e.Wt_lo2 && e.ldw >= N && e.ldwt >= M && e.ldw % 8 == 0 && e.ldwt % 8 == 0,
+                  "dw_opt_n: bad parameter images (split-bf16 mode needs Wt_lo2; W_lo2 is optional)");
     DAE_CHECK_ARG(e.opt >= DAE_OPT_SGD && e.opt <= DAE_OPT_ADAM && (e.opt == DAE_OPT_SGD || e.s1) && (e.opt != DAE_OPT_ADAM || e.s2),
                   "dw_opt_n: optimizer slots missing");
     const int tiles_m = (M + DW_BM - 1) / DW_BM, tiles_n = N / BN, per = (tiles_m + 7) / 8;

@@ -983,11 +983,9 @@ int dae::launch_batch_all(const float* D_slabs, int d_splits, int64_t slab_strid
     if (!pos_only && Bp <= 1024 && g_miner_tile) {
         // the lane-grid kernel: one workgroup per anchor, all of them resident (4 per CU)
         const size_t tl = (size_t)Bp * 16 + (size_t)(4 * Bp > 1024 ? 4 * Bp : 1024) * 4 + 32 * sizeof(int) + 12 * sizeof(float);
-        static bool tile_attr_done = false;
-        if (!tile_attr_done) {
-            DAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(batch_all_tile_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            tile_attr_done = true;
-        }
+        static const int tile_attr_rc =          // once per process, thread-safe (function-local static initialiser)
+            (int)hipFuncSetAttribute(reinterpret_cast<const void*>(batch_all_tile_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        DAE_CHECK_ARG(tile_attr_rc == 0, "batch_all: hipFuncSetAttribute failed (%d)", tile_attr_rc);
         hipLaunchKernelGGL(batch_all_tile_kernel<4>, dim3(n_anchors), dim3(TRIP_THREADS), tl, st, D_slabs, d_splits, slab_stride, ldd, labels, B, Bp,
                            loss_part, npos_part, G, role_cnt, fast, a0, /*order=*/nullptr, cls);   // every anchor is resident: the dispatch order is moot
         DAE_CHECK_LAUNCH();
@@ -995,22 +993,22 @@ int dae::launch_batch_all(const float* D_slabs, int d_splits, int64_t slab_strid
     }
     typedef void (*ba_fn)(const float*, int, int64_t, int64_t, const int32_t*, int, int, float*, uint32_t*, float*, uint32_t*, int, int, const int32_t*, int, const int32_t*);
     ba_fn k = pos_only ? batch_all_kernel<true, 3> : batch_all_kernel<false, 3>;      // 3 workgroups per CU (168 VGPRs)
-    static bool attr_done = false;
-    if (!attr_done) {
-        ba_fn all[2] = {batch_all_kernel<true, 3>, batch_all_kernel<false, 3>};
-        for (ba_fn f : all)
-            DAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
-    }
+    static const int attr_rc = [] {
+        int rc = 0;
+        const ba_fn all[2] = {batch_all_kernel<true, 3>, batch_all_kernel<false, 3>};
+        for (ba_fn f : all) rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        return rc;
+    }();
+    DAE_CHECK_ARG(attr_rc == 0, "batch_all: hipFuncSetAttribute failed (%d)", attr_rc);
     // at most one resident round: 3 workgroups per CU (168 VGPRs); the workgroups walk the anchor list in snake order (see the kernel)
-    static int slots = 0;
-    if (!slots) {
-        int dev = 0, cus = 0;
-        DAE_CHECK_HIP(hipGetDevice(&dev));
-        DAE_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        const int per_cu = (int)((160 * 1024) / lds) < 3 ? (int)((160 * 1024) / lds) : 3;
-        slots = cus * (per_cu < 1 ? 1 : per_cu);
-    }
+    static const int cus = [] {                  // the device's CU count is read once; the resident slots follow THIS call's LDS footprint
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        return n;
+    }();
+    DAE_CHECK_ARG(cus > 0, "batch_all: cannot read the device's compute-unit count");
+    const int per_cu = (int)((160 * 1024) / lds) < 3 ? (int)((160 * 1024) / lds) : 3;
+    const int slots = cus * (per_cu < 1 ? 1 : per_cu);
     const int nwg = (g_miner_pack && n_anchors > slots) ? slots : n_anchors;
     hipLaunchKernelGGL(k, dim3(nwg), dim3(TRIP_THREADS), lds, st, D_slabs, d_splits, slab_stride, ldd, labels, B, Bp, loss_part, npos_part, G,
                        role_cnt, fast, a0, order, n_anchors, cls);

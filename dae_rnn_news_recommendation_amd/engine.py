@@ -223,7 +223,11 @@ class Engine:
     def stream_wait_dw(self, stream):
         """Make the torch stream `stream` wait for the W gradient of the last enqueued step (event between the dW GEMM and the step tail).
         Returns False when the event did not exist yet (first call): the caller then waits for the whole step."""
-        return self.lib.dae_plan_stream_wait_dw(self.plan, C.c_void_p(stream.cuda_stream)) == 0
+        rc = self.lib.dae_plan_stream_wait_dw(self.plan, C.c_void_p(stream.cuda_stream))
+        if rc == L.WAIT_DW_CREATED:
+            return False
+        L.check(rc, "dae_plan_stream_wait_dw")        # a genuine HIP error must not read as "event not ready"
+        return True
 
     def apply_rows_packed(self, grad_rows, f0, f1, send, bias_off, grad_scale=1.0):
         """Sharded-optimizer step on the rows [f0, f1); their low-precision image goes straight into the all-gather send buffer
@@ -278,6 +282,10 @@ class Engine:
     def set_option(self, name, value):
         """Code-path choice of the plan (A/B measurements, equivalence tests): see dae_plan_set_option in include/dae_hip.h."""
         L.check(self.lib.dae_plan_set_option(self.plan, name.encode(), int(value)), "dae_plan_set_option")
+        # options that change the split-K plan (x3_dec_wlo, x3_dh_hlo, gram_fp32) also change the workspace size; they are refused once bound
+        ws_bytes = int(self.lib.dae_plan_workspace_bytes(self.plan))
+        if ws_bytes > self.workspace.numel():
+            self.workspace = torch.zeros(ws_bytes, dtype=torch.uint8, device=self.device)
 
     def profile(self, enable):
         L.check(self.lib.dae_plan_profile(self.plan, int(bool(enable))), "dae_plan_profile")

@@ -441,7 +441,10 @@ int      dae_plan_sync_shadows(dae_plan* p, void* stream);
  * (batch_all workgroups = one resident round, each walking the anchor list in snake order; 0 = one workgroup per anchor), "encode_w32" (bf16 mode: the
  * sparse encode reads the fp32 master weights, so h -- and with the split-bf16 Gram matrix the triplet leg -- is fp32-accurate; default
  * on; a sharded-optimizer exchange must turn it off because only W_lo is current on every rank), "encode_w32_cols" (128 | 64 columns
- * per workgroup of that kernel).  Unknown names are an error. */
+ * per workgroup of that kernel), "x3_dec_wlo" / "x3_dh_hlo" (split-bf16 mode, before dae_plan_bind only: 1 = the decode also multiplies
+ * (h_hi, W_lo) resp. the dh GEMM also multiplies (Gs, h^T_lo) -- the two product terms the 20-step loss curve does not need
+ * (tools/precision_study.py --per-term, profiles/r04_precision_terms.txt); default 0, and the dW epilogue then skips the lo image of the
+ * row-major shadow, which only that decode term reads).  Unknown names are an error. */
 int      dae_plan_set_option(dae_plan* p, const char* name, int32_t value);
 int      dae_train_step(dae_plan* p, const dae_step* step, void* stream);
 int      dae_plan_apply(dae_plan* p, int32_t adam_t, float grad_scale, void* stream);
@@ -462,7 +465,9 @@ int      dae_plan_refresh_wt(dae_plan* p, void* stream);
  *     computes the same sum).  dae_dp_unpack is the plan-free form. */
 /* Data parallel: `stream` waits until the W gradient of the last enqueued dae_train_step is complete (an event between the dW GEMM and
  * the step's tail kernel), so that a reduce-scatter issued on `stream` runs beside the tail.  The first call only creates the event and
- * returns 1 (steps enqueued earlier are not covered: wait for the step's stream instead). */
+ * returns DAE_WAIT_DW_CREATED (not an error, dae_last_error untouched; steps enqueued earlier are not covered: wait for the step's
+ * stream instead); 0 = the wait was enqueued; any other value is an error. */
+#define DAE_WAIT_DW_CREATED 2
 int dae_plan_stream_wait_dw(dae_plan* plan, void* stream);
 int dae_plan_apply_rows_packed(dae_plan* plan, int32_t adam_t, float grad_scale, const float* grad_rows, int32_t f0, int32_t f1,
                                void* send, int64_t bias_off_bytes, void* stream);

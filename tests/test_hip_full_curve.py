@@ -23,9 +23,16 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PATH = os.path.join(HERE, "golden", "full_curve_c2.npz")
 
 
+# bf16x3: the product default drops two lo product terms the curve does not need (decode h_hi.W_lo, dh Gs.h^T_lo: tools/precision_study.py
+# --per-term, profiles/r04_precision_terms.txt); "all terms" switches both back on (plan options x3_dec_wlo / x3_dh_hlo) -- same 1e-4 gate
+ALL_TERMS = {"x3_dec_wlo": 1, "x3_dh_hlo": 1}
+
+
 @pytest.mark.skipif(not os.path.exists(PATH), reason="tests/golden/full_curve_c2.npz not generated")
-@pytest.mark.parametrize("precision,tol,tol_saturated", [("fp32", 2e-5, 2e-5), ("bf16", 1e-4, 6e-4), ("bf16x3", 1e-4, 1e-4)])
-def test_full_shape_loss_curve(tmp_path, precision, tol, tol_saturated):
+@pytest.mark.parametrize("precision,tol,tol_saturated,plan_options",
+                         [("fp32", 2e-5, 2e-5, None), ("bf16", 1e-4, 6e-4, None), ("bf16x3", 1e-4, 1e-4, None), ("bf16x3", 1e-4, 1e-4, ALL_TERMS)],
+                         ids=["fp32", "bf16", "bf16x3", "bf16x3-all-terms"])
+def test_full_shape_loss_curve(tmp_path, precision, tol, tol_saturated, plan_options):
     sys.path.insert(0, os.path.join(HERE, "golden"))
     import make_full_curve as M
     from dae_rnn_news_recommendation_amd.autoencoder import DenoisingAutoencoder
@@ -37,7 +44,7 @@ def test_full_shape_loss_curve(tmp_path, precision, tol, tol_saturated):
                                  dec_act_func="sigmoid", loss_func="cross_entropy", num_epochs=c["epochs"], batch_size=c["batch"],
                                  opt="gradient_descent", learning_rate=c["learning_rate"], corr_type="masking", corr_frac=c["corr_frac"],
                                  verbose=0, verbose_step=1, seed=c["seed"], alpha=c["alpha"], triplet_strategy="batch_all",
-                                 precision=precision, rng="numpy", init_weights=W0, results_root=str(tmp_path) + "/")
+                                 precision=precision, rng="numpy", init_weights=W0, results_root=str(tmp_path) + "/", plan_options=plan_options)
     model.fit(m, train_set_label=lab)
     for e in range(c["epochs"]):
         pb = model.epoch_stats(e + 1)["per_batch"]
@@ -47,7 +54,7 @@ def test_full_shape_loss_curve(tmp_path, precision, tol, tol_saturated):
             if key == "triplet" and precision == "bf16":
                 step = np.arange(pb.shape[0]) + e * pb.shape[0]
                 gate = np.where(step < 3, 1e-4, np.where(step == 3, 5e-4, 1e-2))
-            print(f"[curve] {precision} epoch {e} {key}: max rel {rel.max():.2e} at batch {int(rel.argmax())}")
+            print(f"[curve] {precision}{' all-terms' if plan_options else ''} epoch {e} {key}: max rel {rel.max():.2e} at batch {int(rel.argmax())}")
             assert (rel <= gate).all(), (precision, e, key, rel)
         if precision == "fp32":
             assert np.abs(pb[:, 4] - G["num"][e]).max() <= 200        # of ~5*10^7 positive triplets: near-ties of the fp32 Gram matrix

@@ -160,6 +160,24 @@ def test_step_bf16x3_dense_input_matches_oracle(loss_func, acts, strategy):
         assert _rel(a, b) < 2e-4, _rel(a, b)
 
 
+@pytest.mark.parametrize("dense", [False, True])
+def test_step_bf16x3_all_terms_option(dense):
+    """Plan options x3_dec_wlo / x3_dh_hlo = 1 restore the two lo product terms the default split-bf16 step drops (decode: h_hi.W_lo, dh:
+    Gs.h^T_lo): both forms sit at the fp64 oracle, and next to each other."""
+    a, ra, pa = _run_case("bf16x3", "batch_all", "cross_entropy", ("sigmoid", "sigmoid"), "gradient_descent", steps=3, seed=11, dense=dense)
+    b, rb, pb = _run_case("bf16x3", "batch_all", "cross_entropy", ("sigmoid", "sigmoid"), "gradient_descent", steps=3, seed=11, dense=dense,
+                          options={"x3_dec_wlo": 1, "x3_dh_hlo": 1})
+    for out in (a, b):
+        for r, st, dW, dbh, dbv in out:
+            assert abs(st[0] - r["cost"]) <= 2e-5 * abs(r["cost"]), (st[0], r["cost"])
+            assert _rel(dW, r["dW"]) < 1e-4 and _rel(dbv, r["dbv"]) < 1e-4, (_rel(dW, r["dW"]), _rel(dbv, r["dbv"]))
+    for (_, sa, dWa, *_), (_, sb, dWb, *_) in zip(a, b):
+        assert np.allclose(sa[:3], sb[:3], rtol=2e-5, atol=0), (sa, sb)
+        assert _rel(dWa, np.asarray(dWb, np.float64)) < 1e-4
+    for u, v in zip(pa, pb):
+        assert _rel(u, np.asarray(v, np.float64)) < 1e-4
+
+
 def test_step_bf16x3_shape_beyond_one_dw_round():
     """A W of more 160 x 128 tiles than the chip has CUs (5120 x 1280 -> 320): the split-bf16 step takes the N-segment dW GEMM to memory +
     the optimizer kernel that writes all four shadow images instead of refusing the shape."""

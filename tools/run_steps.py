@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """N plain training steps (no event profiling) -- the workload run under rocprofv3 --pmc.
-usage: python tools/run_steps.py [steps] [strategy] [c2|c4]      (c2: BASELINE configs[1] CSR step; c4: dense fp32 tf-idf, F = 50000)"""
+usage: python tools/run_steps.py [steps] [strategy] [c2|c4] [precision]   (c2: BASELINE configs[1] CSR step; c4: dense fp32 tf-idf, F = 50000;
+precision: bf16x3 (default = what precision='auto' resolves to, the bench headline) | bf16 | fp32)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -10,19 +11,23 @@ from dae_rnn_news_recommendation_amd.synthetic import synthetic_csr, synthetic_l
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 strategy = sys.argv[2] if len(sys.argv) > 2 else "batch_all"
 cfg = sys.argv[3] if len(sys.argv) > 3 else "c2"
+precision = sys.argv[4] if len(sys.argv) > 4 else "bf16x3"
 F, H = (10000, 500) if cfg == "c2" else (50000, 1000)
 m = synthetic_csr(1600, F, nnz_per_row=200 if cfg == "c2" else 300, seed=1, tfidf=(cfg != "c2")); lab = synthetic_labels(1600, seed=1).astype(np.int32)
-eng = Engine(F, H, 800, dtype="bf16", triplet=strategy, learning_rate=0.1)
+eng = Engine(F, H, 800, dtype=precision, triplet=strategy, learning_rate=0.1)
 if cfg == "c2":
     eng.upload_csr(m)
 else:
     eng.upload_dense(np.ascontiguousarray(m.toarray(), dtype=np.float32))
 eng.set_params(xavier_uniform(F, H))
 stats = torch.zeros((2, 8), device="cuda")
+# class-sorted batches, as fit() and bench.py stage them (utils.class_sort_batches): the miner takes its class-range path
+rows = [np.arange(b * 800, b * 800 + 800) for b in range(2)]
+rows = [r[np.argsort(lab[r], kind="stable")] for r in rows]
 for s in range(steps):
-    idx = torch.arange((s % 2) * 800, (s % 2) * 800 + 800, dtype=torch.int32, device="cuda")
-    labs = torch.from_numpy(lab[(s % 2) * 800:(s % 2) * 800 + 800]).cuda()
+    idx = torch.from_numpy(rows[s % 2].astype(np.int32)).cuda()
+    labs = torch.from_numpy(lab[rows[s % 2]]).cuda()
     eng.train_step(idx, labs if strategy != "none" else None, stats[s % 2], corr_mode=L.CORR_PHILOX_MASK, seed=1, rng_stream=s, corr_frac=0.3, phase=3)
 torch.cuda.synchronize()
 st = stats.cpu().numpy()
-print("done cost/ae/triplet", st[0, :3], "mean_n_valid", float(st[:, 5].mean()))
+print("precision", precision, "done cost/ae/triplet", st[0, :3], "mean_n_valid", float(st[:, 5].mean()))
