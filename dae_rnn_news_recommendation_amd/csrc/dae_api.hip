@@ -126,6 +126,7 @@ struct dae_plan {
     // split-bf16 mode, product terms that the 20-step curve does not need (tools/precision_study.py --per-term, profiles/r04_precision_terms.txt):
     bool x3_dec_wlo;                 // option "x3_dec_wlo": decode also multiplies (h_hi, W_lo)  [default off: z2 = h_hi.W_hi + h_lo.W_hi]
     bool x3_dh_hlo;                  // option "x3_dh_hlo": dh also multiplies (Gs, h^T_lo)       [default off: Gs.h^T_hi only]
+    bool dw_pair_ok;                 // option "dw_pair": split-bf16 dW kernel streams x~^T resp. delta2^T_hi ONCE for the hi and lo image of delta1^T resp. h^T
     bool xct2_clean;
     uint32_t* xtb;                   // x~^T as a bit image [Fp x Bpm/32] (binary CSR + bf16: operand of the sparse half of the dW kernel)
     bool xtb_clean;                  // the bit image holds only zeros (every step clears what it set; see step_tail_kernel)
@@ -266,6 +267,7 @@ extern "C" int dae_plan_create(const dae_config* cfg, dae_plan** out) {
     // split-bf16 mode on dense-ndarray input: the encode contraction has 3 K segments and dh 5; the 256 x 256 kernel is taken exactly when the
     // launch is handed ITS slice count for the real K-tile total, so these are planned with the segment lists' totals
     p->x3_dec_wlo = false; p->x3_dh_hlo = false;
+    p->dw_pair_ok = true;
     plan_x3_splits(p);
     if (p->s_gram > p->Hp * 4 / 128) p->s_gram = p->Hp * 4 / 128;
     p->gram_split = (cfg->dtype == DAE_BF16) && (p->x3 || cfg->triplet == DAE_TRIPLET_BATCH_ALL || cfg->triplet == DAE_TRIPLET_BATCH_HARD);   // x3: hcat_a also holds the row-major h_lo
@@ -310,6 +312,7 @@ extern "C" int dae_plan_set_option(dae_plan* p, const char* name, int32_t value)
     else if (!strcmp(name, "x_bits")) p->xbits_ok = on && p->cfg.dtype == DAE_BF16;
     else if (!strcmp(name, "fused_opt")) p->fuse_opt_ok = on;
     else if (!strcmp(name, "dw_bits")) p->dw_bits_ok = on;
+    else if (!strcmp(name, "dw_pair")) p->dw_pair_ok = on;
     else if (!strcmp(name, "encode_w32")) p->enc_w32_ok = on && p->cfg.dtype == DAE_BF16;
     else if (!strcmp(name, "encode_w32_cols")) { DAE_CHECK_ARG(value == 64 || value == 128, "plan_set_option: encode_w32_cols is 64 or 128"); p->w32_cols = value; }
     else if (!strcmp(name, "tail")) p->tail_ok = on;
@@ -729,7 +732,7 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
         }
         if (x3) {   // x~^T.(d1_hi + d1_lo) + (d2^T_hi, h^T_hi) (d2^T_hi, h^T_lo) (d2^T_lo, h^T_hi); the epilogue writes both parts of both shadows
             oe.W_lo2 = p->x3_dec_wlo ? p->W_lo2 : nullptr; oe.Wt_lo2 = p->Wt_lo2;     // W_lo2 feeds the decode's (h_hi, W_lo) term only
-            PROF(PS_DW_GEMM, launch_dw_opt_n(Fp, Hp, ws3, 6, oe, st));
+            PROF(PS_DW_GEMM, launch_dw_opt_n(Fp, Hp, ws3, 6, oe, st, p->dw_pair_ok));
         } else if (dw_bits) {
             DwBitsArgs xa{p->xtb, ldB / 32, s->scale};
             PROF(PS_DW_GEMM, launch_dw_opt(Fp, Hp, nullptr, ldB, p->delta1_t, ldB, Bp, p->delta2_t, ldB, p->h_t, ldB, Bp, oe, st, &xa));

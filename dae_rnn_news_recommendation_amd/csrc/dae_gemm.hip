@@ -53,6 +53,7 @@ struct GemmSeg {
 constexpr int GEMM_MAX_SEG = 6;    // K segments of one contraction: split-bf16 operands need (hi,hi) (hi,lo) (lo,hi) per product (dW with a valued x~^T: 2 x 3)
 struct GemmParams {
     GemmSeg seg[GEMM_MAX_SEG];
+    const char* bt2[GEMM_MAX_SEG];   // gemm_dw_pc<PAIR> only: a second Bt operand of the segment (same leading dimension) that shares its A tiles, or NULL
     int nseg;                  // non-empty segments, walked in order
     int ktiles_total;
     int tiles_m, tiles_n, splits;
@@ -749,6 +750,11 @@ constexpr int DW_RING = DW_NST * DW_STAGE;                             // 144 Ki
 constexpr int DW_GRAD_ONLY = DW_OPT_GRAD_ONLY;                         // OPT value: gradient to memory, no update
 constexpr int DW_LDS = DW_RING;
 constexpr int DWB_MAXKT = 16;                                          // XBITS: K tiles of the x~^T segment (Bp <= 1024)
+// PAIR (split-bf16 mode): a stage holds ONE A tile and TWO B tiles (A . [B_hi ; B_lo]: the hi and lo images of delta1^T resp. h^T share the
+// x~^T resp. delta2^T_hi tile), so the pair costs one A stream, 7 fragment reads per 10 MFMAs instead of 12, and one barrier instead of two
+constexpr int DW_STAGE2 = DW_A_BYTES + 2 * TILE_BYTES;                 // 52 KiB
+constexpr int DW_NST2 = 3;
+constexpr int DW_RING2 = DW_NST2 * DW_STAGE2;                          // 156 KiB
 
 struct DwBits {
     const uint32_t* xtb; int64_t ldxt;       // x~^T bit image [Mrows x ldxt words]
@@ -767,13 +773,39 @@ __device__ __forceinline__ void wait_vm_n(int n) {   // counted vmcnt wait for t
         case 17: wait_vm<17>(); break;
         case 18: wait_vm<18>(); break;
         case 22: wait_vm<22>(); break;
-        default: wait_vm<27>(); break;
+        case 26: wait_vm<26>(); break;
+        case 27: wait_vm<27>(); break;
+        default: wait_vm<0>(); break;                    // an op count nobody planned for: drain (always correct)
     }
 }
 
-template <int OPT, bool XBITS, bool X3 = false>      // X3 (split-bf16 mode): the lo images of both shadows are written too (e.W_lo2 / e.Wt_lo2)
+template <int OPT, bool XBITS, bool X3 = false, bool PAIR = false>      // X3 (split-bf16 mode): the lo images of both shadows are written too (e.W_lo2 / e.Wt_lo2)
 __global__ __launch_bounds__(PC_THREADS, 1) void gemm_dw_pc(GemmParams p, OptEpi e, int Mrows, DwBits xb) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    static_assert(!PAIR || (X3 && !XBITS), "paired stages exist for the split-bf16 contraction on dense operand images");
+    constexpr int STG = PAIR ? DW_STAGE2 : DW_STAGE;                        // bytes per ring stage
+    constexpr int NSTG = PAIR ? DW_NST2 : DW_NST;                           // ring depth
+    // PAIR: does K tile t belong to a segment with a second B operand?  (uniform; a walk over <= 6 segments)
+    // (segment ends and pair flags are read from the kernel arguments ONCE, with static indices: the K loops call pair_of() every iteration and a
+    // scalar load there would put an s_waitcnt lgkmcnt(0) in front of the counted fragment waits)
+    int seg_end_[GEMM_MAX_SEG];
+    uint32_t pairbits = 0u;
+    if constexpr (PAIR) {
+        int base = 0;
+#pragma unroll
+        for (int sgi = 0; sgi < GEMM_MAX_SEG; ++sgi) {
+            base += sgi < p.nseg ? p.seg[sgi].ktiles : 0;
+            seg_end_[sgi] = base;
+            if (sgi < p.nseg && p.bt2[sgi] != nullptr) pairbits |= 1u << sgi;
+        }
+    }
+    auto pair_of = [&](int t) -> bool {
+        if constexpr (!PAIR) return false;
+        int sg = 0;
+#pragma unroll
+        for (int sgi = 0; sgi + 1 < GEMM_MAX_SEG; ++sgi) sg += t >= seg_end_[sgi] ? 1 : 0;
+        return ((pairbits >> sg) & 1u) != 0u;
+    };
     // XCD-banded tile map: XCD x = b % 8 owns 8 consecutive row tiles (all column tiles), so a band's A panel is read from
     // HBM by one XCD and re-used from its L2 by the 4 column tiles
     const int b = blockIdx.x, xcd = b & 7, l = b >> 3;
@@ -846,12 +878,13 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_dw_pc(GemmParams p, OptEpi
             }
         }
         uint32_t voA[5], voB[4];
-        const char *gA = nullptr, *gB = nullptr;
+        const char *gA = nullptr, *gB = nullptr, *gB2 = nullptr;
         int kt_dma = 0, seg_end = 0;
         auto seg_setup = [&](int kt) {
             int k;
             const int sg = seg_locate(p, kt, k, seg_end);
             const uint32_t lda = (uint32_t)p.seg[sg].lda_b, ldb = (uint32_t)p.seg[sg].ldb_b;
+            if constexpr (PAIR) gB2 = p.bt2[sg] ? p.bt2[sg] + (int64_t)k * BKB : nullptr;
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
                 const int row = (i * 4 + wave) * 8 + (lane >> 3);
@@ -918,26 +951,34 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_dw_pc(GemmParams p, OptEpi
             for (int i = 0; i < 4; ++i)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gB + voB[i]),
                                                  (__attribute__((address_space(3))) void*)(slot + DW_A_BYTES + (i * 4 + wave) * 1024), 16, 0, 0);
+            if constexpr (PAIR) {
+                if (gB2) {                                                  // the segment's second B tile (same rows, same leading dimension)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gB2 + voB[i]),
+                                                         (__attribute__((address_space(3))) void*)(slot + DW_A_BYTES + TILE_BYTES + (i * 4 + wave) * 1024), 16, 0, 0);
+                }
+            }
             if (built) build_a(slot);
             ++kt_dma;
             if (kt_dma == seg_end) { if (kt_dma < p.ktiles_total) seg_setup(kt_dma); }
-            else { gA += BKB; gB += BKB; }
+            else { gA += BKB; gB += BKB; if constexpr (PAIR) { if (gB2) gB2 += BKB; } }
         };
-        auto ops = [&](int st) { return st >= nk ? 0 : ((XBITS && st < nk0) ? 4 : 9); };   // LDS-DMA pieces of stage st (per wave)
+        auto ops = [&](int st) { return st >= nk ? 0 : ((XBITS && st < nk0) ? 4 : (pair_of(st) ? 13 : 9)); };   // LDS-DMA pieces of stage st (per wave)
 #pragma unroll
-        for (int st = 0; st < DW_NST; ++st)
-            if (st < nk) dma_stage(lds + st * DW_STAGE);
-        wait_vm_n(ops(1) + ops(2) + ops(3));                                // stage 0 landed (older plain loads return first)
+        for (int st = 0; st < NSTG; ++st)
+            if (st < nk) dma_stage(lds + st * STG);
+        wait_vm_n(ops(1) + ops(2) + (PAIR ? 0 : ops(3)));                   // stage 0 landed (older plain loads return first)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // ... and every A tile built so far is written
         __builtin_amdgcn_s_barrier();
         int cur = 0;
         for (int i = 0; i < nk; ++i) {
-            wait_vm_n(ops(i + 2) + ops(i + 3));                             // stage i+1 landed; younger stages stay in flight
+            wait_vm_n(ops(i + 2) + (PAIR ? 0 : ops(i + 3)));                // stage i+1 landed; younger stages stay in flight
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (i + DW_NST < nk) dma_stage(lds + cur * DW_STAGE);
-            cur = cur + 1 == DW_NST ? 0 : cur + 1;
+            if (i + NSTG < nk) dma_stage(lds + cur * STG);
+            cur = cur + 1 == NSTG ? 0 : cur + 1;
         }
     } else {
         // ================= consumer =================
@@ -953,9 +994,16 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_dw_pc(GemmParams p, OptEpi
         uint32_t so[4];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) so[kk] = (uint32_t)(((kk * 2 + g) ^ swz) << 4);
-        i32x4 fa[2][DW_MB], fb[2];
-#define DAE_DW_READ(S, KK, SLOTBASE)                                                   \
+        i32x4 fa[2][DW_MB], fb[2], fb2[PAIR ? 2 : 1];
+        // PAIR: every k step also reads a fragment of the stage's SECOND B tile (for an unpaired stage: the first tile's fragment once more, never
+        // multiplied) -- the read count per step is then the same for both kinds of stage and the counted lgkmcnt waits stay compile-time
+        constexpr uint32_t kOffB2 = DW_A_BYTES + TILE_BYTES;
+        bool pair_cur = pair_of(0), pair_nxt = false;
+        uint32_t ob2_cur = (pair_cur ? kOffB2 : (uint32_t)DW_A_BYTES) + (wave * 32 + r) * BKB, ob2_nxt = ob2_cur;
+        (void)pair_nxt; (void)ob2_nxt;
+#define DAE_DW_READ(S, KK, SLOTBASE, OB2)                                              \
     fb[S] = lds_read_b128((SLOTBASE) + offb + so[KK]);                                 \
+    if constexpr (PAIR) fb2[PAIR ? S : 0] = lds_read_b128((SLOTBASE) + (OB2) + so[KK]); \
     fa[S][0] = lds_read_b128((SLOTBASE) + offa + so[KK]);                              \
     fa[S][1] = lds_read_b128_off4096((SLOTBASE) + offa + so[KK]);                      \
     fa[S][2] = lds_read_b128((SLOTBASE) + offa + 8192 + so[KK]);                       \
@@ -966,54 +1014,72 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_dw_pc(GemmParams p, OptEpi
     Mma<bf16_t>::run(fa[S][1], fb[S], acc[1]);                                         \
     Mma<bf16_t>::run(fa[S][2], fb[S], acc[2]);                                         \
     Mma<bf16_t>::run(fa[S][3], fb[S], acc[3]);                                         \
-    Mma<bf16_t>::run(fa[S][4], fb[S], acc[4]);
+    Mma<bf16_t>::run(fa[S][4], fb[S], acc[4]);                                         \
+    if constexpr (PAIR) {                                                              \
+        if (pair_cur) {                                                                \
+            Mma<bf16_t>::run(fa[S][0], fb2[PAIR ? S : 0], acc[0]);                     \
+            Mma<bf16_t>::run(fa[S][1], fb2[PAIR ? S : 0], acc[1]);                     \
+            Mma<bf16_t>::run(fa[S][2], fb2[PAIR ? S : 0], acc[2]);                     \
+            Mma<bf16_t>::run(fa[S][3], fb2[PAIR ? S : 0], acc[3]);                     \
+            Mma<bf16_t>::run(fa[S][4], fb2[PAIR ? S : 0], acc[4]);                     \
+        }                                                                              \
+    }
+#define DAE_DW_WAIT_SET()                                                              \
+    if constexpr (PAIR) asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");             \
+    else asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
 #if defined(DAE_DW_PROBE) && (DAE_DW_PROBE & 32)           // probe: the consumers only take part in the barriers
 #undef DAE_DW_READ
 #undef DAE_DW_MMA
-#define DAE_DW_READ(S, KK, SLOTBASE) fb[S] = i32x4{0, 0, 0, 0}; fa[S][0] = fa[S][1] = fa[S][2] = fa[S][3] = fa[S][4] = fb[S];
+#define DAE_DW_READ(S, KK, SLOTBASE, OB2) fb[S] = i32x4{0, 0, 0, 0}; fa[S][0] = fa[S][1] = fa[S][2] = fa[S][3] = fa[S][4] = fb[S];
 #define DAE_DW_MMA(S)
 #elif defined(DAE_DW_PROBE) && (DAE_DW_PROBE & 64)          // probe: fragment reads but no MFMAs
 #undef DAE_DW_MMA
 #define DAE_DW_MMA(S) asm volatile("" :: "v"(fa[S][0]), "v"(fa[S][1]), "v"(fa[S][2]), "v"(fa[S][3]), "v"(fa[S][4]), "v"(fb[S]));
 #elif defined(DAE_DW_PROBE) && (DAE_DW_PROBE & 128)         // probe: MFMAs on whatever the registers hold, no fragment reads
 #undef DAE_DW_READ
-#define DAE_DW_READ(S, KK, SLOTBASE) asm volatile("" : "+v"(fa[S][0]), "+v"(fa[S][1]), "+v"(fa[S][2]), "+v"(fa[S][3]), "+v"(fa[S][4]), "+v"(fb[S]));
+#define DAE_DW_READ(S, KK, SLOTBASE, OB2) asm volatile("" : "+v"(fa[S][0]), "+v"(fa[S][1]), "+v"(fa[S][2]), "+v"(fa[S][3]), "+v"(fa[S][4]), "+v"(fb[S]));
 #endif
         __builtin_amdgcn_s_barrier();                                       // stage 0 landed (producers waited for it)
         asm volatile("" ::: "memory");
-        DAE_DW_READ(0, 0, lbase)
+        DAE_DW_READ(0, 0, lbase, ob2_cur)
         __builtin_amdgcn_sched_barrier(0);
         int cur = 0;
         for (int i = 0; i < nk; ++i) {
-            const int nxt = cur + 1 == DW_NST ? 0 : cur + 1;
-            const uint32_t sb = lbase + cur * DW_STAGE, nb = lbase + nxt * DW_STAGE;
-            DAE_DW_READ(1, 1, sb)                                            // k step 1 -> set 1
-            asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");              // k step 0 (set 0) landed
+            const int nxt = cur + 1 == NSTG ? 0 : cur + 1;
+            const uint32_t sb = lbase + cur * STG, nb = lbase + nxt * STG;
+            if constexpr (PAIR) {                                           // kind of the NEXT stage (its first k step is read behind the barrier below)
+                pair_nxt = (i + 1 < nk) && pair_of(i + 1);
+                ob2_nxt = (pair_nxt ? kOffB2 : (uint32_t)DW_A_BYTES) + (wave * 32 + r) * BKB;
+            }
+            DAE_DW_READ(1, 1, sb, ob2_cur)                                   // k step 1 -> set 1
+            DAE_DW_WAIT_SET()                                                // k step 0 (set 0) landed
             __builtin_amdgcn_sched_barrier(0);
             DAE_DW_MMA(0)
             __builtin_amdgcn_sched_barrier(0);
-            DAE_DW_READ(0, 2, sb)
-            asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+            DAE_DW_READ(0, 2, sb, ob2_cur)
+            DAE_DW_WAIT_SET()
             __builtin_amdgcn_sched_barrier(0);
             DAE_DW_MMA(1)
             __builtin_amdgcn_sched_barrier(0);
-            DAE_DW_READ(1, 3, sb)
-            asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+            DAE_DW_READ(1, 3, sb, ob2_cur)
+            DAE_DW_WAIT_SET()
             __builtin_amdgcn_sched_barrier(0);
             DAE_DW_MMA(0)
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // every LDS read of tile i is done
             __builtin_amdgcn_s_barrier();                                   // slot free for the producers; stage i+1 landed
             asm volatile("" ::: "memory");
-            DAE_DW_READ(0, 0, nb)                                            // stale (never consumed) after the last tile
+            DAE_DW_READ(0, 0, nb, ob2_nxt)                                   // stale (never consumed) after the last tile
             __builtin_amdgcn_sched_barrier(0);
-            DAE_DW_MMA(1)
+            DAE_DW_MMA(1)                                                    // (k step 3 of tile i: pair_cur is still tile i's)
             __builtin_amdgcn_sched_barrier(0);
             cur = nxt;
+            if constexpr (PAIR) { pair_cur = pair_nxt; ob2_cur = ob2_nxt; }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #undef DAE_DW_READ
 #undef DAE_DW_MMA
+#undef DAE_DW_WAIT_SET
     }
     __builtin_amdgcn_s_barrier();                                           // B1: every wave is out of the K loop; the ring is dead
     asm volatile("" ::: "memory");
@@ -1023,7 +1089,8 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_dw_pc(GemmParams p, OptEpi
     //      the transposed shadow is staged in a second LDS tile and leaves in 16-byte pieces ----
     float* Gt = reinterpret_cast<float*>(lds);                              // [160][128] fp32 (80 KiB)
     char* R1 = lds + DW_BM * 128 * 4;                                       // Wt_lo tile  [128][DW_P1] (42 KiB)
-    static_assert(DW_BM * 128 * 4 + 128 * DW_P1 <= DW_RING, "the epilogue tiles must fit the dead ring");
+    static_assert(DW_BM * 128 * 4 + 128 * DW_P1 <= DW_RING && DW_BM * 128 * 4 + 128 * DW_P1 <= DW_RING2, "the epilogue tiles must fit the dead ring");
+    static_assert(DW_RING2 <= 160 * 1024, "the paired ring must fit the CU's LDS");
     if (wave8 < 4) {
         const int lcol = wave8 * 32 + c;
 #pragma unroll
@@ -1711,6 +1778,7 @@ static int fill_params_n(GemmParams& p, int dtype, int M, int N, const GemmSegDe
     DAE_CHECK_ARG(segs && nsegs >= 1 && nsegs <= GEMM_MAX_SEG, "gemm: %d K segments (1..%d)", nsegs, GEMM_MAX_SEG);
     DAE_CHECK_ARG(segs[0].K > 0, "gemm: the first K segment is empty");
     memset(p.seg, 0, sizeof(p.seg));
+    memset(p.bt2, 0, sizeof(p.bt2));
     p.nseg = 0; p.ktiles_total = 0;
     for (int i = 0; i < nsegs; ++i) {
         const GemmSegDesc& d = segs[i];
@@ -1991,9 +2059,28 @@ int launch_dw_opt(int M, int N, const void* A0, int64_t lda0, const void* Bt0, i
 // dW GEMM + optimizer in split-bf16 mode: the contraction runs over up to 5 K segments (x~^T.delta1_hi, x~^T.delta1_lo, delta2^T_hi.h^T_hi,
 // delta2^T_hi.h^T_lo, delta2^T_lo.h^T_hi) and the epilogue also writes the lo images of both shadows (e.W_lo2, e.Wt_lo2).  One-round
 // 160 x 128 kernel only (the shapes whose tiles fill the chip once); other shapes are refused for now.
-int launch_dw_opt_n(int M, int N, const GemmSegDesc* segs, int nsegs, const OptEpi& e, hipStream_t st) {
+int launch_dw_opt_n(int M, int N, const GemmSegDesc* segs_in, int nsegs_in, const OptEpi& e, hipStream_t st, bool pair) {
+    // pair: consecutive non-empty segments that share their A operand (x~^T . [delta1^T_hi ; delta1^T_lo], delta2^T_hi . [h^T_hi ; h^T_lo]) become ONE
+    // segment with two B operands (GemmParams::bt2): the kernel streams the A tile once and multiplies it with both B tiles of the stage
+    DAE_CHECK_ARG(segs_in && nsegs_in >= 1 && nsegs_in <= GEMM_MAX_SEG, "dw_opt_n: %d K segments (1..%d)", nsegs_in, GEMM_MAX_SEG);
+    GemmSegDesc segs[GEMM_MAX_SEG];
+    const void* second[GEMM_MAX_SEG];
+    int nsegs = 0;
+    for (int i = 0; i < nsegs_in; ++i) {
+        if (segs_in[i].K == 0) continue;
+        if (pair && nsegs > 0 && !second[nsegs - 1] && segs[nsegs - 1].A == segs_in[i].A && segs[nsegs - 1].lda == segs_in[i].lda &&
+            segs[nsegs - 1].ldb == segs_in[i].ldb && segs[nsegs - 1].K == segs_in[i].K && ((uintptr_t)segs_in[i].Bt % 16) == 0) {
+            second[nsegs - 1] = segs_in[i].Bt;
+            continue;
+        }
+        segs[nsegs] = segs_in[i]; second[nsegs] = nullptr; ++nsegs;
+    }
+    DAE_CHECK_ARG(nsegs >= 1, "dw_opt_n: every K segment is empty");
     GemmParams p;
     if (int rc = fill_params_n(p, DAE_BF16, M, N, segs, nsegs, 1)) return rc;
+    DAE_CHECK_ARG(p.nseg == nsegs, "dw_opt_n: segment bookkeeping");
+    bool any_pair = false;
+    for (int i = 0; i < nsegs; ++i) { p.bt2[i] = (const char*)second[i]; any_pair = any_pair || second[i]; }
     if (int rc = gemm_init()) return rc;
     DAE_CHECK_ARG(e.W && e.W_lo && e.Wt_lo && e.Wt_lo2 && e.ldw >= N && e.ldwt >= M && e.ldw % 8 == 0 && e.ldwt % 8 == 0,
                   "dw_opt_n: bad parameter images (split-bf16 mode needs Wt_lo2; W_lo2 is optional)");
@@ -2005,18 +2092,21 @@ int launch_dw_opt_n(int M, int N, const GemmSegDesc* segs, int nsegs, const OptE
     DAE_CHECK_ARG(g_dw_pc && k64 && 8 * per * tiles_n <= g_cus,
                   "dw_opt_n: the split-bf16 dW kernel runs shapes of at most one 160 x 128 tile per CU (M=%d N=%d)", M, N);
     typedef void (*dwpc_fn)(GemmParams, OptEpi, int, DwBits);
-    static const dwpc_fn x3s[4] = {gemm_dw_pc<DAE_OPT_SGD, false, true>, gemm_dw_pc<DAE_OPT_ADAGRAD, false, true>,
-                                   gemm_dw_pc<DAE_OPT_MOMENTUM, false, true>, gemm_dw_pc<DAE_OPT_ADAM, false, true>};
+    static const dwpc_fn x3s[2][4] = {{gemm_dw_pc<DAE_OPT_SGD, false, true>, gemm_dw_pc<DAE_OPT_ADAGRAD, false, true>,
+                                       gemm_dw_pc<DAE_OPT_MOMENTUM, false, true>, gemm_dw_pc<DAE_OPT_ADAM, false, true>},
+                                      {gemm_dw_pc<DAE_OPT_SGD, false, true, true>, gemm_dw_pc<DAE_OPT_ADAGRAD, false, true, true>,
+                                       gemm_dw_pc<DAE_OPT_MOMENTUM, false, true, true>, gemm_dw_pc<DAE_OPT_ADAM, false, true, true>}};
     static int rc3 = [] {
         int rc = 0;
-        for (dwpc_fn f : x3s) rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS);
+        for (dwpc_fn f : x3s[0]) rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS);
+        for (dwpc_fn f : x3s[1]) rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, DW_RING2);
         return rc;
     }();
     DAE_CHECK_ARG(rc3 == 0, "dw_opt_n: hipFuncSetAttribute failed");
     GemmParams q = p;
     q.tiles_m = tiles_m; q.tiles_n = tiles_n;
     DwBits xb; memset(&xb, 0, sizeof(xb));
-    hipLaunchKernelGGL(x3s[e.opt], dim3(8 * per * tiles_n), dim3(PC_THREADS), DW_LDS, st, q, e, M, xb);
+    hipLaunchKernelGGL(x3s[any_pair ? 1 : 0][e.opt], dim3(8 * per * tiles_n), dim3(PC_THREADS), any_pair ? DW_RING2 : DW_LDS, st, q, e, M, xb);
     DAE_CHECK_LAUNCH();
     return 0;
 }

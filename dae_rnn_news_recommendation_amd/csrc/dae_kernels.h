@@ -145,7 +145,8 @@ bool dw_x3_fits(int M, int N, int Bp);       // split-bf16 mode: can launch_dw_o
 // xa != NULL: segment 0 is x~^T (bit image, A0 ignored) . Bt0 = delta1^T; segment 1 = delta2^T . h^T as usual
 int launch_dw_opt(int M, int N, const void* A0, int64_t lda0, const void* Bt0, int64_t ldb0, int K0, const void* A1, int64_t lda1,
                   const void* Bt1, int64_t ldb1, int K1, const OptEpi& e, hipStream_t st, const DwBitsArgs* xa = nullptr);
-int launch_dw_opt_n(int M, int N, const GemmSegDesc* segs, int nsegs, const OptEpi& e, hipStream_t st);   // split-bf16 mode (e.W_lo2 / e.Wt_lo2 set)
+// split-bf16 mode (e.Wt_lo2 set, e.W_lo2 optional); pair: segments that share their A operand run as paired stages (one A tile, two B tiles)
+int launch_dw_opt_n(int M, int N, const GemmSegDesc* segs, int nsegs, const OptEpi& e, hipStream_t st, bool pair = false);
 void set_use_glds(int nst);
 void set_gather_tile(int v);          // dense gather tile: bit 0 = 128 features (else 64), bit 1 = 128 rows (else 64)
 int launch_gemm_trace(int dtype, int M, int N, const void* A0, int64_t lda0, const void* Bt0, int64_t ldb0, int K0, const void* A1,

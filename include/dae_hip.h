@@ -444,7 +444,9 @@ int      dae_plan_sync_shadows(dae_plan* p, void* stream);
  * per workgroup of that kernel), "x3_dec_wlo" / "x3_dh_hlo" (split-bf16 mode, before dae_plan_bind only: 1 = the decode also multiplies
  * (h_hi, W_lo) resp. the dh GEMM also multiplies (Gs, h^T_lo) -- the two product terms the 20-step loss curve does not need
  * (tools/precision_study.py --per-term, profiles/r04_precision_terms.txt); default 0, and the dW epilogue then skips the lo image of the
- * row-major shadow, which only that decode term reads).  Unknown names are an error. */
+ * row-major shadow, which only that decode term reads), "dw_pair" (split-bf16 mode: the dW kernel runs the K segments that share their A operand
+ * -- x~^T . [delta1^T_hi ; delta1^T_lo], delta2^T_hi . [h^T_hi ; h^T_lo] -- as paired ring stages of one A tile and two B tiles; default 1, 0 = one
+ * segment after the other).  Unknown names are an error. */
 int      dae_plan_set_option(dae_plan* p, const char* name, int32_t value);
 int      dae_train_step(dae_plan* p, const dae_step* step, void* stream);
 int      dae_plan_apply(dae_plan* p, int32_t adam_t, float grad_scale, void* stream);

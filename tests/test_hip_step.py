@@ -178,6 +178,25 @@ def test_step_bf16x3_all_terms_option(dense):
         assert _rel(u, np.asarray(v, np.float64)) < 1e-4
 
 
+@pytest.mark.parametrize("scale,opt", [(1.0, "gradient_descent"), (0.7, "adam")])
+def test_step_bf16x3_dw_pair_option(scale, opt):
+    """Split-bf16 dW kernel: by default the segments that share their A operand run as PAIRED stages (x~^T resp. delta2^T_hi streamed once for the hi
+    and the lo image of delta1^T resp. h^T: one A tile + two B tiles per ring stage); option dw_pair = 0 walks them one after the other.  Same
+    products, another accumulation order: both at the oracle and next to each other.  scale 0.7: x~ gets a lo image, an unpaired stage sits between the pairs."""
+    a, _, pa = _run_case("bf16x3", "batch_all", "cross_entropy", ("sigmoid", "sigmoid"), opt, steps=3, seed=21, scale=scale)
+    b, _, pb = _run_case("bf16x3", "batch_all", "cross_entropy", ("sigmoid", "sigmoid"), opt, steps=3, seed=21, scale=scale, options={"dw_pair": 0})
+    for out in (a, b):
+        for r, st, dW, dbh, dbv in out:
+            assert abs(st[0] - r["cost"]) <= (2e-5 if opt == "gradient_descent" else 1e-4) * abs(r["cost"]), (st[0], r["cost"])
+            assert _rel(dW, r["dW"]) < 1e-4, _rel(dW, r["dW"])
+    for (_, sa, dWa, *_), (_, sb, dWb, *_) in zip(a, b):
+        assert np.allclose(sa[:3], sb[:3], rtol=5e-6, atol=0), (sa, sb)
+        assert _rel(dWa, np.asarray(dWb, np.float64)) < 1e-5
+    if opt == "gradient_descent":
+        for u, v in zip(pa, pb):
+            assert _rel(u, np.asarray(v, np.float64)) < 1e-5
+
+
 def test_step_bf16x3_shape_beyond_one_dw_round():
     """A W of more 160 x 128 tiles than the chip has CUs (5120 x 1280 -> 320): the split-bf16 step takes the N-segment dW GEMM to memory +
     the optimizer kernel that writes all four shadow images instead of refusing the shape."""
