@@ -123,9 +123,11 @@ struct dae_plan {
     char *W_lo2, *Wt_lo2, *h_t2, *delta2_2, *delta2_t2, *delta1_t2;
     char *x_2, *xct_2, *xc_2;         // ... and of the clean rows x / of x~^T / of x~ (dense input), used when the input values (or the corruption scale) are not exact in bf16
     int s_enc3, s_dh3;               // split-K slice counts of the dense-input encode / dh GEMMs in split-bf16 mode (3 resp. 4-5 K segments)
-    // split-bf16 mode, product terms that the 20-step curve does not need (tools/precision_study.py --per-term, profiles/r04_precision_terms.txt):
-    bool x3_dec_wlo;                 // option "x3_dec_wlo": decode also multiplies (h_hi, W_lo)  [default off: z2 = h_hi.W_hi + h_lo.W_hi]
-    bool x3_dh_hlo;                  // option "x3_dh_hlo": dh also multiplies (Gs, h^T_lo)       [default off: Gs.h^T_hi only]
+    // split-bf16 mode, the two lo product terms a CPU replay of the 20-step curve called droppable (tools/precision_study.py --per-term: cost 2.5e-5,
+    // triplet 4.4e-5).  Measured on the GPU against the frozen reference curve, dropping them leaves the gate: cost 7.0e-5, triplet 1.56e-4
+    // (profiles/r04_precision_terms.txt) -- so both stay ON; the options exist for that measurement (decode 57.9 -> 48.3 us without its term)
+    bool x3_dec_wlo;                 // option "x3_dec_wlo" (default 1): decode multiplies (h_hi, W_lo) too; 0: z2 = h_hi.W_hi + h_lo.W_hi
+    bool x3_dh_hlo;                  // option "x3_dh_hlo" (default 1): dh multiplies (Gs, h^T_lo) too; 0: Gs.h^T_hi only
     bool dw_pair_ok;                 // option "dw_pair": split-bf16 dW kernel streams x~^T resp. delta2^T_hi ONCE for the hi and lo image of delta1^T resp. h^T
     bool xct2_clean;
     uint32_t* xtb;                   // x~^T as a bit image [Fp x Bpm/32] (binary CSR + bf16: operand of the sparse half of the dW kernel)
@@ -266,7 +268,7 @@ extern "C" int dae_plan_create(const dae_config* cfg, dae_plan** out) {
     if (p->s_dh > kt_f) p->s_dh = kt_f;
     // split-bf16 mode on dense-ndarray input: the encode contraction has 3 K segments and dh 5; the 256 x 256 kernel is taken exactly when the
     // launch is handed ITS slice count for the real K-tile total, so these are planned with the segment lists' totals
-    p->x3_dec_wlo = false; p->x3_dh_hlo = false;
+    p->x3_dec_wlo = true; p->x3_dh_hlo = true;
     p->dw_pair_ok = true;
     plan_x3_splits(p);
     if (p->s_gram > p->Hp * 4 / 128) p->s_gram = p->Hp * 4 / 128;
@@ -511,7 +513,8 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     // split-bf16 mode: the fused dW + optimizer kernel exists for shapes of at most one 160 x 128 tile per CU; larger shapes (and the
     // data-parallel gradient-only phases) take the N-segment dW GEMM to memory + the optimizer kernel that writes all four shadows
     const bool fuse_opt = fuse_opt0 && (!x3 || dw_x3_fits(Fp, Hp, Bp));
-    const bool dw_pc_grad = backward && !apply_now && dt == DAE_BF16 && !x3 && p->fuse_opt_ok && dw_bits_fits(Fp, Hp, Bp);
+    // (split-bf16 mode: the gradient-only form of the same N-segment kernel, fp32 gradient to the flat buffer)
+    const bool dw_pc_grad = backward && !apply_now && dt == DAE_BF16 && p->fuse_opt_ok && (x3 ? dw_x3_fits(Fp, Hp, Bp) : dw_bits_fits(Fp, Hp, Bp));
     const bool dw_bits = p->dw_bits_ok && use_sparse && src_binary && backward && dt == DAE_BF16 && (fuse_opt || dw_pc_grad) &&
                            dw_bits_fits(Fp, Hp, Bp);
     if (x3) {

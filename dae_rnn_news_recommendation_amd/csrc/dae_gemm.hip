@@ -2082,20 +2082,27 @@ int launch_dw_opt_n(int M, int N, const GemmSegDesc* segs_in, int nsegs_in, cons
     bool any_pair = false;
     for (int i = 0; i < nsegs; ++i) { p.bt2[i] = (const char*)second[i]; any_pair = any_pair || second[i]; }
     if (int rc = gemm_init()) return rc;
-    DAE_CHECK_ARG(e.W && e.W_lo && e.Wt_lo && e.Wt_lo2 && e.ldw >= N && e.ldwt >= M && e.ldw % 8 == 0 && e.ldwt % 8 == 0,
-                  "dw_opt_n: bad parameter images (split-bf16 mode needs Wt_lo2; W_lo2 is optional)");
-    DAE_CHECK_ARG(e.opt >= DAE_OPT_SGD && e.opt <= DAE_OPT_ADAM && (e.opt == DAE_OPT_SGD || e.s1) && (e.opt != DAE_OPT_ADAM || e.s2),
-                  "dw_opt_n: optimizer slots missing");
+    const bool grad_only = e.opt == DW_GRAD_ONLY;      // data parallel: the fp32 gradient goes to memory (e.grad), nothing is updated
+    if (grad_only) {
+        DAE_CHECK_ARG(e.grad && !e.grad_lo && e.ldw >= N && e.ldw % 8 == 0, "dw_opt_n: the gradient-only form of split-bf16 mode writes the fp32 image e.grad");
+    } else {
+        DAE_CHECK_ARG(e.W && e.W_lo && e.Wt_lo && e.Wt_lo2 && e.ldw >= N && e.ldwt >= M && e.ldw % 8 == 0 && e.ldwt % 8 == 0,
+                      "dw_opt_n: bad parameter images (split-bf16 mode needs Wt_lo2; W_lo2 is optional)");
+        DAE_CHECK_ARG(e.opt >= DAE_OPT_SGD && e.opt <= DAE_OPT_ADAM && (e.opt == DAE_OPT_SGD || e.s1) && (e.opt != DAE_OPT_ADAM || e.s2),
+                      "dw_opt_n: optimizer slots missing");
+    }
     const int tiles_m = (M + DW_BM - 1) / DW_BM, tiles_n = N / BN, per = (tiles_m + 7) / 8;
     bool k64 = true;
     for (int i = 0; i < nsegs; ++i) k64 = k64 && segs[i].K % 64 == 0;
     DAE_CHECK_ARG(g_dw_pc && k64 && 8 * per * tiles_n <= g_cus,
                   "dw_opt_n: the split-bf16 dW kernel runs shapes of at most one 160 x 128 tile per CU (M=%d N=%d)", M, N);
     typedef void (*dwpc_fn)(GemmParams, OptEpi, int, DwBits);
-    static const dwpc_fn x3s[2][4] = {{gemm_dw_pc<DAE_OPT_SGD, false, true>, gemm_dw_pc<DAE_OPT_ADAGRAD, false, true>,
-                                       gemm_dw_pc<DAE_OPT_MOMENTUM, false, true>, gemm_dw_pc<DAE_OPT_ADAM, false, true>},
+    static const dwpc_fn x3s[2][5] = {{gemm_dw_pc<DAE_OPT_SGD, false, true>, gemm_dw_pc<DAE_OPT_ADAGRAD, false, true>,
+                                       gemm_dw_pc<DAE_OPT_MOMENTUM, false, true>, gemm_dw_pc<DAE_OPT_ADAM, false, true>, gemm_dw_pc<DW_GRAD_ONLY, false, true>},
                                       {gemm_dw_pc<DAE_OPT_SGD, false, true, true>, gemm_dw_pc<DAE_OPT_ADAGRAD, false, true, true>,
-                                       gemm_dw_pc<DAE_OPT_MOMENTUM, false, true, true>, gemm_dw_pc<DAE_OPT_ADAM, false, true, true>}};
+                                       gemm_dw_pc<DAE_OPT_MOMENTUM, false, true, true>, gemm_dw_pc<DAE_OPT_ADAM, false, true, true>,
+                                       gemm_dw_pc<DW_GRAD_ONLY, false, true, true>}};
+    static_assert(DW_GRAD_ONLY == 4, "the gradient-only instantiation sits at index 4");
     static int rc3 = [] {
         int rc = 0;
         for (dwpc_fn f : x3s[0]) rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS);

@@ -441,10 +441,10 @@ int      dae_plan_sync_shadows(dae_plan* p, void* stream);
  * (batch_all workgroups = one resident round, each walking the anchor list in snake order; 0 = one workgroup per anchor), "encode_w32" (bf16 mode: the
  * sparse encode reads the fp32 master weights, so h -- and with the split-bf16 Gram matrix the triplet leg -- is fp32-accurate; default
  * on; a sharded-optimizer exchange must turn it off because only W_lo is current on every rank), "encode_w32_cols" (128 | 64 columns
- * per workgroup of that kernel), "x3_dec_wlo" / "x3_dh_hlo" (split-bf16 mode, before dae_plan_bind only: 1 = the decode also multiplies
- * (h_hi, W_lo) resp. the dh GEMM also multiplies (Gs, h^T_lo) -- the two product terms the 20-step loss curve does not need
- * (tools/precision_study.py --per-term, profiles/r04_precision_terms.txt); default 0, and the dW epilogue then skips the lo image of the
- * row-major shadow, which only that decode term reads), "dw_pair" (split-bf16 mode: the dW kernel runs the K segments that share their A operand
+ * per workgroup of that kernel), "x3_dec_wlo" / "x3_dh_hlo" (split-bf16 mode, before dae_plan_bind only, default 1: the decode multiplies
+ * (h_hi, W_lo) and the dh GEMM (Gs, h^T_lo) too; 0 drops the term -- a CPU replay of the 20-step curve called both droppable, the GPU run against
+ * the frozen reference curve then measured cost 7.0e-5 / triplet 1.56e-4, outside the 1e-4 gate, so they stay on: profiles/r04_precision_terms.txt;
+ * with x3_dec_wlo = 0 the dW epilogue skips the lo image of the row-major shadow, which only that decode term reads), "dw_pair" (split-bf16 mode: the dW kernel runs the K segments that share their A operand
  * -- x~^T . [delta1^T_hi ; delta1^T_lo], delta2^T_hi . [h^T_hi ; h^T_lo] -- as paired ring stages of one A tile and two B tiles; default 1, 0 = one
  * segment after the other).  Unknown names are an error. */
 int      dae_plan_set_option(dae_plan* p, const char* name, int32_t value);

@@ -23,15 +23,16 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PATH = os.path.join(HERE, "golden", "full_curve_c2.npz")
 
 
-# bf16x3: the product default drops two lo product terms the curve does not need (decode h_hi.W_lo, dh Gs.h^T_lo: tools/precision_study.py
-# --per-term, profiles/r04_precision_terms.txt); "all terms" switches both back on (plan options x3_dec_wlo / x3_dh_hlo) -- same 1e-4 gate
-ALL_TERMS = {"x3_dec_wlo": 1, "x3_dh_hlo": 1}
+# bf16x3-dropped-terms: plan options x3_dec_wlo = 0 / x3_dh_hlo = 0 drop the two lo product terms a CPU replay of this curve called droppable
+# (decode h_hi.W_lo, dh Gs.h^T_lo: tools/precision_study.py --per-term predicted cost 2.5e-5 / triplet 4.4e-5).  Measured here: cost 7.0e-5,
+# triplet 1.56e-4 -- OUTSIDE the 1e-4 gate, which is why the product keeps all terms (profiles/r04_precision_terms.txt); the case pins that measurement
+DROPPED = {"x3_dec_wlo": 0, "x3_dh_hlo": 0}
 
 
 @pytest.mark.skipif(not os.path.exists(PATH), reason="tests/golden/full_curve_c2.npz not generated")
 @pytest.mark.parametrize("precision,tol,tol_saturated,plan_options",
-                         [("fp32", 2e-5, 2e-5, None), ("bf16", 1e-4, 6e-4, None), ("bf16x3", 1e-4, 1e-4, None), ("bf16x3", 1e-4, 1e-4, ALL_TERMS)],
-                         ids=["fp32", "bf16", "bf16x3", "bf16x3-all-terms"])
+                         [("fp32", 2e-5, 2e-5, None), ("bf16", 1e-4, 6e-4, None), ("bf16x3", 1e-4, 1e-4, None), ("bf16x3", 1e-4, 5e-4, DROPPED)],
+                         ids=["fp32", "bf16", "bf16x3", "bf16x3-dropped-terms"])
 def test_full_shape_loss_curve(tmp_path, precision, tol, tol_saturated, plan_options):
     sys.path.insert(0, os.path.join(HERE, "golden"))
     import make_full_curve as M
@@ -54,10 +55,10 @@ def test_full_shape_loss_curve(tmp_path, precision, tol, tol_saturated, plan_opt
             if key == "triplet" and precision == "bf16":
                 step = np.arange(pb.shape[0]) + e * pb.shape[0]
                 gate = np.where(step < 3, 1e-4, np.where(step == 3, 5e-4, 1e-2))
-            print(f"[curve] {precision}{' all-terms' if plan_options else ''} epoch {e} {key}: max rel {rel.max():.2e} at batch {int(rel.argmax())}")
+            print(f"[curve] {precision}{' dropped-terms' if plan_options else ''} epoch {e} {key}: max rel {rel.max():.2e} at batch {int(rel.argmax())}")
             assert (rel <= gate).all(), (precision, e, key, rel)
         if precision == "fp32":
             assert np.abs(pb[:, 4] - G["num"][e]).max() <= 200        # of ~5*10^7 positive triplets: near-ties of the fp32 Gram matrix
     W = model.engine.get_params()[0].astype(np.float64)
     got = np.array([np.abs(W).sum(), (W ** 2).sum(), W[17, 3], W[9999, 499]])
-    assert np.abs(got - G["W_checksum"]).max() <= {"fp32": 1e-5, "bf16x3": 1e-4}.get(precision, 5e-3) * np.abs(G["W_checksum"]).max()
+    assert np.abs(got - G["W_checksum"]).max() <= ({"fp32": 1e-5, "bf16x3": 1e-4}.get(precision, 5e-3) if not plan_options else 5e-3) * np.abs(G["W_checksum"]).max()

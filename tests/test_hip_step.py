@@ -161,21 +161,19 @@ def test_step_bf16x3_dense_input_matches_oracle(loss_func, acts, strategy):
 
 
 @pytest.mark.parametrize("dense", [False, True])
-def test_step_bf16x3_all_terms_option(dense):
-    """Plan options x3_dec_wlo / x3_dh_hlo = 1 restore the two lo product terms the default split-bf16 step drops (decode: h_hi.W_lo, dh:
-    Gs.h^T_lo): both forms sit at the fp64 oracle, and next to each other."""
+def test_step_bf16x3_dropped_terms_option(dense):
+    """Plan options x3_dec_wlo / x3_dh_hlo = 0 drop two lo product terms of the split-bf16 step (decode: h_hi.W_lo, dh: Gs.h^T_lo).  The step
+    still runs and stays an order of magnitude closer to the oracle than plain bf16 (2e-2), but -- with weights of this size -- no longer inside
+    1e-4 (measured 1.4e-4 .. 4.4e-4 on dW here, and 1.56e-4 on the full-shape curve: why the default keeps every term)."""
     a, ra, pa = _run_case("bf16x3", "batch_all", "cross_entropy", ("sigmoid", "sigmoid"), "gradient_descent", steps=3, seed=11, dense=dense)
     b, rb, pb = _run_case("bf16x3", "batch_all", "cross_entropy", ("sigmoid", "sigmoid"), "gradient_descent", steps=3, seed=11, dense=dense,
-                          options={"x3_dec_wlo": 1, "x3_dh_hlo": 1})
-    for out in (a, b):
+                          options={"x3_dec_wlo": 0, "x3_dh_hlo": 0})
+    for out, gate in ((a, 1e-4), (b, 2e-3)):
         for r, st, dW, dbh, dbv in out:
-            assert abs(st[0] - r["cost"]) <= 2e-5 * abs(r["cost"]), (st[0], r["cost"])
-            assert _rel(dW, r["dW"]) < 1e-4 and _rel(dbv, r["dbv"]) < 1e-4, (_rel(dW, r["dW"]), _rel(dbv, r["dbv"]))
-    for (_, sa, dWa, *_), (_, sb, dWb, *_) in zip(a, b):
-        assert np.allclose(sa[:3], sb[:3], rtol=2e-5, atol=0), (sa, sb)
-        assert _rel(dWa, np.asarray(dWb, np.float64)) < 1e-4
+            assert abs(st[0] - r["cost"]) <= max(2e-5, gate / 5) * abs(r["cost"]), (st[0], r["cost"])
+            assert _rel(dW, r["dW"]) < gate and _rel(dbv, r["dbv"]) < gate, (gate, _rel(dW, r["dW"]), _rel(dbv, r["dbv"]))
     for u, v in zip(pa, pb):
-        assert _rel(u, np.asarray(v, np.float64)) < 1e-4
+        assert _rel(u, np.asarray(v, np.float64)) < 2e-3
 
 
 @pytest.mark.parametrize("scale,opt", [(1.0, "gradient_descent"), (0.7, "adam")])
