@@ -55,6 +55,7 @@ struct GemmParams {
     GemmSeg seg[GEMM_MAX_SEG];
     const char* bt2[GEMM_MAX_SEG];   // gemm_dw_pc<PAIR> only: a second Bt operand of the segment (same leading dimension) that shares its A tiles, or NULL
     int nseg;                  // non-empty segments, walked in order
+    int epi_vec;               // gemm_nt_pc: 1 = LDS-staged epilogue (16-byte pieces, all 8 waves), 0 = dword stores from the accumulator layout (A/B)
     int ktiles_total;
     int tiles_m, tiles_n, splits;
     unsigned long long* trace;   // dae_gemm_trace only: [blocks][4 waves][8] shader-clock sums per K-loop phase
@@ -594,9 +595,10 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_nt_pc(GemmParams p, float*
     const int nk = kt1 - kt0;
     const int row0_m = tm * BM, row0_n = tn * BN;
 
+    f32x16 acc[2][2];
     if (wave8 >= 4) {
         // ================= producer =================
-        if (nk <= 0) return;
+        if (nk > 0) {
         const int wave = wave8 - 4;
         uint32_t voA[4], voB[4];
         const char *gA = nullptr, *gB = nullptr;
@@ -645,13 +647,11 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_nt_pc(GemmParams p, float*
             if (i + NST < nk) dma_stage(lds + cur * STAGE_BYTES);
             cur = cur + 1 == NST ? 0 : cur + 1;
         }
-        return;
-    }
-
+        }
+    } else {
     // ================= consumer =================
     const int wave = wave8;
     const int wm = wave >> 1, wn = wave & 1;
-    f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -704,18 +704,46 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_nt_pc(GemmParams p, float*
 #undef DAE_READ_KK
 #undef DAE_MMA4
     }
-    const int g = lane >> 5, c = lane & 31;
-    float* Cs = C + (int64_t)split * slab_stride;
+    }
+    // ---- epilogue, all 8 waves: the accumulators are parked in LDS (fp32 [128][128], 64 KiB of the dead ring; conflict-free from the accumulator
+    //      layout) and leave as 16-byte pieces of 512-byte row runs, 8 per thread.  (Before: 64 dword stores per lane from the four MFMA waves alone,
+    //      two 128-byte runs per instruction, the producer waves gone -- the slab store tail was a third of the Gram launch.)
+    if (!p.epi_vec) {                                                     // A/B (dae_set_glds(-9)): the former epilogue
+        if (wave8 < 4) {
+            const int wm = wave8 >> 1, wn = wave8 & 1, g = lane >> 5, c = lane & 31;
+            float* Cd = C + (int64_t)split * slab_stride;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+                for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int row = tm * BM + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-                int col = tn * BN + wn * 64 + nt * 32 + c;
-                Cs[(int64_t)row * ldc + col] = acc[mt][nt][r];
-            }
+                    for (int r = 0; r < 16; ++r)
+                        Cd[(int64_t)(tm * BM + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g) * ldc + tn * BN + wn * 64 + nt * 32 + c] = acc[mt][nt][r];
+        }
+        return;
+    }
+    __builtin_amdgcn_s_barrier();                                         // every wave is out of the K loop: the ring is dead (all LDS-DMA landed)
+    asm volatile("" ::: "memory");
+    float* Ct = reinterpret_cast<float*>(lds);
+    if (wave8 < 4) {
+        const int wm = wave8 >> 1, wn = wave8 & 1, g = lane >> 5, c = lane & 31;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    Ct[(wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g) * BN + wn * 64 + nt * 32 + c] = acc[mt][nt][r];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                         // the tile is complete
+    asm volatile("" ::: "memory");
+    float* Cs = C + (int64_t)split * slab_stride + (int64_t)(tm * BM) * ldc + tn * BN;
+#pragma unroll
+    for (int i = 0; i < (BM * BN / 4) / PC_THREADS; ++i) {
+        const int q = tid + PC_THREADS * i, row = q >> 5, c4 = q & 31;
+        *reinterpret_cast<f32x4*>(Cs + (int64_t)row * ldc + c4 * 4) = *reinterpret_cast<const f32x4*>(Ct + row * BN + c4 * 4);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1779,7 +1807,7 @@ static int fill_params_n(GemmParams& p, int dtype, int M, int N, const GemmSegDe
     DAE_CHECK_ARG(segs[0].K > 0, "gemm: the first K segment is empty");
     memset(p.seg, 0, sizeof(p.seg));
     memset(p.bt2, 0, sizeof(p.bt2));
-    p.nseg = 0; p.ktiles_total = 0;
+    p.nseg = 0; p.ktiles_total = 0; p.epi_vec = 0;
     for (int i = 0; i < nsegs; ++i) {
         const GemmSegDesc& d = segs[i];
         DAE_CHECK_ARG(d.K >= 0 && d.K % kel == 0, "gemm: K of segment %d = %d must be a multiple of %d", i, d.K, kel);
@@ -1841,6 +1869,7 @@ template <typename T> static pc_fn pc_kernel(int role) {
 static int g_cus = 0;        // compute units of the current device (set by gemm_init)
 static int g_dw_pc = 1;      // dW + optimizer on the 160 x 128 producer/consumer kernel when its grid fills one round (dae_set_glds(-3/-4))
 static int g_use_pc = 1;     // dae_set_glds(-1) keeps the 4-wave kernel for every grid (A/B)
+static int g_pc_vec = 1;     // gemm_nt_pc epilogue: 1 = LDS-staged 16-byte pieces (default), 0 = dword stores (dae_set_glds(-9) / (-10))
 typedef void (*decode_fn)(GemmParams, DecodeEpi);
 static decode_fn decode_kernel_xbits(int loss, int act) {
 #define DAE_DKX(LV, AV) if (loss == LV && act == AV) return gemm_decode_loss<bf16_t, LV, AV, true, DECODE_BN_BF16>;
@@ -1958,8 +1987,11 @@ int launch_gemm_f32out_n(int dtype, int M, int N, const GemmSegDesc* segs, int n
     }
     dim3 grid(grid_blocks(p)), block(GEMM_THREADS);
     const int nst = g_nst;
+    // (its epilogue writes 16-byte pieces: C, the leading dimension and the slab stride must keep them aligned -- else the 4-wave kernel's dword stores)
+    const bool c_vec_ok = ((uintptr_t)C % 16) == 0 && ldc % 4 == 0 && slab_stride % 4 == 0;
     if (nst == DEFAULT_NST && (int)grid.x <= g_cus && g_use_pc) {      // at most one workgroup per CU: producer/consumer waves
         pc_fn kp = dtype == DAE_BF16 ? pc_kernel<bf16_t>(role) : pc_kernel<float>(role);
+        p.epi_vec = (g_pc_vec && c_vec_ok) ? 1 : 0;
         LabelJob job; memset(&job, 0, sizeof(job));
         const bool with_labels = label_job && label_job->Bp <= 1024 && (int)grid.x < g_cus;      // a CU must be free for it
         if (with_labels) job = *label_job;
@@ -2419,6 +2451,8 @@ void set_use_glds(int nst) {
     if (nst == -5) { g_dw_pc = 2; return; }          // tests: the 160 x 128 kernel for every grid that fits one round
     if (nst == -6) { g_w8 = 0; return; }             // A/B: never the 256 x 256 / 8-MFMA-wave kernel
     if (nst == -7) { g_w8 = 1; return; }
+    if (nst == -9) { g_pc_vec = 0; return; }         // A/B: gemm_nt_pc stores its tile as dwords straight from the accumulators
+    if (nst == -10) { g_pc_vec = 1; return; }
     if (nst <= -1000) {                              // tests: pretend the device has (-nst - 1000) compute units, so that every CU-count-keyed
         if (gemm_init() == 0) g_cus = -nst - 1000;   // dispatch (one-round kernels, label riders, 256 x 256 slices) is exercised on any box
         return;
