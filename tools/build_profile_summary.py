@@ -20,8 +20,8 @@ SLOT_KERNEL_C4 = [("gather", "gather_dense_kernel"), ("encode_gemm", "gemm_nt_w8
                   ("decode_loss", "gemm_decode_loss"), ("dh_gemm", "gemm_nt_w8<2>"), ("dw_gemm", "gemm_dw")]
 NOTE = {"encode_gemm": "corrupt + gather + sparse x~.W (fp32 master W) + bias + act, all images of h, x bit image, x~^T scatter, label statistics",
         "gram": "split-bf16 (3 products), split-K 4", "miner": "batch_all on a 16 x 16 lane grid (FAST pair sweep), positive-triplet count from sorted runs", "sym_scale": "Gs = a/Nv (G + G^T) -> bf16",
-        "decode_loss": "128 x 64 tiles: GEMM + loss + delta2 (two layouts), x from bits", "dh_gemm": "delta2.W + Gs.h, split-K 8",
-        "dh_finish": "slab reduction, act', delta1^T, column sums", "dw_gemm": "160 x 128 tiles: dW GEMM + SGD update of W and both bf16 shadows",
+        "decode_loss": "128 x 64 tiles: GEMM + loss + delta2 (two layouts; split mode: 3 K segments, hi + lo images), x from bits", "dh_gemm": "delta2.W + Gs.h, split-K 8 (split mode: 5 K segments)",
+        "dh_finish": "slab reduction, act', delta1^T, column sums", "dw_gemm": "160 x 128 tiles: dW GEMM + SGD update of W and both bf16 shadows (split mode: paired stages, hi + lo shadows)",
         "bias_grads": "step tail: bias grads + update, statistics, x~^T un-scatter"}
 
 
@@ -104,7 +104,7 @@ L = []
 L.append(f"# Round {rnd[1:]} -- measured on 1x MI355X (gfx950), ROCm 7.2, host: {host[1].split(':')[-1].strip() if len(host) > 1 else '?'} ({host[0]} hw threads)\n")
 L.append("All files of this set come from ONE `tools/make_profile_report.sh` run (one box; boxes of the pool differ by up to 1.4x on the same\n"
          f"binary).  Kernel sources hash `{traffic['_source_hash']}` (bench.source_hash).\n")
-L.append("\n## Headline (`python bench.py --steps 300 --warmup 30`, default config c2 = BASELINE configs[1])\n\n| metric | value |\n|---|---|")
+L.append(f"\n## Headline (`python bench.py --gpus 1 --steps {b['steps']} --warmup {b['warmup']}`, default config c2 = BASELINE configs[1], precision {b.get('dtype')})\n\n| metric | value |\n|---|---|")
 L.append(f"| training samples/s (device-Philox masking, `value`) | **{b['value']:,.0f}** ({1e3 * b['ms_per_step']:.1f} us/step) |")
 f = b.get("fit", {})
 if "philox" in f: L.append(f"| through `DenoisingAutoencoder.fit()` (N x timed epochs / wall, first epoch excluded), Philox | {f['philox']['samples_per_s']:,.0f} |")
