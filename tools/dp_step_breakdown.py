@@ -1,19 +1,20 @@
 #!/usr/bin/env python3
 """Where the data-parallel step form spends its time WITHOUT communication: a one-rank RCCL group on one GPU runs
 phase-1 step -> reduce-scatter -> sharded apply -> all-gather -> transpose rebuild, each piece bracketed by events.
-usage: python tools/dp_step_breakdown.py [--grad-dtype fp32|bf16]"""
+usage: python tools/dp_step_breakdown.py [--grad-dtype fp32|bf16] [--precision bf16|bf16x3]
+(bf16x3, the product default: fp32 gradients, fp32 master rows all-gathered, four shadow images rebuilt per rank -- dp.ShardedExchange's split-mode form)"""
 import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, torch.distributed as dist
 from dae_rnn_news_recommendation_amd import _lib as L, dp
 from dae_rnn_news_recommendation_amd.engine import Engine
 from dae_rnn_news_recommendation_amd.synthetic import synthetic_csr, synthetic_labels, xavier_uniform
-ap = argparse.ArgumentParser(); ap.add_argument("--grad-dtype", default="fp32"); a = ap.parse_args()
+ap = argparse.ArgumentParser(); ap.add_argument("--grad-dtype", default="fp32"); ap.add_argument("--precision", default="bf16"); a = ap.parse_args()
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29534")
 torch.cuda.set_device(0); dist.init_process_group("nccl", rank=0, world_size=1); dp.quiet_first_collective()
 F, H, B = 10000, 500, 800
 m = synthetic_csr(1600, F, seed=1); lab = synthetic_labels(1600, seed=1).astype(np.int32)
-eng = Engine(F, H, B, dtype="bf16", triplet="batch_all", learning_rate=0.1, dp_world=1)
+eng = Engine(F, H, B, dtype=a.precision, triplet="batch_all", learning_rate=0.1, dp_world=1)
 eng.upload_csr(m); eng.set_params(xavier_uniform(F, H))
 ex = dp.ShardedExchange(eng, grad_dtype=a.grad_dtype)
 idx = torch.arange(B, dtype=torch.int32, device="cuda"); labs = torch.from_numpy(lab[:B]).cuda(); stats = torch.zeros(8, device="cuda")
@@ -27,6 +28,26 @@ def timed(fn, n=50):
     return 1e3 * e0.elapsed_time(e1) / n, host
 Hp, c = eng.Hp, eng.chunk_rows
 gw = eng.grad[:ex.n_w]; bias = eng.grad[eng.Fp * Hp:eng.Fp * Hp + Hp + eng.Fp]
+if a.precision == "bf16x3":          # the split mode has ONE exchange form (three collectives, fp32 everywhere)
+    my_w = torch.zeros((c, Hp), dtype=torch.float32, device="cuda")
+    def step_and3(after_dw):
+        eng.train_step(idx, labs, stats, phase=1, **kw); ex.step(grad_scale=1.0, grad_ready_after_dw=after_dw)
+    rows = [("fused single-GPU step (phase 3)", lambda: eng.train_step(idx, labs, stats, phase=3, **kw)),
+            ("phase-1 step (fp32 gradient to memory)", lambda: eng.train_step(idx, labs, stats, phase=1, **kw)),
+            ("reduce_scatter fp32 (1 rank)", lambda: dist.reduce_scatter_tensor(ex.rs_out, gw)),
+            ("all_reduce bias (1 rank)", lambda: dist.all_reduce(bias)),
+            ("apply_rows (all rows at 1 rank)", lambda: eng.apply_rows(ex.rs_f32, ex.f0, ex.f1, grad_scale=1.0, update_bias=True)),
+            ("copy of my fp32 master rows", lambda: my_w.copy_(eng.W_full[:c])),
+            ("all_gather of the master rows (1 rank)", lambda: dist.all_gather_into_tensor(eng.W_full.view(-1), my_w.view(-1))),
+            ("sync_shadows (four images)", lambda: eng.sync_shadows()),
+            ("whole exchange.step", lambda: ex.step(grad_scale=1.0)),
+            ("phase-1 step + exchange", lambda: step_and3(False))]
+    print(f"precision bf16x3  {'piece':40s} {'GPU us':>9s} {'host us/call':>13s}")
+    for name, fn in rows:
+        g, h = timed(fn)
+        print(f"{name:40s} {g:9.1f} {h:13.1f}")
+    dist.destroy_process_group()
+    sys.exit(0)
 ex3 = dp.ShardedExchange(eng, grad_dtype=a.grad_dtype, packed=False)
 exn = dp.ShardedExchange(eng, grad_dtype=a.grad_dtype, packed=True, overlap=False)
 def step_and(exch, after_dw):
