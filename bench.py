@@ -15,9 +15,10 @@ Workloads (BASELINE.json configs; SURVEY.md 8(d) inputs), --config:
   c3: batch_hard + 4 category labels, 8000 rows and B=800 per rank (64000 rows over 8 ranks: weak scaling).
   c4: dense fp32 tf-idf ndarray 8000x50000, compress_factor 50 (H=1000), cross_entropy, alpha 1, batch_all -- HBM roofline.
   c5: explicit (anchor, pos, neg) triplets, 3 x 8000x10000 tf-idf CSR per rank, cosine_proximity, B=800 triplets (2400 rows).
-N > 1: weak scaling -- every rank owns its own shard and a local batch; per step the ranks reduce-scatter the W gradient, run
-the optimizer on their row chunk, all-gather the bf16 shadow and rebuild its transpose locally (dp.ShardedExchange); mining is
-per rank (SURVEY 8e mode ii).
+N > 1: weak scaling -- every rank owns its own shard and a local batch; per step, in the default split-bf16 mode, the ranks all-reduce the
+flat fp32 gradient and every rank runs the optimizer on the whole W (dp.AllReduceExchange: one collective); in the bf16 / fp32 modes they
+reduce-scatter the W gradient, run the optimizer on their row chunk, all-gather the low-precision shadow and rebuild its transpose locally
+(dp.ShardedExchange); mining is per rank (SURVEY 8e mode ii).
 
 Prints ONE JSON line (rank 0).  `kernels` / `roofline` come from HIP events recorded on the step's stream around each kernel
 (dae_plan_profile), in a second pass so that `value` is never measured with profiling on; `fit` is the same workload through
@@ -88,6 +89,9 @@ def parse():
     ap.add_argument("--grad-dtype", default=None, choices=["fp32", "bf16"],
                     help="N>1: element type of the reduce-scattered W gradient (default: the compute precision -- bf16 steps exchange the bf16 "
                          "gradient image the dW kernel's epilogue writes, fp32 steps the fp32 gradient)")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "sharded", "allreduce"],
+                    help="N>1: form of the data-parallel exchange (dp.make_exchange): auto = one fp32 all-reduce + full optimizer step per rank in the "
+                         "split-bf16 mode, the sharded exchange (reduce-scatter / sharded optimizer / all-gather) otherwise")
     ap.add_argument("--profile-steps", type=int, default=20)
     ap.add_argument("--fit-epochs", type=int, default=6)
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
@@ -180,7 +184,7 @@ class Runner:
         self.exchange = None
         if world > 1 or a.force_exchange:
             from dae_rnn_news_recommendation_amd import dp
-            self.exchange = dp.ShardedExchange(self.eng, grad_dtype=a.grad_dtype)
+            self.exchange = dp.make_exchange(self.eng, grad_dtype=a.grad_dtype, kind=a.exchange)
         self.nb = -(-self.N // self.B)
         self.stats = torch.zeros((self.nb, L.STATS_STRIDE), dtype=torch.float32, device=self.eng.device)
         self.step_i = 0
@@ -486,9 +490,11 @@ def main():
                                + f", strategy {c['strategy']}, masking 0.3, {c['loss']}, SGD lr 0.1, {a.precision} MFMA operands + fp32 "
                                "accumulate / master weights",
                    "global_batch": c["batch"] * world, "parallelism": f"dp{world}", "rng": a.rng,
-                   "collective": None if world == 1 else f"per step: reduce-scatter of the W gradient ({a.grad_dtype}, written by the dW GEMM's epilogue), "
-                                                         "sharded optimizer writing into the all-gather send buffer, "
-                                                         "all-gather of the low-precision W rows + every rank's bias gradients, one unpack kernel (RCCL)"},
+                   "collective": None if world == 1 else (
+                       "per step: ONE all-reduce of the flat fp32 gradient [dW | dbh | dbv], then the optimizer on the whole W + all four low-precision "
+                       "images on every rank (dp.AllReduceExchange, RCCL)" if type(run.exchange).__name__ == "AllReduceExchange" else
+                       f"per step: reduce-scatter of the W gradient ({a.grad_dtype}, written by the dW GEMM's epilogue), sharded optimizer writing into the "
+                       "all-gather send buffer, all-gather of the low-precision W rows + every rank's bias gradients, one unpack kernel (RCCL)")},
         "final_losses": {"cost": float(last[:, 0].mean()), "autoencoder": float(last[:, 1].mean()),
                          "triplet": float(last[:, 2].mean()), "fraction": float(last[:, 3].mean()),
                          "note": "means over the last epoch's batches, as the reference prints them (autoencoder.py:283-294)"},
@@ -514,8 +520,11 @@ def main():
         out["exposed_us"] = max(0.0, 1e3 * out["ms_per_step"] - local_us)
         out["multi_gpu_note"] = ("no N > 1 hardware number exists for this code until the driver's SCALE run: the exchange has only run "
                                  "as a one-rank RCCL group and over gloo (tests/test_dp_gloo.py, tests/test_hip_dp.py)")
-        out["config"]["exchange_bytes_per_rank"] = int((world - 1) / world * (run.eng.rows_alloc * run.eng.Hp * (4 if a.grad_dtype == "fp32" else 2)
-                                                                               + run.eng.rows_alloc * run.eng.Hp * (2 if a.precision == "bf16" else 4)))
+        if type(run.exchange).__name__ == "AllReduceExchange":
+            out["config"]["exchange_bytes_per_rank"] = int(2 * (world - 1) / world * run.eng.n_flat * 4)
+        else:
+            out["config"]["exchange_bytes_per_rank"] = int((world - 1) / world * (run.eng.rows_alloc * run.eng.Hp * (4 if a.grad_dtype == "fp32" else 2)
+                                                                                   + run.eng.rows_alloc * run.eng.Hp * (2 if a.precision == "bf16" else 4)))
 
     _log("timed region done: %.1f us/step" % (1e6 * dt / a.steps))
     if rank == 0 and not a.no_roofline:

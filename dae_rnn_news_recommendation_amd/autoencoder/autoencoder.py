@@ -15,8 +15,9 @@ New (keyword-only, all optional):
               'philox' -- counter-based masking generated on the device (statistically equivalent,
                           no host RNG in the epoch loop)
   init_weights  (W0[, bh0, bv0]) injected instead of the Xavier draw (tf.random_uniform is not reproducible)
-  data_parallel  True -> shard every mini-batch over torch.distributed ranks (reduce-scatter of the W gradient, sharded
-                 optimizer, all-gather of the low-precision shadow), see dae_rnn_news_recommendation_amd/dp.py
+  data_parallel  True -> shard every mini-batch over torch.distributed ranks; dp_exchange 'auto': in the split-bf16 mode ONE fp32 all-reduce of
+                 the flat gradient + the full optimizer step on every rank (dp.AllReduceExchange), in the bf16 / fp32 modes reduce-scatter of the
+                 W gradient, sharded optimizer, all-gather of the low-precision shadow (dp.ShardedExchange); 'sharded' / 'allreduce' force one
   plan_options   {name: value} handed to dae_plan_set_option (implementation choices of the same arithmetic; A/B runs)
 """
 from __future__ import annotations
@@ -98,7 +99,7 @@ class DenoisingAutoencoder(object):
                  xavier_init=1, opt='gradient_descent', learning_rate=0.01, momentum=0.5, corr_type='none',
                  corr_frac=0., verbose=True, verbose_step=5, seed=-1, alpha=1, triplet_strategy='batch_all',
                  *, precision='auto', rng='numpy', init_weights=None, device=None, data_parallel=False,
-                 dp_grad_dtype='fp32', dp_mining='local', results_root='results/', plan_options=None):
+                 dp_grad_dtype='fp32', dp_mining='local', results_root='results/', plan_options=None, dp_exchange='auto'):
         self.algo_name = algo_name
         self.model_name = model_name
         self.compress_factor = compress_factor
@@ -127,6 +128,8 @@ class DenoisingAutoencoder(object):
         self.dp_grad_dtype = dp_grad_dtype       # 'fp32' | 'bf16': element type of the gradient in the reduce-scatter (data parallel)
         self.dp_mining = dp_mining               # data parallel + triplet strategy: 'local' (each rank mines its shard) | 'global'
         assert self.dp_mining in ('local', 'global')
+        self.dp_exchange = dp_exchange           # data parallel: 'auto' (split-bf16 mode: one fp32 all-reduce + full optimizer step on every rank;
+        assert self.dp_exchange in ('auto', 'sharded', 'allreduce')     # else the sharded exchange) | 'sharded' | 'allreduce'  (dp.make_exchange)
         self.results_root = results_root
         self.plan_options = dict(plan_options or {})   # code-path choices of the step plan (dae_plan_set_option): A/B runs, tests
 
@@ -275,7 +278,7 @@ class DenoisingAutoencoder(object):
             self._write_parameter_to_file(restore_previous_model)
         if world > 1:
             from .. import dp
-            self._exchange = dp.ShardedExchange(eng, grad_dtype=self.dp_grad_dtype)
+            self._exchange = dp.make_exchange(eng, grad_dtype=self.dp_grad_dtype, kind=self.dp_exchange)
             self._miner = None
             if self.triplet_strategy != 'none' and self.dp_mining == 'global':
                 self._miner = dp.GlobalMiner(eng, self.triplet_strategy, float(self.alpha), batch)

@@ -298,6 +298,69 @@ class ShardedExchange:
             part.copy_(full[:eng.Fp])
 
 
+class AllReduceExchange:
+    """The exchange of the split-bf16 mode (precision='bf16x3', what precision='auto' resolves to) under data parallel: ONE collective.
+
+        all-reduce of the flat fp32 gradient [dW | dbh | dbv]    (2 (R-1)/R * 20.7 MB per rank at 10000 x 500 -- exactly the bytes of
+                                                                  ShardedExchange's fp32 reduce-scatter + fp32 master all-gather)
+        dae_plan_apply on every rank                               (optimizer on the whole W and the biases + all four low-precision images,
+                                                                  one opt_w_kernel pass: what the sharded form spends on dae_plan_sync_shadows)
+
+    The split mode cannot shrink the exchange below fp32 gradients in and fp32-accurate weights out, so sharding the optimizer buys
+    no bytes here -- it only adds two collective launches (reduce-scatter + all-gather instead of one all-reduce), the bias all-reduce, a copy of
+    the master rows and torch's stream hops around each of them: without communication the sharded step form costs 93.6 us on top of the phase-1
+    step, this one ~35 (tools/dp_step_breakdown.py --precision bf16x3).  Every rank holds the full master weights and optimizer slots at all
+    times: gather_master / gather_slots are no-ops.  Same interface as ShardedExchange."""
+
+    def __init__(self, eng):
+        import torch
+        import torch.distributed as dist
+        assert is_initialized(), "torch.distributed is not initialised"
+        self.eng, self.torch, self.dist = eng, torch, dist
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        assert eng.dp_world == self.world, "create the Engine with dp_world = world size (%d != %d)" % (eng.dp_world, self.world)
+        self.x3 = bool(getattr(eng, "x3", False))
+        self.grad_dtype, self.packed = "fp32", False
+        self.flat = eng.grad[:eng.n_flat]                       # [dW (Fp*Hp) | dbh (Hp) | dbv (Fp)]
+        self.f0, self.f1 = 0, eng.Fp                            # (interface parity: this rank "owns" every row)
+        self.collective_ms = 0.0
+        self.steps = 0
+        self._ev = tuple(torch.cuda.Event(enable_timing=True) for _ in range(2)) if eng.device.type == "cuda" else None
+        self._pending = None
+
+    def step(self, grad_scale, grad_ready_after_dw=False):
+        """Call after eng.train_step(phase=1): all-reduce + full optimizer step.  grad_scale multiplies the rank-SUMMED gradient."""
+        if self._ev:
+            self._ev[0].record()
+        self.dist.all_reduce(self.flat, op=self.dist.ReduceOp.SUM)
+        if self._ev:
+            self._ev[1].record()
+            self._pending = True
+        self.eng.apply(grad_scale=grad_scale)                   # (counts the Adam step itself)
+        self.steps += 1
+
+    def collect_time(self):
+        if self._ev and self._pending:
+            self._ev[1].synchronize()
+            self.collective_ms += self._ev[0].elapsed_time(self._ev[1])
+            self._pending = None
+
+    def gather_master(self):
+        return
+
+    def gather_slots(self):
+        return
+
+
+def make_exchange(eng, grad_dtype="fp32", kind="auto"):
+    """The data-parallel exchange for `eng`: kind 'auto' = AllReduceExchange in the split-bf16 mode (nothing to gain from sharding there),
+    ShardedExchange otherwise (bf16 gradients / bf16 shadow rows halve its bytes); 'sharded' / 'allreduce' force one form."""
+    assert kind in ("auto", "sharded", "allreduce"), kind
+    if kind == "allreduce" or (kind == "auto" and getattr(eng, "x3", False)):
+        return AllReduceExchange(eng)
+    return ShardedExchange(eng, grad_dtype=grad_dtype)
+
+
 class GlobalMiner:
     """Global-batch triplet mining under data parallel (SURVEY 8e mode i): the reference objective at the GLOBAL batch size.
 

@@ -39,6 +39,7 @@ class FakeEngine:
         self.Wt_lo = torch.zeros((Hp, Fp), dtype=td)
         self.bh = torch.zeros(Hp); self.bv = torch.zeros(Fp)
         self.options, self.shadow_syncs = {}, 0
+        self.n_flat = n_flat
 
     def set_option(self, name, value):
         self.options[name] = value
@@ -85,6 +86,14 @@ class FakeEngine:
     def refresh_wt(self):                                                                 # dae_plan_refresh_wt
         self.Wt_lo.copy_(self.W_lo.T)
 
+    def apply(self, grad_scale=1.0):                                                      # dae_plan_apply: whole W + biases + shadows
+        n = self.Fp * self.Hp
+        self.W -= LR * grad_scale * self.grad[:n].view(self.Fp, self.Hp)
+        b = self._bias_grads()
+        self.bh -= LR * grad_scale * b[:self.Hp]; self.bv -= LR * grad_scale * b[self.Hp:]
+        self.W_lo.copy_(self.W.to(self.td)); self.Wt_lo.copy_(self.W_lo.T)
+        self.n_flat_seen = n + self.Hp + self.Fp
+
     def sync_shadows(self):                                                               # dae_plan_sync_shadows
         self.W_lo.copy_(self.W.to(self.td)); self.Wt_lo.copy_(self.W_lo.T)
         self.shadow_syncs += 1
@@ -102,12 +111,16 @@ def _worker(rank, world, port, mode, Fp, Hp, out):
     from dae_rnn_news_recommendation_amd import dp
     dp.init_from_env("gloo")
     td = torch.float32 if mode == "fp32_shadow" else torch.bfloat16
-    eng = FakeEngine(Fp, Hp, world, td, x3=(mode == "x3"), grad_lo=(mode == "bf16_grad_image"))
+    eng = FakeEngine(Fp, Hp, world, td, x3=mode.startswith("x3"), grad_lo=(mode == "bf16_grad_image"))
     W0 = torch.from_numpy(np.random.default_rng(7).uniform(-0.3, 0.3, (Fp, Hp)).astype(np.float32))
     eng.W.copy_(W0); eng.sync_shadows()
-    ex = dp.ShardedExchange(eng, grad_dtype="bf16" if mode.startswith("bf16_grad") else "fp32", packed=(mode != "three"))
-    assert (ex.packed, ex.grad_dtype) == ((False, "fp32") if mode == "x3" else (mode != "three", ex.grad_dtype))
-    assert ("encode_w32" in eng.options) == (mode != "x3")          # only the split mode keeps the fp32-master encode
+    if mode == "x3_allreduce":                 # what dp.make_exchange(kind='auto') picks for the split mode: ONE all-reduce, full optimizer step per rank
+        ex = dp.make_exchange(eng)
+        assert type(ex).__name__ == "AllReduceExchange" and type(dp.make_exchange(eng, kind="sharded")).__name__ == "ShardedExchange"
+    else:
+        ex = dp.ShardedExchange(eng, grad_dtype="bf16" if mode.startswith("bf16_grad") else "fp32", packed=(mode != "three"))
+        assert (ex.packed, ex.grad_dtype) == ((False, "fp32") if mode == "x3" else (mode != "three", ex.grad_dtype))
+    assert ("encode_w32" in eng.options) == (not mode.startswith("x3"))          # only the split mode keeps the fp32-master encode
     for step in range(3):
         dW, db = _local_grads(Fp, Hp, rank, step)
         eng.grad.zero_()
@@ -123,7 +136,7 @@ def _worker(rank, world, port, mode, Fp, Hp, out):
                      bh=eng.bh.numpy().copy(), bv=eng.bv.numpy().copy(), syncs=eng.shadow_syncs)
 
 
-@pytest.mark.parametrize("mode", ["packed", "fp32_shadow", "bf16_grad_image", "bf16_grad_cast", "three", "x3"])
+@pytest.mark.parametrize("mode", ["packed", "fp32_shadow", "bf16_grad_image", "bf16_grad_cast", "three", "x3", "x3_allreduce"])
 @pytest.mark.parametrize("world,Fp", [(2, 640), (3, 640), (3, 128)])       # 3 x 256 rows > 640: ragged last chunk; 3 x 64 > 128: EMPTY last chunk
 def test_sharded_exchange_equals_single_process(mode, world, Fp):
     Hp = 128
@@ -150,4 +163,4 @@ def test_sharded_exchange_equals_single_process(mode, world, Fp):
         assert np.array_equal(o["Wt_lo"], o["W_lo"].T)
         assert np.abs(o["bh"] - b[:Hp]).max() <= 1e-5 and np.abs(o["bv"] - b[Hp:]).max() <= 1e-5
         assert np.array_equal(o["W_lo"], out[0]["W_lo"]) and np.array_equal(o["bh"], out[0]["bh"])   # every rank holds IDENTICAL shadows / biases
-        assert o["syncs"] == (1 + 3 if mode == "x3" else 1)
+        assert o["syncs"] == (1 + 3 if mode == "x3" else 1)                                         # (the all-reduce form rebuilds the images inside dae_plan_apply)

@@ -31,15 +31,18 @@ def _data():
     return m, lab, W0
 
 
-def _fit(tmp, strategy, opt, dp_flag, grad_dtype="fp32", seed=11, mining="local", precision="fp32"):
+def _fit(tmp, strategy, opt, dp_flag, grad_dtype="fp32", seed=11, mining="local", precision="fp32", exchange="auto"):
     from dae_rnn_news_recommendation_amd.autoencoder import DenoisingAutoencoder
     m, lab, W0 = _data()
     model = DenoisingAutoencoder(model_name="dp", main_dir="dp%d" % os.getpid(), compress_factor=10, enc_act_func="sigmoid",
                                  dec_act_func="sigmoid", loss_func="cross_entropy", num_epochs=2, batch_size=37, opt=opt,
                                  learning_rate=0.05, momentum=0.5, corr_type="masking", corr_frac=0.3, verbose=0, verbose_step=1,
                                  seed=seed, alpha=1, triplet_strategy=strategy, precision=precision, rng="numpy", init_weights=W0,
-                                 data_parallel=dp_flag, dp_grad_dtype=grad_dtype, dp_mining=mining, results_root=tmp + "/")
+                                 data_parallel=dp_flag, dp_grad_dtype=grad_dtype, dp_mining=mining, dp_exchange=exchange, results_root=tmp + "/")
     model.fit(m, train_set_label=lab if strategy != "none" else None)
+    if dp_flag:
+        want = "AllReduceExchange" if (exchange == "allreduce" or (exchange == "auto" and precision in ("auto", "bf16x3"))) else "ShardedExchange"
+        assert type(model._exchange).__name__ == want, (type(model._exchange).__name__, want)
     stats = np.stack([model.epoch_stats(e + 1)["per_batch"] for e in range(2)])
     return stats, model.engine.get_params()
 
@@ -77,25 +80,25 @@ def _worker_ck(rank, world, port, tmp, opt, out):
     torch.distributed.destroy_process_group()
 
 
-def _worker(rank, world, port, tmp, strategy, opt, grad_dtype, seed, mining, out, precision="fp32"):
+def _worker(rank, world, port, tmp, strategy, opt, grad_dtype, seed, mining, out, precision="fp32", exchange="auto"):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LOCAL_RANK="0")
     import torch
     from dae_rnn_news_recommendation_amd import dp
     torch.cuda.set_device(0)
     dp.init_from_env("gloo")
-    stats, params = _fit(tmp, strategy, opt, True, grad_dtype, seed, mining, precision)
+    stats, params = _fit(tmp, strategy, opt, True, grad_dtype, seed, mining, precision, exchange)
     out[rank] = (stats, params)
     dp.barrier()
     torch.distributed.destroy_process_group()
 
 
-def _run_dp(tmp, strategy, opt, grad_dtype="fp32", seed=11, mining="local", precision="fp32"):
+def _run_dp(tmp, strategy, opt, grad_dtype="fp32", seed=11, mining="local", precision="fp32", exchange="auto"):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     mgr = ctx.Manager(); out = mgr.dict()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, tmp, strategy, opt, grad_dtype, seed, mining, out, precision)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, tmp, strategy, opt, grad_dtype, seed, mining, out, precision, exchange)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
@@ -122,13 +125,15 @@ def test_fit_two_ranks_equal_one_rank_strategy_none(tmp_path, opt):
     assert np.array_equal(out[0][1][0], out[1][1][0])                      # both ranks end with the same weights, bit for bit
 
 
-@pytest.mark.parametrize("strategy,mining", [("none", "local"), ("batch_all", "global")])
-def test_fit_two_ranks_split_bf16_equals_one_rank(tmp_path, strategy, mining):
-    """precision='bf16x3' under data parallel: fp32 gradients are reduce-scattered, each rank updates its rows of the fp32 master, the MASTER
-    rows are all-gathered and every rank rebuilds its four bf16 images -- two ranks reproduce one rank at the global batch (and, with
-    dp_mining='global', its triplet leg)."""
+@pytest.mark.parametrize("strategy,mining,exchange", [("none", "local", "auto"), ("batch_all", "global", "auto"), ("batch_all", "global", "sharded"),
+                                                      ("none", "local", "sharded")])
+def test_fit_two_ranks_split_bf16_equals_one_rank(tmp_path, strategy, mining, exchange):
+    """precision='bf16x3' under data parallel.  Default exchange (dp.AllReduceExchange): ONE all-reduce of the flat fp32 gradient, every rank
+    runs the optimizer on the whole W and rebuilds its four bf16 images in the same kernel.  exchange='sharded' (dp.ShardedExchange): fp32
+    gradients reduce-scattered, each rank updates its rows of the fp32 master, the MASTER rows all-gathered, images rebuilt.  Either way two
+    ranks reproduce one rank at the global batch (and, with dp_mining='global', its triplet leg)."""
     ref_stats, ref_p = _fit(str(tmp_path), strategy, "gradient_descent", False, precision="bf16x3")
-    out = _run_dp(str(tmp_path), strategy, "gradient_descent", mining=mining, precision="bf16x3")
+    out = _run_dp(str(tmp_path), strategy, "gradient_descent", mining=mining, precision="bf16x3", exchange=exchange)
     for r in range(2):
         stats, p = out[r]
         assert _rel(stats[..., 0], ref_stats[..., 0]) < 2e-5, (r, stats[..., 0], ref_stats[..., 0])

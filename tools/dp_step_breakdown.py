@@ -16,7 +16,7 @@ F, H, B = 10000, 500, 800
 m = synthetic_csr(1600, F, seed=1); lab = synthetic_labels(1600, seed=1).astype(np.int32)
 eng = Engine(F, H, B, dtype=a.precision, triplet="batch_all", learning_rate=0.1, dp_world=1)
 eng.upload_csr(m); eng.set_params(xavier_uniform(F, H))
-ex = dp.ShardedExchange(eng, grad_dtype=a.grad_dtype)
+ex = dp.ShardedExchange(eng, grad_dtype=a.grad_dtype)      # (the split mode's default is dp.AllReduceExchange: timed below beside this form)
 idx = torch.arange(B, dtype=torch.int32, device="cuda"); labs = torch.from_numpy(lab[:B]).cuda(); stats = torch.zeros(8, device="cuda")
 kw = dict(corr_mode=L.CORR_PHILOX_MASK, seed=1, rng_stream=0, corr_frac=0.3)
 def timed(fn, n=50):
@@ -30,6 +30,7 @@ Hp, c = eng.Hp, eng.chunk_rows
 gw = eng.grad[:ex.n_w]; bias = eng.grad[eng.Fp * Hp:eng.Fp * Hp + Hp + eng.Fp]
 if a.precision == "bf16x3":          # the split mode has ONE exchange form (three collectives, fp32 everywhere)
     my_w = torch.zeros((c, Hp), dtype=torch.float32, device="cuda")
+    exa = dp.AllReduceExchange(eng)
     def step_and3(after_dw):
         eng.train_step(idx, labs, stats, phase=1, **kw); ex.step(grad_scale=1.0, grad_ready_after_dw=after_dw)
     rows = [("fused single-GPU step (phase 3)", lambda: eng.train_step(idx, labs, stats, phase=3, **kw)),
@@ -40,8 +41,12 @@ if a.precision == "bf16x3":          # the split mode has ONE exchange form (thr
             ("copy of my fp32 master rows", lambda: my_w.copy_(eng.W_full[:c])),
             ("all_gather of the master rows (1 rank)", lambda: dist.all_gather_into_tensor(eng.W_full.view(-1), my_w.view(-1))),
             ("sync_shadows (four images)", lambda: eng.sync_shadows()),
-            ("whole exchange.step", lambda: ex.step(grad_scale=1.0)),
-            ("phase-1 step + exchange", lambda: step_and3(False))]
+            ("whole exchange.step (sharded form)", lambda: ex.step(grad_scale=1.0)),
+            ("phase-1 step + sharded exchange", lambda: step_and3(False)),
+            ("all_reduce of the flat fp32 gradient", lambda: dist.all_reduce(exa.flat)),
+            ("dae_plan_apply (whole W + 4 images)", lambda: eng.apply(grad_scale=1.0)),
+            ("whole AllReduceExchange.step (default)", lambda: exa.step(grad_scale=1.0)),
+            ("phase-1 step + all-reduce exchange", lambda: (eng.train_step(idx, labs, stats, phase=1, **kw), exa.step(grad_scale=1.0)))]
     print(f"precision bf16x3  {'piece':40s} {'GPU us':>9s} {'host us/call':>13s}")
     for name, fn in rows:
         g, h = timed(fn)
