@@ -24,9 +24,24 @@ def q(x):
     return x.to(torch.bfloat16).float()
 
 
+def q16(x):
+    """fp16 storage with a per-tensor power-of-two scale (max |x| -> ~2^14): what an fp16 operand image with the scale folded into the consumer's
+    epilogue would hold (11 significant bits instead of bf16's 8; the scale keeps delta2 / Gs, whose entries are ~1e-6, out of the subnormals)."""
+    m = float(x.abs().max())
+    if m == 0.0 or not np.isfinite(m):
+        return x.clone()
+    sc = 2.0 ** np.floor(np.log2(16384.0 / m))
+    return (x * sc).to(torch.float16).float() / sc
+
+
 def parts(x, mode):
     if mode == "f32":
         return [x]
+    if mode in ("f16", "f16split"):
+        hi = q16(x)
+        return [hi] if mode == "f16" else [hi, q16(x - hi)]
+    if mode == "f16raw":                                   # fp16 without the per-tensor scale (small entries fall into the subnormals / to zero)
+        return [x.to(torch.float16).float()]
     hi = q(x)
     return [hi] if mode == "bf16" else [hi, q(x - hi)]
 
@@ -69,20 +84,36 @@ def batch_all(lab, h, chunk=32):
     return tot / (nv + 1e-16), G / (nv + 1e-16), dw, nv
 
 
-def run(mode, data, labels, W0, steps, B, lr=0.1, alpha=1.0, seed=7):
-    """mode: dict operand -> 'f32' | 'bf16' | 'split' for h, W, d2, d1, Gs; a key 'op@gemm' (gemm in dec, dh, dw) overrides 'op' in that GEMM."""
+def run(mode, data, labels, W0, steps, B, lr=0.1, alpha=1.0, seed=7, golden=False):
+    """mode: dict operand -> 'f32' | 'bf16' | 'split' for h, W, d2, d1, Gs; a key 'op@gemm' (gemm in dec, dh, dw) overrides 'op' in that GEMM.
+    golden: batches and corruption exactly as DenoisingAutoencoder.fit(seed=0, rng='numpy') / the reference stage them -- per epoch the keep
+    decisions of the whole set from NumPy's legacy global stream (np.random.rand(nnz) >= v in CSR storage order), then the shuffle -- so the run
+    is comparable step by step with tests/golden/full_curve_c2.npz (what tests/test_hip_full_curve.py holds the GPU to)."""
     def M(op, gemm):
         return mode.get(f"{op}@{gemm}", mode[op])
     rng = np.random.default_rng(seed)
     N, F = data.shape
     W = torch.from_numpy(W0.copy()); bh = torch.zeros(W.shape[1]); bv = torch.zeros(F)
     order = rng.permutation(N)
+    if golden:
+        from dae_rnn_news_recommendation_amd.autoencoder import utils as U
+        np.random.seed(0)
+        nb = -(-N // B)
     out = []
     for s in range(steps):
-        idx = order[(s * B) % N:(s * B) % N + B]
-        x = torch.from_numpy(np.asarray(data[idx].todense(), dtype=np.float32))
-        keep = torch.from_numpy((rng.random(x.shape) >= 0.3).astype(np.float32))
-        xc = x * keep
+        if golden:
+            if s % nb == 0:                                  # a new epoch: corruption of the whole set, then the permutation (reference order)
+                keep_e = np.random.rand(data.nnz) >= 0.3
+                corrupted = data.copy(); corrupted.data = corrupted.data * keep_e
+                order = U.epoch_permutation(N)
+            idx = order[(s % nb) * B:(s % nb) * B + B]
+            x = torch.from_numpy(np.asarray(data[idx].todense(), dtype=np.float32))
+            xc = torch.from_numpy(np.asarray(corrupted[idx].todense(), dtype=np.float32))
+        else:
+            idx = order[(s * B) % N:(s * B) % N + B]
+            x = torch.from_numpy(np.asarray(data[idx].todense(), dtype=np.float32))
+            keep = torch.from_numpy((rng.random(x.shape) >= 0.3).astype(np.float32))
+            xc = x * keep
         lab = torch.from_numpy(labels[idx].astype(np.int64))
         # encode from the fp32 master weights (exact products of 0/1 entries), Gram on fp32 h
         a1 = torch.sigmoid(xc @ W + bh)
@@ -117,6 +148,12 @@ def main():
     ap.add_argument("--per-term", action="store_true",
                     help="third study: split everywhere (Gs bf16), then ONE operand use (operand@gemm) back to plain bf16 -- i.e. one lo.hi / hi.lo "
                          "product term of one GEMM dropped -- and the combinations of the droppable ones (--drop)")
+    ap.add_argument("--golden", action="store_true",
+                    help="inputs, batches and corruption of tests/golden/make_full_curve.py (the reference-exact legacy RNG order); deviations are "
+                         "reported against the frozen float32 reference curve tests/golden/full_curve_c2.npz -- what the GPU test is held to")
+    ap.add_argument("--scheme", action="append", default=[], metavar="OP=MODE[,OP=MODE...]",
+                    help="fourth study: evaluate exactly these storage schemes, e.g. --scheme h=f16,W=f16split,d2=f16,d1=f16,Gs=f16 (modes f32 | bf16 | split "
+                         "| f16 | f16split; OP may be op@gemm; operands not named are f16)")
     ap.add_argument("--drop", action="append", default=[], metavar="OP@GEMM[,OP@GEMM...]",
                     help="with --per-term: evaluate exactly these combinations of dropped terms instead of the single-term sweep")
     a = ap.parse_args()
@@ -124,6 +161,16 @@ def main():
     data = synthetic_csr(a.rows, a.features, seed=1234).tocsr()
     labels = synthetic_labels(a.rows, seed=1234)
     W0 = xavier_uniform(a.features, a.features // 20, seed=42).astype(np.float32)
+    gold = None
+    if a.golden:
+        import os
+        g = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+        sys.path.insert(0, g)
+        import make_full_curve as MF
+        data, labels, W0 = MF.inputs()
+        data = data.tocsr(); W0 = W0.astype(np.float32)
+        G = np.load(os.path.join(g, "full_curve_c2.npz"))
+        gold = np.stack([G["cost"].reshape(-1), G["ae"].reshape(-1), G["triplet"].reshape(-1)], axis=1)[:a.steps]
     ops = ("h", "W", "d2", "d1", "Gs")
     modes = {"all f32 (reference arithmetic)": dict.fromkeys(ops, "f32"),
              "all bf16 (precision='bf16')": dict.fromkeys(ops, "bf16"),
@@ -155,12 +202,25 @@ def main():
                 assert u in uses, u
                 m[u] = "bf16"
             modes["split, lo term dropped: " + " + ".join(combo)] = m
+    if a.scheme:
+        modes = {"all f32 (reference arithmetic)": dict.fromkeys(ops, "f32")}
+        for sch in a.scheme:
+            m = dict.fromkeys(ops, "f16")
+            for kv in sch.split(","):
+                k, v = kv.split("=")
+                assert v in ("f32", "bf16", "split", "f16", "f16split", "f16raw"), v
+                m[k] = v
+            modes["scheme " + sch] = m
     ref = None
     for name, m in modes.items():
         t0 = time.time()
-        r = run(m, data, labels, W0, a.steps, a.batch)
+        r = run(m, data, labels, W0, a.steps, a.batch, golden=a.golden)
         if ref is None:
             ref = r
+            if gold is not None:                                 # the all-f32 replay against the frozen reference curve, then the curve is the reference
+                dev = np.abs(r - gold) / np.abs(gold)
+                print(f"all-f32 replay vs tests/golden/full_curve_c2.npz: cost max {dev[:, 0].max():.2e}  triplet max {dev[:, 2].max():.2e}", flush=True)
+                ref = gold
             print(f"{name}: cost {r[0, 0]:.4f} -> {r[-1, 0]:.4f}, triplet {r[0, 2]:.5f} -> {r[-1, 2]:.5f}   ({time.time() - t0:.0f} s)", flush=True)
             continue
         dev = np.abs(r - ref) / np.abs(ref)
