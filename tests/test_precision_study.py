@@ -44,3 +44,24 @@ def test_curve_replay_orders_the_modes():
     d_sp = (np.abs(sp - ref) / np.abs(ref)).max()
     assert np.isfinite(ref).all() and ref[-1, 0] < ref[0, 0]            # the replay trains
     assert d_sp < 1e-5 and d_bf > 10 * d_sp, (d_bf, d_sp)
+
+
+def test_fp16_storage_modes_and_golden_order():
+    """The fp16 storage modes of the replay (round 4: the scheme study behind DESIGN 11.0) and its golden batch order."""
+    ps = _load()
+    g = torch.Generator().manual_seed(5)
+    a, b = torch.randn(64, 512, generator=g) * 1e-5, torch.randn(512, 48, generator=g)      # delta2-sized entries: far below fp16's normal range
+    ref = a.double() @ b.double()
+    err = lambda ma, mb: float((ps.mm(a, b, ma, mb).double() - ref).abs().max() / ref.abs().max())
+    e16, e16s, ebf, eraw = err("f16", "f16"), err("f16split", "f16split"), err("bf16", "bf16"), err("f16raw", "f16")
+    assert e16 < ebf / 4 and e16s < 1e-5 and e16s < e16 / 50, (e16, e16s, ebf)           # 11 bits vs 8; the split carries ~22
+    assert eraw > 5 * e16, (eraw, e16)                                                    # without the power-of-two scale the small operand sits in the subnormals
+    # golden order: per epoch the keep decisions of the whole set, then the shuffle, both from NumPy's legacy global stream seeded with 0
+    from dae_rnn_news_recommendation_amd.synthetic import synthetic_csr, synthetic_labels, xavier_uniform
+    torch.set_num_threads(4)
+    N, F, B = 300, 400, 100
+    data = synthetic_csr(N, F, nnz_per_row=30, seed=7).tocsr(); labels = synthetic_labels(N, seed=7); W0 = xavier_uniform(F, F // 20, seed=1).astype(np.float32)
+    ops = ("h", "W", "d2", "d1", "Gs")
+    r1 = ps.run(dict.fromkeys(ops, "f32"), data, labels, W0, 4, B, golden=True)
+    r2 = ps.run(dict.fromkeys(ops, "f32"), data, labels, W0, 4, B, golden=True)
+    assert np.array_equal(r1, r2) and np.isfinite(r1).all()                               # the global stream is re-seeded per run: reproducible
