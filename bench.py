@@ -82,7 +82,7 @@ def parse():
     ap.add_argument("--compress-factor", type=int, default=0)
     ap.add_argument("--batch", type=int, default=0)
     ap.add_argument("--strategy", default="", choices=["", "batch_all", "batch_hard", "none"])
-    ap.add_argument("--precision", default="auto", choices=["auto", "bf16x3", "fp32", "bf16"],
+    ap.add_argument("--precision", default="auto", choices=["auto", "f16x2", "bf16x3", "fp32", "bf16", "f16", "f16x3"],
                     help="auto (default) = what DenoisingAutoencoder(precision='auto') resolves to for the config's input: the fastest mode that "
                          "holds the reference's loss curve within 1e-4 (the split-bf16 mode bf16x3); bf16 is faster but outside that gate")
     ap.add_argument("--rng", default="philox", choices=["philox", "numpy"])
@@ -115,8 +115,9 @@ def parse():
         c["strategy"] = a.strategy
     a.cfg = c
     a.precision_asked = a.precision
-    if a.precision == "auto":      # what DenoisingAutoencoder(precision='auto') resolves to (Engine.supports_x3: every input kind)
-        a.precision = "bf16x3"
+    if a.precision == "auto":      # what DenoisingAutoencoder(precision='auto') resolves to (every input kind)
+        from dae_rnn_news_recommendation_amd import _lib as L
+        a.precision = L.AUTO_PRECISION
     if a.grad_dtype is None:
         a.grad_dtype = "bf16" if a.precision == "bf16" else "fp32"
     return a
@@ -167,7 +168,7 @@ class Runner:
         data, self.labels = make_data(c, rank)
         self.eng = Engine(F, H, self.B * (3 if self.explicit else 1), dtype=a.precision, enc_act="sigmoid", dec_act="sigmoid",
                           loss_func=c["loss"], opt="gradient_descent", learning_rate=0.1, alpha=1.0, triplet=c["strategy"],
-                          dp_world=world, grad_lo=((world > 1 or a.force_exchange) and a.grad_dtype == "bf16"))
+                          dp_world=world, grad_lo=((world > 1 or a.force_exchange) and a.grad_dtype == "bf16" and a.exchange != "allreduce"))
         for kv in a.option:
             name, _, value = kv.partition("=")
             self.eng.set_option(name, int(value))
@@ -359,7 +360,7 @@ def kernel_table(a, prof, nsteps):
     """Per-kernel averages + the roofline each kernel is priced against (algorithmic work per launch)."""
     c = a.cfg
     B, F, H = c["batch"] * (3 if c["strategy"] == "explicit" else 1), c["features"], c["features"] // c["cf"]
-    es = 2 if a.precision.startswith("bf16") else 4
+    es = 2 if a.precision != "fp32" else 4
     dense_in = c["kind"] == "dense_tfidf"
     nnz_row = 300 if dense_in else 200
     mfma = {"decode_loss": 2.0 * B * F * H, "dh_gemm": 2.0 * B * F * H + (2.0 * B * B * H if c["strategy"] in ("batch_all", "batch_hard") else 0),
@@ -553,7 +554,7 @@ def main():
         out["profiled_step_us"] = step_us
         # whole-step rooflines (dense accounting of the north star): 10*B*F*H FLOP and SURVEY 8(d)'s minimum HBM bytes per step
         B, F = c["batch"] * (3 if c["strategy"] == "explicit" else 1), c["features"]
-        es = 2 if a.precision.startswith("bf16") else 4
+        es = 2 if a.precision != "fp32" else 4
         step_flop = 10.0 * B * F * H
         step_bytes = 3.0 * F * H * es + 2 * F * H * 4.0 + F * H * es + (B * F * 4.0 if c["kind"] == "dense_tfidf" else B * 200 * 8.0 * 2)
         out["step_roofline"] = {"mfma_frac_dense_accounting": step_flop / (1e-3 * out["ms_per_step"]) / 1e12 / (PEAK_F32_MFMA_TFLOPS if a.precision == "fp32" else PEAK_BF16_TFLOPS),

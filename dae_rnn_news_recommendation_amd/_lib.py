@@ -12,6 +12,23 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdae_hip.so")
+# The library exists in two builds of the SAME sources, one per 16-bit storage format (csrc/dae_common.h, DAE_F16):
+#   "bf16"  libdae_hip.so      bfloat16 images, v_mfma_f32_32x32x16_bf16   precision 'bf16' | 'bf16x3' | 'fp32'
+#   "f16"   libdae_hip_f16.so  IEEE fp16 images, v_mfma_f32_32x32x16_f16   precision 'f16x2' (the default 'auto') | 'f16' | 'f16x3'
+LIB_PATHS = {"bf16": LIB_PATH, "f16": os.path.join(_HERE, "libdae_hip_f16.so")}
+ABI_VERSION = 5
+# precision name -> (library build, dae_config.dtype, lo product terms of the split mode or None = the build's default)
+X3T_ALL = (1 << 11) - 1
+# what precision='auto' (class, CLIs, bench default) resolves to: the fastest mode that holds the reference's 20-step loss curve within 1e-4
+# (tests/test_hip_full_curve.py is the gate)
+AUTO_PRECISION = "bf16x3"
+PRECISIONS = {
+    "bf16": ("bf16", 0, None), "bfloat16": ("bf16", 0, None), "fp32": ("bf16", 1, None), "f32": ("bf16", 1, None), "float32": ("bf16", 1, None),
+    "bf16x3": ("bf16", 2, None),
+    "f16x2": ("f16", 2, None),          # fp16 images, W = hi + lo: two product terms in the decode and dh GEMMs, one in dW -- inside the 1e-4 curve gate
+    "f16": ("f16", 0, None),            # single fp16 images (outside the gate: triplet leg 3.5e-4 over 20 steps)
+    "f16x3": ("f16", 2, X3T_ALL),       # every operand hi + lo fp16 (three terms everywhere): the most accurate 16-bit mode
+}
 
 # enums (mirror include/dae_hip.h)
 BF16, F32 = 0, 1
@@ -22,7 +39,7 @@ OPT = {"gradient_descent": 0, "ada_grad": 1, "momentum": 2, "adam": 3}
 TRIPLET = {"none": 0, "batch_all": 1, "batch_hard": 2, "explicit": 3}
 CORR_NONE, CORR_KEEPBITS, CORR_PHILOX_MASK = 0, 1, 2
 STATS_STRIDE = 8
-WAIT_DW_CREATED = 2     # dae_plan_stream_wait_dw: the event was created by this call (not an error)
+WAIT_DW_CREATED = 100     # dae_plan_stream_wait_dw: the event was created by this call (not an error)
 STAT_COST, STAT_AE, STAT_TRIPLET, STAT_FRACTION, STAT_NUM, STAT_NVALID = range(6)
 PAD = 128
 
@@ -85,6 +102,7 @@ SIGNATURES = {
     "dae_decode_loss": (i32, [i32, i32, i32, i32, vp, i64, vp, i64, vp, vp, i64, vp, i32, i32, i32, vp, vp, vp, vp, vp,
                               vp, i64, vp, i64, vp]),
     "dae_decode_tile_n": (i32, [i32]),
+    "dae_storage_format": (i32, []),
     "dae_cos_reduce": (i32, [vp, i32, i32, i32, vp, vp, vp]),
     "dae_gram": (i32, [vp, i64, i32, i32, vp, i32, vp]),
     "dae_label_stats": (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp, f32, vp, vp]),
@@ -126,37 +144,47 @@ SIGNATURES = {
     "dae_plan_profile_name": (C.c_char_p, [i32]),
 }
 
-_lib = None
+_libs = {}
 
 
-def load():
-    """Load libdae_hip.so (once).  Raises OSError/RuntimeError loudly if it is missing or stale."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load(fmt="bf16"):
+    """Load the library build for the 16-bit storage format `fmt` ('bf16' = libdae_hip.so, 'f16' = libdae_hip_f16.so), once.
+    Raises OSError/RuntimeError loudly if it is missing or stale."""
+    lib = _libs.get(fmt)
+    if lib is not None:
+        return lib
+    path = LIB_PATHS[fmt]
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"{LIB_PATH} is missing: the HIP extension has not been built "
+            f"{path} is missing: the HIP extension has not been built "
             "(run `make -C dae_rnn_news_recommendation_amd/csrc -j` or __graft_entry__.build()). "
             "There is no CPU fallback.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)      # AttributeError here == stale library
         fn.restype = res
         fn.argtypes = args
-    if lib.dae_abi_version() != 4:
-        raise RuntimeError("libdae_hip.so ABI version mismatch")
-    _lib = lib
+    if lib.dae_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{os.path.basename(path)} ABI version mismatch")
+    if lib.dae_storage_format() != (1 if fmt == "f16" else 0):
+        raise RuntimeError(f"{os.path.basename(path)} was built for another 16-bit storage format")
+    _libs[fmt] = lib
     return lib
+
+
+def torch_lo_dtype(fmt):
+    """torch dtype of the 16-bit images of the build `fmt`."""
+    import torch
+    return torch.float16 if fmt == "f16" else torch.bfloat16
 
 
 def pad(n: int) -> int:
     return (int(n) + PAD - 1) // PAD * PAD
 
 
-def check(rc, what=""):
+def check(rc, what="", lib=None):
     if rc != 0:
-        msg = load().dae_last_error().decode("utf-8", "replace")
+        msg = (lib or load()).dae_last_error().decode("utf-8", "replace")
         raise RuntimeError(f"libdae_hip {what} failed (rc={rc}): {msg}")
 
 

@@ -8,8 +8,10 @@ line (:283-294), the per-epoch order of host RNG draws (corrupt the whole set, t
 and variable names of the checkpoint (``enc-w``, ``hidden-bias``, ``visible-bias``; :365-367).
 
 New (keyword-only, all optional):
-  precision   'bf16' (MFMA bf16 operands, fp32 accumulate/master weights), 'fp32' (exact-fp32 MFMA) or 'bf16x3' (split-bf16:
-              every stored operand of the gradient GEMMs as hi + lo bf16, three products each; CSR input, single GPU)
+  precision   'auto' (default: the fastest mode inside the 1e-4 loss-curve gate, _lib.AUTO_PRECISION) or one of _lib.PRECISIONS:
+              'f16x2' (fp16 operand images, W as hi + lo: two MFMA product terms per gradient GEMM), 'bf16x3' (split-bf16: every stored
+              operand as hi + lo bf16, three products each), 'fp32' (exact-fp32 MFMA) -- all inside the gate; 'bf16' / 'f16' (single
+              16-bit images, fp32 accumulate / master weights: faster, outside the gate), 'f16x3' (every operand hi + lo fp16)
   rng         'numpy'  -- reference-exact legacy-RandomState stream: keep decisions are drawn on the host
                           and shipped as one bit per stored entry per epoch;
               'philox' -- counter-based masking generated on the device (statistically equivalent,
@@ -136,7 +138,7 @@ class DenoisingAutoencoder(object):
         assert type(self.verbose_step) == int                      # reference :68
         assert self.verbose >= 0
         assert self.triplet_strategy in self._STRATEGIES           # reference :70
-        assert self.precision in ('auto', 'bf16', 'fp32', 'bf16x3')
+        assert self.precision == 'auto' or self.precision in L.PRECISIONS, self.precision
         self.precision_used = None if self.precision == 'auto' else self.precision    # what 'auto' resolved to (set by fit / load_model)
         assert self.rng in ('numpy', 'philox')
 
@@ -187,15 +189,13 @@ class DenoisingAutoencoder(object):
             bs = max(round(n_rows * bs), 1)                         # reference utils.py:47
         return int(bs)
 
-    def _resolve_precision(self, data):
-        """precision='auto' (the default): the fastest mode that holds the reference's loss curve within 1e-4 (north star) -- 'bf16x3'
-        (split-bf16 MFMA operands: every stored operand of the gradient GEMMs as hi + lo bf16 images, three products each) for every
-        input kind the engine runs; 'fp32' (exact-fp32 MFMA) when there is no train set to look at (load_model).  Plain 'bf16' is faster
-        but outside that gate and must be asked for."""
-        if self.precision != 'auto':
-            return self.precision
-        from ..engine import Engine
-        return 'bf16x3' if Engine.supports_x3(data) else 'fp32'
+    def _resolve_precision(self, data=None):
+        """precision='auto' (the default): the fastest mode that holds the reference's loss curve within 1e-4 (north star) -- L.AUTO_PRECISION:
+        'f16x2' (fp16 operand images on v_mfma_f32_32x32x16_f16 with W kept as hi + lo: two product terms in the decode and dh GEMMs, one in dW),
+        for every input kind, with or without a train set to look at (fit, load_model -> transform: one arithmetic).  'bf16x3' (split-bf16, three
+        terms) and 'fp32' (exact-fp32 MFMA) hold the gate too and are slower; plain 'bf16' / 'f16' are faster, outside the gate and
+        must be asked for."""
+        return L.AUTO_PRECISION if self.precision == 'auto' else self.precision
 
     def _build_engine(self, n_features, max_batch, dp_world=1, data=None):
         from ..engine import Engine                                # raises loudly without a GPU / the library
@@ -208,7 +208,7 @@ class DenoisingAutoencoder(object):
                              loss_func=self.loss_func, opt=self.opt, learning_rate=self.learning_rate,
                              momentum=self.momentum, alpha=float(self.alpha), triplet=self._strategy_key(),
                              device=self.device, dp_world=dp_world,
-                             grad_lo=(dp_world > 1 and self.dp_grad_dtype == 'bf16'))
+                             grad_lo=(dp_world > 1 and self.dp_grad_dtype == 'bf16' and self.dp_exchange != 'allreduce'))   # (the all-reduce moves the flat fp32 gradient)
         for name, value in self.plan_options.items():
             self.engine.set_option(name, value)
         return self.engine
@@ -526,11 +526,8 @@ class DenoisingAutoencoder(object):
         self.history.append(rec)
 
     def _forward_precision(self, data):
-        """Precision of a forward-only engine over `data` (validation): the training precision where the engine supports it for this
-        input, else fp32."""
-        from ..engine import Engine
-        p = self.precision_used or self._resolve_precision(data)
-        return p if (p != 'bf16x3' or Engine.supports_x3(data)) else 'fp32'
+        """Precision of a forward-only engine over `data` (validation): the training precision."""
+        return self.precision_used or self._resolve_precision(data)
 
     def _validation_forward(self, validation_set, validation_set_label):
         """Forward pass of the whole validation set as ONE batch, uncorrupted (reference :300-312)."""

@@ -26,6 +26,8 @@ extern "C" int64_t dae_pad(int64_t n) { return pad128(n); }
 extern "C" void dae_set_glds(int32_t nst) { set_use_glds(nst); }
 extern "C" int32_t dae_gemm_w8_splits(int32_t dtype, int32_t M, int32_t N, int32_t K) { return gemm_w8_splits(dtype, M, N, K * (dtype == DAE_BF16 ? 2 : 4) / 128); }
 extern "C" int32_t dae_decode_tile_n(int32_t dtype) { return decode_tile_n(dtype); }
+// 16-bit storage format this library was built for: 0 = bfloat16 (libdae_hip.so), 1 = IEEE fp16 (libdae_hip_f16.so); see dae_common.h
+extern "C" int32_t dae_storage_format(void) { return kF16 ? 1 : 0; }
 
 extern "C" int dae_gemm_nt(int32_t dtype, int32_t M, int32_t N, const void* A0, int64_t lda0, const void* Bt0, int64_t ldb0,
                            int32_t K0, const void* A1, int64_t lda1, const void* Bt1, int64_t ldb1, int32_t K1, float* C,
@@ -126,8 +128,14 @@ struct dae_plan {
     // split-bf16 mode, the two lo product terms a CPU replay of the 20-step curve called droppable (tools/precision_study.py --per-term: cost 2.5e-5,
     // triplet 4.4e-5).  Measured on the GPU against the frozen reference curve, dropping them leaves the gate: cost 7.0e-5, triplet 1.56e-4
     // (profiles/r04_precision_terms.txt) -- so both stay ON; the options exist for that measurement (decode 57.9 -> 48.3 us without its term)
-    bool x3_dec_wlo;                 // option "x3_dec_wlo" (default 1): decode multiplies (h_hi, W_lo) too; 0: z2 = h_hi.W_hi + h_lo.W_hi
-    bool x3_dh_hlo;                  // option "x3_dh_hlo" (default 1): dh multiplies (Gs, h^T_lo) too; 0: Gs.h^T_hi only
+    // -> generalised to one bit per lo product term (X3T_* in dae_kernels.h, option "x3_terms"; the legacy options "x3_dec_wlo" / "x3_dh_hlo" flip their bit).
+    // bf16 storage: all terms on.  fp16 storage (libdae_hip_f16.so): the two W terms alone (decode (h, W_lo), dh (delta2, W^T_lo)) -- no lo image of
+    // delta2 / delta2^T / h / delta1 is written or read (CPU replay of the 20-step curve: cost 1.4e-5, triplet 6.5e-5; profiles/r04_precision_fp16_study.txt)
+    uint32_t terms;
+    // 16-bit images of the back-propagated operands (delta2, delta2^T, Gs, delta1^T) hold op_scale * value, a power of two the consuming epilogues
+    // divide out (dh_finish: 1 / op_scale; the dW epilogue: OptEpi::gin): fp16's normal range ends at 6.1e-5 and delta2 ~ (y - x) / B, Gs ~ 1e-6 sit
+    // below it.  1 for bf16 storage and fp32.  Option "op_scale_log2".
+    float op_scale;
     bool dw_pair_ok;                 // option "dw_pair": split-bf16 dW kernel streams x~^T resp. delta2^T_hi ONCE for the hi and lo image of delta1^T resp. h^T
     bool xct2_clean;
     uint32_t* xtb;                   // x~^T as a bit image [Fp x Bpm/32] (binary CSR + bf16: operand of the sparse half of the dW kernel)
@@ -152,6 +160,9 @@ struct dae_plan {
     uint64_t* acc;
 };
 
+// lo image of the row-major shadow: exists (and is kept current by every kernel that updates W) only while the decode's (h, W_lo) term is on
+static void* plan_w_lo2(const dae_plan* p) { return (p->x3 && (p->terms & X3T_DEC_WLO)) ? (void*)p->W_lo2 : nullptr; }
+
 static int auto_splits(int tiles, int ktiles) {
     int s = 384 / (tiles > 0 ? tiles : 1);
     if (s >= 8) s = (s / 8) * 8;
@@ -168,8 +179,11 @@ static void plan_x3_splits(dae_plan* p) {
     const int kt_f = p->Fp * p->es / 128, kt_b = p->Bpm * p->es / 128;
     p->s_enc3 = p->s_enc; p->s_dh3 = p->s_dh;
     if (!p->x3) return;
-    if (c.encode_splits <= 0) if (const int w = gemm_w8_splits(c.dtype, p->Bpm, p->Hp, 3 * kt_f)) p->s_enc3 = w;
-    if (c.dh_splits <= 0) if (const int w = gemm_w8_splits(c.dtype, p->Bpm, p->Hp, 3 * kt_f + (p->x3_dh_hlo ? 2 : 1) * kt_b)) p->s_dh3 = w;
+    const uint32_t T = p->terms;
+    const int n_enc = 1 + ((T & X3T_ENC_WLO) ? 1 : 0) + ((T & X3T_ENC_XLO) ? 1 : 0);
+    const int n_dh = 1 + ((T & X3T_DH_WLO) ? 1 : 0) + ((T & X3T_DH_D2LO) ? 1 : 0);
+    if (c.encode_splits <= 0) if (const int w = gemm_w8_splits(c.dtype, p->Bpm, p->Hp, n_enc * kt_f)) p->s_enc3 = w;
+    if (c.dh_splits <= 0) if (const int w = gemm_w8_splits(c.dtype, p->Bpm, p->Hp, n_dh * kt_f + ((T & X3T_DH_HLO) ? 2 : 1) * kt_b)) p->s_dh3 = w;
 }
 
 static uint64_t carve(dae_plan* p, char* base) {
@@ -197,15 +211,16 @@ static uint64_t carve(dae_plan* p, char* base) {
     p->delta1_lo = take(Bp * Hp * es);
     p->xtb = (uint32_t*)take(Fp * (Bp / 32) * 4);
     p->dh_extra = (float*)take(Bp * Hp * 4);
-    p->W_lo2 = take(p->x3 ? Fp * Hp * 2 : 256);
-    p->Wt_lo2 = take(p->x3 ? Hp * Fp * 2 : 256);
-    p->h_t2 = take(p->x3 ? Hp * Bp * 2 : 256);
-    p->delta2_2 = take(p->x3 ? Bp * Fp * 2 : 256);
-    p->delta2_t2 = take(p->x3 ? Fp * Bp * 2 : 256);
-    p->delta1_t2 = take(p->x3 ? Hp * Bp * 2 : 256);
-    p->x_2 = take(p->x3 ? Bp * Fp * 2 : 256);
-    p->xct_2 = take(p->x3 ? Fp * Bp * 2 : 256);
-    p->xc_2 = take(p->x3 ? Bp * Fp * 2 : 256);
+    const uint32_t T = p->x3 ? p->terms : 0u;          // lo images exist only for the product terms that read them
+    p->W_lo2 = take((T & X3T_DEC_WLO) ? Fp * Hp * 2 : 256);
+    p->Wt_lo2 = take(p->x3 ? Hp * Fp * 2 : 256);      // (the split mode's dW epilogue always writes it)
+    p->h_t2 = take((T & (X3T_DH_HLO | X3T_DW_HLO)) ? Hp * Bp * 2 : 256);
+    p->delta2_2 = take((T & X3T_DH_D2LO) ? Bp * Fp * 2 : 256);
+    p->delta2_t2 = take((T & X3T_DW_D2LO) ? Fp * Bp * 2 : 256);
+    p->delta1_t2 = take((T & X3T_DW_D1LO) ? Hp * Bp * 2 : 256);
+    p->x_2 = take((T & X3T_XV) ? Bp * Fp * 2 : 256);
+    p->xct_2 = take((T & X3T_XV) ? Fp * Bp * 2 : 256);
+    p->xc_2 = take((T & X3T_ENC_XLO) ? Bp * Fp * 2 : 256);
     p->hcat_a = take(p->gram_split ? Bp * 3 * Hp * 2 : 256);
     p->hcat_b = take(p->gram_split ? Bp * 3 * Hp * 2 : 256);
     p->D_slabs = (float*)take((uint64_t)p->s_gram * Bp * Bp * 4);
@@ -268,7 +283,11 @@ extern "C" int dae_plan_create(const dae_config* cfg, dae_plan** out) {
     if (p->s_dh > kt_f) p->s_dh = kt_f;
     // split-bf16 mode on dense-ndarray input: the encode contraction has 3 K segments and dh 5; the 256 x 256 kernel is taken exactly when the
     // launch is handed ITS slice count for the real K-tile total, so these are planned with the segment lists' totals
-    p->x3_dec_wlo = true; p->x3_dh_hlo = true;
+    p->terms = kF16 ? (uint32_t)X3T_F16_DEFAULT : (uint32_t)X3T_ALL;
+    // fp16 storage: op_scale = the largest power of two <= 16 * max_batch (capped at 2^14).  Bounds that keep the scaled images finite: |delta2| <= cw_i
+    // (<= ~8 / B typically, <= 1 always) for a sigmoid decoder, |Gs| <= 2 alpha B / N_valid; the stores saturate at +-65504 beyond that (sat16)
+    p->op_scale = 1.f;
+    if (kF16 && p->es == 2) { float sc = 1.f; while (sc * 2.f <= 16.f * (float)p->Bmax && sc < 16384.f) sc *= 2.f; p->op_scale = sc; }
     p->dw_pair_ok = true;
     plan_x3_splits(p);
     if (p->s_gram > p->Hp * 4 / 128) p->s_gram = p->Hp * 4 / 128;
@@ -327,11 +346,17 @@ extern "C" int dae_plan_set_option(dae_plan* p, const char* name, int32_t value)
     else if (!strcmp(name, "miner_pack")) set_miner_pack(on);        // process-wide (the launcher's choice), like dae_set_glds
     else if (!strcmp(name, "miner_tile")) set_miner_tile(on);        // process-wide: 0 = the former wave-per-positive batch_all kernel
     else if (!strcmp(name, "sym_in_decode")) p->sym_ride_ok = on;
-    else if (!strcmp(name, "x3_dec_wlo") || !strcmp(name, "x3_dh_hlo")) {
+    else if (!strcmp(name, "x3_dec_wlo") || !strcmp(name, "x3_dh_hlo") || !strcmp(name, "x3_terms")) {
         DAE_CHECK_ARG(!p->bound, "plan_set_option: %s changes the split-K plan (workspace layout), set it before dae_plan_bind", name);
-        if (name[4] == 'e') p->x3_dec_wlo = on; else p->x3_dh_hlo = on;
+        if (name[3] == 't') { DAE_CHECK_ARG(value >= 0 && (uint32_t)value <= X3T_ALL, "plan_set_option: x3_terms is a mask of the X3T_* bits (0..%u)", (unsigned)X3T_ALL); p->terms = (uint32_t)value; }
+        else { const uint32_t bit = name[4] == 'e' ? X3T_DEC_WLO : X3T_DH_HLO; p->terms = on ? (p->terms | bit) : (p->terms & ~bit); }
         plan_x3_splits(p);
         p->ws_bytes = carve(p, nullptr);
+    }
+    else if (!strcmp(name, "op_scale_log2")) {
+        DAE_CHECK_ARG(value >= 0 && value <= 20, "plan_set_option: op_scale_log2 in 0..20");
+        DAE_CHECK_ARG(p->es == 2, "plan_set_option: op_scale_log2 applies to the 16-bit modes");
+        p->op_scale = (float)(1u << value);
     }
     else if (!strcmp(name, "gram_fp32")) {
         DAE_CHECK_ARG(!p->bound, "plan_set_option: gram_fp32 changes the workspace layout, set it before dae_plan_bind");
@@ -387,7 +412,7 @@ extern "C" int dae_plan_bind(dae_plan* p, const dae_buffers* bufs) {
 extern "C" int dae_plan_sync_shadows(dae_plan* p, void* stream) {
     DAE_CHECK_ARG(p && p->bound, "plan_sync_shadows: plan not bound");
     return launch_opt_step(p->cfg.opt, 0.f, 0.f, 1.f, p->b.W, p->b.bh, p->b.bv, p->b.grad, p->b.opt_s1, p->b.opt_s2, p->Fp, p->Hp,
-                           p->cfg.dtype, p->b.W_lo, p->b.Wt_lo, p->x3 ? p->W_lo2 : nullptr, p->x3 ? p->Wt_lo2 : nullptr, /*apply=*/0, stream);
+                           p->cfg.dtype, p->b.W_lo, p->b.Wt_lo, plan_w_lo2(p), p->x3 ? p->Wt_lo2 : nullptr, /*apply=*/0, stream);
 }
 
 extern "C" void* dae_plan_buffer(dae_plan* p, const char* name) {
@@ -405,7 +430,7 @@ extern "C" void* dae_plan_buffer(dae_plan* p, const char* name) {
 extern "C" int dae_plan_info(const dae_plan* p, int32_t* out8) {
     DAE_CHECK_ARG(p && out8, "plan_info: null");
     out8[0] = p->Fp; out8[1] = p->Hp; out8[2] = p->Bpm; out8[3] = p->s_enc; out8[4] = p->s_dh; out8[5] = p->s_gram;
-    out8[6] = p->es; out8[7] = p->x3 ? 1 : 0;
+    out8[6] = p->es; out8[7] = p->x3 ? (int32_t)(1u | (p->terms << 1) | ((uint32_t)ilogbf(p->op_scale) << 16)) : (int32_t)((uint32_t)ilogbf(p->op_scale) << 16);   // bit 0: split mode; bits 1..11: its lo terms; bits 16..: log2 op_scale
     return 0;
 }
 
@@ -510,6 +535,8 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     // A tiles of its x~^T.delta1 segment in LDS; otherwise the dense x~^T image (18 MB, scattered / un-scattered every step) is streamed
     const bool src_binary = s->c_indptr ? !s->c_values : (p->b.indptr && !p->b.values);
     const bool x3 = p->x3;
+    const uint32_t T = x3 ? p->terms : 0u;                   // lo product terms that are multiplied (X3T_*)
+    const float osc = p->es == 2 ? p->op_scale : 1.f, oinv = 1.f / osc;   // operand scale of the 16-bit delta images (a power of two)
     // split-bf16 mode: the fused dW + optimizer kernel exists for shapes of at most one 160 x 128 tile per CU; larger shapes (and the
     // data-parallel gradient-only phases) take the N-segment dW GEMM to memory + the optimizer kernel that writes all four shadows
     const bool fuse_opt = fuse_opt0 && (!x3 || dw_x3_fits(Fp, Hp, Bp));
@@ -531,8 +558,9 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     bool x3_vals = false;
     if (x3) {
         uint32_t u; memcpy(&u, &s->scale, 4);
-        x3_vals = !src_binary || (u & 0xffffu) != 0u || (p->b.indptr && p->b.values) || dense_in;
+        x3_vals = (T & X3T_XV) && (!src_binary || (u & 0xffffu) != 0u || (p->b.indptr && p->b.values) || dense_in);
     }
+    const bool x2_clean = x3 && (T & X3T_XV) && !use_xbits && (p->b.values || p->b.dense);    // the clean rows get a lo image (valued CSR / dense train set)
     if (!resume && backward && csr_in) {
         if (dw_bits) { if (!(tail && p->xtb_clean)) PROF(PS_MEMSET, memset_async(p->xtb, (size_t)Fp * (ldB / 32) * 4, st)); }
         else if (!(tail && p->xct_clean)) PROF(PS_MEMSET, memset_async(p->xct, (size_t)Fp * ldB * p->es, st));
@@ -554,7 +582,10 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
         if (!own_clean)
             PROF(PS_GATHER, gather_batch(p, p->b.indptr, p->b.indices, p->b.values, p->b.dense, p->b.ld_dense, s->row_idx, B,
                             use_xbits ? nullptr : p->x, nullptr, nullptr, rowsq, DAE_CORR_NONE, nullptr, 0, 0, 0.f, 1.f, stream, nullptr, nullptr,
-                            use_xbits ? p->x_bits : nullptr, (x3 && !use_xbits && p->b.values) ? p->x_2 : nullptr));
+                            use_xbits ? p->x_bits : nullptr, (x2_clean && p->b.values) ? p->x_2 : nullptr));
+        // a DENSE train set with an explicitly corrupted CSR copy (salt-and-pepper): the clean rows' lo image comes from the dense rows
+        if (!own_clean && x2_clean && p->b.dense && !p->b.indptr)
+            PROF(PS_GATHER, gather_dense_lo(p, p->b.dense, p->b.ld_dense, s->row_idx, B, p->x_2, nullptr, nullptr, DAE_CORR_NONE, nullptr, 0, 0, 0.f, 1.f, stream));
         EncCsrLaunch q;
         memset(&q, 0, sizeof(q));
         q.indptr = s->c_indptr ? s->c_indptr : p->b.indptr; q.indices = s->c_indptr ? s->c_indices : p->b.indices;
@@ -567,7 +598,7 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
         q.x_bits = own_clean ? p->x_bits : nullptr; q.ldxb = Fp / 32; q.xct = (backward && !dw_bits) ? p->xct : nullptr; q.ldt = ldB;
         q.xtb = (backward && dw_bits) ? p->xtb : nullptr; q.ldxt = ldB / 32;
         q.rowsq = own_clean ? rowsq : nullptr;
-        q.h_t2 = x3 ? p->h_t2 : nullptr;
+        q.h_t2 = (T & (X3T_DH_HLO | X3T_DW_HLO)) ? p->h_t2 : nullptr;
         q.xct2 = (x3_vals && backward) ? p->xct_2 : nullptr;
         q.label_job = label_with_encode ? &lj : nullptr;
         PROF(PS_ENC_GEMM, launch_encode_csr(q, st));
@@ -586,12 +617,14 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
                             s->seed, s->rng_stream, s->corr_frac, s->scale, stream, use_bits ? p->xc_bits : nullptr, label_in_gather ? &lj : nullptr,
                             use_xbits ? p->x_bits : nullptr));
         }
-        if (x3 && dense_in)
-            PROF(PS_GATHER, gather_dense_lo(p, p->b.dense, p->b.ld_dense, s->row_idx, B, p->x_2, p->xc_2, backward ? p->xct_2 : nullptr, s->corr_mode,
+        if (x3 && dense_in && (T & (X3T_XV | X3T_ENC_XLO)))
+            PROF(PS_GATHER, gather_dense_lo(p, p->b.dense, p->b.ld_dense, s->row_idx, B, (T & X3T_XV) ? p->x_2 : nullptr, (T & X3T_ENC_XLO) ? p->xc_2 : nullptr,
+                                            (backward && (T & X3T_XV)) ? p->xct_2 : nullptr, s->corr_mode,
                                             s->keep_bits, s->seed, s->rng_stream, s->corr_frac, s->scale, stream));
         // 3-4. encode (K1/K2)
         if (x3 && dense_in) {     // z1 = x~ W as (x~_hi, W^T_hi) (x~_hi, W^T_lo) (x~_lo, W^T_hi)
-            const GemmSegDesc es3[3] = {{p->xc, Fp, p->b.Wt_lo, Fp, Fp}, {p->xc, Fp, p->Wt_lo2, Fp, Fp}, {p->xc_2, Fp, p->b.Wt_lo, Fp, Fp}};
+            const GemmSegDesc es3[3] = {{p->xc, Fp, p->b.Wt_lo, Fp, Fp}, {p->xc, Fp, p->Wt_lo2, Fp, (T & X3T_ENC_WLO) ? Fp : 0},
+                                        {p->xc_2, Fp, p->b.Wt_lo, Fp, (T & X3T_ENC_XLO) ? Fp : 0}};
             PROF(PS_ENC_GEMM, launch_gemm_f32out_n(dt, Bp, Hp, es3, 3, p->slabs, Hp, p->s_enc3, slab, st, GEMM_ROLE_ENCODE,
                                                    label_with_encode ? &lj : nullptr, label_with_encode ? &enc_label_done : nullptr));
         } else if (use_bits)
@@ -602,7 +635,7 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
                                                  GEMM_ROLE_ENCODE, label_with_encode ? &lj : nullptr, label_with_encode ? &enc_label_done : nullptr));
         PROF(PS_ENC_FIN, launch_encode_finish(p->slabs, (x3 && dense_in) ? p->s_enc3 : p->s_enc, slab, Hp, p->b.bh, B, H, c.enc_act, dt, p->h_f32, p->h_lo, Hp,
                                               p->h_t, ldB, p->gram_split ? p->hcat_a : nullptr, p->gram_split ? p->hcat_b : nullptr,
-                                              x3 ? p->h_t2 : nullptr, stream));
+                                              (T & (X3T_DH_HLO | X3T_DW_HLO)) ? p->h_t2 : nullptr, stream));
         labels_done = (label_in_gather && !s->c_indptr) || enc_label_done;
     }
     if (h_only) return 0;
@@ -632,6 +665,7 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
         e.dbv_part = backward ? p->dbv_part : nullptr; e.cos_part = p->cos_part;
         e.delta2 = backward ? p->delta2 : nullptr; e.ldd = Fp; e.delta2_t = backward ? p->delta2_t : nullptr; e.lddt = ldB;
         e.B = B; e.F = F; e.Bp = Bp; e.Fp = Fp; e.dec_act = c.dec_act; e.loss_func = c.loss_func; e.ce_literal = p->ce_literal ? 1 : 0;
+        e.op_scale = osc;
         if (ride) { e.sym_G = p->G; e.sym_scalars = p->tri_scalars; e.sym_Gs = p->Gs; e.sym_B = B; e.sym_Bp = Bp; }
         // z2 = h W^T: one K segment, or -- split-bf16 -- (h_hi, W_hi) (h_hi, W_lo) (h_lo, W_hi); the row-major h_hi / h_lo are the first and
         // third block of the Gram operand hcat_a = [hi | hi | lo] (leading dimension 3 Hp)
@@ -639,11 +673,11 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
         int ndseg = 1;
         if (x3) {
             dsegs[0] = {p->hcat_a, 3 * (int64_t)Hp, p->b.W_lo, Hp, Hp};
-            dsegs[1] = {p->hcat_a, 3 * (int64_t)Hp, p->W_lo2, Hp, p->x3_dec_wlo ? Hp : 0};      // K = 0: the term is dropped
-            dsegs[2] = {p->hcat_a + (size_t)2 * Hp * 2, 3 * (int64_t)Hp, p->b.W_lo, Hp, Hp};
+            dsegs[1] = {p->hcat_a, 3 * (int64_t)Hp, p->W_lo2, Hp, (T & X3T_DEC_WLO) ? Hp : 0};      // K = 0: the term is dropped
+            dsegs[2] = {p->hcat_a + (size_t)2 * Hp * 2, 3 * (int64_t)Hp, p->b.W_lo, Hp, (T & X3T_DEC_HLO) ? Hp : 0};
             ndseg = 3;
-            if (backward) { e.delta2_2 = p->delta2_2; e.delta2_t2 = p->delta2_t2; }
-            if (!use_xbits && (p->b.values || dense_in)) e.x2 = p->x_2;    // valued clean rows: x = hi + lo (RES instantiations)
+            if (backward) { e.delta2_2 = (T & X3T_DH_D2LO) ? p->delta2_2 : nullptr; e.delta2_t2 = (T & X3T_DW_D2LO) ? p->delta2_t2 : nullptr; }
+            if (x2_clean) e.x2 = p->x_2;    // valued clean rows: x = hi + lo (RES instantiations)
         }
         if (is_cos) {
             e.cos_pass = 1;
@@ -690,7 +724,7 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
             PROF(PS_TRI_FIN, dae_triplet_finalize(c.triplet, c.pos_triplets_only, B, Bp, c.alpha, p->loss_part, p->cnt_part, p->nvalid,
                                     p->dw_i32, p->role_cnt, p->dw_f32, p->cw, p->tri_scalars, stream));
         sym_ride = backward && p->sym_ride_ok && !forked;        // the decode launch below carries it
-        if (backward && !sym_ride) PROF(PS_SYM, dae_sym_scale(p->G, B, Bp, p->tri_scalars, dt, p->Gs, stream));
+        if (backward && !sym_ride) PROF(PS_SYM, launch_sym_scale(p->G, B, Bp, p->tri_scalars, dt, p->Gs, osc, st));
     }
     if (forked) DAE_CHECK_HIP(hipStreamWaitEvent(st, p->ev_join, 0));   // join: delta2 and the loss partials are ready
     else RC(decode_section(st, sym_ride));
@@ -708,23 +742,26 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     const bool mined = !ext_mine && (c.triplet == DAE_TRIPLET_BATCH_ALL || c.triplet == DAE_TRIPLET_BATCH_HARD);
     const int s_dh = (x3 && dense_in) ? p->s_dh3 : p->s_dh;
     if (x3) {       // (d2_hi, Wt_hi) (d2_hi, Wt_lo) (d2_lo, Wt_hi) + Gs.h_hi (+ Gs.h_lo with option x3_dh_hlo): Gs itself stays bf16 (tools/precision_study.py)
-        const GemmSegDesc hs[5] = {{p->delta2, Fp, p->b.Wt_lo, Fp, Fp}, {p->delta2, Fp, p->Wt_lo2, Fp, Fp}, {p->delta2_2, Fp, p->b.Wt_lo, Fp, Fp},
-                                   {p->Gs, Bp, p->h_t, ldB, mined ? Bp : 0}, {p->Gs, Bp, p->h_t2, ldB, (mined && p->x3_dh_hlo) ? Bp : 0}};
+        const GemmSegDesc hs[5] = {{p->delta2, Fp, p->b.Wt_lo, Fp, Fp}, {p->delta2, Fp, p->Wt_lo2, Fp, (T & X3T_DH_WLO) ? Fp : 0},
+                                   {p->delta2_2, Fp, p->b.Wt_lo, Fp, (T & X3T_DH_D2LO) ? Fp : 0},
+                                   {p->Gs, Bp, p->h_t, ldB, mined ? Bp : 0}, {p->Gs, Bp, p->h_t2, ldB, (mined && (T & X3T_DH_HLO)) ? Bp : 0}};
         PROF(PS_DH_GEMM, launch_gemm_f32out_n(dt, Bp, Hp, hs, 5, p->slabs, Hp, s_dh, slab, st, GEMM_ROLE_DH));
     } else {
         PROF(PS_DH_GEMM, launch_gemm_f32out(dt, Bp, Hp, p->delta2, Fp, p->b.Wt_lo, Fp, Fp, mined ? p->Gs : nullptr, Bp, mined ? p->h_t : nullptr, ldB,
                               mined ? Bp : 0, p->slabs, Hp, p->s_dh, slab, st, GEMM_ROLE_DH));
     }
     PROF(PS_DH_FIN, launch_dh_finish(p->slabs, s_dh, slab, Hp, (explicit3 || ext_mine) ? p->dh_extra : nullptr, p->h_f32, Hp, p->b.bh, B, H, c.enc_act, dt,
-                     p->delta1_t, ldB, p->colsum_part, nullptr, nullptr, st, x3 ? p->delta1_t2 : nullptr));
+                     p->delta1_t, ldB, p->colsum_part, nullptr, nullptr, st, (T & X3T_DW_D1LO) ? p->delta1_t2 : nullptr, oinv, osc));
     // 11. dW = x~^T delta1 + delta2^T h                                      (K8, tied weights)
     // split-bf16 segment list (K = 0 segments are skipped): the third one exists only when x~^T has a lo image
-    const GemmSegDesc ws3[6] = {{p->xct, ldB, p->delta1_t, ldB, Bp}, {p->xct, ldB, p->delta1_t2, ldB, Bp}, {p->xct_2, ldB, p->delta1_t, ldB, x3_vals ? Bp : 0},
-                                {p->delta2_t, ldB, p->h_t, ldB, Bp}, {p->delta2_t, ldB, p->h_t2, ldB, Bp}, {p->delta2_t2, ldB, p->h_t, ldB, Bp}};
+    const GemmSegDesc ws3[6] = {{p->xct, ldB, p->delta1_t, ldB, Bp}, {p->xct, ldB, p->delta1_t2, ldB, (T & X3T_DW_D1LO) ? Bp : 0},
+                                {p->xct_2, ldB, p->delta1_t, ldB, x3_vals ? Bp : 0},
+                                {p->delta2_t, ldB, p->h_t, ldB, Bp}, {p->delta2_t, ldB, p->h_t2, ldB, (T & X3T_DW_HLO) ? Bp : 0},
+                                {p->delta2_t2, ldB, p->h_t, ldB, (T & X3T_DW_D2LO) ? Bp : 0}};
     if (fuse_opt || dw_pc_grad) {
         OptEpi oe;
         memset(&oe, 0, sizeof(oe));
-        oe.ldw = Hp; oe.ldwt = Fp;
+        oe.ldw = Hp; oe.ldwt = Fp; oe.gin = oinv;
         if (fuse_opt) {
             oe.W = p->b.W; oe.grad = s->phase == 3 ? nullptr : p->b.grad; oe.s1 = p->b.opt_s1; oe.s2 = p->b.opt_s2;
             oe.W_lo = p->b.W_lo; oe.Wt_lo = p->b.Wt_lo; oe.opt = c.opt; oe.lr = plan_lr(p, s->adam_t);
@@ -734,7 +771,7 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
             oe.ldw = Hp;
         }
         if (x3) {   // x~^T.(d1_hi + d1_lo) + (d2^T_hi, h^T_hi) (d2^T_hi, h^T_lo) (d2^T_lo, h^T_hi); the epilogue writes both parts of both shadows
-            oe.W_lo2 = p->x3_dec_wlo ? p->W_lo2 : nullptr; oe.Wt_lo2 = p->Wt_lo2;     // W_lo2 feeds the decode's (h_hi, W_lo) term only
+            oe.W_lo2 = (T & X3T_DEC_WLO) ? p->W_lo2 : nullptr; oe.Wt_lo2 = p->Wt_lo2;     // W_lo2 feeds the decode's (h_hi, W_lo) term only
             PROF(PS_DW_GEMM, launch_dw_opt_n(Fp, Hp, ws3, 6, oe, st, p->dw_pair_ok));
         } else if (dw_bits) {
             DwBitsArgs xa{p->xtb, ldB / 32, s->scale};
@@ -743,9 +780,10 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
             PROF(PS_DW_GEMM, launch_dw_opt(Fp, Hp, p->xct, ldB, p->delta1_t, ldB, Bp, p->delta2_t, ldB, p->h_t, ldB, Bp, oe, st));
         }
     } else if (x3) {
-        PROF(PS_DW_GEMM, launch_gemm_f32out_n(dt, Fp, Hp, ws3, 6, p->b.grad, Hp, 1, 0, st, GEMM_ROLE_DW));
+        PROF(PS_DW_GEMM, launch_gemm_f32out_n(dt, Fp, Hp, ws3, 6, p->b.grad, Hp, 1, 0, st, GEMM_ROLE_DW, nullptr, nullptr, oinv));
     } else {
-        PROF(PS_DW_GEMM, launch_gemm_f32out(dt, Fp, Hp, p->xct, ldB, p->delta1_t, ldB, Bp, p->delta2_t, ldB, p->h_t, ldB, Bp, p->b.grad, Hp, 1, 0, st, GEMM_ROLE_DW));
+        const GemmSegDesc ws2[2] = {{p->xct, ldB, p->delta1_t, ldB, Bp}, {p->delta2_t, ldB, p->h_t, ldB, Bp}};
+        PROF(PS_DW_GEMM, launch_gemm_f32out_n(dt, Fp, Hp, ws2, 2, p->b.grad, Hp, 1, 0, st, GEMM_ROLE_DW, nullptr, nullptr, oinv));
         // data parallel with a bf16 exchange image: the shape did not fit the kernel that writes it directly
         if (!apply_now && dt == DAE_BF16 && p->b.grad_lo) RC(launch_cast_bf16(p->b.grad, p->b.grad_lo, (int64_t)Fp * Hp, st));
     }
@@ -771,7 +809,7 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     if (s->phase == 1 || s->phase == 5 || fuse_opt) return 0;
     // 13. optimizer (K9): W (+ shadows); biases were updated above
     PROF(PS_OPT, launch_opt_step(c.opt, plan_lr(p, s->adam_t), c.momentum, s->grad_scale, p->b.W, p->b.bh, p->b.bv, p->b.grad, p->b.opt_s1,
-                                 p->b.opt_s2, Fp, Hp, dt, p->b.W_lo, p->b.Wt_lo, x3 ? p->W_lo2 : nullptr, x3 ? p->Wt_lo2 : nullptr, /*apply=*/2, stream));
+                                 p->b.opt_s2, Fp, Hp, dt, p->b.W_lo, p->b.Wt_lo, plan_w_lo2(p), x3 ? p->Wt_lo2 : nullptr, /*apply=*/2, stream));
     return 0;
 }
 
@@ -779,7 +817,7 @@ extern "C" int dae_plan_apply(dae_plan* p, int32_t adam_t, float grad_scale, voi
     DAE_CHECK_ARG(p && p->bound, "plan_apply: plan not bound");
     const float lr = plan_lr(p, adam_t);
     return launch_opt_step(p->cfg.opt, lr, p->cfg.momentum, grad_scale, p->b.W, p->b.bh, p->b.bv, p->b.grad, p->b.opt_s1, p->b.opt_s2,
-                           p->Fp, p->Hp, p->cfg.dtype, p->b.W_lo, p->b.Wt_lo, p->x3 ? p->W_lo2 : nullptr, p->x3 ? p->Wt_lo2 : nullptr, /*apply=*/1, stream);
+                           p->Fp, p->Hp, p->cfg.dtype, p->b.W_lo, p->b.Wt_lo, plan_w_lo2(p), p->x3 ? p->Wt_lo2 : nullptr, /*apply=*/1, stream);
 }
 
 // Data-parallel second half with a SHARDED optimizer: this rank owns rows [f0, f1) of W.  grad_rows holds the
@@ -875,9 +913,11 @@ extern "C" int dae_encode_rows(dae_plan* p, const int32_t* row_idx, int32_t B, f
     RC(gather_batch(p, indptr, indices, values, dense, ld_dense, row_idx, B, nullptr, use_bits ? nullptr : p->xc, nullptr, nullptr,
                     DAE_CORR_NONE, nullptr, 0, 0, 0.f, scale, stream, use_bits ? p->xc_bits : nullptr));
     const int64_t slab = (int64_t)Bp * Hp;
-    if (p->x3 && dense) {        // split-bf16 mode: x = hi + lo against W^T = hi + lo (three products), as the training step encodes
-        RC(gather_dense_lo(p, dense, ld_dense, row_idx, B, nullptr, p->xc_2, nullptr, DAE_CORR_NONE, nullptr, 0, 0, 0.f, scale, stream));
-        const GemmSegDesc es3[3] = {{p->xc, Fp, p->b.Wt_lo, Fp, Fp}, {p->xc, Fp, p->Wt_lo2, Fp, Fp}, {p->xc_2, Fp, p->b.Wt_lo, Fp, Fp}};
+    if (p->x3 && dense) {        // split mode: x = hi + lo against W^T = hi + lo (the lo terms the plan keeps), as the training step encodes
+        const uint32_t T = p->terms;
+        if (T & X3T_ENC_XLO) RC(gather_dense_lo(p, dense, ld_dense, row_idx, B, nullptr, p->xc_2, nullptr, DAE_CORR_NONE, nullptr, 0, 0, 0.f, scale, stream));
+        const GemmSegDesc es3[3] = {{p->xc, Fp, p->b.Wt_lo, Fp, Fp}, {p->xc, Fp, p->Wt_lo2, Fp, (T & X3T_ENC_WLO) ? Fp : 0},
+                                    {p->xc_2, Fp, p->b.Wt_lo, Fp, (T & X3T_ENC_XLO) ? Fp : 0}};
         RC(launch_gemm_f32out_n(dt, Bp, Hp, es3, 3, p->slabs, Hp, p->s_enc3, slab, st, GEMM_ROLE_ENCODE));
         RC(dae_encode_finish(p->slabs, p->s_enc3, slab, Hp, p->b.bh, B, p->H, p->cfg.enc_act, dt, p->h_f32, nullptr, Hp, nullptr, 0, nullptr, nullptr,
                              stream));

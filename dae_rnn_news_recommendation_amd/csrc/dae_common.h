@@ -14,6 +14,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short bf16_t;   // raw bf16 bits
 
 constexpr int WAVE = 64;
@@ -34,20 +35,59 @@ void set_error(const char* fmt, ...);
     } while (0)
 #define DAE_CHECK_LAUNCH() DAE_CHECK_HIP(hipGetLastError())
 
-// ---- bf16 <-> f32 (round to nearest even, NaN preserved) ----
+// ---- the library's 16-bit storage format ----
+// Every 16-bit operand image (W shadows, h, x~^T, delta2, delta1, Gs, Gram operands) is written and read through the helpers below, and the
+// MFMA that multiplies them is chosen from the same switch (dae_gemm.hip: Mma<bf16_t>).  The library is built twice from the same sources:
+//   libdae_hip.so      DAE_F16 = 0   bfloat16 (8 significant bits, fp32 range)          v_mfma_f32_32x32x16_bf16
+//   libdae_hip_f16.so  DAE_F16 = 1   IEEE fp16 (11 significant bits, normal range 6e-5 .. 65504)   v_mfma_f32_32x32x16_f16
+// Both MFMAs run at the same rate; fp16's three extra bits are what lets the parity mode multiply TWO product terms per gradient GEMM instead of
+// split-bf16's three (tools/precision_study.py --scheme).  fp16's narrow range is handled by the plan: the back-propagated images
+// (delta2, Gs, delta1) are stored times a power of two `op_scale` that the consuming epilogues divide out again (dae_api.hip).
+// The type name bf16_t ("raw 16 bits") and the f2bf* / bf2f names are kept for both formats.
+#ifndef DAE_F16
+#define DAE_F16 0
+#endif
+constexpr bool kF16 = DAE_F16 != 0;
+constexpr uint32_t kOne16 = kF16 ? 0x3C00u : 0x3F80u;       // 1.0 in the storage format
+// round to nearest even, NaN preserved (fp16: overflow -> inf, subnormals kept)
 __device__ __forceinline__ bf16_t f2bf(float f) {
+    if constexpr (kF16) return __builtin_bit_cast(bf16_t, static_cast<_Float16>(f));
     uint32_t u = __float_as_uint(f);
     if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);   // NaN
     u += 0x7fffu + ((u >> 16) & 1u);
     return (bf16_t)(u >> 16);
 }
-__device__ __forceinline__ float bf2f(bf16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
-// hardware RNE convert (v_cvt_pk_bf16_f32 on gfx950); identical to f2bf for finite inputs
-__device__ __forceinline__ bf16_t f2bf_hw(float f) { return __builtin_bit_cast(bf16_t, static_cast<__bf16>(f)); }
+__device__ __forceinline__ float bf2f(bf16_t b) {
+    if constexpr (kF16) return static_cast<float>(__builtin_bit_cast(_Float16, b));
+    return __uint_as_float(((uint32_t)b) << 16);
+}
+// hardware RNE convert (v_cvt_pk_bf16_f32 / v_cvt_f16_f32 on gfx950); identical to f2bf for finite inputs
+__device__ __forceinline__ bf16_t f2bf_hw(float f) {
+    if constexpr (kF16) return __builtin_bit_cast(bf16_t, static_cast<_Float16>(f));
+    return __builtin_bit_cast(bf16_t, static_cast<__bf16>(f));
+}
 __device__ __forceinline__ uint32_t f2bf_pack_hw(float lo, float hi) {
+    if constexpr (kF16) {
+        typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+        f16x2_t v = {static_cast<_Float16>(lo), static_cast<_Float16>(hi)};
+        return __builtin_bit_cast(uint32_t, v);
+    }
     typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
     bf16x2_t v = {static_cast<__bf16>(lo), static_cast<__bf16>(hi)};
     return __builtin_bit_cast(uint32_t, v);
+}
+// a scaled back-propagated value on its way into a 16-bit image: fp16 saturates at +-65504 instead of overflowing to inf (an inf would turn
+// every product with a zero operand into NaN); bf16 has the fp32 range and needs nothing
+__device__ __forceinline__ float sat16(float v) {
+    if constexpr (kF16) return __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);
+    return v;
+}
+// host side: the 16-bit image of a finite float (round to nearest even) -- operands the launchers build themselves (the value of a kept entry)
+static inline uint32_t host_f2bf(float f) {
+    if (kF16) { const _Float16 h = static_cast<_Float16>(f); uint16_t b; memcpy(&b, &h, 2); return b; }
+    uint32_t u; memcpy(&u, &f, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
 }
 
 template <typename T> struct Elem;

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(DHF_THREADS) void dh_finish_kernel(const float* __r
                                                                 const float* __restrict__ bh, int B, int H, int enc_act,
                                                                 T* __restrict__ delta1_t, int64_t ldt, float* __restrict__ colsum_part,
                                                                 int Hp, float* __restrict__ delta1_f32, T* __restrict__ delta1_lo,
-                                                                T* __restrict__ delta1_t2) {
+                                                                T* __restrict__ delta1_t2, float in_scale, float out_scale) {
     __shared__ float tile[32][65];
     __shared__ float cs[2][8][64];
     const int j0 = blockIdx.x * 64, i0 = blockIdx.y * 32;
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(DHF_THREADS) void dh_finish_kernel(const float* __r
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int r = ty + 8 * k, i = i0 + r;
-        float dh = dhv[k] + ex[k];
+        float dh = dhv[k] * in_scale + ex[k];                       // in_scale: 1 / op_scale of the 16-bit delta2 / Gs images (a power of two)
         const bool ok = (i < B && j < H);
         dh = ok ? dh : 0.f;
         const float a1 = hv[k] + ab;                                // act(z1)
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(DHF_THREADS) void dh_finish_kernel(const float* __r
         s_d1 += d1; s_dh += dh;
         tile[r][tx] = d1;
         if (delta1_f32) delta1_f32[(int64_t)i * ldh + j] = d1;
-        if (delta1_lo) delta1_lo[(int64_t)i * ldh + j] = Elem<T>::from(d1);
+        if (delta1_lo) delta1_lo[(int64_t)i * ldh + j] = Elem<T>::from(sizeof(T) == 2 ? sat16(d1 * out_scale) : d1);
     }
     cs[0][ty][tx] = s_d1; cs[1][ty][tx] = s_dh;
     __syncthreads();
@@ -135,8 +135,9 @@ __global__ __launch_bounds__(DHF_THREADS) void dh_finish_kernel(const float* __r
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int r = r0 + 16 * k;
-            delta1_t[(int64_t)(j0 + r) * ldt + i0 + c] = Elem<T>::from(tile[c][r]);
-            if (delta1_t2) delta1_t2[(int64_t)(j0 + r) * ldt + i0 + c] = elem_residual<T>(tile[c][r]);      // split-bf16: the lo image
+            const float d1s = sizeof(T) == 2 ? sat16(tile[c][r] * out_scale) : tile[c][r];      // 16-bit images hold out_scale * delta1
+            delta1_t[(int64_t)(j0 + r) * ldt + i0 + c] = Elem<T>::from(d1s);
+            if (delta1_t2) delta1_t2[(int64_t)(j0 + r) * ldt + i0 + c] = elem_residual<T>(d1s);      // split mode: the lo image
         }
     }
     if (threadIdx.x < 128) {
@@ -151,9 +152,9 @@ __global__ __launch_bounds__(DHF_THREADS) void dh_finish_kernel(const float* __r
 // Gs = scale * (G + G^T) restricted to [0,B)^2, zero elsewhere      (autodiff of D = h h^T)
 template <typename T>
 __global__ __launch_bounds__(256) void sym_scale_kernel(const float* __restrict__ G, int B, int Bp,
-                                                        const float* __restrict__ tri_scalars, T* __restrict__ Gs) {
+                                                        const float* __restrict__ tri_scalars, T* __restrict__ Gs, float mul) {
     __shared__ float tile[64][65];
-    sym_scale_tile<T>(G, B, Bp, tri_scalars, Gs, blockIdx.x, blockIdx.y, tile);
+    sym_scale_tile<T>(G, B, Bp, tri_scalars, Gs, blockIdx.x, blockIdx.y, tile, mul);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -605,17 +606,18 @@ extern "C" int dae_encode_finish(const float* slabs, int32_t splits, int64_t sla
 
 int dae::launch_dh_finish(const float* slabs, int splits, int64_t slab_stride, int64_t ld_slab, const float* dh_extra, const float* h_f32,
                           int64_t ldh, const float* bh, int B, int H, int enc_act, int dtype, void* delta1_t, int64_t ldt, float* colsum_part,
-                          float* delta1_f32, void* delta1_lo, hipStream_t st, void* delta1_t2) {
+                          float* delta1_f32, void* delta1_lo, hipStream_t st, void* delta1_t2, float in_scale, float out_scale) {
     DAE_CHECK_ARG(slabs && h_f32 && bh && colsum_part, "dh_finish: null input");
     DAE_CHECK_ARG(B > 0 && H > 0 && ldh >= dae_pad(H) && splits >= 1, "dh_finish: bad shape");
     const int Bp = (int)dae_pad(B), Hp = (int)dae_pad(H);
     dim3 grid(Hp / 64, Bp / 32), block(DHF_THREADS);
     if (dtype == DAE_BF16)
         hipLaunchKernelGGL((dh_finish_kernel<bf16_t>), grid, block, 0, st, slabs, splits, slab_stride, ld_slab, dh_extra,
-                           h_f32, ldh, bh, B, H, enc_act, (bf16_t*)delta1_t, ldt, colsum_part, Hp, delta1_f32, (bf16_t*)delta1_lo, (bf16_t*)delta1_t2);
+                           h_f32, ldh, bh, B, H, enc_act, (bf16_t*)delta1_t, ldt, colsum_part, Hp, delta1_f32, (bf16_t*)delta1_lo, (bf16_t*)delta1_t2,
+                           in_scale, out_scale);
     else
         hipLaunchKernelGGL((dh_finish_kernel<float>), grid, block, 0, st, slabs, splits, slab_stride, ld_slab, dh_extra,
-                           h_f32, ldh, bh, B, H, enc_act, (float*)delta1_t, ldt, colsum_part, Hp, delta1_f32, (float*)delta1_lo, (float*)nullptr);
+                           h_f32, ldh, bh, B, H, enc_act, (float*)delta1_t, ldt, colsum_part, Hp, delta1_f32, (float*)delta1_lo, (float*)nullptr, in_scale, 1.f);
     DAE_CHECK_LAUNCH();
     return 0;
 }
@@ -627,16 +629,19 @@ extern "C" int dae_dh_finish(const float* slabs, int32_t splits, int64_t slab_st
                             delta1_f32, nullptr, ST(stream));
 }
 
-extern "C" int dae_sym_scale(const float* G, int32_t B, int32_t Bp, const float* tri_scalars, int32_t dtype, void* Gs,
-                             void* stream) {
+int dae::launch_sym_scale(const float* G, int B, int Bp, const float* tri_scalars, int dtype, void* Gs, float mul, hipStream_t st) {
     DAE_CHECK_ARG(G && tri_scalars && Gs && Bp % DAE_PAD == 0 && B <= Bp, "sym_scale: bad args");
     dim3 grid(Bp / 64, Bp / 64), block(256);
     if (dtype == DAE_BF16)
-        hipLaunchKernelGGL((sym_scale_kernel<bf16_t>), grid, block, 0, ST(stream), G, B, Bp, tri_scalars, (bf16_t*)Gs);
+        hipLaunchKernelGGL((sym_scale_kernel<bf16_t>), grid, block, 0, st, G, B, Bp, tri_scalars, (bf16_t*)Gs, mul);
     else
-        hipLaunchKernelGGL((sym_scale_kernel<float>), grid, block, 0, ST(stream), G, B, Bp, tri_scalars, (float*)Gs);
+        hipLaunchKernelGGL((sym_scale_kernel<float>), grid, block, 0, st, G, B, Bp, tri_scalars, (float*)Gs, mul);
     DAE_CHECK_LAUNCH();
     return 0;
+}
+extern "C" int dae_sym_scale(const float* G, int32_t B, int32_t Bp, const float* tri_scalars, int32_t dtype, void* Gs,
+                             void* stream) {
+    return launch_sym_scale(G, B, Bp, tri_scalars, dtype, Gs, 1.f, ST(stream));
 }
 
 extern "C" int dae_label_stats(const int32_t* labels, int32_t B, int32_t Bp, int32_t triplet, int32_t* n_same_scratch,

@@ -59,12 +59,15 @@ struct GemmParams {
     int ktiles_total;
     int tiles_m, tiles_n, splits;
     unsigned long long* trace;   // dae_gemm_trace only: [blocks][4 waves][8] shader-clock sums per K-loop phase
+    float out_scale;           // fp32-output kernels: C = out_scale * accumulator (1 except for the dW gradient of scaled 16-bit delta images)
 };
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
     static __device__ __forceinline__ void run(const i32x4& a, const i32x4& b, f32x16& c) {
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+        // the 16-bit storage format of this build (dae_common.h): fp16 images multiply on v_mfma_f32_32x32x16_f16, bf16 images on ..._bf16 (same rate)
+        if constexpr (kF16) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+        else c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
     }
 };
 template <> struct Mma<float> {
@@ -446,7 +449,7 @@ __global__ __launch_bounds__(GEMM_THREADS, wg_per_cu_for(NST)) void gemm_nt_f32o
             for (int r = 0; r < 16; ++r) {
                 int row = tm * BM + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
                 int col = tn * BN + wn * 64 + nt * 32 + c;
-                Cs[(int64_t)row * ldc + col] = acc[mt][nt][r];
+                Cs[(int64_t)row * ldc + col] = acc[mt][nt][r] * p.out_scale;
             }
 }
 
@@ -478,7 +481,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_dw_opt(GemmParams p, Opt
     float* __restrict__ gradp = e.grad;
     float* __restrict__ s1p = e.s1;
     float* __restrict__ s2p = e.s2;
-    const float lr = e.lr, mom = e.mom, gscale = e.gscale;
+    const float lr = e.lr, mom = e.mom, gscale = e.gscale, gin = e.gin == 0.f ? 1.f : e.gin;
     // block (half, i) of this thread: rows half * 64 + 4 * rg .. + 3, columns 4 * c4 .. + 3 of the tile
     const int rg0 = tid >> 5, c4 = tid & 31;                                  // i-th block: row group rg0 + 8 i
     // plain SGD: this thread's 16 master-weight pieces are requested BEFORE the K loop and ride under it (the stateful optimizers load W
@@ -520,7 +523,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_dw_opt(GemmParams p, Opt
             for (int q = 0; q < 4; ++q) {
                 const int lrow = rg * 4 + q;
                 const int64_t k = (int64_t)(tm * BM + h * 64 + lrow) * e.ldw + tn * BN + c4 * 4;
-                const f32x4 gr = *reinterpret_cast<const f32x4*>(Gt + lrow * 128 + c4 * 4);
+                const f32x4 gr = *reinterpret_cast<const f32x4*>(Gt + lrow * 128 + c4 * 4) * gin;
                 f32x4 p0, a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f}, pn;
                 if constexpr (PREFETCH_W) p0 = wq[h][i][q];
                 else p0 = *reinterpret_cast<const f32x4*>(Wp + k);
@@ -718,7 +721,7 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_nt_pc(GemmParams p, float*
                 for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        Cd[(int64_t)(tm * BM + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g) * ldc + tn * BN + wn * 64 + nt * 32 + c] = acc[mt][nt][r];
+                        Cd[(int64_t)(tm * BM + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g) * ldc + tn * BN + wn * 64 + nt * 32 + c] = acc[mt][nt][r] * p.out_scale;
         }
         return;
     }
@@ -733,7 +736,7 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_nt_pc(GemmParams p, float*
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    Ct[(wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g) * BN + wn * 64 + nt * 32 + c] = acc[mt][nt][r];
+                    Ct[(wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * g) * BN + wn * 64 + nt * 32 + c] = acc[mt][nt][r] * p.out_scale;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                         // the tile is complete
@@ -1136,7 +1139,7 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_dw_pc(GemmParams p, OptEpi
         float* __restrict__ s2p = e.s2;
         bf16_t* __restrict__ Wlo = reinterpret_cast<bf16_t*>(UPDATE ? e.W_lo : e.grad_lo);
         bf16_t* __restrict__ Wlo2 = reinterpret_cast<bf16_t*>(e.W_lo2);
-        const float lr = e.lr, mom = e.mom, gscale = e.gscale;
+        const float lr = e.lr, mom = e.mom, gscale = e.gscale, gin = e.gin == 0.f ? 1.f : e.gin;
 #pragma unroll
         for (int i = 0; i < DW_EB; ++i) {
             const int blk = tid + PC_THREADS * i, rg = blk >> 5, c4 = blk & 31;
@@ -1147,7 +1150,7 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_dw_pc(GemmParams p, OptEpi
                 const int lrow = rg * 4 + q;
                 const bool ok = row0_m + lrow < Mrows;
                 const int64_t k = (int64_t)min(row0_m + lrow, Mrows - 1) * e.ldw + row0_n + c4 * 4;
-                const f32x4 gr = *reinterpret_cast<const f32x4*>(Gt + lrow * 128 + c4 * 4);
+                const f32x4 gr = *reinterpret_cast<const f32x4*>(Gt + lrow * 128 + c4 * 4) * gin;     // un-scale the 16-bit delta images' power of two
                 if constexpr (!UPDATE) {
                     if (ok && gradp) *reinterpret_cast<f32x4*>(gradp + k) = gr;
                     if (ok && Wlo) {
@@ -1458,7 +1461,7 @@ __global__ __launch_bounds__(GEMM_THREADS, DecGeo<BN_T>::WG_PER_CU) void gemm_de
     if (e.sym_G && (int)blockIdx.x >= e.sym_first) {   // rider workgroups: the symmetrised triplet gradient (see DecodeEpi)
         const int t = (int)blockIdx.x - e.sym_first, nt = e.sym_Bp / 64;
         sym_scale_tile<T>(e.sym_G, e.sym_B, e.sym_Bp, e.sym_scalars, reinterpret_cast<T*>(e.sym_Gs), t % nt, t / nt,
-                          reinterpret_cast<float(*)[65]>(lds));
+                          reinterpret_cast<float(*)[65]>(lds), STAGED ? e.op_scale : 1.f);
         return;
     }
     int tm, tn, split, kt0, kt1;
@@ -1558,6 +1561,7 @@ __global__ __launch_bounds__(GEMM_THREADS, DecGeo<BN_T>::WG_PER_CU) void gemm_de
     // differ only by fp32 rounding (the softplus form is the more accurate one).  Waves holding a saturated logit take
     // the reference-literal path, which reproduces TF's fp32 behaviour there (y rounds to 1, log(1e-16) = -36.84).
     const bool want_rows = e.rowloss_part != nullptr;
+    const float osc = e.op_scale;
     float wl_acc = 0.f;                                // this lane's share of sum_i cw_i * loss_if
     uint32_t resv[RES ? 8 : 1][NTB][2];                // RES: packed bf16(d2 - bf16(d2)) of this lane's elements, block (mt, r4) at index mt * 4 + r4
     auto epi_block = [&](auto MT, auto R4, auto FASTV) {
@@ -1607,11 +1611,13 @@ __global__ __launch_bounds__(GEMM_THREADS, DecGeo<BN_T>::WG_PER_CU) void gemm_de
                     l = kLn2 * __builtin_amdgcn_logf(op) + fmaxf(z, 0.f) - x * z;
                     const float d2 = (cwi * cm[nt]) * (yv - x);
                     rl += cm[nt] * l;
-                    d2v[nt][q] = d2;
                     colsum[nt] += d2;
                     if constexpr (STAGED) {
-                        *reinterpret_cast<bf16_t*>(r0_lane + (rloc + q) * P0 + nt * 64) = f2bf_hw(d2);
+                        const float d2s = sat16(d2 * osc);              // the 16-bit images hold op_scale * delta2
+                        d2v[nt][q] = d2s;
+                        *reinterpret_cast<bf16_t*>(r0_lane + (rloc + q) * P0 + nt * 64) = f2bf_hw(d2s);
                     } else {
+                        d2v[nt][q] = d2;
                         if (d2_lane) d2_lane[(int64_t)(rloc + q) * e.ldd + nt * 32] = Elem<T>::from(d2);
                     }
                     continue;
@@ -1639,11 +1645,13 @@ __global__ __launch_bounds__(GEMM_THREADS, DecGeo<BN_T>::WG_PER_CU) void gemm_de
                 }
                 const float d2 = pass1 ? 0.f : (cwi * cm[nt]) * dy * act_bwd<ACT>(y);   // cw is 0 on padded rows
                 rl += cm[nt] * l;
-                d2v[nt][q] = d2;
                 colsum[nt] += d2;
                 if constexpr (STAGED) {
-                    *reinterpret_cast<bf16_t*>(r0_lane + (rloc + q) * P0 + nt * 64) = f2bf_hw(d2);
+                    const float d2s = sat16(d2 * osc);
+                    d2v[nt][q] = d2s;
+                    *reinterpret_cast<bf16_t*>(r0_lane + (rloc + q) * P0 + nt * 64) = f2bf_hw(d2s);
                 } else {
+                    d2v[nt][q] = d2;
                     if (d2_lane && !pass1) d2_lane[(int64_t)(rloc + q) * e.ldd + nt * 32] = Elem<T>::from(d2);
                 }
             }
@@ -1807,7 +1815,7 @@ static int fill_params_n(GemmParams& p, int dtype, int M, int N, const GemmSegDe
     DAE_CHECK_ARG(segs[0].K > 0, "gemm: the first K segment is empty");
     memset(p.seg, 0, sizeof(p.seg));
     memset(p.bt2, 0, sizeof(p.bt2));
-    p.nseg = 0; p.ktiles_total = 0; p.epi_vec = 0;
+    p.nseg = 0; p.ktiles_total = 0; p.epi_vec = 0; p.out_scale = 1.f;
     for (int i = 0; i < nsegs; ++i) {
         const GemmSegDesc& d = segs[i];
         DAE_CHECK_ARG(d.K >= 0 && d.K % kel == 0, "gemm: K of segment %d = %d must be a multiple of %d", i, d.K, kel);
@@ -1962,13 +1970,15 @@ int launch_gemm_f32out(int dtype, int M, int N, const void* A0, int64_t lda0, co
 }
 
 int launch_gemm_f32out_n(int dtype, int M, int N, const GemmSegDesc* segs, int nsegs, float* C, int64_t ldc, int splits, int64_t slab_stride,
-                         hipStream_t st, int role, const LabelJob* label_job, int* label_done) {
+                         hipStream_t st, int role, const LabelJob* label_job, int* label_done, float out_scale) {
     if (label_done) *label_done = 0;
     GemmParams p;
     if (int rc = fill_params_n(p, dtype, M, N, segs, nsegs, splits)) return rc;
     DAE_CHECK_ARG(C != nullptr, "gemm: C is null");
+    DAE_CHECK_ARG(out_scale == 1.f || p.splits == 1, "gemm: out_scale applies to un-split launches (slabs are scaled by the kernel that sums them)");
+    p.out_scale = out_scale;
     if (int rc = gemm_init()) return rc;
-    if (p.splits == gemm_w8_splits(dtype, M, N, p.ktiles_total)) {
+    if (out_scale == 1.f && p.splits == gemm_w8_splits(dtype, M, N, p.ktiles_total)) {      // (the 256 x 256 kernel has no output scale)
         W8Params q;
         for (int i = 0; i < GEMM_MAX_SEG; ++i) q.seg[i] = p.seg[i];
         q.nseg = p.nseg; q.ktiles_total = p.ktiles_total; q.M = M; q.N = N;
@@ -2062,9 +2072,7 @@ int launch_dw_opt(int M, int N, const void* A0, int64_t lda0, const void* Bt0, i
             DwBits xb; memset(&xb, 0, sizeof(xb));
             if (xa) {
                 xb.xtb = xa->xtb; xb.ldxt = xa->ldxt; xb.nwords = K0 / 32;
-                uint32_t u; memcpy(&u, &xa->scale, 4);
-                u += 0x7fffu + ((u >> 16) & 1u);               // bf16(scale), round to nearest even (a finite positive factor)
-                xb.one = u >> 16;
+                xb.one = host_f2bf(xa->scale);                  // 16-bit image of the scale, round to nearest even (a finite positive factor)
                 q.seg[0].A = nullptr;
             }
             hipLaunchKernelGGL(pcs[xa ? 1 : 0][e.opt], dim3(8 * per * tiles_n), dim3(PC_THREADS), DW_LDS, st, q, e, M, xb);
@@ -2172,8 +2180,9 @@ int launch_decode_loss_n(int dtype, int Bp, int Fp, const GemmSegDesc* segs, int
         DAE_CHECK_ARG(dtype == DAE_BF16 && e.ldxb >= Fp / 32 && ((uintptr_t)e.x_bits % 4) == 0, "decode_loss: bad x bit image");
         k = decode_kernel_xbits(e.loss_func, e.dec_act);
     }
-    if (e.delta2_2 || e.delta2_t2) {
-        DAE_CHECK_ARG(dtype == DAE_BF16, "decode_loss: lo images of delta2 exist in bf16 (split) mode only");
+    if (e.op_scale == 0.f) e.op_scale = 1.f;
+    if (e.delta2_2 || e.delta2_t2 || e.x2) {
+        DAE_CHECK_ARG(dtype == DAE_BF16, "decode_loss: lo images of delta2 / x exist in the 16-bit split mode only");
         k = decode_kernel_res(e.loss_func, e.dec_act, e.x_bits != nullptr);
         static int res_rc = [] {
             int rc = 0;
@@ -2278,7 +2287,7 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_encode_bits_pc(EncBitsPara
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const uint32_t b2 = (word >> (8 * j + 2 * q)) & 3u;
-                        v[q] = (int)(((b2 & 1u) * 0x3F80u) | ((b2 >> 1) * 0x3F800000u));
+                        v[q] = (int)(((b2 & 1u) * kOne16) | ((b2 >> 1) * (kOne16 << 16)));
                     }
                     *reinterpret_cast<i32x4*>(slot + arow * BKB + (((uint32_t)(half * 4 + j) ^ aswz) << 4)) = v;
                 }
@@ -2290,7 +2299,7 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_encode_bits_pc(EncBitsPara
                     const int b = __builtin_ctz(word);
                     word &= word - 1;
                     const uint32_t k = (uint32_t)(half * 32 + b);
-                    *reinterpret_cast<bf16_t*>(slot + arow * BKB + (((k >> 3) ^ aswz) << 4) + (k & 7) * 2) = (bf16_t)0x3F80;
+                    *reinterpret_cast<bf16_t*>(slot + arow * BKB + (((k >> 3) ^ aswz) << 4) + (k & 7) * 2) = (bf16_t)kOne16;
                 }
             }
         };

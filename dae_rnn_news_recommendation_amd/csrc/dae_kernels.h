@@ -28,6 +28,28 @@ struct DecodeEpi {
     // optional rider: (sym_Bp/64)^2 extra workgroups at the end of the grid compute Gs = scalars[0] * (G + G^T) for the dh GEMM
     // (the stand-alone sym_scale launch sits between the miner and this kernel and neither depends on the other)
     const float* sym_G; const float* sym_scalars; void* sym_Gs; int sym_B, sym_Bp, sym_first;
+    // 16-bit modes: delta2 / delta2^T (and the rider's Gs) are stored times this power of two (1 unless the storage format is fp16: dae_api.hip op_scale);
+    // the loss, the bias-gradient partials and everything fp32 stay unscaled
+    float op_scale;
+};
+
+// lo product terms of the split 16-bit mode (dae_config.dtype = DAE_BF16X3; plan option "x3_terms"): each bit keeps one (hi, lo) / (lo, hi) product of one
+// contraction -- and with it the lo image it reads.  bf16 storage needs them all (profiles/r04_precision_terms.txt); fp16 storage holds the 1e-4 curve
+// with the two W terms alone (tools/precision_study.py --scheme W=f16split).
+enum : uint32_t {
+    X3T_DEC_WLO = 1u << 0,    // decode   (h_hi, W_lo)
+    X3T_DEC_HLO = 1u << 1,    // decode   (h_lo, W_hi)
+    X3T_DH_WLO = 1u << 2,     // dh       (delta2_hi, W^T_lo)
+    X3T_DH_D2LO = 1u << 3,    // dh       (delta2_lo, W^T_hi)
+    X3T_DH_HLO = 1u << 4,     // dh       (Gs, h^T_lo)
+    X3T_DW_D1LO = 1u << 5,    // dW       (x~^T, delta1^T_lo)
+    X3T_DW_HLO = 1u << 6,     // dW       (delta2^T_hi, h^T_lo)
+    X3T_DW_D2LO = 1u << 7,    // dW       (delta2^T_lo, h^T_hi)
+    X3T_ENC_WLO = 1u << 8,    // dense-input encode (x~_hi, W^T_lo)
+    X3T_ENC_XLO = 1u << 9,    // dense-input encode (x~_lo, W^T_hi)
+    X3T_XV = 1u << 10,        // valued input: lo images of the clean rows x (decode epilogue) and of x~^T (dW: (x~^T_lo, delta1^T_hi))
+    X3T_ALL = (1u << 11) - 1,
+    X3T_F16_DEFAULT = X3T_DEC_WLO | X3T_DH_WLO | X3T_ENC_WLO,
 };
 
 struct LabelJob;
@@ -41,7 +63,8 @@ int launch_gemm_f32out(int dtype, int M, int N, const void* A0, int64_t lda0, co
                        int* label_done = nullptr);
 // the same contraction over up to 5 K segments (split-bf16 operands: (hi,hi) (hi,lo) (lo,hi) per product)
 int launch_gemm_f32out_n(int dtype, int M, int N, const GemmSegDesc* segs, int nsegs, float* C, int64_t ldc, int splits, int64_t slab_stride,
-                         hipStream_t st, int role = 0, const LabelJob* label_job = nullptr, int* label_done = nullptr);
+                         hipStream_t st, int role = 0, const LabelJob* label_job = nullptr, int* label_done = nullptr, float out_scale = 1.f);
+// (out_scale: C = out_scale * sum -- un-split launches only; the dW gradient of a scaled delta image leaves unscaled)
 // K slices the 256 x 256 / 8-MFMA-wave kernel wants for this shape (0: the shape stays on the 128 x 128 kernels); see dae_gemm.hip
 int gemm_w8_splits(int dtype, int M, int N, int ktiles);
 enum { GEMM_ROLE_GENERIC = 0, GEMM_ROLE_ENCODE = 1, GEMM_ROLE_DH = 2, GEMM_ROLE_DW = 3, GEMM_ROLE_GRAM = 4 };
@@ -111,7 +134,10 @@ int launch_opt_step(int opt, float lr, float momentum, float grad_scale, float* 
                     int Fp, int Hp, int dtype, void* W_lo, void* Wt_lo, void* W_lo2, void* Wt_lo2, int apply, void* stream);
 int launch_dh_finish(const float* slabs, int splits, int64_t slab_stride, int64_t ld_slab, const float* dh_extra, const float* h_f32,
                      int64_t ldh, const float* bh, int B, int H, int enc_act, int dtype, void* delta1_t, int64_t ldt, float* colsum_part,
-                     float* delta1_f32, void* delta1_lo, hipStream_t st, void* delta1_t2 = nullptr);   // delta1_t2: lo image of delta1^T (split-bf16)
+                     float* delta1_f32, void* delta1_lo, hipStream_t st, void* delta1_t2 = nullptr,   // delta1_t2: lo image of delta1^T (split-bf16)
+                     float in_scale = 1.f, float out_scale = 1.f);   // dh = in_scale * sum(slabs) + dh_extra; the 16-bit delta1 images hold out_scale * delta1
+// Gs = mul * tri_scalars[0] * (G + G^T): dae_sym_scale with the 16-bit modes' operand scale
+int launch_sym_scale(const float* G, int B, int Bp, const float* tri_scalars, int dtype, void* Gs, float mul, hipStream_t st);
 int launch_cast_bf16(const float* src, void* dst_bf16, int64_t n, hipStream_t st);
 int launch_step_tail(const BiasArgs& ba, const StatsArgs* sa, const ClearArgs* ca, hipStream_t st);
 // batch_all miner with an optional dispatch order of the anchors (dae_triplet.hip)
@@ -133,6 +159,7 @@ struct OptEpi {
     int opt;                  // DAE_OPT_* or DW_OPT_GRAD_ONLY (gradient to memory, no update: `grad` fp32 and / or `grad_lo` bf16)
     float lr, mom, gscale;
     void* grad_lo;            // DW_OPT_GRAD_ONLY: bf16 gradient image [Fp x ldw] (the reduce-scatter operand of data parallel) or NULL
+    float gin;                // the accumulated tile is multiplied by this first (1 / op_scale of the 16-bit delta images; 0 is read as 1)
 };
 enum { DW_OPT_GRAD_ONLY = 4 };
 // x~^T handed to the dW kernel as a BIT image (binary CSR input): the A tiles of the x~^T.delta1 segment are built in LDS

@@ -153,12 +153,13 @@ class ShardedExchange:
         self.f0 = min(eng.Fp, self.rank * c)
         self.f1 = min(eng.Fp, (self.rank + 1) * c)
         self.n_w = eng.rows_alloc * Hp
-        gdt = torch.float32 if grad_dtype == "fp32" else torch.bfloat16
+        lo16 = eng.td if eng.td != torch.float32 else torch.bfloat16      # 16-bit storage format of the loaded library build (bf16 / fp16)
+        gdt = torch.float32 if grad_dtype == "fp32" else lo16
         self.rs_out = torch.zeros(c * Hp, dtype=gdt, device=eng.device)
         self.rs_f32 = self.rs_out if grad_dtype == "fp32" else torch.zeros(c * Hp, dtype=torch.float32, device=eng.device)
         self.my_lo = torch.zeros((c, Hp), dtype=eng.td, device=eng.device)
         # packed chunk: [c x Hp low-precision rows | pad to 16 B | Hp + Fp fp32 bias gradients | pad to 16 B]
-        es = 2 if eng.td == torch.bfloat16 else 4
+        es = 2 if eng.td != torch.float32 else 4
         self.bias_off = -(-(c * Hp * es) // 16) * 16
         self.chunk_stride = self.bias_off + -(-((Hp + eng.Fp) * 4) // 16) * 16
         self.send = torch.zeros(self.chunk_stride, dtype=torch.uint8, device=eng.device)
@@ -181,7 +182,7 @@ class ShardedExchange:
             dist.reduce_scatter_tensor(self.rs_out, gw, op=dist.ReduceOp.SUM)
         else:
             # bf16 exchange: the dW kernel's epilogue wrote the gradient as bf16 (Engine(grad_lo=True)); otherwise cast here
-            src = eng.grad_lo.view(-1) if getattr(eng, "grad_lo", None) is not None else gw.to(torch.bfloat16)
+            src = eng.grad_lo.view(-1) if getattr(eng, "grad_lo", None) is not None else gw.to(self.rs_out.dtype)
             dist.reduce_scatter_tensor(self.rs_out, src, op=dist.ReduceOp.SUM)
             self.rs_f32.copy_(self.rs_out)
 
@@ -319,6 +320,10 @@ class AllReduceExchange:
         self.eng, self.torch, self.dist = eng, torch, dist
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
         assert eng.dp_world == self.world, "create the Engine with dp_world = world size (%d != %d)" % (eng.dp_world, self.world)
+        # the flat fp32 gradient is what gets all-reduced: an engine built with a 16-bit exchange image (grad_lo) writes the W gradient THERE in
+        # phase 1 / 5 steps and leaves eng.grad's W part stale -- refuse the combination instead of training on a stale gradient
+        if getattr(eng, "grad_lo", None) is not None:
+            raise ValueError("AllReduceExchange all-reduces the flat fp32 gradient: build the Engine with grad_lo=False (dp_grad_dtype='fp32')")
         self.x3 = bool(getattr(eng, "x3", False))
         self.grad_dtype, self.packed = "fp32", False
         self.flat = eng.grad[:eng.n_flat]                       # [dW (Fp*Hp) | dbh (Hp) | dbv (Fp)]

@@ -24,22 +24,30 @@ class Engine:
                  grad_lo=False):
         if not torch.cuda.is_available():
             raise RuntimeError("dae_rnn_news_recommendation_amd.Engine needs a ROCm GPU (MI355X): no CPU fallback exists")
-        self.lib = L.load()
+        # precision name -> library build (16-bit storage format), dae_config.dtype and the split mode's lo terms (L.PRECISIONS)
+        if isinstance(dtype, str):
+            assert dtype in L.PRECISIONS, dtype
+            self.fmt, cfg_dtype, terms = L.PRECISIONS[dtype]
+        else:
+            self.fmt, cfg_dtype, terms = "bf16", dtype, None
+        self.precision = dtype
+        self.lib = L.load(self.fmt)
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         self.F, self.H, self.Bmax = int(n_features), int(n_components), int(max_batch)
-        cfg_dtype = {"bf16": L.BF16, "bfloat16": L.BF16, "fp32": L.F32, "f32": L.F32, "float32": L.F32, "bf16x3": L.BF16X3}.get(dtype, dtype)
         assert cfg_dtype in (L.BF16, L.F32, L.BF16X3), dtype
-        # split-bf16 mode stores bf16 everywhere (self.dtype = the element type of the images); only the plan's config says x3
+        # the split modes store 16-bit images everywhere (self.dtype = the element type of the images); only the plan's config says x3
         self.x3 = cfg_dtype == L.BF16X3
         self.dtype = L.BF16 if self.x3 else cfg_dtype
-        self.td = torch.bfloat16 if self.dtype == L.BF16 else torch.float32
+        self.td = L.torch_lo_dtype(self.fmt) if self.dtype == L.BF16 else torch.float32
         self.opt = opt
         self.cfg = L.dae_config(self.F, self.H, self.Bmax, cfg_dtype, L.ACT[enc_act], L.ACT[dec_act], L.LOSS[loss_func],
                                 L.OPT[opt], L.TRIPLET[triplet], int(pos_triplets_only), encode_splits, dh_splits,
                                 gram_splits, float(learning_rate), float(momentum), float(alpha))
         plan = C.c_void_p()
-        L.check(self.lib.dae_plan_create(C.byref(self.cfg), C.byref(plan)), "dae_plan_create")
+        self._chk(self.lib.dae_plan_create(C.byref(self.cfg), C.byref(plan)), "dae_plan_create")
         self.plan = plan
+        if terms is not None:
+            self._chk(self.lib.dae_plan_set_option(self.plan, b"x3_terms", int(terms)), "dae_plan_set_option")
         self.Fp, self.Hp, self.Bpm = L.pad(self.F), L.pad(self.H), L.pad(self.Bmax)
         dev = self.device
         n_flat = self.Fp * self.Hp + self.Hp + self.Fp
@@ -61,7 +69,7 @@ class Engine:
         # this image (dae_buffers.grad_lo) in phase 1 / 5 steps; the bias gradients stay in `grad`
         self.grad_lo = None
         if grad_lo and self.dtype == L.BF16 and not self.x3:       # split-bf16 mode exchanges fp32 gradients
-            self.grad_lo = torch.zeros((self.rows_alloc, self.Hp), dtype=torch.bfloat16, device=dev)
+            self.grad_lo = torch.zeros((self.rows_alloc, self.Hp), dtype=self.td, device=dev)
         self.s1 = self.s2 = None
         if opt == "ada_grad":
             self.s1 = torch.full((n_flat,), 0.1, dtype=torch.float32, device=dev)   # TF initial_accumulator_value
@@ -79,6 +87,9 @@ class Engine:
         self.dense = None
         self.adam_t = 0
         self._bound = False
+
+    def _chk(self, rc, what=""):
+        L.check(rc, what, self.lib)
 
     # ------------------------------------------------------------------ data
     def upload_csr(self, m):
@@ -138,7 +149,7 @@ class Engine:
         b.W_lo = self.W_lo.data_ptr(); b.Wt_lo = self.Wt_lo.data_ptr()
         b.workspace = self.workspace.data_ptr(); b.workspace_bytes = self.workspace.numel()
         b.grad_lo = None if self.grad_lo is None else self.grad_lo.data_ptr()
-        L.check(self.lib.dae_plan_bind(self.plan, C.byref(b)), "dae_plan_bind")
+        self._chk(self.lib.dae_plan_bind(self.plan, C.byref(b)), "dae_plan_bind")
         self._bound = True
 
     # ------------------------------------------------------------------ params
@@ -152,7 +163,7 @@ class Engine:
             self.bh[:self.H] = torch.as_tensor(np.asarray(bh, np.float32)).to(self.device)
         if bv is not None:
             self.bv[:self.F] = torch.as_tensor(np.asarray(bv, np.float32)).to(self.device)
-        L.check(self.lib.dae_plan_sync_shadows(self.plan, L.current_stream()), "dae_plan_sync_shadows")
+        self._chk(self.lib.dae_plan_sync_shadows(self.plan, L.current_stream()), "dae_plan_sync_shadows")
 
     def get_params(self):
         return (self.W[:self.F, :self.H].cpu().numpy(), self.bh[:self.H].cpu().numpy(), self.bv[:self.F].cpu().numpy())
@@ -195,7 +206,7 @@ class Engine:
         if phase in (0, 3) and self.opt == "adam":   # 3 = update without materialising the W gradient
             self.adam_t += 1
         s.adam_t = self.adam_t; s.grad_scale = float(grad_scale)
-        L.check(self.lib.dae_train_step(self.plan, C.byref(s), L.current_stream()), "dae_train_step")
+        self._chk(self.lib.dae_train_step(self.plan, C.byref(s), L.current_stream()), "dae_train_step")
 
     def salt_pepper_batch(self, row_idx, v, lo, hi, seed, rng_stream):
         """Salt-and-pepper corruption of the batch rows on the device (dae_salt_pepper_batch): returns the batch-local corrupted CSR
@@ -210,14 +221,14 @@ class Engine:
                             values=torch.zeros(self.Bmax * cap, dtype=torch.float32, device=dev),
                             rows=torch.arange(0, 2 * self.Bmax, 2, dtype=torch.int32, device=dev))
         sp = self._sp
-        L.check(self.lib.dae_salt_pepper_batch(L.ptr(self.csr["indptr"]), L.ptr(self.csr["indices"]), L.ptr(self.csr["values"]), L.ptr(row_idx),
+        self._chk(self.lib.dae_salt_pepper_batch(L.ptr(self.csr["indptr"]), L.ptr(self.csr["indices"]), L.ptr(self.csr["values"]), L.ptr(row_idx),
                                                B, self.F, int(v), float(lo), float(hi), int(seed), int(rng_stream), L.ptr(sp["span"]),
                                                L.ptr(sp["indices"]), L.ptr(sp["values"]), sp["cap"], L.current_stream()), "dae_salt_pepper_batch")
         return dict(indptr=sp["span"], indices=sp["indices"], values=sp["values"], row_idx=sp["rows"][:B])
 
     def apply_rows(self, grad_rows, f0, f1, grad_scale=1.0, update_bias=True):
         """Sharded-optimizer step on the rows [f0, f1) this rank owns (dp.ShardedExchange); W_lo rows refreshed, Wt_lo not."""
-        L.check(self.lib.dae_plan_apply_rows(self.plan, self.adam_t, float(grad_scale), L.ptr(grad_rows), int(f0), int(f1),
+        self._chk(self.lib.dae_plan_apply_rows(self.plan, self.adam_t, float(grad_scale), L.ptr(grad_rows), int(f0), int(f1),
                                              int(bool(update_bias)), L.current_stream()), "dae_plan_apply_rows")
 
     def stream_wait_dw(self, stream):
@@ -226,23 +237,23 @@ class Engine:
         rc = self.lib.dae_plan_stream_wait_dw(self.plan, C.c_void_p(stream.cuda_stream))
         if rc == L.WAIT_DW_CREATED:
             return False
-        L.check(rc, "dae_plan_stream_wait_dw")        # a genuine HIP error must not read as "event not ready"
+        self._chk(rc, "dae_plan_stream_wait_dw")        # a genuine HIP error must not read as "event not ready"
         return True
 
     def apply_rows_packed(self, grad_rows, f0, f1, send, bias_off, grad_scale=1.0):
         """Sharded-optimizer step on the rows [f0, f1); their low-precision image goes straight into the all-gather send buffer
         `send` (uint8 tensor) and this rank's bias gradients are copied to send[bias_off:] (dp.ShardedExchange, packed form)."""
-        L.check(self.lib.dae_plan_apply_rows_packed(self.plan, self.adam_t, float(grad_scale), L.ptr(grad_rows), int(f0), int(f1),
+        self._chk(self.lib.dae_plan_apply_rows_packed(self.plan, self.adam_t, float(grad_scale), L.ptr(grad_rows), int(f0), int(f1),
                                                     L.ptr(send), int(bias_off), L.current_stream()), "dae_plan_apply_rows_packed")
 
     def dp_unpack(self, recv, world, chunk_stride, bias_off, grad_scale=1.0):
         """After the all-gather of the packed chunks: W_lo, Wt_lo and the biases (rank-ordered sum of the gathered bias gradients)."""
-        L.check(self.lib.dae_plan_dp_unpack(self.plan, L.ptr(recv), int(world), int(self.chunk_rows), int(chunk_stride), int(bias_off),
+        self._chk(self.lib.dae_plan_dp_unpack(self.plan, L.ptr(recv), int(world), int(self.chunk_rows), int(chunk_stride), int(bias_off),
                                             self.adam_t, float(grad_scale), L.current_stream()), "dae_plan_dp_unpack")
 
     def sync_shadows(self):
         """Rebuild every low-precision image of W (W_lo, Wt_lo and, in split-bf16 mode, their lo parts) from the fp32 master."""
-        L.check(self.lib.dae_plan_sync_shadows(self.plan, L.current_stream()), "dae_plan_sync_shadows")
+        self._chk(self.lib.dae_plan_sync_shadows(self.plan, L.current_stream()), "dae_plan_sync_shadows")
 
     def zero_grads(self):
         """An empty shard contributes nothing to the exchange: clear the flat gradient AND its bf16 exchange image."""
@@ -251,19 +262,19 @@ class Engine:
             self.grad_lo.zero_()
 
     def refresh_wt(self):
-        L.check(self.lib.dae_plan_refresh_wt(self.plan, L.current_stream()), "dae_plan_refresh_wt")
+        self._chk(self.lib.dae_plan_refresh_wt(self.plan, L.current_stream()), "dae_plan_refresh_wt")
 
     def apply(self, grad_scale=1.0):
         """Optimizer step on the (all-reduced) flat gradient -- the second half of a DP step."""
         if self.opt == "adam":
             self.adam_t += 1
-        L.check(self.lib.dae_plan_apply(self.plan, self.adam_t, float(grad_scale), L.current_stream()), "dae_plan_apply")
+        self._chk(self.lib.dae_plan_apply(self.plan, self.adam_t, float(grad_scale), L.current_stream()), "dae_plan_apply")
 
     def encode_rows(self, row_idx, out, *, scale=1.0, csr=None, dense=None):
         """out[B x H] (device fp32) = encode(scale * rows) -- transform() (autoencoder.py:479-505)."""
         csr = self.csr if (csr is None and dense is None) else csr
         dense = self.dense if (csr is None and dense is None) else dense
-        L.check(self.lib.dae_encode_rows(
+        self._chk(self.lib.dae_encode_rows(
             self.plan, L.ptr(row_idx), int(row_idx.numel()), float(scale),
             None if csr is None else L.ptr(csr["indptr"]), None if csr is None else L.ptr(csr["indices"]),
             None if csr is None else L.ptr(csr["values"]),
@@ -281,26 +292,28 @@ class Engine:
 
     def set_option(self, name, value):
         """Code-path choice of the plan (A/B measurements, equivalence tests): see dae_plan_set_option in include/dae_hip.h."""
-        L.check(self.lib.dae_plan_set_option(self.plan, name.encode(), int(value)), "dae_plan_set_option")
+        self._chk(self.lib.dae_plan_set_option(self.plan, name.encode(), int(value)), "dae_plan_set_option")
         # options that change the split-K plan (x3_dec_wlo, x3_dh_hlo, gram_fp32) also change the workspace size; they are refused once bound
         ws_bytes = int(self.lib.dae_plan_workspace_bytes(self.plan))
         if ws_bytes > self.workspace.numel():
             self.workspace = torch.zeros(ws_bytes, dtype=torch.uint8, device=self.device)
 
     def profile(self, enable):
-        L.check(self.lib.dae_plan_profile(self.plan, int(bool(enable))), "dae_plan_profile")
+        self._chk(self.lib.dae_plan_profile(self.plan, int(bool(enable))), "dae_plan_profile")
 
     def profile_read(self):
         """{kernel slot name: (total ms, launches)} accumulated since profile(True)."""
         n = int(self.lib.dae_plan_profile_slots())
         ms = (C.c_double * n)(); cnt = (C.c_int32 * n)()
-        L.check(self.lib.dae_plan_profile_read(self.plan, n, ms, cnt), "dae_plan_profile_read")
+        self._chk(self.lib.dae_plan_profile_read(self.plan, n, ms, cnt), "dae_plan_profile_read")
         return {self.lib.dae_plan_profile_name(i).decode(): (float(ms[i]), int(cnt[i])) for i in range(n)}
 
     def info(self):
         out = (C.c_int32 * 8)()
-        L.check(self.lib.dae_plan_info(self.plan, out), "dae_plan_info")
-        return dict(Fp=out[0], Hp=out[1], Bpm=out[2], encode_splits=out[3], dh_splits=out[4], gram_splits=out[5], es=out[6])
+        self._chk(self.lib.dae_plan_info(self.plan, out), "dae_plan_info")
+        w = int(out[7]) & 0xffffffff
+        return dict(Fp=out[0], Hp=out[1], Bpm=out[2], encode_splits=out[3], dh_splits=out[4], gram_splits=out[5], es=out[6],
+                    split=bool(w & 1), x3_terms=(w >> 1) & L.X3T_ALL, op_scale=float(2 ** ((w >> 16) & 0xff)), storage=self.fmt)
 
     def __del__(self):
         try:

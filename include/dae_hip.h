@@ -29,12 +29,14 @@ extern "C" {
 #endif
 
 #define DAE_PAD 128
-#define DAE_ABI_VERSION 4   /* 4: DAE_BF16X3 (split-bf16 mode), dae_gemm_nt_n; 3: dae_buffers.grad_lo, options dw_bits / encode_w32; 2: dae_step.c_row_idx, plan options, phases 4/5, sharded apply */
+#define DAE_ABI_VERSION 5   /* 5: dae_storage_format (the fp16 build libdae_hip_f16.so), options x3_terms / op_scale_log2, DAE_WAIT_DW_CREATED = 100; 4: DAE_BF16X3 (split-bf16 mode), dae_gemm_nt_n; 3: dae_buffers.grad_lo, options dw_bits / encode_w32; 2: dae_step.c_row_idx, plan options, phases 4/5, sharded apply */
 
 enum { DAE_BF16 = 0, DAE_F32 = 1,
        DAE_BF16X3 = 2 /* dae_config.dtype only: bf16 storage and MFMA, but every stored operand of the three gradient GEMMs is kept as
                          hi + lo (both bf16) and multiplied as (hi,hi) + (hi,lo) + (lo,hi) -- 2^-16 operands at ~3x the bf16 GEMM work;
-                         CSR input, single GPU (first cut) */ };
+                         every input kind and phase.  In the fp16 build of the library (dae_storage_format() == 1) the same dtype keeps only the
+                         lo terms of plan option "x3_terms" -- by default the two W terms -- i.e. TWO products per gradient GEMM: the product's
+                         precision='f16x2' */ };
 enum { DAE_ACT_NONE = 0, DAE_ACT_SIGMOID = 1, DAE_ACT_TANH = 2 };
 enum { DAE_LOSS_CROSS_ENTROPY = 0, DAE_LOSS_MEAN_SQUARED = 1, DAE_LOSS_COSINE = 2 };
 enum { DAE_OPT_SGD = 0, DAE_OPT_ADAGRAD = 1, DAE_OPT_MOMENTUM = 2, DAE_OPT_ADAM = 3 };
@@ -446,8 +448,16 @@ int      dae_plan_sync_shadows(dae_plan* p, void* stream);
  * the frozen reference curve then measured cost 7.0e-5 / triplet 1.56e-4, outside the 1e-4 gate, so they stay on: profiles/r04_precision_terms.txt;
  * with x3_dec_wlo = 0 the dW epilogue skips the lo image of the row-major shadow, which only that decode term reads), "dw_pair" (split-bf16 mode: the dW kernel runs the K segments that share their A operand
  * -- x~^T . [delta1^T_hi ; delta1^T_lo], delta2^T_hi . [h^T_hi ; h^T_lo] -- as paired ring stages of one A tile and two B tiles; default 1, 0 = one
- * segment after the other).  Unknown names are an error. */
+ * segment after the other), "x3_terms" (split mode, before dae_plan_bind only: bit mask of the lo product terms that are multiplied -- bit 0 decode
+ * (h_hi, W_lo), 1 decode (h_lo, W_hi), 2 dh (delta2_hi, W^T_lo), 3 dh (delta2_lo, W^T_hi), 4 dh (Gs, h^T_lo), 5 dW (x~^T, delta1^T_lo), 6 dW (delta2^T_hi,
+ * h^T_lo), 7 dW (delta2^T_lo, h^T_hi), 8 / 9 dense-input encode (x~_hi, W^T_lo) / (x~_lo, W^T_hi), 10 lo images of valued inputs (clean rows, x~^T); default
+ * all (bf16 storage) or bits 0, 2, 8 (fp16 storage); a lo image whose terms are all off is neither written nor allocated), "op_scale_log2" (16-bit modes:
+ * the images of delta2, delta2^T, Gs and delta1^T hold 2^value times the quantity and the consuming epilogues divide it out; default 0 for bf16 storage,
+ * log2 of the largest power of two <= 16 * max_batch (at most 14) for fp16 storage, whose normal range ends at 6.1e-5).  Unknown names are an error. */
 int      dae_plan_set_option(dae_plan* p, const char* name, int32_t value);
+/* 16-bit storage format the loaded library was built for: 0 = bfloat16 (libdae_hip.so), 1 = IEEE fp16 (libdae_hip_f16.so: the same sources compiled with
+ * -DDAE_F16=1; every 16-bit image and the MFMA that multiplies it switch together).  DAE_BF16 / DAE_BF16X3 name "the 16-bit format" in either build. */
+int32_t  dae_storage_format(void);
 int      dae_train_step(dae_plan* p, const dae_step* step, void* stream);
 int      dae_plan_apply(dae_plan* p, int32_t adam_t, float grad_scale, void* stream);
 /* Data parallel with a SHARDED optimizer: after dae_train_step(phase = 1) the ranks reduce-scatter the W part of the flat gradient
@@ -469,7 +479,7 @@ int      dae_plan_refresh_wt(dae_plan* p, void* stream);
  * the step's tail kernel), so that a reduce-scatter issued on `stream` runs beside the tail.  The first call only creates the event and
  * returns DAE_WAIT_DW_CREATED (not an error, dae_last_error untouched; steps enqueued earlier are not covered: wait for the step's
  * stream instead); 0 = the wait was enqueued; any other value is an error. */
-#define DAE_WAIT_DW_CREATED 2
+#define DAE_WAIT_DW_CREATED 100   /* outside the error codes (1 = bad argument, 2 = HIP failure) */
 int dae_plan_stream_wait_dw(dae_plan* plan, void* stream);
 int dae_plan_apply_rows_packed(dae_plan* plan, int32_t adam_t, float grad_scale, const float* grad_rows, int32_t f0, int32_t f1,
                                void* send, int64_t bias_off_bytes, void* stream);

@@ -17,16 +17,30 @@ def _declared():
     return set(re.findall(r"\b(dae_[a-z0-9_]+)\s*\(", src))
 
 
-def test_library_exports_every_declared_symbol():
+@pytest.mark.parametrize("fmt", ["bf16", "f16"])
+def test_library_exports_every_declared_symbol(fmt):
+    """Both builds of the library (bf16 storage: libdae_hip.so; fp16 storage: libdae_hip_f16.so -- the same sources, csrc/dae_common.h DAE_F16)."""
     from dae_rnn_news_recommendation_amd import _lib
-    lib = _lib.load()
+    lib = _lib.load(fmt)
     names = _declared()
     assert len(names) >= 30
     for n in names:
-        assert hasattr(lib, n), f"{n} declared in dae_hip.h but not exported by libdae_hip.so"
+        assert hasattr(lib, n), f"{n} declared in dae_hip.h but not exported by the {fmt} build"
     assert names == set(_lib.SIGNATURES), names ^ set(_lib.SIGNATURES)
-    assert lib.dae_abi_version() == 4
+    m = re.search(r"#define DAE_ABI_VERSION (\d+)", open(HEADER).read())
+    assert lib.dae_abi_version() == int(m.group(1)) == _lib.ABI_VERSION
+    assert lib.dae_storage_format() == (1 if fmt == "f16" else 0)
     assert lib.dae_pad(800) == 896 and lib.dae_pad(10000) == 10112 and lib.dae_pad(128) == 128
+
+
+def test_precision_table_names_existing_builds():
+    from dae_rnn_news_recommendation_amd import _lib
+    assert _lib.AUTO_PRECISION in _lib.PRECISIONS
+    for name, (fmt, dtype, terms) in _lib.PRECISIONS.items():
+        assert fmt in _lib.LIB_PATHS and dtype in (_lib.BF16, _lib.F32, _lib.BF16X3), name
+        assert terms is None or 0 <= terms <= _lib.X3T_ALL
+    m = re.search(r"#define DAE_WAIT_DW_CREATED (\d+)", open(HEADER).read())
+    assert int(m.group(1)) == _lib.WAIT_DW_CREATED and _lib.WAIT_DW_CREATED not in (0, 1, 2)      # outside the error codes
 
 
 def test_ctypes_arity_matches_header():
@@ -70,6 +84,20 @@ def test_argument_errors_are_reported_without_a_gpu():
     info = (ctypes.c_int32 * 8)()
     assert lib.dae_plan_info(plan, info) == 0 and list(info)[:3] == [10112, 512, 896]
     lib.dae_plan_destroy(plan)
+    # the split mode's lo images are allocated per product term: the fp16 build's default (two W terms) needs ~70 MB less workspace than all terms
+    l16 = _lib.load("f16")
+    sizes = {}
+    for terms in (None, _lib.X3T_ALL):
+        cfg = _lib.dae_config(10000, 500, 800, 2, 1, 1, 0, 0, 1, 0, 0, 0, 0, 0.1, 0.5, 1.0)
+        assert l16.dae_plan_create(ctypes.byref(cfg), ctypes.byref(plan)) == 0
+        if terms is not None:
+            assert l16.dae_plan_set_option(plan, b"x3_terms", terms) == 0
+        assert l16.dae_plan_info(plan, info) == 0
+        sizes[terms] = (l16.dae_plan_workspace_bytes(plan), info[7])
+        l16.dae_plan_destroy(plan)
+    assert sizes[_lib.X3T_ALL][0] - sizes[None][0] > 60 << 20, sizes
+    assert (sizes[None][1] >> 1) & _lib.X3T_ALL == (1 | 4 | 256) and (sizes[None][1] >> 16) == 13      # default terms; op_scale 2^13 at B = 800
+    assert l16.dae_plan_set_option(None, b"x3_terms", 1) != 0                     # null plan: an argument error, not a crash
 
 
 def test_product_never_imports_the_oracle():

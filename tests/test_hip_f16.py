@@ -1,0 +1,139 @@
+"""GPU parity tests of the fp16 build of the library (libdae_hip_f16.so: the same sources with the 16-bit storage format switched to IEEE
+fp16 and v_mfma_f32_32x32x16_f16) -- precision 'f16x2' (fp16 operand images, W kept as hi + lo: two product terms in the decode and dh
+GEMMs, one in dW), 'f16x3' (every operand hi + lo) and 'f16' (single images) -- against the fp64 CPU oracle on identical seeded inputs.
+
+What is specific to this build and covered here: the power-of-two operand scale of the back-propagated images (delta2 / Gs / delta1 are
+stored times op_scale and un-scaled by dh_finish and the dW epilogue -- every path that writes a gradient: fused optimizer, gradient-only
+phase, un-fused GEMM + optimizer kernel, shapes beyond one dW round), the lo-term mask of the split mode, and the MFMA's treatment of
+subnormal fp16 operands (the lo image of W lives there: |W - fp16(W)| <= 2^-12 |W| ~ 6e-6 < 6.1e-5)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from test_hip_step import _rel, _run_case
+
+pytestmark = pytest.mark.gpu
+
+
+def test_f16_library_is_the_fp16_build():
+    from dae_rnn_news_recommendation_amd import _lib as L
+    assert L.load("f16").dae_storage_format() == 1 and L.load("bf16").dae_storage_format() == 0
+    assert L.load("f16").dae_abi_version() == L.ABI_VERSION
+
+
+def test_mfma_f16_keeps_subnormal_operands():
+    """C = A.B^T through dae_gemm_nt of the fp16 build with A = 2^-20 (a subnormal fp16) and B = 2^10: every product is 2^-10 and
+    C = K * 2^-10 exactly.  A matrix core that flushed subnormal inputs would return 0 -- and the (h, W_lo) product terms with it."""
+    from dae_rnn_news_recommendation_amd import _lib as L
+    lib = L.load("f16")
+    M = N = 128; K = 256
+    A = torch.full((M, K), 2.0 ** -20, dtype=torch.float16, device="cuda")
+    B = torch.full((N, K), 2.0 ** 10, dtype=torch.float16, device="cuda")
+    assert float(A[0, 0]) == 2.0 ** -20 and float(A[0, 0]) < 6.1e-5
+    Cm = torch.zeros((M, N), dtype=torch.float32, device="cuda")
+    L.check(lib.dae_gemm_nt(L.BF16, M, N, L.ptr(A), K, L.ptr(B), K, K, None, 0, None, 0, 0, L.ptr(Cm), N, 1, 0, L.current_stream()), "dae_gemm_nt", lib)
+    torch.cuda.synchronize()
+    assert torch.all(Cm == K * 2.0 ** -10), (float(Cm.min()), float(Cm.max()), K * 2.0 ** -10)
+
+
+def test_plan_defaults_of_the_f16_build():
+    from dae_rnn_news_recommendation_amd.engine import Engine
+    e = Engine(10000, 500, 800, dtype="f16x2", triplet="batch_all")
+    i = e.info()
+    assert i["storage"] == "f16" and i["split"] and i["x3_terms"] == (1 | 4 | 256) and i["op_scale"] == 8192.0, i
+    assert e.td == torch.float16
+    e3 = Engine(600, 64, 100, dtype="f16x3", triplet="batch_all")
+    assert e3.info()["x3_terms"] == (1 << 11) - 1 and e3.info()["op_scale"] == 1024.0
+    b = Engine(600, 64, 100, dtype="bf16x3", triplet="batch_all")
+    assert b.info()["storage"] == "bf16" and b.info()["op_scale"] == 1.0 and b.info()["x3_terms"] == (1 << 11) - 1
+
+
+@pytest.mark.parametrize("opt", ["gradient_descent", "adam"])
+@pytest.mark.parametrize("strategy", ["none", "batch_all", "batch_hard"])
+def test_step_f16x3_matches_oracle(strategy, opt):
+    """Every operand hi + lo fp16 (22 significant bits): as close to the fp64 oracle as the split-bf16 mode (16 bits) -- the same gates as
+    test_step_bf16x3_matches_oracle.  Exercises every lo image and the operand scale through the fused dW + optimizer epilogue."""
+    out, ref, got = _run_case("f16x3", strategy, "cross_entropy", ("sigmoid", "sigmoid"), opt, steps=3)
+    tol = 2e-5 if opt == "gradient_descent" else 1e-4
+    for r, st, dW, dbh, dbv in out:
+        assert abs(st[1] - r["ae_loss"]) <= tol * abs(r["ae_loss"]), (st[1], r["ae_loss"])
+        assert abs(st[0] - r["cost"]) <= tol * abs(r["cost"])
+        if strategy == "batch_all":
+            assert abs(st[2] - r["triplet_loss"]) <= tol * abs(r["triplet_loss"])
+        assert _rel(dW, r["dW"]) < 1e-4 and _rel(dbh, r["dbh"]) < 1e-4 and _rel(dbv, r["dbv"]) < 1e-4, (_rel(dW, r["dW"]), _rel(dbh, r["dbh"]))
+    if opt == "gradient_descent":
+        for a, b in zip(got, ref):
+            assert _rel(a, b) < 2e-4, _rel(a, b)
+
+
+@pytest.mark.parametrize("strategy,loss_func,acts", [("none", "cross_entropy", ("sigmoid", "sigmoid")), ("batch_all", "cross_entropy", ("sigmoid", "sigmoid")),
+                                                     ("batch_hard", "cross_entropy", ("sigmoid", "sigmoid")), ("batch_all", "mean_squared", ("tanh", "none")),
+                                                     ("none", "cosine_proximity", ("sigmoid", "sigmoid"))])
+def test_step_f16x2_matches_oracle(strategy, loss_func, acts):
+    """The product's parity mode: single fp16 images of h / delta2 / delta1 / Gs / x~^T (11 significant bits, random rounding) and W as hi + lo.
+    One step's losses sit at the oracle (the forward pass multiplies h by a 22-bit W); its gradients carry the 2^-12 operand rounding --
+    an order of magnitude closer than plain bf16 (2e-2)."""
+    out, ref, got = _run_case("f16x2", strategy, loss_func, acts, "gradient_descent", steps=3)
+    worst = 0.0
+    for r, st, dW, dbh, dbv in out:
+        assert abs(st[1] - r["ae_loss"]) <= 5e-5 * abs(r["ae_loss"]), (st[1], r["ae_loss"])
+        assert abs(st[0] - r["cost"]) <= 5e-5 * abs(r["cost"])
+        worst = max(worst, _rel(dW, r["dW"]), _rel(dbh, r["dbh"]), _rel(dbv, r["dbv"]))
+    print(f"[f16x2] {strategy} {loss_func}: worst gradient deviation {worst:.2e}")
+    assert worst < 1.5e-3, worst
+    for a, b in zip(got, ref):
+        assert _rel(a, b) < 2e-3, _rel(a, b)
+
+
+@pytest.mark.parametrize("dtype", ["f16x2", "f16x3"])
+def test_step_f16_gradient_only_phase_and_unfused_optimizer(dtype):
+    """The operand scale must be divided out on EVERY path that produces a gradient: phase 1 (gradient to the flat buffer, dae_plan_apply
+    afterwards) and fused_opt = 0 (N-segment GEMM to memory + optimizer kernel) against the fused step."""
+    kw = dict(steps=3, seed=5)
+    a, ra, pa = _run_case(dtype, "batch_all", "cross_entropy", ("sigmoid", "sigmoid"), "momentum", **kw)
+    b, rb, pb = _run_case(dtype, "batch_all", "cross_entropy", ("sigmoid", "sigmoid"), "momentum", phase=1, **kw)
+    c, rc, pc = _run_case(dtype, "batch_all", "cross_entropy", ("sigmoid", "sigmoid"), "momentum", options={"fused_opt": 0}, **kw)
+    for (_, sa, dWa, *_), (_, sb, dWb, *_), (_, sc, dWc, *_) in zip(a, b, c):
+        assert np.allclose(sa[:3], sb[:3], rtol=1e-5, atol=0) and np.allclose(sa[:3], sc[:3], rtol=1e-5, atol=0), (sa, sb, sc)
+        assert _rel(dWb, np.asarray(dWa, np.float64)) < 2e-5 and _rel(dWc, np.asarray(dWa, np.float64)) < 2e-5
+    for u, v, w in zip(pa, pb, pc):
+        assert _rel(v, np.asarray(u, np.float64)) < 2e-5 and _rel(w, np.asarray(u, np.float64)) < 2e-5
+    gate = 1e-4 if dtype == "f16x3" else 1.5e-3
+    for r, st, dW, dbh, dbv in b:
+        assert _rel(dW, r["dW"]) < gate and _rel(dbh, r["dbh"]) < gate, (_rel(dW, r["dW"]), _rel(dbh, r["dbh"]))
+
+
+@pytest.mark.parametrize("dtype", ["f16x2", "f16x3"])
+def test_step_f16_dense_and_valued_input(dtype):
+    """Dense ndarray train set (gather + encode GEMM with the W^T lo term) and valued CSR under a scale factor."""
+    gate = 1e-4 if dtype == "f16x3" else 1.5e-3
+    for kw in (dict(dense=True), dict(scale=0.7)):
+        out, ref, got = _run_case(dtype, "batch_all", "mean_squared" if "dense" in kw else "cross_entropy",
+                                  ("tanh", "none") if "dense" in kw else ("sigmoid", "sigmoid"), "gradient_descent", steps=3, **kw)
+        for r, st, dW, dbh, dbv in out:
+            assert abs(st[0] - r["cost"]) <= (2e-5 if dtype == "f16x3" else 1e-4) * abs(r["cost"]), (kw, st[0], r["cost"])
+            assert _rel(dW, r["dW"]) < gate and _rel(dbh, r["dbh"]) < gate, (kw, _rel(dW, r["dW"]), _rel(dbh, r["dbh"]))
+        for a, b in zip(got, ref):
+            assert _rel(a, b) < 2 * gate, (kw, _rel(a, b))
+
+
+def test_step_f16x2_shape_beyond_one_dw_round():
+    """More 160 x 128 tiles than CUs: the dW GEMM goes to memory (un-scaled by its output scale) + the optimizer kernel."""
+    out, ref, got = _run_case("f16x2", "batch_all", "cross_entropy", ("sigmoid", "sigmoid"), "momentum", N=300, F=5000, H=1200, B=128, steps=2)
+    for r, st, dW, dbh, dbv in out:
+        assert abs(st[0] - r["cost"]) <= 5e-5 * abs(r["cost"]), (st[0], r["cost"])
+        assert _rel(dW, r["dW"]) < 1.5e-3, _rel(dW, r["dW"])
+    for a, b in zip(got, ref):
+        assert _rel(a, b) < 2e-3, _rel(a, b)
+
+
+def test_step_f16x2_op_scale_is_transparent():
+    """A different power of two in the operand images changes nothing but the rounding of subnormal entries: the step at op_scale 2^6 and 2^13
+    agrees to fp16 rounding, and both sit at the oracle."""
+    a, ra, pa = _run_case("f16x2", "batch_all", "cross_entropy", ("sigmoid", "sigmoid"), "gradient_descent", steps=2, seed=9, options={"op_scale_log2": 13})
+    b, rb, pb = _run_case("f16x2", "batch_all", "cross_entropy", ("sigmoid", "sigmoid"), "gradient_descent", steps=2, seed=9, options={"op_scale_log2": 6})
+    for (_, sa, dWa, *_), (_, sb, dWb, *_) in zip(a, b):
+        assert np.allclose(sa[:3], sb[:3], rtol=2e-5, atol=0)
+        assert _rel(dWb, np.asarray(dWa, np.float64)) < 1e-3
