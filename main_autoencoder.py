@@ -67,9 +67,10 @@ def build_parser():
     p.add_argument("--alpha", type=float, default=1)
     p.add_argument("--triplet_strategy", default="batch_all", choices=["batch_all", "batch_hard", "none"])
     # MI355X-side additions
-    p.add_argument("--precision", default="auto", choices=["auto", "bf16x3", "fp32", "bf16"],
-                   help="auto (default): the fastest mode that holds the reference's loss curve within 1e-4 -- bf16x3 (split-bf16 MFMA "
-                        "operands: hi + lo images, three products per GEMM); fp32: exact-fp32 MFMA; bf16 is faster but outside that gate")
+    p.add_argument("--precision", default="auto", choices=["auto", "f16x2", "bf16x3", "fp32", "bf16", "f16", "f16x3"],
+                   help="auto (default): the fastest mode that holds the reference's loss curve within 1e-4 -- f16x2 (fp16 MFMA operand images, W as "
+                        "hi + lo: two products per gradient GEMM); bf16x3: split-bf16 (hi + lo images of every operand, three products); fp32: exact-fp32 "
+                        "MFMA; bf16 / f16 (single images) are faster but outside that gate; f16x3: every operand hi + lo fp16")
     p.add_argument("--rng", default="numpy", choices=["numpy", "philox"])
     p.add_argument("--data", default="", help="scipy-sparse .npz or dense .npy feature matrix (rows = articles)")
     p.add_argument("--labels", default="", help=".npy label vector aligned with --data")

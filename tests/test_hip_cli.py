@@ -175,15 +175,14 @@ def test_explicit_triplet_device_salt_and_pepper_runs(tmp_path):
 def test_bench_two_ranks_on_one_gpu(tmp_path):
     """The N > 1 path of bench.py (phase-1 step -> reduce-scatter of the W gradient -> sharded optimizer -> all-gather of the
     low-precision shadow, dp.ShardedExchange) with two processes
-    sharing this box's single GPU (gloo collectives; RCCL needs one GPU per rank): launch line exactly as the driver's,
-    one JSON line from rank 0, n_gpus = 2, a finite loss that went down."""
+    sharing this box's single GPU (gloo collectives; RCCL needs one GPU per rank): `python bench.py --gpus 2 ...` with NO launcher around it
+    (bench.py starts its own ranks), one JSON line from rank 0, n_gpus = 2, a finite loss that went down."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29617", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "3",
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "3",
            "--backend", "gloo", "--single-device", "--no-cpu-baseline", "--no-roofline", "--rows", "1600"]
     out = subprocess.run(cmd, cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]

@@ -41,7 +41,7 @@ def _fit(tmp, strategy, opt, dp_flag, grad_dtype="fp32", seed=11, mining="local"
                                  data_parallel=dp_flag, dp_grad_dtype=grad_dtype, dp_mining=mining, dp_exchange=exchange, results_root=tmp + "/")
     model.fit(m, train_set_label=lab if strategy != "none" else None)
     if dp_flag:
-        want = "AllReduceExchange" if (exchange == "allreduce" or (exchange == "auto" and precision in ("auto", "bf16x3"))) else "ShardedExchange"
+        want = "AllReduceExchange" if (exchange == "allreduce" or (exchange == "auto" and precision in ("auto", "bf16x3", "f16x2"))) else "ShardedExchange"
         assert type(model._exchange).__name__ == want, (type(model._exchange).__name__, want)
     stats = np.stack([model.epoch_stats(e + 1)["per_batch"] for e in range(2)])
     return stats, model.engine.get_params()
@@ -125,20 +125,25 @@ def test_fit_two_ranks_equal_one_rank_strategy_none(tmp_path, opt):
     assert np.array_equal(out[0][1][0], out[1][1][0])                      # both ranks end with the same weights, bit for bit
 
 
-@pytest.mark.parametrize("strategy,mining,exchange", [("none", "local", "auto"), ("batch_all", "global", "auto"), ("batch_all", "global", "sharded"),
-                                                      ("none", "local", "sharded")])
-def test_fit_two_ranks_split_bf16_equals_one_rank(tmp_path, strategy, mining, exchange):
+@pytest.mark.parametrize("strategy,mining,exchange,precision", [("none", "local", "auto", "bf16x3"), ("batch_all", "global", "auto", "bf16x3"),
+                                                                ("batch_all", "global", "sharded", "bf16x3"), ("none", "local", "sharded", "bf16x3"),
+                                                                ("none", "local", "auto", "f16x2"), ("batch_all", "global", "auto", "f16x2"),
+                                                                ("batch_all", "local", "sharded", "f16x2")])
+def test_fit_two_ranks_split_bf16_equals_one_rank(tmp_path, strategy, mining, exchange, precision):
     """precision='bf16x3' under data parallel.  Default exchange (dp.AllReduceExchange): ONE all-reduce of the flat fp32 gradient, every rank
     runs the optimizer on the whole W and rebuilds its four bf16 images in the same kernel.  exchange='sharded' (dp.ShardedExchange): fp32
     gradients reduce-scattered, each rank updates its rows of the fp32 master, the MASTER rows all-gathered, images rebuilt.  Either way two
     ranks reproduce one rank at the global batch (and, with dp_mining='global', its triplet leg)."""
-    ref_stats, ref_p = _fit(str(tmp_path), strategy, "gradient_descent", False, precision="bf16x3")
-    out = _run_dp(str(tmp_path), strategy, "gradient_descent", mining=mining, precision="bf16x3", exchange=exchange)
+    # (f16x2, the fp16 build's split mode = what precision='auto' resolves to: the two half batches round their fp16 images differently from the
+    #  whole batch -- the ranks agree with one rank to the mode's own gradient accuracy)
+    ref_stats, ref_p = _fit(str(tmp_path), strategy, "gradient_descent", False, precision=precision)
+    out = _run_dp(str(tmp_path), strategy, "gradient_descent", mining=mining, precision=precision, exchange=exchange)
     for r in range(2):
         stats, p = out[r]
-        assert _rel(stats[..., 0], ref_stats[..., 0]) < 2e-5, (r, stats[..., 0], ref_stats[..., 0])
-        for a, b in zip(p, ref_p):
-            assert _rel(a, b) < 1e-4
+        if mining == "global" or strategy == "none":
+            assert _rel(stats[..., 0], ref_stats[..., 0]) < (2e-5 if precision == "bf16x3" else 1e-4), (r, stats[..., 0], ref_stats[..., 0])
+            for a, b in zip(p, ref_p):
+                assert _rel(a, b) < (1e-4 if precision == "bf16x3" else 2e-3)
     assert np.array_equal(out[0][1][0], out[1][1][0])
 
 

@@ -704,3 +704,34 @@ def test_full_size_step_config2(dtype, strategy):
     gt = 5e-4 if dtype == "fp32" else 6e-3          # the oracle leg is fp32 NumPy here: its own rounding is ~1e-4; bf16 operands: ~2e-3 measured
     e = (_rel(dW, r["dW"]), _rel(dbh, r["dbh"]), _rel(dbv, r["dbv"]))
     assert max(e) < gt, e
+
+
+@pytest.mark.parametrize("dtype", ["bf16x3", "f16x3"])
+def test_step_split_mode_dense_train_set_with_corrupted_csr_copy(dtype):
+    """A DENSE valued train set stepped with an explicitly corrupted CSR copy (what fit() does for salt-and-pepper noise on ndarray input): the clean
+    rows reach the decode epilogue through the dense gather, so their lo image must come from the dense rows too (it was keyed on the CSR
+    values and silently missing here -- the loss and delta2 then used 16-bit-rounded x, 2^-9 relative in bf16)."""
+    from dae_rnn_news_recommendation_amd import _lib as L
+    from dae_rnn_news_recommendation_amd.engine import Engine
+    rng = np.random.default_rng(31)
+    N, F, H, B = 300, 700, 90, 128
+    X = (_mk(rng, N, F, False, density=0.2).toarray()).astype(np.float32)
+    keep = rng.random(X.shape) >= 0.3
+    Xc = sparse.csr_matrix(X * keep); Xc.sort_indices()
+    lab = rng.integers(0, 4, N)
+    W0 = rng.uniform(-0.3, 0.3, (F, H)).astype(np.float32)
+    eng = Engine(F, H, B, dtype=dtype, enc_act="tanh", dec_act="none", loss_func="mean_squared", opt="gradient_descent", learning_rate=0.05,
+                 alpha=0.7, triplet="batch_all")
+    eng.upload_dense(X); eng.set_params(W0)
+    cc = Engine.to_device_csr(Xc, eng.device)
+    idx = rng.permutation(N)[:B]
+    stats = torch.zeros(8, device="cuda")
+    eng.train_step(torch.from_numpy(idx.astype(np.int32)).cuda(), torch.from_numpy(lab[idx].astype(np.int32)).cuda(), stats, corrupted_csr=cc, phase=0)
+    torch.cuda.synchronize()
+    r = O.forward_backward(W0.astype(np.float64), np.zeros(H), np.zeros(F), X[idx], Xc[idx].toarray(), lab[idx], enc_act="tanh", dec_act="none",
+                           loss_func="mean_squared", triplet_strategy="batch_all", alpha=0.7, dt=np.float64)
+    st = stats.cpu().numpy()
+    dW, dbh, dbv = eng.grads()
+    print(dtype, "cost", st[0], r["cost"], "dW", _rel(dW, r["dW"]), "dbv", _rel(dbv, r["dbv"]))
+    assert abs(st[0] - r["cost"]) <= 2e-5 * abs(r["cost"]), (st[0], r["cost"])
+    assert _rel(dW, r["dW"]) < 1e-4 and _rel(dbv, r["dbv"]) < 1e-4, (_rel(dW, r["dW"]), _rel(dbv, r["dbv"]))
