@@ -126,6 +126,7 @@ SIGNATURES = {
     "dae_plan_set_option": (i32, [vp, C.c_char_p, i32]),
     "dae_train_step": (i32, [vp, C.POINTER(dae_step), vp]),
     "dae_plan_apply": (i32, [vp, i32, f32, vp]),
+    "dae_plan_apply_band": (i32, [vp, i32, f32, i32, i32, vp]),
     "dae_plan_apply_rows": (i32, [vp, i32, f32, vp, i32, i32, i32, vp]),
     "dae_plan_refresh_wt": (i32, [vp, vp]),
     "dae_plan_stream_wait_dw": (i32, [vp, vp]),

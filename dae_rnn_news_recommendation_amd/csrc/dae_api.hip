@@ -341,6 +341,7 @@ extern "C" int dae_plan_set_option(dae_plan* p, const char* name, int32_t value)
     else if (!strcmp(name, "ce_literal")) p->ce_literal = on;
     else if (!strcmp(name, "overlap")) p->overlap_ok = on;
     else if (!strcmp(name, "gather_tile")) set_gather_tile(value);        // process-wide: tile shape of the dense gather (A/B measurements)
+    else if (!strcmp(name, "dw_rounds")) { DAE_CHECK_ARG(value >= 1 && value <= 64, "plan_set_option: dw_rounds in 1..64"); set_use_glds(-100 - value); }   // process-wide, like miner_pack
     else if (!strcmp(name, "miner_order")) p->miner_order_ok = on;
     else if (!strcmp(name, "miner_ranges")) p->miner_ranges_ok = on;
     else if (!strcmp(name, "miner_pack")) set_miner_pack(on);        // process-wide (the launcher's choice), like dae_set_glds
@@ -818,6 +819,16 @@ extern "C" int dae_plan_apply(dae_plan* p, int32_t adam_t, float grad_scale, voi
     const float lr = plan_lr(p, adam_t);
     return launch_opt_step(p->cfg.opt, lr, p->cfg.momentum, grad_scale, p->b.W, p->b.bh, p->b.bv, p->b.grad, p->b.opt_s1, p->b.opt_s2,
                            p->Fp, p->Hp, p->cfg.dtype, p->b.W_lo, p->b.Wt_lo, plan_w_lo2(p), p->x3 ? p->Wt_lo2 : nullptr, /*apply=*/1, stream);
+}
+
+// The same on the row band [f0, f1) of W (multiples of 64) -- dp.AllReduceExchange with buckets: the flat gradient is all-reduced band by band and every
+// band is applied as soon as its sum has arrived, while the next band is still on the wire.  The band that ends at Fp also updates the biases (their
+// gradients sit behind the W part of the flat buffer, i.e. in the last bucket).  Bands applied in any order give the weights of one dae_plan_apply.
+extern "C" int dae_plan_apply_band(dae_plan* p, int32_t adam_t, float grad_scale, int32_t f0, int32_t f1, void* stream) {
+    DAE_CHECK_ARG(p && p->bound, "plan_apply_band: plan not bound");
+    const float lr = plan_lr(p, adam_t);
+    return launch_opt_step(p->cfg.opt, lr, p->cfg.momentum, grad_scale, p->b.W, p->b.bh, p->b.bv, p->b.grad, p->b.opt_s1, p->b.opt_s2,
+                           p->Fp, p->Hp, p->cfg.dtype, p->b.W_lo, p->b.Wt_lo, plan_w_lo2(p), p->x3 ? p->Wt_lo2 : nullptr, /*apply=*/1, stream, f0, f1);
 }
 
 // Data-parallel second half with a SHARDED optimizer: this rank owns rows [f0, f1) of W.  grad_rows holds the

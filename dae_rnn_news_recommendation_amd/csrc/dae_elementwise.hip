@@ -354,33 +354,70 @@ __global__ void bias_grads_kernel(BiasArgs a) { bias_grads_body(a, blockIdx.x * 
 // ------------------------------------------------------------------------------------------------
 // K9 optimizer (autoencoder.py:444-477, tf.train.* semantics)
 // ------------------------------------------------------------------------------------------------
+// 64 x 64 tiles, 256 threads; a thread owns 4 consecutive columns of rows r0, r0 + 16, r0 + 32, r0 + 48: master weights, gradient and optimizer slots move
+// as 16-byte pieces of 256-byte row runs, the row-major shadow(s) as 8-byte pieces; the transposed shadow(s) leave through an LDS tile as 8-byte pieces of
+// 128-byte runs.  (The element-per-thread form of this kernel moved ~1 GB in 202 us at F = 50000: half the HBM rate of the dW epilogue's block-wise form.)
 template <typename T>
 __global__ __launch_bounds__(256) void opt_w_kernel(int opt, float lr, float mom, float gscale, float* __restrict__ W,
                                                     const float* __restrict__ grad, float* __restrict__ s1,
-                                                    float* __restrict__ s2, int Fp, int Hp, T* __restrict__ W_lo,
+                                                    float* __restrict__ s2, int ldwt, int Hp, T* __restrict__ W_lo,
                                                     T* __restrict__ Wt_lo, int apply, T* __restrict__ W_lo2, T* __restrict__ Wt_lo2) {
-    // W_lo2 / Wt_lo2 (split-bf16 mode): the lo images, bf16(W - bf16(W)) in both layouts
+    // W_lo2 / Wt_lo2 (split mode): the lo images, lo16(W - hi16(W)) in both layouts.  ldwt: leading dimension of the transposed shadows (Fp); the pointers
+    // may address a row band of W (launch_opt_step's f0 / f1): blockIdx.y counts 64-row blocks from the band's first row
     __shared__ float tile[64][65];
     const int j0 = blockIdx.x * 64, f0 = blockIdx.y * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-#pragma unroll 4
-    for (int r = ty; r < 64; r += 4) {
-        const int64_t k = (int64_t)(f0 + r) * Hp + j0 + tx;
-        float p = W[k];
+    const int c4 = threadIdx.x & 15, r0 = threadIdx.x >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + 16 * i;
+        const int64_t k = (int64_t)(f0 + r) * Hp + j0 + c4 * 4;
+        f32x4 p = *reinterpret_cast<const f32x4*>(W + k);
         if (apply) {
-            p = opt_update(opt, lr, mom, p, grad[k] * gscale, s1, s2, k);
-            W[k] = p;
+            const f32x4 g = *reinterpret_cast<const f32x4*>(grad + k) * gscale;
+            if (opt == DAE_OPT_SGD) {
+                p = p - lr * g;
+            } else if (opt == DAE_OPT_ADAGRAD) {
+                f32x4 a = *reinterpret_cast<const f32x4*>(s1 + k) + g * g;
+                *reinterpret_cast<f32x4*>(s1 + k) = a;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) p[j] = p[j] - lr * g[j] * rsqrtf(a[j]);
+            } else if (opt == DAE_OPT_MOMENTUM) {
+                const f32x4 a = mom * *reinterpret_cast<const f32x4*>(s1 + k) + g;
+                *reinterpret_cast<f32x4*>(s1 + k) = a;
+                p = p - lr * a;
+            } else {             // Adam; lr already holds lr_t = lr*sqrt(1-b2^t)/(1-b1^t)
+                const f32x4 m = 0.9f * *reinterpret_cast<const f32x4*>(s1 + k) + 0.1f * g;
+                const f32x4 v = 0.999f * *reinterpret_cast<const f32x4*>(s2 + k) + 0.001f * g * g;
+                *reinterpret_cast<f32x4*>(s1 + k) = m; *reinterpret_cast<f32x4*>(s2 + k) = v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) p[j] = p[j] - lr * m[j] / (sqrtf(v[j]) + 1e-8f);
+            }
+            *reinterpret_cast<f32x4*>(W + k) = p;
         }
-        if (W_lo) W_lo[k] = Elem<T>::from(p);
-        if (W_lo2) W_lo2[k] = elem_residual<T>(p);
-        tile[r][tx] = p;
+        if constexpr (sizeof(T) == 2) {
+            if (W_lo) { uint2 v; v.x = f2bf_pack_hw(p[0], p[1]); v.y = f2bf_pack_hw(p[2], p[3]); *reinterpret_cast<uint2*>(W_lo + k) = v; }
+            if (W_lo2) { uint2 v; v.x = bf_residual_pack_hw(p[0], p[1]); v.y = bf_residual_pack_hw(p[2], p[3]); *reinterpret_cast<uint2*>(W_lo2 + k) = v; }
+        } else {
+            if (W_lo) *reinterpret_cast<f32x4*>(W_lo + k) = p;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tile[r][c4 * 4 + j] = p[j];
     }
     __syncthreads();
-    if (Wt_lo) {
-#pragma unroll 4
-        for (int r = ty; r < 64; r += 4) {
-            Wt_lo[(int64_t)(j0 + r) * Fp + f0 + tx] = Elem<T>::from(tile[tx][r]);
-            if (Wt_lo2) Wt_lo2[(int64_t)(j0 + r) * Fp + f0 + tx] = elem_residual<T>(tile[tx][r]);
+    if (Wt_lo) {                                        // transposed tile: thread (c4, r0) writes features 4 c4 .. + 3 of hidden rows r0 + 16 i
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = r0 + 16 * i;
+            const float a = tile[c4 * 4][r], b = tile[c4 * 4 + 1][r], c = tile[c4 * 4 + 2][r], d = tile[c4 * 4 + 3][r];
+            const int64_t kt = (int64_t)(j0 + r) * ldwt + f0 + c4 * 4;
+            if constexpr (sizeof(T) == 2) {
+                uint2 v; v.x = f2bf_pack_hw(a, b); v.y = f2bf_pack_hw(c, d);
+                *reinterpret_cast<uint2*>(Wt_lo + kt) = v;
+                if (Wt_lo2) { uint2 w; w.x = bf_residual_pack_hw(a, b); w.y = bf_residual_pack_hw(c, d); *reinterpret_cast<uint2*>(Wt_lo2 + kt) = w; }
+            } else {
+                f32x4 v = {a, b, c, d};
+                *reinterpret_cast<f32x4*>(Wt_lo + kt) = v;
+            }
         }
     }
 }
@@ -711,25 +748,34 @@ extern "C" int dae_bias_grads(const float* dbv_part, int32_t n_row_waves, const 
 
 // flat layout of grad / s1 / s2: [W (Fp*Hp) | bh (Hp) | bv (Fp)]
 int dae::launch_opt_step(int opt, float lr, float momentum, float grad_scale, float* W, float* bh, float* bv, const float* grad, float* s1,
-                         float* s2, int Fp, int Hp, int dtype, void* W_lo, void* Wt_lo, void* W_lo2, void* Wt_lo2, int apply, void* stream) {
+                         float* s2, int Fp, int Hp, int dtype, void* W_lo, void* Wt_lo, void* W_lo2, void* Wt_lo2, int apply, void* stream, int f0, int f1) {
+    // [f0, f1): the row band of W to update / refresh (multiples of 64; f1 < 0: all Fp rows) -- the bucketed data-parallel exchange applies the optimizer
+    // band by band while the next band's all-reduce is on the wire (dp.AllReduceExchange); the biases are updated with the LAST band (f1 == Fp)
     const bool skip_bias = (apply == 2);     // apply: 0 refresh shadows only, 1 update W and biases, 2 update W only
     if (apply == 2) apply = 1;
+    if (f1 < 0) { f0 = 0; f1 = Fp; }
     DAE_CHECK_ARG(W && Fp % DAE_PAD == 0 && Hp % DAE_PAD == 0, "opt_step: bad args");
+    DAE_CHECK_ARG(f0 >= 0 && f0 < f1 && f1 <= Fp && f0 % 64 == 0 && f1 % 64 == 0, "opt_step: row band [%d, %d) outside [0, %d] or not multiples of 64", f0, f1, Fp);
     DAE_CHECK_ARG(opt >= DAE_OPT_SGD && opt <= DAE_OPT_ADAM, "opt_step: unknown optimizer %d", opt);
     if (apply) {
         DAE_CHECK_ARG(grad && bh && bv, "opt_step: null grad/bias");
         DAE_CHECK_ARG(opt == DAE_OPT_SGD || s1, "opt_step: optimizer slot s1 required");
         DAE_CHECK_ARG(opt != DAE_OPT_ADAM || s2, "opt_step: optimizer slot s2 required");
     }
-    dim3 grid(Hp / 64, Fp / 64), block(256);
+    dim3 grid(Hp / 64, (f1 - f0) / 64), block(256);
+    const int64_t ro = (int64_t)f0 * Hp;                  // first element of the band in the row-major images
+    const int es = dtype == DAE_BF16 ? 2 : 4;
+    auto rows = [&](void* q, int64_t off_elems) -> void* { return q ? (char*)q + off_elems * es : nullptr; };
     if (dtype == DAE_BF16)
-        hipLaunchKernelGGL((opt_w_kernel<bf16_t>), grid, block, 0, ST(stream), opt, lr, momentum, grad_scale, W, grad, s1, s2, Fp, Hp,
-                           (bf16_t*)W_lo, (bf16_t*)Wt_lo, apply, (bf16_t*)W_lo2, (bf16_t*)Wt_lo2);
+        hipLaunchKernelGGL((opt_w_kernel<bf16_t>), grid, block, 0, ST(stream), opt, lr, momentum, grad_scale, W + ro, grad ? grad + ro : nullptr,
+                           s1 ? s1 + ro : nullptr, s2 ? s2 + ro : nullptr, Fp, Hp, (bf16_t*)rows(W_lo, ro), (bf16_t*)rows(Wt_lo, f0), apply,
+                           (bf16_t*)rows(W_lo2, ro), (bf16_t*)rows(Wt_lo2, f0));
     else
-        hipLaunchKernelGGL((opt_w_kernel<float>), grid, block, 0, ST(stream), opt, lr, momentum, grad_scale, W, grad, s1, s2, Fp, Hp,
-                           (float*)W_lo, (float*)Wt_lo, apply, (float*)nullptr, (float*)nullptr);
+        hipLaunchKernelGGL((opt_w_kernel<float>), grid, block, 0, ST(stream), opt, lr, momentum, grad_scale, W + ro, grad ? grad + ro : nullptr,
+                           s1 ? s1 + ro : nullptr, s2 ? s2 + ro : nullptr, Fp, Hp, (float*)rows(W_lo, ro), (float*)rows(Wt_lo, f0), apply,
+                           (float*)nullptr, (float*)nullptr);
     DAE_CHECK_LAUNCH();
-    if (apply && !skip_bias) {
+    if (apply && !skip_bias && f1 == Fp) {
         const int64_t off = (int64_t)Fp * Hp;
         hipLaunchKernelGGL(opt_bias_kernel, dim3((Hp + Fp + 255) / 256), dim3(256), 0, ST(stream), opt, lr, momentum, grad_scale, bh,
                            bv, grad + off, s1 ? s1 + off : nullptr, s2 ? s2 + off : nullptr, Hp, Fp);

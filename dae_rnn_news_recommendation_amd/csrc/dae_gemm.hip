@@ -1876,6 +1876,11 @@ template <typename T> static pc_fn pc_kernel(int role) {
 }
 static int g_cus = 0;        // compute units of the current device (set by gemm_init)
 static int g_dw_pc = 1;      // dW + optimizer on the 160 x 128 producer/consumer kernel when its grid fills one round (dae_set_glds(-3/-4))
+static int g_dw_rounds = 1;  // ... or at most this many rounds of the chip (dae_set_glds(-100 - r)): one workgroup per CU at a time, the next tile's K loop starts when a CU
+                             // frees -- the optimizer stays in the epilogue for shapes beyond 256 tiles (F = 50000: 2504 tiles) instead of a gradient round trip
+                             // through HBM + a separate optimizer launch
+static int g_dw_rounds_split = 16;   // the split 16-bit modes take the multi-round form by default: measured at 896 x 50048 x 1024 (c4, f16x2) 357 us fused against
+                                     // 246 us GEMM to memory + 208 us optimizer kernel (profiles/r05_c4_dw_rounds.txt)
 static int g_use_pc = 1;     // dae_set_glds(-1) keeps the 4-wave kernel for every grid (A/B)
 static int g_pc_vec = 1;     // gemm_nt_pc epilogue: 1 = LDS-staged 16-byte pieces (default), 0 = dword stores (dae_set_glds(-9) / (-10))
 typedef void (*decode_fn)(GemmParams, DecodeEpi);
@@ -2022,13 +2027,13 @@ int launch_gemm_f32out_n(int dtype, int M, int N, const GemmSegDesc* segs, int n
 bool dw_bits_fits(int M, int N, int Bp) {
     if (gemm_init()) return false;
     const int tiles_m = (M + DW_BM - 1) / DW_BM, tiles_n = N / BN, per = (tiles_m + 7) / 8;
-    return N % BN == 0 && Bp % 64 == 0 && Bp / 64 <= DWB_MAXKT && 8 * per * tiles_n <= g_cus && g_dw_pc != 0;
+    return N % BN == 0 && Bp % 64 == 0 && Bp / 64 <= DWB_MAXKT && 8 * per * tiles_n <= g_cus * g_dw_rounds && g_dw_pc != 0;
 }
 
 bool dw_x3_fits(int M, int N, int Bp) {
     if (gemm_init()) return false;
     const int tiles_m = (M + DW_BM - 1) / DW_BM, tiles_n = N / BN, per = (tiles_m + 7) / 8;
-    return N % BN == 0 && Bp % 64 == 0 && 8 * per * tiles_n <= g_cus && g_dw_pc != 0;
+    return N % BN == 0 && Bp % 64 == 0 && 8 * per * tiles_n <= g_cus * g_dw_rounds_split && g_dw_pc != 0;
 }
 
 int launch_dw_opt(int M, int N, const void* A0, int64_t lda0, const void* Bt0, int64_t ldb0, int K0, const void* A1, int64_t lda1,
@@ -2048,11 +2053,11 @@ int launch_dw_opt(int M, int N, const void* A0, int64_t lda0, const void* Bt0, i
     {   // 160 x 128 tiles, 8-wave producer/consumer: one workgroup per CU in a single round when the tile count fits the chip
         const int tiles_m = (M + DW_BM - 1) / DW_BM, tiles_n = N / BN;
         const int per = (tiles_m + 7) / 8;
-        const bool fits = g_dw_pc && K0 % 64 == 0 && K1 % 64 == 0 && 8 * per * tiles_n <= g_cus;
+        const bool fits = g_dw_pc && K0 % 64 == 0 && K1 % 64 == 0 && 8 * per * tiles_n <= g_cus * g_dw_rounds;
         DAE_CHECK_ARG(!xa || (fits && K0 / 64 <= DWB_MAXKT && xa->xtb && xa->ldxt >= K0 / 32),
                       "dw: the bit-image form of x~^T does not fit this shape (M=%d N=%d Bp=%d)", M, N, K0);
         DAE_CHECK_ARG(!grad_only || fits, "dw: the gradient-only form runs on the 160 x 128 kernel only (M=%d N=%d)", M, N);
-        if (fits && (xa || grad_only || g_dw_pc == 2 || 8 * per * tiles_n > (3 * g_cus) / 4)) {
+        if (fits && (xa || grad_only || g_dw_pc == 2 || g_dw_rounds > 1 || 8 * per * tiles_n > (3 * g_cus) / 4)) {
             typedef void (*dwpc_fn)(GemmParams, OptEpi, int, DwBits);
             static const dwpc_fn pcs[2][5] = {
                 {gemm_dw_pc<DAE_OPT_SGD, false>, gemm_dw_pc<DAE_OPT_ADAGRAD, false>, gemm_dw_pc<DAE_OPT_MOMENTUM, false>, gemm_dw_pc<DAE_OPT_ADAM, false>,
@@ -2134,8 +2139,8 @@ int launch_dw_opt_n(int M, int N, const GemmSegDesc* segs_in, int nsegs_in, cons
     const int tiles_m = (M + DW_BM - 1) / DW_BM, tiles_n = N / BN, per = (tiles_m + 7) / 8;
     bool k64 = true;
     for (int i = 0; i < nsegs; ++i) k64 = k64 && segs[i].K % 64 == 0;
-    DAE_CHECK_ARG(g_dw_pc && k64 && 8 * per * tiles_n <= g_cus,
-                  "dw_opt_n: the split-bf16 dW kernel runs shapes of at most one 160 x 128 tile per CU (M=%d N=%d)", M, N);
+    DAE_CHECK_ARG(g_dw_pc && k64 && 8 * per * tiles_n <= g_cus * g_dw_rounds_split,
+                  "dw_opt_n: the split-mode dW kernel runs shapes of at most %d 160 x 128 tiles per CU (M=%d N=%d)", g_dw_rounds_split, M, N);
     typedef void (*dwpc_fn)(GemmParams, OptEpi, int, DwBits);
     static const dwpc_fn x3s[2][5] = {{gemm_dw_pc<DAE_OPT_SGD, false, true>, gemm_dw_pc<DAE_OPT_ADAGRAD, false, true>,
                                        gemm_dw_pc<DAE_OPT_MOMENTUM, false, true>, gemm_dw_pc<DAE_OPT_ADAM, false, true>, gemm_dw_pc<DW_GRAD_ONLY, false, true>},
@@ -2460,6 +2465,7 @@ void set_use_glds(int nst) {
     if (nst == -5) { g_dw_pc = 2; return; }          // tests: the 160 x 128 kernel for every grid that fits one round
     if (nst == -6) { g_w8 = 0; return; }             // A/B: never the 256 x 256 / 8-MFMA-wave kernel
     if (nst == -7) { g_w8 = 1; return; }
+    if (nst <= -100 && nst > -1000) { g_dw_rounds = g_dw_rounds_split = (-nst - 100 < 1 ? 1 : -nst - 100); return; }    // rounds of the chip the 160 x 128 dW kernel may take
     if (nst == -9) { g_pc_vec = 0; return; }         // A/B: gemm_nt_pc stores its tile as dwords straight from the accumulators
     if (nst == -10) { g_pc_vec = 1; return; }
     if (nst <= -1000) {                              // tests: pretend the device has (-nst - 1000) compute units, so that every CU-count-keyed

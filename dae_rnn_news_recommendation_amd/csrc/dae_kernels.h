@@ -131,7 +131,7 @@ struct ClearArgs {            // CSR rows whose entries were scattered into x~^T
 // K8 (middle), see dae_dh_finish; delta1_lo: optional ROW-MAJOR delta1 [Bp x ldh] in `dtype` (operand of the sparse x~^T.delta1)
 // K9 on the whole of W (+ biases): dae_opt_step with the lo images of the split-bf16 shadows (NULL outside that mode)
 int launch_opt_step(int opt, float lr, float momentum, float grad_scale, float* W, float* bh, float* bv, const float* grad, float* s1, float* s2,
-                    int Fp, int Hp, int dtype, void* W_lo, void* Wt_lo, void* W_lo2, void* Wt_lo2, int apply, void* stream);
+                    int Fp, int Hp, int dtype, void* W_lo, void* Wt_lo, void* W_lo2, void* Wt_lo2, int apply, void* stream, int f0 = 0, int f1 = -1);
 int launch_dh_finish(const float* slabs, int splits, int64_t slab_stride, int64_t ld_slab, const float* dh_extra, const float* h_f32,
                      int64_t ldh, const float* bh, int B, int H, int enc_act, int dtype, void* delta1_t, int64_t ldt, float* colsum_part,
                      float* delta1_f32, void* delta1_lo, hipStream_t st, void* delta1_t2 = nullptr,   // delta1_t2: lo image of delta1^T (split-bf16)

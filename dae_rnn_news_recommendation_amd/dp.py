@@ -311,9 +311,16 @@ class AllReduceExchange:
     no bytes here -- it only adds two collective launches (reduce-scatter + all-gather instead of one all-reduce), the bias all-reduce, a copy of
     the master rows and torch's stream hops around each of them: without communication the sharded step form costs 93.6 us on top of the phase-1
     step, this one ~35 (tools/dp_step_breakdown.py --precision bf16x3).  Every rank holds the full master weights and optimizer slots at all
-    times: gather_master / gather_slots are no-ops.  Same interface as ShardedExchange."""
+    times: gather_master / gather_slots are no-ops.  Same interface as ShardedExchange.
 
-    def __init__(self, eng):
+    buckets > 1 (default 4 when the world has more than one rank): the flat gradient is cut into `buckets` row bands of W (whole 64-row blocks; the
+    bias gradients ride at the end of the last band).  All bands are handed to the collective library at once (async_op: RCCL runs them back to back
+    on its own stream) and the step's stream applies band k (dae_plan_apply_band: master rows, slots and every 16-bit image of those rows) as soon as
+    band k has arrived -- the optimizer pass over band k runs while band k + 1 is on the wire, so of the ~20 us optimizer pass only the last band's
+    share stays exposed behind the collective.  Element-wise the same sums and the same update as the single-bucket form (bit-identical for two
+    ranks; for more ranks the reduction order inside the collective library may differ by bucket size)."""
+
+    def __init__(self, eng, buckets=None):
         import torch
         import torch.distributed as dist
         assert is_initialized(), "torch.distributed is not initialised"
@@ -328,6 +335,13 @@ class AllReduceExchange:
         self.grad_dtype, self.packed = "fp32", False
         self.flat = eng.grad[:eng.n_flat]                       # [dW (Fp*Hp) | dbh (Hp) | dbv (Fp)]
         self.f0, self.f1 = 0, eng.Fp                            # (interface parity: this rank "owns" every row)
+        if buckets is None:
+            buckets = 4 if self.world > 1 else 1
+        nblk = eng.Fp // 64
+        self.buckets = max(1, min(int(buckets), nblk))
+        # band k = rows [bounds[k], bounds[k + 1]) of W; its slice of the flat buffer ends at the band's last row -- or at the end of the buffer (biases)
+        self.bounds = [64 * ((nblk * k) // self.buckets) for k in range(self.buckets)] + [eng.Fp]
+        self.slices = [self.flat[self.bounds[k] * eng.Hp:(self.bounds[k + 1] * eng.Hp if k + 1 < self.buckets else eng.n_flat)] for k in range(self.buckets)]
         self.collective_ms = 0.0
         self.steps = 0
         self._ev = tuple(torch.cuda.Event(enable_timing=True) for _ in range(2)) if eng.device.type == "cuda" else None
@@ -337,11 +351,21 @@ class AllReduceExchange:
         """Call after eng.train_step(phase=1): all-reduce + full optimizer step.  grad_scale multiplies the rank-SUMMED gradient."""
         if self._ev:
             self._ev[0].record()
-        self.dist.all_reduce(self.flat, op=self.dist.ReduceOp.SUM)
-        if self._ev:
-            self._ev[1].record()
-            self._pending = True
-        self.eng.apply(grad_scale=grad_scale)                   # (counts the Adam step itself)
+        if self.buckets == 1:
+            self.dist.all_reduce(self.flat, op=self.dist.ReduceOp.SUM)
+            if self._ev:
+                self._ev[1].record()
+                self._pending = True
+            self.eng.apply(grad_scale=grad_scale)               # (counts the Adam step itself)
+        else:
+            works = [self.dist.all_reduce(sl, op=self.dist.ReduceOp.SUM, async_op=True) for sl in self.slices]
+            self.eng.begin_apply()                              # one optimizer step (Adam's t), applied band by band
+            for k, w in enumerate(works):
+                w.wait()                                        # the step's stream waits for band k only
+                if k == self.buckets - 1 and self._ev:
+                    self._ev[1].record()
+                    self._pending = True
+                self.eng.apply_band(self.bounds[k], self.bounds[k + 1], grad_scale=grad_scale)
         self.steps += 1
 
     def collect_time(self):
@@ -357,12 +381,12 @@ class AllReduceExchange:
         return
 
 
-def make_exchange(eng, grad_dtype="fp32", kind="auto"):
+def make_exchange(eng, grad_dtype="fp32", kind="auto", buckets=None):
     """The data-parallel exchange for `eng`: kind 'auto' = AllReduceExchange in the split-bf16 mode (nothing to gain from sharding there),
     ShardedExchange otherwise (bf16 gradients / bf16 shadow rows halve its bytes); 'sharded' / 'allreduce' force one form."""
     assert kind in ("auto", "sharded", "allreduce"), kind
     if kind == "allreduce" or (kind == "auto" and getattr(eng, "x3", False)):
-        return AllReduceExchange(eng)
+        return AllReduceExchange(eng, buckets=buckets)
     return ShardedExchange(eng, grad_dtype=grad_dtype)
 
 

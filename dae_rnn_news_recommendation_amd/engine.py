@@ -270,6 +270,15 @@ class Engine:
             self.adam_t += 1
         self._chk(self.lib.dae_plan_apply(self.plan, self.adam_t, float(grad_scale), L.current_stream()), "dae_plan_apply")
 
+    def begin_apply(self):
+        """Count one optimizer step (Adam's t) for a sequence of apply_band calls that together cover W."""
+        if self.opt == "adam":
+            self.adam_t += 1
+
+    def apply_band(self, f0, f1, grad_scale=1.0):
+        """Optimizer step on the rows [f0, f1) of W from the (all-reduced) flat gradient; the band ending at Fp also updates the biases."""
+        self._chk(self.lib.dae_plan_apply_band(self.plan, self.adam_t, float(grad_scale), int(f0), int(f1), L.current_stream()), "dae_plan_apply_band")
+
     def encode_rows(self, row_idx, out, *, scale=1.0, csr=None, dense=None):
         """out[B x H] (device fp32) = encode(scale * rows) -- transform() (autoencoder.py:479-505)."""
         csr = self.csr if (csr is None and dense is None) else csr

@@ -460,6 +460,9 @@ int      dae_plan_set_option(dae_plan* p, const char* name, int32_t value);
 int32_t  dae_storage_format(void);
 int      dae_train_step(dae_plan* p, const dae_step* step, void* stream);
 int      dae_plan_apply(dae_plan* p, int32_t adam_t, float grad_scale, void* stream);
+/* dae_plan_apply restricted to the rows [f0, f1) of W (multiples of 64; every low-precision image of those rows is rebuilt): the bucketed form of the
+ * data-parallel all-reduce applies band k while band k + 1 is still being reduced.  The band with f1 == Fp also updates the biases. */
+int      dae_plan_apply_band(dae_plan* p, int32_t adam_t, float grad_scale, int32_t f0, int32_t f1, void* stream);
 /* Data parallel with a SHARDED optimizer: after dae_train_step(phase = 1) the ranks reduce-scatter the W part of the flat gradient
  * by row chunks and all-reduce its (small) bias part; every rank then updates the rows [f0, f1) it owns from grad_rows (fp32
  * [f1-f0 x Hp], rank-summed) and -- update_bias != 0 -- the biases, all-gathers W_lo and rebuilds Wt_lo = W_lo^T locally

@@ -94,6 +94,19 @@ class FakeEngine:
         self.W_lo.copy_(self.W.to(self.td)); self.Wt_lo.copy_(self.W_lo.T)
         self.n_flat_seen = n + self.Hp + self.Fp
 
+    def begin_apply(self):                                                                # one optimizer step for a sequence of apply_band calls
+        self.bands_seen = []
+
+    def apply_band(self, f0, f1, grad_scale=1.0):                                         # dae_plan_apply_band: rows [f0, f1) of W (+ biases with the last band)
+        assert 0 <= f0 < f1 <= self.Fp and f0 % 64 == 0 and f1 % 64 == 0
+        n = self.Fp * self.Hp
+        self.W[f0:f1] -= LR * grad_scale * self.grad[:n].view(self.Fp, self.Hp)[f0:f1]
+        self.W_lo[f0:f1] = self.W[f0:f1].to(self.td); self.Wt_lo[:, f0:f1] = self.W_lo[f0:f1].T
+        if f1 == self.Fp:
+            b = self._bias_grads()
+            self.bh -= LR * grad_scale * b[:self.Hp]; self.bv -= LR * grad_scale * b[self.Hp:]
+        self.bands_seen.append((f0, f1))
+
     def sync_shadows(self):                                                               # dae_plan_sync_shadows
         self.W_lo.copy_(self.W.to(self.td)); self.Wt_lo.copy_(self.W_lo.T)
         self.shadow_syncs += 1
@@ -114,9 +127,13 @@ def _worker(rank, world, port, mode, Fp, Hp, out):
     eng = FakeEngine(Fp, Hp, world, td, x3=mode.startswith("x3"), grad_lo=(mode == "bf16_grad_image"))
     W0 = torch.from_numpy(np.random.default_rng(7).uniform(-0.3, 0.3, (Fp, Hp)).astype(np.float32))
     eng.W.copy_(W0); eng.sync_shadows()
-    if mode == "x3_allreduce":                 # what dp.make_exchange(kind='auto') picks for the split mode: ONE all-reduce, full optimizer step per rank
-        ex = dp.make_exchange(eng)
+    if mode.startswith("x3_allreduce"):        # what dp.make_exchange(kind='auto') picks for the split mode: all-reduce + full optimizer step per rank
+        ex = dp.make_exchange(eng, buckets=1 if mode == "x3_allreduce_1" else None)      # default: 4 buckets (row bands applied as they arrive)
         assert type(ex).__name__ == "AllReduceExchange" and type(dp.make_exchange(eng, kind="sharded")).__name__ == "ShardedExchange"
+        assert ex.buckets == (1 if mode == "x3_allreduce_1" else min(4, Fp // 64)) and ex.bounds[0] == 0 and ex.bounds[-1] == Fp
+        lo_eng = FakeEngine(Fp, Hp, world, td, x3=True, grad_lo=True)                    # a 16-bit exchange image would leave the flat gradient stale
+        with pytest.raises(ValueError, match="grad_lo"):
+            dp.AllReduceExchange(lo_eng)
     else:
         ex = dp.ShardedExchange(eng, grad_dtype="bf16" if mode.startswith("bf16_grad") else "fp32", packed=(mode != "three"))
         assert (ex.packed, ex.grad_dtype) == ((False, "fp32") if mode == "x3" else (mode != "three", ex.grad_dtype))
@@ -133,10 +150,10 @@ def _worker(rank, world, port, mode, Fp, Hp, out):
     ex.gather_master()
     dp.barrier()
     out[rank] = dict(W_lo=shadow.numpy(), Wt_lo=shadow_t.numpy(), own=(own[0], own[1], own[2].numpy()), W=eng.W.clone().numpy(),
-                     bh=eng.bh.numpy().copy(), bv=eng.bv.numpy().copy(), syncs=eng.shadow_syncs)
+                     bh=eng.bh.numpy().copy(), bv=eng.bv.numpy().copy(), syncs=eng.shadow_syncs, bands=getattr(eng, "bands_seen", None))
 
 
-@pytest.mark.parametrize("mode", ["packed", "fp32_shadow", "bf16_grad_image", "bf16_grad_cast", "three", "x3", "x3_allreduce"])
+@pytest.mark.parametrize("mode", ["packed", "fp32_shadow", "bf16_grad_image", "bf16_grad_cast", "three", "x3", "x3_allreduce", "x3_allreduce_1"])
 @pytest.mark.parametrize("world,Fp", [(2, 640), (3, 640), (3, 128)])       # 3 x 256 rows > 640: ragged last chunk; 3 x 64 > 128: EMPTY last chunk
 def test_sharded_exchange_equals_single_process(mode, world, Fp):
     Hp = 128
@@ -164,3 +181,21 @@ def test_sharded_exchange_equals_single_process(mode, world, Fp):
         assert np.abs(o["bh"] - b[:Hp]).max() <= 1e-5 and np.abs(o["bv"] - b[Hp:]).max() <= 1e-5
         assert np.array_equal(o["W_lo"], out[0]["W_lo"]) and np.array_equal(o["bh"], out[0]["bh"])   # every rank holds IDENTICAL shadows / biases
         assert o["syncs"] == (1 + 3 if mode == "x3" else 1)                                         # (the all-reduce form rebuilds the images inside dae_plan_apply)
+        if mode == "x3_allreduce":                                                                  # bucketed: the bands tile [0, Fp) in order
+            nb = min(4, Fp // 64)
+            assert len(o["bands"]) == nb and o["bands"][0][0] == 0 and o["bands"][-1][1] == Fp
+            assert all(o["bands"][i][1] == o["bands"][i + 1][0] for i in range(nb - 1))
+
+
+def test_bucketed_allreduce_is_bitwise_the_single_bucket_form():
+    """Two ranks: a sum of two floats does not depend on how the buffer is cut, so the bucketed exchange must reproduce the one-collective form bit
+    for bit -- master weights, both shadows and biases."""
+    Fp, Hp, world = 640, 128, 2
+    res = {}
+    for mode in ("x3_allreduce", "x3_allreduce_1"):
+        mgr = mp.Manager(); out = mgr.dict()
+        mp.spawn(_worker, args=(world, _free_port(), mode, Fp, Hp, out), nprocs=world, join=True)
+        res[mode] = {r: dict(out[r]) for r in range(world)}
+    for r in range(world):
+        for key in ("W", "W_lo", "Wt_lo", "bh", "bv"):
+            assert np.array_equal(res["x3_allreduce"][r][key], res["x3_allreduce_1"][r][key]), (r, key)

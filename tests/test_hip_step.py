@@ -735,3 +735,41 @@ def test_step_split_mode_dense_train_set_with_corrupted_csr_copy(dtype):
     print(dtype, "cost", st[0], r["cost"], "dW", _rel(dW, r["dW"]), "dbv", _rel(dbv, r["dbv"]))
     assert abs(st[0] - r["cost"]) <= 2e-5 * abs(r["cost"]), (st[0], r["cost"])
     assert _rel(dW, r["dW"]) < 1e-4 and _rel(dbv, r["dbv"]) < 1e-4, (_rel(dW, r["dW"]), _rel(dbv, r["dbv"]))
+
+
+@pytest.mark.parametrize("dtype,opt", [("f16x2", "adam"), ("bf16x3", "momentum"), ("bf16", "gradient_descent"), ("fp32", "ada_grad")])
+def test_apply_in_row_bands_equals_one_apply(dtype, opt):
+    """dae_plan_apply_band over bands that tile [0, Fp) (any order; the band ending at Fp carries the biases) == dae_plan_apply: master weights, biases,
+    optimizer slots and every 16-bit image, bit for bit -- what the bucketed data-parallel all-reduce relies on (dp.AllReduceExchange)."""
+    from dae_rnn_news_recommendation_amd import _lib as L
+    from dae_rnn_news_recommendation_amd.engine import Engine
+    rng = np.random.default_rng(41)
+    N, F, H, B = 300, 700, 90, 128
+    m = _mk(rng, N, F, True)
+    lab = rng.integers(0, 4, N)
+    W0 = rng.uniform(-0.3, 0.3, (F, H)).astype(np.float32)
+    idx = torch.from_numpy(rng.permutation(N)[:B].astype(np.int32)).cuda()
+    labs = torch.from_numpy(lab[idx.cpu().numpy()].astype(np.int32)).cuda()
+    res = []
+    for banded in (False, True):
+        eng = Engine(F, H, B, dtype=dtype, opt=opt, learning_rate=0.05, triplet="batch_all")
+        eng.upload_csr(m); eng.set_params(W0)
+        stats = torch.zeros(8, device="cuda")
+        for _ in range(2):
+            eng.train_step(idx, labs, stats, phase=1)
+            if banded:
+                eng.begin_apply()
+                for f0, f1 in ((256, 512), (0, 256), (512, eng.Fp)):
+                    eng.apply_band(f0, f1)
+            else:
+                eng.apply()
+        torch.cuda.synchronize()
+        imgs = [eng.W.clone(), eng.bh.clone(), eng.bv.clone(), eng.W_lo.clone().view(torch.int16 if eng.td != torch.float32 else torch.int32),
+                eng.Wt_lo.clone().view(torch.int16 if eng.td != torch.float32 else torch.int32)]
+        if eng.x3:
+            imgs.append(eng.buffer("Wt_lo2", (eng.Hp, eng.Fp), torch.int16).clone())
+        if eng.s1 is not None:
+            imgs.append(eng.s1.clone())
+        res.append(imgs)
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
