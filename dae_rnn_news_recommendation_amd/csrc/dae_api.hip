@@ -136,6 +136,8 @@ struct dae_plan {
     // divide out (dh_finish: 1 / op_scale; the dW epilogue: OptEpi::gin): fp16's normal range ends at 6.1e-5 and delta2 ~ (y - x) / B, Gs ~ 1e-6 sit
     // below it.  1 for bf16 storage and fp32.  Option "op_scale_log2".
     float op_scale;
+    int dec_bn;                      // tile width of the decode kernel: decode_tile_n(dtype), or 128 in the 16-bit modes when the 64-column tiles would be more than
+                                     // DEC_WIDE_ROUNDS rounds of the chip's 768 slots (option "decode_bn" = 64 | 128 | 0 auto; before dae_plan_bind)
     bool dw_pair_ok;                 // option "dw_pair": split-bf16 dW kernel streams x~^T resp. delta2^T_hi ONCE for the hi and lo image of delta1^T resp. h^T
     bool xct2_clean;
     uint32_t* xtb;                   // x~^T as a bit image [Fp x Bpm/32] (binary CSR + bf16: operand of the sparse half of the dW kernel)
@@ -144,6 +146,7 @@ struct dae_plan {
     bool enc_w32_ok;                 // option "encode_w32": bf16 mode encodes from the fp32 MASTER weights (h fp32-accurate); 0 = from W_lo
     int w32_cols;                    // option "encode_w32_cols": 128 (default) or 64 H columns per workgroup of that kernel
     bool gram_split;                 // Gram matrix as a 3-term split-bf16 MFMA GEMM (bf16 mode) instead of exact-fp32 MFMA
+    bool gram64_ok;                  // option "gram64" (default 1): the split Gram on 64 x 64 tiles over the whole K, ONE slab (gram64_kernel); 0: 128 x 128 tiles, split-K
     float *slabs, *h_f32, *D_slabs, *G, *rowloss_part, *dbv_part, *colsum_part, *cos_part, *cos_stats, *cw, *loss_part,
         *dw_f32, *tri_scalars, *dh_extra, *rowsq_scratch, *tile_part;
     uint32_t *cnt_part, *role_cnt, *xc_bits, *x_bits;
@@ -162,6 +165,17 @@ struct dae_plan {
 
 // lo image of the row-major shadow: exists (and is kept current by every kernel that updates W) only while the decode's (h, W_lo) term is on
 static void* plan_w_lo2(const dae_plan* p) { return (p->x3 && (p->terms & X3T_DEC_WLO)) ? (void*)p->W_lo2 : nullptr; }
+
+// tile width the decode launch of this plan uses (see dae_plan::dec_bn); lo images of delta2 / valued x keep the 64-column kernel
+static int plan_dec_bn(const dae_plan* p) {
+    const int def = decode_tile_n(p->cfg.dtype);
+    if (p->es != 2) return def;
+    const bool res = p->x3 && (p->terms & (X3T_DH_D2LO | X3T_DW_D2LO | X3T_XV));
+    if (res) return def;
+    if (p->dec_bn == 64 || p->dec_bn == 128) return p->dec_bn;
+    const int64_t tiles64 = (int64_t)(p->Bpm / 128) * (p->Fp / 64);
+    return tiles64 > 4 * 768 ? 128 : def;             // F = 50000: 5474 tiles of 128 x 64 = 7.1 rounds of 768 slots -> 2737 wide tiles
+}
 
 static int auto_splits(int tiles, int ktiles) {
     int s = 384 / (tiles > 0 ? tiles : 1);
@@ -227,7 +241,7 @@ static uint64_t carve(dae_plan* p, char* base) {
     p->G = (float*)take(Bp * Bp * 4);
     p->Gs = take(Bp * Bp * es);
     p->role_cnt = (uint32_t*)take(Bp * Bp * 4);        // pos_triplets_only role counts (probe builds: the miner's timeline stamps)
-    const uint64_t dbn = decode_tile_n(p->cfg.dtype);   // tile width of the decode kernel: lays out its partial-sum arrays
+    const uint64_t dbn = plan_dec_bn(p);                 // tile width of the decode kernel: lays out its partial-sum arrays
     p->rowloss_part = (float*)take((2 * Fp / dbn) * Bp * 4);
     p->dbv_part = (float*)take((2 * Bp / 128) * Fp * 4);
     p->colsum_part = (float*)take(2 * (Bp / 32) * Hp * 4);
@@ -292,6 +306,8 @@ extern "C" int dae_plan_create(const dae_config* cfg, dae_plan** out) {
     plan_x3_splits(p);
     if (p->s_gram > p->Hp * 4 / 128) p->s_gram = p->Hp * 4 / 128;
     p->gram_split = (cfg->dtype == DAE_BF16) && (p->x3 || cfg->triplet == DAE_TRIPLET_BATCH_ALL || cfg->triplet == DAE_TRIPLET_BATCH_HARD);   // x3: hcat_a also holds the row-major h_lo
+    p->gram64_ok = p->gram_split && cfg->gram_splits <= 0;        // (an explicit split count keeps the 128 x 128 split-K form)
+    if (p->gram64_ok) p->s_gram = 1;
     p->ws_bytes = carve(p, nullptr);
     // code-path choices below are plan state (dae_plan_set_option), never read from the environment
     p->fuse_opt_ok = true;
@@ -354,15 +370,35 @@ extern "C" int dae_plan_set_option(dae_plan* p, const char* name, int32_t value)
         plan_x3_splits(p);
         p->ws_bytes = carve(p, nullptr);
     }
+    else if (!strcmp(name, "decode_bn")) {
+        DAE_CHECK_ARG(!p->bound, "plan_set_option: decode_bn changes the workspace layout, set it before dae_plan_bind");
+        DAE_CHECK_ARG(value == 0 || value == 64 || value == 128, "plan_set_option: decode_bn is 0 (auto), 64 or 128");
+        p->dec_bn = value;
+        p->ws_bytes = carve(p, nullptr);
+    }
     else if (!strcmp(name, "op_scale_log2")) {
         DAE_CHECK_ARG(value >= 0 && value <= 20, "plan_set_option: op_scale_log2 in 0..20");
         DAE_CHECK_ARG(p->es == 2, "plan_set_option: op_scale_log2 applies to the 16-bit modes");
         p->op_scale = (float)(1u << value);
     }
+    else if (!strcmp(name, "gram64")) {
+        DAE_CHECK_ARG(!p->bound, "plan_set_option: gram64 changes the workspace layout (slab count), set it before dae_plan_bind");
+        p->gram64_ok = on && p->gram_split;
+        const int tiles_bb = (p->Bpm / 128) * (p->Bpm / 128);
+        p->s_gram = p->gram64_ok ? 1 : (p->cfg.gram_splits > 0 ? p->cfg.gram_splits : auto_splits(tiles_bb, p->Hp * 4 / 128));
+        if (p->s_gram > p->Hp * 4 / 128) p->s_gram = p->Hp * 4 / 128;
+        p->ws_bytes = carve(p, nullptr);
+    }
     else if (!strcmp(name, "gram_fp32")) {
         DAE_CHECK_ARG(!p->bound, "plan_set_option: gram_fp32 changes the workspace layout, set it before dae_plan_bind");
         DAE_CHECK_ARG(!p->x3, "plan_set_option: gram_fp32 is not available in split-bf16 mode (its Gram operands double as the row-major h images)");
         p->gram_split = !on && p->cfg.dtype == DAE_BF16 && (p->cfg.triplet == DAE_TRIPLET_BATCH_ALL || p->cfg.triplet == DAE_TRIPLET_BATCH_HARD);
+        if (!p->gram_split && p->gram64_ok) {          // the exact-fp32 Gram runs on the 128 x 128 split-K kernel: its slab count again
+            p->gram64_ok = false;
+            const int tiles_bb = (p->Bpm / 128) * (p->Bpm / 128);
+            p->s_gram = p->cfg.gram_splits > 0 ? p->cfg.gram_splits : auto_splits(tiles_bb, p->Hp * 4 / 128);
+            if (p->s_gram > p->Hp * 4 / 128) p->s_gram = p->Hp * 4 / 128;
+        }
         p->ws_bytes = carve(p, nullptr);
     } else {
         set_error("plan_set_option: unknown option '%s'", name);
@@ -467,6 +503,7 @@ static float plan_lr(const dae_plan* p, int adam_t) {
     return lr;
 }
 static int launch_gram(dae_plan* p, int Bp, int Hp, int64_t dslab, hipStream_t st) {
+    if (p->gram_split && p->gram64_ok && p->s_gram == 1) return launch_gram64(p->hcat_a, p->hcat_b, Bp, Hp, p->D_slabs, st);
     if (p->gram_split)
         return launch_gemm_f32out(DAE_BF16, Bp, Bp, p->hcat_a, 3 * Hp, p->hcat_b, 3 * Hp, 3 * Hp, nullptr, 0, nullptr, 0, 0, p->D_slabs, Bp,
                                   p->s_gram, dslab, st, GEMM_ROLE_GRAM);
@@ -656,7 +693,7 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     bool forked = false, sym_ride = false;
     const bool fold_finalize = (c.triplet == DAE_TRIPLET_BATCH_ALL && !c.pos_triplets_only) && !ext_mine;
     // 7. decode + reconstruction loss + d cost/d z2   (K3/K4) -- on stream `ds`; `ride`: the launch also scales G + G^T (sym_scale)
-    const int dbn = decode_tile_n(dt);
+    const int dbn = plan_dec_bn(p);
     const int ncw = 2 * Fp / dbn;
     auto decode_section = [&](hipStream_t ds, bool ride) -> int {
         DecodeEpi e;
@@ -666,7 +703,7 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
         e.dbv_part = backward ? p->dbv_part : nullptr; e.cos_part = p->cos_part;
         e.delta2 = backward ? p->delta2 : nullptr; e.ldd = Fp; e.delta2_t = backward ? p->delta2_t : nullptr; e.lddt = ldB;
         e.B = B; e.F = F; e.Bp = Bp; e.Fp = Fp; e.dec_act = c.dec_act; e.loss_func = c.loss_func; e.ce_literal = p->ce_literal ? 1 : 0;
-        e.op_scale = osc;
+        e.op_scale = osc; e.bn = dbn;
         if (ride) { e.sym_G = p->G; e.sym_scalars = p->tri_scalars; e.sym_Gs = p->Gs; e.sym_B = B; e.sym_Bp = Bp; }
         // z2 = h W^T: one K segment, or -- split-bf16 -- (h_hi, W_hi) (h_hi, W_lo) (h_lo, W_hi); the row-major h_hi / h_lo are the first and
         // third block of the Gram operand hcat_a = [hi | hi | lo] (leading dimension 3 Hp)

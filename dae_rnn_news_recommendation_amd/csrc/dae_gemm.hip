@@ -1445,6 +1445,122 @@ __device__ __forceinline__ void mainloop_n64(const GemmParams& p, int tm, int tn
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Gram matrix D = h h^T of the 16-bit modes (split operands [hi | hi | lo] . [hi | lo | hi]^T, K = 3 Hp) on 64 x 64 tiles, ONE slab.
+// The 128 x 128 / split-K-4 form (gemm_nt_pc<GRAM>) is pure latency at this size -- 196 workgroups of 6 K tiles each, 4 slabs of 3.2 MB written
+// and read back by the miner's prologue (12.5 MB + 10.6 MB per step, 13 us).  Here a workgroup owns a 64 x 64 tile of D over the WHOLE K (24 K
+// tiles at H = 500): 196 workgroups = one per CU, four waves of one 32 x 32 accumulator each, an 8-stage LDS ring (16 KiB per stage) filled by
+// LDS-DMA so that seven stages are in flight while one is multiplied -- the K loop never waits for memory after the first stage -- and D leaves
+// once, as the sum the miner wants.  Tile map: XCD x = b % 8 takes a contiguous run of tiles (same row tile = same A panel in its L2).
+// ------------------------------------------------------------------------------------------------
+constexpr int G64_NST = 8;
+constexpr int G64_TILE = 64 * BKB;                 // 8 KiB per operand per stage
+constexpr int G64_STAGE = 2 * G64_TILE;
+constexpr int G64_LDS = G64_NST * G64_STAGE;       // 128 KiB: one workgroup per CU
+__device__ __forceinline__ void wait_vm_4n(int n) {   // vmcnt(4 n): n younger stages of 4 LDS-DMA pieces each may stay in flight
+    switch (n) {
+        case 0: wait_vm<0>(); break;
+        case 1: wait_vm<4>(); break;
+        case 2: wait_vm<8>(); break;
+        case 3: wait_vm<12>(); break;
+        case 4: wait_vm<16>(); break;
+        case 5: wait_vm<20>(); break;
+        case 6: wait_vm<24>(); break;
+        default: wait_vm<28>(); break;
+    }
+}
+__global__ __launch_bounds__(GEMM_THREADS, 1) void gram64_kernel(const char* __restrict__ A, int64_t lda_b, const char* __restrict__ Bt, int64_t ldb_b,
+                                                                 int nk, int tiles, float* __restrict__ D, int64_t ldd) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int b = blockIdx.x, per = (tiles * tiles + 7) >> 3;
+    const int t = (b & 7) * per + (b >> 3);
+    if ((b >> 3) >= per || t >= tiles * tiles) return;
+    const int tm = t / tiles, tn = t % tiles;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    // LDS-DMA: this wave's pieces {wave, wave + 4} of each operand tile (8 rows of 128 B per 1-KiB piece), swizzled source slot per lane
+    uint32_t voA[2], voB[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (i * 4 + wave) * 8 + (lane >> 3);
+        const uint32_t ss = (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) << 4);
+        voA[i] = (uint32_t)(tm * 64 + row) * (uint32_t)lda_b + ss;
+        voB[i] = (uint32_t)(tn * 64 + row) * (uint32_t)ldb_b + ss;
+    }
+    const char *gA = A, *gB = Bt;
+    auto dma_stage = [&](char* slot) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gA + voA[i]),
+                                             (__attribute__((address_space(3))) void*)(slot + (i * 4 + wave) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gB + voB[i]),
+                                             (__attribute__((address_space(3))) void*)(slot + G64_TILE + (i * 4 + wave) * 1024), 16, 0, 0);
+        }
+        gA += BKB; gB += BKB;
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int r = lane & 31, g = lane >> 5;
+    const int swz = (r >> 1) & 7;
+    const uint32_t lbase = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)lds;
+    const uint32_t offa = (wm * 32 + r) * BKB, offb = G64_TILE + (wn * 32 + r) * BKB;
+    uint32_t so[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) so[kk] = (uint32_t)(((kk * 2 + g) ^ swz) << 4);
+#pragma unroll
+    for (int st = 0; st < G64_NST; ++st)
+        if (st < nk) dma_stage(lds + st * G64_STAGE);
+    // ONE barrier per K tile: passing the barrier of iteration i proves that every wave has finished iteration i - 1 (its fragment reads included), so
+    // the slot of stage i - 1 is refilled right behind it (stage i - 1 + NST) -- issued between this tile's fragment reads and its MFMAs, where the
+    // ~50-cycle issue cost of each LDS-DMA piece hides the LDS latency of the reads
+    int cur = 0, prev = G64_NST - 1;
+    for (int i = 0; i < nk; ++i) {
+        const int issued = i == 0 ? min(nk, G64_NST) : min(nk, i - 1 + G64_NST);      // stages requested so far
+        wait_vm_4n(issued - (i + 1));                      // everything up to stage i has landed (this wave's pieces)
+        __builtin_amdgcn_s_barrier();                      // ... and every other wave's; slot `prev` is free
+        asm volatile("" ::: "memory");
+        const uint32_t sb = lbase + cur * G64_STAGE;
+        i32x4 fa[4], fb[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            fa[kk] = lds_read_b128(sb + offa + so[kk]);
+            fb[kk] = lds_read_b128(sb + offb + so[kk]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (i >= 1 && i - 1 + G64_NST < nk) dma_stage(lds + prev * G64_STAGE);
+        __builtin_amdgcn_sched_barrier(0);
+#define DAE_G64_STEP(KK, CNT)                                    \
+    asm volatile("s_waitcnt lgkmcnt(" #CNT ")" ::: "memory");    \
+    __builtin_amdgcn_sched_barrier(0);                           \
+    Mma<bf16_t>::run(fa[KK], fb[KK], acc);
+        DAE_G64_STEP(0, 6)
+        DAE_G64_STEP(1, 4)
+        DAE_G64_STEP(2, 2)
+        DAE_G64_STEP(3, 0)
+#undef DAE_G64_STEP
+        __builtin_amdgcn_sched_barrier(0);
+        prev = cur;
+        cur = cur + 1 == G64_NST ? 0 : cur + 1;
+    }
+    float* Dt = D + (int64_t)(tm * 64 + wm * 32) * ldd + tn * 64 + wn * 32 + r;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) Dt[(int64_t)((q & 3) + 8 * (q >> 2) + 4 * g) * ldd] = acc[q];
+}
+
+int launch_gram64(const void* hcat_a, const void* hcat_b, int Bp, int Hp, float* D, hipStream_t st) {
+    DAE_CHECK_ARG(hcat_a && hcat_b && D && Bp % 64 == 0 && Hp % 64 == 0, "gram64: bad arguments");
+    DAE_CHECK_ARG((uint64_t)Bp * (uint64_t)(3 * Hp * 2) < (1ull << 32), "gram64: operand panel beyond 4 GiB");
+    static int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(gram64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G64_LDS);
+    DAE_CHECK_ARG(rc == 0, "gram64: hipFuncSetAttribute failed");
+    const int tiles = Bp / 64, per = (tiles * tiles + 7) / 8;
+    hipLaunchKernelGGL(gram64_kernel, dim3(8 * per), dim3(GEMM_THREADS), G64_LDS, st, (const char*)hcat_a, (int64_t)3 * Hp * 2, (const char*)hcat_b,
+                       (int64_t)3 * Hp * 2, 3 * Hp * 2 / BKB, tiles, D, (int64_t)Bp);
+    DAE_CHECK_LAUNCH();
+    return 0;
+}
+
 constexpr float CE_FAST_ZMAX = 14.0f;               // sigmoid(14) = 1 - 8.3e-7: five fp32 ulps from saturation
 constexpr int DECODE_NST = 2;
 template <typename T, int LOSS, int ACT, bool XBITS = false, int BN_T = 128, bool RES = false>   // RES (split-bf16 mode): also the lo images of delta2 / delta2^T
@@ -1899,6 +2015,17 @@ static decode_fn decode_kernel_res(int loss, int act, bool xbits) {
 #undef DAE_DKR
     return nullptr;
 }
+// 128-column tiles for the 16-bit modes (DecodeEpi::bn = 128): half the LDS-DMA instructions per MFMA of the 64-column tile (A 16 KiB + B 16 KiB per 16 MFMAs
+// of a wave instead of A 16 KiB + B 8 KiB per 8) at two workgroups per CU -- pays when the tile count is several rounds of the chip (F = 50000) or the K
+// loop is long (the split modes' extra product terms); the lo images of delta2 (RES) exist for the 64-column form only
+static decode_fn decode_kernel_wide(int loss, int act, bool xbits) {
+#define DAE_DKW(LV, AV)                                                                                       \
+    if (loss == LV && act == AV)                                                                              \
+        return xbits ? gemm_decode_loss<bf16_t, LV, AV, true, BN> : gemm_decode_loss<bf16_t, LV, AV, false, BN>;
+    DAE_DKW(0, 0) DAE_DKW(0, 1) DAE_DKW(0, 2) DAE_DKW(1, 0) DAE_DKW(1, 1) DAE_DKW(1, 2) DAE_DKW(2, 0) DAE_DKW(2, 1) DAE_DKW(2, 2)
+#undef DAE_DKW
+    return nullptr;
+}
 template <typename T> static decode_fn decode_kernel(int loss, int act) {
 #define DAE_DK(LV, AV) if (loss == LV && act == AV) return gemm_decode_loss<T, LV, AV, false, (sizeof(T) == 2 ? DECODE_BN_BF16 : BN)>;
     DAE_DK(0, 0) DAE_DK(0, 1) DAE_DK(0, 2) DAE_DK(1, 0) DAE_DK(1, 1) DAE_DK(1, 2) DAE_DK(2, 0) DAE_DK(2, 1) DAE_DK(2, 2)
@@ -2174,7 +2301,9 @@ int launch_decode_loss(int dtype, int Bp, int Fp, int Hp, const void* h_lo, int6
 int launch_decode_loss_n(int dtype, int Bp, int Fp, const GemmSegDesc* segs, int nsegs, const DecodeEpi& e_in, hipStream_t st) {
     DecodeEpi e = e_in;
     GemmParams p;
-    const int bn = decode_tile_n(dtype);
+    const bool wide = dtype == DAE_BF16 && e.bn == BN && !(e.delta2_2 || e.delta2_t2 || e.x2);
+    DAE_CHECK_ARG(e.bn == 0 || e.bn == decode_tile_n(dtype) || wide, "decode_loss: tile width %d is not available for this mode (lo images of delta2 / x need the 64-column tile)", e.bn);
+    const int bn = wide ? BN : decode_tile_n(dtype);
     if (int rc = fill_params_n(p, dtype, Bp, Fp, segs, nsegs, 1, bn)) return rc;
     if (int rc = gemm_init()) return rc;
     DAE_CHECK_ARG(e.dec_act >= 0 && e.dec_act <= 2 && e.loss_func >= 0 && e.loss_func <= 2, "decode_loss: bad act/loss");
@@ -2186,6 +2315,19 @@ int launch_decode_loss_n(int dtype, int Bp, int Fp, const GemmSegDesc* segs, int
         k = decode_kernel_xbits(e.loss_func, e.dec_act);
     }
     if (e.op_scale == 0.f) e.op_scale = 1.f;
+    if (wide) {
+        k = decode_kernel_wide(e.loss_func, e.dec_act, e.x_bits != nullptr);
+        static int wide_rc = [] {
+            int rc = 0;
+            for (int l = 0; l < 3; ++l)
+                for (int a = 0; a < 3; ++a)
+                    for (int x = 0; x < 2; ++x)
+                        rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(decode_kernel_wide(l, a, x != 0)),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, DecGeo<BN>::LDS_BYTES);
+            return rc;
+        }();
+        DAE_CHECK_ARG(wide_rc == 0, "decode_loss: hipFuncSetAttribute failed");
+    }
     if (e.delta2_2 || e.delta2_t2 || e.x2) {
         DAE_CHECK_ARG(dtype == DAE_BF16, "decode_loss: lo images of delta2 / x exist in the 16-bit split mode only");
         k = decode_kernel_res(e.loss_func, e.dec_act, e.x_bits != nullptr);
@@ -2208,7 +2350,7 @@ int launch_decode_loss_n(int dtype, int Bp, int Fp, const GemmSegDesc* segs, int
     }
     dim3 grid(nblocks), block(GEMM_THREADS);
     static_assert(DecGeo<DECODE_BN_BF16>::LDS_BYTES >= 64 * 65 * 4 && DecGeo<BN>::LDS_BYTES >= 64 * 65 * 4, "rider tile must fit the decode LDS");
-    hipLaunchKernelGGL(k, grid, block, dtype == DAE_BF16 ? DecGeo<DECODE_BN_BF16>::LDS_BYTES : DecGeo<BN>::LDS_BYTES, st, p, e);
+    hipLaunchKernelGGL(k, grid, block, (dtype == DAE_BF16 && !wide) ? DecGeo<DECODE_BN_BF16>::LDS_BYTES : DecGeo<BN>::LDS_BYTES, st, p, e);
     DAE_CHECK_LAUNCH();
     return 0;
 }

@@ -31,6 +31,8 @@ struct DecodeEpi {
     // 16-bit modes: delta2 / delta2^T (and the rider's Gs) are stored times this power of two (1 unless the storage format is fp16: dae_api.hip op_scale);
     // the loss, the bias-gradient partials and everything fp32 stay unscaled
     float op_scale;
+    int bn;                   // tile width (columns of y per workgroup): 0 = the mode's default (decode_tile_n), 128 = the wide 16-bit kernel; the partial-sum arrays
+                              // (rowloss_part / cos_part: 2 * Fp / bn rows; tile_part: (Bp / 128) * (Fp / bn)) are laid out by it
 };
 
 // lo product terms of the split 16-bit mode (dae_config.dtype = DAE_BF16X3; plan option "x3_terms"): each bit keeps one (hi, lo) / (lo, hi) product of one
@@ -74,6 +76,8 @@ int launch_decode_loss_n(int dtype, int Bp, int Fp, const GemmSegDesc* segs, int
 // tile width (columns of y per workgroup) of the decode kernel for `dtype`: the partial-sum arrays it writes
 // (rowloss_part / cos_part: 2 * Fp / width rows; tile_part: (Bp/128) * (Fp/width) entries) are laid out by it
 int decode_tile_n(int dtype);
+// D = hcat_a . hcat_b^T (the split 16-bit Gram operands, K = 3 Hp) on 64 x 64 tiles, one slab [Bp x Bp] (dae_gemm.hip: gram64_kernel)
+int launch_gram64(const void* hcat_a, const void* hcat_b, int Bp, int Hp, float* D, hipStream_t st);
 // label statistics job (dae_label.h): either its own launch or an extra block of the CSR gather kernel
 struct LabelJob {
     const int32_t* labels; int B, Bp, triplet; int64_t* nvalid; int64_t* dw; float* cw; float alpha; float* tri_scalars;

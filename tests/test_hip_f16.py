@@ -137,3 +137,37 @@ def test_step_f16x2_op_scale_is_transparent():
     for (_, sa, dWa, *_), (_, sb, dWb, *_) in zip(a, b):
         assert np.allclose(sa[:3], sb[:3], rtol=2e-5, atol=0)
         assert _rel(dWb, np.asarray(dWa, np.float64)) < 1e-3
+
+
+@pytest.mark.parametrize("dtype,loss_func,acts", [("f16x2", "cross_entropy", ("sigmoid", "sigmoid")), ("bf16", "cosine_proximity", ("sigmoid", "sigmoid")),
+                                                  ("f16", "mean_squared", ("tanh", "none"))])
+def test_step_wide_decode_tile_equals_narrow(dtype, loss_func, acts):
+    """Plan option decode_bn = 128 (the 128 x 128 decode tile the plan picks by itself for F = 50000) against the default 128 x 64 tile: every logit is
+    the same K-ordered MFMA sum, so delta2, the gradients and the parameters agree to the last bit; only the loss partial sums are added in another order."""
+    kw = dict(steps=2, seed=17, N=400, F=900, H=90, B=150)
+    a, _, pa = _run_case(dtype, "batch_all", loss_func, acts, "gradient_descent", options={"decode_bn": 64}, **kw)
+    b, _, pb = _run_case(dtype, "batch_all", loss_func, acts, "gradient_descent", options={"decode_bn": 128}, **kw)
+    for (_, sa, dWa, dbha, dbva), (_, sb, dWb, dbhb, dbvb) in zip(a, b):
+        assert np.allclose(sa[:3], sb[:3], rtol=2e-6, atol=0), (sa, sb)
+        if loss_func == "cosine_proximity":      # its row statistics (sum y^2, sum xhat.y) are partial sums over the tiles: another order, last-bit differences in delta2
+            assert _rel(dWa, np.asarray(dWb, np.float64)) < 5e-4 and _rel(dbha, np.asarray(dbhb, np.float64)) < 5e-4      # (a flipped bf16 rounding of delta2 = 2^-9 of one element)
+        else:
+            assert np.array_equal(dWa, dWb) and np.array_equal(dbha, dbhb)
+        assert np.allclose(dbva, dbvb, rtol=1e-5, atol=1e-9)
+    for u, v in zip(pa[:2], pb[:2]):
+        assert np.array_equal(u, v) if loss_func != "cosine_proximity" else _rel(u, np.asarray(v, np.float64)) < 5e-4
+
+
+@pytest.mark.parametrize("dtype,strategy,B", [("f16x2", "batch_all", 150), ("bf16", "batch_hard", 150), ("bf16x3", "batch_all", 300)])
+def test_gram_on_64x64_tiles_single_slab_equals_split_k_form(dtype, strategy, B):
+    """The split 16-bit Gram matrix on 64 x 64 tiles over the whole K (gram64_kernel: ONE slab, the default) against the 128 x 128 split-K form whose
+    slabs the miner's prologue sums (option gram64 = 0): the same products, summed in another order -- losses and gradients agree to fp32 rounding."""
+    kw = dict(steps=2, seed=23, N=600, F=700, H=90, B=B)
+    a, _, pa = _run_case(dtype, strategy, "cross_entropy", ("sigmoid", "sigmoid"), "gradient_descent", options={"gram64": 1}, **kw)
+    b, _, pb = _run_case(dtype, strategy, "cross_entropy", ("sigmoid", "sigmoid"), "gradient_descent", options={"gram64": 0}, **kw)
+    for (ra, sa, dWa, *_), (_, sb, dWb, *_) in zip(a, b):
+        assert np.allclose(sa[:3], sb[:3], rtol=5e-6, atol=0), (sa, sb)
+        if strategy == "batch_all":
+            assert abs(sa[4] - sb[4]) <= 2 and sa[5] == sb[5]            # positive-triplet count (near-ties), N_valid
+            assert abs(sa[2] - ra["triplet_loss"]) <= 1e-4 * abs(ra["triplet_loss"])
+            assert _rel(dWa, np.asarray(dWb, np.float64)) < 2e-5

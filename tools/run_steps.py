@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """N plain training steps (no event profiling) -- the workload run under rocprofv3 --pmc.
 usage: python tools/run_steps.py [steps] [strategy] [c2|c4] [precision]   (c2: BASELINE configs[1] CSR step; c4: dense fp32 tf-idf, F = 50000;
-precision: bf16x3 (default = what precision='auto' resolves to, the bench headline) | bf16 | fp32)"""
+precision: default = what precision='auto' resolves to, the bench headline) | bf16 | fp32)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -11,7 +11,7 @@ from dae_rnn_news_recommendation_amd.synthetic import synthetic_csr, synthetic_l
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 strategy = sys.argv[2] if len(sys.argv) > 2 else "batch_all"
 cfg = sys.argv[3] if len(sys.argv) > 3 else "c2"
-precision = sys.argv[4] if len(sys.argv) > 4 else "bf16x3"
+precision = sys.argv[4] if len(sys.argv) > 4 else L.AUTO_PRECISION
 F, H = (10000, 500) if cfg == "c2" else (50000, 1000)
 m = synthetic_csr(1600, F, nnz_per_row=200 if cfg == "c2" else 300, seed=1, tfidf=(cfg != "c2")); lab = synthetic_labels(1600, seed=1).astype(np.int32)
 eng = Engine(F, H, 800, dtype=precision, triplet=strategy, learning_rate=0.1)
