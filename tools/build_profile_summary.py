@@ -13,15 +13,15 @@ TRAFFIC_ONLY = "--traffic-only" in sys.argv
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 dst = os.path.join(root, "profiles")
 # step slot (bench.py `kernels` key) -> kernel symbol prefix in the rocprofv3 tables
-SLOT_KERNEL = [("encode_gemm", "encode_csr_kernel"), ("gram", "gemm_nt_pc<unsigned short, 4, 4>"), ("miner", "batch_all_tile_kernel"),
+SLOT_KERNEL = [("encode_gemm", "encode_csr_kernel"), ("gram", "gram64_kernel"), ("miner", "batch_all_tile_kernel"),
                ("sym_scale", "sym_scale_kernel"), ("decode_loss", "gemm_decode_loss<unsigned short"), ("dh_gemm", "gemm_nt_pc<unsigned short, 4, 2>"),
                ("dh_finish", "dh_finish_kernel<unsigned short"), ("dw_gemm", "gemm_dw_pc"), ("bias_grads", "step_tail_kernel")]
 SLOT_KERNEL_C4 = [("gather", "gather_dense_kernel"), ("encode_gemm", "gemm_nt_w8<1>"), ("encode_finish", "encode_finish_kernel"),
                   ("decode_loss", "gemm_decode_loss"), ("dh_gemm", "gemm_nt_w8<2>"), ("dw_gemm", "gemm_dw")]
 NOTE = {"encode_gemm": "corrupt + gather + sparse x~.W (fp32 master W) + bias + act, all images of h, x bit image, x~^T scatter, label statistics",
-        "gram": "split-bf16 (3 products), split-K 4", "miner": "batch_all on a 16 x 16 lane grid (FAST pair sweep), positive-triplet count from sorted runs", "sym_scale": "Gs = a/Nv (G + G^T) -> bf16",
-        "decode_loss": "128 x 64 tiles: GEMM + loss + delta2 (two layouts; split mode: 3 K segments, hi + lo images), x from bits", "dh_gemm": "delta2.W + Gs.h, split-K 8 (split mode: 5 K segments)",
-        "dh_finish": "slab reduction, act', delta1^T, column sums", "dw_gemm": "160 x 128 tiles: dW GEMM + SGD update of W and both bf16 shadows (split mode: paired stages, hi + lo shadows)",
+        "gram": "split 16-bit Gram (3 products) on 64 x 64 tiles over the whole K, one slab", "miner": "batch_all on a 16 x 16 lane grid (FAST pair sweep), positive-triplet count from sorted runs", "sym_scale": "Gs = a/Nv (G + G^T) -> bf16",
+        "decode_loss": "128 x 64 tiles: GEMM (f16x2: h.W_hi + h.W_lo) + loss + delta2 (two layouts), x from bits", "dh_gemm": "delta2.W_hi + delta2.W_lo + Gs.h, split-K 8",
+        "dh_finish": "slab reduction, act', delta1^T, column sums", "dw_gemm": "160 x 128 tiles: dW GEMM (two K segments) + SGD update of W and the hi + lo images of both 16-bit shadows",
         "bias_grads": "step tail: bias grads + update, statistics, x~^T un-scatter"}
 
 
@@ -114,12 +114,14 @@ if cb and cb.get("value"):
     L.append(f"| CPU baseline: PyTorch-CPU fp32 restatement, literal B^3 batch_all, {cb['cores']} threads | {cb['value']:.1f} samples/s |")
     if cb.get("chunked"): L.append(f"| CPU baseline, chunked (memory-lean) form | {cb['chunked']['samples_per_s']:.1f} samples/s |")
 fl = b["final_losses"]
-if b.get("bf16x3") and b["bf16x3"].get("value"):
-    L.append(f"| `precision='bf16x3'` (split-bf16: holds the 1e-4 curve gate on all 20 steps), same K steps | {b['bf16x3']['value']:,.0f} ({1e3 * b['bf16x3']['ms_per_step']:.1f} us/step) |")
+for mode, what in (("f16x2", "fp16 images, W hi + lo: inside the 1e-4 curve gate"), ("bf16x3", "split-bf16, three terms: inside the gate"),
+                   ("fp32", "exact-fp32 MFMA: inside the gate"), ("bf16", "plain bf16: OUTSIDE the gate")):
+    if b.get(mode) and b[mode].get("value"):
+        L.append(f"| `precision='{mode}'` ({what}), same K steps | {b[mode]['value']:,.0f} ({1e3 * b[mode]['ms_per_step']:.1f} us/step) |")
 L.append(f"| final losses (means over the last epoch's batches) | cost {fl['cost']:.2f}, AE {fl['autoencoder']:.2f}, triplet {fl['triplet']:.4f}, fraction {fl['fraction']:.4f} |")
 r = b.get("roofline")
 if r:
-    both = f" (byte floor binds: {100 * r['hbm_frac']:.1f} % of HBM peak by minimum bytes, {100 * r['mfma_frac']:.1f} % of the MFMA peak by dense FLOPs)" if "mfma_frac" in r else ""
+    both = f" (SURVEY 8(d)-strict accounting; {100 * r['frac_min_bytes']:.1f} % of HBM peak by this data flow's minimum bytes, {100 * r['mfma_frac']:.1f} % of the MFMA peak by dense FLOPs)" if "mfma_frac" in r else ""
     L.append(f"| `roofline` ({r['kernel'].split(' (')[0]}) | {r['achieved']:.0f} {r['unit']} = **{100 * r['frac']:.1f} %** of {r['peak']:.0f}{both}; traffic {r['traffic']} B ({r.get('traffic_source')}) |")
 sr = b.get("step_roofline")
 if sr: L.append(f"| whole step | {100 * sr['mfma_frac_dense_accounting']:.1f} % of bf16 MFMA peak by dense accounting (10.B.F.H), {100 * sr['hbm_frac_min_bytes']:.1f} % of HBM peak by minimum bytes |")

@@ -9,7 +9,7 @@ import numpy as np, torch, torch.distributed as dist
 from dae_rnn_news_recommendation_amd import _lib as L, dp
 from dae_rnn_news_recommendation_amd.engine import Engine
 from dae_rnn_news_recommendation_amd.synthetic import synthetic_csr, synthetic_labels, xavier_uniform
-ap = argparse.ArgumentParser(); ap.add_argument("--grad-dtype", default="fp32"); ap.add_argument("--precision", default="bf16"); a = ap.parse_args()
+ap = argparse.ArgumentParser(); ap.add_argument("--grad-dtype", default="fp32"); ap.add_argument("--precision", default=L.AUTO_PRECISION); a = ap.parse_args()
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29534")
 torch.cuda.set_device(0); dist.init_process_group("nccl", rank=0, world_size=1); dp.quiet_first_collective()
 F, H, B = 10000, 500, 800
@@ -28,9 +28,10 @@ def timed(fn, n=50):
     return 1e3 * e0.elapsed_time(e1) / n, host
 Hp, c = eng.Hp, eng.chunk_rows
 gw = eng.grad[:ex.n_w]; bias = eng.grad[eng.Fp * Hp:eng.Fp * Hp + Hp + eng.Fp]
-if a.precision == "bf16x3":          # the split mode has ONE exchange form (three collectives, fp32 everywhere)
+if eng.x3:          # the split modes (f16x2 = the product default, bf16x3): fp32 gradients in, fp32-accurate weights out
     my_w = torch.zeros((c, Hp), dtype=torch.float32, device="cuda")
-    exa = dp.AllReduceExchange(eng)
+    exa = dp.AllReduceExchange(eng, buckets=1)
+    exb = dp.AllReduceExchange(eng, buckets=4)       # what N > 1 ranks run: 4 row bands, band k applied while band k + 1 is on the wire
     def step_and3(after_dw):
         eng.train_step(idx, labs, stats, phase=1, **kw); ex.step(grad_scale=1.0, grad_ready_after_dw=after_dw)
     rows = [("fused single-GPU step (phase 3)", lambda: eng.train_step(idx, labs, stats, phase=3, **kw)),
@@ -45,9 +46,12 @@ if a.precision == "bf16x3":          # the split mode has ONE exchange form (thr
             ("phase-1 step + sharded exchange", lambda: step_and3(False)),
             ("all_reduce of the flat fp32 gradient", lambda: dist.all_reduce(exa.flat)),
             ("dae_plan_apply (whole W + 4 images)", lambda: eng.apply(grad_scale=1.0)),
-            ("whole AllReduceExchange.step (default)", lambda: exa.step(grad_scale=1.0)),
-            ("phase-1 step + all-reduce exchange", lambda: (eng.train_step(idx, labs, stats, phase=1, **kw), exa.step(grad_scale=1.0)))]
-    print(f"precision bf16x3  {'piece':40s} {'GPU us':>9s} {'host us/call':>13s}")
+            ("whole AllReduceExchange.step, 1 bucket", lambda: exa.step(grad_scale=1.0)),
+            ("phase-1 step + all-reduce exchange (1)", lambda: (eng.train_step(idx, labs, stats, phase=1, **kw), exa.step(grad_scale=1.0))),
+            ("apply in 4 row bands (dae_plan_apply_band)", lambda: (eng.begin_apply(), [eng.apply_band(exb.bounds[k], exb.bounds[k + 1]) for k in range(4)])),
+            ("whole AllReduceExchange.step, 4 buckets", lambda: exb.step(grad_scale=1.0)),
+            ("phase-1 step + bucketed exchange (default)", lambda: (eng.train_step(idx, labs, stats, phase=1, **kw), exb.step(grad_scale=1.0)))]
+    print(f"precision {a.precision}  {'piece':40s} {'GPU us':>9s} {'host us/call':>13s}")
     for name, fn in rows:
         g, h = timed(fn)
         print(f"{name:40s} {g:9.1f} {h:13.1f}")
