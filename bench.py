@@ -93,6 +93,8 @@ def parse():
     ap.add_argument("--exchange", default="auto", choices=["auto", "sharded", "allreduce"],
                     help="N>1: form of the data-parallel exchange (dp.make_exchange): auto = one fp32 all-reduce + full optimizer step per rank in the "
                          "split-bf16 mode, the sharded exchange (reduce-scatter / sharded optimizer / all-gather) otherwise")
+    ap.add_argument("--buckets", type=int, default=None,
+                    help="N>1, all-reduce exchange: row bands the flat gradient is reduced and applied in (dp.AllReduceExchange; default 1)")
     ap.add_argument("--profile-steps", type=int, default=20)
     ap.add_argument("--fit-epochs", type=int, default=6)
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
@@ -189,7 +191,7 @@ class Runner:
         self.exchange = None
         if world > 1 or a.force_exchange:
             from dae_rnn_news_recommendation_amd import dp
-            self.exchange = dp.make_exchange(self.eng, grad_dtype=a.grad_dtype, kind=a.exchange)
+            self.exchange = dp.make_exchange(self.eng, grad_dtype=a.grad_dtype, kind=a.exchange, buckets=a.buckets)
         self.nb = -(-self.N // self.B)
         self.stats = torch.zeros((self.nb, L.STATS_STRIDE), dtype=torch.float32, device=self.eng.device)
         self.step_i = 0

@@ -313,12 +313,15 @@ class AllReduceExchange:
     step, this one ~35 (tools/dp_step_breakdown.py --precision bf16x3).  Every rank holds the full master weights and optimizer slots at all
     times: gather_master / gather_slots are no-ops.  Same interface as ShardedExchange.
 
-    buckets > 1 (default 4 when the world has more than one rank): the flat gradient is cut into `buckets` row bands of W (whole 64-row blocks; the
+    buckets > 1 (an option; default 1): the flat gradient is cut into `buckets` row bands of W (whole 64-row blocks; the
     bias gradients ride at the end of the last band).  All bands are handed to the collective library at once (async_op: RCCL runs them back to back
     on its own stream) and the step's stream applies band k (dae_plan_apply_band: master rows, slots and every 16-bit image of those rows) as soon as
     band k has arrived -- the optimizer pass over band k runs while band k + 1 is on the wire, so of the ~20 us optimizer pass only the last band's
     share stays exposed behind the collective.  Element-wise the same sums and the same update as the single-bucket form (bit-identical for two
-    ranks; for more ranks the reduction order inside the collective library may differ by bucket size)."""
+    ranks; for more ranks the reduction order inside the collective library may differ by bucket size).  Measured without communication (one-rank RCCL
+    group, tools/dp_step_breakdown.py, profiles/r05_dp_step_breakdown.txt): every torch.distributed call costs ~25 us of HOST time, so four buckets
+    make the exchange 117 us of host work per step against 30 us for one -- the bands only pay when the all-reduce on the wire is longer than that,
+    which a one-GPU box cannot show; the default therefore stays ONE bucket until a multi-GPU measurement says otherwise (bench.py --buckets N)."""
 
     def __init__(self, eng, buckets=None):
         import torch
@@ -336,7 +339,7 @@ class AllReduceExchange:
         self.flat = eng.grad[:eng.n_flat]                       # [dW (Fp*Hp) | dbh (Hp) | dbv (Fp)]
         self.f0, self.f1 = 0, eng.Fp                            # (interface parity: this rank "owns" every row)
         if buckets is None:
-            buckets = 4 if self.world > 1 else 1
+            buckets = 1
         nblk = eng.Fp // 64
         self.buckets = max(1, min(int(buckets), nblk))
         # band k = rows [bounds[k], bounds[k + 1]) of W; its slice of the flat buffer ends at the band's last row -- or at the end of the buffer (biases)

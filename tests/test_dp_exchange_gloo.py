@@ -128,7 +128,7 @@ def _worker(rank, world, port, mode, Fp, Hp, out):
     W0 = torch.from_numpy(np.random.default_rng(7).uniform(-0.3, 0.3, (Fp, Hp)).astype(np.float32))
     eng.W.copy_(W0); eng.sync_shadows()
     if mode.startswith("x3_allreduce"):        # what dp.make_exchange(kind='auto') picks for the split mode: all-reduce + full optimizer step per rank
-        ex = dp.make_exchange(eng, buckets=1 if mode == "x3_allreduce_1" else None)      # default: 4 buckets (row bands applied as they arrive)
+        ex = dp.make_exchange(eng, buckets=None if mode == "x3_allreduce_1" else 4)      # default: one bucket; 4 = row bands applied as they arrive
         assert type(ex).__name__ == "AllReduceExchange" and type(dp.make_exchange(eng, kind="sharded")).__name__ == "ShardedExchange"
         assert ex.buckets == (1 if mode == "x3_allreduce_1" else min(4, Fp // 64)) and ex.bounds[0] == 0 and ex.bounds[-1] == Fp
         lo_eng = FakeEngine(Fp, Hp, world, td, x3=True, grad_lo=True)                    # a 16-bit exchange image would leave the flat gradient stale
