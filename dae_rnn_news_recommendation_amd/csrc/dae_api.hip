@@ -358,6 +358,7 @@ extern "C" int dae_plan_set_option(dae_plan* p, const char* name, int32_t value)
     else if (!strcmp(name, "overlap")) p->overlap_ok = on;
     else if (!strcmp(name, "gather_tile")) set_gather_tile(value);        // process-wide: tile shape of the dense gather (A/B measurements)
     else if (!strcmp(name, "dw_rounds")) { DAE_CHECK_ARG(value >= 1 && value <= 64, "plan_set_option: dw_rounds in 1..64"); set_use_glds(-100 - value); }   // process-wide, like miner_pack
+    else if (!strcmp(name, "pad_skip")) set_use_glds(on ? -12 : -11);      // process-wide: 0 = multiply / evaluate the all-padding 32-row blocks of the last batch tile too (A/B)
     else if (!strcmp(name, "miner_order")) p->miner_order_ok = on;
     else if (!strcmp(name, "miner_ranges")) p->miner_ranges_ok = on;
     else if (!strcmp(name, "miner_pack")) set_miner_pack(on);        // process-wide (the launcher's choice), like dae_set_glds
@@ -778,24 +779,27 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     if (!backward) return 0;
     // 9-10. dL/dh = delta2 W + alpha (G+G^T) h ; delta1                     (K8)
     const bool mined = !ext_mine && (c.triplet == DAE_TRIPLET_BATCH_ALL || c.triplet == DAE_TRIPLET_BATCH_HARD);
+    // contractions over the BATCH (dW's K, the Gs.h segment of dh) stop at the last 64-deep K tile that holds a real row: the images are zero beyond B, and
+    // B = 800 pads to 896 = 14 K tiles of which 13 hold data
+    const int Bk = (B + 63) / 64 * 64;
     const int s_dh = (x3 && dense_in) ? p->s_dh3 : p->s_dh;
     if (x3) {       // (d2_hi, Wt_hi) (d2_hi, Wt_lo) (d2_lo, Wt_hi) + Gs.h_hi (+ Gs.h_lo with option x3_dh_hlo): Gs itself stays bf16 (tools/precision_study.py)
         const GemmSegDesc hs[5] = {{p->delta2, Fp, p->b.Wt_lo, Fp, Fp}, {p->delta2, Fp, p->Wt_lo2, Fp, (T & X3T_DH_WLO) ? Fp : 0},
                                    {p->delta2_2, Fp, p->b.Wt_lo, Fp, (T & X3T_DH_D2LO) ? Fp : 0},
-                                   {p->Gs, Bp, p->h_t, ldB, mined ? Bp : 0}, {p->Gs, Bp, p->h_t2, ldB, (mined && (T & X3T_DH_HLO)) ? Bp : 0}};
-        PROF(PS_DH_GEMM, launch_gemm_f32out_n(dt, Bp, Hp, hs, 5, p->slabs, Hp, s_dh, slab, st, GEMM_ROLE_DH));
+                                   {p->Gs, Bp, p->h_t, ldB, mined ? Bk : 0}, {p->Gs, Bp, p->h_t2, ldB, (mined && (T & X3T_DH_HLO)) ? Bk : 0}};
+        PROF(PS_DH_GEMM, launch_gemm_f32out_n(dt, Bp, Hp, hs, 5, p->slabs, Hp, s_dh, slab, st, GEMM_ROLE_DH, nullptr, nullptr, 1.f, B));
     } else {
         PROF(PS_DH_GEMM, launch_gemm_f32out(dt, Bp, Hp, p->delta2, Fp, p->b.Wt_lo, Fp, Fp, mined ? p->Gs : nullptr, Bp, mined ? p->h_t : nullptr, ldB,
-                              mined ? Bp : 0, p->slabs, Hp, p->s_dh, slab, st, GEMM_ROLE_DH));
+                              mined ? Bk : 0, p->slabs, Hp, p->s_dh, slab, st, GEMM_ROLE_DH, nullptr, nullptr, B));
     }
     PROF(PS_DH_FIN, launch_dh_finish(p->slabs, s_dh, slab, Hp, (explicit3 || ext_mine) ? p->dh_extra : nullptr, p->h_f32, Hp, p->b.bh, B, H, c.enc_act, dt,
                      p->delta1_t, ldB, p->colsum_part, nullptr, nullptr, st, (T & X3T_DW_D1LO) ? p->delta1_t2 : nullptr, oinv, osc));
     // 11. dW = x~^T delta1 + delta2^T h                                      (K8, tied weights)
     // split-bf16 segment list (K = 0 segments are skipped): the third one exists only when x~^T has a lo image
-    const GemmSegDesc ws3[6] = {{p->xct, ldB, p->delta1_t, ldB, Bp}, {p->xct, ldB, p->delta1_t2, ldB, (T & X3T_DW_D1LO) ? Bp : 0},
-                                {p->xct_2, ldB, p->delta1_t, ldB, x3_vals ? Bp : 0},
-                                {p->delta2_t, ldB, p->h_t, ldB, Bp}, {p->delta2_t, ldB, p->h_t2, ldB, (T & X3T_DW_HLO) ? Bp : 0},
-                                {p->delta2_t2, ldB, p->h_t, ldB, (T & X3T_DW_D2LO) ? Bp : 0}};
+    const GemmSegDesc ws3[6] = {{p->xct, ldB, p->delta1_t, ldB, Bk}, {p->xct, ldB, p->delta1_t2, ldB, (T & X3T_DW_D1LO) ? Bk : 0},
+                                {p->xct_2, ldB, p->delta1_t, ldB, x3_vals ? Bk : 0},
+                                {p->delta2_t, ldB, p->h_t, ldB, Bk}, {p->delta2_t, ldB, p->h_t2, ldB, (T & X3T_DW_HLO) ? Bk : 0},
+                                {p->delta2_t2, ldB, p->h_t, ldB, (T & X3T_DW_D2LO) ? Bk : 0}};
     if (fuse_opt || dw_pc_grad) {
         OptEpi oe;
         memset(&oe, 0, sizeof(oe));
@@ -813,14 +817,14 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
             PROF(PS_DW_GEMM, launch_dw_opt_n(Fp, Hp, ws3, 6, oe, st, p->dw_pair_ok));
         } else if (dw_bits) {
             DwBitsArgs xa{p->xtb, ldB / 32, s->scale};
-            PROF(PS_DW_GEMM, launch_dw_opt(Fp, Hp, nullptr, ldB, p->delta1_t, ldB, Bp, p->delta2_t, ldB, p->h_t, ldB, Bp, oe, st, &xa));
+            PROF(PS_DW_GEMM, launch_dw_opt(Fp, Hp, nullptr, ldB, p->delta1_t, ldB, Bk, p->delta2_t, ldB, p->h_t, ldB, Bk, oe, st, &xa));
         } else {
-            PROF(PS_DW_GEMM, launch_dw_opt(Fp, Hp, p->xct, ldB, p->delta1_t, ldB, Bp, p->delta2_t, ldB, p->h_t, ldB, Bp, oe, st));
+            PROF(PS_DW_GEMM, launch_dw_opt(Fp, Hp, p->xct, ldB, p->delta1_t, ldB, Bk, p->delta2_t, ldB, p->h_t, ldB, Bk, oe, st));
         }
     } else if (x3) {
         PROF(PS_DW_GEMM, launch_gemm_f32out_n(dt, Fp, Hp, ws3, 6, p->b.grad, Hp, 1, 0, st, GEMM_ROLE_DW, nullptr, nullptr, oinv));
     } else {
-        const GemmSegDesc ws2[2] = {{p->xct, ldB, p->delta1_t, ldB, Bp}, {p->delta2_t, ldB, p->h_t, ldB, Bp}};
+        const GemmSegDesc ws2[2] = {{p->xct, ldB, p->delta1_t, ldB, Bk}, {p->delta2_t, ldB, p->h_t, ldB, Bk}};
         PROF(PS_DW_GEMM, launch_gemm_f32out_n(dt, Fp, Hp, ws2, 2, p->b.grad, Hp, 1, 0, st, GEMM_ROLE_DW, nullptr, nullptr, oinv));
         // data parallel with a bf16 exchange image: the shape did not fit the kernel that writes it directly
         if (!apply_now && dt == DAE_BF16 && p->b.grad_lo) RC(launch_cast_bf16(p->b.grad, p->b.grad_lo, (int64_t)Fp * Hp, st));

@@ -1609,8 +1609,13 @@ __global__ __launch_bounds__(GEMM_THREADS, DecGeo<BN_T>::WG_PER_CU) void gemm_de
     }
 
     f32x16 acc[2][NTB];
+    // 32-row blocks of this tile that hold a real batch row (1..4); block (wm, mt) of this wave is 2 wm + mt
+    const int vblk = e.no_pad_skip ? 4 : min(4, (e.B - tm * BM + 31) >> 5);
+    const bool vb[2] = {2 * wm < vblk, 2 * wm + 1 < vblk};
     if constexpr (BN_T == 128) gemm_mainloop<T, DECODE_NST>(p, tm, tn, kt0, kt1, lds, acc);
     else mainloop_n64<T>(p, tm, tn, lds, acc);
+    // (the K loop multiplies the padding blocks too: branching around MFMAs would put them in basic blocks of their own, out of reach of the static check
+    //  of the hand-placed LDS waits, tools/check_gemm_asm.py -- measured worth < 1 % of the step; the EPILOGUE below skips their loss evaluation)
     __syncthreads();                                   // every wave is done with the K-loop stages
 
     char* R0 = lds;                                    // x tile, overwritten in place by delta2   [128][P0]
@@ -1802,11 +1807,43 @@ __global__ __launch_bounds__(GEMM_THREADS, DecGeo<BN_T>::WG_PER_CU) void gemm_de
             }
         }
     };
+    // a 32-row block of pure padding (rows >= B): delta2 = 0 without evaluating the loss (cw is 0 there, so the evaluated form stores the same zeros)
+    auto zero_block = [&](auto MT) {
+        constexpr int mt = decltype(MT)::value;
+        if constexpr (STAGED) {
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int rloc = mt * 32 + 8 * r4;
+#pragma unroll
+                for (int nt = 0; nt < NTB; ++nt) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) *reinterpret_cast<bf16_t*>(r0_lane + (rloc + q) * P0 + nt * 64) = (bf16_t)0;
+                    uint2 z; z.x = 0u; z.y = 0u;
+                    *reinterpret_cast<uint2*>(r1_lane + nt * 32 * P1 + rloc * 2) = z;
+                    if constexpr (RES) { resv[mt * 4 + r4][nt][0] = 0u; resv[mt * 4 + r4][nt][1] = 0u; }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4)
+#pragma unroll
+                for (int nt = 0; nt < NTB; ++nt) {
+                    const int rloc = mt * 32 + 8 * r4;
+                    if (!pass1) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) if (d2_lane) d2_lane[(int64_t)(rloc + q) * e.ldd + nt * 32] = Elem<T>::from(0.f);
+                        if (d2t_lane) store4<T>(d2t_lane + (int64_t)nt * 32 * e.lddt + rloc, 0.f, 0.f, 0.f, 0.f);
+                    }
+                }
+        }
+    };
 #define DAE_EPI_ROWS(MTV, FV)                                                                                              \
+    if (vb[MTV]) {                                                                                                         \
     epi_block(std::integral_constant<int, MTV>{}, std::integral_constant<int, 0>{}, std::integral_constant<bool, FV>{});   \
     epi_block(std::integral_constant<int, MTV>{}, std::integral_constant<int, 1>{}, std::integral_constant<bool, FV>{});   \
     epi_block(std::integral_constant<int, MTV>{}, std::integral_constant<int, 2>{}, std::integral_constant<bool, FV>{});   \
-    epi_block(std::integral_constant<int, MTV>{}, std::integral_constant<int, 3>{}, std::integral_constant<bool, FV>{});
+    epi_block(std::integral_constant<int, MTV>{}, std::integral_constant<int, 3>{}, std::integral_constant<bool, FV>{});   \
+    } else zero_block(std::integral_constant<int, MTV>{});
     bool fast = false;
     if constexpr (LOSS == DAE_LOSS_CROSS_ENTROPY && ACT == DAE_ACT_SIGMOID) {
         float zmax = 0.f;
@@ -1998,6 +2035,7 @@ static int g_dw_rounds = 1;  // ... or at most this many rounds of the chip (dae
 static int g_dw_rounds_split = 16;   // the split 16-bit modes take the multi-round form by default: measured at 896 x 50048 x 1024 (c4, f16x2) 357 us fused against
                                      // 246 us GEMM to memory + 208 us optimizer kernel (profiles/r05_c4_dw_rounds.txt)
 static int g_use_pc = 1;     // dae_set_glds(-1) keeps the 4-wave kernel for every grid (A/B)
+static int g_pad_skip = 1;   // skip the MFMAs / loss evaluation of 32-row blocks that are pure batch padding (dae_set_glds(-11) off, (-12) on: A/B; plan option "pad_skip")
 static int g_pc_vec = 1;     // gemm_nt_pc epilogue: 1 = LDS-staged 16-byte pieces (default), 0 = dword stores (dae_set_glds(-9) / (-10))
 typedef void (*decode_fn)(GemmParams, DecodeEpi);
 static decode_fn decode_kernel_xbits(int loss, int act) {
@@ -2096,19 +2134,20 @@ int gemm_w8_splits(int dtype, int M, int N, int ktiles) {
 }
 int launch_gemm_f32out(int dtype, int M, int N, const void* A0, int64_t lda0, const void* Bt0, int64_t ldb0, int K0,
                        const void* A1, int64_t lda1, const void* Bt1, int64_t ldb1, int K1, float* C, int64_t ldc,
-                       int splits, int64_t slab_stride, hipStream_t st, int role, const LabelJob* label_job, int* label_done) {
+                       int splits, int64_t slab_stride, hipStream_t st, int role, const LabelJob* label_job, int* label_done, int m_valid) {
     const GemmSegDesc segs[2] = {{A0, lda0, Bt0, ldb0, K0}, {A1, lda1, Bt1, ldb1, K1}};
-    return launch_gemm_f32out_n(dtype, M, N, segs, 2, C, ldc, splits, slab_stride, st, role, label_job, label_done);
+    return launch_gemm_f32out_n(dtype, M, N, segs, 2, C, ldc, splits, slab_stride, st, role, label_job, label_done, 1.f, m_valid);
 }
 
 int launch_gemm_f32out_n(int dtype, int M, int N, const GemmSegDesc* segs, int nsegs, float* C, int64_t ldc, int splits, int64_t slab_stride,
-                         hipStream_t st, int role, const LabelJob* label_job, int* label_done, float out_scale) {
+                         hipStream_t st, int role, const LabelJob* label_job, int* label_done, float out_scale, int m_valid) {
     if (label_done) *label_done = 0;
     GemmParams p;
     if (int rc = fill_params_n(p, dtype, M, N, segs, nsegs, splits)) return rc;
     DAE_CHECK_ARG(C != nullptr, "gemm: C is null");
     DAE_CHECK_ARG(out_scale == 1.f || p.splits == 1, "gemm: out_scale applies to un-split launches (slabs are scaled by the kernel that sums them)");
     p.out_scale = out_scale;
+    (void)m_valid;          // (rows of A that hold data: reserved -- skipping the all-padding MFMA blocks was measured worth < 1 % and is not done, see gemm_decode_loss)
     if (int rc = gemm_init()) return rc;
     if (out_scale == 1.f && p.splits == gemm_w8_splits(dtype, M, N, p.ktiles_total)) {      // (the 256 x 256 kernel has no output scale)
         W8Params q;
@@ -2315,6 +2354,7 @@ int launch_decode_loss_n(int dtype, int Bp, int Fp, const GemmSegDesc* segs, int
         k = decode_kernel_xbits(e.loss_func, e.dec_act);
     }
     if (e.op_scale == 0.f) e.op_scale = 1.f;
+    e.no_pad_skip = g_pad_skip ? 0 : 1;
     if (wide) {
         k = decode_kernel_wide(e.loss_func, e.dec_act, e.x_bits != nullptr);
         static int wide_rc = [] {
@@ -2608,6 +2648,8 @@ void set_use_glds(int nst) {
     if (nst == -6) { g_w8 = 0; return; }             // A/B: never the 256 x 256 / 8-MFMA-wave kernel
     if (nst == -7) { g_w8 = 1; return; }
     if (nst <= -100 && nst > -1000) { g_dw_rounds = g_dw_rounds_split = (-nst - 100 < 1 ? 1 : -nst - 100); return; }    // rounds of the chip the 160 x 128 dW kernel may take
+    if (nst == -11) { g_pad_skip = 0; return; }
+    if (nst == -12) { g_pad_skip = 1; return; }
     if (nst == -9) { g_pc_vec = 0; return; }         // A/B: gemm_nt_pc stores its tile as dwords straight from the accumulators
     if (nst == -10) { g_pc_vec = 1; return; }
     if (nst <= -1000) {                              // tests: pretend the device has (-nst - 1000) compute units, so that every CU-count-keyed

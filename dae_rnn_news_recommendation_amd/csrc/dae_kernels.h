@@ -31,6 +31,7 @@ struct DecodeEpi {
     // 16-bit modes: delta2 / delta2^T (and the rider's Gs) are stored times this power of two (1 unless the storage format is fp16: dae_api.hip op_scale);
     // the loss, the bias-gradient partials and everything fp32 stay unscaled
     float op_scale;
+    int no_pad_skip;          // 1: evaluate every 32-row block, padding included (A/B; set by the launcher from the process-wide switch)
     int bn;                   // tile width (columns of y per workgroup): 0 = the mode's default (decode_tile_n), 128 = the wide 16-bit kernel; the partial-sum arrays
                               // (rowloss_part / cos_part: 2 * Fp / bn rows; tile_part: (Bp / 128) * (Fp / bn)) are laid out by it
 };
@@ -62,10 +63,11 @@ struct GemmSegDesc { const void* A; int64_t lda; const void* Bt; int64_t ldb; in
 int launch_gemm_f32out(int dtype, int M, int N, const void* A0, int64_t lda0, const void* Bt0, int64_t ldb0, int K0,
                        const void* A1, int64_t lda1, const void* Bt1, int64_t ldb1, int K1, float* C, int64_t ldc, int splits,
                        int64_t slab_stride, hipStream_t st, int role = 0, const struct LabelJob* label_job = nullptr,
-                       int* label_done = nullptr);
+                       int* label_done = nullptr, int m_valid = 0);
 // the same contraction over up to 5 K segments (split-bf16 operands: (hi,hi) (hi,lo) (lo,hi) per product)
 int launch_gemm_f32out_n(int dtype, int M, int N, const GemmSegDesc* segs, int nsegs, float* C, int64_t ldc, int splits, int64_t slab_stride,
-                         hipStream_t st, int role = 0, const LabelJob* label_job = nullptr, int* label_done = nullptr, float out_scale = 1.f);
+                         hipStream_t st, int role = 0, const LabelJob* label_job = nullptr, int* label_done = nullptr, float out_scale = 1.f,
+                         int m_valid = 0);   // m_valid: rows of A that hold data (0 = all M): the producer/consumer kernel skips the MFMAs of all-padding 32-row blocks
 // (out_scale: C = out_scale * sum -- un-split launches only; the dW gradient of a scaled delta image leaves unscaled)
 // K slices the 256 x 256 / 8-MFMA-wave kernel wants for this shape (0: the shape stays on the 128 x 128 kernels); see dae_gemm.hip
 int gemm_w8_splits(int dtype, int M, int N, int ktiles);
