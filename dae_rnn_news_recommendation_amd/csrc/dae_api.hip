@@ -146,6 +146,10 @@ struct dae_plan {
     bool enc_w32_ok;                 // option "encode_w32": bf16 mode encodes from the fp32 MASTER weights (h fp32-accurate); 0 = from W_lo
     int w32_cols;                    // option "encode_w32_cols": 128 (default) or 64 H columns per workgroup of that kernel
     bool gram_split;                 // Gram matrix as a 3-term split-bf16 MFMA GEMM (bf16 mode) instead of exact-fp32 MFMA
+    int dw_tr_mode;                  // option "dw_tr": the dW kernel reads x~ and delta2 ROW-MAJOR through transposing LDS reads (gemm_dw_pc<TRA>) -- the decode stores
+                                     // delta2 once (no delta2^T), the gathers write x~ instead of x~^T.  1 on, 0 off, -1 (default) = on for DENSE train sets only:
+                                     // measured (profiles/r05_ab_measurements.txt) -38 us per step at F = 50000 (the gather and the decode each write 90 MB less),
+                                     // but +3..5 us at the CSR shape of c2 (11 fragment-read instructions per k step instead of 6; its decode does not get faster)
     bool gram64_ok;                  // option "gram64" (default 1): the split Gram on 64 x 64 tiles over the whole K, ONE slab (gram64_kernel); 0: 128 x 128 tiles, split-K
     float *slabs, *h_f32, *D_slabs, *G, *rowloss_part, *dbv_part, *colsum_part, *cos_part, *cos_stats, *cw, *loss_part,
         *dw_f32, *tri_scalars, *dh_extra, *rowsq_scratch, *tile_part;
@@ -306,6 +310,7 @@ extern "C" int dae_plan_create(const dae_config* cfg, dae_plan** out) {
     plan_x3_splits(p);
     if (p->s_gram > p->Hp * 4 / 128) p->s_gram = p->Hp * 4 / 128;
     p->gram_split = (cfg->dtype == DAE_BF16) && (p->x3 || cfg->triplet == DAE_TRIPLET_BATCH_ALL || cfg->triplet == DAE_TRIPLET_BATCH_HARD);   // x3: hcat_a also holds the row-major h_lo
+    p->dw_tr_mode = -1;
     p->gram64_ok = p->gram_split && cfg->gram_splits <= 0;        // (an explicit split count keeps the 128 x 128 split-K form)
     if (p->gram64_ok) p->s_gram = 1;
     p->ws_bytes = carve(p, nullptr);
@@ -350,6 +355,7 @@ extern "C" int dae_plan_set_option(dae_plan* p, const char* name, int32_t value)
     else if (!strcmp(name, "fused_opt")) p->fuse_opt_ok = on;
     else if (!strcmp(name, "dw_bits")) p->dw_bits_ok = on;
     else if (!strcmp(name, "dw_pair")) p->dw_pair_ok = on;
+    else if (!strcmp(name, "dw_tr")) { DAE_CHECK_ARG(value >= -1 && value <= 1, "plan_set_option: dw_tr is -1 (auto), 0 or 1"); p->dw_tr_mode = value; p->xct_clean = false; }
     else if (!strcmp(name, "encode_w32")) p->enc_w32_ok = on && p->cfg.dtype == DAE_BF16;
     else if (!strcmp(name, "encode_w32_cols")) { DAE_CHECK_ARG(value == 64 || value == 128, "plan_set_option: encode_w32_cols is 64 or 128"); p->w32_cols = value; }
     else if (!strcmp(name, "tail")) p->tail_ok = on;
@@ -583,6 +589,16 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     const bool dw_pc_grad = backward && !apply_now && dt == DAE_BF16 && p->fuse_opt_ok && (x3 ? dw_x3_fits(Fp, Hp, Bp) : dw_bits_fits(Fp, Hp, Bp));
     const bool dw_bits = p->dw_bits_ok && use_sparse && src_binary && backward && dt == DAE_BF16 && (fuse_opt || dw_pc_grad) &&
                            dw_bits_fits(Fp, Hp, Bp);
+    // contractions over the BATCH (dW's K, the Gs.h segment of dh) stop at the last 64-deep K tile that holds a real row: the images are zero beyond B, and
+    // B = 800 pads to 896 = 14 K tiles of which 13 hold data
+    const int Bk = (B + 63) / 64 * 64;
+    // Transposed-A dW (gemm_dw_pc<TRA>): x~ and delta2 are consumed ROW-MAJOR [batch x feature], so delta2^T is never stored and the gathers write x~ (the
+    // CSR scatter lands in one 20 KB row per batch row instead of one line per entry).  Needs the 160 x 128 kernel and the two plain K segments
+    // (16-bit modes without lo images of x~ / delta2 / delta1 / h in dW: f16x2, bf16, f16); decided from plan state and shapes only, so that the
+    // phase-4 / phase-5 halves of an externally mined step agree
+    const bool dw_plain2 = !x3 || !(T & (X3T_DW_D1LO | X3T_DW_HLO | X3T_DW_D2LO | X3T_XV));
+    const bool dw_tr = (p->dw_tr_mode == 1 || (p->dw_tr_mode < 0 && dense_in)) && dt == DAE_BF16 && backward && (fuse_opt || dw_pc_grad) && dw_plain2 && !dw_bits && (use_sparse || dense_in) &&
+                       (x3 || dw_pc_taken(Fp, Hp, Bk, Bk, !fuse_opt));
     if (x3) {
         // split-bf16 mode: CSR input encoded from the fp32 master weights (h is fp32-accurate and its hi / lo images come from the same
         // launch); x~ must be exact in bf16 (binary data, or values with <= 8 significant bits).  Every phase: the data-parallel
@@ -634,7 +650,8 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
         q.corr_frac = s->corr_frac; q.scale = s->scale;
         q.h_f32 = p->h_f32; q.h_lo = p->h_lo; q.ldh = Hp; q.h_t = p->h_t; q.ldht = ldB;
         q.hcat_a = p->gram_split ? p->hcat_a : nullptr; q.hcat_b = p->gram_split ? p->hcat_b : nullptr;
-        q.x_bits = own_clean ? p->x_bits : nullptr; q.ldxb = Fp / 32; q.xct = (backward && !dw_bits) ? p->xct : nullptr; q.ldt = ldB;
+        q.x_bits = own_clean ? p->x_bits : nullptr; q.ldxb = Fp / 32; q.xct = (backward && !dw_bits) ? p->xct : nullptr; q.ldt = dw_tr ? Fp : ldB;
+        q.xct_rm = dw_tr ? 1 : 0;
         q.xtb = (backward && dw_bits) ? p->xtb : nullptr; q.ldxt = ldB / 32;
         q.rowsq = own_clean ? rowsq : nullptr;
         q.h_t2 = (T & (X3T_DH_HLO | X3T_DW_HLO)) ? p->h_t2 : nullptr;
@@ -652,7 +669,7 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
             // binary CSR, unit scale, bf16: the corrupted batch goes to the encode GEMM as a BIT image (1.1 MB, not 18 MB of bf16)
             use_bits = p->bits_ok && p->b.indptr && !p->b.values && s->scale == 1.0f;
             PROF(PS_GATHER, gather_batch(p, p->b.indptr, p->b.indices, p->b.values, p->b.dense, p->b.ld_dense, s->row_idx, B,
-                            use_xbits ? nullptr : p->x, use_bits ? nullptr : p->xc, backward ? p->xct : nullptr, rowsq, s->corr_mode, s->keep_bits,
+                            use_xbits ? nullptr : p->x, use_bits ? nullptr : p->xc, (backward && !dw_tr) ? p->xct : nullptr, rowsq, s->corr_mode, s->keep_bits,
                             s->seed, s->rng_stream, s->corr_frac, s->scale, stream, use_bits ? p->xc_bits : nullptr, label_in_gather ? &lj : nullptr,
                             use_xbits ? p->x_bits : nullptr));
         }
@@ -702,7 +719,7 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
         e.bv = p->b.bv; e.x = p->x; e.ldx = Fp; e.x_bits = use_xbits ? p->x_bits : nullptr; e.ldxb = Fp / 32; e.cw = p->cw; e.cos_stats = is_cos ? p->cos_stats : nullptr;
         e.rowloss_part = is_cos ? p->rowloss_part : nullptr; e.tile_part = is_cos ? nullptr : p->tile_part;
         e.dbv_part = backward ? p->dbv_part : nullptr; e.cos_part = p->cos_part;
-        e.delta2 = backward ? p->delta2 : nullptr; e.ldd = Fp; e.delta2_t = backward ? p->delta2_t : nullptr; e.lddt = ldB;
+        e.delta2 = backward ? p->delta2 : nullptr; e.ldd = Fp; e.delta2_t = (backward && !dw_tr) ? p->delta2_t : nullptr; e.lddt = ldB;
         e.B = B; e.F = F; e.Bp = Bp; e.Fp = Fp; e.dec_act = c.dec_act; e.loss_func = c.loss_func; e.ce_literal = p->ce_literal ? 1 : 0;
         e.op_scale = osc; e.bn = dbn;
         if (ride) { e.sym_G = p->G; e.sym_scalars = p->tri_scalars; e.sym_Gs = p->Gs; e.sym_B = B; e.sym_Bp = Bp; }
@@ -779,9 +796,6 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
     if (!backward) return 0;
     // 9-10. dL/dh = delta2 W + alpha (G+G^T) h ; delta1                     (K8)
     const bool mined = !ext_mine && (c.triplet == DAE_TRIPLET_BATCH_ALL || c.triplet == DAE_TRIPLET_BATCH_HARD);
-    // contractions over the BATCH (dW's K, the Gs.h segment of dh) stop at the last 64-deep K tile that holds a real row: the images are zero beyond B, and
-    // B = 800 pads to 896 = 14 K tiles of which 13 hold data
-    const int Bk = (B + 63) / 64 * 64;
     const int s_dh = (x3 && dense_in) ? p->s_dh3 : p->s_dh;
     if (x3) {       // (d2_hi, Wt_hi) (d2_hi, Wt_lo) (d2_lo, Wt_hi) + Gs.h_hi (+ Gs.h_lo with option x3_dh_hlo): Gs itself stays bf16 (tools/precision_study.py)
         const GemmSegDesc hs[5] = {{p->delta2, Fp, p->b.Wt_lo, Fp, Fp}, {p->delta2, Fp, p->Wt_lo2, Fp, (T & X3T_DH_WLO) ? Fp : 0},
@@ -796,9 +810,13 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
                      p->delta1_t, ldB, p->colsum_part, nullptr, nullptr, st, (T & X3T_DW_D1LO) ? p->delta1_t2 : nullptr, oinv, osc));
     // 11. dW = x~^T delta1 + delta2^T h                                      (K8, tied weights)
     // split-bf16 segment list (K = 0 segments are skipped): the third one exists only when x~^T has a lo image
-    const GemmSegDesc ws3[6] = {{p->xct, ldB, p->delta1_t, ldB, Bk}, {p->xct, ldB, p->delta1_t2, ldB, (T & X3T_DW_D1LO) ? Bk : 0},
+    // (dw_tr: the A operands are the row-major images -- x~ from the CSR scatter (p->xct used as [Bp x Fp]) or the dense gather (p->xc), and delta2)
+    const void* a_x = dw_tr ? (const void*)(dense_in ? p->xc : p->xct) : (const void*)p->xct;
+    const void* a_d2 = dw_tr ? (const void*)p->delta2 : (const void*)p->delta2_t;
+    const int64_t lda_w = dw_tr ? Fp : ldB;
+    const GemmSegDesc ws3[6] = {{a_x, lda_w, p->delta1_t, ldB, Bk}, {p->xct, ldB, p->delta1_t2, ldB, (T & X3T_DW_D1LO) ? Bk : 0},
                                 {p->xct_2, ldB, p->delta1_t, ldB, x3_vals ? Bk : 0},
-                                {p->delta2_t, ldB, p->h_t, ldB, Bk}, {p->delta2_t, ldB, p->h_t2, ldB, (T & X3T_DW_HLO) ? Bk : 0},
+                                {a_d2, lda_w, p->h_t, ldB, Bk}, {p->delta2_t, ldB, p->h_t2, ldB, (T & X3T_DW_HLO) ? Bk : 0},
                                 {p->delta2_t2, ldB, p->h_t, ldB, (T & X3T_DW_D2LO) ? Bk : 0}};
     if (fuse_opt || dw_pc_grad) {
         OptEpi oe;
@@ -814,12 +832,12 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
         }
         if (x3) {   // x~^T.(d1_hi + d1_lo) + (d2^T_hi, h^T_hi) (d2^T_hi, h^T_lo) (d2^T_lo, h^T_hi); the epilogue writes both parts of both shadows
             oe.W_lo2 = (T & X3T_DEC_WLO) ? p->W_lo2 : nullptr; oe.Wt_lo2 = p->Wt_lo2;     // W_lo2 feeds the decode's (h_hi, W_lo) term only
-            PROF(PS_DW_GEMM, launch_dw_opt_n(Fp, Hp, ws3, 6, oe, st, p->dw_pair_ok));
+            PROF(PS_DW_GEMM, launch_dw_opt_n(Fp, Hp, ws3, 6, oe, st, p->dw_pair_ok, dw_tr));
         } else if (dw_bits) {
             DwBitsArgs xa{p->xtb, ldB / 32, s->scale};
             PROF(PS_DW_GEMM, launch_dw_opt(Fp, Hp, nullptr, ldB, p->delta1_t, ldB, Bk, p->delta2_t, ldB, p->h_t, ldB, Bk, oe, st, &xa));
         } else {
-            PROF(PS_DW_GEMM, launch_dw_opt(Fp, Hp, p->xct, ldB, p->delta1_t, ldB, Bk, p->delta2_t, ldB, p->h_t, ldB, Bk, oe, st));
+            PROF(PS_DW_GEMM, launch_dw_opt(Fp, Hp, a_x, lda_w, p->delta1_t, ldB, Bk, a_d2, lda_w, p->h_t, ldB, Bk, oe, st, nullptr, dw_tr));
         }
     } else if (x3) {
         PROF(PS_DW_GEMM, launch_gemm_f32out_n(dt, Fp, Hp, ws3, 6, p->b.grad, Hp, 1, 0, st, GEMM_ROLE_DW, nullptr, nullptr, oinv));
@@ -839,8 +857,8 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
                     fuse_bias ? 1 : 0, c.opt, plan_lr(p, s->adam_t), c.momentum, s->grad_scale, p->b.bv,
                     p->b.opt_s1 ? p->b.opt_s1 + boff : nullptr, p->b.opt_s2 ? p->b.opt_s2 + boff : nullptr};
         ClearArgs ca{s->c_indptr ? s->c_indptr : p->b.indptr, s->c_indptr ? s->c_indices : p->b.indices,
-                     (s->c_indptr && s->c_row_idx) ? s->c_row_idx : s->row_idx, B, F, dw_bits ? nullptr : p->xct, ldB, p->es,
-                     dw_bits ? p->xtb : nullptr, ldB / 32, x3_vals ? p->xct_2 : nullptr};
+                     (s->c_indptr && s->c_row_idx) ? s->c_row_idx : s->row_idx, B, F, dw_bits ? nullptr : p->xct, dw_tr ? (int64_t)Fp : (int64_t)ldB, p->es,
+                     dw_bits ? p->xtb : nullptr, ldB / 32, x3_vals ? p->xct_2 : nullptr, dw_tr ? 1 : 0};
         PROF(PS_BIAS, launch_step_tail(ba, &sa, csr_in ? &ca : nullptr, st));
         if (csr_in) { if (dw_bits) p->xtb_clean = true; else p->xct_clean = true; if (x3_vals) p->xct2_clean = true; }
     } else {

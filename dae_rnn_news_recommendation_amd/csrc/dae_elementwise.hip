@@ -565,10 +565,11 @@ __global__ __launch_bounds__(256) void step_tail_kernel(BiasArgs ba, StatsArgs s
             if (col[j] < ca.F) {
                 if (ca.xtb) ca.xtb[(int64_t)col[j] * ca.ldxt + (i >> 5)] = 0u;        // every lane that touches the word writes the same zero
                 else if (ca.es == 2) {
-                    reinterpret_cast<bf16_t*>(ca.xct)[(int64_t)col[j] * ca.ldt + i] = 0;
-                    if (ca.xct2) reinterpret_cast<bf16_t*>(ca.xct2)[(int64_t)col[j] * ca.ldt + i] = 0;
+                    const int64_t o = ca.rm ? (int64_t)i * ca.ldt + col[j] : (int64_t)col[j] * ca.ldt + i;
+                    reinterpret_cast<bf16_t*>(ca.xct)[o] = 0;
+                    if (ca.xct2) reinterpret_cast<bf16_t*>(ca.xct2)[o] = 0;
                 }
-                else reinterpret_cast<float*>(ca.xct)[(int64_t)col[j] * ca.ldt + i] = 0.f;
+                else reinterpret_cast<float*>(ca.xct)[ca.rm ? (int64_t)i * ca.ldt + col[j] : (int64_t)col[j] * ca.ldt + i] = 0.f;
             }
         }
     }

@@ -297,6 +297,7 @@ struct EncCsrArgs {
     uint32_t* x_bits; int64_t ldxb;             // clean bit image [Bp x ldxb] (binary data) or NULL
     void* xct; int64_t ldt;                     // x~^T [Fp x ldt] scatter target (pre-zeroed) or NULL
     void* xct2;                                 // split-bf16 mode, x~ not exact in bf16: lo image of x~^T (same layout, pre-zeroed) or NULL
+    int xct_rm;                                 // 1: xct / xct2 are row-major x~ [Bp x ldt] (entry (i, col) at i * ldt + col)
     uint32_t* xtb; int64_t ldxt;                // x~^T as a BIT image [Fp x ldxt words] (pre-zeroed; bit i of row f <=> entry (i, f) kept) or NULL
     int xtl_off, Fp;                            // xtl_off > 0: LDS byte image [Fp] of the workgroup's 8 batch rows at that offset (else global atomics)
     float* rowsq;                               // [Bp] or NULL
@@ -434,8 +435,9 @@ __global__ __launch_bounds__(ENC_THREADS, 4) void encode_csr_kernel(EncCsrArgs a
                     if (xt_lds) atomicOr(&xtl[col[u] >> 2], 1u << (8 * (col[u] & 3) + r));
                     else if (a.xtb) atomicOr(&a.xtb[(int64_t)col[u] * a.ldxt + (i >> 5)], 1u << (i & 31));
                     else {
-                        xct[(int64_t)col[u] * a.ldt + i] = Elem<T>::from(w);
-                        if (a.xct2) reinterpret_cast<T*>(a.xct2)[(int64_t)col[u] * a.ldt + i] = elem_residual<T>(w);
+                        const int64_t o = a.xct_rm ? (int64_t)i * a.ldt + col[u] : (int64_t)col[u] * a.ldt + i;
+                        xct[o] = Elem<T>::from(w);
+                        if (a.xct2) reinterpret_cast<T*>(a.xct2)[o] = elem_residual<T>(w);
                     }
                 }
                 if (do_rowsq) sq += v * v;
@@ -632,7 +634,7 @@ int dae::launch_encode_csr(const EncCsrLaunch& q, hipStream_t st) {
     const int Bp = (int)dae_pad(q.B), Hp = (int)dae_pad(q.H);
     DAE_CHECK_ARG(q.ldw >= Hp && q.ldh >= Hp && (!q.h_t || q.ldht >= Bp), "encode_csr: leading dimensions too small");
     DAE_CHECK_ARG(!q.x_bits || (!q.values && q.ldxb >= dae_pad(q.F) / 32), "encode_csr: the bit image of x needs binary data and ldxb >= Fp/32");
-    DAE_CHECK_ARG(!q.xct || q.ldt >= Bp, "encode_csr: ldt too small");
+    DAE_CHECK_ARG(!q.xct || q.ldt >= (q.xct_rm ? (int)dae_pad(q.F) : Bp), "encode_csr: ldt too small");
     DAE_CHECK_ARG(!q.xtb || (!q.values && q.ldxt >= Bp / 32 && !q.xct), "encode_csr: the bit image of x~^T needs binary data, ldxt >= Bp/32 and no dense x~^T");
     DAE_CHECK_ARG(!q.label_job || q.label_job->Bp <= 1024, "encode_csr: in-kernel label statistics need a padded batch <= 1024");
     DAE_CHECK_ARG((q.hcat_a == nullptr) == (q.hcat_b == nullptr), "encode_csr: hcat_a/hcat_b must be given together");
@@ -643,7 +645,7 @@ int dae::launch_encode_csr(const EncCsrLaunch& q, hipStream_t st) {
     a.corr_mode = q.corr_mode; a.keep_bits = q.keep_bits; a.seed = q.seed; a.stream = q.rng_stream; a.corr_frac = q.corr_frac; a.scale = q.scale;
     a.enc_act = q.enc_act; a.h_f32 = q.h_f32; a.h_lo = q.h_lo; a.ldh = q.ldh; a.h_t = q.h_t; a.ldht = q.ldht; a.h_t2 = q.h_t2;
     a.hcat_a = (bf16_t*)q.hcat_a; a.hcat_b = (bf16_t*)q.hcat_b; a.x_bits = q.x_bits; a.ldxb = q.ldxb; a.xct = q.xct; a.ldt = q.ldt;
-    a.xtb = q.xtb; a.ldxt = q.ldxt; a.xct2 = q.xct2;
+    a.xtb = q.xtb; a.ldxt = q.ldxt; a.xct2 = q.xct2; a.xct_rm = q.xct_rm;
     DAE_CHECK_ARG(!q.xct2 || (q.xct && q.dtype == DAE_BF16), "encode_csr: the lo image of x~^T needs the dense x~^T and bf16");
     const int cols = enc_cols(q.dtype, q.w_f32, q.w32_cols);
     a.rowsq = q.rowsq; a.n_slices = Hp / cols;

@@ -810,10 +810,26 @@ __device__ __forceinline__ void wait_vm_n(int n) {   // counted vmcnt wait for t
     }
 }
 
-template <int OPT, bool XBITS, bool X3 = false, bool PAIR = false>      // X3 (split-bf16 mode): the lo images of both shadows are written too (e.W_lo2 / e.Wt_lo2)
+// TRA (round 5): the A operands are the ROW-MAJOR batch images x~ [Bp x Fp] and delta2 [Bp x Fp] -- K (the batch) is their ROW index -- instead of the
+// transposed images x~^T / delta2^T, so the decode kernel stores delta2 once and the gathers write no x~^T.  An LDS stage then holds the A tile as
+// [64 k][160 m] 16-bit (pitch 320 B: the same 20 KiB, filled by the same 20 LDS-DMA pieces, each lane fetching 8 consecutive features of one batch row) and
+// the consumers read their MFMA A fragments with gfx950's transposing LDS read: lane (row m, k group g) gets A[m][8 g .. 8 g + 7] from TWO
+// ds_read_b64_tr_b16 (4 k each; lane i of a 16-lane group addresses k row i >> 2, features 4 (i & 3) .. + 3; tools/tr_probe.hip pins the mapping on the
+// box).  The pitch of 320 B puts the four k rows of a 32-lane access into disjoint bank groups (80 dwords = 16 mod 64): conflict-free.
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+template <int OFF> __device__ __forceinline__ i32x2 lds_read_tr16_b64(uint32_t addr) {
+    i32x2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=&v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+constexpr int DW_TR_PITCH = DW_BM * 2;                                  // bytes per k row of the [k][m] A image
+static_assert(64 * DW_TR_PITCH == DW_A_BYTES, "the [k][m] image of a K tile fills the A tile exactly");
+
+template <int OPT, bool XBITS, bool X3 = false, bool PAIR = false, bool TRA = false>      // X3 (split-bf16 mode): the lo images of both shadows are written too (e.W_lo2 / e.Wt_lo2)
 __global__ __launch_bounds__(PC_THREADS, 1) void gemm_dw_pc(GemmParams p, OptEpi e, int Mrows, DwBits xb) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     static_assert(!PAIR || (X3 && !XBITS), "paired stages exist for the split-bf16 contraction on dense operand images");
+    static_assert(!TRA || (!PAIR && !XBITS), "the transposed-A form streams plain K segments of dense row-major images");
     constexpr int STG = PAIR ? DW_STAGE2 : DW_STAGE;                        // bytes per ring stage
     constexpr int NSTG = PAIR ? DW_NST2 : DW_NST;                           // ring depth
     // PAIR: does K tile t belong to a segment with a second B operand?  (uniform; a walk over <= 6 segments)
@@ -910,6 +926,7 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_dw_pc(GemmParams p, OptEpi
         }
         uint32_t voA[5], voB[4];
         const char *gA = nullptr, *gB = nullptr, *gB2 = nullptr;
+        int64_t a_adv = BKB;                                                 // bytes the A stream advances per K tile (TRA: 64 batch rows)
         int kt_dma = 0, seg_end = 0;
         auto seg_setup = [&](int kt) {
             int k;
@@ -918,16 +935,22 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_dw_pc(GemmParams p, OptEpi
             if constexpr (PAIR) gB2 = p.bt2[sg] ? p.bt2[sg] + (int64_t)k * BKB : nullptr;
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
+                if constexpr (TRA) {       // chunk c of the linear [64 k][20 chunks of 8 features] image: batch row c / 20 of the K tile, features 8 (c % 20) ..
+                    const int cch = (i * 4 + wave) * 64 + lane, kr = cch / 20, mc = cch % 20;
+                    voA[i] = (uint32_t)kr * lda + (uint32_t)min(row0_m + mc * 8, Mrows - 8) * 2u;
+                } else {
                 const int row = (i * 4 + wave) * 8 + (lane >> 3);
                 const int grow = min(row0_m + row, Mrows - 1);
                 voA[i] = (uint32_t)grow * lda + (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) << 4);
+                }
             }
+            a_adv = TRA ? (int64_t)64 * lda : (int64_t)BKB;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = (i * 4 + wave) * 8 + (lane >> 3);
                 voB[i] = (uint32_t)(row0_n + row) * ldb + (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) << 4);
             }
-            gA = p.seg[sg].A + (int64_t)k * BKB;
+            gA = p.seg[sg].A + (int64_t)k * a_adv;
             gB = p.seg[sg].Bt + (int64_t)k * BKB;
         };
         seg_setup(0);
@@ -993,7 +1016,7 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_dw_pc(GemmParams p, OptEpi
             if (built) build_a(slot);
             ++kt_dma;
             if (kt_dma == seg_end) { if (kt_dma < p.ktiles_total) seg_setup(kt_dma); }
-            else { gA += BKB; gB += BKB; if constexpr (PAIR) { if (gB2) gB2 += BKB; } }
+            else { gA += a_adv; gB += BKB; if constexpr (PAIR) { if (gB2) gB2 += BKB; } }
         };
         auto ops = [&](int st) { return st >= nk ? 0 : ((XBITS && st < nk0) ? 4 : (pair_of(st) ? 13 : 9)); };   // LDS-DMA pieces of stage st (per wave)
 #pragma unroll
@@ -1032,14 +1055,26 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_dw_pc(GemmParams p, OptEpi
         bool pair_cur = pair_of(0), pair_nxt = false;
         uint32_t ob2_cur = (pair_cur ? kOffB2 : (uint32_t)DW_A_BYTES) + (wave * 32 + r) * BKB, ob2_nxt = ob2_cur;
         (void)pair_nxt; (void)ob2_nxt;
+        // TRA: per-lane base of the transposing reads -- k row 8 g + (i >> 2) of the k step, features 16 (q & 1) + 4 (i & 3) of the 32-row block (q = lane >> 4,
+        // i = lane & 15); k step KK, half t and row block mb are immediate offsets (KK * 16 + 4 t rows of 320 B, mb * 64 B)
+        const uint32_t ta = (uint32_t)((g * 8 + ((lane & 15) >> 2)) * DW_TR_PITCH + ((((lane >> 4) & 1) * 16 + 4 * (lane & 3)) * 2));
+#define DAE_DW_TR(S, KK, SLOTBASE, MB)                                                                                          \
+    { const i32x2 lo__ = lds_read_tr16_b64<(KK) * 16 * DW_TR_PITCH + (MB) * 64>((SLOTBASE) + ta);                               \
+      const i32x2 hi__ = lds_read_tr16_b64<((KK) * 16 + 4) * DW_TR_PITCH + (MB) * 64>((SLOTBASE) + ta);                         \
+      fa[S][MB] = i32x4{lo__.x, lo__.y, hi__.x, hi__.y}; }
 #define DAE_DW_READ(S, KK, SLOTBASE, OB2)                                              \
     fb[S] = lds_read_b128((SLOTBASE) + offb + so[KK]);                                 \
     if constexpr (PAIR) fb2[PAIR ? S : 0] = lds_read_b128((SLOTBASE) + (OB2) + so[KK]); \
+    if constexpr (TRA) {                                                               \
+        DAE_DW_TR(S, KK, SLOTBASE, 0) DAE_DW_TR(S, KK, SLOTBASE, 1) DAE_DW_TR(S, KK, SLOTBASE, 2)                               \
+        DAE_DW_TR(S, KK, SLOTBASE, 3) DAE_DW_TR(S, KK, SLOTBASE, 4)                    \
+    } else {                                                                           \
     fa[S][0] = lds_read_b128((SLOTBASE) + offa + so[KK]);                              \
     fa[S][1] = lds_read_b128_off4096((SLOTBASE) + offa + so[KK]);                      \
     fa[S][2] = lds_read_b128((SLOTBASE) + offa + 8192 + so[KK]);                       \
     fa[S][3] = lds_read_b128_off4096((SLOTBASE) + offa + 8192 + so[KK]);               \
-    fa[S][4] = lds_read_b128((SLOTBASE) + offa + 16384 + so[KK]);
+    fa[S][4] = lds_read_b128((SLOTBASE) + offa + 16384 + so[KK]);                      \
+    }
 #define DAE_DW_MMA(S)                                                                  \
     Mma<bf16_t>::run(fa[S][0], fb[S], acc[0]);                                         \
     Mma<bf16_t>::run(fa[S][1], fb[S], acc[1]);                                         \
@@ -1057,6 +1092,7 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_dw_pc(GemmParams p, OptEpi
     }
 #define DAE_DW_WAIT_SET()                                                              \
     if constexpr (PAIR) asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");             \
+    else if constexpr (TRA) asm volatile("s_waitcnt lgkmcnt(11)" ::: "memory");        \
     else asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
 #if defined(DAE_DW_PROBE) && (DAE_DW_PROBE & 32)           // probe: the consumers only take part in the barriers
 #undef DAE_DW_READ
@@ -1109,6 +1145,7 @@ __global__ __launch_bounds__(PC_THREADS, 1) void gemm_dw_pc(GemmParams p, OptEpi
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #undef DAE_DW_READ
+#undef DAE_DW_TR
 #undef DAE_DW_MMA
 #undef DAE_DW_WAIT_SET
     }
@@ -1793,10 +1830,12 @@ __global__ __launch_bounds__(GEMM_THREADS, DecGeo<BN_T>::WG_PER_CU) void gemm_de
 #pragma unroll
         for (int nt = 0; nt < NTB; ++nt) {
             if constexpr (STAGED) {
-                uint2 v;
-                v.x = f2bf_pack_hw(d2v[nt][0], d2v[nt][1]);
-                v.y = f2bf_pack_hw(d2v[nt][2], d2v[nt][3]);
-                *reinterpret_cast<uint2*>(r1_lane + nt * 32 * P1 + rloc * 2) = v;
+                if (D2T) {                                  // (NULL: the dW kernel reads delta2 row-major, no transposed image -- gemm_dw_pc<TRA>)
+                    uint2 v;
+                    v.x = f2bf_pack_hw(d2v[nt][0], d2v[nt][1]);
+                    v.y = f2bf_pack_hw(d2v[nt][2], d2v[nt][3]);
+                    *reinterpret_cast<uint2*>(r1_lane + nt * 32 * P1 + rloc * 2) = v;
+                }
                 if constexpr (RES) {
                     resv[mt * 4 + r4][nt][0] = bf_residual_pack_hw(d2v[nt][0], d2v[nt][1]);
                     resv[mt * 4 + r4][nt][1] = bf_residual_pack_hw(d2v[nt][2], d2v[nt][3]);
@@ -1819,7 +1858,7 @@ __global__ __launch_bounds__(GEMM_THREADS, DecGeo<BN_T>::WG_PER_CU) void gemm_de
 #pragma unroll
                     for (int q = 0; q < 4; ++q) *reinterpret_cast<bf16_t*>(r0_lane + (rloc + q) * P0 + nt * 64) = (bf16_t)0;
                     uint2 z; z.x = 0u; z.y = 0u;
-                    *reinterpret_cast<uint2*>(r1_lane + nt * 32 * P1 + rloc * 2) = z;
+                    if (D2T) *reinterpret_cast<uint2*>(r1_lane + nt * 32 * P1 + rloc * 2) = z;
                     if constexpr (RES) { resv[mt * 4 + r4][nt][0] = 0u; resv[mt * 4 + r4][nt][1] = 0u; }
                 }
             }
@@ -1959,7 +1998,8 @@ __global__ __launch_bounds__(GEMM_THREADS, DecGeo<BN_T>::WG_PER_CU) void gemm_de
 static int g_nst = 2;   // staging variant of the plain GEMM: 0 register-staged, 2/3/4 global_load_lds ring depth
 
 // one K segment of a contraction as the host hands it over: A_seg [M x K], Bt_seg [N x K], both K-contiguous, leading dimensions in elements
-static int fill_params_n(GemmParams& p, int dtype, int M, int N, const GemmSegDesc* segs, int nsegs, int splits, int bn = BN) {
+static int fill_params_n(GemmParams& p, int dtype, int M, int N, const GemmSegDesc* segs, int nsegs, int splits, int bn = BN, bool a_is_k_by_m = false) {
+    // a_is_k_by_m (gemm_dw_pc<TRA>): A_seg is a row-major [K x M] image -- its 32-bit DMA offsets span one K tile (64 rows), not M rows
     const int es = (dtype == DAE_BF16) ? 2 : 4;
     const int kel = BKB / es;
     DAE_CHECK_ARG(dtype == DAE_BF16 || dtype == DAE_F32, "gemm: bad dtype %d", dtype);
@@ -1976,7 +2016,7 @@ static int fill_params_n(GemmParams& p, int dtype, int M, int N, const GemmSegDe
         DAE_CHECK_ARG(d.A && d.Bt, "gemm: null operand in segment %d", i);
         DAE_CHECK_ARG((d.lda * es) % 16 == 0 && (d.ldb * es) % 16 == 0, "gemm: leading dimensions must be 16-byte multiples");
         DAE_CHECK_ARG(((uintptr_t)d.A % 16) == 0 && ((uintptr_t)d.Bt % 16) == 0, "gemm: operands must be 16-byte aligned");
-        DAE_CHECK_ARG((uint64_t)M * (uint64_t)(d.lda * es) < (1ull << 32) && (uint64_t)N * (uint64_t)(d.ldb * es) < (1ull << 32),
+        DAE_CHECK_ARG((uint64_t)(a_is_k_by_m ? 64 : M) * (uint64_t)(d.lda * es) < (1ull << 32) && (uint64_t)N * (uint64_t)(d.ldb * es) < (1ull << 32),
                       "gemm: an operand panel (rows x leading dimension) must stay below 4 GiB (32-bit DMA offsets)");
         p.seg[p.nseg++] = {(const char*)d.A, (const char*)d.Bt, d.lda * es, d.ldb * es, d.K / kel};
         p.ktiles_total += d.K / kel;
@@ -2202,11 +2242,22 @@ bool dw_x3_fits(int M, int N, int Bp) {
     return N % BN == 0 && Bp % 64 == 0 && 8 * per * tiles_n <= g_cus * g_dw_rounds_split && g_dw_pc != 0;
 }
 
+// does launch_dw_opt take the 160 x 128 producer/consumer kernel for this shape (the only kernel with a transposed-A form)?
+bool dw_pc_taken(int M, int N, int K0, int K1, bool grad_only) {
+    if (gemm_init()) return false;
+    const int tiles_m = (M + DW_BM - 1) / DW_BM, tiles_n = N / BN, per = (tiles_m + 7) / 8;
+    const bool fits = g_dw_pc && N % BN == 0 && K0 % 64 == 0 && K1 % 64 == 0 && 8 * per * tiles_n <= g_cus * g_dw_rounds;
+    return fits && (grad_only || g_dw_pc == 2 || g_dw_rounds > 1 || 8 * per * tiles_n > (3 * g_cus) / 4);
+}
+
 int launch_dw_opt(int M, int N, const void* A0, int64_t lda0, const void* Bt0, int64_t ldb0, int K0, const void* A1, int64_t lda1,
-                  const void* Bt1, int64_t ldb1, int K1, const OptEpi& e, hipStream_t st, const DwBitsArgs* xa) {
+                  const void* Bt1, int64_t ldb1, int K1, const OptEpi& e, hipStream_t st, const DwBitsArgs* xa, bool tra) {
     GemmParams p;
     // xa: segment 0's A operand is the bit image (A0 == NULL); fill_params only needs a non-null, aligned placeholder
-    if (int rc = fill_params(p, DAE_BF16, M, N, xa ? Bt0 : A0, xa ? ldb0 : lda0, Bt0, ldb0, K0, A1, lda1, Bt1, ldb1, K1, 1)) return rc;
+    {
+        const GemmSegDesc segs2[2] = {{xa ? Bt0 : A0, xa ? ldb0 : lda0, Bt0, ldb0, K0}, {A1, lda1, Bt1, ldb1, K1}};
+        if (int rc = fill_params_n(p, DAE_BF16, M, N, segs2, 2, 1, BN, tra)) return rc;
+    }
     if (int rc = gemm_init()) return rc;
     const bool grad_only = e.opt == DW_GRAD_ONLY;
     if (grad_only) {
@@ -2230,14 +2281,19 @@ int launch_dw_opt(int M, int N, const void* A0, int64_t lda0, const void* Bt0, i
                  gemm_dw_pc<DW_GRAD_ONLY, false>},
                 {gemm_dw_pc<DAE_OPT_SGD, true>, gemm_dw_pc<DAE_OPT_ADAGRAD, true>, gemm_dw_pc<DAE_OPT_MOMENTUM, true>, gemm_dw_pc<DAE_OPT_ADAM, true>,
                  gemm_dw_pc<DW_GRAD_ONLY, true>}};
+            static const dwpc_fn pcs_tr[5] = {gemm_dw_pc<DAE_OPT_SGD, false, false, false, true>, gemm_dw_pc<DAE_OPT_ADAGRAD, false, false, false, true>,
+                                              gemm_dw_pc<DAE_OPT_MOMENTUM, false, false, false, true>, gemm_dw_pc<DAE_OPT_ADAM, false, false, false, true>,
+                                              gemm_dw_pc<DW_GRAD_ONLY, false, false, false, true>};
             static int pc_rc = [] {
                 int rc = 0;
                 for (int v = 0; v < 2; ++v)
                     for (dwpc_fn f : pcs[v])
                         rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS);
+                for (dwpc_fn f : pcs_tr) rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS);
                 return rc;
             }();
             DAE_CHECK_ARG(pc_rc == 0, "dw_pc: hipFuncSetAttribute failed");
+            DAE_CHECK_ARG(!tra || !xa, "dw: the transposed-A form takes dense row-major images (no bit image)");
             GemmParams q = p;
             q.tiles_m = tiles_m; q.tiles_n = tiles_n;
             DwBits xb; memset(&xb, 0, sizeof(xb));
@@ -2246,11 +2302,12 @@ int launch_dw_opt(int M, int N, const void* A0, int64_t lda0, const void* Bt0, i
                 xb.one = host_f2bf(xa->scale);                  // 16-bit image of the scale, round to nearest even (a finite positive factor)
                 q.seg[0].A = nullptr;
             }
-            hipLaunchKernelGGL(pcs[xa ? 1 : 0][e.opt], dim3(8 * per * tiles_n), dim3(PC_THREADS), DW_LDS, st, q, e, M, xb);
+            hipLaunchKernelGGL(tra ? pcs_tr[e.opt] : pcs[xa ? 1 : 0][e.opt], dim3(8 * per * tiles_n), dim3(PC_THREADS), DW_LDS, st, q, e, M, xb);
             DAE_CHECK_LAUNCH();
             return 0;
         }
     }
+    DAE_CHECK_ARG(!tra, "dw: the transposed-A form exists on the 160 x 128 kernel only (ask dw_pc_taken first)");
     typedef void (*dwo_fn)(GemmParams, OptEpi);
     static const dwo_fn fns[4] = {gemm_dw_opt<DAE_OPT_SGD>, gemm_dw_opt<DAE_OPT_ADAGRAD>, gemm_dw_opt<DAE_OPT_MOMENTUM>, gemm_dw_opt<DAE_OPT_ADAM>};
     constexpr int ldsb = DWO_LDS > lds_bytes_for(2) ? DWO_LDS : lds_bytes_for(2);
@@ -2270,7 +2327,8 @@ int launch_dw_opt(int M, int N, const void* A0, int64_t lda0, const void* Bt0, i
 // dW GEMM + optimizer in split-bf16 mode: the contraction runs over up to 5 K segments (x~^T.delta1_hi, x~^T.delta1_lo, delta2^T_hi.h^T_hi,
 // delta2^T_hi.h^T_lo, delta2^T_lo.h^T_hi) and the epilogue also writes the lo images of both shadows (e.W_lo2, e.Wt_lo2).  One-round
 // 160 x 128 kernel only (the shapes whose tiles fill the chip once); other shapes are refused for now.
-int launch_dw_opt_n(int M, int N, const GemmSegDesc* segs_in, int nsegs_in, const OptEpi& e, hipStream_t st, bool pair) {
+int launch_dw_opt_n(int M, int N, const GemmSegDesc* segs_in, int nsegs_in, const OptEpi& e, hipStream_t st, bool pair, bool tra) {
+    if (tra) pair = false;        // (the transposed-A form walks plain segments)
     // pair: consecutive non-empty segments that share their A operand (x~^T . [delta1^T_hi ; delta1^T_lo], delta2^T_hi . [h^T_hi ; h^T_lo]) become ONE
     // segment with two B operands (GemmParams::bt2): the kernel streams the A tile once and multiplies it with both B tiles of the stage
     DAE_CHECK_ARG(segs_in && nsegs_in >= 1 && nsegs_in <= GEMM_MAX_SEG, "dw_opt_n: %d K segments (1..%d)", nsegs_in, GEMM_MAX_SEG);
@@ -2288,7 +2346,7 @@ int launch_dw_opt_n(int M, int N, const GemmSegDesc* segs_in, int nsegs_in, cons
     }
     DAE_CHECK_ARG(nsegs >= 1, "dw_opt_n: every K segment is empty");
     GemmParams p;
-    if (int rc = fill_params_n(p, DAE_BF16, M, N, segs, nsegs, 1)) return rc;
+    if (int rc = fill_params_n(p, DAE_BF16, M, N, segs, nsegs, 1, BN, tra)) return rc;
     DAE_CHECK_ARG(p.nseg == nsegs, "dw_opt_n: segment bookkeeping");
     bool any_pair = false;
     for (int i = 0; i < nsegs; ++i) { p.bt2[i] = (const char*)second[i]; any_pair = any_pair || second[i]; }
@@ -2314,8 +2372,12 @@ int launch_dw_opt_n(int M, int N, const GemmSegDesc* segs_in, int nsegs_in, cons
                                        gemm_dw_pc<DAE_OPT_MOMENTUM, false, true, true>, gemm_dw_pc<DAE_OPT_ADAM, false, true, true>,
                                        gemm_dw_pc<DW_GRAD_ONLY, false, true, true>}};
     static_assert(DW_GRAD_ONLY == 4, "the gradient-only instantiation sits at index 4");
+    static const dwpc_fn x3s_tr[5] = {gemm_dw_pc<DAE_OPT_SGD, false, true, false, true>, gemm_dw_pc<DAE_OPT_ADAGRAD, false, true, false, true>,
+                                      gemm_dw_pc<DAE_OPT_MOMENTUM, false, true, false, true>, gemm_dw_pc<DAE_OPT_ADAM, false, true, false, true>,
+                                      gemm_dw_pc<DW_GRAD_ONLY, false, true, false, true>};
     static int rc3 = [] {
         int rc = 0;
+        for (dwpc_fn f : x3s_tr) rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS);
         for (dwpc_fn f : x3s[0]) rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, DW_LDS);
         for (dwpc_fn f : x3s[1]) rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, DW_RING2);
         return rc;
@@ -2324,7 +2386,7 @@ int launch_dw_opt_n(int M, int N, const GemmSegDesc* segs_in, int nsegs_in, cons
     GemmParams q = p;
     q.tiles_m = tiles_m; q.tiles_n = tiles_n;
     DwBits xb; memset(&xb, 0, sizeof(xb));
-    hipLaunchKernelGGL(x3s[any_pair ? 1 : 0][e.opt], dim3(8 * per * tiles_n), dim3(PC_THREADS), any_pair ? DW_RING2 : DW_LDS, st, q, e, M, xb);
+    hipLaunchKernelGGL(tra ? x3s_tr[e.opt] : x3s[any_pair ? 1 : 0][e.opt], dim3(8 * per * tiles_n), dim3(PC_THREADS), any_pair ? DW_RING2 : DW_LDS, st, q, e, M, xb);
     DAE_CHECK_LAUNCH();
     return 0;
 }

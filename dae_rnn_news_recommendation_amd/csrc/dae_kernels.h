@@ -115,6 +115,8 @@ struct EncCsrLaunch {
     int w32_cols;                  // w_f32: 64 (default: one 2.6 MB slice per XCD L2) or 128 columns per workgroup
     void* h_t2;                    // split-bf16 mode: lo image of h^T [Hp x ldht] (h_t holds hi); NULL otherwise
     void* xct2;                    // split-bf16 mode, x~ not exact in bf16: lo image of x~^T (layout of xct, pre-zeroed); NULL otherwise
+    int xct_rm;                    // 1: `xct` (and xct2) is the ROW-MAJOR image x~ [Bp x ldt] instead of x~^T [Fp x ldt] -- entry (i, col) at i * ldt + col: the operand
+                                   // layout of the dW kernel's transposed-A form (gemm_dw_pc<TRA>), which reads its A tiles [k = batch][m = feature]
 };
 int launch_encode_csr(const EncCsrLaunch& q, hipStream_t st);
 size_t encode_csr_lds_bytes(int dtype, int w_f32, int w32_cols, int64_t ldxb);
@@ -133,6 +135,7 @@ struct ClearArgs {            // CSR rows whose entries were scattered into x~^T
     const int64_t* indptr; const int32_t* indices; const int32_t* row_idx; int B, F; void* xct; int64_t ldt; int es;
     uint32_t* xtb; int64_t ldxt;   // the bit image of x~^T instead of the dense one (xct == NULL): clears the word holding bit (i, col)
     void* xct2;                    // split-bf16 mode with inexact x~: the lo image of x~^T, cleared alongside (bf16; NULL otherwise)
+    int rm;                        // 1: xct / xct2 are row-major x~ [Bp x ldt] (entry (i, col) at i * ldt + col), see EncCsrLaunch::xct_rm
 };
 // K8 (middle), see dae_dh_finish; delta1_lo: optional ROW-MAJOR delta1 [Bp x ldh] in `dtype` (operand of the sparse x~^T.delta1)
 // K9 on the whole of W (+ biases): dae_opt_step with the lo images of the split-bf16 shadows (NULL outside that mode)
@@ -177,9 +180,11 @@ bool dw_bits_fits(int M, int N, int Bp);
 bool dw_x3_fits(int M, int N, int Bp);       // split-bf16 mode: can launch_dw_opt_n (one 160 x 128 tile per CU, whole 64-deep K tiles) run the shape?
 // xa != NULL: segment 0 is x~^T (bit image, A0 ignored) . Bt0 = delta1^T; segment 1 = delta2^T . h^T as usual
 int launch_dw_opt(int M, int N, const void* A0, int64_t lda0, const void* Bt0, int64_t ldb0, int K0, const void* A1, int64_t lda1,
-                  const void* Bt1, int64_t ldb1, int K1, const OptEpi& e, hipStream_t st, const DwBitsArgs* xa = nullptr);
+                  const void* Bt1, int64_t ldb1, int K1, const OptEpi& e, hipStream_t st, const DwBitsArgs* xa = nullptr, bool tra = false);
+// tra: the A operands are ROW-MAJOR batch images [K x M] (x~, delta2: lda = their leading dimension) read through transposing LDS reads (gemm_dw_pc<TRA>)
+bool dw_pc_taken(int M, int N, int K0, int K1, bool grad_only);
 // split-bf16 mode (e.Wt_lo2 set, e.W_lo2 optional); pair: segments that share their A operand run as paired stages (one A tile, two B tiles)
-int launch_dw_opt_n(int M, int N, const GemmSegDesc* segs, int nsegs, const OptEpi& e, hipStream_t st, bool pair = false);
+int launch_dw_opt_n(int M, int N, const GemmSegDesc* segs, int nsegs, const OptEpi& e, hipStream_t st, bool pair = false, bool tra = false);
 void set_use_glds(int nst);
 void set_gather_tile(int v);          // dense gather tile: bit 0 = 128 features (else 64), bit 1 = 128 rows (else 64)
 int launch_gemm_trace(int dtype, int M, int N, const void* A0, int64_t lda0, const void* Bt0, int64_t ldb0, int K0, const void* A1,

@@ -171,3 +171,27 @@ def test_gram_on_64x64_tiles_single_slab_equals_split_k_form(dtype, strategy, B)
             assert abs(sa[4] - sb[4]) <= 2 and sa[5] == sb[5]            # positive-triplet count (near-ties), N_valid
             assert abs(sa[2] - ra["triplet_loss"]) <= 1e-4 * abs(ra["triplet_loss"])
             assert _rel(dWa, np.asarray(dWb, np.float64)) < 2e-5
+
+
+@pytest.mark.parametrize("dtype,dense,phase,opt,B", [("f16x2", False, 0, "gradient_descent", 150), ("f16x2", True, 0, "adam", 150), ("bf16", False, 1, "momentum", 200),
+                                                     ("f16", False, 0, "ada_grad", 130), ("f16x2", False, 1, "gradient_descent", 64)])
+def test_dw_transposed_a_form_equals_transposed_images(dtype, dense, phase, opt, B):
+    """Plan option dw_tr (default: on for dense train sets, where it saves 38 us per step at F = 50000; off for CSR input, where it costs 3-5 us): the dW kernel consumes x~ and delta2 ROW-MAJOR through transposing LDS reads (gemm_dw_pc<TRA>) -- the decode stores
+    delta2 once, the CSR scatter / dense gather write x~ instead of x~^T.  Against dw_tr = 0 (transposed operand images): the same MFMA products in the same K
+    order, so gradients and updated parameters are bit-identical."""
+    from dae_rnn_news_recommendation_amd import _lib as L
+    L.load("f16" if dtype.startswith("f16") else "bf16").dae_set_glds(-5)          # the 160 x 128 kernel for every grid that fits one round (small test shapes)
+    try:
+        kw = dict(steps=3, seed=29, N=500, F=1000, H=200, B=B, dense=dense, phase=phase)
+        a, ra, pa = _run_case(dtype, "batch_all", "cross_entropy" if not dense else "mean_squared", ("sigmoid", "sigmoid") if not dense else ("tanh", "none"),
+                              opt, options={"dw_tr": 1}, **kw)
+        b, rb, pb = _run_case(dtype, "batch_all", "cross_entropy" if not dense else "mean_squared", ("sigmoid", "sigmoid") if not dense else ("tanh", "none"),
+                              opt, options={"dw_tr": 0}, **kw)
+    finally:
+        L.load("f16" if dtype.startswith("f16") else "bf16").dae_set_glds(-4)
+    for (r, sa, dWa, dbha, dbva), (_, sb, dWb, dbhb, dbvb) in zip(a, b):
+        assert np.array_equal(sa[:5], sb[:5]), (sa, sb)
+        assert np.array_equal(dWa, dWb) and np.array_equal(dbha, dbhb) and np.array_equal(dbva, dbvb)
+    assert _rel(a[0][2], a[0][0]["dW"]) < (2e-2 if dtype == "bf16" else 3e-3)            # ... and both at the oracle (first step: identical weights)
+    for u, v in zip(pa, pb):
+        assert np.array_equal(u, v)

@@ -3,7 +3,7 @@
 
 The fragment reads are inline-asm ds_read_b128 and the waits are inline-asm `s_waitcnt lgkmcnt(N)`; hipcc's own
 scoreboard does not see them, and register-only MFMAs may be moved across an asm wait.  This script compiles the
-file to gfx950 assembly and, for every basic block that contains MFMAs fed by ds_read_b128 results, replays the
+file to gfx950 assembly and, for every basic block that contains MFMAs fed by ds_read_b128 / ds_read_b64_tr_b16 results, replays the
 in-order LDS return rule: after `s_waitcnt lgkmcnt(N)` all but the youngest N reads have landed.  Every MFMA
 source register must come from a read that has landed.  Exit code 1 on any violation.
 
@@ -48,7 +48,7 @@ def main():
         tok = t.replace(",", " ").split()
         if not tok:
             continue
-        if tok[0] == "ds_read_b128":
+        if tok[0] in ("ds_read_b128", "ds_read_b64_tr_b16"):      # (the transposing reads of gemm_dw_pc<TRA>: two 64-bit halves per A fragment)
             pending.append(regs(tok[1]))
         elif tok[0] == "s_waitcnt":
             m = re.search(r"lgkmcnt\((\d+)\)", t)
