@@ -195,7 +195,15 @@ class DenoisingAutoencoder(object):
         for every input kind, with or without a train set to look at (fit, load_model -> transform: one arithmetic).  'bf16x3' (split-bf16, three
         terms) and 'fp32' (exact-fp32 MFMA) hold the gate too and are slower; plain 'bf16' / 'f16' are faster, outside the gate and
         must be asked for."""
-        return L.AUTO_PRECISION if self.precision == 'auto' else self.precision
+        if self.precision != 'auto':
+            return self.precision
+        # fp16 images hold |x| <= 65504 (and the corrupted values scale * x with them): count data far outside tf-idf / binary BoW takes the split-bf16
+        # mode, whose images have the fp32 range -- the only input-dependent part of 'auto'
+        if data is not None and L.PRECISIONS[L.AUTO_PRECISION][0] == "f16":
+            vals = data if isinstance(data, np.ndarray) else getattr(data, "data", None)
+            if vals is not None and np.size(vals) and float(np.max(np.abs(vals))) > 1.0e4:
+                return 'bf16x3'
+        return L.AUTO_PRECISION
 
     def _build_engine(self, n_features, max_batch, dp_world=1, data=None):
         from ..engine import Engine                                # raises loudly without a GPU / the library

@@ -453,7 +453,13 @@ int      dae_plan_sync_shadows(dae_plan* p, void* stream);
  * h^T_lo), 7 dW (delta2^T_lo, h^T_hi), 8 / 9 dense-input encode (x~_hi, W^T_lo) / (x~_lo, W^T_hi), 10 lo images of valued inputs (clean rows, x~^T); default
  * all (bf16 storage) or bits 0, 2, 8 (fp16 storage); a lo image whose terms are all off is neither written nor allocated), "op_scale_log2" (16-bit modes:
  * the images of delta2, delta2^T, Gs and delta1^T hold 2^value times the quantity and the consuming epilogues divide it out; default 0 for bf16 storage,
- * log2 of the largest power of two <= 16 * max_batch (at most 14) for fp16 storage, whose normal range ends at 6.1e-5).  Unknown names are an error. */
+ * log2 of the largest power of two <= 16 * max_batch (at most 14) for fp16 storage, whose normal range ends at 6.1e-5), "gram64" (16-bit modes, before
+ * dae_plan_bind: the split Gram matrix on 64 x 64 tiles over the whole K, ONE slab -- default 1; 0 = 128 x 128 tiles, split-K slabs summed by the miner),
+ * "decode_bn" (16-bit modes, before dae_plan_bind: tile width of the decode kernel, 64 | 128 | 0 = by tile count: 128 once the 64-column tiles are more than
+ * four rounds of the chip, i.e. F = 50000), "dw_tr" (-1 | 0 | 1: the dW kernel reads x~ and delta2 row-major through transposing LDS reads, so that
+ * delta2^T / x~^T are never written; -1 = for dense train sets only, where it was measured faster), "dw_rounds" (process-wide: rounds of the chip the fused
+ * 160 x 128 dW + optimizer kernel may take, default 16 for the split modes / 1 otherwise), "pad_skip" (process-wide, default 1: the decode epilogue does not
+ * evaluate the loss of 32-row blocks that are pure batch padding).  Unknown names are an error. */
 int      dae_plan_set_option(dae_plan* p, const char* name, int32_t value);
 /* 16-bit storage format the loaded library was built for: 0 = bfloat16 (libdae_hip.so), 1 = IEEE fp16 (libdae_hip_f16.so: the same sources compiled with
  * -DDAE_F16=1; every 16-bit image and the MFMA that multiplies it switch together).  DAE_BF16 / DAE_BF16X3 name "the 16-bit format" in either build. */

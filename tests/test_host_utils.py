@@ -204,3 +204,18 @@ def test_class_sort_batches_keeps_every_batch_as_a_set():
     # stable: rows of one class keep their shuffled order
     first = out[:250]; want = [r for c in range(5) for r in order[:250] if lab[r] == c]
     assert list(first) == want
+
+
+def test_auto_precision_resolution_is_input_aware_only_for_the_fp16_range(tmp_path):
+    """precision='auto' = _lib.AUTO_PRECISION (f16x2) with or without a train set to look at; data beyond the fp16 range takes the split-bf16 mode."""
+    from scipy import sparse
+    from dae_rnn_news_recommendation_amd import _lib as L
+    from dae_rnn_news_recommendation_amd.autoencoder import DenoisingAutoencoder
+    m = DenoisingAutoencoder(model_name="p", main_dir="p", results_root=str(tmp_path) + "/", verbose=False)
+    assert m._resolve_precision(None) == L.AUTO_PRECISION == "f16x2"
+    x = sparse.random(20, 30, density=0.2, format="csr", dtype=np.float32, random_state=np.random.RandomState(0))
+    assert m._resolve_precision(x) == "f16x2" and m._resolve_precision(x.toarray()) == "f16x2"
+    big = x.copy(); big.data[:] = 3.0e4
+    assert m._resolve_precision(big) == "bf16x3" and m._resolve_precision(big.toarray()) == "bf16x3"
+    m2 = DenoisingAutoencoder(model_name="p2", main_dir="p2", results_root=str(tmp_path) + "/", verbose=False, precision="fp32")
+    assert m2._resolve_precision(big) == "fp32"
