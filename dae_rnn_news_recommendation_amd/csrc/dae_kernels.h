@@ -52,7 +52,9 @@ enum : uint32_t {
     X3T_ENC_XLO = 1u << 9,    // dense-input encode (x~_lo, W^T_hi)
     X3T_XV = 1u << 10,        // valued input: lo images of the clean rows x (decode epilogue) and of x~^T (dW: (x~^T_lo, delta1^T_hi))
     X3T_ALL = (1u << 11) - 1,
-    X3T_F16_DEFAULT = X3T_DEC_WLO | X3T_DH_WLO | X3T_ENC_WLO,
+    // (the dense-input encode's (x~, W^T_lo) term is NOT in the fp16 default: the 20-step curve of c4 does not move without it -- cost 7.0e-6 / triplet
+    //  1.7e-5 against 7.6e-6 / 1.3e-5 with it, profiles/r05_c4_terms.txt -- and the encode GEMM at F = 50000 takes 114 instead of 191 us)
+    X3T_F16_DEFAULT = X3T_DEC_WLO | X3T_DH_WLO,
 };
 
 struct LabelJob;

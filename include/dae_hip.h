@@ -451,7 +451,7 @@ int      dae_plan_sync_shadows(dae_plan* p, void* stream);
  * segment after the other), "x3_terms" (split mode, before dae_plan_bind only: bit mask of the lo product terms that are multiplied -- bit 0 decode
  * (h_hi, W_lo), 1 decode (h_lo, W_hi), 2 dh (delta2_hi, W^T_lo), 3 dh (delta2_lo, W^T_hi), 4 dh (Gs, h^T_lo), 5 dW (x~^T, delta1^T_lo), 6 dW (delta2^T_hi,
  * h^T_lo), 7 dW (delta2^T_lo, h^T_hi), 8 / 9 dense-input encode (x~_hi, W^T_lo) / (x~_lo, W^T_hi), 10 lo images of valued inputs (clean rows, x~^T); default
- * all (bf16 storage) or bits 0, 2, 8 (fp16 storage); a lo image whose terms are all off is neither written nor allocated), "op_scale_log2" (16-bit modes:
+ * all (bf16 storage) or bits 0 and 2 (fp16 storage); a lo image whose terms are all off is neither written nor allocated), "op_scale_log2" (16-bit modes:
  * the images of delta2, delta2^T, Gs and delta1^T hold 2^value times the quantity and the consuming epilogues divide it out; default 0 for bf16 storage,
  * log2 of the largest power of two <= 16 * max_batch (at most 14) for fp16 storage, whose normal range ends at 6.1e-5), "gram64" (16-bit modes, before
  * dae_plan_bind: the split Gram matrix on 64 x 64 tiles over the whole K, ONE slab -- default 1; 0 = 128 x 128 tiles, split-K slabs summed by the miner),

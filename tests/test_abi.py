@@ -96,7 +96,7 @@ def test_argument_errors_are_reported_without_a_gpu():
         sizes[terms] = (l16.dae_plan_workspace_bytes(plan), info[7])
         l16.dae_plan_destroy(plan)
     assert sizes[_lib.X3T_ALL][0] - sizes[None][0] > 60 << 20, sizes
-    assert (sizes[None][1] >> 1) & _lib.X3T_ALL == (1 | 4 | 256) and (sizes[None][1] >> 16) == 13      # default terms; op_scale 2^13 at B = 800
+    assert (sizes[None][1] >> 1) & _lib.X3T_ALL == (1 | 4) and (sizes[None][1] >> 16) == 13      # default terms; op_scale 2^13 at B = 800
     assert l16.dae_plan_set_option(None, b"x3_terms", 1) != 0                     # null plan: an argument error, not a crash
 
 

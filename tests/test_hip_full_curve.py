@@ -30,7 +30,7 @@ DROPPED = {"x3_dec_wlo": 0, "x3_dh_hlo": 0}
 # f16x2: the fp16 build's parity mode -- fp16 operand images, only W kept as hi + lo (lo terms: decode (h, W_lo), dh (delta2, W^T_lo)); the CPU replay
 # (tools/precision_study.py --golden --scheme W=f16split) predicted cost 1.4e-5 / triplet 6.5e-5.  f16x2-h-split adds the three h terms (decode (h_lo, W),
 # dh (Gs, h^T_lo), dW (delta2^T, h^T_lo)): predicted 1.0e-5 / 2.75e-5 -- the fallback segment list should the two-term form leave the gate
-F16_WH = {"x3_terms": 1 | 4 | 256 | 2 | 16 | 64}
+F16_WH = {"x3_terms": 1 | 4 | 2 | 16 | 64}
 
 
 @pytest.mark.skipif(not os.path.exists(PATH), reason="tests/golden/full_curve_c2.npz not generated")
