@@ -1598,10 +1598,97 @@ int launch_gram64(const void* hcat_a, const void* hcat_b, int Bp, int Hp, float*
     return 0;
 }
 
+// Paired form of the same loop for the split modes' two W terms, z2 = h.W_hi^T + h.W_lo^T: both K segments multiply the SAME A tile (h), so a stage
+// holds ONE A tile and the B tiles of BOTH segments (16 + 8 + 8 KiB).  Per K tile pair a wave then issues 8 LDS-DMA pieces and 16 fragment reads for its
+// 16 MFMAs instead of 12 and 24 -- the decode's K loop is bound by exactly those two (LDS bandwidth and LDS-DMA issue) -- at one barrier pair
+// instead of two.  64 KiB of LDS per workgroup: two workgroups per CU instead of three.  The accumulation order differs from the unpaired walk
+// ((hi, lo) interleaved per K tile instead of all hi then all lo): same products, fp32 sums in another order.
+template <typename T>
+__device__ __forceinline__ void mainloop_n64_pair(const GemmParams& p, int tm, int tn, char* lds, f32x16 (&acc)[2][1]) {
+    constexpr int BT = 64 * BKB;                       // one B tile: 8 KiB
+    constexpr int STAGE = TILE_BYTES + 2 * BT;         // 32 KiB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int row0_m = tm * BM, row0_n = tn * 64;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+    const int nk = p.seg[0].ktiles;                    // both segments: the same K extent (checked by the launcher)
+    if (nk <= 0) return;
+    uint32_t voA[4], voB[2];
+    const uint32_t lda = (uint32_t)p.seg[0].lda_b, ldb = (uint32_t)p.seg[0].ldb_b;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (i * 4 + wave) * 8 + (lane >> 3);
+        voA[i] = (uint32_t)(row0_m + row) * lda + (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (i * 4 + wave) * 8 + (lane >> 3);
+        voB[i] = (uint32_t)(row0_n + row) * ldb + (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) << 4);
+    }
+    const char *gA = p.seg[0].A, *gB0 = p.seg[0].Bt, *gB1 = p.seg[1].Bt;
+    auto dma_stage = [&](char* slot) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gA + voA[i]),
+                                             (__attribute__((address_space(3))) void*)(slot + (i * 4 + wave) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gB0 + voB[i]),
+                                             (__attribute__((address_space(3))) void*)(slot + TILE_BYTES + (i * 4 + wave) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gB1 + voB[i]),
+                                             (__attribute__((address_space(3))) void*)(slot + TILE_BYTES + BT + (i * 4 + wave) * 1024), 16, 0, 0);
+        }
+        gA += BKB; gB0 += BKB; gB1 += BKB;
+    };
+    const int r = lane & 31, g = lane >> 5;
+    const int swz = (r >> 1) & 7;
+    const uint32_t lbase = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)lds;
+    const uint32_t offa = (wm * 64 + r) * BKB, offb = TILE_BYTES + (wn * 32 + r) * BKB;
+    uint32_t so[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) so[kk] = (uint32_t)(((kk * 2 + g) ^ swz) << 4);
+    dma_stage(lds);
+    for (int i = 0; i < nk; ++i) {
+        if (i + 1 < nk) { dma_stage(lds + ((i + 1) & 1) * STAGE); wait_vm<8>(); }
+        else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();                  // stage i landed for every wave
+        asm volatile("" ::: "memory");
+        const uint32_t sb = lbase + (i & 1) * STAGE;
+        i32x4 fa[4][2], fb0[4], fb1[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            fa[kk][0] = lds_read_b128(sb + offa + so[kk]);
+            fa[kk][1] = lds_read_b128_off4096(sb + offa + so[kk]);
+            fb0[kk] = lds_read_b128(sb + offb + so[kk]);
+            fb1[kk] = lds_read_b128(sb + offb + BT + so[kk]);
+        }
+#define DAE_N64P_GROUP(KK, CNT)                                  \
+    asm volatile("s_waitcnt lgkmcnt(" #CNT ")" ::: "memory");    \
+    __builtin_amdgcn_sched_barrier(0);                           \
+    Mma<T>::run(fa[KK][0], fb0[KK], acc[0][0]);                  \
+    Mma<T>::run(fa[KK][1], fb0[KK], acc[1][0]);                  \
+    Mma<T>::run(fa[KK][0], fb1[KK], acc[0][0]);                  \
+    Mma<T>::run(fa[KK][1], fb1[KK], acc[1][0]);
+        DAE_N64P_GROUP(0, 12)
+        DAE_N64P_GROUP(1, 8)
+        DAE_N64P_GROUP(2, 4)
+        DAE_N64P_GROUP(3, 0)
+#undef DAE_N64P_GROUP
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();                  // every wave has read slot i & 1: iteration i+1 may refill it
+        asm volatile("" ::: "memory");
+    }
+}
+
 constexpr float CE_FAST_ZMAX = 14.0f;               // sigmoid(14) = 1 - 8.3e-7: five fp32 ulps from saturation
 constexpr int DECODE_NST = 2;
-template <typename T, int LOSS, int ACT, bool XBITS = false, int BN_T = 128, bool RES = false>   // RES (split-bf16 mode): also the lo images of delta2 / delta2^T
-__global__ __launch_bounds__(GEMM_THREADS, DecGeo<BN_T>::WG_PER_CU) void gemm_decode_loss(GemmParams p, DecodeEpi e) {
+template <typename T, int LOSS, int ACT, bool XBITS = false, int BN_T = 128, bool RES = false, bool PAIRD = false>   // RES (split-bf16 mode): also the lo images of delta2 / delta2^T; PAIRD: mainloop_n64_pair
+__global__ __launch_bounds__(GEMM_THREADS, PAIRD ? 2 : DecGeo<BN_T>::WG_PER_CU) void gemm_decode_loss(GemmParams p, DecodeEpi e) {
+    static_assert(!PAIRD || (BN_T == 64 && sizeof(T) == 2 && !RES), "the paired K loop exists for the 64-column 16-bit kernel");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     using Geo = DecGeo<BN_T>;
     constexpr int NTB = Geo::NTB, WCOLS = Geo::WCOLS, P0 = Geo::P0, P1 = Geo::P1;
@@ -1650,6 +1737,7 @@ __global__ __launch_bounds__(GEMM_THREADS, DecGeo<BN_T>::WG_PER_CU) void gemm_de
     const int vblk = e.no_pad_skip ? 4 : min(4, (e.B - tm * BM + 31) >> 5);
     const bool vb[2] = {2 * wm < vblk, 2 * wm + 1 < vblk};
     if constexpr (BN_T == 128) gemm_mainloop<T, DECODE_NST>(p, tm, tn, kt0, kt1, lds, acc);
+    else if constexpr (PAIRD) mainloop_n64_pair<T>(p, tm, tn, lds, acc);
     else mainloop_n64<T>(p, tm, tn, lds, acc);
     // (the K loop multiplies the padding blocks too: branching around MFMAs would put them in basic blocks of their own, out of reach of the static check
     //  of the hand-placed LDS waits, tools/check_gemm_asm.py -- measured worth < 1 % of the step; the EPILOGUE below skips their loss evaluation)
@@ -2104,6 +2192,17 @@ static decode_fn decode_kernel_wide(int loss, int act, bool xbits) {
 #undef DAE_DKW
     return nullptr;
 }
+// the 64-column kernel with the paired K loop (two K segments that share their A operand: the split modes' h.W_hi + h.W_lo)
+static decode_fn decode_kernel_pair(int loss, int act, bool xbits) {
+#define DAE_DKP(LV, AV)                                                                                       \
+    if (loss == LV && act == AV)                                                                              \
+        return xbits ? gemm_decode_loss<bf16_t, LV, AV, true, DECODE_BN_BF16, false, true> : gemm_decode_loss<bf16_t, LV, AV, false, DECODE_BN_BF16, false, true>;
+    DAE_DKP(0, 0) DAE_DKP(0, 1) DAE_DKP(0, 2) DAE_DKP(1, 0) DAE_DKP(1, 1) DAE_DKP(1, 2) DAE_DKP(2, 0) DAE_DKP(2, 1) DAE_DKP(2, 2)
+#undef DAE_DKP
+    return nullptr;
+}
+constexpr int DECODE_PAIR_LDS = 2 * (TILE_BYTES + 2 * 64 * BKB) > DecGeo<DECODE_BN_BF16>::EPI_BYTES ? 2 * (TILE_BYTES + 2 * 64 * BKB) : DecGeo<DECODE_BN_BF16>::EPI_BYTES;
+static int g_decode_pair = 0;      // dae_set_glds(-13) off / (-14) on; plan option "decode_pair"
 template <typename T> static decode_fn decode_kernel(int loss, int act) {
 #define DAE_DK(LV, AV) if (loss == LV && act == AV) return gemm_decode_loss<T, LV, AV, false, (sizeof(T) == 2 ? DECODE_BN_BF16 : BN)>;
     DAE_DK(0, 0) DAE_DK(0, 1) DAE_DK(0, 2) DAE_DK(1, 0) DAE_DK(1, 1) DAE_DK(1, 2) DAE_DK(2, 0) DAE_DK(2, 1) DAE_DK(2, 2)
@@ -2415,6 +2514,23 @@ int launch_decode_loss_n(int dtype, int Bp, int Fp, const GemmSegDesc* segs, int
         DAE_CHECK_ARG(dtype == DAE_BF16 && e.ldxb >= Fp / 32 && ((uintptr_t)e.x_bits % 4) == 0, "decode_loss: bad x bit image");
         k = decode_kernel_xbits(e.loss_func, e.dec_act);
     }
+    // two K segments over the same A operand and K extent (the split modes' decode): the paired K loop
+    bool paird = false;
+    if (g_decode_pair && dtype == DAE_BF16 && !wide && !(e.delta2_2 || e.delta2_t2 || e.x2) && p.nseg == 2 && p.seg[0].A == p.seg[1].A &&
+        p.seg[0].lda_b == p.seg[1].lda_b && p.seg[0].ldb_b == p.seg[1].ldb_b && p.seg[0].ktiles == p.seg[1].ktiles) {
+        paird = true;
+        k = decode_kernel_pair(e.loss_func, e.dec_act, e.x_bits != nullptr);
+        static int pair_rc = [] {
+            int rc = 0;
+            for (int l = 0; l < 3; ++l)
+                for (int a = 0; a < 3; ++a)
+                    for (int x = 0; x < 2; ++x)
+                        rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(decode_kernel_pair(l, a, x != 0)),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, DECODE_PAIR_LDS);
+            return rc;
+        }();
+        DAE_CHECK_ARG(pair_rc == 0, "decode_loss: hipFuncSetAttribute failed");
+    }
     if (e.op_scale == 0.f) e.op_scale = 1.f;
     e.no_pad_skip = g_pad_skip ? 0 : 1;
     if (wide) {
@@ -2452,7 +2568,7 @@ int launch_decode_loss_n(int dtype, int Bp, int Fp, const GemmSegDesc* segs, int
     }
     dim3 grid(nblocks), block(GEMM_THREADS);
     static_assert(DecGeo<DECODE_BN_BF16>::LDS_BYTES >= 64 * 65 * 4 && DecGeo<BN>::LDS_BYTES >= 64 * 65 * 4, "rider tile must fit the decode LDS");
-    hipLaunchKernelGGL(k, grid, block, (dtype == DAE_BF16 && !wide) ? DecGeo<DECODE_BN_BF16>::LDS_BYTES : DecGeo<BN>::LDS_BYTES, st, p, e);
+    hipLaunchKernelGGL(k, grid, block, paird ? DECODE_PAIR_LDS : ((dtype == DAE_BF16 && !wide) ? DecGeo<DECODE_BN_BF16>::LDS_BYTES : DecGeo<BN>::LDS_BYTES), st, p, e);
     DAE_CHECK_LAUNCH();
     return 0;
 }
@@ -2710,6 +2826,8 @@ void set_use_glds(int nst) {
     if (nst == -6) { g_w8 = 0; return; }             // A/B: never the 256 x 256 / 8-MFMA-wave kernel
     if (nst == -7) { g_w8 = 1; return; }
     if (nst <= -100 && nst > -1000) { g_dw_rounds = g_dw_rounds_split = (-nst - 100 < 1 ? 1 : -nst - 100); return; }    // rounds of the chip the 160 x 128 dW kernel may take
+    if (nst == -13) { g_decode_pair = 0; return; }
+    if (nst == -14) { g_decode_pair = 1; return; }
     if (nst == -11) { g_pad_skip = 0; return; }
     if (nst == -12) { g_pad_skip = 1; return; }
     if (nst == -9) { g_pc_vec = 0; return; }         // A/B: gemm_nt_pc stores its tile as dwords straight from the accumulators

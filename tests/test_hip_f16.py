@@ -195,3 +195,22 @@ def test_dw_transposed_a_form_equals_transposed_images(dtype, dense, phase, opt,
     assert _rel(a[0][2], a[0][0]["dW"]) < (2e-2 if dtype == "bf16" else 3e-3)            # ... and both at the oracle (first step: identical weights)
     for u, v in zip(pa, pb):
         assert np.array_equal(u, v)
+
+
+@pytest.mark.parametrize("dtype,loss_func,acts,strategy", [("f16x2", "cross_entropy", ("sigmoid", "sigmoid"), "batch_all"), ("f16x2", "mean_squared", ("tanh", "none"), "none"),
+                                                          ("f16x2", "cosine_proximity", ("sigmoid", "sigmoid"), "batch_hard")])
+def test_decode_paired_k_loop_equals_unpaired(dtype, loss_func, acts, strategy):
+    """Plan option decode_pair: the decode's two W terms (h.W_hi + h.W_lo) as paired K-loop stages -- one h tile, both W tiles, (hi, lo) products interleaved per
+    K tile -- against the walk over one segment after the other: the same products, fp32 sums in another order."""
+    kw = dict(steps=2, seed=37, N=400, F=900, H=150, B=150)
+    a, ra, pa = _run_case(dtype, strategy, loss_func, acts, "gradient_descent", options={"decode_pair": 1}, **kw)
+    try:
+        b, rb, pb = _run_case(dtype, strategy, loss_func, acts, "gradient_descent", options={"decode_pair": 0}, **kw)
+    finally:
+        pass
+    for (r, sa, dWa, dbha, dbva), (_, sb, dWb, dbhb, dbvb) in zip(a, b):
+        assert np.allclose(sa[:3], sb[:3], rtol=3e-6, atol=0), (sa, sb)
+        assert _rel(dWa, np.asarray(dWb, np.float64)) < 1e-3                          # (a flipped fp16 rounding of delta2 = 2^-12 of one element)
+        assert abs(sa[0] - r["cost"]) <= 5e-5 * abs(r["cost"])
+    for u, v in zip(pa, pb):
+        assert _rel(u, np.asarray(v, np.float64)) < 1e-3
