@@ -47,10 +47,10 @@ if eng.x3:          # the split modes (f16x2 = the product default, bf16x3): fp3
             ("all_reduce of the flat fp32 gradient", lambda: dist.all_reduce(exa.flat)),
             ("dae_plan_apply (whole W + 4 images)", lambda: eng.apply(grad_scale=1.0)),
             ("whole AllReduceExchange.step, 1 bucket", lambda: exa.step(grad_scale=1.0)),
-            ("phase-1 step + all-reduce exchange (1)", lambda: (eng.train_step(idx, labs, stats, phase=1, **kw), exa.step(grad_scale=1.0))),
+            ("phase-1 step + all-reduce exchange (default)", lambda: (eng.train_step(idx, labs, stats, phase=1, **kw), exa.step(grad_scale=1.0))),
             ("apply in 4 row bands (dae_plan_apply_band)", lambda: (eng.begin_apply(), [eng.apply_band(exb.bounds[k], exb.bounds[k + 1]) for k in range(4)])),
             ("whole AllReduceExchange.step, 4 buckets", lambda: exb.step(grad_scale=1.0)),
-            ("phase-1 step + bucketed exchange (default)", lambda: (eng.train_step(idx, labs, stats, phase=1, **kw), exb.step(grad_scale=1.0)))]
+            ("phase-1 step + bucketed exchange (4 buckets)", lambda: (eng.train_step(idx, labs, stats, phase=1, **kw), exb.step(grad_scale=1.0)))]
     print(f"precision {a.precision}  {'piece':40s} {'GPU us':>9s} {'host us/call':>13s}")
     for name, fn in rows:
         g, h = timed(fn)
