@@ -104,6 +104,8 @@ struct dae_plan {
     hipEvent_t ev_dw;                 // recorded right behind the kernel that completes the W gradient (dae_plan_dw_event): a data-parallel
                                       // caller starts its reduce-scatter from here, beside the step's tail kernel
     bool overlap_ok;
+    int overlap_mode;                 // option "overlap" value: 1 = fork the decode before the Gram launch, 2 = after it (the Gram kernel needs a whole CU's LDS per workgroup
+                                      // and cannot start beside resident decode workgroups), 3 = like 2 with the MINER on the side stream and the decode on the step's
     bool sym_ride_ok;                 // Gs = a/Nv (G + G^T) computed by rider workgroups of the decode launch instead of its own launch
     bool miner_order_ok;              // dispatch the batch_all workgroups by descending sweep cost (LabelJob::order)
     int32_t* miner_order;
@@ -361,7 +363,7 @@ extern "C" int dae_plan_set_option(dae_plan* p, const char* name, int32_t value)
     else if (!strcmp(name, "tail")) p->tail_ok = on;
     else if (!strcmp(name, "label_with_encode")) p->label_enc_ok = on;
     else if (!strcmp(name, "ce_literal")) p->ce_literal = on;
-    else if (!strcmp(name, "overlap")) p->overlap_ok = on;
+    else if (!strcmp(name, "overlap")) { p->overlap_ok = on; p->overlap_mode = value; }
     else if (!strcmp(name, "gather_tile")) set_gather_tile(value);        // process-wide: tile shape of the dense gather (A/B measurements)
     else if (!strcmp(name, "dw_rounds")) { DAE_CHECK_ARG(value >= 1 && value <= 64, "plan_set_option: dw_rounds in 1..64"); set_use_glds(-100 - value); }   // process-wide, like miner_pack
     else if (!strcmp(name, "decode_pair")) set_use_glds(on ? -14 : -13);   // process-wide: the decode's two W terms as paired K-loop stages (one h tile, both W tiles)
@@ -757,6 +759,8 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
         // the decode kernel (MFMA + loss epilogue) are independent until dL/dh.  Option "overlap": the decode forks onto the side stream,
         // the chain stays on the step's stream and joins before the dh GEMM (never while profiling: the slot events are per stream)
         const bool overlap = p->overlap_ok && !p->prof && c.triplet == DAE_TRIPLET_BATCH_ALL && !c.pos_triplets_only;
+        const bool gram_first = overlap && p->overlap_mode >= 2;
+        if (gram_first) PROF(PS_GRAM, launch_gram(p, Bp, Hp, dslab, st));
         if (overlap) {
             if (!p->side) {
                 DAE_CHECK_HIP(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
@@ -765,11 +769,13 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
             }
             DAE_CHECK_HIP(hipEventRecord(p->ev_fork, st));
             DAE_CHECK_HIP(hipStreamWaitEvent(p->side, p->ev_fork, 0));
-            RC(decode_section(p->side, false));
-            DAE_CHECK_HIP(hipEventRecord(p->ev_join, p->side));
+            if (p->overlap_mode != 3) {
+                RC(decode_section(p->side, false));
+                DAE_CHECK_HIP(hipEventRecord(p->ev_join, p->side));
+            }
             forked = true;
         }
-        PROF(PS_GRAM, launch_gram(p, Bp, Hp, dslab, st));
+        if (!gram_first) PROF(PS_GRAM, launch_gram(p, Bp, Hp, dslab, st));
         if (c.triplet == DAE_TRIPLET_BATCH_ALL)
             PROF(PS_MINER, launch_batch_all(p->D_slabs, p->s_gram, dslab, Bp, s->labels, B, Bp, 0, B,
                                      (c.pos_triplets_only ? DAE_MINER_POS_ONLY : 0) | (dt == DAE_BF16 ? DAE_MINER_FAST : 0), p->loss_part,
@@ -777,6 +783,10 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
         else
             PROF(PS_MINER, dae_triplet_batch_hard(p->D_slabs, p->s_gram, dslab, Bp, s->labels, B, Bp, p->loss_part, p->cnt_part, p->dw_i32, p->G,
                                       stream));
+        if (overlap && p->overlap_mode == 3) {                // the miner's workgroups are queued first, the decode's fill in beside / behind them
+            RC(decode_section(p->side, false));
+            DAE_CHECK_HIP(hipEventRecord(p->ev_join, p->side));
+        }
         if (!fold_finalize)   // batch_all over all valid triplets: scale comes from label_stats, sums from step_stats
             PROF(PS_TRI_FIN, dae_triplet_finalize(c.triplet, c.pos_triplets_only, B, Bp, c.alpha, p->loss_part, p->cnt_part, p->nvalid,
                                     p->dw_i32, p->role_cnt, p->dw_f32, p->cw, p->tri_scalars, stream));
