@@ -229,3 +229,48 @@ def test_cli_training_values_match_the_oracle(tmp_path, monkeypatch, capsys, pre
             assert abs(float(lines[e][0]) - want["cost"]) <= tol * abs(want["cost"]) + 1e-4
     p = model.get_model_parameters()
     assert np.abs(p["enc_w"] - r["W"]).max() <= (2e-4 if precision == "fp32" else 2e-3) * np.abs(r["W"]).max()
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 3e-5), ("auto", 1e-4)])
+def test_triplet_cli_training_values_match_the_oracle(tmp_path, monkeypatch, capsys, precision, tol):
+    """main_autoencoder_triplet.py on values: the (org, pos, neg) matrices rebuilt exactly as the CLI builds them (same seed, similar_articles on the same labels),
+    then the explicit-triplet fit restated on the oracle's step -- corrupt org / pos / neg in dict order, ONE shared shuffle, fractional batch size
+    (autoencoder_triplet.py:106-146, utils.py:73-91) -- reproduces every epoch's mean cost / AE / triplet loss and the final weights."""
+    import argparse
+    import main_autoencoder as base
+    import main_autoencoder_triplet as cli
+    from dae_rnn_news_recommendation_amd.autoencoder import utils
+    monkeypatch.chdir(tmp_path)
+    seed, epochs, rows, F = 6, 3, 300, 600
+    argv = ["--model_name", "vals3", "--num_epochs", str(epochs), "--train_row", str(rows), "--max_features", str(F), "--verbose", "--verbose_step", "1",
+            "--seed", str(seed), "--similarity", "false", "--precision", precision]
+    model = cli.main(argv)
+    a = base.validate(cli.build_parser().parse_args(argv))
+    np.random.seed(seed)
+    wide = argparse.Namespace(**vars(a)); wide.train_row, wide.validate_row = int(a.train_row * 1.25) + 8, int(a.validate_row * 1.25) + 8
+    X, y = base.load_data(wide)
+    train, _, _, _, _ = cli.build_triplets(X, y, a.train_row, a.validate_row, a.validation)
+    ms = [train[k].tocsr() for k in ("org", "pos", "neg")]
+    N = ms[0].shape[0]; H = F // 20
+    dt = np.float32
+    W = utils.xavier_init(F, H, 1, rng=np.random.RandomState(seed)).astype(dt); bh = np.zeros(H, dt); bv = np.zeros(F, dt)
+    st = O.OptState("gradient_descent", [W.shape, bh.shape, bv.shape], dt)
+    np.random.seed(seed)                                                    # the estimator's constructor re-seeds the legacy stream (reference :72-73)
+    bs = max(round(N * 0.1), 1)
+    assert len(model.history) == epochs
+    for e in range(epochs):
+        xcs = [O.masking_noise(m, 0.3) for m in ms]
+        index = list(range(N)); np.random.shuffle(index)
+        rec = dict(cost=[], ae=[], triplet=[])
+        for i in range(0, N, bs):
+            idx = index[i:i + bs]
+            r = O.explicit_triplet_forward_backward(W, bh, bv, [m[idx].toarray() for m in ms], [x[idx].toarray() for x in xcs], loss_func="cross_entropy",
+                                                    alpha=1.0, dt=dt)
+            O.opt_apply(st, [W, bh, bv], [r["dW"], r["dbh"], r["dbv"]], 0.1, 0.5, dt)
+            rec["cost"].append(float(r["cost"])); rec["ae"].append(float(r["ae_loss"])); rec["triplet"].append(float(r["triplet_loss"]))
+        got = model.history[e]
+        for k in ("cost", "ae", "triplet"):
+            want = float(np.mean(rec[k]))
+            assert abs(got[k] - want) <= tol * abs(want), (e, k, got[k], want)
+    p = model.get_model_parameters()
+    assert np.abs(p["enc_w"] - W).max() <= (2e-4 if precision == "fp32" else 2e-3) * np.abs(W).max()
