@@ -205,9 +205,22 @@ class DenoisingAutoencoder(object):
                 return 'bf16x3'
         return L.AUTO_PRECISION
 
+    def _check_storage_range(self, data):
+        """A model whose engine stores fp16 images (built by load_model() with no data to look at, or asked for by name) refuses values an fp16 image
+        cannot hold instead of encoding infinities: the caller re-creates it with precision='bf16x3' (fp32 range)."""
+        used = self.precision_used or self._resolve_precision(None)
+        if L.PRECISIONS[used][0] != "f16":
+            return
+        vals = data if isinstance(data, np.ndarray) else getattr(data, "data", None)
+        if vals is not None and np.size(vals) and float(np.max(np.abs(vals))) > 6.0e4:
+            raise ValueError("values up to %.3g do not fit the fp16 operand images of precision=%r: use precision='bf16x3' (or 'fp32')"
+                             % (float(np.max(np.abs(vals))), used))
+
     def _build_engine(self, n_features, max_batch, dp_world=1, data=None):
         from ..engine import Engine                                # raises loudly without a GPU / the library
         self.precision_used = self._resolve_precision(data)
+        if data is not None:
+            self._check_storage_range(data)                        # an fp16 mode asked for by name on data it cannot hold: refused, not saturated
         if self.opt not in L.OPT:
             raise ValueError("unknown optimizer %r (reference :444-475 silently builds no train step)" % (self.opt,))
         act = lambda a: a if a in ('sigmoid', 'tanh') else 'none'
@@ -569,6 +582,7 @@ class DenoisingAutoencoder(object):
         from ..engine import Engine
         assert self.engine is not None, "fit() or load_model() first"
         eng = self.engine
+        self._check_storage_range(data)
         n = data.shape[0]
         dev = eng.device
         out = torch.empty((n, eng.H), dtype=torch.float32, device=dev)

@@ -219,3 +219,12 @@ def test_auto_precision_resolution_is_input_aware_only_for_the_fp16_range(tmp_pa
     assert m._resolve_precision(big) == "bf16x3" and m._resolve_precision(big.toarray()) == "bf16x3"
     m2 = DenoisingAutoencoder(model_name="p2", main_dir="p2", results_root=str(tmp_path) + "/", verbose=False, precision="fp32")
     assert m2._resolve_precision(big) == "fp32"
+    # a model that stores fp16 images (load_model() resolves 'auto' with no data to look at) refuses values fp16 cannot hold, loudly
+    m._check_storage_range(x); m._check_storage_range(x.toarray()); m._check_storage_range(big)
+    huge = x.copy(); huge.data[:] = 7.0e4
+    with pytest.raises(ValueError, match="bf16x3"):
+        m._check_storage_range(huge.toarray())
+    with pytest.raises(ValueError, match="bf16x3"):
+        m._check_storage_range(huge)
+    m2._check_storage_range(huge)
+    DenoisingAutoencoder(model_name="p3", main_dir="p3", results_root=str(tmp_path) + "/", verbose=False, precision="bf16x3")._check_storage_range(huge)
