@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Where the data-parallel step form spends its time WITHOUT communication: a one-rank RCCL group on one GPU runs
 phase-1 step -> reduce-scatter -> sharded apply -> all-gather -> transpose rebuild, each piece bracketed by events.
-usage: python tools/dp_step_breakdown.py [--grad-dtype fp32|bf16] [--precision bf16|bf16x3]
-(bf16x3, the product default: fp32 gradients, fp32 master rows all-gathered, four shadow images rebuilt per rank -- dp.ShardedExchange's split-mode form)"""
+usage: python tools/dp_step_breakdown.py [--grad-dtype fp32|bf16] [--precision f16x2|bf16x3|bf16]
+(the split modes -- f16x2, the product default, and bf16x3: fp32 gradients, fp32 master rows all-gathered, the shadow images rebuilt per rank in
+dp.ShardedExchange's form; the all-reduce form those modes default to is timed beside it)"""
 import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, torch.distributed as dist
