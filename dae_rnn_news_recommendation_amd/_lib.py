@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libdae_hip.so")
 #   "bf16"  libdae_hip.so      bfloat16 images, v_mfma_f32_32x32x16_bf16   precision 'bf16' | 'bf16x3' | 'fp32'
 #   "f16"   libdae_hip_f16.so  IEEE fp16 images, v_mfma_f32_32x32x16_f16   precision 'f16x2' (the default 'auto') | 'f16' | 'f16x3'
 LIB_PATHS = {"bf16": LIB_PATH, "f16": os.path.join(_HERE, "libdae_hip_f16.so")}
-ABI_VERSION = 5
+ABI_VERSION = 6
 # precision name -> (library build, dae_config.dtype, lo product terms of the split mode or None = the build's default)
 X3T_ALL = (1 << 11) - 1
 # what precision='auto' (class, CLIs, bench default) resolves to: the fastest mode that holds the reference's 20-step loss curve within 1e-4
@@ -39,6 +39,7 @@ OPT = {"gradient_descent": 0, "ada_grad": 1, "momentum": 2, "adam": 3}
 TRIPLET = {"none": 0, "batch_all": 1, "batch_hard": 2, "explicit": 3}
 CORR_NONE, CORR_KEEPBITS, CORR_PHILOX_MASK = 0, 1, 2
 STATS_STRIDE = 8
+COMM_ID_BYTES, COMM_MAX_BUCKETS = 128, 8
 WAIT_DW_CREATED = 100     # dae_plan_stream_wait_dw: the event was created by this call (not an error)
 STAT_COST, STAT_AE, STAT_TRIPLET, STAT_FRACTION, STAT_NUM, STAT_NVALID = range(6)
 PAD = 128
@@ -137,6 +138,15 @@ SIGNATURES = {
     "dae_opt_bias": (i32, [i32, f32, f32, f32, vp, vp, vp, vp, vp, i32, i32, vp]),
     "dae_transpose_shadow": (i32, [vp, i32, i32, i32, vp, vp]),
     "dae_encode_rows": (i32, [vp, vp, i32, f32, vp, vp, vp, vp, i64, vp, i64, vp]),
+    "dae_comm_unique_id": (i32, [vp]),
+    "dae_comm_init": (i32, [vp, i32, i32, C.POINTER(vp)]),
+    "dae_comm_destroy": (None, [vp]),
+    "dae_comm_info": (i32, [vp, vp]),
+    "dae_comm_library": (C.c_char_p, []),
+    "dae_comm_allreduce_f32": (i32, [vp, vp, i64, i32, vp]),
+    "dae_dp_bands": (i32, [i32, i32, vp]),
+    "dae_allreduce_grads": (i32, [vp, vp, vp]),
+    "dae_dp_exchange": (i32, [vp, vp, i32, f32, i32, vp]),
     "dae_plan_buffer": (vp, [vp, C.c_char_p]),
     "dae_plan_info": (i32, [vp, vp]),
     "dae_plan_profile": (i32, [vp, i32]),

@@ -320,8 +320,14 @@ template <> struct WRow<bf16_t, 8> {
     static __device__ __forceinline__ void fma(const Raw& v, float w, float (&acc)[8]) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            acc[2 * q] = fmaf(w, __uint_as_float(((uint32_t)v[q]) << 16), acc[2 * q]);
-            acc[2 * q + 1] = fmaf(w, __uint_as_float(((uint32_t)v[q]) & 0xffff0000u), acc[2 * q + 1]);
+            // a packed pair of the library's 16-bit storage format (bf16: the two halves ARE the fp32 high words; fp16 build: two v_cvt_f32_f16)
+            if constexpr (kF16) {
+                acc[2 * q] = fmaf(w, bf2f((bf16_t)((uint32_t)v[q] & 0xffffu)), acc[2 * q]);
+                acc[2 * q + 1] = fmaf(w, bf2f((bf16_t)((uint32_t)v[q] >> 16)), acc[2 * q + 1]);
+            } else {
+                acc[2 * q] = fmaf(w, __uint_as_float(((uint32_t)v[q]) << 16), acc[2 * q]);
+                acc[2 * q + 1] = fmaf(w, __uint_as_float(((uint32_t)v[q]) & 0xffff0000u), acc[2 * q + 1]);
+            }
         }
     }
 };

@@ -71,6 +71,23 @@ def quiet_first_collective():
         os.close(saved)
 
 
+class _stdout_to_stderr:
+    """File descriptor 1 pointed at stderr for the duration (C stdio of loaded libraries included; flushed before it is restored)."""
+
+    def __enter__(self):
+        import sys
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def allreduce_sum_(flat):
     """In-place sum of the flat gradient over all ranks (RCCL all-reduce on the current stream)."""
     import torch.distributed as dist
@@ -87,6 +104,17 @@ def allreduce_max_float(x):
     dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
     t = torch.tensor([float(x)], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def allreduce_sum_float(x):
+    import torch
+    import torch.distributed as dist
+    if not (is_initialized() and dist.get_world_size() > 1):
+        return float(x)
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([float(x)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
 
 
@@ -384,11 +412,139 @@ class AllReduceExchange:
         return
 
 
-def make_exchange(eng, grad_dtype="fp32", kind="auto", buckets=None):
-    """The data-parallel exchange for `eng`: kind 'auto' = AllReduceExchange in the split-bf16 mode (nothing to gain from sharding there),
-    ShardedExchange otherwise (bf16 gradients / bf16 shadow rows halve its bytes); 'sharded' / 'allreduce' force one form."""
+class Comm:
+    """One RCCL communicator of the library's own (include/dae_hip.h: dae_comm_*): the collectives are issued by the C ABI on the step's stream
+    instead of through torch.distributed's process group (its own stream: two cross-stream hops and ~25 us of host time per call,
+    profiles/r05_dp_step_breakdown.txt).  The 128-byte id travels over whatever channel the host has -- here torch.distributed's broadcast (any
+    backend) when a process group exists; a one-rank communicator needs none.  `ranks_seen` = an all-reduced token: what the communicator really spans."""
+
+    def __init__(self, lib, device, rank=None, world=None):
+        import ctypes as C
+        import torch
+        from . import _lib as L
+        self.lib, self.L, self.C, self.torch = lib, L, C, torch
+        self.rank = rank if rank is not None else (globals()["rank"]())
+        self.world = world if world is not None else world_size()
+        self.device = torch.device(device)
+        idb = (C.c_uint8 * L.COMM_ID_BYTES)()
+        with torch.cuda.device(self.device), _stdout_to_stderr():      # RCCL prints its version banner to STDOUT when a communicator comes up
+            if self.rank == 0:
+                L.check(lib.dae_comm_unique_id(idb), "dae_comm_unique_id", lib)
+            if self.world > 1:
+                raw = broadcast_array(np.frombuffer(bytes(idb), np.uint8).copy(), src=0)
+                idb = (C.c_uint8 * L.COMM_ID_BYTES)(*[int(v) for v in raw])
+            h = C.c_void_p()
+            L.check(lib.dae_comm_init(idb, self.rank, self.world, C.byref(h)), "dae_comm_init", lib)
+            self.handle = h
+            tok = torch.ones(1, dtype=torch.float32, device=self.device)
+            self.allreduce_(tok)
+            torch.cuda.synchronize(self.device)
+        self.ranks_seen = int(tok.item())
+        if self.ranks_seen != self.world:
+            raise RuntimeError("dae_comm spans %d ranks, expected %d" % (self.ranks_seen, self.world))
+        self.library = lib.dae_comm_library().decode()
+
+    def allreduce_(self, t, op="sum"):
+        """In-place all-reduce of a float32 device tensor on the current stream."""
+        L = self.L
+        assert t.dtype == self.torch.float32 and t.is_contiguous()
+        L.check(self.lib.dae_comm_allreduce_f32(self.handle, L.ptr(t), t.numel(), 0 if op == "sum" else 1, L.current_stream()), "dae_comm_allreduce_f32", self.lib)
+        return t
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.dae_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:        # noqa: BLE001
+            pass
+
+
+class NativeAllReduceExchange:
+    """AllReduceExchange with the collective in the C ABI (dae_dp_exchange, csrc/dae_api.hip + dae_comm.hip): ONE library call per step enqueues the
+    all-reduce of the flat fp32 gradient [dW | dbh | dbv] and the optimizer behind it.  buckets = 1: both on the step's stream, no hop.  buckets > 1: the
+    W-only row bands are reduced on the communicator's wire stream from the moment the dW GEMM has finished (beside the step's tail kernel), the last
+    band (bias gradients) behind the tail, and the step's stream applies band k while band k + 1 is on the wire -- event waits cost microseconds here,
+    so the bands are affordable (through torch.distributed four buckets cost 117 us of host time per step).  Same interface and the same arithmetic
+    as AllReduceExchange (the band boundaries are dae_dp_bands == AllReduceExchange.bounds: tests/test_dp_exchange_gloo.py)."""
+
+    def __init__(self, eng, buckets=None, comm=None):
+        import torch
+        self.eng, self.torch = eng, torch
+        if getattr(eng, "grad_lo", None) is not None:
+            raise ValueError("the all-reduce exchange moves the flat fp32 gradient: build the Engine with grad_lo=False (dp_grad_dtype='fp32')")
+        self.comm = comm if comm is not None else Comm(eng.lib, eng.device)
+        self.world, self.rank = self.comm.world, self.comm.rank
+        assert eng.dp_world == self.world, "create the Engine with dp_world = world size (%d != %d)" % (eng.dp_world, self.world)
+        self.x3 = bool(getattr(eng, "x3", False))
+        self.grad_dtype, self.packed = "fp32", False
+        self.f0, self.f1 = 0, eng.Fp
+        self.bounds = native_bands(eng.lib, eng.Fp, 1 if buckets is None else buckets)
+        self.buckets = len(self.bounds) - 1
+        self.collective_ms = 0.0
+        self.steps = 0
+        self._ev = tuple(torch.cuda.Event(enable_timing=True) for _ in range(2))
+        self._pending = None
+
+    def step(self, grad_scale, grad_ready_after_dw=False):
+        """Call after eng.train_step(phase=1).  grad_scale multiplies the rank-SUMMED gradient."""
+        L, eng = self.comm.L, self.eng
+        self._ev[0].record()
+        eng.begin_apply()
+        L.check(eng.lib.dae_dp_exchange(eng.plan, self.comm.handle, eng.adam_t, float(grad_scale), self.buckets, L.current_stream()), "dae_dp_exchange", eng.lib)
+        self._ev[1].record()          # (brackets all-reduce + optimizer: the whole second half of the step)
+        self._pending = True
+        self.steps += 1
+
+    def collect_time(self):
+        if self._pending:
+            self._ev[1].synchronize()
+            self.collective_ms += self._ev[0].elapsed_time(self._ev[1])
+            self._pending = None
+
+    def gather_master(self):
+        return
+
+    def gather_slots(self):
+        return
+
+
+def native_bands(lib, Fp, buckets):
+    """Row-band boundaries of the bucketed exchange as the C ABI computes them (dae_dp_bands; host arithmetic, no GPU)."""
+    import ctypes as C
+    b = (C.c_int32 * 16)()
+    n = lib.dae_dp_bands(int(Fp), int(buckets), b)
+    return [int(b[k]) for k in range(n + 1)]
+
+
+def native_collective_ok(eng):
+    """Can the library's own RCCL communicator carry this process group?  One rank per device over the nccl backend (or no group at all: one rank)."""
+    import torch.distributed as dist
+    if eng.device.type != "cuda":
+        return False
+    return (not is_initialized()) or dist.get_world_size() == 1 or dist.get_backend() == "nccl"
+
+
+def make_exchange(eng, grad_dtype="fp32", kind="auto", buckets=None, impl="auto"):
+    """The data-parallel exchange for `eng`: kind 'auto' = the all-reduce form in the split modes (nothing to gain from sharding there),
+    ShardedExchange otherwise (bf16 gradients / bf16 shadow rows halve its bytes); 'sharded' / 'allreduce' force one form.
+    impl: who issues the all-reduce -- 'native' = the C ABI's own RCCL communicator on the step's stream (NativeAllReduceExchange), 'torch' =
+    torch.distributed's process group (AllReduceExchange: any backend, the form the gloo tests drive), 'auto' = native whenever the group is one rank
+    per device over RCCL; should the native communicator fail to come up there, the torch form takes over with a message on stderr (both are RCCL)."""
     assert kind in ("auto", "sharded", "allreduce"), kind
+    assert impl in ("auto", "native", "torch"), impl
     if kind == "allreduce" or (kind == "auto" and getattr(eng, "x3", False)):
+        if impl == "native" or (impl == "auto" and native_collective_ok(eng)):
+            try:
+                return NativeAllReduceExchange(eng, buckets=buckets)
+            except Exception as e:        # noqa: BLE001
+                if impl == "native" or not is_initialized():
+                    raise
+                import sys
+                print("[dae dp] native RCCL communicator unavailable (%s): using torch.distributed's process group" % (repr(e)[:200],), file=sys.stderr, flush=True)
         return AllReduceExchange(eng, buckets=buckets)
     return ShardedExchange(eng, grad_dtype=grad_dtype)
 

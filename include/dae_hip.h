@@ -29,7 +29,7 @@ extern "C" {
 #endif
 
 #define DAE_PAD 128
-#define DAE_ABI_VERSION 5   /* 5: dae_storage_format (the fp16 build libdae_hip_f16.so), options x3_terms / op_scale_log2, DAE_WAIT_DW_CREATED = 100; 4: DAE_BF16X3 (split-bf16 mode), dae_gemm_nt_n; 3: dae_buffers.grad_lo, options dw_bits / encode_w32; 2: dae_step.c_row_idx, plan options, phases 4/5, sharded apply */
+#define DAE_ABI_VERSION 6   /* 6: dae_comm_* / dae_allreduce_grads / dae_dp_exchange / dae_dp_bands (the data-parallel collective in the C ABI, RCCL on the step's stream); 5: dae_storage_format (the fp16 build libdae_hip_f16.so), options x3_terms / op_scale_log2, DAE_WAIT_DW_CREATED = 100; 4: DAE_BF16X3 (split-bf16 mode), dae_gemm_nt_n; 3: dae_buffers.grad_lo, options dw_bits / encode_w32; 2: dae_step.c_row_idx, plan options, phases 4/5, sharded apply */
 
 enum { DAE_BF16 = 0, DAE_F32 = 1,
        DAE_BF16X3 = 2 /* dae_config.dtype only: bf16 storage and MFMA, but every stored operand of the three gradient GEMMs is kept as
@@ -497,6 +497,43 @@ int dae_plan_dp_unpack(dae_plan* plan, const void* recv, int32_t world, int32_t 
 int dae_dp_unpack(const void* recv, int32_t world, int32_t chunk_rows, int64_t chunk_stride_bytes, int64_t bias_off_bytes,
                   int32_t Fp, int32_t Hp, int32_t dtype, void* W_lo, void* Wt_lo, int32_t opt, float lr, float momentum,
                   float grad_scale, float* bh, float* bv, float* s1b, float* s2b, float* grad_b, void* stream);
+/* -------------------------------------------------------------------------------------------------
+ * The data-parallel collective in the C ABI (SURVEY 8(b) proposed `dae_allreduce_grads`; SURVEY 8(e): all-reduce(sum) of the flat gradient
+ * [dW | dbh | dbv] over xGMI, then the identical optimizer step on every rank).  Shards the reference's per-mini-batch step,
+ * autoencoder/autoencoder.py:206-246 (one session.run), over one process per GPU.
+ *
+ *   dae_comm_unique_id   rank 0 draws a DAE_COMM_ID_BYTES id (ncclGetUniqueId) and shares it with the other ranks over any out-of-band
+ *                        channel the host has (a file, a socket, torch.distributed's store, MPI).
+ *   dae_comm_init        every rank, on its own device (the calling thread's current HIP device): ncclCommInitRank.  world = 1 is valid (a
+ *                        one-rank communicator: the exchange then equals dae_plan_apply).  RCCL is located with dlopen at this point -- a
+ *                        copy already loaded into the process is shared, else librccl.so.1 of the ROCm install -- so single-GPU users of the
+ *                        library never load it; a missing RCCL is an error here, not at load time.
+ *   dae_allreduce_grads  in-place ncclAllReduce(sum, fp32) of the plan's flat gradient, enqueued on `stream` -- the stream the step's kernels
+ *                        run on: no process-group stream, no cross-stream hop, no host synchronisation.
+ *   dae_dp_exchange      all-reduce + optimizer, i.e. everything behind dae_train_step(phase = 1).  buckets <= 1: dae_allreduce_grads +
+ *                        dae_plan_apply back to back on `stream`.  buckets > 1 (at most DAE_COMM_MAX_BUCKETS): the flat buffer is reduced in
+ *                        row bands of W (dae_dp_bands) on the communicator's own wire stream -- the W-only bands start behind the dW GEMM,
+ *                        beside the step's tail kernel; the last band (it carries the bias gradients) behind the tail -- and `stream`
+ *                        applies band k (dae_plan_apply_band) while band k + 1 is on the wire.  Same sums, same update as one bucket.
+ *   dae_dp_bands         the band boundaries (host arithmetic; bounds[0 .. n], bounds[n] = Fp), returns n.
+ *   dae_comm_allreduce_f32  the bare collective on a caller buffer (op 0 = sum, 1 = max): loss normalisers, "ranks seen" tokens, timings.
+ * Return codes as everywhere (0 ok, 1 bad argument, 2 HIP failure) plus 3 = RCCL failure; text in dae_last_error().
+ * ------------------------------------------------------------------------------------------------- */
+#define DAE_COMM_ID_BYTES 128
+#define DAE_COMM_MAX_BUCKETS 8
+typedef struct dae_comm dae_comm;
+int         dae_comm_unique_id(void* id_out);
+int         dae_comm_init(const void* id, int32_t rank, int32_t world, dae_comm** out);
+void        dae_comm_destroy(dae_comm* c);
+/* out4 = {rank, world, RCCL version code, DAE_COMM_MAX_BUCKETS} */
+int         dae_comm_info(const dae_comm* c, int32_t* out4);
+/* which RCCL the library resolved ("" before the first dae_comm_unique_id / dae_comm_init) */
+const char* dae_comm_library(void);
+int         dae_comm_allreduce_f32(dae_comm* c, float* buf, int64_t n, int32_t op, void* stream);
+int32_t     dae_dp_bands(int32_t Fp, int32_t buckets, int32_t* bounds);
+int         dae_allreduce_grads(dae_plan* p, dae_comm* c, void* stream);
+int         dae_dp_exchange(dae_plan* p, dae_comm* c, int32_t adam_t, float grad_scale, int32_t buckets, void* stream);
+
 /* transform(): out[B x H] fp32 (ld_out) = encode of rows row_idx (autoencoder.py:479-505) */
 int      dae_encode_rows(dae_plan* p, const int32_t* row_idx, int32_t B, float scale,
                          const int64_t* indptr, const int32_t* indices, const float* values,

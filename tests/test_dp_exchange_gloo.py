@@ -199,3 +199,19 @@ def test_bucketed_allreduce_is_bitwise_the_single_bucket_form():
     for r in range(world):
         for key in ("W", "W_lo", "Wt_lo", "bh", "bv"):
             assert np.array_equal(res["x3_allreduce"][r][key], res["x3_allreduce_1"][r][key]), (r, key)
+
+
+def test_native_band_boundaries_equal_the_python_exchange():
+    """dae_dp_bands (the row bands dae_dp_exchange reduces and applies, C ABI) == AllReduceExchange.bounds (the torch.distributed form whose bucketed
+    arithmetic the gloo tests above pin) for every shape / bucket count in use; pure host arithmetic, no GPU."""
+    from dae_rnn_news_recommendation_amd import _lib as L, dp
+    for fmt in ("bf16", "f16"):
+        lib = L.load(fmt)
+        for Fp in (128, 640, 768, 10112, 50048):
+            for buckets in (1, 2, 3, 4, 7, 8, 11):
+                nblk = Fp // 64
+                nb = max(1, min(buckets, nblk, L.COMM_MAX_BUCKETS))
+                want = [64 * ((nblk * k) // nb) for k in range(nb)] + [Fp]
+                got = dp.native_bands(lib, Fp, buckets)
+                assert got == want, (Fp, buckets, got, want)
+                assert all(b % 64 == 0 for b in got) and got == sorted(set(got))

@@ -218,3 +218,82 @@ def test_dp_checkpoint_carries_every_ranks_optimizer_slots(tmp_path, opt):
         assert np.count_nonzero(slots[k]) > 0.5 * np.count_nonzero(ref_slots[k])
     for a, b in zip(params, ref_p):
         assert _rel(a, b) < tol
+
+
+# ---- the collective in the C ABI (include/dae_hip.h: dae_comm_*, dae_allreduce_grads, dae_dp_exchange) on a ONE-rank RCCL communicator ----
+@pytest.mark.parametrize("dtype,opt,buckets", [("f16x2", "adam", 1), ("f16x2", "gradient_descent", 4), ("bf16x3", "momentum", 3), ("fp32", "ada_grad", 8)])
+def test_native_exchange_on_one_rank_equals_plan_apply(dtype, opt, buckets):
+    """dae_dp_exchange over a one-rank communicator (the sum over one rank is the gradient itself) == dae_plan_apply: master weights, biases, slots and
+    every 16-bit image bit for bit, for one bucket (all-reduce + apply on the step's stream) and for row bands reduced on the wire stream while the step's
+    stream applies them (event-ordered: a missing wait would apply a band before its all-reduce or all-reduce it before the dW GEMM finished)."""
+    import numpy as np
+    import torch
+    from scipy import sparse
+    from dae_rnn_news_recommendation_amd import dp
+    from dae_rnn_news_recommendation_amd.engine import Engine
+    rng = np.random.default_rng(43)
+    N, F, H, B = 300, 700, 90, 128
+    m = sparse.random(N, F, density=0.06, random_state=np.random.RandomState(3), format="csr", dtype=np.float32); m.data[:] = 1.0; m.sort_indices()
+    lab = rng.integers(0, 4, N)
+    W0 = rng.uniform(-0.3, 0.3, (F, H)).astype(np.float32)
+    idx = torch.from_numpy(rng.permutation(N)[:B].astype(np.int32)).cuda()
+    labs = torch.from_numpy(lab[idx.cpu().numpy()].astype(np.int32)).cuda()
+    res = []
+    comm = None
+    for native in (False, True):
+        eng = Engine(F, H, B, dtype=dtype, opt=opt, learning_rate=0.05, triplet="batch_all")
+        eng.upload_csr(m); eng.set_params(W0)
+        stats = torch.zeros(8, device="cuda")
+        ex = None
+        if native:
+            ex = dp.NativeAllReduceExchange(eng, buckets=buckets)
+            comm = ex.comm
+            assert comm.ranks_seen == 1 and comm.world == 1 and "rccl" in comm.library
+            assert ex.buckets == min(buckets, eng.Fp // 64) and ex.bounds[0] == 0 and ex.bounds[-1] == eng.Fp
+        for _ in range(3):
+            eng.train_step(idx, labs, stats, phase=1)
+            if native:
+                ex.step(grad_scale=1.0)
+            else:
+                eng.apply()
+        torch.cuda.synchronize()
+        it = torch.int16 if eng.td != torch.float32 else torch.int32
+        imgs = [eng.W.clone(), eng.bh.clone(), eng.bv.clone(), eng.W_lo.clone().view(it), eng.Wt_lo.clone().view(it), stats.clone()]
+        if eng.x3:
+            imgs.append(eng.buffer("Wt_lo2", (eng.Hp, eng.Fp), torch.int16).clone())
+        if eng.s1 is not None:
+            imgs.append(eng.s1.clone())
+        res.append(imgs)
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    ex.collect_time()
+    assert ex.collective_ms > 0 and ex.steps == 3
+    comm.close()
+
+
+def test_native_allreduce_entry_points_on_one_rank():
+    """dae_comm_allreduce_f32 (sum / max) and dae_allreduce_grads leave a one-rank buffer unchanged; dae_comm_info reports the communicator; errors are
+    reported, not swallowed (a plan with a 16-bit exchange image refuses the flat all-reduce)."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    from scipy import sparse
+    from dae_rnn_news_recommendation_amd import _lib as L, dp
+    from dae_rnn_news_recommendation_amd.engine import Engine
+    eng = Engine(600, 64, 128, dtype="bf16", triplet="none", grad_lo=True)
+    comm = dp.Comm(eng.lib, eng.device, rank=0, world=1)
+    info = (C.c_int32 * 4)()
+    L.check(eng.lib.dae_comm_info(comm.handle, info), "dae_comm_info", eng.lib)
+    assert list(info)[:2] == [0, 1] and info[2] > 20000 and info[3] == L.COMM_MAX_BUCKETS
+    t = torch.arange(1000, dtype=torch.float32, device="cuda") - 17.5
+    want = t.clone()
+    comm.allreduce_(t); comm.allreduce_(t, op="max")
+    torch.cuda.synchronize()
+    assert torch.equal(t, want)
+    m = sparse.random(200, 600, density=0.05, random_state=np.random.RandomState(1), format="csr", dtype=np.float32); m.data[:] = 1.0
+    eng.upload_csr(m)
+    rc = eng.lib.dae_allreduce_grads(eng.plan, comm.handle, L.current_stream())
+    assert rc == 1 and b"grad_lo" in eng.lib.dae_last_error()
+    with pytest.raises(ValueError):
+        dp.NativeAllReduceExchange(eng, comm=comm)
+    comm.close()

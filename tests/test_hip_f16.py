@@ -214,3 +214,15 @@ def test_decode_paired_k_loop_equals_unpaired(dtype, loss_func, acts, strategy):
         assert abs(sa[0] - r["cost"]) <= 5e-5 * abs(r["cost"])
     for u, v in zip(pa, pb):
         assert _rel(u, np.asarray(v, np.float64)) < 1e-3
+
+
+@pytest.mark.parametrize("dtype", ["f16", "f16x2"])
+def test_step_f16_encode_from_the_16bit_shadow(dtype):
+    """encode_w32 = 0 makes the sparse encode read the 16-bit shadow W_lo instead of the fp32 master (what dp.ShardedExchange selects for the non-split
+    modes, where only the shadow is current on every rank).  In the fp16 build that shadow holds IEEE fp16 words: the kernel has to decode them as such
+    (it used the bf16 bit trick there and h came out as garbage without an error).  Against the fp64 oracle, fp16-rounded weights."""
+    out, ref, got = _run_case(dtype, "batch_all", "cross_entropy", ("sigmoid", "sigmoid"), "gradient_descent", steps=2, options={"encode_w32": 0})
+    for r, st, dW, dbh, dbv in out:
+        assert abs(st[0] - r["cost"]) <= 1e-3 * abs(r["cost"]), (st[0], r["cost"])          # h from 11-bit weights: ~2e-4 on the cost
+        assert abs(st[2] - r["triplet_loss"]) <= 2e-3 * abs(r["triplet_loss"]), (st[2], r["triplet_loss"])
+        assert _rel(dW, r["dW"]) < 2e-2 and _rel(dbh, r["dbh"]) < 2e-2, (_rel(dW, r["dW"]), _rel(dbh, r["dbh"]))

@@ -32,7 +32,10 @@ gw = eng.grad[:ex.n_w]; bias = eng.grad[eng.Fp * Hp:eng.Fp * Hp + Hp + eng.Fp]
 if eng.x3:          # the split modes (f16x2 = the product default, bf16x3): fp32 gradients in, fp32-accurate weights out
     my_w = torch.zeros((c, Hp), dtype=torch.float32, device="cuda")
     exa = dp.AllReduceExchange(eng, buckets=1)
-    exb = dp.AllReduceExchange(eng, buckets=4)       # what N > 1 ranks run: 4 row bands, band k applied while band k + 1 is on the wire
+    exb = dp.AllReduceExchange(eng, buckets=4)       # torch.distributed form of the bands (25 us of host time per collective call)
+    nx1 = dp.NativeAllReduceExchange(eng, buckets=1)               # round 6: the collective in the C ABI, on the step's own stream (dae_dp_exchange)
+    nx4 = dp.NativeAllReduceExchange(eng, buckets=4, comm=nx1.comm)
+    print(f"native communicator: RCCL from {nx1.comm.library}, ranks_seen {nx1.comm.ranks_seen}")
     def step_and3(after_dw):
         eng.train_step(idx, labs, stats, phase=1, **kw); ex.step(grad_scale=1.0, grad_ready_after_dw=after_dw)
     rows = [("fused single-GPU step (phase 3)", lambda: eng.train_step(idx, labs, stats, phase=3, **kw)),
@@ -51,7 +54,12 @@ if eng.x3:          # the split modes (f16x2 = the product default, bf16x3): fp3
             ("phase-1 step + all-reduce exchange (default)", lambda: (eng.train_step(idx, labs, stats, phase=1, **kw), exa.step(grad_scale=1.0))),
             ("apply in 4 row bands (dae_plan_apply_band)", lambda: (eng.begin_apply(), [eng.apply_band(exb.bounds[k], exb.bounds[k + 1]) for k in range(4)])),
             ("whole AllReduceExchange.step, 4 buckets", lambda: exb.step(grad_scale=1.0)),
-            ("phase-1 step + bucketed exchange (4 buckets)", lambda: (eng.train_step(idx, labs, stats, phase=1, **kw), exb.step(grad_scale=1.0)))]
+            ("phase-1 step + bucketed exchange (4 buckets)", lambda: (eng.train_step(idx, labs, stats, phase=1, **kw), exb.step(grad_scale=1.0))),
+            ("NATIVE dae_allreduce_grads (1 rank)", lambda: L.check(eng.lib.dae_allreduce_grads(eng.plan, nx1.comm.handle, L.current_stream()), "ar", eng.lib)),
+            ("NATIVE whole dae_dp_exchange, 1 bucket", lambda: nx1.step(grad_scale=1.0)),
+            ("phase-1 step + NATIVE exchange, 1 bucket", lambda: (eng.train_step(idx, labs, stats, phase=1, **kw), nx1.step(grad_scale=1.0))),
+            ("NATIVE whole dae_dp_exchange, 4 buckets", lambda: nx4.step(grad_scale=1.0)),
+            ("phase-1 step + NATIVE exchange, 4 buckets", lambda: (eng.train_step(idx, labs, stats, phase=1, **kw), nx4.step(grad_scale=1.0)))]
     print(f"precision {a.precision}  {'piece':40s} {'GPU us':>9s} {'host us/call':>13s}")
     for name, fn in rows:
         g, h = timed(fn)
