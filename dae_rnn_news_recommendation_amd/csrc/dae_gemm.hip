@@ -2081,6 +2081,424 @@ __global__ __launch_bounds__(GEMM_THREADS, PAIRD ? 2 : DecGeo<BN_T>::WG_PER_CU) 
 }
 
 // ------------------------------------------------------------------------------------------------
+// A-stationary persistent decode (round 6; 16-bit modes, K = Hp <= 512, every K segment over the SAME h -- f16x2's (h, W_hi) (h, W_lo), plain bf16 / f16).
+//
+// What bounds gemm_decode_loss<.., 64> at c2 is not the MFMA pipe: per K tile a 128 x 64 workgroup moves 24 KiB through LDS-DMA and reads 48 KiB of
+// fragments (every A fragment twice, every B fragment twice) for 32 MFMAs, pays two barriers, and a launch is 1106 short-lived workgroups in 1.44 rounds
+// of the chip's 768 slots (tools/decode_quant_probe.sh: t = 17 us + 24 ns per tile).  Here
+//   * h never goes through LDS: wave w of a workgroup owns rows [32 w, +32) of a 128-row panel and keeps their fragments over the WHOLE K in registers
+//     (8 K tiles x 4 k-steps x 16 B = 128 VGPRs), loaded once per panel; both W terms of the split modes multiply the same registers;
+//   * only W streams: one 64-row B tile (8 KiB) per K tile through a 4-deep LDS-DMA ring, 2 pieces per wave and ONE barrier per K tile; a wave reads the
+//     whole B tile (8 ds_read_b128) for its 8 MFMAs -- 40 KiB of LDS traffic per K tile instead of 72;
+//   * workgroups are persistent: 2 per CU, each walks a contiguous run of tiles of ITS XCD's column band (the band's W rows, 2.5 MB hi + lo, stay in that
+//     XCD's L2); the ring runs across tile boundaries, so tile t's loss VALU and its 24 KiB store burst overlap the first B tiles of tile t + 1 already
+//     in flight -- and the other workgroup of the CU, which sits in another phase;
+//   * the Gs rider tiles are done by the same workgroups while their first stages are in flight (no extra workgroups queueing for a slot).
+// Epilogue: the arithmetic of gemm_decode_loss (same FAST / literal split, same op_scale, same partial-sum layouts), on the wave layout 4 x 1.
+// Reference: autoencoder.py:395-415 (decode), triplet_loss_utils.py:262-277 (weighted_loss).
+// ------------------------------------------------------------------------------------------------
+// workgroup barrier that orders LDS accesses only: __syncthreads() also waits vmcnt(0), i.e. for every LDS-DMA stage and global store still in flight
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+struct DecAst {
+    static constexpr int NST = 4;                          // ring depth (B tiles)
+    static constexpr int BT = 64 * BKB;                    // one B tile: 64 W rows x 128 B = 8 KiB
+    static constexpr int RING = NST * BT;
+    static constexpr int MAXKT = 8;                        // K tiles whose A fragments a wave holds (Hp <= 512 in 16-bit elements)
+    static constexpr int LDS_BYTES = RING + DecGeo<64>::EPI_BYTES;
+};
+static_assert(2 * DecAst::LDS_BYTES <= 160 * 1024, "two persistent decode workgroups per CU");
+static_assert(DecGeo<64>::EPI_BYTES >= 64 * 65 * 4, "the Gs rider tile fits the epilogue region");
+
+template <int LOSS, int ACT, bool XBITS>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_decode_ast(GemmParams p, DecodeEpi e) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    using T = bf16_t;
+    using Geo = DecGeo<64>;
+    constexpr int BN_T = 64, NT = 2, P0 = Geo::P0, P1 = Geo::P1, WPR = 2, NST = DecAst::NST, BT = DecAst::BT;
+    constexpr bool IS_COS = (LOSS == DAE_LOSS_COSINE);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 5, c = lane & 31;
+    char* epi = lds + DecAst::RING;
+
+    // ---- this workgroup's run of tiles: XCD x = b % nx owns the column tiles [c0, c1); its workgroups split the band's tiles_m * nc tiles, panel-major ----
+    const int nwg = (int)gridDim.x, b = (int)blockIdx.x;
+    const int nx = nwg < 8 ? nwg : 8;
+    const int x = b % nx, j = b / nx, J = (nwg - x + nx - 1) / nx;
+    const int c0 = (p.tiles_n * x) / nx, c1 = (p.tiles_n * (x + 1)) / nx, nc = c1 - c0;
+    const int n_x = p.tiles_m * nc;
+    const int i0 = (int)(((int64_t)n_x * j) / J), i1 = (int)(((int64_t)n_x * (j + 1)) / J);
+    const int ntiles = i1 - i0;
+    const int nkt = p.seg[0].ktiles, nseg = p.nseg, nks = nkt * nseg;          // K tiles per segment (<= 8), stages per output tile
+    const int Q = ntiles * nks;                                               // stages this workgroup streams
+
+    // ---- producer state: stage qp = (tile, segment, k tile) -> B tile of W rows [tn * 64, +64) ----
+    const uint32_t ldb = (uint32_t)p.seg[0].ldb_b;
+    uint32_t voB[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (i * 4 + wave) * 8 + (lane >> 3);
+        voB[i] = (uint32_t)row * ldb + (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) << 4);
+    }
+    int qp = 0, p_it = 0, p_sg = 0, p_kt = 0;
+    const char* gB = nullptr;
+    auto p_base = [&]() {
+        const int i = i0 + p_it;
+        const int tn = c0 + i % nc;
+        gB = p.seg[p_sg].Bt + (int64_t)tn * BN_T * ldb;
+    };
+    auto dma_next = [&]() {                                // issue stage qp into ring slot qp % NST (2 pieces of 1 KiB per wave)
+        char* slot = lds + (qp & (NST - 1)) * BT;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (!(e.dbg & 4)) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gB + (int64_t)p_kt * BKB + voB[i]),
+                                             (__attribute__((address_space(3))) void*)(slot + (i * 4 + wave) * 1024), 16, 0, 0);
+        ++qp;
+        if (++p_kt == nkt) {
+            p_kt = 0;
+            if (++p_sg == nseg) { p_sg = 0; ++p_it; }
+            if (qp < Q) p_base();
+        }
+    };
+    if (Q > 0) {
+        p_base();
+        for (int s = 0; s < NST - 1 && qp < Q; ++s) dma_next();
+    }
+
+    // ---- Gs rider tiles (DecodeEpi::sym_*), while the first stages are in flight ----
+    if (e.sym_G) {
+        const int nt64 = e.sym_Bp / 64;
+        for (int t = b; t < nt64 * nt64; t += nwg) {
+            sym_scale_tile<T>(e.sym_G, e.sym_B, e.sym_Bp, e.sym_scalars, reinterpret_cast<T*>(e.sym_Gs), t % nt64, t / nt64,
+                              reinterpret_cast<float(*)[65]>(epi), e.op_scale);
+            __syncthreads();
+        }
+    }
+    if (ntiles <= 0) return;
+
+    const T* X = reinterpret_cast<const T*>(e.x);
+    T* D2 = reinterpret_cast<T*>(e.delta2);
+    T* D2T = reinterpret_cast<T*>(e.delta2_t);
+    const bool pass1 = IS_COS && e.cos_pass == 1;
+    char* R0 = epi;                                    // x tile, overwritten in place by delta2   [128][P0]
+    char* R1 = epi + Geo::R0_BYTES;                    // delta2^T tile                             [64][P1]
+    float* aux = reinterpret_cast<float*>(epi + Geo::AUX_OFF);
+    float* cw_l = aux;                                 // [128] row weights
+    float* bv_l = aux + 128;                           // [64] visible bias
+    float* rowsum_l = aux + 256;                       // [128]
+    float* colsum_l = aux + 512;                       // [4 (wave)][64]
+    float* inx_l = aux + 768;                          // [128] 1/|x|            (cosine)
+    float* cyy_l = aux + 896;                          // [128] sum y^2          (cosine pass 2)
+    float* cxy_l = aux + 1024;                         // [128] sum xhat.y       (cosine pass 2)
+    float* pyy_l = aux + 1152;                         // [128] partial sum y^2  (cosine pass 1); [0..3]: the waves' loss shares otherwise
+    float* pxy_l = aux + 1408;                         // [128] partial sum xhat.y
+    uint32_t* xb_l = reinterpret_cast<uint32_t*>(aux + 1664);   // [128][2] bit image of the clean-input tile (XBITS)
+
+    const uint32_t lbase = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)lds;
+    const int swz = (c >> 1) & 7;
+    uint32_t so[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) so[kk] = (uint32_t)(c * BKB) + (uint32_t)(((kk * 2 + g) ^ swz) << 4);
+
+    i32x4 fa[DecAst::MAXKT][4];                        // this wave's h fragments: rows [32 wave, +32) of the panel, all of K
+    int tm_loaded = -1;
+    int q = 0;                                         // consumer stage counter (== stages multiplied so far)
+    for (int it = 0; it < ntiles; ++it) {
+        const int ti = i0 + it;
+        const int tm = ti / nc, tn = c0 + ti % nc;
+        if (tm != tm_loaded) {                         // (a run of tiles may cross a panel boundary)
+            const char* Ap = p.seg[0].A + (int64_t)(tm * BM + wave * 32 + c) * p.seg[0].lda_b + g * 16;
+#pragma unroll
+            for (int kt = 0; kt < DecAst::MAXKT; ++kt)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    if (kt < nkt && !(e.dbg & 1)) fa[kt][kk] = *reinterpret_cast<const i32x4*>(Ap + kt * BKB + kk * 32);
+                    else fa[kt][kk] = i32x4{0, 0, 0, 0};
+                }
+            tm_loaded = tm;
+        }
+        // ---- prefetch the clean-input tile: the bit image now (one register across the K loop); a valued tile is fetched behind the K loop ----
+        uint32_t xb = 0;
+        if constexpr (XBITS) xb = e.x_bits[(int64_t)(tm * BM + (tid >> 1)) * e.ldxb + tn * WPR + (tid & 1)];
+        f32x16 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+
+        // ---- K loop: nseg passes over the same A registers; stage q sits in ring slot q % NST ----
+        for (int sg = 0; sg < nseg; ++sg) {
+#pragma unroll
+            for (int kt = 0; kt < DecAst::MAXKT; ++kt) {
+                if (kt < nkt) {
+                    // this wave's pieces of stage q have landed once at most the pieces of the (NST - 2) younger stages are outstanding
+                    if (q + NST - 2 < Q) wait_vm<2 * (NST - 2)>(); else wait_vm<0>();
+                    __builtin_amdgcn_s_barrier();      // stage q landed for every wave; every wave is done reading slot (q - 1) % NST
+                    asm volatile("" ::: "memory");
+                    if (qp < Q) dma_next();            // stage q + NST - 1 into the slot stage q - 1 occupied
+                    if (e.dbg & 2) { ++q; } else {
+                    const uint32_t sb = lbase + (uint32_t)(q & (NST - 1)) * BT;
+                    i32x4 fb[4][NT];
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        fb[kk][0] = lds_read_b128(sb + so[kk]);
+                        fb[kk][1] = lds_read_b128_off4096(sb + so[kk]);          // + 32 W rows
+                    }
+#define DAE_AST_GROUP(KK, CNT)                                   \
+    asm volatile("s_waitcnt lgkmcnt(" #CNT ")" ::: "memory");    \
+    __builtin_amdgcn_sched_barrier(0);                           \
+    Mma<T>::run(fa[kt][KK], fb[KK][0], acc[0]);                  \
+    Mma<T>::run(fa[kt][KK], fb[KK][1], acc[1]);
+                    DAE_AST_GROUP(0, 6)
+                    DAE_AST_GROUP(1, 4)
+                    DAE_AST_GROUP(2, 2)
+                    DAE_AST_GROUP(3, 0)
+#undef DAE_AST_GROUP
+                    __builtin_amdgcn_sched_barrier(0);
+                    ++q;
+                    }
+                }
+            }
+        }
+
+        // ---- epilogue of tile (tm, tn): gemm_decode_loss's, on the wave layout 4 x 1 (wave w: rows [32 w, +32), all 64 columns) ----
+        // Everything below is recomputed per tile from a laundered thread id: hoisted out of the tile loop, the epilogue's per-lane addresses and
+        // constants (~60 VGPRs) sat beside the 128 A registers through the K loop and went to scratch -- and a scratch reload in a kernel with two
+        // waves per SIMD is a ~1 us stall each (measured: 22 us of the kernel).
+        {
+        int tid_l = threadIdx.x;
+        asm volatile("" : "+v"(tid_l));
+        const int tid = tid_l, lane = tid & 63, g = lane >> 5, c = lane & 31;
+        lds_barrier();                               // the previous tile's staged rows have left (every wave passed its store loop)
+        if constexpr (XBITS) {
+            xb_l[(tid >> 1) * WPR + (tid & 1)] = xb;
+        } else {
+            i32x4 xr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ch = tid + GEMM_THREADS * i;
+                const int row = ch >> 3, c16 = ch & 7;
+                xr[i] = *reinterpret_cast<const i32x4*>(X + (int64_t)(tm * BM + row) * e.ldx + tn * BN_T + c16 * 8);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ch = tid + GEMM_THREADS * i;
+                const int row = ch >> 3, c16 = ch & 7;
+                *reinterpret_cast<i32x4*>(R0 + row * P0 + c16 * 16) = xr[i];
+            }
+        }
+        if (tid < 128) {
+            const int row = tm * BM + tid, col = tn * BN_T + tid;
+            cw_l[tid] = e.cw[row];                     // zero beyond B by construction
+            if (tid < BN_T) bv_l[tid] = col < e.F ? e.bv[col] : 0.f;
+            if constexpr (IS_COS) {
+                inx_l[tid] = rsqrtf(fmaxf(e.cos_stats[row], 1e-12f));
+                cyy_l[tid] = e.cos_pass == 2 ? e.cos_stats[e.Bp + row] : 0.f;
+                cxy_l[tid] = e.cos_pass == 2 ? e.cos_stats[2 * e.Bp + row] : 0.f;
+            }
+        }
+        lds_barrier();
+
+        const int lrow0 = wave * 32 + 4 * g;           // local row of r = 0
+        const float eps = 1e-16f;
+        float colsum[NT], cm[NT], bvv[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            colsum[nt] = 0.f;
+            cm[nt] = (tn * BN_T + c + nt * 32) < e.F ? 1.f : 0.f;
+            bvv[nt] = bv_l[c + nt * 32];
+        }
+        char* r0_lane = R0 + lrow0 * P0 + c * 2;
+        char* r1_lane = R1 + c * P1 + lrow0 * 2;
+        const bool want_rows = e.rowloss_part != nullptr;
+        const float osc = e.op_scale;
+        float wl_acc = 0.f;                            // this lane's share of sum_i cw_i * loss_if
+        auto epi_block = [&](auto R4, auto FASTV) {
+            constexpr int r4 = decltype(R4)::value;
+            constexpr bool FAST = decltype(FASTV)::value;
+            constexpr int rloc = 8 * r4;
+            float d2v[NT][4];
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const int r = r4 * 4 + qq;
+                const int lrow = lrow0 + rloc + qq;
+                const float cwi = cw_l[lrow];
+                float rl = 0.f, s_yy = 0.f, s_xy = 0.f;
+                float inx = 0.f, cs_yy = 0.f, cs_xy = 0.f;
+                if constexpr (IS_COS) { inx = inx_l[lrow]; cs_yy = cyy_l[lrow]; cs_xy = cxy_l[lrow]; }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float z = acc[nt][r] + bvv[nt];
+                    float xv;
+                    if constexpr (XBITS) xv = (float)((xb_l[lrow * WPR + nt] >> c) & 1u);
+                    else xv = bf2f(*reinterpret_cast<const bf16_t*>(r0_lane + (rloc + qq) * P0 + nt * 64));
+                    float l = 0.f, dy = 0.f;
+                    if constexpr (FAST) {
+                        const float en = __builtin_amdgcn_exp2f(-fabsf(z) * kLog2e);          // exp(-|z|)
+                        const float op = 1.0f + en;
+                        const float rr = __builtin_amdgcn_rcpf(op);
+                        const float yv = z >= 0.f ? rr : en * rr;
+                        l = kLn2 * __builtin_amdgcn_logf(op) + fmaxf(z, 0.f) - xv * z;
+                        const float d2 = (cwi * cm[nt]) * (yv - xv);
+                        rl += cm[nt] * l;
+                        colsum[nt] += d2;
+                        const float d2s = sat16(d2 * osc);                  // the 16-bit images hold op_scale * delta2
+                        d2v[nt][qq] = d2s;
+                        *reinterpret_cast<bf16_t*>(r0_lane + (rloc + qq) * P0 + nt * 64) = f2bf_hw(d2s);
+                        continue;
+                    }
+                    const float y = act_fwd<ACT>(z);
+                    if constexpr (LOSS == DAE_LOSS_CROSS_ENTROPY) {
+                        const float a = y + eps, bb = (1.0f - y) + eps;         // reference op order: (1.-y)+1e-16
+                        const float la = __builtin_amdgcn_logf(a), lb = __builtin_amdgcn_logf(bb);
+                        l = -kLn2 * (xv * la + (1.0f - xv) * lb);
+                        dy = (1.0f - xv) * __builtin_amdgcn_rcpf(bb) - xv * __builtin_amdgcn_rcpf(a);
+                    } else if constexpr (LOSS == DAE_LOSS_MEAN_SQUARED) {
+                        const float d = xv - y;
+                        l = d * d;
+                        dy = -2.0f * d;
+                    } else {
+                        const float xh = xv * inx;
+                        if (pass1) {
+                            s_yy += cm[nt] * y * y;
+                            s_xy += cm[nt] * xh * y;
+                        } else {
+                            const float big = cs_yy >= 1e-12f ? 1.f : 0.f;      // tf.maximum routes grad to sum y^2 iff >= eps
+                            const float s = rsqrtf(fmaxf(cs_yy, 1e-12f));
+                            dy = -(xh * s - big * cs_xy * s * s * s * y);
+                        }
+                    }
+                    const float d2 = pass1 ? 0.f : (cwi * cm[nt]) * dy * act_bwd<ACT>(y);   // cw is 0 on padded rows
+                    rl += cm[nt] * l;
+                    colsum[nt] += d2;
+                    const float d2s = sat16(d2 * osc);
+                    d2v[nt][qq] = d2s;
+                    *reinterpret_cast<bf16_t*>(r0_lane + (rloc + qq) * P0 + nt * 64) = f2bf_hw(d2s);
+                }
+                // wavefront (DPP) sum over the 32 lanes that share this row; lanes 16..31 / 48..63 hold it
+                if constexpr (IS_COS) {
+                    if (pass1) {
+                        s_yy = half32_sum_hi(s_yy); s_xy = half32_sum_hi(s_xy);
+                        if (c == 31) { pyy_l[lrow] = s_yy; pxy_l[lrow] = s_xy; }
+                    }
+                } else {
+                    wl_acc += cwi * rl;
+                    if (want_rows) {
+                        rl = half32_sum_hi(rl);
+                        if (c == 31) rowsum_l[lrow] = rl;
+                    }
+                }
+            }
+            // (staged whether or not a delta2^T image is wanted -- a branch here made hipcc sink all eight packed pairs behind the four blocks, through scratch)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                uint2 v;
+                v.x = f2bf_pack_hw(d2v[nt][0], d2v[nt][1]);
+                v.y = f2bf_pack_hw(d2v[nt][2], d2v[nt][3]);
+                *reinterpret_cast<uint2*>(r1_lane + nt * 32 * P1 + rloc * 2) = v;
+            }
+            // one block's sums are closed before the next block starts: left free, the scheduler sank all 16 column-sum / loss-share additions behind the
+            // four blocks and carried their 48 operands there -- through scratch, with 128 registers of h resident
+            asm volatile("" : "+v"(colsum[0]), "+v"(colsum[1]), "+v"(wl_acc));
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // this wave's 32 rows are pure batch padding (rows >= B): delta2 = 0 without evaluating the loss (cw is 0 there)
+        const int vblk = e.no_pad_skip ? 4 : min(4, (e.B - tm * BM + 31) >> 5);
+        bool fast = false;
+        if constexpr (LOSS == DAE_LOSS_CROSS_ENTROPY && ACT == DAE_ACT_SIGMOID) {
+            float zmax = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zmax = fmaxf(zmax, fabsf(acc[nt][r] + bvv[nt]));
+            fast = __builtin_amdgcn_ballot_w64(!(zmax < CE_FAST_ZMAX)) == 0ull && !e.ce_literal;   // NaN logits take the literal path
+        }
+        if (wave >= vblk || (e.dbg & 8)) {
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) *reinterpret_cast<bf16_t*>(r0_lane + (8 * r4 + qq) * P0 + nt * 64) = (bf16_t)0;
+                    uint2 z; z.x = 0u; z.y = 0u;
+                    *reinterpret_cast<uint2*>(r1_lane + nt * 32 * P1 + 8 * r4 * 2) = z;
+                }
+            if (want_rows && !IS_COS && c == 31)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rowsum_l[lrow0 + 8 * (r >> 2) + (r & 3)] = 0.f;
+            if (pass1 && c == 31)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { pyy_l[lrow0 + 8 * (r >> 2) + (r & 3)] = 0.f; pxy_l[lrow0 + 8 * (r >> 2) + (r & 3)] = 0.f; }
+        } else if (fast) {
+            if constexpr (LOSS == DAE_LOSS_CROSS_ENTROPY && ACT == DAE_ACT_SIGMOID) {
+                epi_block(std::integral_constant<int, 0>{}, std::true_type{});
+                epi_block(std::integral_constant<int, 1>{}, std::true_type{});
+                epi_block(std::integral_constant<int, 2>{}, std::true_type{});
+                epi_block(std::integral_constant<int, 3>{}, std::true_type{});
+            }
+        } else {
+            epi_block(std::integral_constant<int, 0>{}, std::false_type{});
+            epi_block(std::integral_constant<int, 1>{}, std::false_type{});
+            epi_block(std::integral_constant<int, 2>{}, std::false_type{});
+            epi_block(std::integral_constant<int, 3>{}, std::false_type{});
+        }
+        if (!pass1) {                                       // column sums: rows of g = 0 and g = 1, then one lane per column
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float v = colsum[nt] + __shfl_xor(colsum[nt], 32, 64);
+                if (g == 0) colsum_l[wave * BN_T + c + nt * 32] = v;
+            }
+        }
+        if constexpr (!IS_COS) {
+            if (e.tile_part) {                              // this tile's share of sum_i cw_i * rowloss_i (4 waves, fixed order)
+                const float v = wave64_sum_hi(wl_acc);
+                if (lane == 63) pyy_l[wave] = v;            // pyy_l is unused outside cosine
+            }
+        }
+        lds_barrier();
+
+        // ---- leave the CU: coalesced tiles and per-wave partial sums ----
+        if (!pass1 && !(e.dbg & 16)) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ch = tid + GEMM_THREADS * i;
+                if (D2) {
+                    const int row = ch >> 3, c16 = ch & 7;
+                    *reinterpret_cast<i32x4*>(D2 + (int64_t)(tm * BM + row) * e.ldd + tn * BN_T + c16 * 8) =
+                        *reinterpret_cast<const i32x4*>(R0 + row * P0 + c16 * 16);
+                }
+                if (D2T) {
+                    const int row = ch >> 4, c16 = ch & 15;
+                    *reinterpret_cast<i32x4*>(D2T + (int64_t)(tn * BN_T + row) * e.lddt + tm * BM + c16 * 8) =
+                        *reinterpret_cast<const i32x4*>(R1 + row * P1 + c16 * 16);
+                }
+            }
+        }
+        {
+            const int w = tid >> 7, k = tid & 127;          // two partial rows per column tile in the consumers' layout: [0] = the row sums, [1] = 0
+            const bool rowok = (tm * BM + k) < e.B;
+            if constexpr (IS_COS) {
+                if (pass1) {
+                    e.cos_part[(int64_t)(tn * 2 + w) * e.Bp + tm * BM + k] = (rowok && w == 0) ? pyy_l[k] : 0.f;
+                    e.cos_part[(int64_t)(2 * p.tiles_n + tn * 2 + w) * e.Bp + tm * BM + k] = (rowok && w == 0) ? pxy_l[k] : 0.f;
+                }
+            } else {
+                if (e.rowloss_part) e.rowloss_part[(int64_t)(tn * 2 + w) * e.Bp + tm * BM + k] = (rowok && w == 0) ? rowsum_l[k] : 0.f;
+            }
+            if (e.dbv_part && !pass1 && tid < 2 * BN_T) {   // two partial rows per row tile: rows [0, 64) and [64, 128) of the panel
+                const int w2 = tid / BN_T, k2 = tid % BN_T;
+                e.dbv_part[(int64_t)(tm * 2 + w2) * e.Fp + tn * BN_T + k2] = colsum_l[(2 * w2) * BN_T + k2] + colsum_l[(2 * w2 + 1) * BN_T + k2];
+            }
+            if constexpr (!IS_COS) {
+                if (e.tile_part && tid == 0) e.tile_part[tm * p.tiles_n + tn] = (pyy_l[0] + pyy_l[1]) + (pyy_l[2] + pyy_l[3]);
+            }
+        }
+        }   // (laundered-id scope of the epilogue)
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------------
 static int g_nst = 2;   // staging variant of the plain GEMM: 0 register-staged, 2/3/4 global_load_lds ring depth
@@ -2201,6 +2619,17 @@ static decode_fn decode_kernel_pair(int loss, int act, bool xbits) {
 #undef DAE_DKP
     return nullptr;
 }
+// the A-stationary persistent kernel (gemm_decode_ast)
+static decode_fn decode_kernel_ast(int loss, int act, bool xbits) {
+#define DAE_DKA(LV, AV)                                                                                       \
+    if (loss == LV && act == AV)                                                                              \
+        return xbits ? gemm_decode_ast<LV, AV, true> : gemm_decode_ast<LV, AV, false>;
+    DAE_DKA(0, 0) DAE_DKA(0, 1) DAE_DKA(0, 2) DAE_DKA(1, 0) DAE_DKA(1, 1) DAE_DKA(1, 2) DAE_DKA(2, 0) DAE_DKA(2, 1) DAE_DKA(2, 2)
+#undef DAE_DKA
+    return nullptr;
+}
+static int g_decode_dbg = 0;       // dae_set_glds(-500000 - bits): timing probes of gemm_decode_ast (DecodeEpi::dbg)
+static int g_decode_ast = 1;       // dae_set_glds(-15) off / (-16) on; plan option "decode_ast"
 constexpr int DECODE_PAIR_LDS = 2 * (TILE_BYTES + 2 * 64 * BKB) > DecGeo<DECODE_BN_BF16>::EPI_BYTES ? 2 * (TILE_BYTES + 2 * 64 * BKB) : DecGeo<DECODE_BN_BF16>::EPI_BYTES;
 static int g_decode_pair = 0;      // dae_set_glds(-13) off / (-14) on; plan option "decode_pair"
 template <typename T> static decode_fn decode_kernel(int loss, int act) {
@@ -2533,6 +2962,31 @@ int launch_decode_loss_n(int dtype, int Bp, int Fp, const GemmSegDesc* segs, int
     }
     if (e.op_scale == 0.f) e.op_scale = 1.f;
     e.no_pad_skip = g_pad_skip ? 0 : 1;
+    e.dbg = g_decode_dbg;
+    // A-stationary persistent form: 16-bit, 64-column tiles, no lo images, every K segment over the same h with K <= 8 tiles (Hp <= 512)
+    bool ast = g_decode_ast && dtype == DAE_BF16 && !wide && !paird && !(e.delta2_2 || e.delta2_t2 || e.x2) && p.seg[0].ktiles <= DecAst::MAXKT;
+    for (int s = 1; s < p.nseg && ast; ++s)
+        ast = p.seg[s].A == p.seg[0].A && p.seg[s].lda_b == p.seg[0].lda_b && p.seg[s].ldb_b == p.seg[0].ldb_b && p.seg[s].ktiles == p.seg[0].ktiles;
+    if (ast) {
+        decode_fn ka = decode_kernel_ast(e.loss_func, e.dec_act, e.x_bits != nullptr);
+        static int ast_rc = [] {
+            int rc = 0;
+            for (int l = 0; l < 3; ++l)
+                for (int a = 0; a < 3; ++a)
+                    for (int x = 0; x < 2; ++x)
+                        rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(decode_kernel_ast(l, a, x != 0)),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, DecAst::LDS_BYTES);
+            return rc;
+        }();
+        DAE_CHECK_ARG(ast_rc == 0, "decode_loss: hipFuncSetAttribute failed");
+        if (e.sym_G) DAE_CHECK_ARG(e.sym_scalars && e.sym_Gs && e.sym_Bp % 64 == 0 && e.sym_B <= e.sym_Bp, "decode_loss: bad sym_scale rider");
+        const int tiles = p.tiles_m * p.tiles_n;
+        int nwg = 2 * (g_cus > 0 ? g_cus : 256);          // two resident workgroups per CU
+        if (nwg > tiles) nwg = tiles;
+        hipLaunchKernelGGL(ka, dim3(nwg), dim3(GEMM_THREADS), DecAst::LDS_BYTES, st, p, e);
+        DAE_CHECK_LAUNCH();
+        return 0;
+    }
     if (wide) {
         k = decode_kernel_wide(e.loss_func, e.dec_act, e.x_bits != nullptr);
         static int wide_rc = [] {
@@ -2825,9 +3279,12 @@ void set_use_glds(int nst) {
     if (nst == -5) { g_dw_pc = 2; return; }          // tests: the 160 x 128 kernel for every grid that fits one round
     if (nst == -6) { g_w8 = 0; return; }             // A/B: never the 256 x 256 / 8-MFMA-wave kernel
     if (nst == -7) { g_w8 = 1; return; }
+    if (nst <= -500000 && nst > -500064) { g_decode_dbg = -500000 - nst; return; }
     if (nst <= -100 && nst > -1000) { g_dw_rounds = g_dw_rounds_split = (-nst - 100 < 1 ? 1 : -nst - 100); return; }    // rounds of the chip the 160 x 128 dW kernel may take
     if (nst == -13) { g_decode_pair = 0; return; }
     if (nst == -14) { g_decode_pair = 1; return; }
+    if (nst == -15) { g_decode_ast = 0; return; }
+    if (nst == -16) { g_decode_ast = 1; return; }
     if (nst == -11) { g_pad_skip = 0; return; }
     if (nst == -12) { g_pad_skip = 1; return; }
     if (nst == -9) { g_pc_vec = 0; return; }         // A/B: gemm_nt_pc stores its tile as dwords straight from the accumulators

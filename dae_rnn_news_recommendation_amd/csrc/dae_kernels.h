@@ -32,6 +32,7 @@ struct DecodeEpi {
     // the loss, the bias-gradient partials and everything fp32 stay unscaled
     float op_scale;
     int no_pad_skip;          // 1: evaluate every 32-row block, padding included (A/B; set by the launcher from the process-wide switch)
+    int dbg;                  // timing probes of gemm_decode_ast (dae_set_glds(-500000 - bits); results are garbage when set): 1 no A loads, 2 no fragment reads / MFMAs, 4 no LDS-DMA, 8 no epilogue arithmetic, 16 no tile stores
     int bn;                   // tile width (columns of y per workgroup): 0 = the mode's default (decode_tile_n), 128 = the wide 16-bit kernel; the partial-sum arrays
                               // (rowloss_part / cos_part: 2 * Fp / bn rows; tile_part: (Bp / 128) * (Fp / bn)) are laid out by it
 };

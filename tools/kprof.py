@@ -25,11 +25,11 @@ if a.lib:
     L.LIB_PATH = os.path.abspath(a.lib)
 if a.nst >= 0:
     L.load().dae_set_glds(a.nst)
-for code in a.glds:
-    L.load().dae_set_glds(code)
 m = synthetic_csr(a.rows, a.features, seed=1); lab = synthetic_labels(a.rows, seed=1).astype(np.int32)
 eng = Engine(a.features, a.hidden, a.batch, dtype=a.precision, triplet=a.strategy, loss_func=a.loss, learning_rate=0.1,
              encode_splits=a.enc_splits, dh_splits=a.enc_splits, gram_splits=a.gram_splits)
+for code in a.glds:          # process-wide switches live in the library build this engine runs on
+    eng.lib.dae_set_glds(code)
 for o in a.opt:
     k, v = o.split("="); eng.set_option(k, int(v))
 eng.upload_csr(m); eng.set_params(xavier_uniform(a.features, a.hidden))
