@@ -8,10 +8,11 @@ line (:283-294), the per-epoch order of host RNG draws (corrupt the whole set, t
 and variable names of the checkpoint (``enc-w``, ``hidden-bias``, ``visible-bias``; :365-367).
 
 New (keyword-only, all optional):
-  precision   'auto' (default: the fastest mode inside the 1e-4 loss-curve gate, _lib.AUTO_PRECISION) or one of _lib.PRECISIONS:
-              'f16x2' (fp16 operand images, W as hi + lo: two MFMA product terms per gradient GEMM), 'bf16x3' (split-bf16: every stored
-              operand as hi + lo bf16, three products each), 'fp32' (exact-fp32 MFMA) -- all inside the gate; 'bf16' / 'f16' (single
-              16-bit images, fp32 accumulate / master weights: faster, outside the gate), 'f16x3' (every operand hi + lo fp16)
+  precision   'auto' (default: per triplet strategy the cheapest mode measured to hold the reference's loss curve over 100 steps, _lib.AUTO_BY_STRATEGY:
+              none -> 'f16x2d', batch_all -> 'f16x2h', batch_hard -> 'bf16x3') or one of _lib.PRECISIONS: 'f16x2h' / 'f16x2d' (fp16 operand images; W
+              and the h resp. delta2 operands as hi + lo), 'bf16x3' (split-bf16: every stored operand as hi + lo bf16, three products each), 'fp32'
+              (exact-fp32 MFMA), 'f16x3' (every operand hi + lo fp16); 'f16x2' (W alone hi + lo: holds 20 steps, not 100), 'bf16' / 'f16' (single
+              16-bit images, fp32 accumulate / master weights: faster, outside the gate)
   rng         'numpy'  -- reference-exact legacy-RandomState stream: keep decisions are drawn on the host
                           and shipped as one bit per stored entry per epoch;
               'philox' -- counter-based masking generated on the device (statistically equivalent,
@@ -189,32 +190,48 @@ class DenoisingAutoencoder(object):
             bs = max(round(n_rows * bs), 1)                         # reference utils.py:47
         return int(bs)
 
+    @staticmethod
+    def _abs_max(data):
+        """Largest |value| of a train / validation / transform input: ndarray, scipy sparse matrix, torch tensor, or a list / dict of those (the explicit
+        triplet estimator's org / pos / neg)."""
+        if data is None:
+            return 0.0
+        if isinstance(data, dict):
+            data = list(data.values())
+        if isinstance(data, (list, tuple)):
+            return max([DenoisingAutoencoder._abs_max(d) for d in data] + [0.0])
+        vals = data if isinstance(data, np.ndarray) else getattr(data, "data", None)
+        if vals is None and hasattr(data, "abs") and hasattr(data, "max"):      # torch tensor
+            return float(data.abs().max()) if data.numel() else 0.0
+        if isinstance(vals, memoryview) or vals is None:
+            vals = np.asarray(data)
+        return float(np.max(np.abs(vals))) if np.size(vals) else 0.0
+
     def _resolve_precision(self, data=None):
-        """precision='auto' (the default): the fastest mode that holds the reference's loss curve within 1e-4 (north star) -- L.AUTO_PRECISION:
-        'f16x2' (fp16 operand images on v_mfma_f32_32x32x16_f16 with W kept as hi + lo: two product terms in the decode and dh GEMMs, one in dW),
-        for every input kind, with or without a train set to look at (fit, load_model -> transform: one arithmetic).  'bf16x3' (split-bf16, three
-        terms) and 'fp32' (exact-fp32 MFMA) hold the gate too and are slower; plain 'bf16' / 'f16' are faster, outside the gate and
-        must be asked for."""
+        """precision='auto' (the default) resolves PER TRIPLET STRATEGY to the cheapest mode measured to hold the reference's loss curve (L.AUTO_BY_STRATEGY:
+        1e-4 on every one of 100 steps of the frozen float32-oracle curves for 'none' / 'batch_all' -- 'f16x2d' / 'f16x2h', fp16 operand images with W and
+        the operands each strategy is sensitive to kept as hi + lo; the oracle-derived envelope for 'batch_hard' -- 'bf16x3'), with or without a train set
+        to look at (fit, load_model -> transform: one arithmetic).  'f16x2' (round 5's default: faster, holds 20 steps, leaves 1e-4 at step 29 of c2 / 76 of
+        c1), plain 'bf16' / 'f16' (faster still, outside the gate) must be asked for by name."""
         if self.precision != 'auto':
             return self.precision
+        mode = L.auto_precision(self._strategy_key())
         # fp16 images hold |x| <= 65504 (and the corrupted values scale * x with them): count data far outside tf-idf / binary BoW takes the split-bf16
         # mode, whose images have the fp32 range -- the only input-dependent part of 'auto'
-        if data is not None and L.PRECISIONS[L.AUTO_PRECISION][0] == "f16":
-            vals = data if isinstance(data, np.ndarray) else getattr(data, "data", None)
-            if vals is not None and np.size(vals) and float(np.max(np.abs(vals))) > 1.0e4:
-                return 'bf16x3'
-        return L.AUTO_PRECISION
+        if data is not None and L.PRECISIONS[mode][0] == "f16" and self._abs_max(data) > 1.0e4:
+            return 'bf16x3'
+        return mode
 
     def _check_storage_range(self, data):
         """A model whose engine stores fp16 images (built by load_model() with no data to look at, or asked for by name) refuses values an fp16 image
-        cannot hold instead of encoding infinities: the caller re-creates it with precision='bf16x3' (fp32 range)."""
+        cannot hold instead of encoding infinities: the caller re-creates it with precision='bf16x3' (fp32 range).  Every matrix handed to fit() /
+        validation / transform passes through here (lists and dicts of matrices included)."""
         used = self.precision_used or self._resolve_precision(None)
         if L.PRECISIONS[used][0] != "f16":
             return
-        vals = data if isinstance(data, np.ndarray) else getattr(data, "data", None)
-        if vals is not None and np.size(vals) and float(np.max(np.abs(vals))) > 6.0e4:
-            raise ValueError("values up to %.3g do not fit the fp16 operand images of precision=%r: use precision='bf16x3' (or 'fp32')"
-                             % (float(np.max(np.abs(vals))), used))
+        top = self._abs_max(data)
+        if top > 6.0e4:
+            raise ValueError("values up to %.3g do not fit the fp16 operand images of precision=%r: use precision='bf16x3' (or 'fp32')" % (top, used))
 
     def _build_engine(self, n_features, max_batch, dp_world=1, data=None):
         from ..engine import Engine                                # raises loudly without a GPU / the library
@@ -547,8 +564,13 @@ class DenoisingAutoencoder(object):
         self.history.append(rec)
 
     def _forward_precision(self, data):
-        """Precision of a forward-only engine over `data` (validation): the training precision."""
-        return self.precision_used or self._resolve_precision(data)
+        """Precision of a forward-only engine over `data` (validation): the training precision; a validation set an fp16-storage engine cannot hold is
+        refused like a train set (it used to skip the range check)."""
+        used = self.precision_used or self._resolve_precision(data)
+        if L.PRECISIONS[used][0] == "f16" and self._abs_max(data) > 6.0e4:
+            raise ValueError("validation values up to %.3g do not fit the fp16 operand images of precision=%r: use precision='bf16x3' (or 'fp32')"
+                             % (self._abs_max(data), used))
+        return used
 
     def _validation_forward(self, validation_set, validation_set_label):
         """Forward pass of the whole validation set as ONE batch, uncorrupted (reference :300-312)."""

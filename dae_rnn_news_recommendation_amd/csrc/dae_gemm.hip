@@ -2083,44 +2083,71 @@ __global__ __launch_bounds__(GEMM_THREADS, PAIRD ? 2 : DecGeo<BN_T>::WG_PER_CU) 
 // ------------------------------------------------------------------------------------------------
 // A-stationary persistent decode (round 6; 16-bit modes, K = Hp <= 512, every K segment over the SAME h -- f16x2's (h, W_hi) (h, W_lo), plain bf16 / f16).
 //
-// What bounds gemm_decode_loss<.., 64> at c2 is not the MFMA pipe: per K tile a 128 x 64 workgroup moves 24 KiB through LDS-DMA and reads 48 KiB of
-// fragments (every A fragment twice, every B fragment twice) for 32 MFMAs, pays two barriers, and a launch is 1106 short-lived workgroups in 1.44 rounds
-// of the chip's 768 slots (tools/decode_quant_probe.sh: t = 17 us + 24 ns per tile).  Here
-//   * h never goes through LDS: wave w of a workgroup owns rows [32 w, +32) of a 128-row panel and keeps their fragments over the WHOLE K in registers
-//     (8 K tiles x 4 k-steps x 16 B = 128 VGPRs), loaded once per panel; both W terms of the split modes multiply the same registers;
-//   * only W streams: one 64-row B tile (8 KiB) per K tile through a 4-deep LDS-DMA ring, 2 pieces per wave and ONE barrier per K tile; a wave reads the
-//     whole B tile (8 ds_read_b128) for its 8 MFMAs -- 40 KiB of LDS traffic per K tile instead of 72;
-//   * workgroups are persistent: 2 per CU, each walks a contiguous run of tiles of ITS XCD's column band (the band's W rows, 2.5 MB hi + lo, stay in that
-//     XCD's L2); the ring runs across tile boundaries, so tile t's loss VALU and its 24 KiB store burst overlap the first B tiles of tile t + 1 already
-//     in flight -- and the other workgroup of the CU, which sits in another phase;
-//   * the Gs rider tiles are done by the same workgroups while their first stages are in flight (no extra workgroups queueing for a slot).
-// Epilogue: the arithmetic of gemm_decode_loss (same FAST / literal split, same op_scale, same partial-sum layouts), on the wave layout 4 x 1.
-// Reference: autoencoder.py:395-415 (decode), triplet_loss_utils.py:262-277 (weighted_loss).
+// gemm_decode_loss<.., 64> is bound by neither the MFMA pipe nor HBM at c2: per K tile a 128 x 64 workgroup moves 24 KiB through LDS-DMA and reads 48 KiB
+// of fragments for 32 MFMAs, holds ONE K tile in flight (48 KiB of LDS = two stages), and a launch is 1106 one-tile workgroups in 1.44 rounds of the chip's 768
+// slots (tools/decode_quant_probe.sh: t = 17 us + 24 ns per tile).  Every phase of it is a latency chain.  Here
+//   * h never stays in LDS: wave w of a workgroup owns rows [32 w, +32) of a 128-row panel and keeps their fragments over the WHOLE K in registers
+//     (8 K tiles x 4 k-steps x 16 B = 128 VGPRs), filled once per panel through the same ring the W tiles use; both W terms of the split modes multiply
+//     the same registers;
+//   * only W streams afterwards: one 64-row B tile (8 KiB) per K tile through a 7-slot LDS-DMA ring -- six K tiles in flight per workgroup instead of one --
+//     at ONE barrier per K tile; a wave reads the whole B tile (8 ds_read_b128) for its 8 MFMAs: 40 KiB of LDS traffic per K tile instead of 72;
+//   * workgroups are persistent, two per CU; each walks a contiguous run of tiles of ITS XCD's column band (the band's W rows, 2.5 MB hi + lo, stay in that
+//     XCD's L2).  The ring runs across tile boundaries: while a tile's loss is evaluated the next tile's first six B tiles are already on their way;
+//   * the epilogue is wave-local: a wave's 32 rows are its own, so the clean-input bits, the row weights, the staged delta2 rows and their coalesced
+//     stores need no workgroup barrier (one remains, for the column sums of the bias gradient); delta2^T leaves straight from the accumulator layout
+//     (8-byte pieces: four consecutive batch rows of one feature), so no second staging tile exists;
+//   * the Gs rider tiles are done by the same workgroups before their first slots land (no extra workgroups queueing for a slot).
+// The arithmetic is gemm_decode_loss's (same FAST / literal split, same op_scale, same partial-sum layouts; the column / row partial sums are added in the
+// order of the 4 x 1 wave layout).  Reference: autoencoder.py:395-415 (decode), triplet_loss_utils.py:262-277 (weighted_loss).
 // ------------------------------------------------------------------------------------------------
-// workgroup barrier that orders LDS accesses only: __syncthreads() also waits vmcnt(0), i.e. for every LDS-DMA stage and global store still in flight
+// workgroup barrier that orders LDS accesses only: __syncthreads() also waits vmcnt(0), i.e. for every LDS-DMA slot and global store still in flight
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 struct DecAst {
-    static constexpr int NST = 4;                          // ring depth (B tiles)
-    static constexpr int BT = 64 * BKB;                    // one B tile: 64 W rows x 128 B = 8 KiB
-    static constexpr int RING = NST * BT;
+    static constexpr int NST = 6;                          // ring slots (7 would be 79 KiB per workgroup: measured ONE resident workgroup per CU then)
+    static constexpr int SLOT = 64 * BKB;                  // one slot: 64 rows x 128 B = 8 KiB (a B tile of W rows, or half of an A tile of h rows)
+    static constexpr int RING = NST * SLOT;
     static constexpr int MAXKT = 8;                        // K tiles whose A fragments a wave holds (Hp <= 512 in 16-bit elements)
-    static constexpr int LDS_BYTES = RING + DecGeo<64>::EPI_BYTES;
+    static constexpr int P0 = 64 * 2 + 16;                 // staged row pitch of a wave's [32][64] delta2 rows (16-bit + 16 B pad)
+    static constexpr int R0W = 32 * P0;                    // per wave
+    // floats behind the four R0W blocks: per wave [32] cw, [32] rowsum / sum y^2, [32] sum xhat.y, [32] 1/|x|, [32] cyy, [32] cxy, [32][2] x bits; shared [4][64] colsum, [4] loss shares
+    static constexpr int WAVE_FLOATS = 6 * 32 + 64;
+    static constexpr int AUX_FLOATS = 4 * WAVE_FLOATS + 4 * 64 + 4;
+    static constexpr int EPI_BYTES = 4 * R0W + AUX_FLOATS * 4;
+    static constexpr int LDS_BYTES = RING + EPI_BYTES;
 };
 static_assert(2 * DecAst::LDS_BYTES <= 160 * 1024, "two persistent decode workgroups per CU");
-static_assert(DecGeo<64>::EPI_BYTES >= 64 * 65 * 4, "the Gs rider tile fits the epilogue region");
+static_assert(DecAst::RING >= 64 * 65 * 4, "the Gs rider tile fits the ring");
+__device__ __forceinline__ void wait_vm_2n(int n) {        // vmcnt(2 n): the pieces of n younger ring slots (2 per wave each) may stay in flight
+    switch (n) {
+        case 0: wait_vm<0>(); break;
+        case 1: wait_vm<2>(); break;
+        case 2: wait_vm<4>(); break;
+        case 3: wait_vm<6>(); break;
+        case 4: wait_vm<8>(); break;
+        case 5: wait_vm<10>(); break;
+        default: wait_vm<12>(); break;
+    }
+}
 
 template <int LOSS, int ACT, bool XBITS>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_decode_ast(GemmParams p, DecodeEpi e) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     using T = bf16_t;
-    using Geo = DecGeo<64>;
-    constexpr int BN_T = 64, NT = 2, P0 = Geo::P0, P1 = Geo::P1, WPR = 2, NST = DecAst::NST, BT = DecAst::BT;
+    constexpr int BN_T = 64, NT = 2, P0 = DecAst::P0, NST = DecAst::NST, SLOT = DecAst::SLOT;
     constexpr bool IS_COS = (LOSS == DAE_LOSS_COSINE);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 5, c = lane & 31;
     char* epi = lds + DecAst::RING;
+    // timing probe (DecodeEpi::dbg & 64): workgroup b leaves 100 MHz timestamps in dbv_part[b * 32 ..] (as uint64) instead of the bias-gradient partials
+    int n_stamp = 0;
+    auto stamp = [&]() {
+        if ((e.dbg & 64) && threadIdx.x == 0 && n_stamp < 16)
+            reinterpret_cast<unsigned long long*>(e.dbv_part)[(int64_t)blockIdx.x * 16 + n_stamp] = __builtin_amdgcn_s_memrealtime();
+        ++n_stamp;
+    };
+    stamp();
 
     // ---- this workgroup's run of tiles: XCD x = b % nx owns the column tiles [c0, c1); its workgroups split the band's tiles_m * nc tiles, panel-major ----
     const int nwg = (int)gridDim.x, b = (int)blockIdx.x;
@@ -2130,187 +2157,236 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_decode_ast(GemmParams p,
     const int n_x = p.tiles_m * nc;
     const int i0 = (int)(((int64_t)n_x * j) / J), i1 = (int)(((int64_t)n_x * (j + 1)) / J);
     const int ntiles = i1 - i0;
-    const int nkt = p.seg[0].ktiles, nseg = p.nseg, nks = nkt * nseg;          // K tiles per segment (<= 8), stages per output tile
-    const int Q = ntiles * nks;                                               // stages this workgroup streams
+    const int nkt = p.seg[0].ktiles, nseg = p.nseg;                          // K tiles per segment (<= 8); segments share h
 
-    // ---- producer state: stage qp = (tile, segment, k tile) -> B tile of W rows [tn * 64, +64) ----
-    const uint32_t ldb = (uint32_t)p.seg[0].ldb_b;
-    uint32_t voB[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = (i * 4 + wave) * 8 + (lane >> 3);
-        voB[i] = (uint32_t)row * ldb + (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) << 4);
-    }
-    int qp = 0, p_it = 0, p_sg = 0, p_kt = 0;
-    const char* gB = nullptr;
-    auto p_base = [&]() {
-        const int i = i0 + p_it;
-        const int tn = c0 + i % nc;
-        gB = p.seg[p_sg].Bt + (int64_t)tn * BN_T * ldb;
-    };
-    auto dma_next = [&]() {                                // issue stage qp into ring slot qp % NST (2 pieces of 1 KiB per wave)
-        char* slot = lds + (qp & (NST - 1)) * BT;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            if (!(e.dbg & 4)) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gB + (int64_t)p_kt * BKB + voB[i]),
-                                             (__attribute__((address_space(3))) void*)(slot + (i * 4 + wave) * 1024), 16, 0, 0);
-        ++qp;
-        if (++p_kt == nkt) {
-            p_kt = 0;
-            if (++p_sg == nseg) { p_sg = 0; ++p_it; }
-            if (qp < Q) p_base();
-        }
-    };
-    if (Q > 0) {
-        p_base();
-        for (int s = 0; s < NST - 1 && qp < Q; ++s) dma_next();
-    }
-
-    // ---- Gs rider tiles (DecodeEpi::sym_*), while the first stages are in flight ----
+    // ---- Gs rider tiles (DecodeEpi::sym_*) first: the ring is still empty ----
     if (e.sym_G) {
         const int nt64 = e.sym_Bp / 64;
         for (int t = b; t < nt64 * nt64; t += nwg) {
             sym_scale_tile<T>(e.sym_G, e.sym_B, e.sym_Bp, e.sym_scalars, reinterpret_cast<T*>(e.sym_Gs), t % nt64, t / nt64,
-                              reinterpret_cast<float(*)[65]>(epi), e.op_scale);
+                              reinterpret_cast<float(*)[65]>(lds), e.op_scale);
             __syncthreads();
         }
     }
     if (ntiles <= 0) return;
 
+    // ---- producer: the slot stream, in RUNS of nkt slots (K tiles 0 .. nkt-1 of one 64-row block).  Per tile: [h rows [0, 64) | h rows [64, 128)] when the tile
+    // opens a new panel, then one run of W rows per K segment.  Kept small on purpose (one call site, pointer bumps; the run switch is the only slow path):
+    // an earlier form with the switch logic inlined at 24 sites of an unrolled K loop was 60 KB of code and spent 0.3 - 0.7 us per ring step fetching it.
+    constexpr int L = NST - 1;                             // slots in flight ahead of the consumer
+    const uint32_t lda = (uint32_t)p.seg[0].lda_b, ldb = (uint32_t)p.seg[0].ldb_b;
+    uint32_t vrow[2], vsl[2];                              // this lane's row of a slot's two pieces and the (swizzled) 16-byte slot it fetches
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        vrow[i] = (uint32_t)((i * 4 + wave) * 8 + (lane >> 3));
+        vsl[i] = (uint32_t)(((lane & 7) ^ ((vrow[i] >> 1) & 7)) << 4);
+    }
+    const int runs_per_tile = 2 + nseg;                    // run 0 / 1: the A halves (only when the panel changes), run 2 + s: segment s
+    int p_it = 0, p_run = 0, p_left = 0, p_tm = -1, p_tn = 0;
+    uint32_t ps_off = 0;                                   // ring byte offset of the next slot to fill
+    const char* p_src = nullptr;
+    uint32_t vo0 = 0, vo1 = 0;
+    bool p_more = true;
+    auto run_setup = [&]() {                               // p_run of tile p_it starts
+        p_left = nkt;
+        // (no dynamic index into the kernarg struct, no table of per-lane offsets: either would live in scratch, a ~1 us reload on the producer's path)
+        const uint32_t ld = p_run < 2 ? lda : ldb;
+        p_src = p_run < 2 ? p.seg[0].A + ((int64_t)p_tm * BM + p_run * 64) * lda : (p_run == 2 ? p.seg[0].Bt : p.seg[1].Bt) + (int64_t)p_tn * BN_T * ldb;
+        vo0 = vrow[0] * ld + vsl[0];
+        vo1 = vrow[1] * ld + vsl[1];
+    };
+    auto tile_open = [&]() {
+        const int i = i0 + p_it;
+        const int tm = i / nc;
+        p_tn = c0 + i % nc;
+        p_run = tm != p_tm ? 0 : 2;
+        p_tm = tm;
+        run_setup();
+    };
+    auto dma_one = [&]() {
+        char* slot = lds + ps_off;
+        if (!(e.dbg & 4)) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p_src + vo0),
+                                             (__attribute__((address_space(3))) void*)(slot + wave * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p_src + vo1),
+                                             (__attribute__((address_space(3))) void*)(slot + (4 + wave) * 1024), 16, 0, 0);
+        }
+        p_src += BKB;
+        ps_off += SLOT;
+        if (ps_off == DecAst::RING) ps_off = 0;
+        if (--p_left == 0) {                               // next run / next tile / end of the stream
+            if (++p_run < runs_per_tile) run_setup();
+            else if (++p_it < ntiles) tile_open();
+            else p_more = false;
+        }
+    };
+    tile_open();
+#pragma nounroll
+    for (int s = 0; s < L && p_more; ++s) dma_one();
+    stamp();
+
     const T* X = reinterpret_cast<const T*>(e.x);
     T* D2 = reinterpret_cast<T*>(e.delta2);
     T* D2T = reinterpret_cast<T*>(e.delta2_t);
     const bool pass1 = IS_COS && e.cos_pass == 1;
-    char* R0 = epi;                                    // x tile, overwritten in place by delta2   [128][P0]
-    char* R1 = epi + Geo::R0_BYTES;                    // delta2^T tile                             [64][P1]
-    float* aux = reinterpret_cast<float*>(epi + Geo::AUX_OFF);
-    float* cw_l = aux;                                 // [128] row weights
-    float* bv_l = aux + 128;                           // [64] visible bias
-    float* rowsum_l = aux + 256;                       // [128]
-    float* colsum_l = aux + 512;                       // [4 (wave)][64]
-    float* inx_l = aux + 768;                          // [128] 1/|x|            (cosine)
-    float* cyy_l = aux + 896;                          // [128] sum y^2          (cosine pass 2)
-    float* cxy_l = aux + 1024;                         // [128] sum xhat.y       (cosine pass 2)
-    float* pyy_l = aux + 1152;                         // [128] partial sum y^2  (cosine pass 1); [0..3]: the waves' loss shares otherwise
-    float* pxy_l = aux + 1408;                         // [128] partial sum xhat.y
-    uint32_t* xb_l = reinterpret_cast<uint32_t*>(aux + 1664);   // [128][2] bit image of the clean-input tile (XBITS)
+    char* R0 = epi + wave * DecAst::R0W;               // this wave's rows: x tile, overwritten in place by delta2   [32][P0]
+    float* auxw = reinterpret_cast<float*>(epi + 4 * DecAst::R0W) + wave * DecAst::WAVE_FLOATS;
+    float* cw_l = auxw;                                // [32] row weights of this wave's rows
+    float* rs_l = auxw + 32;                           // [32] row sums (loss), or sum y^2 (cosine pass 1)
+    float* xy_l = auxw + 64;                           // [32] sum xhat.y (cosine pass 1)
+    float* inx_l = auxw + 96;                          // [32] 1/|x|            (cosine)
+    float* cyy_l = auxw + 128;                         // [32] sum y^2          (cosine pass 2)
+    float* cxy_l = auxw + 160;                         // [32] sum xhat.y       (cosine pass 2)
+    uint32_t* xb_l = reinterpret_cast<uint32_t*>(auxw + 192);   // [32][2] bit image of this wave's clean-input rows (XBITS)
+    float* colsum_l = reinterpret_cast<float*>(epi + 4 * DecAst::R0W) + 4 * DecAst::WAVE_FLOATS;   // [4 (wave)][64]
+    float* share_l = colsum_l + 4 * 64;                // [4] the waves' shares of sum_i cw_i * rowloss_i
 
     const uint32_t lbase = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)lds;
     const int swz = (c >> 1) & 7;
     uint32_t so[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) so[kk] = (uint32_t)(c * BKB) + (uint32_t)(((kk * 2 + g) ^ swz) << 4);
+    const uint32_t a_row_off = (uint32_t)((wave & 1) * 32 * BKB);        // this wave's 32 rows inside its A half slot
+    uint32_t cs_off = 0;                               // ring byte offset of the next slot to consume
 
     i32x4 fa[DecAst::MAXKT][4];                        // this wave's h fragments: rows [32 wave, +32) of the panel, all of K
+#pragma unroll
+    for (int kt = 0; kt < DecAst::MAXKT; ++kt)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) fa[kt][kk] = i32x4{0, 0, 0, 0};
     int tm_loaded = -1;
-    int q = 0;                                         // consumer stage counter (== stages multiplied so far)
     for (int it = 0; it < ntiles; ++it) {
         const int ti = i0 + it;
         const int tm = ti / nc, tn = c0 + ti % nc;
-        if (tm != tm_loaded) {                         // (a run of tiles may cross a panel boundary)
-            const char* Ap = p.seg[0].A + (int64_t)(tm * BM + wave * 32 + c) * p.seg[0].lda_b + g * 16;
-#pragma unroll
-            for (int kt = 0; kt < DecAst::MAXKT; ++kt)
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    if (kt < nkt && !(e.dbg & 1)) fa[kt][kk] = *reinterpret_cast<const i32x4*>(Ap + kt * BKB + kk * 32);
-                    else fa[kt][kk] = i32x4{0, 0, 0, 0};
-                }
-            tm_loaded = tm;
-        }
-        // ---- prefetch the clean-input tile: the bit image now (one register across the K loop); a valued tile is fetched behind the K loop ----
+        // ---- tile prologue: what the epilogue needs from memory is requested now and parked in a few registers across the K loop ----
         uint32_t xb = 0;
-        if constexpr (XBITS) xb = e.x_bits[(int64_t)(tm * BM + (tid >> 1)) * e.ldxb + tn * WPR + (tid & 1)];
+        if constexpr (XBITS) xb = e.x_bits[(int64_t)(tm * BM + wave * 32 + (lane & 31)) * e.ldxb + tn * 2 + (lane >> 5)];
+        const float cw_r = e.cw[tm * BM + wave * 32 + (lane & 31)];                 // zero beyond B by construction
+        float bvv[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bvv[nt] = (tn * BN_T + c + nt * 32) < e.F ? e.bv[tn * BN_T + c + nt * 32] : 0.f;
+
         f32x16 acc[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
 
-        // ---- K loop: nseg passes over the same A registers; stage q sits in ring slot q % NST ----
-        for (int sg = 0; sg < nseg; ++sg) {
+        // ---- the tile's runs, one ring slot per step: passes 0 / 1 move the new panel's h fragments ring -> registers (the waves of that row half read),
+        //      passes 2 + s multiply K segment s.  One barrier per step; the body of K tile kt is selected by a uniform switch so that fa[kt] stays a
+        //      compile-time register index while the loop itself is NOT unrolled ----
+        auto ring_step = [&]() -> uint32_t {
+            // the slot to consume has landed once at most the pieces of the L - 1 younger slots are outstanding (exactly L are issued ahead while the
+            // stream lasts; behind its end everything outstanding is waited for)
+            if (p_more) wait_vm<2 * (L - 1)>(); else wait_vm<0>();
+            __builtin_amdgcn_s_barrier();              // it landed for every wave, and every wave is done reading the slot consumed one step ago
+            asm volatile("" ::: "memory");
+            if (p_more) dma_one();                     // refill that slot: L stay in flight
+            const uint32_t sb = lbase + cs_off;
+            cs_off += SLOT;
+            if (cs_off == DecAst::RING) cs_off = 0;
+            return sb;
+        };
+        if (tm != tm_loaded) {                         // a new panel: runs 0 / 1 move its h fragments ring -> registers (the waves of that row half read)
+#pragma nounroll
+            for (int half = 0; half < 2; ++half) {
 #pragma unroll
-            for (int kt = 0; kt < DecAst::MAXKT; ++kt) {
-                if (kt < nkt) {
-                    // this wave's pieces of stage q have landed once at most the pieces of the (NST - 2) younger stages are outstanding
-                    if (q + NST - 2 < Q) wait_vm<2 * (NST - 2)>(); else wait_vm<0>();
-                    __builtin_amdgcn_s_barrier();      // stage q landed for every wave; every wave is done reading slot (q - 1) % NST
-                    asm volatile("" ::: "memory");
-                    if (qp < Q) dma_next();            // stage q + NST - 1 into the slot stage q - 1 occupied
-                    if (e.dbg & 2) { ++q; } else {
-                    const uint32_t sb = lbase + (uint32_t)(q & (NST - 1)) * BT;
-                    i32x4 fb[4][NT];
+                for (int kt = 0; kt < DecAst::MAXKT; ++kt) {
+                    if (kt < nkt) {
+                        const uint32_t sb = ring_step();
+                        if ((wave >> 1) == half && !(e.dbg & 1)) {
 #pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) {
-                        fb[kk][0] = lds_read_b128(sb + so[kk]);
-                        fb[kk][1] = lds_read_b128_off4096(sb + so[kk]);          // + 32 W rows
-                    }
-#define DAE_AST_GROUP(KK, CNT)                                   \
-    asm volatile("s_waitcnt lgkmcnt(" #CNT ")" ::: "memory");    \
-    __builtin_amdgcn_sched_barrier(0);                           \
-    Mma<T>::run(fa[kt][KK], fb[KK][0], acc[0]);                  \
-    Mma<T>::run(fa[kt][KK], fb[KK][1], acc[1]);
-                    DAE_AST_GROUP(0, 6)
-                    DAE_AST_GROUP(1, 4)
-                    DAE_AST_GROUP(2, 2)
-                    DAE_AST_GROUP(3, 0)
-#undef DAE_AST_GROUP
-                    __builtin_amdgcn_sched_barrier(0);
-                    ++q;
+                            for (int kk = 0; kk < 4; ++kk) fa[kt][kk] = lds_read_b128(sb + a_row_off + so[kk]);
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        }
                     }
                 }
             }
+            stamp();
         }
+        // runs 2 + s multiply K segment s, one ring slot per step.  The body of K tile kt is selected by a uniform switch so that fa[kt] stays a
+        // compile-time register index while the loop itself is NOT unrolled (one copy of the ring step)
+        for (int sg = 0; sg < nseg; ++sg) {
+#pragma nounroll
+            for (int kt = 0; kt < nkt; ++kt) {
+                const uint32_t sb = ring_step();
+                if (!(e.dbg & 2)) {
+                    // B fragments of k-step kk for both column blocks; two k-steps are in flight at a time (16 registers, not 32: beside the 128 of h
+                    // the full set pushed one K tile of h into scratch)
+                    i32x4 f0a = lds_read_b128(sb + so[0]), f0b = lds_read_b128_off4096(sb + so[0]);
+                    i32x4 f1a = lds_read_b128(sb + so[1]), f1b = lds_read_b128_off4096(sb + so[1]);
+                    i32x4 f2a, f2b, f3a, f3b;
+#define DAE_AST_MM(KT, KK, FA, FB)                               \
+    __builtin_amdgcn_sched_barrier(0);                           \
+    Mma<T>::run(fa[KT][KK], FA, acc[0]);                         \
+    Mma<T>::run(fa[KT][KK], FB, acc[1]);                         \
+    __builtin_amdgcn_sched_barrier(0);
+#define DAE_AST_BCASE(KT)                                                                                       \
+    case KT:                                                                                                    \
+        asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");                                                      \
+        DAE_AST_MM(KT, 0, f0a, f0b)                                                                             \
+        f2a = lds_read_b128(sb + so[2]); f2b = lds_read_b128_off4096(sb + so[2]);                               \
+        asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");                                                      \
+        DAE_AST_MM(KT, 1, f1a, f1b)                                                                             \
+        f3a = lds_read_b128(sb + so[3]); f3b = lds_read_b128_off4096(sb + so[3]);                               \
+        asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");                                                      \
+        DAE_AST_MM(KT, 2, f2a, f2b)                                                                             \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
+        DAE_AST_MM(KT, 3, f3a, f3b)                                                                             \
+        break;
+                    switch (kt) { DAE_AST_BCASE(0) DAE_AST_BCASE(1) DAE_AST_BCASE(2) DAE_AST_BCASE(3) DAE_AST_BCASE(4) DAE_AST_BCASE(5) DAE_AST_BCASE(6) DAE_AST_BCASE(7) default: break; }
+#undef DAE_AST_BCASE
+#undef DAE_AST_MM
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // (the default case: no read may stay pending into the next step)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        tm_loaded = tm;
 
-        // ---- epilogue of tile (tm, tn): gemm_decode_loss's, on the wave layout 4 x 1 (wave w: rows [32 w, +32), all 64 columns) ----
-        // Everything below is recomputed per tile from a laundered thread id: hoisted out of the tile loop, the epilogue's per-lane addresses and
-        // constants (~60 VGPRs) sat beside the 128 A registers through the K loop and went to scratch -- and a scratch reload in a kernel with two
-        // waves per SIMD is a ~1 us stall each (measured: 22 us of the kernel).
+        stamp();
+        // ---- epilogue of tile (tm, tn): gemm_decode_loss's arithmetic on the wave layout 4 x 1 (wave w: rows [32 w, +32), all 64 columns), wave-local ----
+        // Everything below is recomputed per tile from a laundered lane id: hoisted out of the tile loop, the epilogue's per-lane addresses and constants
+        // (~60 VGPRs) sat beside the 128 A registers through the K loop and went to scratch -- and a scratch reload in a kernel with two waves per SIMD is
+        // a ~1 us stall each (measured: 22 us of the kernel).
         {
-        int tid_l = threadIdx.x;
-        asm volatile("" : "+v"(tid_l));
-        const int tid = tid_l, lane = tid & 63, g = lane >> 5, c = lane & 31;
-        lds_barrier();                               // the previous tile's staged rows have left (every wave passed its store loop)
+        int lane_l = threadIdx.x & 63;
+        asm volatile("" : "+v"(lane_l));
+        const int lane = lane_l, g = lane >> 5, c = lane & 31;
+        const int row0 = tm * BM + wave * 32;          // first batch row of this wave
+        if (lane < 32) cw_l[lane] = cw_r;
         if constexpr (XBITS) {
-            xb_l[(tid >> 1) * WPR + (tid & 1)] = xb;
-        } else {
+            xb_l[(lane & 31) * 2 + (lane >> 5)] = xb;
+        } else {                                       // valued clean rows: this wave's [32][64] tile, fetched now (binary input is the hot case)
             i32x4 xr[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int ch = tid + GEMM_THREADS * i;
-                const int row = ch >> 3, c16 = ch & 7;
-                xr[i] = *reinterpret_cast<const i32x4*>(X + (int64_t)(tm * BM + row) * e.ldx + tn * BN_T + c16 * 8);
+                const int ch = lane + 64 * i;
+                xr[i] = *reinterpret_cast<const i32x4*>(X + (int64_t)(row0 + (ch >> 3)) * e.ldx + tn * BN_T + (ch & 7) * 8);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int ch = tid + GEMM_THREADS * i;
-                const int row = ch >> 3, c16 = ch & 7;
-                *reinterpret_cast<i32x4*>(R0 + row * P0 + c16 * 16) = xr[i];
+                const int ch = lane + 64 * i;
+                *reinterpret_cast<i32x4*>(R0 + (ch >> 3) * P0 + (ch & 7) * 16) = xr[i];
             }
         }
-        if (tid < 128) {
-            const int row = tm * BM + tid, col = tn * BN_T + tid;
-            cw_l[tid] = e.cw[row];                     // zero beyond B by construction
-            if (tid < BN_T) bv_l[tid] = col < e.F ? e.bv[col] : 0.f;
-            if constexpr (IS_COS) {
-                inx_l[tid] = rsqrtf(fmaxf(e.cos_stats[row], 1e-12f));
-                cyy_l[tid] = e.cos_pass == 2 ? e.cos_stats[e.Bp + row] : 0.f;
-                cxy_l[tid] = e.cos_pass == 2 ? e.cos_stats[2 * e.Bp + row] : 0.f;
+        if constexpr (IS_COS) {
+            if (lane < 32) {
+                inx_l[lane] = rsqrtf(fmaxf(e.cos_stats[row0 + lane], 1e-12f));
+                cyy_l[lane] = e.cos_pass == 2 ? e.cos_stats[e.Bp + row0 + lane] : 0.f;
+                cxy_l[lane] = e.cos_pass == 2 ? e.cos_stats[2 * e.Bp + row0 + lane] : 0.f;
             }
         }
-        lds_barrier();
-
-        const int lrow0 = wave * 32 + 4 * g;           // local row of r = 0
+        const int lrow0 = 4 * g;                       // row of r = 0 inside the wave's 32
         const float eps = 1e-16f;
-        float colsum[NT], cm[NT], bvv[NT];
+        float colsum[NT], cm[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             colsum[nt] = 0.f;
             cm[nt] = (tn * BN_T + c + nt * 32) < e.F ? 1.f : 0.f;
-            bvv[nt] = bv_l[c + nt * 32];
         }
         char* r0_lane = R0 + lrow0 * P0 + c * 2;
-        char* r1_lane = R1 + c * P1 + lrow0 * 2;
+        T* d2t_lane = D2T ? D2T + (int64_t)(tn * BN_T + c) * e.lddt + row0 + lrow0 : nullptr;
         const bool want_rows = e.rowloss_part != nullptr;
         const float osc = e.op_scale;
         float wl_acc = 0.f;                            // this lane's share of sum_i cw_i * loss_if
@@ -2331,7 +2407,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_decode_ast(GemmParams p,
                 for (int nt = 0; nt < NT; ++nt) {
                     const float z = acc[nt][r] + bvv[nt];
                     float xv;
-                    if constexpr (XBITS) xv = (float)((xb_l[lrow * WPR + nt] >> c) & 1u);
+                    if constexpr (XBITS) xv = (float)((xb_l[lrow * 2 + nt] >> c) & 1u);
                     else xv = bf2f(*reinterpret_cast<const bf16_t*>(r0_lane + (rloc + qq) * P0 + nt * 64));
                     float l = 0.f, dy = 0.f;
                     if constexpr (FAST) {
@@ -2380,23 +2456,26 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_decode_ast(GemmParams p,
                 if constexpr (IS_COS) {
                     if (pass1) {
                         s_yy = half32_sum_hi(s_yy); s_xy = half32_sum_hi(s_xy);
-                        if (c == 31) { pyy_l[lrow] = s_yy; pxy_l[lrow] = s_xy; }
+                        if (c == 31) { rs_l[lrow] = s_yy; xy_l[lrow] = s_xy; }
                     }
                 } else {
                     wl_acc += cwi * rl;
                     if (want_rows) {
                         rl = half32_sum_hi(rl);
-                        if (c == 31) rowsum_l[lrow] = rl;
+                        if (c == 31) rs_l[lrow] = rl;
                     }
                 }
             }
-            // (staged whether or not a delta2^T image is wanted -- a branch here made hipcc sink all eight packed pairs behind the four blocks, through scratch)
+            // delta2^T straight from the accumulator layout: four consecutive batch rows of feature (c + 32 nt) are 8 contiguous bytes of its image row
+            // (the g = 0 / g = 1 lanes of a column write adjacent pieces; a column's 64 bytes of this wave complete within the four blocks)
+            if (d2t_lane && !pass1 && !(e.dbg & 32)) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                uint2 v;
-                v.x = f2bf_pack_hw(d2v[nt][0], d2v[nt][1]);
-                v.y = f2bf_pack_hw(d2v[nt][2], d2v[nt][3]);
-                *reinterpret_cast<uint2*>(r1_lane + nt * 32 * P1 + rloc * 2) = v;
+                for (int nt = 0; nt < NT; ++nt) {
+                    uint2 v;
+                    v.x = f2bf_pack_hw(d2v[nt][0], d2v[nt][1]);
+                    v.y = f2bf_pack_hw(d2v[nt][2], d2v[nt][3]);
+                    *reinterpret_cast<uint2*>(d2t_lane + (int64_t)nt * 32 * e.lddt + rloc) = v;
+                }
             }
             // one block's sums are closed before the next block starts: left free, the scheduler sank all 16 column-sum / loss-share additions behind the
             // four blocks and carried their 48 operands there -- through scratch, with 128 registers of h resident
@@ -2422,14 +2501,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_decode_ast(GemmParams p,
 #pragma unroll
                     for (int qq = 0; qq < 4; ++qq) *reinterpret_cast<bf16_t*>(r0_lane + (8 * r4 + qq) * P0 + nt * 64) = (bf16_t)0;
                     uint2 z; z.x = 0u; z.y = 0u;
-                    *reinterpret_cast<uint2*>(r1_lane + nt * 32 * P1 + 8 * r4 * 2) = z;
+                    if (d2t_lane && !pass1 && !(e.dbg & 32)) *reinterpret_cast<uint2*>(d2t_lane + (int64_t)nt * 32 * e.lddt + 8 * r4) = z;
                 }
-            if (want_rows && !IS_COS && c == 31)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) rowsum_l[lrow0 + 8 * (r >> 2) + (r & 3)] = 0.f;
-            if (pass1 && c == 31)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { pyy_l[lrow0 + 8 * (r >> 2) + (r & 3)] = 0.f; pxy_l[lrow0 + 8 * (r >> 2) + (r & 3)] = 0.f; }
+            if (lane < 32) { rs_l[lane] = 0.f; xy_l[lane] = 0.f; }
         } else if (fast) {
             if constexpr (LOSS == DAE_LOSS_CROSS_ENTROPY && ACT == DAE_ACT_SIGMOID) {
                 epi_block(std::integral_constant<int, 0>{}, std::true_type{});
@@ -2443,7 +2517,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_decode_ast(GemmParams p,
             epi_block(std::integral_constant<int, 2>{}, std::false_type{});
             epi_block(std::integral_constant<int, 3>{}, std::false_type{});
         }
-        if (!pass1) {                                       // column sums: rows of g = 0 and g = 1, then one lane per column
+        if (!pass1) {                                       // column sums of this wave's 32 rows: rows of g = 0 and g = 1, then one lane per column
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const float v = colsum[nt] + __shfl_xor(colsum[nt], 32, 64);
@@ -2451,49 +2525,42 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_decode_ast(GemmParams p,
             }
         }
         if constexpr (!IS_COS) {
-            if (e.tile_part) {                              // this tile's share of sum_i cw_i * rowloss_i (4 waves, fixed order)
+            if (e.tile_part) {
                 const float v = wave64_sum_hi(wl_acc);
-                if (lane == 63) pyy_l[wave] = v;            // pyy_l is unused outside cosine
+                if (lane == 63) share_l[wave] = v;
             }
         }
-        lds_barrier();
-
-        // ---- leave the CU: coalesced tiles and per-wave partial sums ----
-        if (!pass1 && !(e.dbg & 16)) {
+        // ---- this wave's rows leave the CU: delta2 as coalesced 16-byte pieces of 128-byte row runs, the per-row partial sums ----
+        if (!pass1 && D2 && !(e.dbg & 16)) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int ch = tid + GEMM_THREADS * i;
-                if (D2) {
-                    const int row = ch >> 3, c16 = ch & 7;
-                    *reinterpret_cast<i32x4*>(D2 + (int64_t)(tm * BM + row) * e.ldd + tn * BN_T + c16 * 8) =
-                        *reinterpret_cast<const i32x4*>(R0 + row * P0 + c16 * 16);
-                }
-                if (D2T) {
-                    const int row = ch >> 4, c16 = ch & 15;
-                    *reinterpret_cast<i32x4*>(D2T + (int64_t)(tn * BN_T + row) * e.lddt + tm * BM + c16 * 8) =
-                        *reinterpret_cast<const i32x4*>(R1 + row * P1 + c16 * 16);
-                }
+                const int ch = lane + 64 * i;
+                *reinterpret_cast<i32x4*>(D2 + (int64_t)(row0 + (ch >> 3)) * e.ldd + tn * BN_T + (ch & 7) * 8) =
+                    *reinterpret_cast<const i32x4*>(R0 + (ch >> 3) * P0 + (ch & 7) * 16);
             }
         }
         {
-            const int w = tid >> 7, k = tid & 127;          // two partial rows per column tile in the consumers' layout: [0] = the row sums, [1] = 0
-            const bool rowok = (tm * BM + k) < e.B;
+            // two partial rows per column tile in the consumers' layout: [0] = the row sums of the 64 columns, [1] = 0
+            const int k = lane & 31, w = lane >> 5;
+            const bool rowok = (row0 + k) < e.B;
             if constexpr (IS_COS) {
                 if (pass1) {
-                    e.cos_part[(int64_t)(tn * 2 + w) * e.Bp + tm * BM + k] = (rowok && w == 0) ? pyy_l[k] : 0.f;
-                    e.cos_part[(int64_t)(2 * p.tiles_n + tn * 2 + w) * e.Bp + tm * BM + k] = (rowok && w == 0) ? pxy_l[k] : 0.f;
+                    e.cos_part[(int64_t)(tn * 2 + w) * e.Bp + row0 + k] = (rowok && w == 0) ? rs_l[k] : 0.f;
+                    e.cos_part[(int64_t)(2 * p.tiles_n + tn * 2 + w) * e.Bp + row0 + k] = (rowok && w == 0) ? xy_l[k] : 0.f;
                 }
             } else {
-                if (e.rowloss_part) e.rowloss_part[(int64_t)(tn * 2 + w) * e.Bp + tm * BM + k] = (rowok && w == 0) ? rowsum_l[k] : 0.f;
-            }
-            if (e.dbv_part && !pass1 && tid < 2 * BN_T) {   // two partial rows per row tile: rows [0, 64) and [64, 128) of the panel
-                const int w2 = tid / BN_T, k2 = tid % BN_T;
-                e.dbv_part[(int64_t)(tm * 2 + w2) * e.Fp + tn * BN_T + k2] = colsum_l[(2 * w2) * BN_T + k2] + colsum_l[(2 * w2 + 1) * BN_T + k2];
-            }
-            if constexpr (!IS_COS) {
-                if (e.tile_part && tid == 0) e.tile_part[tm * p.tiles_n + tn] = (pyy_l[0] + pyy_l[1]) + (pyy_l[2] + pyy_l[3]);
+                if (e.rowloss_part) e.rowloss_part[(int64_t)(tn * 2 + w) * e.Bp + row0 + k] = (rowok && w == 0) ? rs_l[k] : 0.f;
             }
         }
+        lds_barrier();                                      // the four waves' column sums and loss shares are in LDS
+        if (e.dbv_part && !pass1 && wave < 2 && !(e.dbg & 64)) {             // two partial rows per row tile: rows [0, 64) and [64, 128) of the panel; wave w2 adds its pair
+            e.dbv_part[(int64_t)(tm * 2 + wave) * e.Fp + tn * BN_T + lane] = colsum_l[(2 * wave) * BN_T + lane] + colsum_l[(2 * wave + 1) * BN_T + lane];
+        }
+        if constexpr (!IS_COS) {
+            if (e.tile_part && wave == 2 && lane == 0) e.tile_part[tm * p.tiles_n + tn] = (share_l[0] + share_l[1]) + (share_l[2] + share_l[3]);
+        }
+        stamp();
+        // (the next tile's first ring_step barrier orders these LDS reads before the next epilogue's writes)
         }   // (laundered-id scope of the epilogue)
     }
 }
@@ -2629,7 +2696,7 @@ static decode_fn decode_kernel_ast(int loss, int act, bool xbits) {
     return nullptr;
 }
 static int g_decode_dbg = 0;       // dae_set_glds(-500000 - bits): timing probes of gemm_decode_ast (DecodeEpi::dbg)
-static int g_decode_ast = 1;       // dae_set_glds(-15) off / (-16) on; plan option "decode_ast"
+static int g_decode_ast = 0;       // dae_set_glds(-15) off / (-16) on; plan option "decode_ast".  OFF: measured 44 us against 38 for the tile kernel at c2 (profiles/r06_decode_ast.txt)
 constexpr int DECODE_PAIR_LDS = 2 * (TILE_BYTES + 2 * 64 * BKB) > DecGeo<DECODE_BN_BF16>::EPI_BYTES ? 2 * (TILE_BYTES + 2 * 64 * BKB) : DecGeo<DECODE_BN_BF16>::EPI_BYTES;
 static int g_decode_pair = 0;      // dae_set_glds(-13) off / (-14) on; plan option "decode_pair"
 template <typename T> static decode_fn decode_kernel(int loss, int act) {
@@ -2964,7 +3031,7 @@ int launch_decode_loss_n(int dtype, int Bp, int Fp, const GemmSegDesc* segs, int
     e.no_pad_skip = g_pad_skip ? 0 : 1;
     e.dbg = g_decode_dbg;
     // A-stationary persistent form: 16-bit, 64-column tiles, no lo images, every K segment over the same h with K <= 8 tiles (Hp <= 512)
-    bool ast = g_decode_ast && dtype == DAE_BF16 && !wide && !paird && !(e.delta2_2 || e.delta2_t2 || e.x2) && p.seg[0].ktiles <= DecAst::MAXKT;
+    bool ast = g_decode_ast && dtype == DAE_BF16 && !wide && !paird && !(e.delta2_2 || e.delta2_t2 || e.x2) && p.seg[0].ktiles <= DecAst::MAXKT && p.nseg <= 2;
     for (int s = 1; s < p.nseg && ast; ++s)
         ast = p.seg[s].A == p.seg[0].A && p.seg[s].lda_b == p.seg[0].lda_b && p.seg[s].ldb_b == p.seg[0].ldb_b && p.seg[s].ktiles == p.seg[0].ktiles;
     if (ast) {
@@ -3279,7 +3346,7 @@ void set_use_glds(int nst) {
     if (nst == -5) { g_dw_pc = 2; return; }          // tests: the 160 x 128 kernel for every grid that fits one round
     if (nst == -6) { g_w8 = 0; return; }             // A/B: never the 256 x 256 / 8-MFMA-wave kernel
     if (nst == -7) { g_w8 = 1; return; }
-    if (nst <= -500000 && nst > -500064) { g_decode_dbg = -500000 - nst; return; }
+    if (nst <= -500000 && nst > -500128) { g_decode_dbg = -500000 - nst; return; }
     if (nst <= -100 && nst > -1000) { g_dw_rounds = g_dw_rounds_split = (-nst - 100 < 1 ? 1 : -nst - 100); return; }    // rounds of the chip the 160 x 128 dW kernel may take
     if (nst == -13) { g_decode_pair = 0; return; }
     if (nst == -14) { g_decode_pair = 1; return; }

@@ -2,7 +2,7 @@
 """Round-6 fixtures behind the north star's CURVE gate ("loss curve matching reference within 1e-4"), both from the FLOAT32 oracle with the
 reference-exact legacy-RNG stream, exactly like make_full_curve.py / make_curves.py (whose inputs and hyper-parameters they reuse):
 
-  long c1|c2      100 per-batch steps (10 epochs of 10 batches; reference loop autoencoder.py:175-246, the values its epoch line averages at :283-294;
+  long c1|c2|c5   100 per-batch steps (10 epochs of 10 batches; reference loop autoencoder.py:175-246, the values its epoch line averages at :283-294;
                   the CLI's default run is 50 epochs, main_autoencoder.py:71-72) -> long_curve_<cfg>.npz.  The 20-step files stop while the default
                   mode's deviation is still growing; these say where it goes.
   envelope c3 [K [K_order]] the oracle's OWN determinacy of the batch_hard curve (triplet_loss_utils.py:202-259: min / max + float equality route every anchor's
@@ -67,8 +67,18 @@ def run(data, lab, W0, kw, epochs):
 
 def make_long(name):
     import make_curves as M
-    data, lab, W0, kw, _ = config(name)
     t0 = time.time()
+    if name == "c5":           # explicit (anchor, pos, neg) triplets: the estimator's own epoch loop restated in make_curves.fit_explicit
+        data, lab, W0 = M.inputs("c5")
+        r = M.fit_explicit(data, W0, dict(M.CFGS["c5"], epochs=LONG_EPOCHS))
+        out = {k: np.array([h[k] for h in r["history"]], np.float64).reshape(-1) for k in KEYS}
+        W = r["W"].astype(np.float64)
+        out["W_checksum"] = np.array([np.abs(W).sum(), (W ** 2).sum(), W[17, 3], W[-1, -1]])
+        out["inputs_checksum"] = M.checksum(data, lab)
+        np.savez_compressed(long_path(name), **out)
+        print("wrote", long_path(name), "in %.0f s" % (time.time() - t0), "cost", out["cost"][[0, 19, -1]], flush=True)
+        return
+    data, lab, W0, kw, _ = config(name)
     out = run(data, lab, W0, kw, LONG_EPOCHS)
     out["inputs_checksum"] = M.checksum(data, lab)
     np.savez_compressed(long_path(name), **out)

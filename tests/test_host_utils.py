@@ -206,25 +206,38 @@ def test_class_sort_batches_keeps_every_batch_as_a_set():
     assert list(first) == want
 
 
-def test_auto_precision_resolution_is_input_aware_only_for_the_fp16_range(tmp_path):
-    """precision='auto' = _lib.AUTO_PRECISION (f16x2) with or without a train set to look at; data beyond the fp16 range takes the split-bf16 mode."""
+def test_auto_precision_resolution_per_strategy_and_fp16_range(tmp_path):
+    """precision='auto' resolves PER TRIPLET STRATEGY (_lib.AUTO_BY_STRATEGY: the cheapest mode measured to hold the reference's curve over 100 steps -- none
+    f16x2d, batch_all f16x2h, batch_hard bf16x3, explicit triplets f16x2d), with or without a train set to look at; data beyond the fp16 range takes the
+    split-bf16 mode; every input container (ndarray, sparse, list / dict of matrices, validation sets) goes through the fp16 range check."""
     from scipy import sparse
     from dae_rnn_news_recommendation_amd import _lib as L
-    from dae_rnn_news_recommendation_amd.autoencoder import DenoisingAutoencoder
-    m = DenoisingAutoencoder(model_name="p", main_dir="p", results_root=str(tmp_path) + "/", verbose=False)
-    assert m._resolve_precision(None) == L.AUTO_PRECISION == "f16x2"
+    from dae_rnn_news_recommendation_amd.autoencoder import DenoisingAutoencoder, DenoisingAutoencoderTriplet
+    kw = dict(results_root=str(tmp_path) + "/", verbose=False)
+    assert L.AUTO_BY_STRATEGY == {"none": "f16x2d", "batch_all": "f16x2h", "batch_hard": "bf16x3", "explicit": "f16x2d"}
+    assert all(v in L.PRECISIONS for v in L.AUTO_BY_STRATEGY.values()) and L.AUTO_PRECISION == "f16x2h"
+    assert L.PRECISIONS["f16x2h"] == ("f16", 2, 1 | 2 | 4 | 16 | 32 | 64) and L.PRECISIONS["f16x2d"] == ("f16", 2, 1 | 4 | 8 | 128)
     x = sparse.random(20, 30, density=0.2, format="csr", dtype=np.float32, random_state=np.random.RandomState(0))
-    assert m._resolve_precision(x) == "f16x2" and m._resolve_precision(x.toarray()) == "f16x2"
     big = x.copy(); big.data[:] = 3.0e4
-    assert m._resolve_precision(big) == "bf16x3" and m._resolve_precision(big.toarray()) == "bf16x3"
-    m2 = DenoisingAutoencoder(model_name="p2", main_dir="p2", results_root=str(tmp_path) + "/", verbose=False, precision="fp32")
-    assert m2._resolve_precision(big) == "fp32"
-    # a model that stores fp16 images (load_model() resolves 'auto' with no data to look at) refuses values fp16 cannot hold, loudly
-    m._check_storage_range(x); m._check_storage_range(x.toarray()); m._check_storage_range(big)
     huge = x.copy(); huge.data[:] = 7.0e4
-    with pytest.raises(ValueError, match="bf16x3"):
-        m._check_storage_range(huge.toarray())
-    with pytest.raises(ValueError, match="bf16x3"):
-        m._check_storage_range(huge)
+    for strategy, want in (("none", "f16x2d"), ("batch_all", "f16x2h"), ("batch_hard", "bf16x3")):
+        m = DenoisingAutoencoder(model_name="p" + strategy, main_dir="p" + strategy, triplet_strategy=strategy, **kw)
+        assert m._resolve_precision(None) == want and m._resolve_precision(x) == want and m._resolve_precision(x.toarray()) == want, strategy
+        assert m._resolve_precision(big) == "bf16x3" and m._resolve_precision(big.toarray()) == "bf16x3"
+    mt = DenoisingAutoencoderTriplet(model_name="pt", main_dir="pt", **kw)
+    assert mt._resolve_precision(None) == "f16x2d" and mt._resolve_precision({"org": x, "pos": x, "neg": big}) == "bf16x3"
+    m = DenoisingAutoencoder(model_name="p", main_dir="p", **kw)
+    m2 = DenoisingAutoencoder(model_name="p2", main_dir="p2", precision="fp32", **kw)
+    assert m2._resolve_precision(big) == "fp32"
+    # a model that stores fp16 images (load_model() resolves 'auto' with no data to look at) refuses values fp16 cannot hold, loudly -- whatever the container
+    m._check_storage_range(x); m._check_storage_range(x.toarray()); m._check_storage_range(big); m._check_storage_range([x, big]); m._check_storage_range({"a": x})
+    for bad in (huge.toarray(), huge, [x, huge], {"org": x, "neg": huge.toarray()}):
+        with pytest.raises(ValueError, match="bf16x3"):
+            m._check_storage_range(bad)
+    assert m._forward_precision(huge) == "bf16x3"          # nothing trained yet: 'auto' still looks at the data
+    m.precision_used = "f16x2h"                            # ... after fit() the training precision is fixed: a validation set it cannot hold is refused
+    with pytest.raises(ValueError, match="validation"):
+        m._forward_precision(huge)
+    assert m._forward_precision(x) == "f16x2h"
     m2._check_storage_range(huge)
-    DenoisingAutoencoder(model_name="p3", main_dir="p3", results_root=str(tmp_path) + "/", verbose=False, precision="bf16x3")._check_storage_range(huge)
+    DenoisingAutoencoder(model_name="p3", main_dir="p3", precision="bf16x3", **kw)._check_storage_range(huge)

@@ -1,13 +1,7 @@
 #!/bin/bash
-# round 6, GPU call 4: gemm_decode_ast without scratch spills -- parity, then timing probes
-mkdir -p gpurun_out/r06c4
-O=gpurun_out/r06c4
-timeout 300 python -m pytest tests/test_hip_kernels.py -k "decode" -q -x > $O/tests_decode.txt 2>&1; echo "rc $?" >> $O/tests_decode.txt
-tail -3 $O/tests_decode.txt
-for d in 0 1 8 16 24 25 27 31; do
-  timeout 200 python tools/kprof.py --precision f16x2 --strategy none --tag "dbg=$d" --glds $((-500000 - d)) 2>&1 | grep -E "^==|decode_loss" | sed 's/info=.*//' >> $O/probe.txt
-done
-timeout 200 python tools/kprof.py --precision f16x2 --opt decode_ast=0 2>&1 | grep -E "^==|decode_loss" | sed 's/info=.*//' >> $O/probe.txt
-timeout 200 python tools/kprof.py --precision f16x2 2>&1 | grep -E "^==|decode_loss" | sed 's/info=.*//' >> $O/probe.txt
-timeout 200 python tools/kprof.py --precision bf16 2>&1 | grep -E "^==|decode_loss" | sed 's/info=.*//' >> $O/probe.txt
-cat $O/probe.txt
+# round 6, GPU call 10: which lo terms does c1 (strategy none) need to hold 1e-4 over 100 steps?  and f16x2h candidates on c2
+mkdir -p gpurun_out/r06c10
+O=gpurun_out/r06c10
+timeout 900 python tools/curve_modes.py --config c1 --modes f16x2:13,f16x2:37,f16x2:133,f16x2:45,f16x2:141,f16x2:165,f16x2:173,f16x3 --time > $O/curve_c1_masks.txt 2>&1
+timeout 900 python tools/curve_modes.py --config c2 --modes f16x2:69,f16x2:21,f16x2:85,f16x2:375,f16x2:471 --time > $O/curve_c2_masks.txt 2>&1
+grep -h "^\[" $O/curve_c1_masks.txt $O/curve_c2_masks.txt
