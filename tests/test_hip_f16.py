@@ -226,3 +226,24 @@ def test_step_f16_encode_from_the_16bit_shadow(dtype):
         assert abs(st[0] - r["cost"]) <= 1e-3 * abs(r["cost"]), (st[0], r["cost"])          # h from 11-bit weights: ~2e-4 on the cost
         assert abs(st[2] - r["triplet_loss"]) <= 2e-3 * abs(r["triplet_loss"]), (st[2], r["triplet_loss"])
         assert _rel(dW, r["dW"]) < 2e-2 and _rel(dbh, r["dbh"]) < 2e-2, (_rel(dW, r["dW"]), _rel(dbh, r["dbh"]))
+
+
+@pytest.mark.parametrize("dtype,strategy,loss_func,acts", [("f16x2", "batch_all", "cross_entropy", ("sigmoid", "sigmoid")), ("f16", "none", "mean_squared", ("tanh", "none")),
+                                                           ("bf16", "batch_all", "cosine_proximity", ("sigmoid", "sigmoid"))])
+def test_step_with_the_persistent_a_stationary_decode_kernel(dtype, strategy, loss_func, acts):
+    """Plan option decode_ast = 1 (gemm_decode_ast: h fragments register-resident over the whole K, W streamed through a 6-slot LDS-DMA ring, persistent
+    workgroups, wave-local epilogue, delta2^T straight from the accumulator layout) against the default tile kernel: the same products summed per K tile in
+    the same order, so the losses agree to fp32 rounding of the partial sums and the gradients / parameters to the last bits of the 16-bit delta2 images.
+    The kernel is OFF by default (measured 44 us against 38 at c2: profiles/r06_decode_ast.txt); this keeps its parity covered."""
+    from dae_rnn_news_recommendation_amd import _lib as L
+    kw = dict(steps=2, seed=23, N=500, F=1100, H=200, B=300)
+    try:
+        a, ra, pa = _run_case(dtype, strategy, loss_func, acts, "gradient_descent", options={"decode_ast": 1}, **kw)
+    finally:
+        L.set_glds_all(-15)
+    b, rb, pb = _run_case(dtype, strategy, loss_func, acts, "gradient_descent", options={"decode_ast": 0}, **kw)
+    for (r, sa, dWa, dbha, dbva), (_, sb, dWb, dbhb, dbvb) in zip(a, b):
+        assert np.allclose(sa[:3], sb[:3], rtol=3e-6, atol=0), (sa, sb)
+        assert abs(sa[0] - r["cost"]) <= (1e-4 if dtype != "bf16" else 2e-3) * abs(r["cost"])
+        assert _rel(dWa, np.asarray(dWb, np.float64)) < 1e-3 and _rel(dbha, np.asarray(dbhb, np.float64)) < 1e-3, (_rel(dWa, np.asarray(dWb, np.float64)),)
+        assert np.allclose(dbva, dbvb, rtol=1e-4, atol=1e-7)

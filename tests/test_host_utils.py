@@ -216,7 +216,7 @@ def test_auto_precision_resolution_per_strategy_and_fp16_range(tmp_path):
     kw = dict(results_root=str(tmp_path) + "/", verbose=False)
     assert L.AUTO_BY_STRATEGY == {"none": "f16x2d", "batch_all": "f16x2h", "batch_hard": "bf16x3", "explicit": "f16x2d"}
     assert all(v in L.PRECISIONS for v in L.AUTO_BY_STRATEGY.values()) and L.AUTO_PRECISION == "f16x2h"
-    assert L.PRECISIONS["f16x2h"] == ("f16", 2, 1 | 2 | 4 | 16 | 32 | 64) and L.PRECISIONS["f16x2d"] == ("f16", 2, 1 | 4 | 8 | 128)
+    assert L.PRECISIONS["f16x2h"] == ("f16", 2, 1 | 2 | 4 | 32 | 64) and L.PRECISIONS["f16x2d"] == ("f16", 2, 1 | 4 | 8 | 128)
     x = sparse.random(20, 30, density=0.2, format="csr", dtype=np.float32, random_state=np.random.RandomState(0))
     big = x.copy(); big.data[:] = 3.0e4
     huge = x.copy(); huge.data[:] = 7.0e4
