@@ -99,7 +99,7 @@ def parse():
     ap.add_argument("--exchange-impl", default="auto", choices=["auto", "native", "torch"],
                     help="N>1, all-reduce exchange: who issues the collective -- native = the C ABI's own RCCL communicator on the step's stream "
                          "(dae_dp_exchange), torch = torch.distributed's process group; auto = native over the nccl backend")
-    ap.add_argument("--prewarm", type=float, default=0.25, help="seconds of untimed GPU work before the warm-up steps (clock ramp); 0 = none")
+    ap.add_argument("--prewarm", type=float, default=0.25, help="seconds of untimed steps of the same loop before the W warm-up steps (clock ramp of a fresh process); 0 = none")
     ap.add_argument("--profile-steps", type=int, default=20)
     ap.add_argument("--fit-epochs", type=int, default=6)
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
@@ -224,9 +224,8 @@ class Runner:
         o = order.astype(np.int32)
         if self.explicit:
             d["order"] = pinned_copy(np.stack([o, o + self.N, o + 2 * self.N]))
-        else:
-            d["order"] = pinned_copy(o)
-            d["labels"] = pinned_copy(self.labels[order])
+        else:          # one pinned array [row order | labels in that order], one H2D copy per epoch (as DenoisingAutoencoder._stage_epoch)
+            d["order_labels"] = pinned_copy(np.stack([o, self.labels[order].astype(np.int32)]))
         return d
 
     def _prep_epoch(self):
@@ -237,8 +236,11 @@ class Runner:
             self.plan = dict(corr_mode=L.CORR_KEEPBITS, keep_bits=self.bits)
         else:
             self.plan = dict(corr_mode=L.CORR_PHILOX_MASK, seed=1234, rng_stream=self.epoch, corr_frac=0.3)
-        self.order = d["order"].to(self.eng.device, non_blocking=True)
-        self.lab = None if self.explicit else d["labels"].to(self.eng.device, non_blocking=True)
+        if self.explicit:
+            self.order, self.lab = d["order"].to(self.eng.device, non_blocking=True), None
+        else:
+            both = d["order_labels"].to(self.eng.device, non_blocking=True)
+            self.order, self.lab = both[0], both[1]
 
     def batch(self, b):
         lo = b * self.B
@@ -438,6 +440,12 @@ def timed_steps(run, steps, warmup):
     t0 = time.perf_counter()
     for _ in range(steps):
         run.step()
+    # poll an event recorded behind the last step before the synchronize: a blocking hipDeviceSynchronize wakes the host 50-200 us after the GPU went idle
+    # (measured: 18 us per step of a 20-step region), which is host scheduling, not step time; the bracket stays barrier + synchronize on both sides
+    done = torch.cuda.Event()
+    done.record()
+    while not done.query():
+        pass
     torch.cuda.synchronize(); dp.barrier(); torch.cuda.synchronize()
     return dp.allreduce_max_float(time.perf_counter() - t0)
 
@@ -463,15 +471,19 @@ def box_info(torch):
     return info
 
 
-def _prewarm_clocks(torch, device, seconds=0.25):
-    """Untimed, outside the model: keep the GPU busy for a moment so that the W warm-up steps and the timed steps run at
-    steady clocks (a fresh process starts from the idle power state; a 5 ms warm-up does not leave it)."""
-    x = torch.randn(4096, 4096, device=device, dtype=torch.bfloat16)
+def _prewarm_clocks(torch, run, seconds=0.25):
+    """Untimed, before the W warm-up steps: keep the GPU busy with the workload's OWN step loop for a moment, so that the warm-up and the timed steps run at
+    steady clocks.  A fresh process starts from the idle power state and this latency-bound step climbs to its steady rate over tens of milliseconds
+    (tools/region_trace.py, profiles/r06_region_trace.txt: 211 -> 202 -> 197 -> 194 us per step over the first 60 ms; a 0.25 s bf16 matmul in front -- rounds 3-5 --
+    changed nothing).  Reported in the JSON line as `prewarm`; the W warm-up steps and the K timed steps follow exactly as the contract asks."""
     t0 = time.perf_counter()
+    n = 0
     while time.perf_counter() - t0 < seconds:
-        for _ in range(10):
-            x = (x @ x).clamp_(-1, 1)
+        for _ in range(20):
+            run.step()
+        n += 20
         torch.cuda.synchronize()
+    return n
 
 
 def self_launch(n):
@@ -536,8 +548,7 @@ def main():
     assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world} (an external launcher started another number of ranks)"
     c = a.cfg
     run = Runner(a, rank, world)
-    if a.prewarm > 0:
-        _prewarm_clocks(torch, run.eng.device, a.prewarm)
+    n_prewarm = _prewarm_clocks(torch, run, a.prewarm) if a.prewarm > 0 else 0
     _log("runner ready")
 
     dt = timed_steps(run, a.steps, a.warmup)
@@ -561,6 +572,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
         "fit": None,          # filled below: the same workload through DenoisingAutoencoder.fit() (timed over ~0.1 s; the sturdier figure)
         "timed_region": {"steps": a.steps, "seconds": dt}, "long_run": long_run, "box": box_info(torch),
+        "prewarm": {"seconds": a.prewarm, "steps": n_prewarm, "what": "untimed steps of the same loop before the W warm-up steps (clock ramp of a fresh process; --prewarm 0 disables)"},
         "precision_note": ("`value`, `kernels`, `roofline` are measured in precision=%r -- %s; the other modes are the objects `f16x2` / `bf16x3` / `fp32` / `bf16` "
                            "below, `bf16` being faster but outside the 1e-4 gate" % (a.precision, "what precision='auto' (the product default) resolves to for "
                            "this config's triplet strategy: the cheapest mode measured to hold the reference's loss curve within 1e-4 over 100 steps (batch_hard: inside the oracle's own envelope)" if a.precision_asked == "auto" else "as asked")),

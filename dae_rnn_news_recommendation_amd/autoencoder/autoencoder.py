@@ -419,9 +419,14 @@ class DenoisingAutoencoder(object):
         if sort_batch and label_ids is not None:
             draw['order'] = utils.class_sort_batches(draw['order'], label_ids, sort_batch)
         order = draw['order']
-        draw['order_t'] = pinned_copy(order.astype(np.int32))
-        if label_ids is not None:
-            draw['labels_t'] = pinned_copy(label_ids[order])
+        if label_ids is not None and np.asarray(label_ids).dtype == np.int32:
+            # ONE pinned array [2 x N] = [row order | labels in that order]: the step that opens an epoch waits for ONE host -> device copy on its
+            # stream instead of two (measured: +34 us on that step for the two copies, tools/region_trace.py)
+            draw['order_labels_t'] = pinned_copy(np.stack([order.astype(np.int32), np.asarray(label_ids)[order]]))
+        else:
+            draw['order_t'] = pinned_copy(order.astype(np.int32))
+            if label_ids is not None:
+                draw['labels_t'] = pinned_copy(label_ids[order])
         if 'bits' in draw:
             draw['bits_t'] = pinned_copy(draw['bits'])
         return draw
@@ -454,10 +459,14 @@ class DenoisingAutoencoder(object):
         N = train_set.shape[0]
         plan = self._corruption_plan(draw, epoch)
         order = draw['order']
-        order_dev = (draw['order_t'] if 'order_t' in draw else torch.from_numpy(order.astype(np.int32))).to(eng.device, non_blocking=True)
         labels_dev = None
-        if label_ids is not None:
-            labels_dev = (draw['labels_t'] if 'labels_t' in draw else torch.from_numpy(label_ids[order])).to(eng.device, non_blocking=True)
+        if 'order_labels_t' in draw:
+            both = draw['order_labels_t'].to(eng.device, non_blocking=True)
+            order_dev, labels_dev = both[0], both[1]
+        else:
+            order_dev = (draw['order_t'] if 'order_t' in draw else torch.from_numpy(order.astype(np.int32))).to(eng.device, non_blocking=True)
+            if label_ids is not None:
+                labels_dev = (draw['labels_t'] if 'labels_t' in draw else torch.from_numpy(label_ids[order])).to(eng.device, non_blocking=True)
         stats = self._stats[epoch]
         shard_w = []
         sp = plan.pop('_sp', None)

@@ -20,8 +20,8 @@ SLOT_KERNEL_C4 = [("gather", "gather_dense_kernel"), ("encode_gemm", "gemm_nt_w8
                   ("decode_loss", "gemm_decode_loss"), ("dh_gemm", "gemm_nt_w8<2>"), ("dw_gemm", "gemm_dw")]
 NOTE = {"encode_gemm": "corrupt + gather + sparse x~.W (fp32 master W) + bias + act, all images of h, x bit image, x~^T scatter, label statistics",
         "gram": "split 16-bit Gram (3 products) on 64 x 64 tiles over the whole K, one slab", "miner": "batch_all on a 16 x 16 lane grid (FAST pair sweep), positive-triplet count from sorted runs", "sym_scale": "Gs = a/Nv (G + G^T) -> bf16",
-        "decode_loss": "128 x 64 tiles: GEMM (f16x2: h.W_hi + h.W_lo) + loss + delta2 (two layouts), x from bits", "dh_gemm": "delta2.W_hi + delta2.W_lo + Gs.h, split-K 8",
-        "dh_finish": "slab reduction, act', delta1^T, column sums", "dw_gemm": "160 x 128 tiles: dW GEMM (two K segments) + SGD update of W and the hi + lo images of both 16-bit shadows",
+        "decode_loss": "128 x 64 tiles: GEMM (f16x2h: h.W_hi + h.W_lo + h_lo.W_hi) + loss + delta2 (two layouts), x from bits", "dh_gemm": "delta2.W_hi + delta2.W_lo + Gs.h, split-K 8",
+        "dh_finish": "slab reduction, act', delta1^T, column sums", "dw_gemm": "160 x 128 tiles: dW GEMM (f16x2h: x~^T.[d1_hi ; d1_lo] + d2^T.[h_hi ; h_lo], paired stages) + SGD update of W and the hi + lo images of both 16-bit shadows",
         "bias_grads": "step tail: bias grads + update, statistics, x~^T un-scatter"}
 
 
@@ -34,7 +34,7 @@ for c in (() if TRAFFIC_ONLY else ("c1", "c2", "c3", "c4", "c5")):
     copy(f"bench_{c}.json", f"bench_n1_{c}.json")
 copy("bench_under_rocprof.json", "bench_under_rocprof.json")
 copy("kernel_stats.md", "rocprofv3_kernel_stats.md"); copy("pmc_counters.md", "rocprofv3_pmc_counters.md")
-copy("pmc_counters_c4.md", "rocprofv3_pmc_counters_c4.md"); copy("host.txt", "host.txt")
+copy("pmc_counters_c4.md", "rocprofv3_pmc_counters_c4.md"); copy("pmc_counters_c5.md", "rocprofv3_pmc_counters_c5.md"); copy("host.txt", "host.txt")
 copy("kprof.txt", "kprof.txt"); copy("miner_timeline.txt", "miner_timeline.txt"); copy("dp_step_breakdown.txt", "dp_step_breakdown.txt")
 
 
@@ -74,11 +74,11 @@ def pmc_of(fname):
     return out
 
 
-pmc, pmc4 = pmc_of("pmc_counters.md"), pmc_of("pmc_counters_c4.md")
+pmc, pmc4, pmc5 = pmc_of("pmc_counters.md"), pmc_of("pmc_counters_c4.md"), pmc_of("pmc_counters_c5.md")
 traffic = {"_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), per launch, KB->bytes, FETCH_SIZE doubled (gfx950 "
                     "correction, MI355X_MICROARCH.md); workload = tools/run_steps.py (c2: BASELINE configs[1] step; c4: dense F = 50000)",
            "_source_hash": open(os.path.join(src, "source_hash.txt")).read().strip()}
-for cfg, slots, tab in (("c2", SLOT_KERNEL, pmc), ("c4", SLOT_KERNEL_C4, pmc4)):
+for cfg, slots, tab in (("c2", SLOT_KERNEL, pmc), ("c4", SLOT_KERNEL_C4, pmc4), ("c5", SLOT_KERNEL, pmc5)):
     traffic[cfg] = {}
     for slot, kern in slots:
         c = find(tab, kern)
@@ -114,7 +114,8 @@ if cb and cb.get("value"):
     L.append(f"| CPU baseline: PyTorch-CPU fp32 restatement, literal B^3 batch_all, {cb['cores']} threads | {cb['value']:.1f} samples/s |")
     if cb.get("chunked"): L.append(f"| CPU baseline, chunked (memory-lean) form | {cb['chunked']['samples_per_s']:.1f} samples/s |")
 fl = b["final_losses"]
-for mode, what in (("f16x2", "fp16 images, W hi + lo: inside the 1e-4 curve gate"), ("bf16x3", "split-bf16, three terms: inside the gate"),
+for mode, what in (("f16x2h", "fp16 images; W, h, delta1 hi + lo: inside the 1e-4 gate over 100 steps"), ("f16x2d", "fp16 images; W, delta2 hi + lo"),
+                   ("f16x2", "fp16 images, W alone hi + lo: holds 20 steps, leaves 1e-4 at step 29"), ("bf16x3", "split-bf16, three terms: inside the gate"),
                    ("fp32", "exact-fp32 MFMA: inside the gate"), ("bf16", "plain bf16: OUTSIDE the gate")):
     if b.get(mode) and b[mode].get("value"):
         L.append(f"| `precision='{mode}'` ({what}), same K steps | {b[mode]['value']:,.0f} ({1e3 * b[mode]['ms_per_step']:.1f} us/step) |")
