@@ -30,7 +30,7 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
-# ---- fault hunting (tools/history/r04_guard.sh): both knobs are test infrastructure, off unless the environment asks --------------------
+# ---- fault hunting (profiles/history_gpu_call_scripts.txt: r04_guard.sh): both knobs are test infrastructure, off unless the environment asks --------------------
 # DAE_GUARD_ALLOC=end|start : every torch device tensor gets its own mapping with unmapped address space on both sides
 #                             (tools/guard_alloc.cpp), so an out-of-bounds access of a kernel faults on every box
 # DAE_FORCE_CUS=n           : the GEMM dispatch believes the device has n compute units (dae_set_glds(-1000 - n))

@@ -34,7 +34,7 @@ for c in (() if TRAFFIC_ONLY else ("c1", "c2", "c3", "c4", "c5")):
     copy(f"bench_{c}.json", f"bench_n1_{c}.json")
 copy("bench_under_rocprof.json", "bench_under_rocprof.json")
 copy("kernel_stats.md", "rocprofv3_kernel_stats.md"); copy("pmc_counters.md", "rocprofv3_pmc_counters.md")
-copy("pmc_counters_c4.md", "rocprofv3_pmc_counters_c4.md"); copy("pmc_counters_c5.md", "rocprofv3_pmc_counters_c5.md"); copy("host.txt", "host.txt")
+copy("pmc_counters_c4.md", "rocprofv3_pmc_counters_c4.md"); copy("pmc_counters_c5.md", "rocprofv3_pmc_counters_c5.md"); copy("pmc_counters_c1.md", "rocprofv3_pmc_counters_c1.md"); copy("pmc_counters_c3.md", "rocprofv3_pmc_counters_c3.md"); copy("bench_driver_form.json", "bench_driver_form.json"); copy("host.txt", "host.txt")
 copy("kprof.txt", "kprof.txt"); copy("miner_timeline.txt", "miner_timeline.txt"); copy("dp_step_breakdown.txt", "dp_step_breakdown.txt")
 
 
@@ -75,10 +75,11 @@ def pmc_of(fname):
 
 
 pmc, pmc4, pmc5 = pmc_of("pmc_counters.md"), pmc_of("pmc_counters_c4.md"), pmc_of("pmc_counters_c5.md")
+pmc1, pmc3 = pmc_of("pmc_counters_c1.md"), pmc_of("pmc_counters_c3.md")
 traffic = {"_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), per launch, KB->bytes, FETCH_SIZE doubled (gfx950 "
                     "correction, MI355X_MICROARCH.md); workload = tools/run_steps.py (c2: BASELINE configs[1] step; c4: dense F = 50000)",
            "_source_hash": open(os.path.join(src, "source_hash.txt")).read().strip()}
-for cfg, slots, tab in (("c2", SLOT_KERNEL, pmc), ("c4", SLOT_KERNEL_C4, pmc4), ("c5", SLOT_KERNEL, pmc5)):
+for cfg, slots, tab in (("c2", SLOT_KERNEL, pmc), ("c4", SLOT_KERNEL_C4, pmc4), ("c5", SLOT_KERNEL, pmc5), ("c1", SLOT_KERNEL, pmc1), ("c3", SLOT_KERNEL, pmc3)):
     traffic[cfg] = {}
     for slot, kern in slots:
         c = find(tab, kern)
@@ -106,6 +107,10 @@ L.append("All files of this set come from ONE `tools/make_profile_report.sh` run
          f"binary).  Kernel sources hash `{traffic['_source_hash']}` (bench.source_hash).\n")
 L.append(f"\n## Headline (`python bench.py --gpus 1 --steps {b['steps']} --warmup {b['warmup']}`, default config c2 = BASELINE configs[1], precision {b.get('dtype')})\n\n| metric | value |\n|---|---|")
 L.append(f"| training samples/s (device-Philox masking, `value`) | **{b['value']:,.0f}** ({1e3 * b['ms_per_step']:.1f} us/step) |")
+bd = load("bench_driver_form.json")
+if bd:
+    L.append(f"| the driver's command, `python bench.py --gpus 1 --steps 20 --warmup 5` (`value` over exactly 20 steps) | {bd['value']:,.0f} ({1e3 * bd['ms_per_step']:.1f} us/step"
+             + (f"; >= 50 ms `long_run` of the same process: {1e3 * bd['long_run']['ms_per_step']:.1f} us/step" if bd.get("long_run") else "") + ") |")
 f = b.get("fit", {})
 if "philox" in f: L.append(f"| through `DenoisingAutoencoder.fit()` (N x timed epochs / wall, first epoch excluded), Philox | {f['philox']['samples_per_s']:,.0f} |")
 if "numpy" in f: L.append(f"| same, reference-exact NumPy legacy stream (native MT19937 continuation, feeder thread) | {f['numpy']['samples_per_s']:,.0f} |")
@@ -132,8 +137,9 @@ for c in ("c1", "c2", "c3", "c4", "c5"):
     if not x: continue
     ff = x.get("fit", {})
     rr = x.get("roofline") or {}
-    L.append(f"| {c} | {x['value']:,.0f} | {1e3 * x['ms_per_step']:.1f} | {ff.get('philox', {}).get('samples_per_s', float('nan')):,.0f} | "
-             f"{ff.get('numpy', {}).get('samples_per_s', float('nan')):,.0f} | {rr.get('bound', '')} {100 * rr.get('frac', 0):.1f} % ({rr.get('kernel', '').split(' (')[0]}) |")
+    sps = lambda k: (ff.get(k) or {}).get('samples_per_s') or float('nan')         # (c4: the numpy-RNG leg is skipped with a stated reason)
+    L.append(f"| {c} ({x.get('dtype')}) | {x['value']:,.0f} | {1e3 * x['ms_per_step']:.1f} | {sps('philox'):,.0f} | "
+             f"{sps('numpy'):,.0f} | {rr.get('bound', '')} {100 * rr.get('frac', 0):.1f} % ({rr.get('kernel', '').split(' (')[0]}; traffic {rr.get('traffic')}) |")
 L.append("\n## Per-kernel breakdown of one c2 step (HIP events on the step's stream vs rocprofv3 --kernel-trace of the same bench)\n")
 L.append("| step slot | kernel symbol | HIP-event avg us | rocprofv3 avg us | roofline (events) | HBM read MB (FETCH_SIZE x2) | HBM write MB | what it does |")
 L.append("|---|---|---:|---:|---|---:|---:|---|")
@@ -188,6 +194,6 @@ if os.path.exists(fb):
              "epoch and the container's 16-CPU cgroup quota throttled the whole process; with the single-threaded staging the reference-exact RNG mode "
              "runs at the Philox rate (table above).\n")
 L.append(f"PMC detail: `{rnd}_rocprofv3_pmc_counters.md` (c4: `{rnd}_rocprofv3_pmc_counters_c4.md`); per-workgroup timeline of the miner: `{rnd}_miner_timeline.txt`;\n"
-         f"`tools/kprof.py` output: `{rnd}_kprof.txt`; what was tried and what it bought: `{rnd}_experiments.md`.\n")
+         f"`tools/kprof.py` output: `{rnd}_kprof.txt`; round-6 evidence files: `{rnd}_curve_modes.txt` (which mode holds which curve), `{rnd}_curve_tests.txt`, `{rnd}_decode_ast.txt` (the persistent decode kernel: built, slower), `{rnd}_region_trace.txt`.\n")
 open(os.path.join(dst, f"{rnd}_summary.md"), "w").write("\n".join(L))
 print("\n".join(L))

@@ -17,6 +17,12 @@ $T $PMC SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLE
 $T $PMC SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAVES TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc_sq2 -o s2 -- python tools/run_steps.py 20 > /dev/null 2>> $OUT/pmc.err
 $T $PMC FETCH_SIZE -d $OUT/pmc_fetch4 -o f4 -- python tools/run_steps.py 10 batch_all c4 > /dev/null 2>> $OUT/pmc.err
 $T $PMC WRITE_SIZE -d $OUT/pmc_write4 -o w4 -- python tools/run_steps.py 10 batch_all c4 > /dev/null 2>> $OUT/pmc.err
+for cs in "1 none" "3 batch_hard"; do set -- $cs   # c1 / c3 run other precision modes than c2 (auto per strategy): their own passes
+  $T $PMC FETCH_SIZE -d $OUT/pmc_fetch$1 -o f$1 -- python tools/run_steps.py 20 $2 c2 > /dev/null 2>> $OUT/pmc.err
+  $T $PMC WRITE_SIZE -d $OUT/pmc_write$1 -o w$1 -- python tools/run_steps.py 20 $2 c2 > /dev/null 2>> $OUT/pmc.err
+  python tools/pmc_summary.py $OUT/pmc_fetch$1/f$1_results.db $OUT/pmc_write$1/w$1_results.db > $OUT/pmc_counters_c$1.md
+  rm -rf $OUT/pmc_fetch$1 $OUT/pmc_write$1
+done
 $T $PMC FETCH_SIZE -d $OUT/pmc_fetch5 -o f5 -- python tools/run_steps.py 20 explicit c5 > /dev/null 2>> $OUT/pmc.err
 $T $PMC WRITE_SIZE -d $OUT/pmc_write5 -o w5 -- python tools/run_steps.py 20 explicit c5 > /dev/null 2>> $OUT/pmc.err
 python tools/pmc_summary.py $OUT/pmc_fetch/f_results.db $OUT/pmc_write/w_results.db $OUT/pmc_sq/s_results.db $OUT/pmc_sq2/s2_results.db > $OUT/pmc_counters.md
@@ -25,7 +31,8 @@ python tools/pmc_summary.py $OUT/pmc_fetch5/f5_results.db $OUT/pmc_write5/w5_res
 rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_sq $OUT/pmc_sq2 $OUT/pmc_fetch4 $OUT/pmc_write4 $OUT/pmc_fetch5 $OUT/pmc_write5
 # the traffic file bench.py quotes (same kernels, same box, minutes apart)
 python tools/build_profile_summary.py $OUT $TAG --traffic-only > /dev/null
-$T python bench.py --config c2 --steps 300 --warmup 30 > $OUT/bench_c2.json 2> $OUT/bench.err
+$T python bench.py --steps 20 --warmup 5 > $OUT/bench_driver_form.json 2> $OUT/bench.err      # exactly the driver's command
+$T python bench.py --config c2 --steps 300 --warmup 30 > $OUT/bench_c2.json 2>> $OUT/bench.err
 $T python bench.py --config c1 --steps 300 --warmup 30 > $OUT/bench_c1.json 2>> $OUT/bench.err
 $T python bench.py --config c3 --steps 300 --warmup 30 > $OUT/bench_c3.json 2>> $OUT/bench.err
 $T python bench.py --config c5 --steps 200 --warmup 20 --no-cpu-baseline > $OUT/bench_c5.json 2>> $OUT/bench.err
