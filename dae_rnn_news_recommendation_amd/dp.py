@@ -428,11 +428,18 @@ class Comm:
         self.device = torch.device(device)
         idb = (C.c_uint8 * L.COMM_ID_BYTES)()
         with torch.cuda.device(self.device), _stdout_to_stderr():      # RCCL prints its version banner to STDOUT when a communicator comes up
+            err = None
             if self.rank == 0:
-                L.check(lib.dae_comm_unique_id(idb), "dae_comm_unique_id", lib)
+                try:
+                    L.check(lib.dae_comm_unique_id(idb), "dae_comm_unique_id", lib)
+                except RuntimeError as e:      # (RCCL missing ...): the other ranks are waiting in the broadcast below -- send them an all-zero id so
+                    err = e                    # that EVERY rank raises and falls back together instead of rank 0 alone leaving the rendezvous
+                    idb = (C.c_uint8 * L.COMM_ID_BYTES)()
             if self.world > 1:
                 raw = broadcast_array(np.frombuffer(bytes(idb), np.uint8).copy(), src=0)
                 idb = (C.c_uint8 * L.COMM_ID_BYTES)(*[int(v) for v in raw])
+            if not any(bytes(idb)):
+                raise RuntimeError("dae_comm: rank 0 could not create a communicator id (%s)" % (err if err is not None else "all-zero id received"))
             h = C.c_void_p()
             L.check(lib.dae_comm_init(idb, self.rank, self.world, C.byref(h)), "dae_comm_init", lib)
             self.handle = h
