@@ -608,6 +608,8 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
         // split-bf16 mode: CSR input encoded from the fp32 master weights (h is fp32-accurate and its hi / lo images come from the same
         // launch); x~ must be exact in bf16 (binary data, or values with <= 8 significant bits).  Every phase: the data-parallel
         // exchange of this mode moves fp32 gradients and fp32 master rows (dp.ShardedExchange), so the master is current on every rank
+        // (h from the 16-bit hi image of W alone was measured in round 6, profiles/r06_ab_measurements.txt: the same 26.8 us -- the kernel is not bound by its
+        //  W-row bytes -- and the triplet leg of c2 leaves the gate at step 5 (1.5e-3): refused, not offered)
         DAE_CHECK_ARG((use_sparse && p->enc_w32_ok) || dense_in, "train_step: split-bf16 mode needs the fp32-master sparse encode (CSR input) or a dense train set");
         DAE_CHECK_ARG(!p->b.grad_lo, "train_step: split-bf16 mode exchanges fp32 gradients (no bf16 gradient image)");
         DAE_CHECK_ARG(!dw_bits, "train_step: split-bf16 mode streams the dense x~^T image (option dw_bits off)");

@@ -4,7 +4,7 @@ tests/golden/make_long_curves.py:
   --config c1|c2  the 100-step float32-oracle curve (long_curve_<cfg>.npz): max relative deviation per leg, the first step that leaves 1e-4
   --config c3     the 20-step batch_hard curve against the oracle's own envelope (envelope_c3.npz: K+1 oracle runs, one weight +-1 ulp each):
                   per leg the largest deviation from run 0 and the largest ratio deviation / gate, gate = max(1e-4, 3 x running envelope)
-A mode is `name` or `name:x3_terms` (plan option, the lo-term mask of the split 16-bit modes).  Also prints the step time of each mode (--time).
+A mode is `name[:x3_terms][:option=value ...]` (plan options; x3_terms = the lo-term mask of the split 16-bit modes).  Also prints the step time of each mode (--time).
 usage: python tools/curve_modes.py --config c3 --modes f16x2,f16x2:343,f16x3,bf16x3,fp32 [--time]"""
 import argparse
 import os
@@ -71,8 +71,15 @@ def main():
         gold = {q: G[q] for q in ("cost", "ae", "triplet")}
         gate = {q: np.full(len(G["cost"]), 1e-4) for q in gold}
     for spec in a.modes.split(","):
-        mode, _, terms = spec.partition(":")
-        opts = {"x3_terms": int(terms)} if terms else None
+        parts = spec.split(":")                 # name[:x3_terms][:option=value ...]
+        mode = parts[0]
+        opts = {}
+        for q in parts[1:]:
+            if "=" in q:
+                k, v = q.split("="); opts[k] = int(v)
+            elif q:
+                opts["x3_terms"] = int(q)
+        opts = opts or None
         model, pb = fit_curve(name, mode, data, lab, W0, kw, epochs, opts)
         out = []
         for col, q in ((0, "cost"), (1, "ae"), (2, "triplet")):
