@@ -1,4 +1,4 @@
-"""100-step (10-epoch) full-shape loss curves of BASELINE.json configs c1, c2 and c5 against the FLOAT32 oracle's per-batch losses frozen by
+"""100-step (10-epoch; c4: 50 epochs of its 1600-row set) full-shape loss curves of BASELINE.json configs c1, c2, c4 and c5 against the FLOAT32 oracle's per-batch losses frozen by
 tests/golden/make_long_curves.py -- the north star's gate is a CURVE ("loss curve matching reference within 1e-4"), the reference CLI trains 50 epochs
 (main_autoencoder.py:71-72; the per-batch values its epoch line averages: autoencoder.py:283-294), and a 20-step curve stops while a low-precision mode's
 deviation is still growing: round 5's default 'f16x2' (fp16 images, W alone hi + lo) holds 20 steps and then leaves 1e-4 at step 29 of c2 (triplet leg,
@@ -18,8 +18,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "golden"))
 
 # (config, precision, gate on every step, what the case pins)
-CASES = [("c2", "auto", 1e-4), ("c1", "auto", 1e-4), ("c5", "auto", 1e-4), ("c2", "bf16x3", 2e-5), ("c1", "bf16x3", 2e-5),
+CASES = [("c2", "auto", 1e-4), ("c1", "auto", 1e-4), ("c5", "auto", 1e-4), ("c4", "auto", 1e-4), ("c2", "bf16x3", 2e-5), ("c1", "bf16x3", 2e-5),
          ("c2", "f16x2", 6e-4), ("c1", "f16x2", 6e-4)]
+
+
+def _epochs(name):
+    import make_long_curves as ML
+    return 50 if name == "c4" else ML.LONG_EPOCHS          # c4's set is 1600 rows = 2 steps per epoch
 
 
 def _fit(name, precision, tmp):
@@ -34,10 +39,10 @@ def _fit(name, precision, tmp):
         cf = c["cf"]
     else:
         data, lab, W0, kw, _ = ML.config(name)
-        cf = 20
+        cf = M.CFGS[name]["cf"] if name in M.CFGS else 20
     assert M.checksum(data, lab).tolist() == G["inputs_checksum"].tolist()          # the same regenerated inputs
     common = dict(model_name=name, main_dir=name, compress_factor=cf, enc_act_func="sigmoid", dec_act_func="sigmoid", loss_func=kw["loss_func"],
-                  num_epochs=ML.LONG_EPOCHS, batch_size=kw["batch_size"], opt="gradient_descent", learning_rate=kw["learning_rate"], corr_type="masking",
+                  num_epochs=_epochs(name), batch_size=kw["batch_size"], opt="gradient_descent", learning_rate=kw["learning_rate"], corr_type="masking",
                   corr_frac=kw["corr_frac"], verbose=0, verbose_step=1, seed=kw["seed"], alpha=kw["alpha"], precision=precision, rng="numpy",
                   init_weights=W0, results_root=str(tmp) + "/")
     if name == "c5":
@@ -46,7 +51,7 @@ def _fit(name, precision, tmp):
     else:
         model = DenoisingAutoencoder(triplet_strategy=kw["triplet_strategy"], **common)
         model.fit(data, train_set_label=lab)
-    pb = np.concatenate([model.epoch_stats(e + 1)["per_batch"] for e in range(ML.LONG_EPOCHS)])
+    pb = np.concatenate([model.epoch_stats(e + 1)["per_batch"] for e in range(_epochs(name))])
     return model, pb, G
 
 
@@ -59,7 +64,7 @@ def test_hundred_step_curve(tmp_path, name, precision, gate):
     model, pb, G = _fit(name, precision, tmp_path)
     assert pb.shape[0] == 100
     if precision == "auto":
-        assert model.precision_used == L.auto_precision({"c1": "none", "c2": "batch_all", "c5": "explicit"}[name])
+        assert model.precision_used == L.auto_precision({"c1": "none", "c2": "batch_all", "c4": "batch_all", "c5": "explicit"}[name])
     worst = {}
     for col, q in ((0, "cost"), (1, "ae"), (2, "triplet")):
         g = G[q]

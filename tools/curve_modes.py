@@ -67,7 +67,7 @@ def main():
         gate = {q: np.maximum(1e-4, 3.0 * E["envmono_" + q]) for q in ("cost", "ae", "triplet")}
         gate = {q: np.where(np.arange(len(g)) < 4, 1e-4, g) for q, g in gate.items()}
     else:
-        G = np.load(ML.long_path(name)); epochs = ML.LONG_EPOCHS
+        G = np.load(ML.long_path(name)); epochs = 50 if name == "c4" else ML.LONG_EPOCHS
         gold = {q: G[q] for q in ("cost", "ae", "triplet")}
         gate = {q: np.full(len(G["cost"]), 1e-4) for q in gold}
     for spec in a.modes.split(","):
