@@ -478,6 +478,13 @@ def _prewarm_clocks(torch, run, seconds=0.25):
     changed nothing).  Reported in the JSON line as `prewarm`; the W warm-up steps and the K timed steps follow exactly as the contract asks."""
     t0 = time.perf_counter()
     n = 0
+    if run.world > 1:
+        # every step holds a collective: all ranks must run the SAME number of steps -- a count fixed from the time budget (~250 us per step), not a clock
+        n = max(20, int(seconds / 250e-6) // 20 * 20)
+        for _ in range(n):
+            run.step()
+        torch.cuda.synchronize()
+        return n
     while time.perf_counter() - t0 < seconds:
         for _ in range(20):
             run.step()
