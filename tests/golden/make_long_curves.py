@@ -14,7 +14,7 @@ reference-exact legacy-RNG stream, exactly like make_full_curve.py / make_curves
                   of a hand-sized tail.
   envelope c2 [K] the same for c2 over the 100-step horizon (context for the long curve: does the reference's arithmetic pin ITS OWN step 100 to 1e-4?)
 
-CPU only; c2 costs ~1 minute per 10 steps.  usage: python tests/golden/make_long_curves.py long c2 | envelope c3 16 8"""
+CPU only; c2 costs ~1 minute per 10 steps.  usage: python tests/golden/make_long_curves.py long c2 [epochs] | envelope c3 16 8   (long c1 50 / long c5 50: the CLI's default 50 epochs = 500 steps)"""
 import os
 import sys
 import time
@@ -30,8 +30,9 @@ LONG_EPOCHS = 10
 KEYS = ("cost", "ae", "triplet", "fraction", "num")
 
 
-def long_path(name):
-    return os.path.join(HERE, f"long_curve_{name}.npz")
+def long_path(name, epochs=None):
+    """long_curve_<cfg>.npz = the 100-step curve; long_curve_<cfg>_e<epochs>.npz = a longer one (c1 / c5 at the CLI's default 50 epochs = 500 steps)."""
+    return os.path.join(HERE, f"long_curve_{name}.npz" if epochs in (None, LONG_EPOCHS) or name == "c4" else f"long_curve_{name}_e{epochs}.npz")
 
 
 def envelope_path(name):
@@ -65,24 +66,25 @@ def run(data, lab, W0, kw, epochs):
     return out
 
 
-def make_long(name):
+def make_long(name, epochs=None):
     import make_curves as M
     t0 = time.time()
+    epochs = epochs or LONG_EPOCHS
     if name == "c5":           # explicit (anchor, pos, neg) triplets: the estimator's own epoch loop restated in make_curves.fit_explicit
         data, lab, W0 = M.inputs("c5")
-        r = M.fit_explicit(data, W0, dict(M.CFGS["c5"], epochs=LONG_EPOCHS))
+        r = M.fit_explicit(data, W0, dict(M.CFGS["c5"], epochs=epochs))
         out = {k: np.array([h[k] for h in r["history"]], np.float64).reshape(-1) for k in KEYS}
         W = r["W"].astype(np.float64)
         out["W_checksum"] = np.array([np.abs(W).sum(), (W ** 2).sum(), W[17, 3], W[-1, -1]])
         out["inputs_checksum"] = M.checksum(data, lab)
-        np.savez_compressed(long_path(name), **out)
-        print("wrote", long_path(name), "in %.0f s" % (time.time() - t0), "cost", out["cost"][[0, 19, -1]], flush=True)
+        np.savez_compressed(long_path(name, epochs), **out)
+        print("wrote", long_path(name, epochs), "in %.0f s" % (time.time() - t0), "cost", out["cost"][[0, 19, -1]], flush=True)
         return
     data, lab, W0, kw, _ = config(name)
-    out = run(data, lab, W0, kw, 50 if name == "c4" else LONG_EPOCHS)       # (c4: 1600 rows = 2 steps per epoch -> 50 epochs for 100 steps)
+    out = run(data, lab, W0, kw, 50 if name == "c4" else epochs)       # (c4: 1600 rows = 2 steps per epoch -> 50 epochs for 100 steps)
     out["inputs_checksum"] = M.checksum(data, lab)
-    np.savez_compressed(long_path(name), **out)
-    print("wrote", long_path(name), "in %.0f s" % (time.time() - t0), "cost", out["cost"][[0, 19, -1]], flush=True)
+    np.savez_compressed(long_path(name, epochs), **out)
+    print("wrote", long_path(name, epochs), "in %.0f s" % (time.time() - t0), "cost", out["cost"][[0, 19, -1]], flush=True)
 
 
 def perturbed(W0, k, n_ulp):
@@ -141,7 +143,7 @@ def make_envelope(name, K, K_order=0):
 if __name__ == "__main__":
     mode, name = sys.argv[1], sys.argv[2]
     if mode == "long":
-        make_long(name)
+        make_long(name, int(sys.argv[3]) if len(sys.argv) > 3 else None)
     elif mode == "envelope":
         make_envelope(name, int(sys.argv[3]) if len(sys.argv) > 3 else 16, int(sys.argv[4]) if len(sys.argv) > 4 else 8)
     else:

@@ -19,19 +19,22 @@ sys.path.insert(0, os.path.join(HERE, "golden"))
 
 # (config, precision, gate on every step, what the case pins)
 CASES = [("c2", "auto", 1e-4), ("c1", "auto", 1e-4), ("c5", "auto", 1e-4), ("c4", "auto", 1e-4), ("c2", "bf16x3", 2e-5), ("c1", "bf16x3", 2e-5),
-         ("c2", "f16x2", 6e-4), ("c1", "f16x2", 6e-4)]
+         ("c2", "f16x2", 6e-4), ("c1", "f16x2", 6e-4), ("c1@50", "auto", 1e-4), ("c5@50", "auto", 1e-4)]      # @50: the CLI's default 50 epochs = 500 steps
 
 
 def _epochs(name):
     import make_long_curves as ML
+    if "@" in name:
+        return int(name.split("@")[1])
     return 50 if name == "c4" else ML.LONG_EPOCHS          # c4's set is 1600 rows = 2 steps per epoch
 
 
-def _fit(name, precision, tmp):
+def _fit(case, precision, tmp):
     import make_curves as M
     import make_long_curves as ML
     from dae_rnn_news_recommendation_amd.autoencoder import DenoisingAutoencoder, DenoisingAutoencoderTriplet
-    G = np.load(ML.long_path(name))
+    name = case.split("@")[0]
+    G = np.load(ML.long_path(name, _epochs(case)))
     if name == "c5":
         c, k = M.CFGS["c5"], M.COMMON
         data, lab, W0 = M.inputs("c5")
@@ -42,7 +45,7 @@ def _fit(name, precision, tmp):
         cf = M.CFGS[name]["cf"] if name in M.CFGS else 20
     assert M.checksum(data, lab).tolist() == G["inputs_checksum"].tolist()          # the same regenerated inputs
     common = dict(model_name=name, main_dir=name, compress_factor=cf, enc_act_func="sigmoid", dec_act_func="sigmoid", loss_func=kw["loss_func"],
-                  num_epochs=_epochs(name), batch_size=kw["batch_size"], opt="gradient_descent", learning_rate=kw["learning_rate"], corr_type="masking",
+                  num_epochs=_epochs(case), batch_size=kw["batch_size"], opt="gradient_descent", learning_rate=kw["learning_rate"], corr_type="masking",
                   corr_frac=kw["corr_frac"], verbose=0, verbose_step=1, seed=kw["seed"], alpha=kw["alpha"], precision=precision, rng="numpy",
                   init_weights=W0, results_root=str(tmp) + "/")
     if name == "c5":
@@ -51,7 +54,7 @@ def _fit(name, precision, tmp):
     else:
         model = DenoisingAutoencoder(triplet_strategy=kw["triplet_strategy"], **common)
         model.fit(data, train_set_label=lab)
-    pb = np.concatenate([model.epoch_stats(e + 1)["per_batch"] for e in range(_epochs(name))])
+    pb = np.concatenate([model.epoch_stats(e + 1)["per_batch"] for e in range(_epochs(case))])
     return model, pb, G
 
 
@@ -59,10 +62,12 @@ def _fit(name, precision, tmp):
 def test_hundred_step_curve(tmp_path, name, precision, gate):
     import make_long_curves as ML
     from dae_rnn_news_recommendation_amd import _lib as L
-    if not os.path.exists(ML.long_path(name)):
-        pytest.skip(f"{ML.long_path(name)} not generated (python tests/golden/make_long_curves.py long {name})")
+    path = ML.long_path(name.split("@")[0], _epochs(name))
+    if not os.path.exists(path):
+        pytest.skip(f"{path} not generated (python tests/golden/make_long_curves.py long {name.split('@')[0]} [epochs])")
     model, pb, G = _fit(name, precision, tmp_path)
-    assert pb.shape[0] == 100
+    assert pb.shape[0] == (100 if "@" not in name else 10 * _epochs(name))
+    name = name.split("@")[0]
     if precision == "auto":
         assert model.precision_used == L.auto_precision({"c1": "none", "c2": "batch_all", "c4": "batch_all", "c5": "explicit"}[name])
     worst = {}

@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--config", default="c2")
     ap.add_argument("--modes", default="f16x2")
     ap.add_argument("--time", action="store_true")
+    ap.add_argument("--epochs", type=int, default=0, help="c1 / c5: compare against long_curve_<cfg>_e<epochs>.npz (50 = the CLI's default run, 500 steps)")
     a = ap.parse_args()
     import make_long_curves as ML
     name = a.config
@@ -67,7 +68,8 @@ def main():
         gate = {q: np.maximum(1e-4, 3.0 * E["envmono_" + q]) for q in ("cost", "ae", "triplet")}
         gate = {q: np.where(np.arange(len(g)) < 4, 1e-4, g) for q, g in gate.items()}
     else:
-        G = np.load(ML.long_path(name)); epochs = 50 if name == "c4" else ML.LONG_EPOCHS
+        epochs = 50 if name == "c4" else (a.epochs or ML.LONG_EPOCHS)
+        G = np.load(ML.long_path(name, epochs))
         gold = {q: G[q] for q in ("cost", "ae", "triplet")}
         gate = {q: np.full(len(G["cost"]), 1e-4) for q in gold}
     for spec in a.modes.split(","):
