@@ -9,7 +9,7 @@ and variable names of the checkpoint (``enc-w``, ``hidden-bias``, ``visible-bias
 
 New (keyword-only, all optional):
   precision   'auto' (default: per triplet strategy the cheapest mode measured to hold the reference's loss curve over 100 steps, _lib.AUTO_BY_STRATEGY:
-              none -> 'f16x2d', batch_all -> 'f16x2h', batch_hard -> 'bf16x3') or one of _lib.PRECISIONS: 'f16x2h' / 'f16x2d' (fp16 operand images; W
+              none -> 'f16x2d', batch_all / batch_hard -> 'f16x2h') or one of _lib.PRECISIONS: 'f16x2h' / 'f16x2d' (fp16 operand images; W
               and the h resp. delta2 operands as hi + lo), 'bf16x3' (split-bf16: every stored operand as hi + lo bf16, three products each), 'fp32'
               (exact-fp32 MFMA), 'f16x3' (every operand hi + lo fp16); 'f16x2' (W alone hi + lo: holds 20 steps, not 100), 'bf16' / 'f16' (single
               16-bit images, fp32 accumulate / master weights: faster, outside the gate)
@@ -210,7 +210,7 @@ class DenoisingAutoencoder(object):
     def _resolve_precision(self, data=None):
         """precision='auto' (the default) resolves PER TRIPLET STRATEGY to the cheapest mode measured to hold the reference's loss curve (L.AUTO_BY_STRATEGY:
         1e-4 on every one of 100 steps of the frozen float32-oracle curves for 'none' / 'batch_all' -- 'f16x2d' / 'f16x2h', fp16 operand images with W and
-        the operands each strategy is sensitive to kept as hi + lo; the oracle-derived envelope for 'batch_hard' -- 'bf16x3'), with or without a train set
+        the operands each strategy is sensitive to kept as hi + lo; the oracle-derived envelope for 'batch_hard' -- 'f16x2h' again), with or without a train set
         to look at (fit, load_model -> transform: one arithmetic).  'f16x2' (round 5's default: faster, holds 20 steps, leaves 1e-4 at step 29 of c2 / 76 of
         c1), plain 'bf16' / 'f16' (faster still, outside the gate) must be asked for by name."""
         if self.precision != 'auto':

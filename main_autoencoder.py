@@ -69,8 +69,8 @@ def build_parser():
     # MI355X-side additions
     p.add_argument("--precision", default="auto", choices=["auto", "f16x2h", "f16x2d", "bf16x3", "fp32", "f16x3", "f16x2", "bf16", "f16"],
                    help="auto (default): per triplet strategy the cheapest mode measured to hold the reference's loss curve within 1e-4 over 100 steps -- batch_all "
-                        "f16x2h, none f16x2d (fp16 MFMA operand images; W and the operands the strategy is sensitive to as hi + lo), batch_hard bf16x3 (split-bf16: "
-                        "hi + lo images of every operand); fp32: exact-fp32 MFMA; f16x3: every operand hi + lo fp16; f16x2 (W alone hi + lo) holds 20 steps, not 100; "
+                        "/ batch_hard f16x2h, none f16x2d (fp16 MFMA operand images; W and the operands the strategy is sensitive to as hi + lo); bf16x3: split-bf16, "
+                        "hi + lo images of every operand; fp32: exact-fp32 MFMA; f16x3: every operand hi + lo fp16; f16x2 (W alone hi + lo) holds 20 steps, not 100; "
                         "bf16 / f16 (single images) are faster still and outside the gate")
     p.add_argument("--rng", default="numpy", choices=["numpy", "philox"])
     p.add_argument("--data", default="", help="scipy-sparse .npz or dense .npy feature matrix (rows = articles)")

@@ -12,8 +12,8 @@ same regenerated inputs, reference-exact legacy RNG stream, injected W0.
                                          gradient rows.  No implementation whose fp32 sums are ordered differently from TensorFlow's can hold 1e-4 there
                                          (this repo's exact-fp32 MFMA mode measures 8.9e-5 / 1.8e-4): steps 1-4 are held to the north star's 1e-4, the
                                          rest to an ORACLE-DERIVED envelope (c3_gate below: 25 oracle runs, one-ulp and summation-order families; round 5
-                                         had hand-sized tail gates here).  precision='auto' resolves to bf16x3 for batch_hard: the cheapest mode inside
-                                         that envelope (f16x2 1.28 x the gate, f16x2h 1.06 x: outside; bf16x3 0.25 x, f16x3 0.32 x, fp32 0.17 x)
+                                         had hand-sized tail gates here).  precision='auto' resolves to f16x2h for batch_hard too: the cheapest mode well inside
+                                         that envelope (f16x2 1.28 x the gate, the same mask without delta1 1.06 x: outside; f16x2h 0.29 x, bf16x3 0.25 x, f16x3 0.32 x, fp32 0.17 x)
   c4  dense tf-idf ndarray, F = 50000   (N = 1600 rows: 10 epochs of 2 steps)
   c5  explicit triplets, cosine loss    (autoencoder_triplet.py:296-314)"""
 import os
@@ -58,7 +58,7 @@ def _dev(pb, gold, col, key):
     return np.abs(pb[:, col] - g) / np.maximum(np.abs(g), 1e-30)
 
 
-CASES = [("c1", "auto"), ("c3", "auto"), ("c3", "fp32"), ("c3", "f16x3"), ("c4", "auto"), ("c5", "auto"), ("c1", "bf16x3")]
+CASES = [("c1", "auto"), ("c3", "auto"), ("c3", "fp32"), ("c3", "bf16x3"), ("c3", "f16x3"), ("c4", "auto"), ("c5", "auto"), ("c1", "bf16x3")]
 
 
 def c3_gate(leg):
