@@ -1,5 +1,6 @@
 #!/bin/bash
-# round 6: fp16-storage lo-term masks on c3 against the envelope gate (is there a cheaper passing mode than bf16x3 for batch_hard?)
-mkdir -p gpurun_out/r06c22
-timeout 900 python tools/curve_modes.py --config c3 --modes f16x2h,f16x2:39,f16x2:111,f16x2:47,bf16x3 --time > gpurun_out/r06c22/curve_c3_masks2.txt 2>&1
-grep -h "^\[\|Error" gpurun_out/r06c22/curve_c3_masks2.txt | sed 's/; ae max[^;]*;/;/'
+# round 6: cost of a cross-stream dependency by mechanism (event, stream memory ops, device-side flag)
+mkdir -p gpurun_out/r06c25
+hipcc --offload-arch=gfx950 -O2 tools/hop_probe.hip -o /tmp/hop_probe
+(echo "# flag in uncached device memory"; timeout 30 /tmp/hop_probe; echo "rc $?"; echo "# flag in fine-grained device memory"; HOP_FINE=1 timeout 30 /tmp/hop_probe | grep -A1 "^S"; echo "rc $?") > gpurun_out/r06c25/hop_probe.txt 2>&1
+cat gpurun_out/r06c25/hop_probe.txt
