@@ -1684,11 +1684,231 @@ __device__ __forceinline__ void mainloop_n64_pair(const GemmParams& p, int tm, i
     }
 }
 
+// Three-term form for the split modes that keep h AND W as hi + lo (f16x2h: z2 = h_hi.W_hi^T + h_hi.W_lo^T + h_lo.W_hi^T).  The plain walk streams three K
+// segments -- 3 stages per K tile, every h_hi and every W_hi tile fetched and read twice.  Here the stages alternate (h_hi, W_hi)[k] -> (h_lo, W_lo)[k]
+// and the hi stage's fragments STAY IN REGISTERS (48 VGPRs: the kernel has the room at three workgroups per CU) over the lo stage, which multiplies
+// (h_hi, W_lo) and (h_lo, W_hi): 2 stages per K tile -- 12 LDS-DMA pieces, 24 fragment reads, 4 barriers per wave -- for the same 24 MFMAs instead of 3
+// (18, 36, 6), at the unchanged 48 KiB of LDS.  Same products as the three-segment walk, fp32 sums in another order (per K tile: hi.hi, hi.lo, lo.hi).
+template <typename T>
+__device__ __forceinline__ void mainloop_n64_x3(const GemmParams& p, int tm, int tn, char* lds, f32x16 (&acc)[2][1]) {
+    constexpr int STAGE = DecGeo<64>::STAGE;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int row0_m = tm * BM, row0_n = tn * 64;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+    const int nk = p.seg[0].ktiles;                    // the three segments: the same K extent and leading dimensions (checked by the launcher)
+    if (nk <= 0) return;
+    uint32_t voA[4], voB[2];
+    const uint32_t lda = (uint32_t)p.seg[0].lda_b, ldb = (uint32_t)p.seg[0].ldb_b;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (i * 4 + wave) * 8 + (lane >> 3);
+        voA[i] = (uint32_t)(row0_m + row) * lda + (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (i * 4 + wave) * 8 + (lane >> 3);
+        voB[i] = (uint32_t)(row0_n + row) * ldb + (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) << 4);
+    }
+    // segments as the launcher lists them: 0 = (h_hi, W_hi), 1 = (h_hi, W_lo), 2 = (h_lo, W_hi)
+    const char *gAh = p.seg[0].A, *gBh = p.seg[0].Bt, *gAl = p.seg[2].A, *gBl = p.seg[1].Bt;
+    auto dma_stage = [&](char* slot, const char* gA, const char* gB) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gA + voA[i]),
+                                             (__attribute__((address_space(3))) void*)(slot + (i * 4 + wave) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gB + voB[i]),
+                                             (__attribute__((address_space(3))) void*)(slot + TILE_BYTES + (i * 4 + wave) * 1024), 16, 0, 0);
+    };
+    const int r = lane & 31, g = lane >> 5;
+    const int swz = (r >> 1) & 7;
+    const uint32_t lbase = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)lds;
+    const uint32_t offa = (wm * 64 + r) * BKB, offb = TILE_BYTES + (wn * 32 + r) * BKB;
+    uint32_t so[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) so[kk] = (uint32_t)(((kk * 2 + g) ^ swz) << 4);
+    dma_stage(lds, gAh, gBh);
+    for (int i = 0; i < nk; ++i) {
+        // ---- hi stage (slot 0): the lo stage of this K tile goes out first
+        dma_stage(lds + STAGE, gAl, gBl);
+        gAl += BKB; gBl += BKB;
+        wait_vm<6>();
+        __builtin_amdgcn_s_barrier();                  // the hi stage landed for every wave
+        asm volatile("" ::: "memory");
+        i32x4 fah[4][2], fbh[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            fah[kk][0] = lds_read_b128(lbase + offa + so[kk]);
+            fah[kk][1] = lds_read_b128_off4096(lbase + offa + so[kk]);
+            fbh[kk] = lds_read_b128(lbase + offb + so[kk]);
+        }
+#define DAE_N64X_HI(KK, CNT)                                     \
+    asm volatile("s_waitcnt lgkmcnt(" #CNT ")" ::: "memory");    \
+    __builtin_amdgcn_sched_barrier(0);                           \
+    Mma<T>::run(fah[KK][0], fbh[KK], acc[0][0]);                 \
+    Mma<T>::run(fah[KK][1], fbh[KK], acc[1][0]);
+        DAE_N64X_HI(0, 9)
+        DAE_N64X_HI(1, 6)
+        DAE_N64X_HI(2, 3)
+        DAE_N64X_HI(3, 0)
+#undef DAE_N64X_HI
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();                  // every wave has read slot 0: the next K tile's hi stage may refill it
+        asm volatile("" ::: "memory");
+        // ---- lo stage (slot 1)
+        if (i + 1 < nk) {
+            gAh += BKB; gBh += BKB;
+            dma_stage(lds, gAh, gBh);
+            wait_vm<6>();
+        } else {
+            wait_vm<0>();
+        }
+        __builtin_amdgcn_s_barrier();                  // the lo stage landed for every wave
+        asm volatile("" ::: "memory");
+        i32x4 fal[4][2], fbl[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            fal[kk][0] = lds_read_b128(lbase + STAGE + offa + so[kk]);
+            fal[kk][1] = lds_read_b128_off4096(lbase + STAGE + offa + so[kk]);
+            fbl[kk] = lds_read_b128(lbase + STAGE + offb + so[kk]);
+        }
+#define DAE_N64X_LO(KK, CNT)                                     \
+    asm volatile("s_waitcnt lgkmcnt(" #CNT ")" ::: "memory");    \
+    __builtin_amdgcn_sched_barrier(0);                           \
+    Mma<T>::run(fah[KK][0], fbl[KK], acc[0][0]);                 \
+    Mma<T>::run(fah[KK][1], fbl[KK], acc[1][0]);                 \
+    Mma<T>::run(fal[KK][0], fbh[KK], acc[0][0]);                 \
+    Mma<T>::run(fal[KK][1], fbh[KK], acc[1][0]);
+        DAE_N64X_LO(0, 9)
+        DAE_N64X_LO(1, 6)
+        DAE_N64X_LO(2, 3)
+        DAE_N64X_LO(3, 0)
+#undef DAE_N64X_LO
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();                  // every wave has read slot 1
+        asm volatile("" ::: "memory");
+    }
+}
+
+// Two-term form (the split modes that keep only W as hi + lo in the decode -- f16x2d, f16x2: z2 = h.W_hi^T + h.W_lo^T) with the same register carry: the hi
+// stage holds (h, W_hi)[k], the lo stage ONLY the 8 KiB W_lo[k] tile, multiplied with the h fragments still in registers (32 VGPRs).  Per K tile and wave
+// 8 LDS-DMA pieces and 16 fragment reads for the 16 MFMAs instead of 12 and 24 -- what mainloop_n64_pair buys, without its 64 KiB of LDS (three
+// workgroups per CU stay).  Same products as the two-segment walk, (hi, lo) interleaved per K tile.
+template <typename T>
+__device__ __forceinline__ void mainloop_n64_c2(const GemmParams& p, int tm, int tn, char* lds, f32x16 (&acc)[2][1]) {
+    constexpr int STAGE = DecGeo<64>::STAGE;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int row0_m = tm * BM, row0_n = tn * 64;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+    const int nk = p.seg[0].ktiles;                    // both segments: the same A operand, K extent and leading dimensions (checked by the launcher)
+    if (nk <= 0) return;
+    uint32_t voA[4], voB[2];
+    const uint32_t lda = (uint32_t)p.seg[0].lda_b, ldb = (uint32_t)p.seg[0].ldb_b;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (i * 4 + wave) * 8 + (lane >> 3);
+        voA[i] = (uint32_t)(row0_m + row) * lda + (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (i * 4 + wave) * 8 + (lane >> 3);
+        voB[i] = (uint32_t)(row0_n + row) * ldb + (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) << 4);
+    }
+    const char *gA = p.seg[0].A, *gBh = p.seg[0].Bt, *gBl = p.seg[1].Bt;
+    auto dma_hi = [&](char* slot) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gA + voA[i]),
+                                             (__attribute__((address_space(3))) void*)(slot + (i * 4 + wave) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gBh + voB[i]),
+                                             (__attribute__((address_space(3))) void*)(slot + TILE_BYTES + (i * 4 + wave) * 1024), 16, 0, 0);
+        gA += BKB; gBh += BKB;
+    };
+    auto dma_lo = [&](char* slot) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gBl + voB[i]),
+                                             (__attribute__((address_space(3))) void*)(slot + TILE_BYTES + (i * 4 + wave) * 1024), 16, 0, 0);
+        gBl += BKB;
+    };
+    const int r = lane & 31, g = lane >> 5;
+    const int swz = (r >> 1) & 7;
+    const uint32_t lbase = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)lds;
+    const uint32_t offa = (wm * 64 + r) * BKB, offb = TILE_BYTES + (wn * 32 + r) * BKB;
+    uint32_t so[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) so[kk] = (uint32_t)(((kk * 2 + g) ^ swz) << 4);
+    dma_hi(lds);
+    for (int i = 0; i < nk; ++i) {
+        // ---- hi stage (slot 0); the W_lo tile of this K tile goes out first (slot 1, B region)
+        dma_lo(lds + STAGE);
+        wait_vm<2>();
+        __builtin_amdgcn_s_barrier();                  // the hi stage landed for every wave
+        asm volatile("" ::: "memory");
+        i32x4 fa[4][2], fbh[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            fa[kk][0] = lds_read_b128(lbase + offa + so[kk]);
+            fa[kk][1] = lds_read_b128_off4096(lbase + offa + so[kk]);
+            fbh[kk] = lds_read_b128(lbase + offb + so[kk]);
+        }
+#define DAE_N64C_HI(KK, CNT)                                     \
+    asm volatile("s_waitcnt lgkmcnt(" #CNT ")" ::: "memory");    \
+    __builtin_amdgcn_sched_barrier(0);                           \
+    Mma<T>::run(fa[KK][0], fbh[KK], acc[0][0]);                  \
+    Mma<T>::run(fa[KK][1], fbh[KK], acc[1][0]);
+        DAE_N64C_HI(0, 9)
+        DAE_N64C_HI(1, 6)
+        DAE_N64C_HI(2, 3)
+        DAE_N64C_HI(3, 0)
+#undef DAE_N64C_HI
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();                  // every wave has read slot 0: the next K tile's hi stage may refill it
+        asm volatile("" ::: "memory");
+        // ---- lo stage: W_lo[k] against the h fragments in registers
+        if (i + 1 < nk) { dma_hi(lds); wait_vm<6>(); }
+        else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();                  // the W_lo tile landed for every wave
+        asm volatile("" ::: "memory");
+        i32x4 fbl[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) fbl[kk] = lds_read_b128(lbase + STAGE + offb + so[kk]);
+#define DAE_N64C_LO(KK, CNT)                                     \
+    asm volatile("s_waitcnt lgkmcnt(" #CNT ")" ::: "memory");    \
+    __builtin_amdgcn_sched_barrier(0);                           \
+    Mma<T>::run(fa[KK][0], fbl[KK], acc[0][0]);                  \
+    Mma<T>::run(fa[KK][1], fbl[KK], acc[1][0]);
+        DAE_N64C_LO(0, 3)
+        DAE_N64C_LO(1, 2)
+        DAE_N64C_LO(2, 1)
+        DAE_N64C_LO(3, 0)
+#undef DAE_N64C_LO
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();                  // every wave has read the W_lo tile
+        asm volatile("" ::: "memory");
+    }
+}
+
 constexpr float CE_FAST_ZMAX = 14.0f;               // sigmoid(14) = 1 - 8.3e-7: five fp32 ulps from saturation
 constexpr int DECODE_NST = 2;
-template <typename T, int LOSS, int ACT, bool XBITS = false, int BN_T = 128, bool RES = false, bool PAIRD = false>   // RES (split-bf16 mode): also the lo images of delta2 / delta2^T; PAIRD: mainloop_n64_pair
+template <typename T, int LOSS, int ACT, bool XBITS = false, int BN_T = 128, bool RES = false, bool PAIRD = false, bool X3 = false, bool C2 = false>   // RES (split-bf16 mode): also the lo images of delta2 / delta2^T; PAIRD: mainloop_n64_pair; X3: mainloop_n64_x3; C2: mainloop_n64_c2
 __global__ __launch_bounds__(GEMM_THREADS, PAIRD ? 2 : DecGeo<BN_T>::WG_PER_CU) void gemm_decode_loss(GemmParams p, DecodeEpi e) {
     static_assert(!PAIRD || (BN_T == 64 && sizeof(T) == 2 && !RES), "the paired K loop exists for the 64-column 16-bit kernel");
+    static_assert(!X3 || (BN_T == 64 && sizeof(T) == 2 && !RES && !PAIRD), "the three-term K loop exists for the 64-column 16-bit kernel");
+    static_assert(!C2 || (BN_T == 64 && sizeof(T) == 2 && !X3 && !PAIRD), "the two-term register-carry K loop exists for the 64-column 16-bit kernel");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     using Geo = DecGeo<BN_T>;
     constexpr int NTB = Geo::NTB, WCOLS = Geo::WCOLS, P0 = Geo::P0, P1 = Geo::P1;
@@ -1738,6 +1958,8 @@ __global__ __launch_bounds__(GEMM_THREADS, PAIRD ? 2 : DecGeo<BN_T>::WG_PER_CU) 
     const bool vb[2] = {2 * wm < vblk, 2 * wm + 1 < vblk};
     if constexpr (BN_T == 128) gemm_mainloop<T, DECODE_NST>(p, tm, tn, kt0, kt1, lds, acc);
     else if constexpr (PAIRD) mainloop_n64_pair<T>(p, tm, tn, lds, acc);
+    else if constexpr (X3) mainloop_n64_x3<T>(p, tm, tn, lds, acc);
+    else if constexpr (C2) mainloop_n64_c2<T>(p, tm, tn, lds, acc);
     else mainloop_n64<T>(p, tm, tn, lds, acc);
     // (the K loop multiplies the padding blocks too: branching around MFMAs would put them in basic blocks of their own, out of reach of the static check
     //  of the hand-placed LDS waits, tools/check_gemm_asm.py -- measured worth < 1 % of the step; the EPILOGUE below skips their loss evaluation)
@@ -2686,6 +2908,23 @@ static decode_fn decode_kernel_pair(int loss, int act, bool xbits) {
 #undef DAE_DKP
     return nullptr;
 }
+// the 64-column kernel with the three-term K loop (mainloop_n64_x3: (h_hi, W_hi) (h_hi, W_lo) (h_lo, W_hi) in two stages per K tile)
+// (binary input = the bit image of x only: with the 16-byte x prefetch registers on top the loop does not fit the 168 VGPRs of three workgroups per CU)
+static decode_fn decode_kernel_x3(int loss, int act) {
+#define DAE_DK3(LV, AV) if (loss == LV && act == AV) return gemm_decode_loss<bf16_t, LV, AV, true, DECODE_BN_BF16, false, false, true>;
+    DAE_DK3(0, 0) DAE_DK3(0, 1) DAE_DK3(0, 2) DAE_DK3(1, 0) DAE_DK3(1, 1) DAE_DK3(1, 2) DAE_DK3(2, 0) DAE_DK3(2, 1) DAE_DK3(2, 2)
+#undef DAE_DK3
+    return nullptr;
+}
+// ... and with the two-term register-carry loop (mainloop_n64_c2: (h, W_hi) (h, W_lo)); binary input, with or without the lo images of delta2
+static decode_fn decode_kernel_c2(int loss, int act, bool res) {
+#define DAE_DKC(LV, AV)                                                                                       \
+    if (loss == LV && act == AV)                                                                              \
+        return res ? gemm_decode_loss<bf16_t, LV, AV, true, DECODE_BN_BF16, true, false, false, true> : gemm_decode_loss<bf16_t, LV, AV, true, DECODE_BN_BF16, false, false, false, true>;
+    DAE_DKC(0, 0) DAE_DKC(0, 1) DAE_DKC(0, 2) DAE_DKC(1, 0) DAE_DKC(1, 1) DAE_DKC(1, 2) DAE_DKC(2, 0) DAE_DKC(2, 1) DAE_DKC(2, 2)
+#undef DAE_DKC
+    return nullptr;
+}
 // the A-stationary persistent kernel (gemm_decode_ast)
 static decode_fn decode_kernel_ast(int loss, int act, bool xbits) {
 #define DAE_DKA(LV, AV)                                                                                       \
@@ -2696,6 +2935,7 @@ static decode_fn decode_kernel_ast(int loss, int act, bool xbits) {
     return nullptr;
 }
 static int g_decode_dbg = 0;       // dae_set_glds(-500000 - bits): timing probes of gemm_decode_ast (DecodeEpi::dbg)
+static int g_decode_x3 = 1;        // dae_set_glds(-17) off / (-18) on; plan option "decode_x3": the three-term decode (f16x2h) on mainloop_n64_x3 instead of three K segments
 static int g_decode_ast = 0;       // dae_set_glds(-15) off / (-16) on; plan option "decode_ast".  OFF: measured 44 us against 38 for the tile kernel at c2 (profiles/r06_decode_ast.txt)
 constexpr int DECODE_PAIR_LDS = 2 * (TILE_BYTES + 2 * 64 * BKB) > DecGeo<DECODE_BN_BF16>::EPI_BYTES ? 2 * (TILE_BYTES + 2 * 64 * BKB) : DecGeo<DECODE_BN_BF16>::EPI_BYTES;
 static int g_decode_pair = 0;      // dae_set_glds(-13) off / (-14) on; plan option "decode_pair"
@@ -3027,11 +3267,44 @@ int launch_decode_loss_n(int dtype, int Bp, int Fp, const GemmSegDesc* segs, int
         }();
         DAE_CHECK_ARG(pair_rc == 0, "decode_loss: hipFuncSetAttribute failed");
     }
+    // three K segments (h_hi, W_hi) (h_hi, W_lo) (h_lo, W_hi) over one K extent: the two-stage walk that keeps the hi fragments in registers
+    bool x3d = false;
+    if (g_decode_x3 && dtype == DAE_BF16 && e.x_bits && !wide && !paird && !(e.delta2_2 || e.delta2_t2 || e.x2) && p.nseg == 3 && p.seg[0].A == p.seg[1].A &&
+        p.seg[0].Bt == p.seg[2].Bt && p.seg[0].A != p.seg[2].A && p.seg[0].Bt != p.seg[1].Bt && p.seg[0].lda_b == p.seg[1].lda_b && p.seg[0].lda_b == p.seg[2].lda_b &&
+        p.seg[0].ldb_b == p.seg[1].ldb_b && p.seg[0].ldb_b == p.seg[2].ldb_b && p.seg[0].ktiles == p.seg[1].ktiles && p.seg[0].ktiles == p.seg[2].ktiles) {
+        x3d = true;
+        k = decode_kernel_x3(e.loss_func, e.dec_act);
+        static int x3_rc = [] {
+            int rc = 0;
+            for (int l = 0; l < 3; ++l)
+                for (int a = 0; a < 3; ++a)
+                    rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(decode_kernel_x3(l, a)), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   DecGeo<DECODE_BN_BF16>::LDS_BYTES);
+            return rc;
+        }();
+        DAE_CHECK_ARG(x3_rc == 0, "decode_loss: hipFuncSetAttribute failed");
+    }
+    // two K segments over the same h (h.W_hi + h.W_lo), binary input: the register-carry walk (the lo stage is the W_lo tile alone)
+    bool c2d = false;
+    if (g_decode_x3 && dtype == DAE_BF16 && e.x_bits && !wide && !paird && !x3d && !e.x2 && p.nseg == 2 && p.seg[0].A == p.seg[1].A && p.seg[0].Bt != p.seg[1].Bt &&
+        p.seg[0].lda_b == p.seg[1].lda_b && p.seg[0].ldb_b == p.seg[1].ldb_b && p.seg[0].ktiles == p.seg[1].ktiles) {
+        c2d = true;
+        static int c2_rc = [] {
+            int rc = 0;
+            for (int l = 0; l < 3; ++l)
+                for (int a = 0; a < 3; ++a)
+                    for (int rs = 0; rs < 2; ++rs)
+                        rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(decode_kernel_c2(l, a, rs != 0)), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                       DecGeo<DECODE_BN_BF16>::LDS_BYTES);
+            return rc;
+        }();
+        DAE_CHECK_ARG(c2_rc == 0, "decode_loss: hipFuncSetAttribute failed");
+    }
     if (e.op_scale == 0.f) e.op_scale = 1.f;
     e.no_pad_skip = g_pad_skip ? 0 : 1;
     e.dbg = g_decode_dbg;
     // A-stationary persistent form: 16-bit, 64-column tiles, no lo images, every K segment over the same h with K <= 8 tiles (Hp <= 512)
-    bool ast = g_decode_ast && dtype == DAE_BF16 && !wide && !paird && !(e.delta2_2 || e.delta2_t2 || e.x2) && p.seg[0].ktiles <= DecAst::MAXKT && p.nseg <= 2;
+    bool ast = g_decode_ast && dtype == DAE_BF16 && !wide && !paird && !x3d && !c2d && !(e.delta2_2 || e.delta2_t2 || e.x2) && p.seg[0].ktiles <= DecAst::MAXKT && p.nseg <= 2;
     for (int s = 1; s < p.nseg && ast; ++s)
         ast = p.seg[s].A == p.seg[0].A && p.seg[s].lda_b == p.seg[0].lda_b && p.seg[s].ldb_b == p.seg[0].ldb_b && p.seg[s].ktiles == p.seg[0].ktiles;
     if (ast) {
@@ -3081,6 +3354,7 @@ int launch_decode_loss_n(int dtype, int Bp, int Fp, const GemmSegDesc* segs, int
         }();
         DAE_CHECK_ARG(res_rc == 0, "decode_loss: hipFuncSetAttribute failed");
     }
+    if (c2d) k = decode_kernel_c2(e.loss_func, e.dec_act, e.delta2_2 || e.delta2_t2);
     int nblocks = grid_blocks(p);
     if (e.sym_G) {
         DAE_CHECK_ARG(e.sym_scalars && e.sym_Gs && e.sym_Bp % 64 == 0 && e.sym_B <= e.sym_Bp, "decode_loss: bad sym_scale rider");
@@ -3350,6 +3624,8 @@ void set_use_glds(int nst) {
     if (nst <= -100 && nst > -1000) { g_dw_rounds = g_dw_rounds_split = (-nst - 100 < 1 ? 1 : -nst - 100); return; }    // rounds of the chip the 160 x 128 dW kernel may take
     if (nst == -13) { g_decode_pair = 0; return; }
     if (nst == -14) { g_decode_pair = 1; return; }
+    if (nst == -17) { g_decode_x3 = 0; return; }
+    if (nst == -18) { g_decode_x3 = 1; return; }
     if (nst == -15) { g_decode_ast = 0; return; }
     if (nst == -16) { g_decode_ast = 1; return; }
     if (nst == -11) { g_pad_skip = 0; return; }

@@ -144,8 +144,12 @@ def test_step_f16x2_op_scale_is_transparent():
 def test_step_wide_decode_tile_equals_narrow(dtype, loss_func, acts):
     """Plan option decode_bn = 128 (the 128 x 128 decode tile the plan picks by itself for F = 50000) against the default 128 x 64 tile: every logit is
     the same K-ordered MFMA sum, so delta2, the gradients and the parameters agree to the last bit; only the loss partial sums are added in another order."""
+    from dae_rnn_news_recommendation_amd import _lib as L
     kw = dict(steps=2, seed=17, N=400, F=900, H=90, B=150)
-    a, _, pa = _run_case(dtype, "batch_all", loss_func, acts, "gradient_descent", options={"decode_bn": 64}, **kw)
+    try:        # (decode_x3 = 0: the narrow tile on the segment walk, the K order of the wide kernel; its register-carry loops interleave the hi / lo products per K tile)
+        a, _, pa = _run_case(dtype, "batch_all", loss_func, acts, "gradient_descent", options={"decode_bn": 64, "decode_x3": 0}, **kw)
+    finally:
+        L.set_glds_all(-18)
     b, _, pb = _run_case(dtype, "batch_all", loss_func, acts, "gradient_descent", options={"decode_bn": 128}, **kw)
     for (_, sa, dWa, dbha, dbva), (_, sb, dWb, dbhb, dbvb) in zip(a, b):
         assert np.allclose(sa[:3], sb[:3], rtol=2e-6, atol=0), (sa, sb)
@@ -212,6 +216,34 @@ def test_decode_paired_k_loop_equals_unpaired(dtype, loss_func, acts, strategy):
         assert np.allclose(sa[:3], sb[:3], rtol=3e-6, atol=0), (sa, sb)
         assert _rel(dWa, np.asarray(dWb, np.float64)) < 1e-3                          # (a flipped fp16 rounding of delta2 = 2^-12 of one element)
         assert abs(sa[0] - r["cost"]) <= 5e-5 * abs(r["cost"])
+    for u, v in zip(pa, pb):
+        assert _rel(u, np.asarray(v, np.float64)) < 1e-3
+
+
+@pytest.mark.parametrize("dtype,strategy,loss_func,acts,shape", [("f16x2h", "batch_all", "cross_entropy", ("sigmoid", "sigmoid"), dict(N=400, F=900, H=150, B=150)),
+                                                                ("f16x2h", "batch_hard", "cross_entropy", ("sigmoid", "sigmoid"), dict(N=500, F=1100, H=200, B=300)),
+                                                                ("f16x2h", "none", "cross_entropy", ("sigmoid", "sigmoid"), dict(N=400, F=700, H=500, B=130)),
+                                                                ("f16x2d", "none", "cross_entropy", ("sigmoid", "sigmoid"), dict(N=400, F=900, H=150, B=150)),
+                                                                ("f16x2d", "batch_all", "cross_entropy", ("sigmoid", "tanh"), dict(N=400, F=700, H=500, B=130)),
+                                                                ("f16x2", "batch_all", "cross_entropy", ("sigmoid", "sigmoid"), dict(N=500, F=1100, H=200, B=300))])
+def test_decode_register_carry_k_loops_equal_the_segment_walk(dtype, strategy, loss_func, acts, shape):
+    """f16x2h keeps h AND W as hi + lo in the decode: z2 = h_hi.W_hi + h_hi.W_lo + h_lo.W_hi.  mainloop_n64_x3 (plan option decode_x3, default on, binary
+    input) walks it in two stages per K tile -- (h_hi, W_hi), then (h_lo, W_lo) with the hi stage's fragments kept in registers -- instead of three K segments;
+    f16x2d / f16x2 (W alone hi + lo: two segments over the same h) take mainloop_n64_c2, whose lo stage is the W_lo tile alone against the h fragments in
+    registers (f16x2d: the kernel instantiation that also writes the lo images of delta2).  The same products, fp32 sums in another order.  Against the
+    segment walk (decode_x3 = 0) and against the fp64 oracle."""
+    from dae_rnn_news_recommendation_amd import _lib as L
+    kw = dict(steps=2, seed=41, **shape)
+    a, ra, pa = _run_case(dtype, strategy, loss_func, acts, "gradient_descent", options={"decode_x3": 1}, **kw)
+    try:
+        b, rb, pb = _run_case(dtype, strategy, loss_func, acts, "gradient_descent", options={"decode_x3": 0}, **kw)
+    finally:
+        L.set_glds_all(-18)
+    for (r, sa, dWa, dbha, dbva), (_, sb, dWb, dbhb, dbvb) in zip(a, b):
+        assert np.allclose(sa[:3], sb[:3], rtol=3e-6, atol=0), (sa, sb)
+        assert _rel(dWa, np.asarray(dWb, np.float64)) < 1e-3 and _rel(dbha, np.asarray(dbhb, np.float64)) < 1e-3      # (a flipped fp16 rounding of delta2 = 2^-12 of one element)
+        assert abs(sa[0] - r["cost"]) <= 3e-5 * abs(r["cost"]) and abs(sb[0] - r["cost"]) <= 3e-5 * abs(r["cost"]), (sa[0], sb[0], r["cost"])
+        assert _rel(dWa, r["dW"]) < 2e-3, _rel(dWa, r["dW"])
     for u, v in zip(pa, pb):
         assert _rel(u, np.asarray(v, np.float64)) < 1e-3
 

@@ -1,6 +1,13 @@
 #!/bin/bash
-# round 6: cost of a cross-stream dependency by mechanism (event, stream memory ops, device-side flag)
-mkdir -p gpurun_out/r06c25
-hipcc --offload-arch=gfx950 -O2 tools/hop_probe.hip -o /tmp/hop_probe
-(echo "# flag in uncached device memory"; timeout 30 /tmp/hop_probe; echo "rc $?"; echo "# flag in fine-grained device memory"; HOP_FINE=1 timeout 30 /tmp/hop_probe | grep -A1 "^S"; echo "rc $?") > gpurun_out/r06c25/hop_probe.txt 2>&1
-cat gpurun_out/r06c25/hop_probe.txt
+# round 6: the two-term register-carry decode loop (mainloop_n64_c2: f16x2d / f16x2): parity tests, per-kernel A/B on c1's mode, c1 / c5 curves
+mkdir -p gpurun_out/r06c29
+O=gpurun_out/r06c29
+timeout 900 python -m pytest tests/test_hip_f16.py -q -x 2>&1 | tail -5 > $O/tests.txt; cat $O/tests.txt
+for i in 1 2; do
+timeout 300 python tools/kprof.py --precision f16x2d --strategy none --opt decode_x3=0 --tag seg2 2>/dev/null | grep "==\|decode_loss" | cut -c1-140 >> $O/kprof_ab.txt
+timeout 300 python tools/kprof.py --precision f16x2d --strategy none --opt decode_x3=1 --tag c2 2>/dev/null | grep "==\|decode_loss" | cut -c1-140 >> $O/kprof_ab.txt
+done
+timeout 300 python tools/kprof.py --precision f16x2 --opt decode_x3=0 --tag seg2 2>/dev/null | grep "==\|decode_loss" | cut -c1-140 >> $O/kprof_ab.txt
+timeout 300 python tools/kprof.py --precision f16x2 --opt decode_x3=1 --tag c2 2>/dev/null | grep "==\|decode_loss" | cut -c1-140 >> $O/kprof_ab.txt
+cat $O/kprof_ab.txt
+timeout 900 python -m pytest tests/test_hip_long_curves.py tests/test_hip_curves.py -q -x -s 2>&1 | grep -E "curve\]|passed|failed|FAILED|Error|^E " | cut -c1-260 > $O/curves.txt; cat $O/curves.txt
