@@ -758,7 +758,7 @@ def main():
             "bf16": "precision='bf16': plain bf16 MFMA operands -- FASTER BUT OUTSIDE the north star's 1e-4 loss-curve gate (cost <= 2.8e-4, triplet <= "
                     "6.8e-3 over the 20-step curve, profiles/r03_bf16_curve.txt); reported for reference, never the headline"}
         notes["f16x2"] = ("precision='f16x2' (round 5's default): fp16 operand images on v_mfma_f32_32x32x16_f16, W alone kept as hi + lo -- FASTER BUT it holds the "
-                          "1e-4 loss-curve gate for 20 steps only: over the 100-step curves it leaves 1e-4 at step 29 of c2 (triplet 3.4e-4) and step 76 of c1 (cost 2.7e-4), "
+                          "1e-4 loss-curve gate for 20 steps only: over the 100-step curves it leaves 1e-4 at step 37 of c2 (triplet 2.8e-4) and step 76 of c1 (cost 2.7e-4), "
                           "profiles/r06_curve_modes.txt")
         notes["f16x2h"] = ("precision='f16x2h' ('auto' for batch_all and batch_hard): fp16 images, W, h (decode and dW) and delta1 as hi + lo; c2 over 100 steps: cost 9.8e-6, triplet 4.8e-5")
         notes["f16x2d"] = ("precision='f16x2d' ('auto' for strategy none / explicit triplets): fp16 images, W + delta2 (in dh AND dW) as hi + lo; c1 over 100 steps: 1.6e-5")

@@ -25,7 +25,7 @@ PRECISIONS = {
     "bf16": ("bf16", 0, None), "bfloat16": ("bf16", 0, None), "fp32": ("bf16", 1, None), "f32": ("bf16", 1, None), "float32": ("bf16", 1, None),
     "bf16x3": ("bf16", 2, None),        # every stored operand hi + lo bf16, three product terms everywhere: holds every measured curve (20 and 100 steps) by > 10x
     "f16x2": ("f16", 2, None),          # fp16 images, W = hi + lo (two terms in decode and dh, one in dW).  Holds the 20-step curves; over 100 steps it leaves 1e-4
-                                        # at step 29 of c2 (triplet 3.4e-4 at step 42) and step 76 of c1 (cost 2.7e-4) -- round 5's default, no longer 'auto'
+                                        # at step 37 of c2 (triplet 2.8e-4 at step 42; step 29 / 3.4e-4 on round 5's K-segment walk) and step 76 of c1 (cost 2.7e-4) -- round 5's default, no longer 'auto'
     "f16x2h": ("f16", 2, X3T_DEC_WLO | X3T_DEC_HLO | X3T_DH_WLO | X3T_DW_D1LO | X3T_DW_HLO),   # W + h in the decode and dW + delta1: c2 over 100 steps 4.8e-5
                                         # (mask 103; the (Gs, h^T_lo) term of dh changes nothing: 119 measures 5.1e-5; without delta1, 71: 7.4e-5; without h@dec: outside)
     "f16x2d": ("f16", 2, X3T_DEC_WLO | X3T_DH_WLO | X3T_DH_D2LO | X3T_DW_D2LO),                               # W + delta2 in dh AND dW: c1 over 100 steps 1.6e-5
@@ -37,7 +37,7 @@ PRECISIONS = {
 # batch_hard, whose curve the reference's own float32 arithmetic does not pin to 1e-4, the oracle-derived envelope of tests/golden/envelope_c3.npz
 # (tests/test_hip_curves.py).  Measurements: profiles/r06_curve_modes.txt (round 6; tools/curve_modes.py).
 #   none        f16x2d   c1: 1.6e-5 over 100 steps at 141 us / step   (f16x2: leaves 1e-4 at step 76; bf16x3: 3.5e-7 at 162 us)
-#   batch_all   f16x2h   c2: 4.8e-5 over 100 steps at 188 us / step   (f16x2: leaves 1e-4 at step 29; bf16x3: 6.5e-6 at 209 us)
+#   batch_all   f16x2h   c2: 4.8e-5 over 100 steps at 188 us / step   (f16x2: leaves 1e-4 at step 37; bf16x3: 6.5e-6 at 209 us)
 #   batch_hard  f16x2h   c3: 0.29 x the envelope gate at 178 us / step (f16x2: 1.28 x, the same mask without delta1 [87]: 1.06 x -- outside; bf16x3: 0.25 x at 198 us)
 #   explicit    f16x2d   c5 (DenoisingAutoencoderTriplet: three row blocks, no miner): see AUTO_BY_STRATEGY's test
 AUTO_BY_STRATEGY = {"none": "f16x2d", "batch_all": "f16x2h", "batch_hard": "f16x2h", "explicit": "f16x2d"}

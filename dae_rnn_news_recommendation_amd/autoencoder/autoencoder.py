@@ -211,7 +211,7 @@ class DenoisingAutoencoder(object):
         """precision='auto' (the default) resolves PER TRIPLET STRATEGY to the cheapest mode measured to hold the reference's loss curve (L.AUTO_BY_STRATEGY:
         1e-4 on every one of 100 steps of the frozen float32-oracle curves for 'none' / 'batch_all' -- 'f16x2d' / 'f16x2h', fp16 operand images with W and
         the operands each strategy is sensitive to kept as hi + lo; the oracle-derived envelope for 'batch_hard' -- 'f16x2h' again), with or without a train set
-        to look at (fit, load_model -> transform: one arithmetic).  'f16x2' (round 5's default: faster, holds 20 steps, leaves 1e-4 at step 29 of c2 / 76 of
+        to look at (fit, load_model -> transform: one arithmetic).  'f16x2' (round 5's default: faster, holds 20 steps, leaves 1e-4 at step 37 of c2 / 76 of
         c1), plain 'bf16' / 'f16' (faster still, outside the gate) must be asked for by name."""
         if self.precision != 'auto':
             return self.precision

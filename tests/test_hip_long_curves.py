@@ -1,8 +1,8 @@
 """100-step (10-epoch; c4: 50 epochs of its 1600-row set) full-shape loss curves of BASELINE.json configs c1, c2, c4 and c5 against the FLOAT32 oracle's per-batch losses frozen by
 tests/golden/make_long_curves.py -- the north star's gate is a CURVE ("loss curve matching reference within 1e-4"), the reference CLI trains 50 epochs
 (main_autoencoder.py:71-72; the per-batch values its epoch line averages: autoencoder.py:283-294), and a 20-step curve stops while a low-precision mode's
-deviation is still growing: round 5's default 'f16x2' (fp16 images, W alone hi + lo) holds 20 steps and then leaves 1e-4 at step 29 of c2 (triplet leg,
-3.4e-4 at step 42) and at step 76 of c1 (cost 2.7e-4 and growing) -- measured here and pinned below.  What precision='auto' resolves to per strategy
+deviation is still growing: round 5's default 'f16x2' (fp16 images, W alone hi + lo) holds 20 steps and then leaves 1e-4 at step 37 of c2 (triplet leg,
+2.8e-4 at step 42) and at step 76 of c1 (cost 2.7e-4 and growing) -- measured here and pinned below.  What precision='auto' resolves to per strategy
 (_lib.AUTO_BY_STRATEGY) is the cheapest mode that holds all 100 steps: 'f16x2d' for strategy none (delta2 as hi + lo in BOTH gradient GEMMs: with the
 lo image in only one of them the curve leaves the gate by 8.7e-3), 'f16x2h' for batch_all (W + every h term + delta1).
 Measurements per mode and lo-term mask: profiles/r06_curve_modes.txt (tools/curve_modes.py)."""

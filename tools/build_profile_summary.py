@@ -120,7 +120,7 @@ if cb and cb.get("value"):
     if cb.get("chunked"): L.append(f"| CPU baseline, chunked (memory-lean) form | {cb['chunked']['samples_per_s']:.1f} samples/s |")
 fl = b["final_losses"]
 for mode, what in (("f16x2h", "fp16 images; W, h, delta1 hi + lo: inside the 1e-4 gate over 100 steps"), ("f16x2d", "fp16 images; W, delta2 hi + lo"),
-                   ("f16x2", "fp16 images, W alone hi + lo: holds 20 steps, leaves 1e-4 at step 29"), ("bf16x3", "split-bf16, three terms: inside the gate"),
+                   ("f16x2", "fp16 images, W alone hi + lo: holds 20 steps, leaves 1e-4 at step 37"), ("bf16x3", "split-bf16, three terms: inside the gate"),
                    ("fp32", "exact-fp32 MFMA: inside the gate"), ("bf16", "plain bf16: OUTSIDE the gate")):
     if b.get(mode) and b[mode].get("value"):
         L.append(f"| `precision='{mode}'` ({what}), same K steps | {b[mode]['value']:,.0f} ({1e3 * b[mode]['ms_per_step']:.1f} us/step) |")

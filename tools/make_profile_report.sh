@@ -44,7 +44,7 @@ rm -rf $OUT/trace
 bash tools/pmc_c4_sq.sh $TAG > /dev/null 2>&1   # SQ counters of the c4 GEMM kernels (own PMC pass) -> $OUT/pmc_counters_c4_sq.md
 $T python tools/kprof.py --precision f16x2h > $OUT/kprof.txt 2>/dev/null      # the product default for batch_all, per kernel
 $T python tools/kprof.py --precision f16x2d --strategy none >> $OUT/kprof.txt 2>/dev/null      # ... for strategy none
-$T python tools/kprof.py --precision bf16x3 --strategy batch_hard >> $OUT/kprof.txt 2>/dev/null      # ... for batch_hard
+$T python tools/kprof.py --precision f16x2h --strategy batch_hard >> $OUT/kprof.txt 2>/dev/null      # ... for batch_hard
 $T python tools/kprof.py --precision f16x2 >> $OUT/kprof.txt 2>/dev/null       # round 5's default (holds 20 steps, not 100)
 $T python tools/kprof.py --precision bf16x3 >> $OUT/kprof.txt 2>/dev/null      # the split-bf16 mode
 $T python tools/kprof.py --precision bf16 >> $OUT/kprof.txt 2>/dev/null
