@@ -226,20 +226,23 @@ class Runner:
             d["order"] = pinned_copy(np.stack([o, o + self.N, o + 2 * self.N]))
         else:          # one pinned array [row order | labels in that order], one H2D copy per epoch (as DenoisingAutoencoder._stage_epoch)
             d["order_labels"] = pinned_copy(np.stack([o, self.labels[order].astype(np.int32)]))
-        return d
+        # ... and uploaded one epoch ahead on a copy stream by this (feeder) thread, as DenoisingAutoencoder.fit() does
+        from dae_rnn_news_recommendation_amd.autoencoder.autoencoder import upload_ahead
+        return upload_ahead(d, self.eng.device, ("bits", "order", "order_labels"))
 
     def _prep_epoch(self):
         torch, L = self.torch, self.L
+        from dae_rnn_news_recommendation_amd.autoencoder.autoencoder import uploaded
         d = self.feeder.get()
         if self.a.rng == "numpy":
-            self.bits = d["bits"].to(self.eng.device, non_blocking=True)
+            self.bits = uploaded(d, "bits", self.eng.device)
             self.plan = dict(corr_mode=L.CORR_KEEPBITS, keep_bits=self.bits)
         else:
             self.plan = dict(corr_mode=L.CORR_PHILOX_MASK, seed=1234, rng_stream=self.epoch, corr_frac=0.3)
         if self.explicit:
-            self.order, self.lab = d["order"].to(self.eng.device, non_blocking=True), None
+            self.order, self.lab = uploaded(d, "order", self.eng.device), None
         else:
-            both = d["order_labels"].to(self.eng.device, non_blocking=True)
+            both = uploaded(d, "order_labels", self.eng.device)
             self.order, self.lab = both[0], both[1]
 
     def batch(self, b):

@@ -50,6 +50,49 @@ def pinned_copy(arr):
     return t
 
 
+_COPY_STREAMS = {}
+
+
+def upload_ahead(draw, device, names):
+    """Feeder thread: start the host -> device copies of the epoch's PINNED tensors `names` (keys of `draw`) on a copy stream of `device`, one epoch
+    ahead of their use.  A copy issued on the stepping stream itself costs the step that opens an epoch ~34 us (tools/region_trace.py: the copy engine
+    and the compute queue hand over through two signals); issued here it has a whole epoch to land, and `uploaded()` on the stepping thread only
+    orders the stream behind an event that completed long ago.  No-op without a GPU device."""
+    import torch
+    if device is None or torch.device(device).type != 'cuda' or not torch.cuda.is_available():
+        return draw
+    device = torch.device(device)
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    st = _COPY_STREAMS.get(key)
+    if st is None:
+        st = _COPY_STREAMS[key] = torch.cuda.Stream(device=device)
+    dev = {}
+    with torch.cuda.device(device), torch.cuda.stream(st):
+        for n in names:
+            if n in draw and hasattr(draw[n], 'is_pinned') and draw[n].is_pinned():
+                dev[n] = draw[n].to(device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(st)
+    draw['_dev'] = dev
+    draw['_dev_event'] = ev
+    return draw
+
+
+def uploaded(draw, name, device):
+    """Stepping thread: the device copy of draw[name] -- the one `upload_ahead` started (the current stream is ordered behind its event, the block is
+    marked as used by this stream), else an asynchronous copy on the current stream."""
+    import torch
+    dev = draw.get('_dev')
+    if dev is not None and name in dev:
+        cur = torch.cuda.current_stream(dev[name].device)
+        if not draw.get('_dev_waited'):
+            cur.wait_event(draw['_dev_event'])
+            draw['_dev_waited'] = True
+        dev[name].record_stream(cur)
+        return dev[name]
+    return draw[name].to(device, non_blocking=True)
+
+
 class _EpochFeeder(object):
     """Produces the per-epoch host draws one epoch AHEAD of the device, on a thread, in epoch order -- so the legacy global
     NumPy stream is consumed exactly as the reference consumes it (corruption of epoch e, shuffle of epoch e, corruption of
@@ -357,7 +400,9 @@ class DenoisingAutoencoder(object):
         # single GPU + a mining strategy: every mini-batch is handed over class-sorted (utils.class_sort_batches); under data
         # parallel the ranks take contiguous shards of a batch, which must stay a random sample of it
         sort_batch = batch if (world == 1 and label_ids is not None and self.triplet_strategy != 'none') else None
-        feeder = _EpochFeeder(lambda e: self._stage_epoch(self._draw_epoch(train_set, e), label_ids, sort_batch), self.num_epochs)
+        dev = self.engine.device
+        feeder = _EpochFeeder(lambda e: upload_ahead(self._stage_epoch(self._draw_epoch(train_set, e), label_ids, sort_batch), dev,
+                                                     ('order_labels_t', 'order_t', 'labels_t', 'bits_t')), self.num_epochs)
         t_fit = time.time()
         t_first = None
         i = -1
@@ -439,7 +484,7 @@ class DenoisingAutoencoder(object):
             if self.rng == 'philox':
                 seed = self.seed if self.seed >= 0 else 0x5EED
                 return dict(corr_mode=L.CORR_PHILOX_MASK, seed=seed, rng_stream=epoch, corr_frac=float(self.corr_frac))
-            bits = (draw['bits_t'] if 'bits_t' in draw else torch.from_numpy(draw['bits'])).to(eng.device, non_blocking=True)
+            bits = uploaded(draw, 'bits_t', eng.device) if 'bits_t' in draw else torch.from_numpy(draw['bits']).to(eng.device, non_blocking=True)
             self._keep_bits = bits                                                           # keep alive while steps run
             return dict(corr_mode=L.CORR_KEEPBITS, keep_bits=bits)
         if draw['kind'] == 'decay':
@@ -461,12 +506,12 @@ class DenoisingAutoencoder(object):
         order = draw['order']
         labels_dev = None
         if 'order_labels_t' in draw:
-            both = draw['order_labels_t'].to(eng.device, non_blocking=True)
+            both = uploaded(draw, 'order_labels_t', eng.device)
             order_dev, labels_dev = both[0], both[1]
         else:
-            order_dev = (draw['order_t'] if 'order_t' in draw else torch.from_numpy(order.astype(np.int32))).to(eng.device, non_blocking=True)
+            order_dev = uploaded(draw, 'order_t', eng.device) if 'order_t' in draw else torch.from_numpy(order.astype(np.int32)).to(eng.device, non_blocking=True)
             if label_ids is not None:
-                labels_dev = (draw['labels_t'] if 'labels_t' in draw else torch.from_numpy(label_ids[order])).to(eng.device, non_blocking=True)
+                labels_dev = uploaded(draw, 'labels_t', eng.device) if 'labels_t' in draw else torch.from_numpy(label_ids[order]).to(eng.device, non_blocking=True)
         stats = self._stats[epoch]
         shard_w = []
         sp = plan.pop('_sp', None)

@@ -74,7 +74,7 @@ class DenoisingAutoencoderTriplet(DenoisingAutoencoder):
         eng = self.engine
         n_batches = -(-N // batch)
         self._stats = torch.zeros((max(self.num_epochs, 1), n_batches, L.STATS_STRIDE), dtype=torch.float32, device=eng.device)
-        from .autoencoder import _EpochFeeder, pinned_copy
+        from .autoencoder import _EpochFeeder, pinned_copy, upload_ahead, uploaded
 
         def draw_epoch(e):
             # feeder thread, one epoch ahead: ONE corruption draw over the stacked set (org, pos, neg in order), then ONE shuffle
@@ -86,8 +86,9 @@ class DenoisingAutoencoderTriplet(DenoisingAutoencoder):
             d['rows_t'] = pinned_copy(np.concatenate(rows))
             if 'bits' in d:
                 d['bits_t'] = pinned_copy(d['bits'])
-            return d
+            return upload_ahead(d, dev, ('rows_t', 'bits_t'))       # ... and on their way to the device, on a copy stream, an epoch early
 
+        dev = eng.device
         feeder = _EpochFeeder(draw_epoch, self.num_epochs)
         t_fit = time.time()
         t_first = None
@@ -101,7 +102,7 @@ class DenoisingAutoencoderTriplet(DenoisingAutoencoder):
                     d = stacked.data if stacked.nnz else np.zeros(1)
                     full = stacked.nnz == stacked.shape[0] * stacked.shape[1]
                     self._sp_range = (float(d.min() if full else min(d.min(), 0.0)), float(d.max() if full else max(d.max(), 0.0)))
-                rows_dev = draw['rows_t'].to(eng.device, non_blocking=True)
+                rows_dev = uploaded(draw, 'rows_t', eng.device)
                 off = draw['row_offsets']
                 for b in range(n_batches):
                     rows = rows_dev[off[b]:off[b + 1]]
