@@ -368,6 +368,7 @@ extern "C" int dae_plan_set_option(dae_plan* p, const char* name, int32_t value)
     else if (!strcmp(name, "gather_tile")) set_gather_tile(value);        // process-wide: tile shape of the dense gather (A/B measurements)
     else if (!strcmp(name, "dw_rounds")) { DAE_CHECK_ARG(value >= 1 && value <= 64, "plan_set_option: dw_rounds in 1..64"); set_use_glds(-100 - value); }   // process-wide, like miner_pack
     else if (!strcmp(name, "decode_pair")) set_use_glds(on ? -14 : -13);   // process-wide: the decode's two W terms as paired K-loop stages (one h tile, both W tiles)
+    else if (!strcmp(name, "gram_fused")) set_use_glds(on ? -20 : -19);    // process-wide: the split Gram's three products per K tile in one LDS stage (gram64f_kernel; default on), 0 = the K-concatenated walk (gram64_kernel)
     else if (!strcmp(name, "decode_x3")) set_use_glds(on ? -18 : -17);     // process-wide: the split modes' decode on the K loops that keep the hi stage's fragments in registers (mainloop_n64_x3 / _c2; default on, binary input)
     else if (!strcmp(name, "decode_ast")) set_use_glds(on ? -16 : -15);    // process-wide: the A-stationary persistent decode kernel (gemm_decode_ast; default off: measured slower)
     else if (!strcmp(name, "pad_skip")) set_use_glds(on ? -12 : -11);      // process-wide: 0 = multiply / evaluate the all-padding 32-row blocks of the last batch tile too (A/B)

@@ -1586,7 +1586,115 @@ __global__ __launch_bounds__(GEMM_THREADS, 1) void gram64_kernel(const char* __r
     for (int q = 0; q < 16; ++q) Dt[(int64_t)((q & 3) + 8 * (q >> 2) + 4 * g) * ldd] = acc[q];
 }
 
+// The same tile with the THREE products of a K tile in ONE stage (round 6): a stage holds the hi and the lo image of both row panels for 64 columns of h
+// (4 x 8 KiB), a wave reads its 16 fragments once and multiplies hi.hi, hi.lo, lo.hi from registers -- 8 stages of 8 LDS-DMA pieces / 16 fragment reads /
+// one barrier per wave instead of 24 stages of 4 / 8 / one for the same 96 MFMAs, on three independent accumulators (the K-concatenated walk chains all
+// 96 on one).  Same products; the three partial sums are added at the end.  4-stage ring of 32 KiB.
+constexpr int G64F_NST = 4;
+constexpr int G64F_STAGE = 4 * G64_TILE;
+constexpr int G64F_LDS = G64F_NST * G64F_STAGE;
+__device__ __forceinline__ void wait_vm_8n(int n) {   // vmcnt(8 n): n younger stages of 8 LDS-DMA pieces each may stay in flight
+    switch (n) {
+        case 0: wait_vm<0>(); break;
+        case 1: wait_vm<8>(); break;
+        case 2: wait_vm<16>(); break;
+        default: wait_vm<24>(); break;
+    }
+}
+__global__ __launch_bounds__(GEMM_THREADS, 1) void gram64f_kernel(const char* __restrict__ Hhi, const char* __restrict__ Hlo, int64_t ld_b, int nk, int tiles,
+                                                                  float* __restrict__ D, int64_t ldd) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int b = blockIdx.x, per = (tiles * tiles + 7) >> 3;
+    const int t = (b & 7) * per + (b >> 3);
+    if ((b >> 3) >= per || t >= tiles * tiles) return;
+    const int tm = t / tiles, tn = t % tiles;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    // LDS-DMA: this wave's pieces {wave, wave + 4} of each of the four operand tiles (8 rows of 128 B per 1-KiB piece), swizzled source slot per lane
+    uint32_t voA[2], voB[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (i * 4 + wave) * 8 + (lane >> 3);
+        const uint32_t ss = (uint32_t)(((lane & 7) ^ ((row >> 1) & 7)) << 4);
+        voA[i] = (uint32_t)(tm * 64 + row) * (uint32_t)ld_b + ss;
+        voB[i] = (uint32_t)(tn * 64 + row) * (uint32_t)ld_b + ss;
+    }
+    const char *gH = Hhi, *gL = Hlo;
+    auto dma_stage = [&](char* slot) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int piece = (i * 4 + wave) * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gH + voA[i]), (__attribute__((address_space(3))) void*)(slot + piece), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gL + voA[i]), (__attribute__((address_space(3))) void*)(slot + G64_TILE + piece), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gH + voB[i]), (__attribute__((address_space(3))) void*)(slot + 2 * G64_TILE + piece), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gL + voB[i]), (__attribute__((address_space(3))) void*)(slot + 3 * G64_TILE + piece), 16, 0, 0);
+        }
+        gH += BKB; gL += BKB;
+    };
+    f32x16 acc0, acc1, acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; acc2[r] = 0.f; }
+    const int r = lane & 31, g = lane >> 5;
+    const int swz = (r >> 1) & 7;
+    const uint32_t lbase = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)lds;
+    const uint32_t offa = (wm * 32 + r) * BKB, offb = 2 * G64_TILE + (wn * 32 + r) * BKB;
+    uint32_t so[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) so[kk] = (uint32_t)(((kk * 2 + g) ^ swz) << 4);
+#pragma unroll
+    for (int st = 0; st < G64F_NST; ++st)
+        if (st < nk) dma_stage(lds + st * G64F_STAGE);
+    int cur = 0, prev = G64F_NST - 1;
+    for (int i = 0; i < nk; ++i) {
+        const int issued = i == 0 ? min(nk, G64F_NST) : min(nk, i - 1 + G64F_NST);     // stages requested so far
+        wait_vm_8n(issued - (i + 1));                      // everything up to stage i has landed (this wave's pieces)
+        __builtin_amdgcn_s_barrier();                      // ... and every other wave's; slot `prev` is free
+        asm volatile("" ::: "memory");
+        const uint32_t sb = lbase + cur * G64F_STAGE;
+        i32x4 fah[4], fal[4], fbh[4], fbl[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            fah[kk] = lds_read_b128(sb + offa + so[kk]);
+            fbh[kk] = lds_read_b128(sb + offb + so[kk]);
+            fbl[kk] = lds_read_b128(sb + offb + G64_TILE + so[kk]);
+            fal[kk] = lds_read_b128(sb + offa + G64_TILE + so[kk]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (i >= 1 && i - 1 + G64F_NST < nk) dma_stage(lds + prev * G64F_STAGE);      // (its issue cost hides the LDS latency of the reads above)
+        __builtin_amdgcn_sched_barrier(0);
+#define DAE_G64F_STEP(KK, CNT)                                   \
+    asm volatile("s_waitcnt lgkmcnt(" #CNT ")" ::: "memory");    \
+    __builtin_amdgcn_sched_barrier(0);                           \
+    Mma<bf16_t>::run(fah[KK], fbh[KK], acc0);                    \
+    Mma<bf16_t>::run(fah[KK], fbl[KK], acc1);                    \
+    Mma<bf16_t>::run(fal[KK], fbh[KK], acc2);
+        DAE_G64F_STEP(0, 12)
+        DAE_G64F_STEP(1, 8)
+        DAE_G64F_STEP(2, 4)
+        DAE_G64F_STEP(3, 0)
+#undef DAE_G64F_STEP
+        __builtin_amdgcn_sched_barrier(0);
+        prev = cur;
+        cur = cur + 1 == G64F_NST ? 0 : cur + 1;
+    }
+    float* Dt = D + (int64_t)(tm * 64 + wm * 32) * ldd + tn * 64 + wn * 32 + r;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) Dt[(int64_t)((q & 3) + 8 * (q >> 2) + 4 * g) * ldd] = (acc0[q] + acc1[q]) + acc2[q];
+}
+
+static int g_gram_fused = 1;        // dae_set_glds(-19) off / (-20) on: the Gram's three products per K tile in one stage (gram64f_kernel) instead of the K-concatenated walk
 int launch_gram64(const void* hcat_a, const void* hcat_b, int Bp, int Hp, float* D, hipStream_t st) {
+    if (g_gram_fused && hcat_a && hcat_b && D && Bp % 64 == 0 && Hp % 64 == 0 && (uint64_t)Bp * (uint64_t)(3 * Hp * 2) < (1ull << 32)) {
+        // hcat_a = [hi | hi | lo], hcat_b = [hi | lo | hi] (leading dimension 3 Hp): the hi image is block 0 of either, the lo image block 2 of hcat_a
+        static int rcf = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(gram64f_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G64F_LDS);
+        DAE_CHECK_ARG(rcf == 0, "gram64: hipFuncSetAttribute failed");
+        const int tiles = Bp / 64, per = (tiles * tiles + 7) / 8;
+        hipLaunchKernelGGL(gram64f_kernel, dim3(8 * per), dim3(GEMM_THREADS), G64F_LDS, st, (const char*)hcat_a, (const char*)hcat_a + (size_t)2 * Hp * 2,
+                           (int64_t)3 * Hp * 2, Hp * 2 / BKB, tiles, D, (int64_t)Bp);
+        DAE_CHECK_LAUNCH();
+        return 0;
+    }
     DAE_CHECK_ARG(hcat_a && hcat_b && D && Bp % 64 == 0 && Hp % 64 == 0, "gram64: bad arguments");
     DAE_CHECK_ARG((uint64_t)Bp * (uint64_t)(3 * Hp * 2) < (1ull << 32), "gram64: operand panel beyond 4 GiB");
     static int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(gram64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G64_LDS);
@@ -3624,6 +3732,8 @@ void set_use_glds(int nst) {
     if (nst <= -100 && nst > -1000) { g_dw_rounds = g_dw_rounds_split = (-nst - 100 < 1 ? 1 : -nst - 100); return; }    // rounds of the chip the 160 x 128 dW kernel may take
     if (nst == -13) { g_decode_pair = 0; return; }
     if (nst == -14) { g_decode_pair = 1; return; }
+    if (nst == -19) { g_gram_fused = 0; return; }
+    if (nst == -20) { g_gram_fused = 1; return; }
     if (nst == -17) { g_decode_x3 = 0; return; }
     if (nst == -18) { g_decode_x3 = 1; return; }
     if (nst == -15) { g_decode_ast = 0; return; }

@@ -177,6 +177,27 @@ def test_gram_on_64x64_tiles_single_slab_equals_split_k_form(dtype, strategy, B)
             assert _rel(dWa, np.asarray(dWb, np.float64)) < 2e-5
 
 
+@pytest.mark.parametrize("dtype,strategy,shape", [("f16x2h", "batch_all", dict(N=600, F=700, H=90, B=150)), ("bf16x3", "batch_all", dict(N=700, F=900, H=500, B=300)),
+                                                  ("f16x2h", "batch_hard", dict(N=600, F=700, H=200, B=260)), ("bf16", "batch_all", dict(N=600, F=700, H=130, B=64))])
+def test_gram_three_products_in_one_stage_equals_the_k_concatenated_walk(dtype, strategy, shape):
+    """gram64f_kernel (plan option gram_fused, default on): a stage holds the hi AND lo images of both row panels, the wave multiplies hi.hi, hi.lo, lo.hi from
+    one set of fragments on three accumulators -- against gram64_kernel's walk over the K-concatenated operands [hi | hi | lo].[hi | lo | hi]^T (one
+    accumulator): the same products, fp32 sums in another order."""
+    from dae_rnn_news_recommendation_amd import _lib as L
+    kw = dict(steps=2, seed=29, **shape)
+    a, _, pa = _run_case(dtype, strategy, "cross_entropy", ("sigmoid", "sigmoid"), "gradient_descent", options={"gram_fused": 1}, **kw)
+    try:
+        b, _, pb = _run_case(dtype, strategy, "cross_entropy", ("sigmoid", "sigmoid"), "gradient_descent", options={"gram_fused": 0}, **kw)
+    finally:
+        L.set_glds_all(-20)
+    for (ra, sa, dWa, *_), (_, sb, dWb, *_) in zip(a, b):
+        assert np.allclose(sa[:3], sb[:3], rtol=5e-6, atol=0), (sa, sb)
+        if strategy == "batch_all":
+            assert abs(sa[4] - sb[4]) <= 2 and sa[5] == sb[5]            # positive-triplet count (near-ties), N_valid
+            assert abs(sa[2] - ra["triplet_loss"]) <= (1e-4 if dtype != "bf16" else 5e-2) * abs(ra["triplet_loss"])
+            assert _rel(dWa, np.asarray(dWb, np.float64)) < 2e-5
+
+
 @pytest.mark.parametrize("dtype,dense,phase,opt,B", [("f16x2", False, 0, "gradient_descent", 150), ("f16x2", True, 0, "adam", 150), ("bf16", False, 1, "momentum", 200),
                                                      ("f16", False, 0, "ada_grad", 130), ("f16x2", False, 1, "gradient_descent", 64)])
 def test_dw_transposed_a_form_equals_transposed_images(dtype, dense, phase, opt, B):
