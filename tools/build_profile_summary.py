@@ -13,7 +13,7 @@ TRAFFIC_ONLY = "--traffic-only" in sys.argv
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 dst = os.path.join(root, "profiles")
 # step slot (bench.py `kernels` key) -> kernel symbol prefix in the rocprofv3 tables
-SLOT_KERNEL = [("encode_gemm", "encode_csr_kernel"), ("gram", "gram64_kernel"), ("miner", "batch_all_tile_kernel"),
+SLOT_KERNEL = [("encode_gemm", "encode_csr_kernel"), ("gram", "gram64f_kernel"), ("miner", "batch_all_tile_kernel"),
                ("sym_scale", "sym_scale_kernel"), ("decode_loss", "gemm_decode_loss<unsigned short"), ("dh_gemm", "gemm_nt_pc<unsigned short, 4, 2>"),
                ("dh_finish", "dh_finish_kernel<unsigned short"), ("dw_gemm", "gemm_dw_pc"), ("bias_grads", "step_tail_kernel")]
 SLOT_KERNEL_C4 = [("gather", "gather_dense_kernel"), ("encode_gemm", "gemm_nt_w8<1>"), ("encode_finish", "encode_finish_kernel"),
