@@ -14,7 +14,7 @@ reference-exact legacy-RNG stream, exactly like make_full_curve.py / make_curves
                   of a hand-sized tail.
   envelope c2 [K] the same for c2 over the 100-step horizon (context for the long curve: does the reference's arithmetic pin ITS OWN step 100 to 1e-4?)
 
-CPU only; c2 costs ~1 minute per 10 steps.  usage: python tests/golden/make_long_curves.py long c2 [epochs] | envelope c3 16 8   (long c1 50 / long c5 50: the CLI's default 50 epochs = 500 steps)"""
+CPU only; c2 costs ~50 s per STEP (the literal B^3 batch_all in float32: 86 minutes for its 100 steps), c4 57 s per step, c1 / c5 1-4 s.  usage: python tests/golden/make_long_curves.py long c2 [epochs] | envelope c3 16 8   (long c1 50 / long c5 50: the CLI's default 50 epochs = 500 steps)"""
 import os
 import sys
 import time
