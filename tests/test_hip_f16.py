@@ -300,3 +300,34 @@ def test_step_with_the_persistent_a_stationary_decode_kernel(dtype, strategy, lo
         assert abs(sa[0] - r["cost"]) <= (1e-4 if dtype != "bf16" else 2e-3) * abs(r["cost"])
         assert _rel(dWa, np.asarray(dWb, np.float64)) < 1e-3 and _rel(dbha, np.asarray(dbhb, np.float64)) < 1e-3, (_rel(dWa, np.asarray(dWb, np.float64)),)
         assert np.allclose(dbva, dbvb, rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("dtype,strategy", [("f16x2h", "batch_all"), ("f16x2d", "none"), ("f16x2h", "batch_hard")])
+def test_full_shape_steps_are_bit_identical_run_to_run(dtype, strategy):
+    """The product defaults at the full c2 shape (F = 10000, H = 500, B = 800: 1106 decode tiles on the register-carry K loops, the fused-stage Gram, one
+    round of the dW kernel): two engines fed the same rows, the same Philox corruption and the same W0 must end 12 steps with bit-identical parameters
+    and statistics -- an LDS-DMA / barrier race in one of the hand-scheduled loops shows as a run-to-run difference at this occupancy, not at the small
+    shapes of the oracle tests."""
+    from dae_rnn_news_recommendation_amd import _lib as L
+    from dae_rnn_news_recommendation_amd.engine import Engine
+    from dae_rnn_news_recommendation_amd.synthetic import synthetic_csr, synthetic_labels, xavier_uniform
+    N, F, H, B = 2400, 10000, 500, 800
+    m = synthetic_csr(N, F, seed=5); lab = synthetic_labels(N, seed=5).astype(np.int32)
+    W0 = xavier_uniform(F, H)
+    outs = []
+    for rep in range(2):
+        eng = Engine(F, H, B, dtype=dtype, triplet=strategy, loss_func="cross_entropy", learning_rate=0.1)
+        eng.upload_csr(m); eng.set_params(W0)
+        stats = torch.zeros((12, L.STATS_STRIDE), device="cuda")
+        for s in range(12):
+            ids = (np.arange(B) + 800 * (s % 3)) % N
+            ids = ids[np.argsort(lab[ids], kind="stable")]
+            idx = torch.from_numpy(ids.astype(np.int32)).cuda()
+            labs = torch.from_numpy(lab[ids]).cuda() if strategy != "none" else None
+            eng.train_step(idx, labs, stats[s], corr_mode=L.CORR_PHILOX_MASK, seed=11, rng_stream=s, corr_frac=0.3, phase=3)
+        torch.cuda.synchronize()
+        outs.append(([np.asarray(x) for x in eng.get_params()], stats.cpu().numpy()))
+    for u, v in zip(outs[0][0], outs[1][0]):
+        assert np.array_equal(u, v)
+    assert np.array_equal(outs[0][1], outs[1][1])
+    assert np.isfinite(outs[0][1][:, 0]).all() and outs[0][1][-1, 0] < outs[0][1][0, 0]          # ... and it trained
