@@ -155,7 +155,8 @@ struct dae_plan {
                                      // but +3..5 us at the CSR shape of c2 (11 fragment-read instructions per k step instead of 6; its decode does not get faster)
     bool gram64_ok;                  // option "gram64" (default 1): the split Gram on 64 x 64 tiles over the whole K, ONE slab (gram64_kernel); 0: 128 x 128 tiles, split-K
     float *slabs, *h_f32, *D_slabs, *G, *rowloss_part, *dbv_part, *colsum_part, *cos_part, *cos_stats, *cw, *loss_part,
-        *dw_f32, *tri_scalars, *dh_extra, *rowsq_scratch, *tile_part;
+        *dw_f32, *tri_scalars, *dh_extra, *rowsq_scratch, *tile_part, *zbuf;
+    bool cos_zstore_ok;               // option "cos_zstore" (default 1): the cosine decode's second pass reads the first pass's accumulators back instead of recomputing the GEMM
     uint32_t *cnt_part, *role_cnt, *xc_bits, *x_bits;
     bool xbits_ok;                   // binary CSR + bf16: the decode epilogue reads x as a bit image (option "x_bits" = 0 disables)
     bool xct_clean;                  // x~^T holds only zeros (every step un-scatters what it wrote; see step_tail_kernel)
@@ -255,6 +256,7 @@ static uint64_t carve(dae_plan* p, char* base) {
     p->cos_part = (float*)take(2 * (2 * Fp / dbn) * Bp * 4);
     p->cos_stats = (float*)take(3 * Bp * 4);
     p->rowsq_scratch = (float*)take((Fp / 64) * Bp * 4);
+    p->zbuf = (float*)take(p->cfg.loss_func == DAE_LOSS_COSINE ? Bp * Fp * 4 : 256);     // cosine: the decode's accumulators between its two passes (DecodeEpi::z_io)
     p->tile_part = (float*)take((Bp / 128) * (Fp / dbn) * 4);
     p->cw = (float*)take(Bp * 4);
     p->loss_part = (float*)take(Bp * 4);
@@ -332,6 +334,7 @@ extern "C" int dae_plan_create(const dae_config* cfg, dae_plan** out) {
     p->sparse_ok = true;
     p->miner_order_ok = true; p->sym_ride_ok = true; p->miner_ranges_ok = true;
     p->overlap_ok = false;                              // measured: running the miner chain beside decode is SLOWER (0.410 vs 0.351 ms/step)
+    p->cos_zstore_ok = true;
     *out = p;
     return 0;
 }
@@ -368,6 +371,7 @@ extern "C" int dae_plan_set_option(dae_plan* p, const char* name, int32_t value)
     else if (!strcmp(name, "gather_tile")) set_gather_tile(value);        // process-wide: tile shape of the dense gather (A/B measurements)
     else if (!strcmp(name, "dw_rounds")) { DAE_CHECK_ARG(value >= 1 && value <= 64, "plan_set_option: dw_rounds in 1..64"); set_use_glds(-100 - value); }   // process-wide, like miner_pack
     else if (!strcmp(name, "decode_pair")) set_use_glds(on ? -14 : -13);   // process-wide: the decode's two W terms as paired K-loop stages (one h tile, both W tiles)
+    else if (!strcmp(name, "cos_zstore")) p->cos_zstore_ok = on;
     else if (!strcmp(name, "gram_fused")) set_use_glds(on ? -20 : -19);    // process-wide: the split Gram's three products per K tile in one LDS stage (gram64f_kernel; default on), 0 = the K-concatenated walk (gram64_kernel)
     else if (!strcmp(name, "decode_x3")) set_use_glds(on ? -18 : -17);     // process-wide: the split modes' decode on the K loops that keep the hi stage's fragments in registers (mainloop_n64_x3 / _c2; default on, binary input)
     else if (!strcmp(name, "decode_ast")) set_use_glds(on ? -16 : -15);    // process-wide: the A-stationary persistent decode kernel (gemm_decode_ast; default off: measured slower)
@@ -746,7 +750,10 @@ extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
         }
         if (is_cos) {
             e.cos_pass = 1;
+            const bool zs = backward && p->cos_zstore_ok && p->zbuf;
+            if (zs) { e.z_io = p->zbuf; e.ldz = Fp; e.z_mode = 1; }
             PROF(PS_DECODE, launch_decode_loss_n(dt, Bp, Fp, dsegs, ndseg, e, ds));
+            if (zs) e.z_mode = 2;
             PROF(PS_COS_REDUCE, dae_cos_reduce(p->cos_part, ncw, B, Bp, p->cos_stats, p->rowloss_part, (void*)ds));
             e.sym_G = nullptr;                                 // the first pass carried the rider
             if (backward) { e.cos_pass = 2; PROF(PS_DECODE, launch_decode_loss_n(dt, Bp, Fp, dsegs, ndseg, e, ds)); }

@@ -503,6 +503,22 @@ def test_sym_scale_rider_equals_own_launch(strategy, loss):
         assert np.array_equal(np.asarray(u), np.asarray(v))
 
 
+@pytest.mark.parametrize("dtype,strategy,dense", [("bf16", "batch_all", False), ("fp32", "none", False), ("bf16x3", "batch_hard", False), ("bf16", "none", True)])
+def test_cosine_second_pass_from_stored_logits_equals_recomputation(dtype, strategy, dense):
+    """cosine_proximity needs two passes over the decode (row statistics, then the gradient).  Plan option cos_zstore (default on): the first pass parks its
+    GEMM accumulators in memory and the second pass loads them instead of walking K again -- the same fp32 values, so every statistic, gradient and
+    parameter must be bit-identical to the recomputing form (cos_zstore = 0)."""
+    kw = dict(steps=2, seed=33, N=400, F=900, H=150, B=150, dense=dense)
+    a, _, pa = _run_case(dtype, strategy, "cosine_proximity", ("sigmoid", "sigmoid"), "gradient_descent", **kw)
+    b, _, pb = _run_case(dtype, strategy, "cosine_proximity", ("sigmoid", "sigmoid"), "gradient_descent", options={"cos_zstore": 0}, **kw)
+    for (r, sa, dWa, dbha, dbva), (_, sb, dWb, dbhb, dbvb) in zip(a, b):
+        assert np.array_equal(sa[:6], sb[:6])
+        assert np.array_equal(dWa, dWb) and np.array_equal(dbha, dbhb) and np.array_equal(dbva, dbvb)
+        assert abs(sa[1] - r["ae_loss"]) <= (2e-5 if dtype == "fp32" else 3e-3) * abs(r["ae_loss"])
+    for u, v in zip(pa, pb):
+        assert np.array_equal(np.asarray(u), np.asarray(v))
+
+
 def test_phase3_updates_like_phase0():
     """phase 3 (no W-gradient image) must leave the same parameters as phase 0."""
     from dae_rnn_news_recommendation_amd import _lib as L
