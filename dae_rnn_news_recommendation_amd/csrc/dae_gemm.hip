@@ -2065,16 +2065,21 @@ __global__ __launch_bounds__(GEMM_THREADS, PAIRD ? 2 : DecGeo<BN_T>::WG_PER_CU) 
     const int vblk = e.no_pad_skip ? 4 : min(4, (e.B - tm * BM + 31) >> 5);
     const bool vb[2] = {2 * wm < vblk, 2 * wm + 1 < vblk};
     // cosine, second pass: the accumulators of the statistics pass come back from memory (DecodeEpi::z_io) instead of a second walk over K -- the decode
-    // GEMM of this loss runs ONCE per step.  Accumulator element r of block (mt, nt) is row 64 wm + 32 mt + 8 (r >> 2) + (r & 3) + 4 g, column WCOLS wn + 32 nt + c.
+    // GEMM of this loss runs ONCE per step.
     const bool z_load = IS_COS && e.z_mode == 2 && e.z_io;
     if (z_load) {
-        const float* zp = e.z_io + (int64_t)(tm * BM + wm * 64 + 4 * g) * e.ldz + tn * BN_T + wn * WCOLS + c;
+        // (the buffer is private to these two passes: it holds the accumulator registers themselves, tile by tile and wave by wave, as 16-byte pieces of
+        //  consecutive lanes -- 8 NTB fully coalesced 1-KiB accesses per wave instead of 32 NTB dword ones on row-major logits)
+        const f32x4* zp = reinterpret_cast<const f32x4*>(e.z_io) + ((int64_t)(tm * (e.Fp / BN_T) + tn) * 4 + wave) * (2 * NTB * 4 * 64) + lane;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NTB; ++nt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = zp[(int64_t)(mt * 32 + 8 * (r >> 2) + (r & 3)) * e.ldz + nt * 32];
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = zp[((mt * NTB + nt) * 4 + q) * 64];
+                    acc[mt][nt][4 * q] = v[0]; acc[mt][nt][4 * q + 1] = v[1]; acc[mt][nt][4 * q + 2] = v[2]; acc[mt][nt][4 * q + 3] = v[3];
+                }
     } else {
     if constexpr (BN_T == 128) gemm_mainloop<T, DECODE_NST>(p, tm, tn, kt0, kt1, lds, acc);
     else if constexpr (PAIRD) mainloop_n64_pair<T>(p, tm, tn, lds, acc);
@@ -2083,13 +2088,16 @@ __global__ __launch_bounds__(GEMM_THREADS, PAIRD ? 2 : DecGeo<BN_T>::WG_PER_CU) 
     else mainloop_n64<T>(p, tm, tn, lds, acc);
     }
     if (IS_COS && e.z_mode == 1 && e.z_io) {           // statistics pass: park the accumulators for the final pass (128-byte row segments per half wave)
-        float* zp = e.z_io + (int64_t)(tm * BM + wm * 64 + 4 * g) * e.ldz + tn * BN_T + wn * WCOLS + c;
+        f32x4* zp = reinterpret_cast<f32x4*>(e.z_io) + ((int64_t)(tm * (e.Fp / BN_T) + tn) * 4 + wave) * (2 * NTB * 4 * 64) + lane;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NTB; ++nt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) zp[(int64_t)(mt * 32 + 8 * (r >> 2) + (r & 3)) * e.ldz + nt * 32] = acc[mt][nt][r];
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v = {acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]};
+                    zp[((mt * NTB + nt) * 4 + q) * 64] = v;
+                }
     }
     // (the K loop multiplies the padding blocks too: branching around MFMAs would put them in basic blocks of their own, out of reach of the static check
     //  of the hand-placed LDS waits, tools/check_gemm_asm.py -- measured worth < 1 % of the step; the EPILOGUE below skips their loss evaluation)

@@ -33,7 +33,7 @@ struct DecodeEpi {
     float op_scale;
     int no_pad_skip;          // 1: evaluate every 32-row block, padding included (A/B; set by the launcher from the process-wide switch)
     int dbg;                  // timing probes of gemm_decode_ast (dae_set_glds(-500000 - bits); results are garbage when set): 1 no A loads, 2 no fragment reads / MFMAs, 4 no LDS-DMA, 8 no epilogue arithmetic, 16 no tile stores
-    float* z_io; int64_t ldz; // cosine only: the logits' GEMM part (accumulators, before the bias) of the statistics pass, [Bp x ldz] fp32 -- z_mode 1: pass 1 stores them,
+    float* z_io; int64_t ldz; // cosine only: the logits' GEMM part (accumulators, before the bias) of the statistics pass, Bp x Fp fp32 in the kernel's own register order (ldz unused) -- z_mode 1: pass 1 stores them,
     int z_mode;               // z_mode 2: pass 2 LOADS them instead of running the K loop again (the same fp32 values the recomputation would produce); 0 / NULL: recompute
     int bn;                   // tile width (columns of y per workgroup): 0 = the mode's default (decode_tile_n), 128 = the wide 16-bit kernel; the partial-sum arrays
                               // (rowloss_part / cos_part: 2 * Fp / bn rows; tile_part: (Bp / 128) * (Fp / bn)) are laid out by it
