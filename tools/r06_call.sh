@@ -1,7 +1,9 @@
 #!/bin/bash
-# round 6: the whole GPU suite + smoke at the final HEAD
-mkdir -p gpurun_out/r06c41
-O=gpurun_out/r06c41
-timeout 2700 python -m pytest tests -m gpu -x -q 2>&1 | tail -6 > $O/gpu_suite.txt; cat $O/gpu_suite.txt
-timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -5 > $O/smoke.txt; cat $O/smoke.txt
-timeout 300 python bench.py --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench.err; python -c "import json; d=json.load(open('$O/bench_default.json')); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['traffic'], d['cpu_baseline']['value'])"
+# round 6: s_setprio(2) around the MFMA groups of the x3 decode loop -- A/B against HEAD is the previous call's numbers; here: kprof x 3 with the seg walk as the same-box yardstick
+mkdir -p gpurun_out/r06c42
+O=gpurun_out/r06c42
+for i in 1 2 3; do
+timeout 300 python tools/kprof.py --precision f16x2h --opt decode_x3=0 --tag seg3 2>/dev/null | grep "==\|decode_loss" | cut -c1-130 >> $O/kprof_ab.txt
+timeout 300 python tools/kprof.py --precision f16x2h --opt decode_x3=1 --tag x3prio 2>/dev/null | grep "==\|decode_loss" | cut -c1-130 >> $O/kprof_ab.txt
+done
+cat $O/kprof_ab.txt
