@@ -38,7 +38,7 @@ PRECISIONS = {
 # (tests/test_hip_curves.py).  Measurements: profiles/r06_curve_modes.txt (round 6; tools/curve_modes.py).
 #   none        f16x2d   c1: 1.6e-5 over 100 steps at 141 us / step   (f16x2: leaves 1e-4 at step 76; bf16x3: 3.5e-7 at 162 us)
 #   batch_all   f16x2h   c2: 4.8e-5 over 100 steps at 188 us / step   (f16x2: leaves 1e-4 at step 37; bf16x3: 6.5e-6 at 209 us)
-#   batch_hard  f16x2h   c3: 0.29 x the envelope gate at 178 us / step (f16x2: 1.28 x, the same mask without delta1 [87]: 1.06 x -- outside; bf16x3: 0.25 x at 198 us)
+#   batch_hard  f16x2h   c3: 0.29-0.40 x the envelope gate at 168 us / step (the ratio moves with the Gram's summation order; f16x2: 0.83-1.28 x, the same mask without delta1 [87]: 1.06 x -- outside; bf16x3: 0.25 x at 198 us)
 #   explicit    f16x2d   c5 (DenoisingAutoencoderTriplet: three row blocks, no miner): see AUTO_BY_STRATEGY's test
 AUTO_BY_STRATEGY = {"none": "f16x2d", "batch_all": "f16x2h", "batch_hard": "f16x2h", "explicit": "f16x2d"}
 AUTO_PRECISION = AUTO_BY_STRATEGY["batch_all"]      # (the bench headline config c2 is batch_all)

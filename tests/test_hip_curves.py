@@ -13,7 +13,7 @@ same regenerated inputs, reference-exact legacy RNG stream, injected W0.
                                          (this repo's exact-fp32 MFMA mode measures 8.9e-5 / 1.8e-4): steps 1-4 are held to the north star's 1e-4, the
                                          rest to an ORACLE-DERIVED envelope (c3_gate below: 25 oracle runs, one-ulp and summation-order families; round 5
                                          had hand-sized tail gates here).  precision='auto' resolves to f16x2h for batch_hard too: the cheapest mode well inside
-                                         that envelope (f16x2 1.28 x the gate, the same mask without delta1 1.06 x: outside; f16x2h 0.29 x, bf16x3 0.25 x, f16x3 0.32 x, fp32 0.17 x)
+                                         that envelope (f16x2 0.83-1.28 x the gate depending on the Gram's summation order, the same mask without delta1 1.06 x: outside; f16x2h 0.29-0.40 x, bf16x3 0.25 x, f16x3 0.32 x, fp32 0.17 x)
   c4  dense tf-idf ndarray, F = 50000   (N = 1600 rows: 10 epochs of 2 steps)
   c5  explicit triplets, cosine loss    (autoencoder_triplet.py:296-314)"""
 import os

@@ -1,9 +1,5 @@
 #!/bin/bash
-# round 6: s_setprio(2) around the MFMA groups of the x3 decode loop -- A/B against HEAD is the previous call's numbers; here: kprof x 3 with the seg walk as the same-box yardstick
-mkdir -p gpurun_out/r06c42
-O=gpurun_out/r06c42
-for i in 1 2 3; do
-timeout 300 python tools/kprof.py --precision f16x2h --opt decode_x3=0 --tag seg3 2>/dev/null | grep "==\|decode_loss" | cut -c1-130 >> $O/kprof_ab.txt
-timeout 300 python tools/kprof.py --precision f16x2h --opt decode_x3=1 --tag x3prio 2>/dev/null | grep "==\|decode_loss" | cut -c1-130 >> $O/kprof_ab.txt
-done
-cat $O/kprof_ab.txt
+# round 6: the c3 envelope ratios of the modes at the final HEAD (the fused-stage Gram changes D's low bits in every split mode)
+mkdir -p gpurun_out/r06c43
+timeout 900 python tools/curve_modes.py --config c3 --modes fp32,bf16x3,f16x2h,f16x3,f16x2,f16x2:87 --time > gpurun_out/r06c43/curve_c3.txt 2>&1
+grep -h "^\[\|Error" gpurun_out/r06c43/curve_c3.txt | sed 's/; ae max[^;]*;/;/'
