@@ -22,7 +22,8 @@ reduce-scatter the W gradient, run the optimizer on their row chunk, all-gather 
 (dp.ShardedExchange); mining is per rank (SURVEY 8e mode ii).
 
 Prints ONE JSON line (rank 0).  `kernels` / `roofline` come from HIP events recorded on the step's stream around each kernel
-(dae_plan_profile), in a second pass so that `value` is never measured with profiling on; `fit` is the same workload through
+(dae_plan_profile mode 3: the pairs are handed to hipExtLaunchKernelGGL and carry each dispatch's own begin / end; launches and steps run
+back to back), in a second pass so that `value` is never measured with profiling on; `fit` is the same workload through
 DenoisingAutoencoder.fit() (N * timed epochs / wall, first epoch excluded); `cpu_baseline` times the PyTorch-CPU fp32
 restatement of the reference step (oracle/torch_baseline.py; TF 1.12 cannot run here) on a bounded sample.
 """
@@ -101,6 +102,11 @@ def parse():
                          "(dae_dp_exchange), torch = torch.distributed's process group; auto = native over the nccl backend")
     ap.add_argument("--prewarm", type=float, default=0.25, help="seconds of untimed steps of the same loop before the W warm-up steps (clock ramp of a fresh process); 0 = none")
     ap.add_argument("--profile-steps", type=int, default=20)
+    ap.add_argument("--profile-mode", default="stamps", choices=["stamps", "queued", "sync"],
+                    help="how the per-kernel HIP events are taken (dae_plan_profile): stamps = event pairs stamped by the dispatch itself "
+                         "(hipExtLaunchKernelGGL: the kernel's own begin / end, what rocprofv3 reports; launches and steps run back to back); "
+                         "queued = hipEventRecord pairs around every launch, read once the pool fills (+ the two marker packets per kernel); "
+                         "sync = the same with a host wait behind every launch (the form of rounds 1-6: each launch starts on an idle device)")
     ap.add_argument("--fit-epochs", type=int, default=6)
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="code-path choice of the plan for A/B measurements (dae_plan_set_option), e.g. --option overlap=1")
@@ -651,7 +657,7 @@ def main():
     _log("timed region done: %.1f us/step" % (1e6 * dt / a.steps))
     if rank == 0 and not a.no_roofline:
         eng = run.eng
-        eng.profile(True)
+        eng.profile(True, queued=a.profile_mode == "queued", stamps=a.profile_mode == "stamps")
         for s in range(a.profile_steps):
             if world == 1:
                 run.step()
@@ -673,6 +679,10 @@ def main():
             e["frac"] = e["achieved"] / e["peak"]
         out["kernels"] = kern
         out["profiled_step_us"] = step_us
+        out["kernel_timing"] = {"stamps": "HIP event pairs handed to hipExtLaunchKernelGGL on the step's stream: each pair carries its dispatch's own begin / end "
+                                          "(no marker packets, no host wait between launches or steps; dae_plan_profile mode 3) -- comparable with rocprofv3 --kernel-trace",
+                                "queued": "hipEventRecord pairs around every launch on the step's stream, read when the pool fills (dae_plan_profile mode 2): kernel + two markers",
+                                "sync": "hipEventRecord pairs around every launch on the step's stream, host wait behind every launch (dae_plan_profile mode 1)"}[a.profile_mode]
         # whole-step rooflines (dense accounting of the north star): 10*B*F*H FLOP and SURVEY 8(d)'s minimum HBM bytes per step
         B, F = c["batch"] * (3 if c["strategy"] == "explicit" else 1), c["features"]
         es = 2 if a.precision != "fp32" else 4

@@ -9,6 +9,7 @@
 namespace dae {
 
 static thread_local char g_err[1024] = "";
+thread_local LaunchTimer g_lt = {nullptr, nullptr, nullptr, 0, 0, false};
 void set_error(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -97,6 +98,14 @@ static const char* const kProfNames[PS_COUNT] = {"memset_xct", "gather", "encode
 struct dae_plan {
     bool prof;
     hipEvent_t ev0, ev1;
+    // profile mode 2 (queued): one event pair per launch taken from this pool, the host never waits between launches; the pairs are read
+    // when the pool cannot hold another step and by dae_plan_profile_read -- kernels and steps run back to back as they do un-profiled
+    enum { PROF_POOL = 256, PROF_STEP_MAX = 48 };
+    bool prof_queued;
+    bool prof_stamps;                 // profile mode 3: the pairs carry the dispatches' own begin / end timestamps (DAE_LAUNCH, dae_common.h)
+    int pev_used;
+    hipEvent_t pev[PROF_POOL];
+    int pev_slot[PROF_POOL / 2];
     // second stream for the miner chain (gram -> sweep -> finalize -> sym_scale): with batch_all the row weights
     // depend on the labels only, so the chain is independent of the decode GEMM and runs beside it
     hipStream_t side;
@@ -343,6 +352,7 @@ extern "C" void dae_plan_destroy(dae_plan* p) {
     if (!p) return;
     if (p->ev0) (void)hipEventDestroy(p->ev0);
     if (p->ev1) (void)hipEventDestroy(p->ev1);
+    for (int i = 0; i < dae_plan::PROF_POOL; ++i) if (p->pev[i]) (void)hipEventDestroy(p->pev[i]);
     if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
     if (p->ev_join) (void)hipEventDestroy(p->ev_join);
     if (p->ev_dw) (void)hipEventDestroy(p->ev_dw);
@@ -425,19 +435,27 @@ extern "C" int dae_plan_set_option(dae_plan* p, const char* name, int32_t value)
     return 0;
 }
 
+static int prof_flush(dae_plan* p);
 extern "C" int dae_plan_profile(dae_plan* p, int32_t enable) {
     DAE_CHECK_ARG(p, "plan_profile: null plan");
     if (enable && !p->ev0) {
         DAE_CHECK_HIP(hipEventCreate(&p->ev0));
         DAE_CHECK_HIP(hipEventCreate(&p->ev1));
     }
+    if (p->pev_used) { if (int rf = prof_flush(p)) return rf; }
+    if ((enable == 2 || enable == 3) && !p->pev[0])
+        for (int i = 0; i < dae_plan::PROF_POOL; ++i) DAE_CHECK_HIP(hipEventCreate(&p->pev[i]));
     if (enable) { memset(p->prof_ms, 0, sizeof(p->prof_ms)); memset(p->prof_n, 0, sizeof(p->prof_n)); }
     p->prof = enable != 0;
+    p->prof_queued = enable == 2 || enable == 3;
+    p->prof_stamps = enable == 3;
+    p->pev_used = 0;
     return 0;
 }
 
 extern "C" int dae_plan_profile_read(const dae_plan* p, int32_t max_slots, double* ms_total, int32_t* counts) {
     DAE_CHECK_ARG(p && ms_total && counts, "plan_profile_read: null argument");
+    if (int rf = prof_flush(const_cast<dae_plan*>(p))) return rf;
     for (int i = 0; i < PS_COUNT && i < max_slots; ++i) { ms_total[i] = p->prof_ms[i]; counts[i] = p->prof_n[i]; }
     return PS_COUNT <= max_slots ? 0 : 1;
 }
@@ -532,9 +550,19 @@ static int launch_gram(dae_plan* p, int Bp, int Hp, int64_t dslab, hipStream_t s
 // elapsed GPU time of that slot (costs a host sync per call, so it is never on when throughput is measured).
 #define PROF(slot, expr)                                                            \
     do {                                                                            \
-        if (p->prof) DAE_CHECK_HIP(hipEventRecord(p->ev0, st));                     \
-        RC(expr);                                                                   \
-        if (p->prof) {                                                              \
+        const bool q__ = p->prof && p->prof_queued && p->pev_used + 2 <= dae_plan::PROF_POOL; \
+        const bool k__ = q__ && p->prof_stamps && (slot) != PS_MEMSET;              \
+        if (k__) g_lt = LaunchTimer{p->pev, &p->pev_used, p->pev_slot, dae_plan::PROF_POOL, (slot), true}; \
+        else if (q__) DAE_CHECK_HIP(hipEventRecord(p->pev[p->pev_used], st));       \
+        else if (p->prof) DAE_CHECK_HIP(hipEventRecord(p->ev0, st));                \
+        const int rc_prof__ = (expr);                                               \
+        if (k__) g_lt.pool = nullptr;                                               \
+        if (rc_prof__) return rc_prof__;                                            \
+        if (k__) {                                                                  \
+        } else if (q__) {                                                           \
+            DAE_CHECK_HIP(hipEventRecord(p->pev[p->pev_used + 1], st));             \
+            p->pev_slot[p->pev_used / 2] = (slot) | 0x100; p->pev_used += 2;        \
+        } else if (p->prof) {                                                       \
             DAE_CHECK_HIP(hipEventRecord(p->ev1, st));                              \
             DAE_CHECK_HIP(hipEventSynchronize(p->ev1));                             \
             float ms__ = 0.f;                                                       \
@@ -542,12 +570,31 @@ static int launch_gram(dae_plan* p, int Bp, int Hp, int64_t dslab, hipStream_t s
             p->prof_ms[slot] += ms__; p->prof_n[slot] += 1;                         \
         }                                                                           \
     } while (0)
+// queued profile mode: wait for the step's last pair, then add every pair to its slot
+static int prof_flush(dae_plan* p) {
+    if (!p->prof_queued || p->pev_used == 0) return 0;
+    DAE_CHECK_HIP(hipEventSynchronize(p->pev[p->pev_used - 1]));
+    for (int i = 0; i < p->pev_used; i += 2) {
+        float ms = 0.f;
+        DAE_CHECK_HIP(hipEventElapsedTime(&ms, p->pev[i], p->pev[i + 1]));
+        const int sl = p->pev_slot[i / 2] & 0xff;          // bit 8: the first launch of its PROF call (a call with several launches counts once)
+        p->prof_ms[sl] += ms; p->prof_n[sl] += (p->pev_slot[i / 2] >> 8) & 1;
+    }
+    p->pev_used = 0;
+    return 0;
+}
 static int memset_async(void* ptr, size_t bytes, hipStream_t st) {
     DAE_CHECK_HIP(hipMemsetAsync(ptr, 0, bytes, st));
     return 0;
 }
 
+static int train_step_body(dae_plan* p, const dae_step* s, void* stream);
 extern "C" int dae_train_step(dae_plan* p, const dae_step* s, void* stream) {
+    const int rc = train_step_body(p, s, stream);
+    if (p && p->prof_queued && p->pev_used + dae_plan::PROF_STEP_MAX > dae_plan::PROF_POOL) { const int rf = prof_flush(p); return rc ? rc : rf; }
+    return rc;
+}
+static int train_step_body(dae_plan* p, const dae_step* s, void* stream) {
     DAE_CHECK_ARG(p && p->bound && s, "train_step: plan not bound / null step");
     DAE_CHECK_ARG(s->row_idx && s->B > 0 && s->B <= p->Bmax, "train_step: batch %d outside (0, %d]", s ? s->B : -1, p->Bmax);
     const dae_config& c = p->cfg;

@@ -1,6 +1,7 @@
 // dae_common.h -- shared device helpers for the gfx950 DAE kernels.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -34,6 +35,30 @@ void set_error(const char* fmt, ...);
         }                                                                                      \
     } while (0)
 #define DAE_CHECK_LAUNCH() DAE_CHECK_HIP(hipGetLastError())
+
+// ---- kernel launches ----
+// Every kernel of the library is launched through DAE_LAUNCH.  Normally that is hipLaunchKernelGGL.  While dae_train_step runs in profile
+// mode 3 (dae_plan_profile, "kernel timestamps") the launch takes an event pair from the plan's pool and goes through hipExtLaunchKernelGGL,
+// which stamps the pair with the dispatch's OWN begin / end times -- what rocprofv3 --kernel-trace reports -- instead of the times of marker
+// packets around it; nothing is added to the stream and the host never waits between launches.
+struct LaunchTimer {
+    hipEvent_t* pool; int* used; int* slots; int cap;   // the plan's event pool (pairs), pairs handed out so far, slot of every pair
+    int slot; bool first;                                 // slot of the PROF call being executed; its first launch carries the call count
+};
+extern thread_local LaunchTimer g_lt;
+inline bool launch_timer_take(hipEvent_t& e0, hipEvent_t& e1) {
+    LaunchTimer& t = g_lt;
+    if (!t.pool || *t.used + 2 > t.cap) return false;
+    e0 = t.pool[*t.used]; e1 = t.pool[*t.used + 1];
+    t.slots[*t.used / 2] = t.slot | (t.first ? 0x100 : 0); t.first = false; *t.used += 2;
+    return true;
+}
+#define DAE_LAUNCH(kernel, grid, block, lds, st, ...)                                                              \
+    do {                                                                                                           \
+        hipEvent_t lt0__, lt1__;                                                                                   \
+        if (dae::launch_timer_take(lt0__, lt1__)) hipExtLaunchKernelGGL(kernel, grid, block, lds, st, lt0__, lt1__, 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                                        \
+    } while (0)
 
 // ---- the library's 16-bit storage format ----
 // Every 16-bit operand image (W shadows, h, x~^T, delta2, delta1, Gs, Gram operands) is written and read through the helpers below, and the

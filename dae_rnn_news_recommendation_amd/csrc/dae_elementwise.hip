@@ -627,10 +627,10 @@ int dae::launch_encode_finish(const float* slabs, int32_t splits, int64_t slab_s
     const int Bp = (int)dae_pad(B), Hp = (int)dae_pad(H);
     dim3 grid(Hp / 64, Bp / 32), block(256);
     if (dtype == DAE_BF16)
-        hipLaunchKernelGGL((encode_finish_kernel<bf16_t>), grid, block, 0, ST(stream), slabs, splits, slab_stride, ld_slab, bh, B,
+        DAE_LAUNCH((encode_finish_kernel<bf16_t>), grid, block, 0, ST(stream), slabs, splits, slab_stride, ld_slab, bh, B,
                            H, enc_act, h_f32, (bf16_t*)h_lo, ldh, (bf16_t*)h_t, ldht, (bf16_t*)hcat_a, (bf16_t*)hcat_b, Hp, (bf16_t*)h_t2);
     else
-        hipLaunchKernelGGL((encode_finish_kernel<float>), grid, block, 0, ST(stream), slabs, splits, slab_stride, ld_slab, bh, B,
+        DAE_LAUNCH((encode_finish_kernel<float>), grid, block, 0, ST(stream), slabs, splits, slab_stride, ld_slab, bh, B,
                            H, enc_act, h_f32, (float*)h_lo, ldh, (float*)h_t, ldht, (bf16_t*)hcat_a, (bf16_t*)hcat_b, Hp, (float*)nullptr);
     DAE_CHECK_LAUNCH();
     return 0;
@@ -650,11 +650,11 @@ int dae::launch_dh_finish(const float* slabs, int splits, int64_t slab_stride, i
     const int Bp = (int)dae_pad(B), Hp = (int)dae_pad(H);
     dim3 grid(Hp / 64, Bp / 32), block(DHF_THREADS);
     if (dtype == DAE_BF16)
-        hipLaunchKernelGGL((dh_finish_kernel<bf16_t>), grid, block, 0, st, slabs, splits, slab_stride, ld_slab, dh_extra,
+        DAE_LAUNCH((dh_finish_kernel<bf16_t>), grid, block, 0, st, slabs, splits, slab_stride, ld_slab, dh_extra,
                            h_f32, ldh, bh, B, H, enc_act, (bf16_t*)delta1_t, ldt, colsum_part, Hp, delta1_f32, (bf16_t*)delta1_lo, (bf16_t*)delta1_t2,
                            in_scale, out_scale);
     else
-        hipLaunchKernelGGL((dh_finish_kernel<float>), grid, block, 0, st, slabs, splits, slab_stride, ld_slab, dh_extra,
+        DAE_LAUNCH((dh_finish_kernel<float>), grid, block, 0, st, slabs, splits, slab_stride, ld_slab, dh_extra,
                            h_f32, ldh, bh, B, H, enc_act, (float*)delta1_t, ldt, colsum_part, Hp, delta1_f32, (float*)delta1_lo, (float*)nullptr, in_scale, 1.f);
     DAE_CHECK_LAUNCH();
     return 0;
@@ -671,9 +671,9 @@ int dae::launch_sym_scale(const float* G, int B, int Bp, const float* tri_scalar
     DAE_CHECK_ARG(G && tri_scalars && Gs && Bp % DAE_PAD == 0 && B <= Bp, "sym_scale: bad args");
     dim3 grid(Bp / 64, Bp / 64), block(256);
     if (dtype == DAE_BF16)
-        hipLaunchKernelGGL((sym_scale_kernel<bf16_t>), grid, block, 0, st, G, B, Bp, tri_scalars, (bf16_t*)Gs, mul);
+        DAE_LAUNCH((sym_scale_kernel<bf16_t>), grid, block, 0, st, G, B, Bp, tri_scalars, (bf16_t*)Gs, mul);
     else
-        hipLaunchKernelGGL((sym_scale_kernel<float>), grid, block, 0, st, G, B, Bp, tri_scalars, (float*)Gs, mul);
+        DAE_LAUNCH((sym_scale_kernel<float>), grid, block, 0, st, G, B, Bp, tri_scalars, (float*)Gs, mul);
     DAE_CHECK_LAUNCH();
     return 0;
 }
@@ -689,18 +689,18 @@ extern "C" int dae_label_stats(const int32_t* labels, int32_t B, int32_t Bp, int
     DAE_CHECK_ARG(triplet == DAE_TRIPLET_NONE || labels, "label_stats: labels required");
     if (Bp <= 1024) {
         LabelJob j{labels, B, Bp, triplet, nvalid_out, dw_out, cw, alpha, tri_scalars};
-        hipLaunchKernelGGL(label_stats_small_kernel, dim3(1), dim3(1024), 0, ST(stream), j);
+        DAE_LAUNCH(label_stats_small_kernel, dim3(1), dim3(1024), 0, ST(stream), j);
         DAE_CHECK_LAUNCH();
         return 0;
     }
     if (triplet != DAE_TRIPLET_NONE) {
         DAE_CHECK_ARG(labels && n_same_scratch && acc_scratch, "label_stats: labels/scratch required");
         DAE_CHECK_HIP(hipMemsetAsync(acc_scratch, 0, 2 * sizeof(uint64_t), ST(stream)));
-        hipLaunchKernelGGL(label_count_kernel, dim3((B + 255) / 256), dim3(256), 0, ST(stream), labels, B, n_same_scratch,
+        DAE_LAUNCH(label_count_kernel, dim3((B + 255) / 256), dim3(256), 0, ST(stream), labels, B, n_same_scratch,
                            (unsigned long long*)acc_scratch);
         DAE_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(label_weight_kernel, dim3((Bp + 255) / 256), dim3(256), 0, ST(stream), n_same_scratch, B, Bp, triplet,
+    DAE_LAUNCH(label_weight_kernel, dim3((Bp + 255) / 256), dim3(256), 0, ST(stream), n_same_scratch, B, Bp, triplet,
                        (const unsigned long long*)acc_scratch, nvalid_out, dw_out, cw, alpha, tri_scalars);
     DAE_CHECK_LAUNCH();
     return 0;
@@ -715,7 +715,7 @@ extern "C" int dae_triplet_finalize(int32_t triplet, int32_t pos_only, int32_t B
     DAE_CHECK_ARG(triplet != DAE_TRIPLET_BATCH_ALL || nvalid, "triplet_finalize: nvalid required");
     if (triplet == DAE_TRIPLET_BATCH_HARD) DAE_CHECK_ARG(dw_i32 && dw_f32_out && cw, "triplet_finalize: dw buffers required");
     if (triplet == DAE_TRIPLET_BATCH_ALL && pos_only) DAE_CHECK_ARG(role_cnt && dw_f32_out && cw, "triplet_finalize: role_cnt required");
-    hipLaunchKernelGGL(triplet_finalize_kernel, dim3(1), dim3(1024), 0, ST(stream), triplet, pos_only, B, Bp, alpha, loss_part,
+    DAE_LAUNCH(triplet_finalize_kernel, dim3(1), dim3(1024), 0, ST(stream), triplet, pos_only, B, Bp, alpha, loss_part,
                        cnt_part, nvalid, dw_i32, role_cnt, dw_f32_out, cw, tri_scalars);
     DAE_CHECK_LAUNCH();
     return 0;
@@ -724,7 +724,7 @@ extern "C" int dae_triplet_finalize(int32_t triplet, int32_t pos_only, int32_t B
 extern "C" int dae_cos_reduce(const float* cos_part, int32_t n_col_waves, int32_t B, int32_t Bp, float* cos_stats,
                               float* rowloss, void* stream) {
     DAE_CHECK_ARG(cos_part && cos_stats && rowloss, "cos_reduce: null input");
-    hipLaunchKernelGGL(cos_reduce_kernel, dim3((Bp + 63) / 64), dim3(256), 0, ST(stream), cos_part, n_col_waves, B, Bp,
+    DAE_LAUNCH(cos_reduce_kernel, dim3((Bp + 63) / 64), dim3(256), 0, ST(stream), cos_part, n_col_waves, B, Bp,
                        cos_stats, rowloss);
     DAE_CHECK_LAUNCH();
     return 0;
@@ -742,7 +742,7 @@ extern "C" int dae_bias_grads(const float* dbv_part, int32_t n_row_waves, const 
     }
     const int n = Fp + Hp;
     BiasArgs ba{dbv_part, n_row_waves, colsum_part, n_row_blocks, bh, H, Hp, F, Fp, enc_act, dbh, dbv, apply, opt, lr, momentum, grad_scale, bv, s1b, s2b};
-    hipLaunchKernelGGL(bias_grads_kernel, dim3((n + 255) / 256), dim3(256), 0, ST(stream), ba);
+    DAE_LAUNCH(bias_grads_kernel, dim3((n + 255) / 256), dim3(256), 0, ST(stream), ba);
     DAE_CHECK_LAUNCH();
     return 0;
 }
@@ -768,17 +768,17 @@ int dae::launch_opt_step(int opt, float lr, float momentum, float grad_scale, fl
     const int es = dtype == DAE_BF16 ? 2 : 4;
     auto rows = [&](void* q, int64_t off_elems) -> void* { return q ? (char*)q + off_elems * es : nullptr; };
     if (dtype == DAE_BF16)
-        hipLaunchKernelGGL((opt_w_kernel<bf16_t>), grid, block, 0, ST(stream), opt, lr, momentum, grad_scale, W + ro, grad ? grad + ro : nullptr,
+        DAE_LAUNCH((opt_w_kernel<bf16_t>), grid, block, 0, ST(stream), opt, lr, momentum, grad_scale, W + ro, grad ? grad + ro : nullptr,
                            s1 ? s1 + ro : nullptr, s2 ? s2 + ro : nullptr, Fp, Hp, (bf16_t*)rows(W_lo, ro), (bf16_t*)rows(Wt_lo, f0), apply,
                            (bf16_t*)rows(W_lo2, ro), (bf16_t*)rows(Wt_lo2, f0));
     else
-        hipLaunchKernelGGL((opt_w_kernel<float>), grid, block, 0, ST(stream), opt, lr, momentum, grad_scale, W + ro, grad ? grad + ro : nullptr,
+        DAE_LAUNCH((opt_w_kernel<float>), grid, block, 0, ST(stream), opt, lr, momentum, grad_scale, W + ro, grad ? grad + ro : nullptr,
                            s1 ? s1 + ro : nullptr, s2 ? s2 + ro : nullptr, Fp, Hp, (float*)rows(W_lo, ro), (float*)rows(Wt_lo, f0), apply,
                            (float*)nullptr, (float*)nullptr);
     DAE_CHECK_LAUNCH();
     if (apply && !skip_bias && f1 == Fp) {
         const int64_t off = (int64_t)Fp * Hp;
-        hipLaunchKernelGGL(opt_bias_kernel, dim3((Hp + Fp + 255) / 256), dim3(256), 0, ST(stream), opt, lr, momentum, grad_scale, bh,
+        DAE_LAUNCH(opt_bias_kernel, dim3((Hp + Fp + 255) / 256), dim3(256), 0, ST(stream), opt, lr, momentum, grad_scale, bh,
                            bv, grad + off, s1 ? s1 + off : nullptr, s2 ? s2 + off : nullptr, Hp, Fp);
         DAE_CHECK_LAUNCH();
     }
@@ -795,7 +795,7 @@ extern "C" int dae_opt_bias(int32_t opt, float lr, float momentum, float grad_sc
                             float* s2b, int32_t Hp, int32_t Fp, void* stream) {
     DAE_CHECK_ARG(bh && bv && grad_b && opt >= DAE_OPT_SGD && opt <= DAE_OPT_ADAM && (opt == DAE_OPT_SGD || s1b) && (opt != DAE_OPT_ADAM || s2b),
                   "opt_bias: bad args");
-    hipLaunchKernelGGL(opt_bias_kernel, dim3((Hp + Fp + 255) / 256), dim3(256), 0, ST(stream), opt, lr, momentum, grad_scale, bh, bv, grad_b, s1b, s2b, Hp, Fp);
+    DAE_LAUNCH(opt_bias_kernel, dim3((Hp + Fp + 255) / 256), dim3(256), 0, ST(stream), opt, lr, momentum, grad_scale, bh, bv, grad_b, s1b, s2b, Hp, Fp);
     DAE_CHECK_LAUNCH();
     return 0;
 }
@@ -811,10 +811,10 @@ extern "C" int dae_opt_step_rows(int32_t opt, float lr, float momentum, float gr
     const size_t es = dtype == DAE_BF16 ? 2 : 4;
     dim3 grid(Hp / 64, (f1 - f0) / 64), block(256);
     if (dtype == DAE_BF16)
-        hipLaunchKernelGGL((opt_w_kernel<bf16_t>), grid, block, 0, ST(stream), opt, lr, momentum, grad_scale, W + off, grad_rows, s1 ? s1 + off : nullptr,
+        DAE_LAUNCH((opt_w_kernel<bf16_t>), grid, block, 0, ST(stream), opt, lr, momentum, grad_scale, W + off, grad_rows, s1 ? s1 + off : nullptr,
                            s2 ? s2 + off : nullptr, 0, Hp, (bf16_t*)((char*)W_lo + off * es), (bf16_t*)nullptr, 1, (bf16_t*)nullptr, (bf16_t*)nullptr);
     else
-        hipLaunchKernelGGL((opt_w_kernel<float>), grid, block, 0, ST(stream), opt, lr, momentum, grad_scale, W + off, grad_rows, s1 ? s1 + off : nullptr,
+        DAE_LAUNCH((opt_w_kernel<float>), grid, block, 0, ST(stream), opt, lr, momentum, grad_scale, W + off, grad_rows, s1 ? s1 + off : nullptr,
                            s2 ? s2 + off : nullptr, 0, Hp, (float*)((char*)W_lo + off * es), (float*)nullptr, 1, (float*)nullptr, (float*)nullptr);
     DAE_CHECK_LAUNCH();
     return 0;
@@ -830,10 +830,10 @@ extern "C" int dae_dp_unpack(const void* recv, int32_t world, int32_t chunk_rows
     const int gx = Hp / 64, nb = (Hp + Fp + 255) / 256;
     dim3 grid(gx, Fp / 64 + (nb + gx - 1) / gx), block(256);
     if (dtype == DAE_BF16)
-        hipLaunchKernelGGL((dp_unpack_kernel<bf16_t>), grid, block, 0, ST(stream), (const char*)recv, world, chunk_rows, chunk_stride_bytes, bias_off_bytes,
+        DAE_LAUNCH((dp_unpack_kernel<bf16_t>), grid, block, 0, ST(stream), (const char*)recv, world, chunk_rows, chunk_stride_bytes, bias_off_bytes,
                            Fp, Hp, (bf16_t*)W_lo, (bf16_t*)Wt_lo, opt, lr, momentum, grad_scale, bh, bv, s1b, s2b, grad_b);
     else
-        hipLaunchKernelGGL((dp_unpack_kernel<float>), grid, block, 0, ST(stream), (const char*)recv, world, chunk_rows, chunk_stride_bytes, bias_off_bytes,
+        DAE_LAUNCH((dp_unpack_kernel<float>), grid, block, 0, ST(stream), (const char*)recv, world, chunk_rows, chunk_stride_bytes, bias_off_bytes,
                            Fp, Hp, (float*)W_lo, (float*)Wt_lo, opt, lr, momentum, grad_scale, bh, bv, s1b, s2b, grad_b);
     DAE_CHECK_LAUNCH();
     return 0;
@@ -842,8 +842,8 @@ extern "C" int dae_dp_unpack(const void* recv, int32_t world, int32_t chunk_rows
 extern "C" int dae_transpose_shadow(const void* W_lo, int32_t Fp, int32_t Hp, int32_t dtype, void* Wt_lo, void* stream) {
     DAE_CHECK_ARG(W_lo && Wt_lo && Fp % 64 == 0 && Hp % 64 == 0, "transpose_shadow: bad args");
     dim3 grid(Hp / 64, Fp / 64), block(256);
-    if (dtype == DAE_BF16) hipLaunchKernelGGL((transpose_lo_kernel<bf16_t>), grid, block, 0, ST(stream), (const bf16_t*)W_lo, Fp, Hp, (bf16_t*)Wt_lo);
-    else hipLaunchKernelGGL((transpose_lo_kernel<float>), grid, block, 0, ST(stream), (const float*)W_lo, Fp, Hp, (float*)Wt_lo);
+    if (dtype == DAE_BF16) DAE_LAUNCH((transpose_lo_kernel<bf16_t>), grid, block, 0, ST(stream), (const bf16_t*)W_lo, Fp, Hp, (bf16_t*)Wt_lo);
+    else DAE_LAUNCH((transpose_lo_kernel<float>), grid, block, 0, ST(stream), (const float*)W_lo, Fp, Hp, (float*)Wt_lo);
     DAE_CHECK_LAUNCH();
     return 0;
 }
@@ -856,7 +856,7 @@ extern "C" int dae_step_stats(const float* rowloss_part, int32_t n_col_waves, co
     DAE_CHECK_ARG(triplet == DAE_TRIPLET_NONE || tri_scalars || loss_part, "step_stats: tri_scalars or miner partials required");
     DAE_CHECK_ARG(!loss_part || (cnt_part && nvalid && triplet == DAE_TRIPLET_BATCH_ALL), "step_stats: miner partials need cnt_part + nvalid");
     StatsArgs sa{rowloss_part, n_col_waves, tile_part, n_tiles, cw, B, Bp, triplet, alpha, tri_scalars, nvalid, stats, loss_part, cnt_part};
-    hipLaunchKernelGGL(step_stats_kernel, dim3(1), dim3(1024), 0, ST(stream), sa);
+    DAE_LAUNCH(step_stats_kernel, dim3(1), dim3(1024), 0, ST(stream), sa);
     DAE_CHECK_LAUNCH();
     return 0;
 }
@@ -873,7 +873,7 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
 }  // namespace dae
 int dae::launch_cast_bf16(const float* src, void* dst_bf16, int64_t n, hipStream_t st) {
     DAE_CHECK_ARG(src && dst_bf16 && n % 4 == 0, "cast_bf16: bad args");
-    hipLaunchKernelGGL(cast_bf16_kernel, dim3(2048), dim3(256), 0, st, src, (bf16_t*)dst_bf16, n / 4);
+    DAE_LAUNCH(cast_bf16_kernel, dim3(2048), dim3(256), 0, st, src, (bf16_t*)dst_bf16, n / 4);
     DAE_CHECK_LAUNCH();
     return 0;
 }
@@ -884,7 +884,7 @@ int dae::launch_step_tail(const BiasArgs& ba, const StatsArgs* sa, const ClearAr
     const int nclear = ca ? (ca->B + 3) / 4 : 0;
     StatsArgs s0; memset(&s0, 0, sizeof(s0));
     ClearArgs c0; memset(&c0, 0, sizeof(c0));
-    hipLaunchKernelGGL(step_tail_kernel, dim3(nb_bias + 1 + nclear), dim3(256), 0, st, ba, sa ? *sa : s0, ca ? *ca : c0, nb_bias, sa ? 1 : 0);
+    DAE_LAUNCH(step_tail_kernel, dim3(nb_bias + 1 + nclear), dim3(256), 0, st, ba, sa ? *sa : s0, ca ? *ca : c0, nb_bias, sa ? 1 : 0);
     DAE_CHECK_LAUNCH();
     return 0;
 }
@@ -892,9 +892,9 @@ int dae::launch_step_tail(const BiasArgs& ba, const StatsArgs* sa, const ClearAr
 extern "C" int dae_explicit_triplet(const float* h3, int64_t ldh, int32_t B, int32_t H, float alpha, float* dh3,
                                     float* loss_part, float* tri_scalars, void* stream) {
     DAE_CHECK_ARG(h3 && dh3 && loss_part && tri_scalars && B > 0, "explicit_triplet: bad args");
-    hipLaunchKernelGGL(explicit_triplet_kernel, dim3((B + 3) / 4), dim3(256), 0, ST(stream), h3, ldh, B, H, alpha, dh3, loss_part);
+    DAE_LAUNCH(explicit_triplet_kernel, dim3((B + 3) / 4), dim3(256), 0, ST(stream), h3, ldh, B, H, alpha, dh3, loss_part);
     DAE_CHECK_LAUNCH();
-    hipLaunchKernelGGL(explicit_triplet_finalize_kernel, dim3(1), dim3(1024), 0, ST(stream), loss_part, B, tri_scalars);
+    DAE_LAUNCH(explicit_triplet_finalize_kernel, dim3(1), dim3(1024), 0, ST(stream), loss_part, B, tri_scalars);
     DAE_CHECK_LAUNCH();
     return 0;
 }
@@ -940,7 +940,7 @@ extern "C" int dae_weighted_loss_rows(const float* x, int64_t ldx, const float* 
                                       int32_t loss_func, float* rowloss, void* stream) {
     DAE_CHECK_ARG(x && y && rowloss && B > 0 && F > 0, "weighted_loss_rows: bad args");
     DAE_CHECK_ARG(loss_func >= DAE_LOSS_CROSS_ENTROPY && loss_func <= DAE_LOSS_COSINE, "weighted_loss_rows: unknown loss");
-    hipLaunchKernelGGL(dae::weighted_loss_rows_kernel, dim3(B), dim3(256), 0, ST(stream), x, ldx, y, ldy, F, loss_func, rowloss);
+    DAE_LAUNCH(dae::weighted_loss_rows_kernel, dim3(B), dim3(256), 0, ST(stream), x, ldx, y, ldy, F, loss_func, rowloss);
     DAE_CHECK_LAUNCH();
     return 0;
 }

@@ -612,11 +612,11 @@ int dae::launch_gather_csr(const int64_t* indptr, const int32_t* indices, const 
     if (label_job) job = *label_job;
     const int label_slice = label_job ? (int)chunks : -1;
     if (dtype == DAE_BF16)
-        hipLaunchKernelGGL((gather_csr_kernel<bf16_t>), grid, block, 0, st, indptr, indices, values, row_idx, B, F,
+        DAE_LAUNCH((gather_csr_kernel<bf16_t>), grid, block, 0, st, indptr, indices, values, row_idx, B, F,
                            (bf16_t*)x, (bf16_t*)xc, ldx, (bf16_t*)xct, ldt, rowsq, corr_mode, keep_bits, seed, rng_stream,
                            corr_frac, scale, xc_bits, ldw, job, label_slice, x_bits, (bf16_t*)x2);
     else
-        hipLaunchKernelGGL((gather_csr_kernel<float>), grid, block, 0, st, indptr, indices, values, row_idx, B, F,
+        DAE_LAUNCH((gather_csr_kernel<float>), grid, block, 0, st, indptr, indices, values, row_idx, B, F,
                            (float*)x, (float*)xc, ldx, (float*)xct, ldt, rowsq, corr_mode, keep_bits, seed, rng_stream,
                            corr_frac, scale, xc_bits, ldw, job, label_slice, x_bits, (float*)nullptr);
     DAE_CHECK_LAUNCH();
@@ -666,11 +666,11 @@ int dae::launch_encode_csr(const EncCsrLaunch& q, hipStream_t st) {
     dim3 grid(nblk + (q.label_job ? 1 : 0)), block(ENC_THREADS);
     // weight image: the low-precision shadow W_lo of the activation type, or -- w_f32, bf16 activations -- the fp32 master
     if (q.dtype == DAE_BF16) {
-        if (!q.w_f32) hipLaunchKernelGGL((encode_csr_kernel<bf16_t, bf16_t, 128>), grid, block, lds, st, a);
-        else if (cols == 64) hipLaunchKernelGGL((encode_csr_kernel<float, bf16_t, 64>), grid, block, lds, st, a);
-        else hipLaunchKernelGGL((encode_csr_kernel<float, bf16_t, 128>), grid, block, lds, st, a);
+        if (!q.w_f32) DAE_LAUNCH((encode_csr_kernel<bf16_t, bf16_t, 128>), grid, block, lds, st, a);
+        else if (cols == 64) DAE_LAUNCH((encode_csr_kernel<float, bf16_t, 64>), grid, block, lds, st, a);
+        else DAE_LAUNCH((encode_csr_kernel<float, bf16_t, 128>), grid, block, lds, st, a);
     } else {
-        hipLaunchKernelGGL((encode_csr_kernel<float, float, 128>), grid, block, lds, st, a);
+        DAE_LAUNCH((encode_csr_kernel<float, float, 128>), grid, block, lds, st, a);
     }
     DAE_CHECK_LAUNCH();
     return 0;
@@ -700,7 +700,7 @@ extern "C" int dae_salt_pepper_batch(const int64_t* indptr, const int32_t* indic
     DAE_CHECK_ARG(lds <= 150 * 1024, "salt_pepper_batch: %d features need %zu B of LDS", F, lds);
     static int attr_rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(salt_pepper_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     DAE_CHECK_ARG(attr_rc == 0, "salt_pepper_batch: hipFuncSetAttribute failed");
-    hipLaunchKernelGGL(salt_pepper_kernel, dim3(B), dim3(SP_THREADS), lds, (hipStream_t)stream, indptr, indices, values, row_idx, F, v, lo, hi,
+    DAE_LAUNCH(salt_pepper_kernel, dim3(B), dim3(SP_THREADS), lds, (hipStream_t)stream, indptr, indices, values, row_idx, F, v, lo, hi,
                        seed, rng_stream, out_span, out_indices, out_values, cap);
     DAE_CHECK_LAUNCH();
     return 0;
@@ -747,7 +747,7 @@ int dae::launch_gather_dense(const float* data, int64_t ld_data, const int32_t* 
         static int attr_rc = ldsb > 64 * 1024 ? (int)hipFuncSetAttribute(reinterpret_cast<const void*>(gather_dense_kernel<TT, VV, TR_, TC_>),    \
                                                                          hipFuncAttributeMaxDynamicSharedMemorySize, ldsb) : 0;                   \
         DAE_CHECK_ARG(attr_rc == 0, "gather_dense: hipFuncSetAttribute failed");                                                                   \
-        hipLaunchKernelGGL((gather_dense_kernel<TT, VV, TR_, TC_>), grid, block, ldsb, st, data, ld_data, row_idx, B, F, (TT*)x, (TT*)xc, ldx,    \
+        DAE_LAUNCH((gather_dense_kernel<TT, VV, TR_, TC_>), grid, block, ldsb, st, data, ld_data, row_idx, B, F, (TT*)x, (TT*)xc, ldx,    \
                            (TT*)xct, ldt, part, corr_mode, keep_bits, seed, rng_stream, corr_frac, scale, res);                                        \
     } while (0)
 #define DAE_GD_T(TT, VV) do { switch (g_gather_tile & 3) { case 0: DAE_GD(TT, VV, 64, 64); break; case 1: DAE_GD(TT, VV, 64, 128); break; \
@@ -758,7 +758,7 @@ int dae::launch_gather_dense(const float* data, int64_t ld_data, const int32_t* 
 #undef DAE_GD
     DAE_CHECK_LAUNCH();
     if (rowsq) {
-        hipLaunchKernelGGL(rowsq_reduce_kernel, dim3((Bp + 255) / 256), dim3(256), 0, st, part, (int)grid.y, Bp, rowsq);
+        DAE_LAUNCH(rowsq_reduce_kernel, dim3((Bp + 255) / 256), dim3(256), 0, st, part, (int)grid.y, Bp, rowsq);
         DAE_CHECK_LAUNCH();
     }
     return 0;

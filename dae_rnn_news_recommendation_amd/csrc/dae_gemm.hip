@@ -1690,7 +1690,7 @@ int launch_gram64(const void* hcat_a, const void* hcat_b, int Bp, int Hp, float*
         static int rcf = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(gram64f_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G64F_LDS);
         DAE_CHECK_ARG(rcf == 0, "gram64: hipFuncSetAttribute failed");
         const int tiles = Bp / 64, per = (tiles * tiles + 7) / 8;
-        hipLaunchKernelGGL(gram64f_kernel, dim3(8 * per), dim3(GEMM_THREADS), G64F_LDS, st, (const char*)hcat_a, (const char*)hcat_a + (size_t)2 * Hp * 2,
+        DAE_LAUNCH(gram64f_kernel, dim3(8 * per), dim3(GEMM_THREADS), G64F_LDS, st, (const char*)hcat_a, (const char*)hcat_a + (size_t)2 * Hp * 2,
                            (int64_t)3 * Hp * 2, Hp * 2 / BKB, tiles, D, (int64_t)Bp);
         DAE_CHECK_LAUNCH();
         return 0;
@@ -1700,7 +1700,7 @@ int launch_gram64(const void* hcat_a, const void* hcat_b, int Bp, int Hp, float*
     static int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(gram64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G64_LDS);
     DAE_CHECK_ARG(rc == 0, "gram64: hipFuncSetAttribute failed");
     const int tiles = Bp / 64, per = (tiles * tiles + 7) / 8;
-    hipLaunchKernelGGL(gram64_kernel, dim3(8 * per), dim3(GEMM_THREADS), G64_LDS, st, (const char*)hcat_a, (int64_t)3 * Hp * 2, (const char*)hcat_b,
+    DAE_LAUNCH(gram64_kernel, dim3(8 * per), dim3(GEMM_THREADS), G64_LDS, st, (const char*)hcat_a, (int64_t)3 * Hp * 2, (const char*)hcat_b,
                        (int64_t)3 * Hp * 2, 3 * Hp * 2 / BKB, tiles, D, (int64_t)Bp);
     DAE_CHECK_LAUNCH();
     return 0;
@@ -3175,7 +3175,7 @@ int launch_gemm_f32out_n(int dtype, int M, int N, const GemmSegDesc* segs, int n
             return rc;
         }();
         DAE_CHECK_ARG(w8_attr_rc == 0, "gemm: hipFuncSetAttribute failed for the 256 x 256 kernel (%d)", w8_attr_rc);
-        hipLaunchKernelGGL(w8_kernel(role), dim3(q.tiles_m * q.tiles_n * ws), dim3(W8_THREADS), W8_LDS, st, q, C, ldc, slab_stride);
+        DAE_LAUNCH(w8_kernel(role), dim3(q.tiles_m * q.tiles_n * ws), dim3(W8_THREADS), W8_LDS, st, q, C, ldc, slab_stride);
         DAE_CHECK_LAUNCH();
         return 0;
     }
@@ -3189,14 +3189,14 @@ int launch_gemm_f32out_n(int dtype, int M, int N, const GemmSegDesc* segs, int n
         LabelJob job; memset(&job, 0, sizeof(job));
         const bool with_labels = label_job && label_job->Bp <= 1024 && (int)grid.x < g_cus;      // a CU must be free for it
         if (with_labels) job = *label_job;
-        hipLaunchKernelGGL(kp, dim3(grid.x + (with_labels ? 1 : 0)), dim3(PC_THREADS), lds_bytes_for(PC_NST), st, p, C, ldc, slab_stride, job,
+        DAE_LAUNCH(kp, dim3(grid.x + (with_labels ? 1 : 0)), dim3(PC_THREADS), lds_bytes_for(PC_NST), st, p, C, ldc, slab_stride, job,
                            with_labels ? (int)grid.x : -1);
         DAE_CHECK_LAUNCH();
         if (with_labels && label_done) *label_done = 1;
         return 0;
     }
     f32out_fn k = dtype == DAE_BF16 ? f32out_kernel<bf16_t>(nst, role) : f32out_kernel<float>(nst, role);
-    hipLaunchKernelGGL(k, grid, block, lds_bytes_for(nst == 0 || nst == 3 || nst == 4 ? nst : 2), st, p, C, ldc, slab_stride);
+    DAE_LAUNCH(k, grid, block, lds_bytes_for(nst == 0 || nst == 3 || nst == 4 ? nst : 2), st, p, C, ldc, slab_stride);
     DAE_CHECK_LAUNCH();
     return 0;
 }
@@ -3275,7 +3275,7 @@ int launch_dw_opt(int M, int N, const void* A0, int64_t lda0, const void* Bt0, i
                 xb.one = host_f2bf(xa->scale);                  // 16-bit image of the scale, round to nearest even (a finite positive factor)
                 q.seg[0].A = nullptr;
             }
-            hipLaunchKernelGGL(tra ? pcs_tr[e.opt] : pcs[xa ? 1 : 0][e.opt], dim3(8 * per * tiles_n), dim3(PC_THREADS), DW_LDS, st, q, e, M, xb);
+            DAE_LAUNCH(tra ? pcs_tr[e.opt] : pcs[xa ? 1 : 0][e.opt], dim3(8 * per * tiles_n), dim3(PC_THREADS), DW_LDS, st, q, e, M, xb);
             DAE_CHECK_LAUNCH();
             return 0;
         }
@@ -3292,7 +3292,7 @@ int launch_dw_opt(int M, int N, const void* A0, int64_t lda0, const void* Bt0, i
     DAE_CHECK_ARG(attr_rc == 0, "dw_opt: hipFuncSetAttribute failed");
     static_assert(DAE_OPT_SGD == 0 && DAE_OPT_ADAGRAD == 1 && DAE_OPT_MOMENTUM == 2 && DAE_OPT_ADAM == 3, "optimizer enum order");
     DAE_CHECK_ARG(!xa && !grad_only, "dw: this shape needs the dense x~^T image and the fused-optimizer form");
-    hipLaunchKernelGGL(fns[e.opt], dim3(grid_blocks(p)), dim3(GEMM_THREADS), ldsb, st, p, e);
+    DAE_LAUNCH(fns[e.opt], dim3(grid_blocks(p)), dim3(GEMM_THREADS), ldsb, st, p, e);
     DAE_CHECK_LAUNCH();
     return 0;
 }
@@ -3359,7 +3359,7 @@ int launch_dw_opt_n(int M, int N, const GemmSegDesc* segs_in, int nsegs_in, cons
     GemmParams q = p;
     q.tiles_m = tiles_m; q.tiles_n = tiles_n;
     DwBits xb; memset(&xb, 0, sizeof(xb));
-    hipLaunchKernelGGL(tra ? x3s_tr[e.opt] : x3s[any_pair ? 1 : 0][e.opt], dim3(8 * per * tiles_n), dim3(PC_THREADS), any_pair ? DW_RING2 : DW_LDS, st, q, e, M, xb);
+    DAE_LAUNCH(tra ? x3s_tr[e.opt] : x3s[any_pair ? 1 : 0][e.opt], dim3(8 * per * tiles_n), dim3(PC_THREADS), any_pair ? DW_RING2 : DW_LDS, st, q, e, M, xb);
     DAE_CHECK_LAUNCH();
     return 0;
 }
@@ -3461,7 +3461,7 @@ int launch_decode_loss_n(int dtype, int Bp, int Fp, const GemmSegDesc* segs, int
         const int tiles = p.tiles_m * p.tiles_n;
         int nwg = 2 * (g_cus > 0 ? g_cus : 256);          // two resident workgroups per CU
         if (nwg > tiles) nwg = tiles;
-        hipLaunchKernelGGL(ka, dim3(nwg), dim3(GEMM_THREADS), DecAst::LDS_BYTES, st, p, e);
+        DAE_LAUNCH(ka, dim3(nwg), dim3(GEMM_THREADS), DecAst::LDS_BYTES, st, p, e);
         DAE_CHECK_LAUNCH();
         return 0;
     }
@@ -3501,7 +3501,7 @@ int launch_decode_loss_n(int dtype, int Bp, int Fp, const GemmSegDesc* segs, int
     }
     dim3 grid(nblocks), block(GEMM_THREADS);
     static_assert(DecGeo<DECODE_BN_BF16>::LDS_BYTES >= 64 * 65 * 4 && DecGeo<BN>::LDS_BYTES >= 64 * 65 * 4, "rider tile must fit the decode LDS");
-    hipLaunchKernelGGL(k, grid, block, paird ? DECODE_PAIR_LDS : ((dtype == DAE_BF16 && !wide) ? DecGeo<DECODE_BN_BF16>::LDS_BYTES : DecGeo<BN>::LDS_BYTES), st, p, e);
+    DAE_LAUNCH(k, grid, block, paird ? DECODE_PAIR_LDS : ((dtype == DAE_BF16 && !wide) ? DecGeo<DECODE_BN_BF16>::LDS_BYTES : DecGeo<BN>::LDS_BYTES), st, p, e);
     DAE_CHECK_LAUNCH();
     return 0;
 }
@@ -3722,7 +3722,7 @@ int launch_encode_bits(int Bp, int Hp, int Fp, const uint32_t* bits, int64_t ldw
     const bool with_labels = label_job && label_job->Bp <= 1024 && grid < g_cus;
     if (with_labels) job = *label_job;
     auto k = nst == 4 ? gemm_encode_bits_pc<4> : gemm_encode_bits_pc<2>;
-    hipLaunchKernelGGL(k, dim3(grid + (with_labels ? 1 : 0)), dim3(PC_THREADS), ldsb, st, p, C, ldc, slab_stride, job, with_labels ? grid : -1);
+    DAE_LAUNCH(k, dim3(grid + (with_labels ? 1 : 0)), dim3(PC_THREADS), ldsb, st, p, C, ldc, slab_stride, job, with_labels ? grid : -1);
     DAE_CHECK_LAUNCH();
     if (with_labels && label_done) *label_done = 1;
     return 0;
@@ -3745,7 +3745,7 @@ int launch_gemm_trace(int dtype, int M, int N, const void* A0, int64_t lda0, con
     p.trace = trace;
     f32out_fn k = nst == 3 ? gemm_nt_trace<bf16_t, 3> : gemm_nt_trace<bf16_t, 2>;
     DAE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes_for(nst)));
-    hipLaunchKernelGGL(k, dim3(grid_blocks(p)), dim3(GEMM_THREADS), lds_bytes_for(nst), st, p, C, ldc, slab_stride);
+    DAE_LAUNCH(k, dim3(grid_blocks(p)), dim3(GEMM_THREADS), lds_bytes_for(nst), st, p, C, ldc, slab_stride);
     DAE_CHECK_LAUNCH();
     return 0;
 }

@@ -75,11 +75,11 @@ extern "C" int dae_pairwise_similarity(const float* X, int64_t ldx, int32_t N, i
     DAE_CHECK_ARG(((uintptr_t)workspace % 16) == 0, "pairwise_similarity: workspace must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     float* Y = (float*)workspace;
-    hipLaunchKernelGGL(row_normalize_kernel, dim3(Np), dim3(256), 0, st, X, ldx, N, D, norm, metric == 0 ? 1 : 0, Y, (int64_t)Dp, Dp);
+    DAE_LAUNCH(row_normalize_kernel, dim3(Np), dim3(256), 0, st, X, ldx, N, D, norm, metric == 0 ? 1 : 0, Y, (int64_t)Dp, Dp);
     DAE_CHECK_LAUNCH();
     if (int rc = launch_gemm_f32out(DAE_F32, Np, Np, Y, Dp, Y, Dp, Dp, nullptr, 0, nullptr, 0, 0, out, ldo, 1, 0, st, GEMM_ROLE_GENERIC)) return rc;
     if (zero_diagonal) {
-        hipLaunchKernelGGL(zero_diag_kernel, dim3((N + 255) / 256), dim3(256), 0, st, out, ldo, N);
+        DAE_LAUNCH(zero_diag_kernel, dim3((N + 255) / 256), dim3(256), 0, st, out, ldo, N);
         DAE_CHECK_LAUNCH();
     }
     return 0;
@@ -241,7 +241,7 @@ extern "C" int dae_pair_stats(const float* S, int64_t lds, const int32_t* labels
     out16[1] = (double)n_rel; out16[2] = (double)n_un;
     DAE_CHECK_HIP(hipMemcpyAsync(labels_dev, labels_host, (size_t)N * 4, hipMemcpyHostToDevice, st));
     DAE_CHECK_HIP(hipMemsetAsync(counters, 0, 16, st));
-    hipLaunchKernelGGL(split_pairs_kernel, dim3(N - 1), dim3(256), 0, st, S, lds, labels_dev, N, rel, unrel, counters);
+    DAE_LAUNCH(split_pairs_kernel, dim3(N - 1), dim3(256), 0, st, S, lds, labels_dev, N, rel, unrel, counters);
     DAE_CHECK_LAUNCH();
     size_t tb = temp_bytes;
     if (n_rel) DAE_CHECK_HIP(rocprim::radix_sort_keys(temp, tb, rel, rel_s, (size_t)n_rel, 0, 32, st));
@@ -250,7 +250,7 @@ extern "C" int dae_pair_stats(const float* S, int64_t lds, const int32_t* labels
     unsigned long long cnt[2] = {0, 0};
     DAE_CHECK_HIP(hipMemcpyAsync(cnt, counters, 16, hipMemcpyDeviceToHost, st));
     if (n_rel && n_un) {
-        hipLaunchKernelGGL(auroc_count_kernel, dim3(PAIR_PART_BLOCKS), dim3(256), 0, st, rel_s, (unsigned long long)n_rel, unrel_s,
+        DAE_LAUNCH(auroc_count_kernel, dim3(PAIR_PART_BLOCKS), dim3(256), 0, st, rel_s, (unsigned long long)n_rel, unrel_s,
                            (unsigned long long)n_un, part_u);
         DAE_CHECK_LAUNCH();
     }
@@ -270,9 +270,9 @@ extern "C" int dae_pair_stats(const float* S, int64_t lds, const int32_t* labels
     if (n_rel) {
         npick = 0; add_class(n_rel, 0);
         DAE_CHECK_HIP(hipMemcpyAsync(pick_idx, idx_h, 10 * 8, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(pick_keys_kernel, dim3(1), dim3(32), 0, st, rel_s, pick_idx, 10, pick_val);
+        DAE_LAUNCH(pick_keys_kernel, dim3(1), dim3(32), 0, st, rel_s, pick_idx, 10, pick_val);
         DAE_CHECK_LAUNCH();
-        hipLaunchKernelGGL(key_sum_kernel, dim3(PAIR_PART_BLOCKS), dim3(256), 0, st, rel_s, (unsigned long long)n_rel, part_r);
+        DAE_LAUNCH(key_sum_kernel, dim3(PAIR_PART_BLOCKS), dim3(256), 0, st, rel_s, (unsigned long long)n_rel, part_r);
         DAE_CHECK_LAUNCH();
         DAE_CHECK_HIP(hipMemcpyAsync(pv.data(), pick_val, 10 * 4, hipMemcpyDeviceToHost, st));
         DAE_CHECK_HIP(hipStreamSynchronize(st));              // idx_h / pick buffers are reused for the second class
@@ -280,9 +280,9 @@ extern "C" int dae_pair_stats(const float* S, int64_t lds, const int32_t* labels
     if (n_un) {
         npick = 0; add_class(n_un, 0);
         DAE_CHECK_HIP(hipMemcpyAsync(pick_idx, idx_h, 10 * 8, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(pick_keys_kernel, dim3(1), dim3(32), 0, st, unrel_s, pick_idx, 10, pick_val);
+        DAE_LAUNCH(pick_keys_kernel, dim3(1), dim3(32), 0, st, unrel_s, pick_idx, 10, pick_val);
         DAE_CHECK_LAUNCH();
-        hipLaunchKernelGGL(key_sum_kernel, dim3(PAIR_PART_BLOCKS), dim3(256), 0, st, unrel_s, (unsigned long long)n_un, part_n);
+        DAE_LAUNCH(key_sum_kernel, dim3(PAIR_PART_BLOCKS), dim3(256), 0, st, unrel_s, (unsigned long long)n_un, part_n);
         DAE_CHECK_LAUNCH();
         DAE_CHECK_HIP(hipMemcpyAsync(pv.data() + 10, pick_val, 10 * 4, hipMemcpyDeviceToHost, st));
     }

@@ -986,7 +986,7 @@ int dae::launch_batch_all(const float* D_slabs, int d_splits, int64_t slab_strid
         static const int tile_attr_rc =          // once per process, thread-safe (function-local static initialiser)
             (int)hipFuncSetAttribute(reinterpret_cast<const void*>(batch_all_tile_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         DAE_CHECK_ARG(tile_attr_rc == 0, "batch_all: hipFuncSetAttribute failed (%d)", tile_attr_rc);
-        hipLaunchKernelGGL(batch_all_tile_kernel<4>, dim3(n_anchors), dim3(TRIP_THREADS), tl, st, D_slabs, d_splits, slab_stride, ldd, labels, B, Bp,
+        DAE_LAUNCH(batch_all_tile_kernel<4>, dim3(n_anchors), dim3(TRIP_THREADS), tl, st, D_slabs, d_splits, slab_stride, ldd, labels, B, Bp,
                            loss_part, npos_part, G, role_cnt, fast, a0, /*order=*/nullptr, cls);   // every anchor is resident: the dispatch order is moot
         DAE_CHECK_LAUNCH();
         return 0;
@@ -1010,7 +1010,7 @@ int dae::launch_batch_all(const float* D_slabs, int d_splits, int64_t slab_strid
     const int per_cu = (int)((160 * 1024) / lds) < 3 ? (int)((160 * 1024) / lds) : 3;
     const int slots = cus * (per_cu < 1 ? 1 : per_cu);
     const int nwg = (g_miner_pack && n_anchors > slots) ? slots : n_anchors;
-    hipLaunchKernelGGL(k, dim3(nwg), dim3(TRIP_THREADS), lds, st, D_slabs, d_splits, slab_stride, ldd, labels, B, Bp, loss_part, npos_part, G,
+    DAE_LAUNCH(k, dim3(nwg), dim3(TRIP_THREADS), lds, st, D_slabs, d_splits, slab_stride, ldd, labels, B, Bp, loss_part, npos_part, G,
                        role_cnt, fast, a0, order, n_anchors, cls);
     DAE_CHECK_LAUNCH();
     return 0;
@@ -1031,7 +1031,7 @@ extern "C" int dae_triplet_batch_hard_rows(const float* D_slabs, int32_t d_split
     hipStream_t st = (hipStream_t)stream;
     DAE_CHECK_HIP(hipMemsetAsync(dw, 0, (size_t)Bp * sizeof(int32_t), st));
     const size_t lds = (size_t)Bp * 4 + 64;
-    hipLaunchKernelGGL(batch_hard_kernel, dim3(n_anchors), dim3(TRIP_THREADS), lds, st, D_slabs, d_splits, slab_stride, ldd, labels, B, Bp,
+    DAE_LAUNCH(batch_hard_kernel, dim3(n_anchors), dim3(TRIP_THREADS), lds, st, D_slabs, d_splits, slab_stride, ldd, labels, B, Bp,
                        loss_part, cnt_part, dw, G, a0);
     DAE_CHECK_LAUNCH();
     return 0;

@@ -307,8 +307,11 @@ class Engine:
         if ws_bytes > self.workspace.numel():
             self.workspace = torch.zeros(ws_bytes, dtype=torch.uint8, device=self.device)
 
-    def profile(self, enable):
-        self._chk(self.lib.dae_plan_profile(self.plan, int(bool(enable))), "dae_plan_profile")
+    def profile(self, enable, queued=False, stamps=False):
+        """Per-launch HIP-event timing of train_step (dae_plan_profile in include/dae_hip.h).  Default: the host waits behind every launch.
+        queued=True: one event pair per launch, read when the pool fills / by profile_read (launches and steps run back to back).
+        stamps=True: queued pairs stamped by the dispatch itself (hipExtLaunchKernelGGL) -- the kernel's own duration, as rocprofv3 reports it."""
+        self._chk(self.lib.dae_plan_profile(self.plan, (3 if stamps else 2 if queued else 1) if enable else 0), "dae_plan_profile")
 
     def profile_read(self):
         """{kernel slot name: (total ms, launches)} accumulated since profile(True)."""

@@ -541,8 +541,14 @@ int      dae_encode_rows(dae_plan* p, const int32_t* row_idx, int32_t B, float s
 /* pointers into the workspace for tests / debugging (NULL if name unknown) */
 void*    dae_plan_buffer(dae_plan* p, const char* name);
 /* Per-kernel timing of dae_train_step with HIP events recorded on the step's own stream (bench.py's
- * roofline leg).  While enabled every launch is bracketed by two events and the host waits for it, so
- * throughput numbers must be taken with profiling off.  Slot names via dae_plan_profile_name(). */
+ * roofline leg).  enable = 1: every launch is bracketed by two events and the host waits for it (a launch
+ * starts on an idle device).  enable = 2 (queued): every launch of a step has its own event pair, nothing
+ * waits between launches or steps, the pairs are read when the pool is full and by dae_plan_profile_read
+ * -- the kernels run back to back as they do un-profiled and the averages come within the two markers' cost of rocprofv3's.  Throughput numbers
+ * enable = 3 (kernel timestamps): like 2, but the pair of a kernel launch is handed to hipExtLaunchKernelGGL
+ * and carries the dispatch's own begin / end times (no marker packets in the stream; a call with several
+ * launches adds them up) -- the figure rocprofv3 --kernel-trace reports.  Throughput numbers
+ * must be taken with profiling off (enable = 0).  Slot names via dae_plan_profile_name(). */
 int         dae_plan_profile(dae_plan* p, int32_t enable);
 int         dae_plan_profile_read(const dae_plan* p, int32_t max_slots, double* ms_total, int32_t* counts);
 int32_t     dae_plan_profile_slots(void);

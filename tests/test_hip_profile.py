@@ -1,0 +1,55 @@
+"""GPU test of the per-kernel event timing (dae_plan_profile, include/dae_hip.h): the queued forms (mode 2: hipEventRecord pairs read when
+the pool fills; mode 3: pairs stamped by the dispatch itself through hipExtLaunchKernelGGL) count the same calls as the host-wait form,
+leave the step's results untouched, and their per-step totals are no longer than the host-wait form's (whose launches each start on an
+idle device); the dispatch stamps are the shortest of the three (no marker packets inside the interval)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(strategy):
+    from dae_rnn_news_recommendation_amd.engine import Engine
+    from dae_rnn_news_recommendation_amd.synthetic import synthetic_csr, synthetic_labels, xavier_uniform
+    N, F, H, B = 1600, 2048, 256, 400
+    m = synthetic_csr(N, F, seed=3); lab = synthetic_labels(N, seed=3).astype(np.int32)
+    eng = Engine(F, H, B, dtype="f16x2h", triplet=strategy, loss_func="cross_entropy", learning_rate=0.1)
+    eng.upload_csr(m); eng.set_params(xavier_uniform(F, H))
+    rows = [np.arange(b * B, (b + 1) * B) for b in range(N // B)]
+    rows = [r[np.argsort(lab[r], kind="stable")] for r in rows]
+    idx = [torch.from_numpy(r.astype(np.int32)).cuda() for r in rows]
+    labs = [torch.from_numpy(lab[r]).cuda() for r in rows]
+    return eng, idx, labs
+
+
+@pytest.mark.parametrize("strategy", ["batch_all", "batch_hard", "none"])
+def test_queued_event_pairs_count_the_same_launches_and_leave_the_step_alone(strategy):
+    from dae_rnn_news_recommendation_amd import _lib as L
+    kw = dict(corr_mode=L.CORR_PHILOX_MASK, seed=5, rng_stream=0, corr_frac=0.3)
+    runs = {}
+    for mode in ("off", "sync", "queued", "stamps"):
+        eng, idx, labs = _engine(strategy)
+        stats = torch.zeros((8, 8), device="cuda")
+        if mode != "off":
+            eng.profile(True, queued=(mode == "queued"), stamps=(mode == "stamps"))
+        for s in range(40):          # 40 steps: the 128-pair pool is read and re-used several times
+            eng.train_step(idx[s % 4], labs[s % 4] if strategy != "none" else None, stats[s % 8], phase=3, **kw)
+        torch.cuda.synchronize()
+        prof = eng.profile_read() if mode != "off" else None
+        if mode != "off":
+            eng.profile(False)
+        W, bh, bv = eng.get_params()
+        runs[mode] = (prof, stats.cpu().numpy().copy(), np.asarray(W).copy())
+    for mode in ("sync", "queued", "stamps"):          # profiling never changes what the step computes
+        assert np.array_equal(runs[mode][1], runs["off"][1]) and np.array_equal(runs[mode][2], runs["off"][2]), mode
+    ps = runs["sync"][0]
+    tot = {}
+    for mode in ("sync", "queued", "stamps"):
+        pq = runs[mode][0]
+        assert {k: n for k, (ms, n) in ps.items()} == {k: n for k, (ms, n) in pq.items()}, mode
+        assert sum(n for ms, n in pq.values()) >= 40 * 5
+        assert all(ms > 0 for ms, n in pq.values() if n), mode
+        tot[mode] = sum(ms for ms, n in pq.values())
+    assert tot["queued"] <= 1.10 * tot["sync"], tot
+    assert tot["stamps"] <= 1.02 * tot["queued"], tot

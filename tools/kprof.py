@@ -19,6 +19,8 @@ ap.add_argument("--corr", default="philox", choices=["philox", "bits", "none"])
 ap.add_argument("--opt", action="append", default=[], help="plan option name=value (dae_plan_set_option), repeatable")
 ap.add_argument("--unsorted", action="store_true", help="batches in row order instead of class-sorted")
 ap.add_argument("--lib", default="", help="alternative libdae_hip build (probe variants; tools only)")
+ap.add_argument("--queued", action="store_true", help="queued event pairs (dae_plan_profile mode 2): no host wait between the launches of a step")
+ap.add_argument("--stamps", action="store_true", help="pairs stamped by the dispatch itself (dae_plan_profile mode 3): the kernel's own duration")
 ap.add_argument("--glds", type=int, action="append", default=[], help="dae_set_glds code(s), e.g. -8 = dW on the producer/consumer kernel")
 a = ap.parse_args()
 if a.lib:
@@ -55,7 +57,7 @@ elif a.corr == "bits":
 for _ in range(5):
     one_step()
 torch.cuda.synchronize()
-eng.profile(True)
+eng.profile(True, queued=a.queued, stamps=a.stamps)
 for _ in range(a.steps):
     one_step()
 prof = eng.profile_read(); eng.profile(False)
@@ -69,6 +71,6 @@ for _ in range(200):
 e1.record(); torch.cuda.synchronize()
 free_us = 1e3 * e0.elapsed_time(e1) / 200
 tot = sum(ms for ms, n in prof.values())
-print(f"== corr={a.corr} {a.tag} glds={a.glds} {a.opt} {a.strategy} {a.precision} total {1e3*tot/a.steps:.1f} us/step (bracketed kernels), {free_us:.1f} us/step un-profiled  info={eng.info()}")
+print(f"== {'stamps' if a.stamps else 'queued' if a.queued else 'sync'} events corr={a.corr} {a.tag} glds={a.glds} {a.opt} {a.strategy} {a.precision} total {1e3*tot/a.steps:.1f} us/step (bracketed kernels), {free_us:.1f} us/step un-profiled  info={eng.info()}")
 for k, (ms, n) in prof.items():
     if n: print(f"   {k:18s} {1e3*ms/n:9.1f} us  x{n/a.steps:.0f}")
