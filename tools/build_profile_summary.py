@@ -154,8 +154,8 @@ for slot, kern in SLOT_KERNEL:
     L.append(f"| {slot} | `{kern}` | {k['avg_us']:.1f} | {rp:.1f} | {roof} | "
              f"{(t['fetch_bytes'] / 1e6 if t else float('nan')):.1f} | {(t['write_bytes'] / 1e6 if t else float('nan')):.1f} | {NOTE[slot]} |")
 tb = sum(v["fetch_bytes"] + v["write_bytes"] for v in traffic["c2"].values())
-L.append(f"\nSums: {tot_ev:.0f} us with event brackets (each adds a host sync and ~2 us), {tot_rp:.0f} us of rocprofv3 kernel time; the un-profiled\n"
-         f"step is {1e3 * b['ms_per_step']:.1f} us (ramp and tail of consecutive kernels overlap).  PMC bytes per step: {tb / 1e6:.0f} MB.\n")
+L.append(f"\nSums: {tot_ev:.0f} us by HIP events ({b.get('kernel_timing', 'host wait behind every launch')}), {tot_rp:.0f} us of rocprofv3 kernel time; the un-profiled\n"
+         f"step is {1e3 * b['ms_per_step']:.1f} us.  PMC bytes per step: {tb / 1e6:.0f} MB.  The three event forms side by side: `r06_event_forms.txt`.\n")
 if "miner_valu" in traffic:
     mv = traffic["miner_valu"]
     L.append(f"Miner VALU accounting (PMC): {mv['wave_insts_per_launch']:.3g} wave instructions per launch for N_valid = {mv['n_valid']:.3g} triplets = "

@@ -42,12 +42,12 @@ python tools/rocprof_summary.py $OUT/trace/t_results.db > $OUT/kernel_stats.md
 python tools/trace_gaps.py $OUT/trace/t_results.db > $OUT/trace_gaps.txt 2>&1
 rm -rf $OUT/trace
 bash tools/pmc_c4_sq.sh $TAG > /dev/null 2>&1   # SQ counters of the c4 GEMM kernels (own PMC pass) -> $OUT/pmc_counters_c4_sq.md
-$T python tools/kprof.py --precision f16x2h > $OUT/kprof.txt 2>/dev/null      # the product default for batch_all, per kernel
-$T python tools/kprof.py --precision f16x2d --strategy none >> $OUT/kprof.txt 2>/dev/null      # ... for strategy none
-$T python tools/kprof.py --precision f16x2h --strategy batch_hard >> $OUT/kprof.txt 2>/dev/null      # ... for batch_hard
-$T python tools/kprof.py --precision f16x2 >> $OUT/kprof.txt 2>/dev/null       # round 5's default (holds 20 steps, not 100)
-$T python tools/kprof.py --precision bf16x3 >> $OUT/kprof.txt 2>/dev/null      # the split-bf16 mode
-$T python tools/kprof.py --precision bf16 >> $OUT/kprof.txt 2>/dev/null
+$T python tools/kprof.py --stamps --precision f16x2h > $OUT/kprof.txt 2>/dev/null      # the product default for batch_all, per kernel
+$T python tools/kprof.py --stamps --precision f16x2d --strategy none >> $OUT/kprof.txt 2>/dev/null      # ... for strategy none
+$T python tools/kprof.py --stamps --precision f16x2h --strategy batch_hard >> $OUT/kprof.txt 2>/dev/null      # ... for batch_hard
+$T python tools/kprof.py --stamps --precision f16x2 >> $OUT/kprof.txt 2>/dev/null       # round 5's default (holds 20 steps, not 100)
+$T python tools/kprof.py --stamps --precision bf16x3 >> $OUT/kprof.txt 2>/dev/null      # the split-bf16 mode
+$T python tools/kprof.py --stamps --precision bf16 >> $OUT/kprof.txt 2>/dev/null
 [ -f dae_rnn_news_recommendation_amd/libdae_mp4.so ] && $T python tools/miner_timeline.py --lib dae_rnn_news_recommendation_amd/libdae_mp4.so > $OUT/miner_timeline.txt 2> $OUT/miner_timeline.err
 $T python tools/dp_step_breakdown.py > $OUT/dp_step_breakdown.txt 2>/dev/null
 nproc > $OUT/host.txt; lscpu | grep "Model name" >> $OUT/host.txt; rocminfo | grep -E "gfx|Compute Unit" | head -4 >> $OUT/host.txt
