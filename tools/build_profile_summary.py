@@ -193,7 +193,8 @@ if os.path.exists(fb):
              "the per-epoch staging fix: its `fit.numpy` figure (0.71 M) shows the bug fixed afterwards -- torch's parallel pinned copy woke 128 OpenMP workers per "
              "epoch and the container's 16-CPU cgroup quota throttled the whole process; with the single-threaded staging the reference-exact RNG mode "
              "runs at the Philox rate (table above).\n")
-L.append(f"PMC detail: `{rnd}_rocprofv3_pmc_counters.md` (c4: `{rnd}_rocprofv3_pmc_counters_c4.md`); per-workgroup timeline of the miner: `{rnd}_miner_timeline.txt`;\n"
+_mt = f"`{rnd}_miner_timeline.txt`" if os.path.exists(os.path.join(dst, f"{rnd}_miner_timeline.txt")) else "`r03_miner_timeline.txt` (the probe build was not re-run since)"
+L.append(f"PMC detail: `{rnd}_rocprofv3_pmc_counters.md` (c4: `{rnd}_rocprofv3_pmc_counters_c4.md`); per-workgroup timeline of the miner: {_mt};\n"
          f"`tools/kprof.py` output: `{rnd}_kprof.txt`; round-6 evidence files: `{rnd}_curve_modes.txt` (which mode holds which curve), `{rnd}_curve_tests.txt`, `{rnd}_decode_ast.txt` (the persistent decode kernel: built, slower), `{rnd}_region_trace.txt`.\n")
 open(os.path.join(dst, f"{rnd}_summary.md"), "w").write("\n".join(L))
 print("\n".join(L))
