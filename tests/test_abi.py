@@ -121,3 +121,28 @@ def test_engine_fails_loudly_without_gpu():
     from dae_rnn_news_recommendation_amd.engine import Engine
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         Engine(100, 10, 16)
+
+
+def test_every_kernel_launch_goes_through_the_timed_launcher():
+    """bench.py's per-kernel table relies on dae_plan_profile mode 3 seeing EVERY launch of a step: the library launches kernels through
+    DAE_LAUNCH (csrc/dae_common.h) alone -- no bare hipLaunchKernelGGL / <<< >>> in the kernel sources -- and the profile call accepts the
+    three documented modes without a GPU (argument handling only: a null plan is an argument error in each)."""
+    csrc = os.path.join(ROOT, "dae_rnn_news_recommendation_amd", "csrc")
+    bad, launches = [], 0
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith((".hip", ".h", ".cpp")):
+            continue
+        text = open(os.path.join(csrc, f)).read()
+        launches += len(re.findall(r"\bDAE_LAUNCH\(", text))
+        if f == "dae_common.h":
+            assert text.count("hipLaunchKernelGGL(") == 1 and "hipExtLaunchKernelGGL(" in text      # the macro's two arms
+            continue
+        if re.search(r"\bhipLaunchKernelGGL\(|<<<|\bhipExtLaunchKernelGGL\(|\bhipModuleLaunchKernel\(", text):
+            bad.append(f)
+    assert not bad, bad
+    assert launches >= 60, launches
+    from dae_rnn_news_recommendation_amd import _lib
+    lib = _lib.load()
+    for mode in (0, 1, 2, 3):
+        assert lib.dae_plan_profile(None, mode) != 0
+        assert b"null plan" in lib.dae_last_error()
