@@ -657,15 +657,32 @@ def main():
     _log("timed region done: %.1f us/step" % (1e6 * dt / a.steps))
     if rank == 0 and not a.no_roofline:
         eng = run.eng
-        eng.profile(True, queued=a.profile_mode == "queued", stamps=a.profile_mode == "stamps")
-        for s in range(a.profile_steps):
-            if world == 1:
-                run.step()
-            else:          # profile the local step only (no collective inside the event brackets)
-                rows, labs = run.batch(s % run.nb)
-                run.eng.train_step(rows, labs, run.stats[s % run.nb], phase=1, **run.plan)
-        prof = eng.profile_read()
-        eng.profile(False)
+
+        def profile_pass(mode):
+            eng.profile(True, queued=mode == "queued", stamps=mode == "stamps")
+            for s in range(a.profile_steps):
+                if world == 1:
+                    run.step()
+                else:          # profile the local step only (no collective inside the event brackets)
+                    rows, labs = run.batch(s % run.nb)
+                    run.eng.train_step(rows, labs, run.stats[s % run.nb], phase=1, **run.plan)
+            pr = eng.profile_read()
+            eng.profile(False)
+            return pr
+        try:
+            prof = profile_pass(a.profile_mode)
+        except RuntimeError as ex:          # a runtime that refuses the stamped launches must not cost the bench line: fall back to plain event pairs, and say so
+            if a.profile_mode == "sync":
+                raise
+            _log("profile mode %r failed (%s): falling back to host-wait event pairs" % (a.profile_mode, ex))
+            out["kernel_timing_fallback"] = "profile mode %r failed (%s); the kernel table below was taken with --profile-mode sync" % (a.profile_mode, ex)
+            try:
+                eng.profile(False)
+            except RuntimeError:
+                pass
+            torch.cuda.synchronize()
+            a.profile_mode = "sync"
+            prof = profile_pass("sync")
         kern, step_us, (mfma, hbm) = kernel_table(a, prof, a.profile_steps)
         if "miner" in kern and kern["miner"].get("bound") == "valu":
             nv = float(np.mean(run.stats.cpu().numpy()[:, 5]))        # N_valid of the last epoch's batches

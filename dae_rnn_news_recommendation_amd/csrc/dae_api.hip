@@ -442,7 +442,7 @@ extern "C" int dae_plan_profile(dae_plan* p, int32_t enable) {
         DAE_CHECK_HIP(hipEventCreate(&p->ev0));
         DAE_CHECK_HIP(hipEventCreate(&p->ev1));
     }
-    if (p->pev_used) { if (int rf = prof_flush(p)) return rf; }
+    const int rf = p->pev_used ? prof_flush(p) : 0;     // pairs still queued belong to the mode being left; a failed read is reported, the switch still happens
     if ((enable == 2 || enable == 3) && !p->pev[0])
         for (int i = 0; i < dae_plan::PROF_POOL; ++i) DAE_CHECK_HIP(hipEventCreate(&p->pev[i]));
     if (enable) { memset(p->prof_ms, 0, sizeof(p->prof_ms)); memset(p->prof_n, 0, sizeof(p->prof_n)); }
@@ -450,7 +450,7 @@ extern "C" int dae_plan_profile(dae_plan* p, int32_t enable) {
     p->prof_queued = enable == 2 || enable == 3;
     p->prof_stamps = enable == 3;
     p->pev_used = 0;
-    return 0;
+    return rf;
 }
 
 extern "C" int dae_plan_profile_read(const dae_plan* p, int32_t max_slots, double* ms_total, int32_t* counts) {
@@ -573,14 +573,15 @@ static int launch_gram(dae_plan* p, int Bp, int Hp, int64_t dslab, hipStream_t s
 // queued profile mode: wait for the step's last pair, then add every pair to its slot
 static int prof_flush(dae_plan* p) {
     if (!p->prof_queued || p->pev_used == 0) return 0;
-    DAE_CHECK_HIP(hipEventSynchronize(p->pev[p->pev_used - 1]));
-    for (int i = 0; i < p->pev_used; i += 2) {
+    const int used = p->pev_used;
+    p->pev_used = 0;                                    // (also on the error paths below: a failed read must not poison the next profile call)
+    DAE_CHECK_HIP(hipEventSynchronize(p->pev[used - 1]));
+    for (int i = 0; i < used; i += 2) {
         float ms = 0.f;
         DAE_CHECK_HIP(hipEventElapsedTime(&ms, p->pev[i], p->pev[i + 1]));
         const int sl = p->pev_slot[i / 2] & 0xff;          // bit 8: the first launch of its PROF call (a call with several launches counts once)
         p->prof_ms[sl] += ms; p->prof_n[sl] += (p->pev_slot[i / 2] >> 8) & 1;
     }
-    p->pev_used = 0;
     return 0;
 }
 static int memset_async(void* ptr, size_t bytes, hipStream_t st) {
