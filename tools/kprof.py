@@ -19,12 +19,15 @@ ap.add_argument("--corr", default="philox", choices=["philox", "bits", "none"])
 ap.add_argument("--opt", action="append", default=[], help="plan option name=value (dae_plan_set_option), repeatable")
 ap.add_argument("--unsorted", action="store_true", help="batches in row order instead of class-sorted")
 ap.add_argument("--lib", default="", help="alternative libdae_hip build (probe variants; tools only)")
+ap.add_argument("--lib-f16", default="", help="alternative libdae_hip_f16 build (A/B of two builds on one box; tools only)")
 ap.add_argument("--queued", action="store_true", help="queued event pairs (dae_plan_profile mode 2): no host wait between the launches of a step")
 ap.add_argument("--stamps", action="store_true", help="pairs stamped by the dispatch itself (dae_plan_profile mode 3): the kernel's own duration")
 ap.add_argument("--glds", type=int, action="append", default=[], help="dae_set_glds code(s), e.g. -8 = dW on the producer/consumer kernel")
 a = ap.parse_args()
 if a.lib:
     L.LIB_PATH = os.path.abspath(a.lib)
+if a.lib_f16:
+    L.LIB_PATHS["f16"] = os.path.abspath(a.lib_f16)
 if a.nst >= 0:
     L.load().dae_set_glds(a.nst)
 m = synthetic_csr(a.rows, a.features, seed=1); lab = synthetic_labels(a.rows, seed=1).astype(np.int32)
