@@ -546,8 +546,10 @@ static int launch_gram(dae_plan* p, int Bp, int Hp, int64_t dslab, hipStream_t s
     return launch_gemm_f32out(DAE_F32, Bp, Bp, p->h_f32, Hp, p->h_f32, Hp, Hp, nullptr, 0, nullptr, 0, 0, p->D_slabs, Bp, p->s_gram, dslab, st,
                               GEMM_ROLE_GRAM);
 }
-// PROF(slot, call): in profile mode bracket the call with HIP events ON THE STEP'S STREAM and accumulate the
-// elapsed GPU time of that slot (costs a host sync per call, so it is never on when throughput is measured).
+// PROF(slot, call): in profile mode time the call with HIP events ON THE STEP'S STREAM and accumulate the elapsed GPU time of that slot
+// (dae_plan_profile, include/dae_hip.h).  Mode 1: an event pair around the call and a host wait behind it.  Mode 2 (q__): a pair of the
+// plan's pool around the call, read later by prof_flush.  Mode 3 (k__): the pool is handed to DAE_LAUNCH (dae_common.h) for the duration
+// of the call, every kernel launch inside takes a pair and has it stamped by its own dispatch; memsets keep the mode-2 form.
 #define PROF(slot, expr)                                                            \
     do {                                                                            \
         const bool q__ = p->prof && p->prof_queued && p->pev_used + 2 <= dae_plan::PROF_POOL; \
@@ -558,8 +560,8 @@ static int launch_gram(dae_plan* p, int Bp, int Hp, int64_t dslab, hipStream_t s
         const int rc_prof__ = (expr);                                               \
         if (k__) g_lt.pool = nullptr;                                               \
         if (rc_prof__) return rc_prof__;                                            \
-        if (k__) {                                                                  \
-        } else if (q__) {                                                           \
+        if (k__) break;                     /* the launches took their pairs */     \
+        if (q__) {                                                                  \
             DAE_CHECK_HIP(hipEventRecord(p->pev[p->pev_used + 1], st));             \
             p->pev_slot[p->pev_used / 2] = (slot) | 0x100; p->pev_used += 2;        \
         } else if (p->prof) {                                                       \
