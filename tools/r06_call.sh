@@ -1,6 +1,6 @@
 #!/bin/bash
-# round 6, final: the whole profile set at HEAD (per-kernel events = dispatch-stamped pairs, dae_plan_profile mode 3) + the profile-mode test
-rm -rf gpurun_out/r06
-timeout 300 python -m pytest tests/test_hip_profile.py tests/test_hip_step.py -x -q -m gpu 2>&1 | tail -3
-bash tools/make_profile_report.sh r06 > gpurun_out/r06_report.log 2>&1
-tail -2 gpurun_out/r06_report.log
+# round 6: the GPU suite and smoke() at the final HEAD
+mkdir -p gpurun_out/r06head
+timeout 1500 python -m pytest tests/ -x -q -m gpu > gpurun_out/r06head/gpu_suite.txt 2>&1; echo "rc $?" >> gpurun_out/r06head/gpu_suite.txt
+tail -4 gpurun_out/r06head/gpu_suite.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r06head/smoke.txt 2>&1; echo "smoke rc $?"; tail -3 gpurun_out/r06head/smoke.txt
